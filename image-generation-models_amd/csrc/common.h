@@ -1,0 +1,62 @@
+// Shared device helpers for the gfx950 DDPM kernels (wave = 64 lanes, hard-coded).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "../../include/mi_ddpm.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+int mi_set_error(int code, const char* fmt, ...);
+
+#define MI_REQUIRE(cond, msg) \
+    do { if (!(cond)) return mi_set_error(-1, "%s: %s", __func__, msg); } while (0)
+#define MI_LAUNCH_CHECK() \
+    do { hipError_t e_ = hipGetLastError(); \
+         if (e_ != hipSuccess) return mi_set_error((int)e_, "%s: %s", __func__, hipGetErrorString(e_)); } while (0)
+
+// two fp32 -> packed bf16x2 (round-to-nearest-even, one v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    bf16x2 p = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, p);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for 256-thread blocks; every thread gets the result. red: >= 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// Mish(x) = x*tanh(softplus(x)) with torch's softplus threshold 20 (ddpm.py:62-64).
+// tanh(log(1+e)) = (e*e+2e)/(e*e+2e+2) with e = exp(x): one exp, one divide, no cancellation.
+__device__ __forceinline__ float mish_f(float x) {
+    if (x > 20.f) return x * tanhf(x);           // softplus(x) = x above the threshold
+    float e = __expf(x);
+    float w = e * (e + 2.f);
+    return x * (w / (w + 2.f));
+}
+// d mish / dx = tanh(sp) + x * (1 - tanh(sp)^2) * sigmoid(x)   (sigmoid -> 1 above threshold)
+__device__ __forceinline__ float mish_grad_f(float x) {
+    if (x > 20.f) { float th = tanhf(x); return th + x * (1.f - th * th); }
+    float e = __expf(x);
+    float w = e * (e + 2.f);
+    float th = w / (w + 2.f);
+    float sg = e / (1.f + e);
+    return th + x * (1.f - th * th) * sg;
+}

@@ -1,0 +1,246 @@
+// Small element-wise kernels around the UNet: time embedding, Mish on vectors, layout changes,
+// the diffusion q_sample / loss / posterior update, fused Adam.  All HBM- or launch-bound.
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline int nblocks(size_t n, int per = TPB, int cap = 8192) {
+    size_t b = (n + per - 1) / per;
+    return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
+}
+
+// SinusoidalPosEmb (ddpm.py:52-59): fp32 throughout, like the reference
+__global__ void time_embed_kernel(int B, int dim, const int64_t* __restrict__ t, float* __restrict__ out, float step) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * dim) return;
+    int b = idx / dim, j = idx % dim, half = dim / 2;
+    int jj = j < half ? j : j - half;
+    float f = expf((float)jj * -step);
+    float ang = (float)t[b] * f;
+    out[idx] = j < half ? sinf(ang) : cosf(ang);
+}
+
+__global__ void mish_fwd_kernel(size_t n, const float* __restrict__ x, float* __restrict__ y) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = mish_f(x[i]);
+}
+__global__ void mish_bwd_kernel(size_t n, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dx[i] = dy[i] * mish_grad_f(x[i]);
+}
+
+__global__ void nchw_to_nhwc_kernel(int B, int C, int HW, const float* __restrict__ x, float* __restrict__ y, int ld) {
+    size_t tot = (size_t)B * HW * ld;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        int c = i % ld; size_t bp = i / ld; int p = bp % HW; int b = bp / HW;
+        y[i] = c < C ? x[((size_t)b * C + c) * HW + p] : 0.f;
+    }
+}
+__global__ void nhwc_to_nchw_kernel(int B, int C, int HW, const float* __restrict__ x, int ld, float* __restrict__ y) {
+    size_t tot = (size_t)B * C * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        int p = i % HW; size_t bc = i / HW; int c = bc % C; int b = bc / C;
+        y[i] = x[((size_t)b * HW + p) * ld + c];
+    }
+}
+
+// x_t = sqrt(ac[t]) x0 + sqrt(1-ac[t]) eps   (ddpm.py:441-444)
+__global__ void q_sample_kernel(int B, int C, int HW, const float* __restrict__ x0, const float* __restrict__ noise,
+                                const int64_t* __restrict__ t, const float* __restrict__ sa, const float* __restrict__ sb,
+                                float* __restrict__ xt_nhwc, int ld, float* __restrict__ xt_nchw) {
+    size_t tot = (size_t)B * HW * ld;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        int c = i % ld; size_t bp = i / ld; int p = bp % HW; int b = bp / HW;
+        float v = 0.f;
+        if (c < C) {
+            size_t j = ((size_t)b * C + c) * HW + p;
+            int64_t tb = t[b];
+            v = sa[tb] * x0[j] + sb[tb] * noise[j];
+            if (xt_nchw) xt_nchw[j] = v;
+        }
+        if (xt_nhwc) xt_nhwc[i] = v;
+    }
+}
+
+// loss = mean |target - pred| or mean (target-pred)^2 (ddpm.py:453-456) + gradient wrt pred
+__global__ __launch_bounds__(256) void eps_loss_kernel(int B, int C, int HW, const float* __restrict__ pred, int ld,
+                                                        const float* __restrict__ target, int loss_type,
+                                                        float* __restrict__ loss, float* __restrict__ dpred, float gscale) {
+    __shared__ float red[8];
+    size_t tot = (size_t)B * HW * ld;
+    const float inv = 1.0f / ((float)B * (float)C * (float)HW);
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        int c = i % ld; size_t bp = i / ld; int p = bp % HW; int b = bp / HW;
+        float g = 0.f;
+        if (c < C) {
+            float d = pred[i] - target[((size_t)b * C + c) * HW + p];
+            if (loss_type == 0) { acc += fabsf(d); g = (d > 0.f) ? 1.f : (d < 0.f ? -1.f : 0.f); }
+            else { acc += d * d; g = 2.f * d; }
+        }
+        if (dpred) dpred[i] = g * inv * gscale;
+    }
+    float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(loss, s * inv);
+}
+
+// posterior step (ddpm.py:359-397)
+__global__ void p_sample_kernel(int B, int C, int HW, const float* __restrict__ x, const float* __restrict__ eps, int ld,
+                                const float* __restrict__ z, const int64_t* __restrict__ t, const float* __restrict__ sr,
+                                const float* __restrict__ srm1, const float* __restrict__ c1, const float* __restrict__ c2,
+                                const float* __restrict__ lv, int clip, float* __restrict__ xp, float* __restrict__ xp_nhwc, int ldo) {
+    size_t tot = (size_t)B * C * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        int p = i % HW; size_t bc = i / HW; int c = bc % C; int b = bc / C;
+        int64_t tb = t[b];
+        float xv = x[i];
+        float e = eps[((size_t)b * HW + p) * ld + c];
+        float x0 = sr[tb] * xv - srm1[tb] * e;
+        if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        float mean = c1[tb] * x0 + c2[tb] * xv;
+        float nz = (tb == 0) ? 0.f : 1.f;
+        float o = mean + nz * expf(0.5f * lv[tb]) * z[i];
+        xp[i] = o;
+        if (xp_nhwc) xp_nhwc[((size_t)b * HW + p) * ldo + c] = o;
+    }
+}
+
+// torch.optim.Adam single-tensor step over a flat buffer
+__global__ void adam_kernel(size_t n4, size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float lr, float b1, float b2, float eps, float bc1, float bc2s, float gs) {
+    const float step = lr / bc1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gr = G[j] * gs;
+            M[j] = M[j] + (1.f - b1) * (gr - M[j]);
+            V[j] = b2 * V[j] + (1.f - b2) * gr * gr;
+            P[j] -= step * M[j] / (sqrtf(V[j]) / bc2s + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    // tail
+    size_t i = n4 * 4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        float gr = g[i] * gs;
+        float mj = m[i] + (1.f - b1) * (gr - m[i]);
+        float vj = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mj; v[i] = vj;
+        p[i] -= step * mj / (sqrtf(vj) / bc2s + eps);
+    }
+}
+
+__global__ void axpby_kernel(size_t n, float a, const float* __restrict__ x, int acc, float* __restrict__ y) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = a * x[i] + (acc ? y[i] : 0.f);
+}
+
+__global__ void axpby2d_kernel(int M, int C, float a, const float* __restrict__ x, int ldx, int acc, float* __restrict__ y, int ldy) {
+    size_t tot = (size_t)M * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        size_t m = i / C; int c = i % C;
+        float* yp = y + m * ldy + c;
+        *yp = a * x[m * ldx + c] + (acc ? *yp : 0.f);
+    }
+}
+
+__global__ void scale_dev_kernel(int M, int C, float* __restrict__ x, int ld, const float* __restrict__ s) {
+    const float a = *s;
+    size_t tot = (size_t)M * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x)
+        x[(i / C) * ld + (i % C)] *= a;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int mi_time_embed(int B, int dim, const int64_t* t, float* out, void* stream) {
+    MI_REQUIRE(B > 0 && dim >= 4 && dim % 2 == 0 && t && out, "bad argument");
+    float step = (float)(log(10000.0) / (double)(dim / 2 - 1));
+    hipLaunchKernelGGL(time_embed_kernel, dim3(nblocks((size_t)B * dim)), dim3(TPB), 0, ST, B, dim, t, out, step);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_mish_fwd(size_t n, const float* x, float* y, void* stream) {
+    MI_REQUIRE(n > 0 && x && y, "bad argument");
+    hipLaunchKernelGGL(mish_fwd_kernel, dim3(nblocks(n)), dim3(TPB), 0, ST, n, x, y);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_mish_bwd(size_t n, const float* x, const float* dy, float* dx, void* stream) {
+    MI_REQUIRE(n > 0 && x && dy && dx, "bad argument");
+    hipLaunchKernelGGL(mish_bwd_kernel, dim3(nblocks(n)), dim3(TPB), 0, ST, n, x, dy, dx);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_nchw_to_nhwc(int B, int C, int HW, const float* x, float* y, int ld, void* stream) {
+    MI_REQUIRE(B > 0 && C > 0 && HW > 0 && ld >= C && x && y, "bad argument");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblocks((size_t)B * HW * ld)), dim3(TPB), 0, ST, B, C, HW, x, y, ld);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_nhwc_to_nchw(int B, int C, int HW, const float* x, int ld, float* y, void* stream) {
+    MI_REQUIRE(B > 0 && C > 0 && HW > 0 && ld >= C && x && y, "bad argument");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblocks((size_t)B * C * HW)), dim3(TPB), 0, ST, B, C, HW, x, ld, y);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_q_sample(int B, int C, int HW, const float* x0, const float* noise, const int64_t* t,
+                           const float* sqrt_ac, const float* sqrt_1mac, float* xt_nhwc, int ld, float* xt_nchw,
+                           void* stream) {
+    MI_REQUIRE(B > 0 && C > 0 && HW > 0 && ld >= C && x0 && noise && t && sqrt_ac && sqrt_1mac && (xt_nhwc || xt_nchw), "bad argument");
+    hipLaunchKernelGGL(q_sample_kernel, dim3(nblocks((size_t)B * HW * ld)), dim3(TPB), 0, ST, B, C, HW, x0, noise, t,
+                       sqrt_ac, sqrt_1mac, xt_nhwc, ld, xt_nchw);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_eps_loss(int B, int C, int HW, const float* pred, int ld, const float* target, int loss_type,
+                           float* loss, float* dpred, float gscale, void* stream) {
+    MI_REQUIRE(B > 0 && C > 0 && HW > 0 && ld >= C && pred && target && loss && (loss_type == 0 || loss_type == 1), "bad argument");
+    hipLaunchKernelGGL(eps_loss_kernel, dim3(nblocks((size_t)B * HW * ld, TPB, 1024)), dim3(TPB), 0, ST, B, C, HW, pred, ld,
+                       target, loss_type, loss, dpred, gscale);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_p_sample_update(int B, int C, int HW, const float* x, const float* eps_hat, int ld, const float* z,
+                                  const int64_t* t, const float* sqrt_recip_ac, const float* sqrt_recipm1_ac,
+                                  const float* coef1, const float* coef2, const float* logvar, int clip,
+                                  float* x_prev, float* x_prev_nhwc, int ldo, void* stream) {
+    MI_REQUIRE(B > 0 && C > 0 && HW > 0 && x && eps_hat && z && t && x_prev, "bad argument");
+    hipLaunchKernelGGL(p_sample_kernel, dim3(nblocks((size_t)B * C * HW)), dim3(TPB), 0, ST, B, C, HW, x, eps_hat, ld, z, t,
+                       sqrt_recip_ac, sqrt_recipm1_ac, coef1, coef2, logvar, clip, x_prev, x_prev_nhwc, ldo);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_adam_step(size_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
+                            float eps, float bc1, float bc2, float gscale, void* stream) {
+    MI_REQUIRE(n > 0 && p && g && m && v, "bad argument");
+    MI_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "buffers must be 16-byte aligned");
+    size_t n4 = n / 4;
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n4 ? n4 : 1, TPB, 4096)), dim3(TPB), 0, ST, n4, n, p, g, m, v, lr, b1, b2,
+                       eps, bc1, sqrtf(bc2), gscale);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_axpby(size_t n, float a, const float* x, int accumulate, float* y, void* stream) {
+    MI_REQUIRE(n > 0 && x && y, "bad argument");
+    hipLaunchKernelGGL(axpby_kernel, dim3(nblocks(n)), dim3(TPB), 0, ST, n, a, x, accumulate, y);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_axpby2d(int M, int C, float a, const float* x, int ldx, int accumulate, float* y, int ldy, void* stream) {
+    MI_REQUIRE(M > 0 && C > 0 && x && y && ldx >= C && ldy >= C, "bad argument");
+    hipLaunchKernelGGL(axpby2d_kernel, dim3(nblocks((size_t)M * C)), dim3(TPB), 0, ST, M, C, a, x, ldx, accumulate, y, ldy);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_scale_by_device_scalar(int M, int C, float* x, int ld, const float* scalar, void* stream) {
+    MI_REQUIRE(M > 0 && C > 0 && x && scalar && ld >= C, "bad argument");
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(nblocks((size_t)M * C)), dim3(TPB), 0, ST, M, C, x, ld, scalar);
+    MI_LAUNCH_CHECK();
+    return 0;
+}

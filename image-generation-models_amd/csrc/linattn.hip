@@ -1,0 +1,229 @@
+// LinearAttention core (ddpm.py:157-165) on the exact-fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32): per (batch, head) with d = e = 32 channels and n = H*W pixels
+//   P[p,d]   = softmax over p of k[p,d]
+//   ctx[d,e] = sum_p P[p,d] v[p,e]          (32x32, K = n)
+//   out[p,e] = sum_d ctx[d,e] q[p,d]        (n x 32, K = 32)
+// qkv is the NHWC output of the to_qkv 1x1 conv: [b][p][q(h,d) | k(h,d) | v(h,e)].
+// One 256-thread workgroup per (b, head); the four waves split the pixel axis.  These are the
+// only matmuls in the path whose contraction is not a convolution, and they stay fp32 in both
+// numeric modes (0.4 % of the FLOPs).
+#include "common.h"
+
+namespace {
+
+constexpr int DH = 32;           // dim_head, fixed by the reference (ddpm.py:147)
+
+struct AttnArgs {
+    const float* qkv; float* out; float* ctx; float* kstat;
+    const float* dout; float* dqkv;
+    int B, n, heads, ldq;        // ldq = 3*heads*32
+};
+
+// acc[r] of a 32x32 MFMA tile <-> (row, col): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+__device__ __forceinline__ int tile_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// S[d][e] = sum_p f(A[p][d]) * Bm[p][e] over this block's pixels, waves split p, result in sm[32][33]
+template <bool EXP>
+__device__ __forceinline__ void reduce_outer(const float* A, const float* Bm, int ldA, int ldB, int n,
+                                             const float* kmax, float* sm, float* wsum, float* scratch) {
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    const int i = l & 31, kk = l >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float mx = EXP ? kmax[i] : 0.f;
+    float ssum = 0.f;
+    for (int p0 = 2 * w; p0 < n; p0 += 8) {
+        int p = p0 + kk;
+        float av = 0.f, bv = 0.f;
+        if (p < n) {
+            av = A[(size_t)p * ldA + i];
+            bv = Bm[(size_t)p * ldB + i];
+            if (EXP) { av = __expf(av - mx); ssum += av; }
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    // combine the four waves through LDS
+    float* mine = scratch + w * (32 * 33);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[tile_row(r, l) * 33 + i] = acc[r];
+    if (EXP) {
+        ssum += __shfl_xor(ssum, 32, 64);
+        if (l < 32) wsum[w * 32 + l] = ssum;
+    }
+    __syncthreads();
+    for (int idx = t; idx < 32 * 32; idx += 256) {
+        int d = idx >> 5, e = idx & 31;
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) v += scratch[ww * (32 * 33) + d * 33 + e];
+        sm[d * 33 + e] = v;
+    }
+    __syncthreads();
+}
+
+// T[p][j] = sum_k A[p][k] * Bs[k][j] for one 32-pixel tile, A from global (row stride ldA), Bs from LDS
+// with element (k, j) at Bs[k*sk + j*sj].
+__device__ __forceinline__ f32x16 tile_mm(const float* A, int ldA, int p0, int n, const float* Bs, int sk, int sj) {
+    const int l = threadIdx.x & 63, i = l & 31, kk = l >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int p = p0 + i;
+    const float* ap = A + (size_t)(p < n ? p : 0) * ldA;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        int k = 2 * s + kk;
+        float av = (p < n) ? ap[k] : 0.f;
+        float bv = Bs[k * sk + i * sj];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
+    __shared__ float scratch[4 * 32 * 33];
+    __shared__ float ctx_s[32 * 33];
+    __shared__ float kmax_s[32], ksum_s[32], wsum[4 * 32], pmax[8 * 32];
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    const int hid = a.heads * DH;
+    const float* q = a.qkv + (size_t)b * a.n * a.ldq + h * DH;
+    const float* k = q + hid;
+    const float* v = q + 2 * hid;
+
+    // column max of k over pixels
+    {
+        int d = t & 31, pr = t >> 5;
+        float m = -INFINITY;
+        for (int p = pr; p < a.n; p += 8) m = fmaxf(m, k[(size_t)p * a.ldq + d]);
+        pmax[pr * 32 + d] = m;
+        __syncthreads();
+        if (t < 32) {
+            float mm = pmax[t];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) mm = fmaxf(mm, pmax[r * 32 + t]);
+            kmax_s[t] = mm;
+        }
+        __syncthreads();
+    }
+    reduce_outer<true>(k, v, a.ldq, a.ldq, a.n, kmax_s, ctx_s, wsum, scratch);
+    if (t < 32) ksum_s[t] = wsum[t] + wsum[32 + t] + wsum[64 + t] + wsum[96 + t];
+    __syncthreads();
+    float* ctx_g = a.ctx + (size_t)blockIdx.x * 32 * 32;
+    for (int idx = t; idx < 32 * 32; idx += 256) {
+        int d = idx >> 5, e = idx & 31;
+        float c = ctx_s[d * 33 + e] / ksum_s[d];
+        ctx_s[d * 33 + e] = c;
+        ctx_g[idx] = c;
+    }
+    if (t < 32) {
+        float* ks = a.kstat + (size_t)blockIdx.x * 64;
+        ks[2 * t] = kmax_s[t]; ks[2 * t + 1] = ksum_s[t];
+    }
+    __syncthreads();
+    // out[p][e] = sum_d q[p][d] ctx[d][e]
+    float* o = a.out + (size_t)b * a.n * hid + h * DH;
+    for (int p0 = 32 * w; p0 < a.n; p0 += 128) {
+        f32x16 acc = tile_mm(q, a.ldq, p0, a.n, ctx_s, 33, 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int p = p0 + tile_row(r, l);
+            if (p < a.n) o[(size_t)p * hid + (l & 31)] = acc[r];
+        }
+    }
+}
+
+// Backward.  With P = softmax_p(k), ctx = P^T v (saved), r[d] = sum_e ctx[d,e] dctx[d,e]:
+//   dctx = q^T dout ; dq = dout ctx^T ; dv = P dctx ; dP = v dctx^T ; dk = P * (dP - r)
+__global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
+    __shared__ float scratch[4 * 32 * 33];
+    __shared__ float ctx_s[32 * 33], dctx_s[32 * 33];
+    __shared__ float kmax_s[32], kinv_s[32], r_s[32];
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int t = threadIdx.x, l = t & 63, w = t >> 6;
+    const int hid = a.heads * DH;
+    const float* q = a.qkv + (size_t)b * a.n * a.ldq + h * DH;
+    const float* k = q + hid;
+    const float* v = q + 2 * hid;
+    const float* dout = a.dout + (size_t)b * a.n * hid + h * DH;
+    float* dq = a.dqkv + (size_t)b * a.n * a.ldq + h * DH;
+    float* dk = dq + hid;
+    float* dv = dq + 2 * hid;
+
+    const float* ctx_g = a.ctx + (size_t)blockIdx.x * 32 * 32;
+    for (int idx = t; idx < 32 * 32; idx += 256) ctx_s[(idx >> 5) * 33 + (idx & 31)] = ctx_g[idx];
+    if (t < 32) {
+        const float* ks = a.kstat + (size_t)blockIdx.x * 64;
+        kmax_s[t] = ks[2 * t]; kinv_s[t] = 1.0f / ks[2 * t + 1];
+    }
+    reduce_outer<false>(q, dout, a.ldq, hid, a.n, nullptr, dctx_s, nullptr, scratch);   // syncs inside
+    if (t < 32) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) s += ctx_s[t * 33 + e] * dctx_s[t * 33 + e];
+        r_s[t] = s;
+    }
+    __syncthreads();
+
+    float* pt = scratch + w * (32 * 33);        // this wave's P tile [pixel][d]
+    for (int p0 = 32 * w; p0 < a.n; p0 += 128) {
+        const int col = l & 31;
+        // dq[p][d] = sum_e dout[p][e] ctx[d][e]      (B(k=e, j=d) = ctx_s[d*33+e])
+        f32x16 acc = tile_mm(dout, hid, p0, a.n, ctx_s, 1, 33);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < a.n) dq[(size_t)p * a.ldq + col] = acc[r]; }
+        // P tile into LDS (rows = pixels) so it can serve as the A operand of dv
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = tile_row(r, l), p = p0 + row;
+            float pv = (p < a.n) ? __expf(k[(size_t)p * a.ldq + col] - kmax_s[col]) * kinv_s[col] : 0.f;
+            pt[row * 33 + col] = pv;
+        }
+        // (wave-private LDS region: the wave's own ds_write -> ds_read ordering is enough)
+        // dv[p][e] = sum_d P[p][d] dctx[d][e]
+        {
+            const int i = l & 31, kk = l >> 5;
+            f32x16 a2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                int kd = 2 * s + kk;
+                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pt[i * 33 + kd], dctx_s[kd * 33 + i], a2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < a.n) dv[(size_t)p * a.ldq + col] = a2[r]; }
+        }
+        // dP[p][d] = sum_e v[p][e] dctx[d][e]        (B(k=e, j=d) = dctx_s[d*33+e]) ; dk = P*(dP - r)
+        acc = tile_mm(v, a.ldq, p0, a.n, dctx_s, 1, 33);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = tile_row(r, l), p = p0 + row;
+            if (p < a.n) dk[(size_t)p * a.ldq + col] = pt[row * 33 + col] * (acc[r] - r_s[col]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mi_linattn_fwd(int B, int n, int heads, const float* qkv, float* out, float* ctx, float* kstat,
+                              void* stream) {
+    MI_REQUIRE(B > 0 && n > 0 && heads > 0 && qkv && out && ctx && kstat, "bad argument");
+    AttnArgs a{};
+    a.qkv = qkv; a.out = out; a.ctx = ctx; a.kstat = kstat; a.B = B; a.n = n; a.heads = heads; a.ldq = 3 * heads * DH;
+    hipLaunchKernelGGL(linattn_fwd_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi_linattn_bwd(int B, int n, int heads, const float* qkv, const float* ctx, const float* kstat,
+                              const float* dout, float* dqkv, void* stream) {
+    MI_REQUIRE(B > 0 && n > 0 && heads > 0 && qkv && ctx && kstat && dout && dqkv, "bad argument");
+    AttnArgs a{};
+    a.qkv = qkv; a.ctx = const_cast<float*>(ctx); a.kstat = const_cast<float*>(kstat); a.dout = dout; a.dqkv = dqkv;
+    a.B = B; a.n = n; a.heads = heads; a.ldq = 3 * heads * DH;
+    hipLaunchKernelGGL(linattn_bwd_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
+    MI_LAUNCH_CHECK();
+    return 0;
+}

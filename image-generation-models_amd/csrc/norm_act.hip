@@ -1,0 +1,431 @@
+// GroupNorm(8)+Mish(+time bias)(+residual) and channel LayerNorm, forward and backward.
+// HBM-bound kernels: one workgroup owns one (sample, group) slice (GroupNorm) or one wave owns
+// one pixel (LayerNorm); the slice is held in registers between the statistics pass and the
+// apply pass so HBM sees one read and one write per element; reductions are wave shuffles.
+// Replaces aten::native_group_norm(+backward), softplus/tanh/mul (Mish, ddpm.py:62-64), the
+// broadcast add at ddpm.py:140, the residual add at ddpm.py:143 and the 7-op LayerNorm
+// at ddpm.py:92-95.
+#include "common.h"
+
+namespace {
+
+template <int VEC> struct V;
+template <> struct V<4> {
+    float v[4];
+    __device__ static V load(const float* p) { float4 t = *reinterpret_cast<const float4*>(p); return V{{t.x, t.y, t.z, t.w}}; }
+    __device__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct V<1> {
+    float v[1];
+    __device__ static V load(const float* p) { return V{{*p}}; }
+    __device__ void store(float* p) const { *p = v[0]; }
+};
+
+struct GnArgs {
+    const float* x; const float* gamma; const float* beta; const float* temb; const float* res;
+    float* y; float* stats;
+    int N, HW, C, G, Cg; float eps; int ldx, ldy, ldr, ldt;
+    // backward
+    const float* dout; float* dx; float* dgamma; float* dbeta; float* dtemb; float* dbias; int lddo, lddx;
+};
+
+// thread layout inside a (n,g) slice: W = Cg/VEC channel units per pixel; unit u = t % W handles
+// channels [u*VEC, u*VEC+VEC); pixel rows pr = t / W, step PP = 256 / W.
+template <int VEC, int MAXU>
+__global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
+    __shared__ float red[8];
+    const int n = blockIdx.x / a.G, g = blockIdx.x % a.G;
+    const int W = a.Cg / VEC, PP = 256 / W;
+    const int t = threadIdx.x, u = t % W, pr = t / W;
+    const int c0 = g * a.Cg + u * VEC;
+    const float* xb = a.x + (size_t)n * a.HW * a.ldx + c0;
+    const float cnt = (float)a.HW * (float)a.Cg;
+
+    V<VEC> cache[MAXU > 0 ? MAXU : 1];
+    float s = 0.f;
+    if constexpr (MAXU > 0) {
+#pragma unroll
+        for (int k = 0; k < MAXU; ++k) {
+            int p = pr + k * PP;
+            if (p < a.HW) {
+                cache[k] = V<VEC>::load(xb + (size_t)p * a.ldx);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) s += cache[k].v[j];
+            }
+        }
+    } else {
+        for (int p = pr; p < a.HW; p += PP) {
+            V<VEC> q = V<VEC>::load(xb + (size_t)p * a.ldx);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s += q.v[j];
+        }
+    }
+    const float mean = block_sum_256(s, red) / cnt;
+    float s2 = 0.f;
+    if constexpr (MAXU > 0) {
+#pragma unroll
+        for (int k = 0; k < MAXU; ++k) {
+            if (pr + k * PP < a.HW) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { float dlt = cache[k].v[j] - mean; s2 += dlt * dlt; }
+            }
+        }
+    } else {
+        for (int p = pr; p < a.HW; p += PP) {
+            V<VEC> q = V<VEC>::load(xb + (size_t)p * a.ldx);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { float dlt = q.v[j] - mean; s2 += dlt * dlt; }
+        }
+    }
+    const float var = block_sum_256(s2, red + 4) / cnt;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    if (t == 0 && a.stats) { a.stats[2 * blockIdx.x] = mean; a.stats[2 * blockIdx.x + 1] = rstd; }
+
+    float ga[VEC], be[VEC], tb[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        ga[j] = a.gamma[c0 + j] * rstd;
+        be[j] = a.beta[c0 + j] - mean * ga[j];
+        tb[j] = a.temb ? a.temb[(size_t)n * a.ldt + c0 + j] : 0.f;
+    }
+    float* yb = a.y + (size_t)n * a.HW * a.ldy + c0;
+    const float* rb = a.res ? a.res + (size_t)n * a.HW * a.ldr + c0 : nullptr;
+    auto apply = [&](V<VEC> q, int p) {
+        V<VEC> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.v[j] = mish_f(q.v[j] * ga[j] + be[j]) + tb[j];
+        if (rb) {
+            V<VEC> r = V<VEC>::load(rb + (size_t)p * a.ldr);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o.v[j] += r.v[j];
+        }
+        o.store(yb + (size_t)p * a.ldy);
+    };
+    if constexpr (MAXU > 0) {
+#pragma unroll
+        for (int k = 0; k < MAXU; ++k) { int p = pr + k * PP; if (p < a.HW) apply(cache[k], p); }
+    } else {
+        for (int p = pr; p < a.HW; p += PP) apply(V<VEC>::load(xb + (size_t)p * a.ldx), p);
+    }
+}
+
+// Backward of y = mish(xhat*gamma+beta) + temb + res wrt x (the conv output), gamma, beta, temb.
+template <int VEC, int MAXU>
+__global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
+    __shared__ float part[4][256 * VEC];
+    __shared__ float chs[4][128];
+    __shared__ float s12[2];
+    const int n = blockIdx.x / a.G, g = blockIdx.x % a.G;
+    const int W = a.Cg / VEC, PP = 256 / W;
+    const int t = threadIdx.x, u = t % W, pr = t / W;
+    const int c0 = g * a.Cg + u * VEC;
+    const float mean = a.stats[2 * blockIdx.x], rstd = a.stats[2 * blockIdx.x + 1];
+    const float* xb = a.x + (size_t)n * a.HW * a.ldx + c0;
+    const float* db = a.dout + (size_t)n * a.HW * a.lddo + c0;
+    const float cnt = (float)a.HW * (float)a.Cg;
+    float ga[VEC], be[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { ga[j] = a.gamma[c0 + j]; be[j] = a.beta[c0 + j]; }
+
+    V<VEC> cx[MAXU > 0 ? MAXU : 1], cd[MAXU > 0 ? MAXU : 1];   // cached xhat and dz
+    float sA[VEC], sD[VEC], sT[VEC], sB[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sA[j] = sD[j] = sT[j] = sB[j] = 0.f;
+
+    auto pass1 = [&](int p, V<VEC>& xh, V<VEC>& dz) {
+        V<VEC> q = V<VEC>::load(xb + (size_t)p * a.ldx);
+        V<VEC> d = V<VEC>::load(db + (size_t)p * a.lddo);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float h = (q.v[j] - mean) * rstd;
+            float z = h * ga[j] + be[j];
+            float dzz = d.v[j] * mish_grad_f(z);
+            xh.v[j] = h; dz.v[j] = dzz;
+            sA[j] += dzz; sD[j] += dzz * h; sT[j] += d.v[j]; sB[j] += h;
+        }
+    };
+    if constexpr (MAXU > 0) {
+#pragma unroll
+        for (int k = 0; k < MAXU; ++k) { int p = pr + k * PP; if (p < a.HW) pass1(p, cx[k], cd[k]); }
+    } else {
+        for (int p = pr; p < a.HW; p += PP) { V<VEC> xh, dz; pass1(p, xh, dz); }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        part[0][t * VEC + j] = sA[j]; part[1][t * VEC + j] = sD[j];
+        part[2][t * VEC + j] = sT[j]; part[3][t * VEC + j] = sB[j];
+    }
+    __syncthreads();
+    // per-channel totals: thread (k, c) for k < 4, c < Cg  (Cg <= 64 -> one pass; Cg == 128 -> two)
+    for (int idx = t; idx < 4 * a.Cg; idx += 256) {
+        int k = idx / a.Cg, c = idx % a.Cg;
+        int uu = c / VEC, jj = c % VEC;
+        float tot = 0.f;
+        for (int r = 0; r < PP; ++r) tot += part[k][(r * W + uu) * VEC + jj];
+        chs[k][c] = tot;
+    }
+    __syncthreads();
+    if (t < 64) {
+        float v1 = 0.f, v2 = 0.f;
+        for (int c = t; c < a.Cg; c += 64) {
+            float gm = a.gamma[g * a.Cg + c];
+            v1 += gm * chs[0][c]; v2 += gm * chs[1][c];
+        }
+        v1 = wave_sum(v1); v2 = wave_sum(v2);
+        if (t == 0) { s12[0] = v1; s12[1] = v2; }
+    }
+    __syncthreads();
+    const float s1 = s12[0], s2 = s12[1];
+    if (t < a.Cg) {
+        int c = g * a.Cg + t;
+        if (a.dbeta) atomicAdd(a.dbeta + c, chs[0][t]);
+        if (a.dgamma) atomicAdd(a.dgamma + c, chs[1][t]);
+        if (a.dtemb) a.dtemb[(size_t)n * a.ldt + c] = chs[2][t];
+        if (a.dbias) {
+            float gm = a.gamma[c];
+            atomicAdd(a.dbias + c, rstd * (gm * chs[0][t] - ((float)a.HW * s1 + s2 * chs[3][t]) / cnt));
+        }
+    }
+    float* dxb = a.dx + (size_t)n * a.HW * a.lddx + c0;
+    auto pass2 = [&](int p, const V<VEC>& xh, const V<VEC>& dz) {
+        V<VEC> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.v[j] = rstd * (dz.v[j] * ga[j] - (s1 + xh.v[j] * s2) / cnt);
+        o.store(dxb + (size_t)p * a.lddx);
+    };
+    if constexpr (MAXU > 0) {
+#pragma unroll
+        for (int k = 0; k < MAXU; ++k) { int p = pr + k * PP; if (p < a.HW) pass2(p, cx[k], cd[k]); }
+    } else {
+        for (int p = pr; p < a.HW; p += PP) {
+            V<VEC> q = V<VEC>::load(xb + (size_t)p * a.ldx);
+            V<VEC> d = V<VEC>::load(db + (size_t)p * a.lddo);
+            V<VEC> xh, dz;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                xh.v[j] = (q.v[j] - mean) * rstd;
+                dz.v[j] = d.v[j] * mish_grad_f(xh.v[j] * ga[j] + be[j]);
+            }
+            pass2(p, xh, dz);
+        }
+    }
+}
+
+int gn_prepare(const MiGnDesc* d, GnArgs& a, int& vec, int& units) {
+    if (!d || d->N <= 0 || d->HW <= 0 || d->C <= 0 || d->G <= 0 || d->C % d->G) return -1;
+    a.N = d->N; a.HW = d->HW; a.C = d->C; a.G = d->G; a.Cg = d->C / d->G; a.eps = d->eps;
+    a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr;
+    int cg = a.Cg;
+    if (cg & (cg - 1)) return -2;                 // power of two channel groups only
+    if (cg > 128) return -3;
+    vec = (cg % 4 == 0) ? 4 : 1;
+    if (vec == 1 && cg > 2) return -2;
+    int W = cg / vec, PP = 256 / W;
+    units = (d->HW + PP - 1) / PP;                // V<VEC> units per thread
+    return 0;
+}
+
+// ------------------------------ channel LayerNorm --------------------------------------------
+// one wave per pixel; lanes stride the channel axis in float4; up to 1024 channels cached.
+struct LnArgs {
+    const float* x; const float* g; const float* b; float* y; const float* dy; float* dx; float* dg; float* db;
+    int M, C, ldx, ldy, lddy, lddx, accumulate; float eps;
+};
+constexpr int LN_MAXV = 4;
+
+__global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const LnArgs a) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nq = a.C / 4;
+    for (int m = blockIdx.x * 4 + w; m < a.M; m += gridDim.x * 4) {
+        const float* xp = a.x + (size_t)m * a.ldx;
+        float4 c[LN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            int q = l + 64 * k;
+            if (q < nq) { c[k] = *reinterpret_cast<const float4*>(xp + 4 * q); s += c[k].x + c[k].y + c[k].z + c[k].w; }
+        }
+        const float mean = wave_sum(s) / (float)a.C;
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            if (l + 64 * k < nq) {
+                float d0 = c[k].x - mean, d1 = c[k].y - mean, d2 = c[k].z - mean, d3 = c[k].w - mean;
+                s2 += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
+        }
+        const float var = wave_sum(s2) / (float)a.C;
+        const float inv = 1.0f / (sqrtf(var) + a.eps);
+        float* yp = a.y + (size_t)m * a.ldy;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            int q = l + 64 * k;
+            if (q < nq) {
+                float4 gg = *reinterpret_cast<const float4*>(a.g + 4 * q);
+                float4 bb = *reinterpret_cast<const float4*>(a.b + 4 * q);
+                float4 o;
+                o.x = (c[k].x - mean) * inv * gg.x + bb.x; o.y = (c[k].y - mean) * inv * gg.y + bb.y;
+                o.z = (c[k].z - mean) * inv * gg.z + bb.z; o.w = (c[k].w - mean) * inv * gg.w + bb.w;
+                *reinterpret_cast<float4*>(yp + 4 * q) = o;
+            }
+        }
+    }
+}
+
+// y = xc * inv * g + b,  inv = 1/(sqrt(var)+eps).  dx_i = inv*(dh_i - mean(dh)) - inv^2 * S * xc_i / (sigma*C),
+// dh = dy*g, S = sum dh*xc.
+__global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
+    __shared__ float red[2][4][1024];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nq = a.C / 4;
+    float4 ag[LN_MAXV], ab[LN_MAXV], gg[LN_MAXV];
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        ag[k] = ab[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int q = l + 64 * k;
+        gg[k] = (q < nq) ? *reinterpret_cast<const float4*>(a.g + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int m = blockIdx.x * 4 + w; m < a.M; m += gridDim.x * 4) {
+        const float* xp = a.x + (size_t)m * a.ldx;
+        const float* dp = a.dy + (size_t)m * a.lddy;
+        float4 c[LN_MAXV], d[LN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            int q = l + 64 * k;
+            if (q < nq) {
+                c[k] = *reinterpret_cast<const float4*>(xp + 4 * q);
+                d[k] = *reinterpret_cast<const float4*>(dp + 4 * q);
+                s += c[k].x + c[k].y + c[k].z + c[k].w;
+            }
+        }
+        const float mean = wave_sum(s) / (float)a.C;
+        float s2 = 0.f, sh = 0.f, sS = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            if (l + 64 * k < nq) {
+                c[k].x -= mean; c[k].y -= mean; c[k].z -= mean; c[k].w -= mean;
+                s2 += c[k].x * c[k].x + c[k].y * c[k].y + c[k].z * c[k].z + c[k].w * c[k].w;
+                float h0 = d[k].x * gg[k].x, h1 = d[k].y * gg[k].y, h2 = d[k].z * gg[k].z, h3 = d[k].w * gg[k].w;
+                sh += h0 + h1 + h2 + h3;
+                sS += h0 * c[k].x + h1 * c[k].y + h2 * c[k].z + h3 * c[k].w;
+            }
+        }
+        const float var = wave_sum(s2) / (float)a.C;
+        const float mh = wave_sum(sh) / (float)a.C;
+        const float S = wave_sum(sS);
+        const float sigma = sqrtf(var);
+        const float inv = 1.0f / (sigma + a.eps);
+        const float k2 = sigma > 0.f ? inv * inv * S / (sigma * (float)a.C) : 0.f;
+        float* op = a.dx + (size_t)m * a.lddx;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            int q = l + 64 * k;
+            if (q < nq) {
+                float4 o;
+                o.x = inv * (d[k].x * gg[k].x - mh) - k2 * c[k].x;
+                o.y = inv * (d[k].y * gg[k].y - mh) - k2 * c[k].y;
+                o.z = inv * (d[k].z * gg[k].z - mh) - k2 * c[k].z;
+                o.w = inv * (d[k].w * gg[k].w - mh) - k2 * c[k].w;
+                if (a.accumulate) {
+                    float4 prev = *reinterpret_cast<const float4*>(op + 4 * q);
+                    o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
+                }
+                *reinterpret_cast<float4*>(op + 4 * q) = o;
+                ag[k].x += d[k].x * c[k].x * inv; ag[k].y += d[k].y * c[k].y * inv;
+                ag[k].z += d[k].z * c[k].z * inv; ag[k].w += d[k].w * c[k].w * inv;
+                ab[k].x += d[k].x; ab[k].y += d[k].y; ab[k].z += d[k].z; ab[k].w += d[k].w;
+            }
+        }
+    }
+    // combine the 4 waves' per-channel partials, one atomic per channel per block
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        int q = l + 64 * k;
+        if (q < nq) {
+            red[0][w][4 * q + 0] = ag[k].x; red[0][w][4 * q + 1] = ag[k].y; red[0][w][4 * q + 2] = ag[k].z; red[0][w][4 * q + 3] = ag[k].w;
+            red[1][w][4 * q + 0] = ab[k].x; red[1][w][4 * q + 1] = ab[k].y; red[1][w][4 * q + 2] = ab[k].z; red[1][w][4 * q + 3] = ab[k].w;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        float v0 = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        float v1 = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        if (a.dg) atomicAdd(a.dg + c, v0);
+        if (a.db) atomicAdd(a.db + c, v1);
+    }
+}
+
+}  // namespace
+
+#define GN_DISPATCH(KERNEL)                                                                         \
+    do {                                                                                            \
+        dim3 grid(a.N * a.G), blk(256);                                                             \
+        if (vec == 4) {                                                                             \
+            if (units <= 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, blk, 0, st, a);                \
+            else if (units <= 16) hipLaunchKernelGGL((KERNEL<4, 16>), grid, blk, 0, st, a);         \
+            else hipLaunchKernelGGL((KERNEL<4, 0>), grid, blk, 0, st, a);                           \
+        } else {                                                                                    \
+            if (units <= 16) hipLaunchKernelGGL((KERNEL<1, 16>), grid, blk, 0, st, a);              \
+            else hipLaunchKernelGGL((KERNEL<1, 0>), grid, blk, 0, st, a);                           \
+        }                                                                                           \
+    } while (0)
+
+extern "C" int mi_gn_mish_fwd(const MiGnDesc* d, const float* x, const float* gamma, const float* beta,
+                              const float* temb, int ldt, const float* residual, float* y, float* stats,
+                              void* stream) {
+    MI_REQUIRE(x && gamma && beta && y, "null argument");
+    GnArgs a{};
+    int vec, units;
+    int rc = gn_prepare(d, a, vec, units);
+    MI_REQUIRE(rc == 0, "C/G must be a power of two <= 128 (and 1, 2 or a multiple of 4)");
+    MI_REQUIRE(vec == 1 || (d->ldx % 4 == 0 && d->ldy % 4 == 0 && (!residual || d->ldr % 4 == 0)), "ld must be a multiple of 4");
+    a.x = x; a.gamma = gamma; a.beta = beta; a.temb = temb; a.ldt = ldt; a.res = residual; a.y = y; a.stats = stats;
+    hipStream_t st = (hipStream_t)stream;
+    GN_DISPATCH(gn_mish_fwd_kernel);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi_gn_mish_bwd(const MiGnDesc* d, const float* x, const float* stats, const float* gamma,
+                              const float* beta, const float* dout, int lddo, float* dx, int lddx,
+                              float* dgamma, float* dbeta, float* dtemb, int ldt, float* dbias, void* stream) {
+    MI_REQUIRE(x && stats && gamma && beta && dout && dx, "null argument");
+    GnArgs a{};
+    int vec, units;
+    int rc = gn_prepare(d, a, vec, units);
+    MI_REQUIRE(rc == 0, "C/G must be a power of two <= 128 (and 1, 2 or a multiple of 4)");
+    MI_REQUIRE(vec == 1 || (d->ldx % 4 == 0 && lddo % 4 == 0 && lddx % 4 == 0), "ld must be a multiple of 4");
+    a.x = x; a.stats = const_cast<float*>(stats); a.gamma = gamma; a.beta = beta; a.dout = dout; a.lddo = lddo;
+    a.dx = dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta; a.dtemb = dtemb; a.ldt = ldt; a.dbias = dbias;
+    hipStream_t st = (hipStream_t)stream;
+    GN_DISPATCH(gn_mish_bwd_kernel);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi_chan_layernorm_fwd(int M, int C, const float* x, int ldx, const float* g, const float* b,
+                                     float eps, float* y, int ldy, void* stream) {
+    MI_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0, "C must be a multiple of 4, <= 1024");
+    MI_REQUIRE(x && g && b && y, "null argument");
+    LnArgs a{};
+    a.x = x; a.g = g; a.b = b; a.y = y; a.M = M; a.C = C; a.ldx = ldx; a.ldy = ldy; a.eps = eps;
+    int blocks = (M + 3) / 4; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(chan_ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi_chan_layernorm_bwd(int M, int C, const float* x, int ldx, const float* g, float eps,
+                                     const float* dy, int lddy, float* dx, int lddx, int accumulate_dx,
+                                     float* dg, float* db, void* stream) {
+    MI_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "C must be a multiple of 4, <= 1024");
+    MI_REQUIRE(x && g && dy && dx, "null argument");
+    LnArgs a{};
+    a.x = x; a.g = g; a.dy = dy; a.dx = dx; a.dg = dg; a.db = db; a.M = M; a.C = C; a.ldx = ldx; a.lddy = lddy;
+    a.lddx = lddx; a.accumulate = accumulate_dx; a.eps = eps;
+    int blocks = (M + 3) / 4; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(chan_ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    MI_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,781 @@
+"""DDPM on MI355X: `Unet`, `GaussianDiffusion`, `DDPM` with the reference's constructor
+signatures, method names and state_dict keys (reference: src/models/ddpm.py:169-521), but
+executed by the hand-written gfx950 kernels of libmi_ddpm.so (include/mi_ddpm.h).
+
+Design (DESIGN.md has the long form):
+  * every UNet parameter is a VIEW into ONE flat fp32 buffer (`Unet.flat_params`); conv weights
+    are stored tap-major [kh][kw][Cin][Cout] and exposed as permuted views with PyTorch's logical
+    shapes, so state_dict()/load_state_dict() round-trip reference checkpoints while forward,
+    dgrad, wgrad, the optimizer and the RCCL all-reduce stream contiguous memory.
+  * activations are NHWC fp32; NCHW only at the `Unet.forward` boundary.
+  * `Unet.forward` is one autograd node: the forward pass records a tape of kernel-level
+    backward steps; `backward` replays it, writing into the flat gradient buffer
+    (`Unet.flat_grads`, which every `param.grad` is a view of).
+  * there is no CPU / ATen fallback: tensors that are not on a HIP device raise.
+"""
+from __future__ import annotations
+
+import math
+import os
+from functools import partial
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..ops import functional as K
+from .base import BaseModel, ValidationResult
+
+_HEADS, _DHEAD = 4, 32            # LinearAttention(dim, heads=4, dim_head=32)   ddpm.py:147
+_GN_GROUPS = 8                    # Block always builds GroupNorm(8, .)           ddpm.py:113,132-133
+
+
+def _mode_id(name: str) -> int:
+    if name not in ("fp32", "bf16"):
+        raise ValueError(f"compute mode must be 'fp32' or 'bf16', got {name!r}")
+    return K.MODE_BF16 if name == "bf16" else K.MODE_FP32
+
+
+# --------------------------------------------------------------------------------------------
+# network description
+# --------------------------------------------------------------------------------------------
+class _Entry:
+    """One parameter: logical (PyTorch) shape, storage layout, init rule."""
+    __slots__ = ("key", "shape", "layout", "init", "fan_in", "rank", "offset", "numel")
+
+    def __init__(self, key, shape, layout, init, fan_in, rank):
+        self.key, self.shape, self.layout, self.init, self.fan_in, self.rank = key, tuple(shape), layout, init, fan_in, rank
+        self.numel = int(np.prod(shape))
+        self.offset = -1
+
+    def storage_view(self, flat: torch.Tensor) -> torch.Tensor:
+        seg = flat[self.offset:self.offset + self.numel]
+        if self.layout == "conv":            # logical [Cout,Cin,kh,kw], stored [kh,kw,Cin,Cout]
+            co, ci, kh, kw = self.shape
+            return seg.view(kh, kw, ci, co)
+        if self.layout == "convT":           # logical [Cin,Cout,kh,kw], stored [kh,kw,Cin,Cout]
+            ci, co, kh, kw = self.shape
+            return seg.view(kh, kw, ci, co)
+        return seg.view(self.shape)
+
+    def logical_view(self, flat: torch.Tensor) -> torch.Tensor:
+        sv = self.storage_view(flat)
+        if self.layout == "conv":
+            return sv.permute(3, 2, 0, 1)
+        if self.layout == "convT":
+            return sv.permute(2, 3, 0, 1)
+        return sv
+
+
+class _Arch:
+    """Static layer list of the reference Unet (ddpm.py:182-236) + parameter table."""
+
+    def __init__(self, dim, dim_mults, channels, out_dim):
+        self.dim, self.channels, self.out_dim = dim, channels, out_dim or channels
+        self.dims = [channels] + [dim * m for m in dim_mults]
+        pairs = list(zip(self.dims[:-1], self.dims[1:]))
+        self.entries: List[_Entry] = []
+        self.res_blocks: List[dict] = []
+        rank = {"time_mlp": 0, "downs": 1, "ups": 2, "mid_block1": 3, "mid_attn": 4, "mid_block2": 5, "final_conv": 6}
+
+        def add(key, shape, layout="plain", init="zero", fan_in=0):
+            self.entries.append(_Entry(key, shape, layout, init, fan_in, rank[key.split(".")[0]]))
+
+        def linear(pre, i, o):
+            add(pre + "weight", (o, i), "plain", "kaiming", i); add(pre + "bias", (o,), "plain", "ubias", i)
+
+        def conv(pre, i, o, k, bias=True, transposed=False):
+            shape = (i, o, k, k) if transposed else (o, i, k, k)
+            fan = shape[1] * k * k
+            add(pre + "weight", shape, "convT" if transposed else "conv", "kaiming", fan)
+            if bias:
+                add(pre + "bias", (o,), "plain", "ubias", fan)
+
+        def norm_affine(wkey, bkey, shape):
+            add(wkey, shape, "plain", "one"); add(bkey, shape, "plain", "zero")
+
+        def resblock(pre, i, o):
+            linear(pre + "mlp.1.", dim, o)
+            for blk, ci in (("block1.", i), ("block2.", o)):
+                conv(pre + blk + "block.0.", ci, o, 3)
+                norm_affine(pre + blk + "block.1.weight", pre + blk + "block.1.bias", (o,))
+            if i != o:
+                conv(pre + "res_conv.", i, o, 1)
+            blk = {"pre": pre, "cin": i, "cout": o, "res": i != o}
+            self.res_blocks.append(blk)
+            return blk
+
+        def attention(pre, c):
+            conv(pre + "fn.fn.to_qkv.", c, 3 * _HEADS * _DHEAD, 1, bias=False)
+            conv(pre + "fn.fn.to_out.", _HEADS * _DHEAD, c, 1)
+            norm_affine(pre + "fn.norm.g", pre + "fn.norm.b", (1, c, 1, 1))
+            return {"pre": pre, "c": c}
+
+        linear("time_mlp.1.", dim, dim * 4)
+        linear("time_mlp.3.", dim * 4, dim)
+        self.downs, self.ups = [], []
+        for L, (i, o) in enumerate(pairs):
+            lvl = {"res1": resblock(f"downs.{L}.0.", i, o), "res2": resblock(f"downs.{L}.1.", o, o),
+                   "attn": attention(f"downs.{L}.2.", o), "down": None}
+            if L < len(pairs) - 1:
+                conv(f"downs.{L}.3.conv.", o, o, 3)
+                lvl["down"] = {"pre": f"downs.{L}.3.conv.", "c": o}
+            self.downs.append(lvl)
+        mid = self.dims[-1]
+        self.mid1 = resblock("mid_block1.", mid, mid)
+        self.mid_attn = attention("mid_attn.", mid)
+        self.mid2 = resblock("mid_block2.", mid, mid)
+        for L, (i, o) in enumerate(reversed(pairs[1:])):
+            lvl = {"res1": resblock(f"ups.{L}.0.", o * 2, i), "res2": resblock(f"ups.{L}.1.", i, i),
+                   "attn": attention(f"ups.{L}.2.", i)}
+            conv(f"ups.{L}.3.conv.", i, i, 4, transposed=True)      # `is_last` never fires (ddpm.py:222)
+            lvl["up"] = {"pre": f"ups.{L}.3.conv.", "c": i}
+            self.ups.append(lvl)
+        c1 = self.dims[1]
+        conv("final_conv.0.block.0.", c1, c1, 3)
+        norm_affine("final_conv.0.block.1.weight", "final_conv.0.block.1.bias", (c1,))
+        conv("final_conv.1.", c1, self.out_dim, 1)
+
+        # flat storage order: all time-bias Linear weights adjacent (one GEMM feeds every
+        # ResnetBlock), then their biases, then everything else; 64-float alignment per entry.
+        mlp_w = [e for e in self.entries if e.key.endswith(".mlp.1.weight")]
+        mlp_b = [e for e in self.entries if e.key.endswith(".mlp.1.bias")]
+        rest = [e for e in self.entries if e not in mlp_w and e not in mlp_b]
+        off = 0
+        for e in mlp_w:
+            e.offset = off; off += e.numel
+        off = (off + 63) // 64 * 64
+        self.mlp_w_off, self.mlp_rows = mlp_w[0].offset, sum(e.shape[0] for e in mlp_w)
+        self.mlp_b_off = off
+        for e in mlp_b:
+            e.offset = off; off += e.numel
+        for e in rest:
+            off = (off + 63) // 64 * 64
+            e.offset = off; off += e.numel
+        self.flat_numel = (off + 63) // 64 * 64
+        col = 0
+        for blk, e in zip(self.res_blocks, mlp_w):
+            assert e.key == blk["pre"] + "mlp.1.weight"
+            blk["tcol"] = col; col += blk["cout"]
+
+
+class _Node(nn.Module):
+    """Anonymous container; the module tree exists only to reproduce the reference's keys."""
+
+
+# --------------------------------------------------------------------------------------------
+# gradient bookkeeping for the tape
+# --------------------------------------------------------------------------------------------
+class _GradMap:
+    def __init__(self):
+        self._g: Dict[int, torch.Tensor] = {}
+        self._keep: List[torch.Tensor] = []
+
+    def take(self, t: torch.Tensor) -> torch.Tensor:
+        return self._g.pop(id(t))
+
+    def add(self, t: torch.Tensor, g: torch.Tensor):
+        """grad[t] += g, by alias when it is the first contribution."""
+        cur = self._g.get(id(t))
+        if cur is None:
+            self._g[id(t)] = g; self._keep.append(t)
+        else:
+            K.axpby(1.0, g, cur, True)
+
+    def target(self, t: torch.Tensor) -> Tuple[torch.Tensor, bool]:
+        """(buffer, accumulate) for a kernel that writes a contribution to grad[t]."""
+        cur = self._g.get(id(t))
+        if cur is not None:
+            return cur, True
+        buf = torch.empty(t.shape, device=t.device, dtype=torch.float32)
+        self._g[id(t)] = buf; self._keep.append(t)
+        return buf, False
+
+
+class _UnetFunction(torch.autograd.Function):
+    """One autograd node for the whole UNet; parameter gradients are written straight into
+    `Unet.flat_grads` (what every param.grad views), so nothing is returned for them."""
+
+    @staticmethod
+    def forward(ctx, x, time, anchor, net):
+        y, tape = net._execute(x, time, record=True)
+        ctx.net, ctx.tape = net, tape
+        ctx.need_dx = x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        net, tape = ctx.net, ctx.tape
+        ctx.tape = None
+        dx = net._backward(tape, dy.contiguous(), need_dx=ctx.need_dx)
+        return dx, None, None, None
+
+
+class Unet(nn.Module):
+    """Drop-in for the reference `Unet` (ddpm.py:169-261): same ctor, `forward(x, time)`,
+    parameters()/state_dict() keys and shapes.  `groups` is accepted and ignored exactly like
+    the reference (its blocks always use 8 groups)."""
+
+    def __init__(self, dim, out_dim=None, dim_mults=(1, 2, 4, 8), groups=8, channels=3, with_time_emb=True):
+        super().__init__()
+        if not with_time_emb:
+            raise NotImplementedError("with_time_emb=False is dead code in the reference (never used by DDPM)")
+        if dim % 8 or dim < 8:
+            raise ValueError("dim must be a multiple of 8")
+        self.channels = channels
+        self.dim = dim
+        arch = _Arch(dim, tuple(dim_mults), channels, out_dim)
+        object.__setattr__(self, "_arch", arch)
+        self.compute_mode = os.environ.get("MI_DDPM_MODE", "fp32")
+        self.accumulate_grads = False
+
+        flat = torch.zeros(arch.flat_numel)
+        # default torch init drawn in the reference's construction order => same seeded weights
+        for e in arch.entries:
+            if e.init == "kaiming":
+                w = torch.empty(e.shape)
+                nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+                e.logical_view(flat).copy_(w)
+            elif e.init == "ubias":
+                bound = 1 / math.sqrt(e.fan_in) if e.fan_in > 0 else 0
+                e.logical_view(flat).copy_(torch.empty(e.shape).uniform_(-bound, bound))
+            elif e.init == "one":
+                e.logical_view(flat).fill_(1.0)
+        object.__setattr__(self, "_flat", flat)
+        object.__setattr__(self, "_gflat", None)
+        object.__setattr__(self, "_anchor", torch.zeros(1, requires_grad=True))
+        # module tree in the reference's registration order (time_mlp, downs, ups, mid_*, final_conv)
+        self._plist: List[Tuple[_Entry, nn.Parameter]] = []
+        for e in sorted(arch.entries, key=lambda q: q.rank):   # stable: keeps construction order inside a group
+            parts = e.key.split(".")
+            node = self
+            for name in parts[:-1]:
+                if name not in node._modules:
+                    node.add_module(name, _Node())
+                node = node._modules[name]
+            p = nn.Parameter(e.logical_view(flat))
+            node.register_parameter(parts[-1], p)
+            self._plist.append((e, p))
+        self._bind(flat)
+
+    # ------------------------------------------------------------------ storage management
+    def _bind(self, flat: torch.Tensor):
+        object.__setattr__(self, "_flat", flat)
+        sv = {}
+        for e, p in self._plist:
+            p.data = e.logical_view(flat)
+            sv[e.key] = e.storage_view(flat)
+        object.__setattr__(self, "_sv", sv)
+        g = self._gflat
+        if g is not None and (g.device != flat.device or g.dtype != flat.dtype):
+            object.__setattr__(self, "_gflat", None)
+            for _, p in self._plist:
+                p.grad = None
+
+    def _apply(self, fn, recurse=True):
+        new = fn(self._flat)
+        if new.dtype != torch.float32:
+            raise RuntimeError("the MI355X UNet keeps fp32 master weights; use compute_mode='bf16' for bf16 math")
+        if new is not self._flat:
+            self._bind(new)
+        return self
+
+    @property
+    def flat_params(self) -> torch.Tensor:
+        return self._flat
+
+    @property
+    def flat_grads(self) -> torch.Tensor:
+        if self._gflat is None:
+            g = torch.zeros_like(self._flat)
+            object.__setattr__(self, "_gflat", g)
+            gv = {}
+            for e, p in self._plist:
+                p.grad = e.logical_view(g)
+                gv[e.key] = e.storage_view(g)
+            object.__setattr__(self, "_gv", gv)
+        return self._gflat
+
+    def zero_grad(self, set_to_none: bool = False):
+        if self._gflat is not None:
+            self._gflat.zero_()
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=False)
+        return out
+
+    # ------------------------------------------------------------------ public forward
+    def forward(self, x, time):
+        if not x.is_cuda:
+            raise RuntimeError("Unet.forward: input is not on a HIP device; this implementation has no CPU path")
+        if self._flat.device != x.device:
+            raise RuntimeError("Unet parameters and input are on different devices; call .to(device) first")
+        if torch.is_grad_enabled() and (self.training or x.requires_grad):
+            if self._anchor.device != x.device:
+                object.__setattr__(self, "_anchor", torch.zeros(1, device=x.device, requires_grad=True))
+            return _UnetFunction.apply(x, time, self._anchor, self)
+        y, _ = self._execute(x, time, record=False)
+        return y
+
+    def _execute(self, x, time, record):
+        """NCHW in -> NCHW out; returns (y, tape)."""
+        x_in = K.nchw_to_nhwc(x.float())
+        eps, tape = self.forward_nhwc(x_in, time, record)
+        return K.nhwc_to_nchw(eps), tape
+
+    # ------------------------------------------------------------------ kernel-level forward
+    def forward_nhwc(self, x, time, record=False):
+        """x: NHWC activation [B,H,W,channels] (pixel stride 4-aligned) -> NHWC eps prediction + tape."""
+        A, sv, mode = self._arch, self._sv, _mode_id(self.compute_mode)
+        tape: Optional[list] = [] if record else None
+        B, H, W, _ = x.shape
+        flat = self._flat
+
+        def lin(inp, wkey, rows=None, w=None, b=None):
+            w = sv[wkey + "weight"] if w is None else w
+            b = sv[wkey + "bias"] if b is None else b
+            o, i = w.shape
+            y = K.conv_igemm(inp.view(B, 1, 1, i), w, kh=1, kw=1, stride=1, pad=0, transposed=False, w_kn=False,
+                             K=i, Nc=o, out_hw=(1, 1), mode=K.MODE_FP32, bias=b)
+            return y.view(B, o)
+
+        # ---- time embedding MLP (ddpm.py:186-193) and every block's time bias (ddpm.py:126-130) in one GEMM
+        te = K.time_embed(time, A.dim)
+        t1 = lin(te, "time_mlp.1.")
+        a1 = K.mish_fwd(t1)
+        temb = lin(a1, "time_mlp.3.")
+        mt = K.mish_fwd(temb)
+        w_all = flat[A.mlp_w_off:A.mlp_w_off + A.mlp_rows * A.dim].view(A.mlp_rows, A.dim)
+        b_all = flat[A.mlp_b_off:A.mlp_b_off + A.mlp_rows]
+        tb_all = lin(mt, None, w=w_all, b=b_all)                       # [B, sum Cout]
+        if record:
+            tape.append(("time", te, t1, a1, temb, mt))
+
+        def conv(inp, pre, k, stride=1, pad=0, x2=None, residual=None, transposed_conv=False, bias=True):
+            w = sv[pre + "weight"]
+            kh, kw, ci, co = w.shape
+            ih, iw = inp.shape[1], inp.shape[2]
+            if transposed_conv:
+                oh, ow = ih * stride, iw * stride
+            else:
+                oh, ow = (ih + 2 * pad - kh) // stride + 1, (iw + 2 * pad - kw) // stride + 1
+            y = K.conv_igemm(inp, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=transposed_conv, w_kn=True,
+                             K=ci, Nc=co, out_hw=(oh, ow), mode=mode, x2=x2,
+                             bias=sv[pre + "bias"] if bias else None, residual=residual)
+            return y
+
+        def resblock(blk, inp, x2=None):
+            pre, co = blk["pre"], blk["cout"]
+            c1 = conv(inp, pre + "block1.block.0.", 3, 1, 1, x2=x2)
+            tb = tb_all[:, blk["tcol"]:blk["tcol"] + co]
+            h1, st1 = K.gn_mish_fwd(c1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], temb=tb)
+            c2 = conv(h1, pre + "block2.block.0.", 3, 1, 1)
+            r = conv(inp, pre + "res_conv.", 1, x2=x2) if blk["res"] else inp
+            out, st2 = K.gn_mish_fwd(c2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], residual=r)
+            if record:
+                tape.append(("res", blk, inp, x2, c1, st1, h1, c2, st2, out))
+            return out
+
+        def attention(at, inp):
+            pre = at["pre"]
+            ln = K.chan_layernorm_fwd(inp, sv[pre + "fn.norm.g"], sv[pre + "fn.norm.b"])
+            qkv = conv(ln, pre + "fn.fn.to_qkv.", 1, bias=False)
+            ao, ctx, kstat = K.linattn_fwd(qkv, _HEADS)
+            out = conv(ao, pre + "fn.fn.to_out.", 1, residual=inp)
+            if record:
+                tape.append(("attn", at, inp, ln, qkv, ctx, kstat, ao, out))
+            return out
+
+        skips = []
+        h = x
+        for lvl in A.downs:
+            h = resblock(lvl["res1"], h)
+            h = resblock(lvl["res2"], h)
+            h = attention(lvl["attn"], h)
+            skips.append(h)
+            if lvl["down"] is not None:
+                inp = h
+                h = conv(inp, lvl["down"]["pre"], 3, 2, 1)
+                if record:
+                    tape.append(("down", lvl["down"], inp, h))
+        h = resblock(A.mid1, h)
+        h = attention(A.mid_attn, h)
+        h = resblock(A.mid2, h)
+        for lvl in A.ups:
+            h = resblock(lvl["res1"], h, x2=skips.pop())          # cat((x, skip)) read in place (ddpm.py:255)
+            h = resblock(lvl["res2"], h)
+            h = attention(lvl["attn"], h)
+            inp = h
+            h = conv(inp, lvl["up"]["pre"], 4, 2, 1, transposed_conv=True)
+            if record:
+                tape.append(("up", lvl["up"], inp, h))
+        cF = conv(h, "final_conv.0.block.0.", 3, 1, 1)
+        hF, stF = K.gn_mish_fwd(cF, sv["final_conv.0.block.1.weight"], sv["final_conv.0.block.1.bias"])
+        eps = conv(hF, "final_conv.1.", 1)
+        if record:
+            tape.append(("final", h, cF, stF, hF, eps))
+            tape.append(("input", x))
+        return eps, tape
+
+    # ------------------------------------------------------------------ kernel-level backward
+    def _backward(self, tape, dy_nchw, need_dx=False):
+        d_eps = K.nchw_to_nhwc(dy_nchw)
+        return self.backward_nhwc(tape, d_eps, need_dx)
+
+    def backward_nhwc(self, tape, d_eps, need_dx=False):
+        """Replays the tape in reverse.  d_eps: NHWC gradient of the eps prediction."""
+        A, sv, mode = self._arch, self._sv, _mode_id(self.compute_mode)
+        gflat = self.flat_grads
+        if not self.accumulate_grads:
+            gflat.zero_()                                  # wgrad / norm kernels accumulate atomically
+        gv = self._gv
+        G = _GradMap()
+        x_in = tape[-1][1]
+        B = x_in.shape[0]
+        dtb_all = torch.zeros((B, A.mlp_rows), device=x_in.device, dtype=torch.float32)
+
+        def conv_bwd(dy, inp, pre, k, stride=1, pad=0, x2=None, transposed_conv=False, bias="colsum", want_dx=True):
+            """Gradients of y = conv(inp [|x2]); dy may be a channel slice."""
+            w = sv[pre + "weight"]
+            kh, kw, ci, co = w.shape
+            ih, iw = inp.shape[1], inp.shape[2]
+            oh, ow = dy.shape[1], dy.shape[2]
+            if transposed_conv:   # dW[tap][ci][co] = sum over input pixels  x[j] * dy[gather(j, tap)]
+                K.conv_wgrad(inp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=False,
+                             Ci=ci, Cj=co, grid_g=(oh, ow), grid_d=(ih, iw), mode=mode)
+            else:
+                K.conv_wgrad(inp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=True,
+                             Ci=ci, Cj=co, grid_g=(ih, iw), grid_d=(oh, ow), mode=mode, P2=x2)
+            if bias == "colsum":
+                K.colsum(dy, gv[pre + "bias"])
+            if not want_dx:
+                return
+            if x2 is None:
+                buf, acc = G.target(inp)
+                K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=not transposed_conv, w_kn=False,
+                             K=co, Nc=ci, out_hw=(ih, iw), mode=mode, out=buf, accumulate=acc)
+            else:
+                # gradient of the (virtual) concat: one buffer, the two sources take channel slices of it
+                cat = G._g.get(("cat", id(inp)))
+                acc = cat is not None
+                if cat is None:
+                    cat = torch.empty((B, ih, iw, ci), device=dy.device, dtype=torch.float32)
+                    G._g[("cat", id(inp))] = cat
+                K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=True, w_kn=False,
+                             K=co, Nc=ci, out_hw=(ih, iw), mode=mode, out=cat, accumulate=acc)
+
+        def res_bwd(rec):
+            _, blk, inp, x2, c1, st1, h1, c2, st2, out = rec
+            pre = blk["pre"]
+            dout = G.take(out)
+            # residual branch first: its gradient is dout itself (read before anything accumulates into it)
+            is_first = inp is x_in
+            want_dx = (not is_first) or need_dx
+            if blk["res"]:
+                conv_bwd(dout, inp, pre + "res_conv.", 1, x2=x2, want_dx=want_dx)
+            else:
+                G.add(inp, dout)
+            dc2 = K.gn_mish_bwd(c2, st2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], dout,
+                                dgamma=gv[pre + "block2.block.1.weight"], dbeta=gv[pre + "block2.block.1.bias"],
+                                dbias=gv[pre + "block2.block.0.bias"])
+            conv_bwd(dc2, h1, pre + "block2.block.0.", 3, 1, 1, bias=None)
+            dh1 = G.take(h1)
+            dtb = dtb_all[:, blk["tcol"]:blk["tcol"] + blk["cout"]]
+            dc1 = K.gn_mish_bwd(c1, st1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], dh1,
+                                dgamma=gv[pre + "block1.block.1.weight"], dbeta=gv[pre + "block1.block.1.bias"],
+                                dtemb=dtb, dbias=gv[pre + "block1.block.0.bias"])
+            conv_bwd(dc1, inp, pre + "block1.block.0.", 3, 1, 1, x2=x2, bias=None, want_dx=want_dx)
+            if x2 is not None:
+                cat = G._g.pop(("cat", id(inp)))
+                k1 = inp.shape[3]
+                G.add(inp, cat[..., :k1])
+                G.add(x2, cat[..., k1:])
+
+        def attn_bwd(rec):
+            _, at, inp, ln, qkv, ctx, kstat, ao, out = rec
+            pre = at["pre"]
+            dout = G.take(out)
+            G.add(inp, dout)                                           # Residual: fn(x) + x  (ddpm.py:45)
+            conv_bwd(dout, ao, pre + "fn.fn.to_out.", 1)
+            dao = G.take(ao)
+            dqkv = K.linattn_bwd(qkv, ctx, kstat, dao, _HEADS)
+            conv_bwd(dqkv, ln, pre + "fn.fn.to_qkv.", 1, bias=None)
+            dln = G.take(ln)
+            buf, acc = G.target(inp)
+            K.chan_layernorm_bwd(inp, sv[pre + "fn.norm.g"], dln, buf, acc, gv[pre + "fn.norm.g"], gv[pre + "fn.norm.b"])
+
+        dx_in = None
+        for rec in reversed(tape):
+            kind = rec[0]
+            if kind == "input":
+                continue
+            if kind == "final":
+                _, h, cF, stF, hF, eps = rec
+                conv_bwd(d_eps, hF, "final_conv.1.", 1)
+                dhF = G.take(hF)
+                dcF = K.gn_mish_bwd(cF, stF, sv["final_conv.0.block.1.weight"], sv["final_conv.0.block.1.bias"], dhF,
+                                    dgamma=gv["final_conv.0.block.1.weight"], dbeta=gv["final_conv.0.block.1.bias"],
+                                    dbias=gv["final_conv.0.block.0.bias"])
+                conv_bwd(dcF, h, "final_conv.0.block.0.", 3, 1, 1, bias=None)
+            elif kind == "res":
+                res_bwd(rec)
+            elif kind == "attn":
+                attn_bwd(rec)
+            elif kind == "down":
+                _, dn, inp, out = rec
+                conv_bwd(G.take(out), inp, dn["pre"], 3, 2, 1)
+            elif kind == "up":
+                _, up, inp, out = rec
+                conv_bwd(G.take(out), inp, up["pre"], 4, 2, 1, transposed_conv=True)
+            elif kind == "time":
+                _, te, t1, a1, temb, mt = rec
+                dim = A.dim
+
+                def lin_bwd(dy, inp, gw, gb, w, want_dx=True):
+                    o, i = w.shape
+                    K.conv_wgrad(dy.view(B, 1, 1, o), inp.view(B, 1, 1, i), gw, kh=1, kw=1, stride=1, pad=0,
+                                 gather_i=True, Ci=o, Cj=i, grid_g=(1, 1), grid_d=(1, 1), mode=K.MODE_FP32)
+                    K.colsum(dy, gb)
+                    if not want_dx:
+                        return None
+                    dx = K.conv_igemm(dy.view(B, 1, 1, o), w, kh=1, kw=1, stride=1, pad=0, transposed=False, w_kn=True,
+                                      K=o, Nc=i, out_hw=(1, 1), mode=K.MODE_FP32)
+                    return dx.view(B, i)
+                w_all = self._flat[A.mlp_w_off:A.mlp_w_off + A.mlp_rows * dim].view(A.mlp_rows, dim)
+                gw_all = gflat[A.mlp_w_off:A.mlp_w_off + A.mlp_rows * dim]
+                gb_all = gflat[A.mlp_b_off:A.mlp_b_off + A.mlp_rows]
+                dmt = lin_bwd(dtb_all, mt, gw_all, gb_all, w_all)
+                dtemb = K.mish_bwd(temb, dmt)
+                da1 = lin_bwd(dtemb, a1, gv["time_mlp.3.weight"], gv["time_mlp.3.bias"], sv["time_mlp.3.weight"])
+                dt1 = K.mish_bwd(t1, da1)
+                lin_bwd(dt1, te, gv["time_mlp.1.weight"], gv["time_mlp.1.bias"], sv["time_mlp.1.weight"], want_dx=False)
+        if need_dx:
+            dx_in = K.nhwc_to_nchw(G.take(x_in))
+        return dx_in
+
+
+# --------------------------------------------------------------------------------------------
+# diffusion process
+# --------------------------------------------------------------------------------------------
+def extract(a, t, x_shape):
+    """a[t] broadcast to x (ddpm.py:263-266); kept for API compatibility."""
+    out = a.gather(-1, t)
+    return out.reshape(t.shape[0], *((1,) * (len(x_shape) - 1)))
+
+
+def cosine_beta_schedule(timesteps, s=0.008):
+    """Cosine schedule exactly as the reference computes it (ddpm.py:281-291): float64 numpy,
+    T+1 grid points over [0, T+1]."""
+    n = timesteps + 1
+    grid = np.linspace(0, n, n)
+    f = np.cos(((grid / n) + s) / (1 + s) * np.pi * 0.5) ** 2
+    f = f / f[0]
+    return np.clip(1 - (f[1:] / f[:-1]), a_min=0, a_max=0.999)
+
+
+def linear_beta_schedule(timesteps):
+    scale = 1000 / timesteps
+    return torch.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=torch.float64)
+
+
+class _LossFunction(torch.autograd.Function):
+    """q_sample -> UNet -> L1/L2 loss as one node: all three stay NHWC and on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x0, t, noise, anchor, gd):
+        net = gd.denoise_fn
+        xt, _ = K.q_sample(x0, noise, t, gd.sqrt_alphas_cumprod, gd.sqrt_one_minus_alphas_cumprod)
+        eps, tape = net.forward_nhwc(xt, t, record=ctx.needs_input_grad[3])
+        loss, dpred = K.eps_loss(eps, noise, 0 if gd.loss_type == "l1" else 1, want_grad=ctx.needs_input_grad[3])
+        ctx.net, ctx.tape, ctx.dpred = net, tape, dpred
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        net, tape, dpred = ctx.net, ctx.tape, ctx.dpred
+        ctx.tape = ctx.dpred = None
+        # d loss is 1.0 in training_step; honour other scales without a host sync
+        d_eps = dpred
+        if dloss is not None:
+            K.scale_by_device_scalar(d_eps, dloss)
+        net.backward_nhwc(tape, d_eps, need_dx=False)
+        return None, None, None, None, None
+
+
+class GaussianDiffusion(nn.Module):
+    """Reference `GaussianDiffusion` (ddpm.py:294-466): same ctor, buffers and methods."""
+
+    def __init__(self, denoise_fn, *, image_size, channels=3, timesteps=1000, loss_type="l1", betas=None):
+        super().__init__()
+        self.channels = channels
+        self.image_size = image_size
+        self.denoise_fn = denoise_fn
+        if betas is not None:
+            betas = betas.detach().cpu().numpy() if isinstance(betas, torch.Tensor) else np.asarray(betas)
+        else:
+            betas = cosine_beta_schedule(timesteps)
+        betas = betas.astype(np.float64)
+        alphas = 1.0 - betas
+        ac = np.cumprod(alphas, axis=0)
+        ac_prev = np.append(1.0, ac[:-1])
+        self.num_timesteps = int(betas.shape[0])
+        if loss_type not in ("l1", "l2"):
+            raise NotImplementedError(loss_type)
+        self.loss_type = loss_type
+        post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+        tables = (
+            ("betas", betas), ("alphas_cumprod", ac), ("alphas_cumprod_prev", ac_prev),
+            ("sqrt_alphas_cumprod", np.sqrt(ac)), ("sqrt_one_minus_alphas_cumprod", np.sqrt(1.0 - ac)),
+            ("log_one_minus_alphas_cumprod", np.log(1.0 - ac)), ("sqrt_recip_alphas_cumprod", np.sqrt(1.0 / ac)),
+            ("sqrt_recipm1_alphas_cumprod", np.sqrt(1.0 / ac - 1)), ("posterior_variance", post_var),
+            ("posterior_log_variance_clipped", np.log(np.maximum(post_var, 1e-20))),
+            ("posterior_mean_coef1", betas * np.sqrt(ac_prev) / (1.0 - ac)),
+            ("posterior_mean_coef2", (1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac)),
+        )
+        for name, val in tables:                      # same 12 fp32 buffers, same order (ddpm.py:329-350)
+            self.register_buffer(name, torch.tensor(val, dtype=torch.float32))
+        self.noise_source = None                      # optional callable(shape, device) -> N(0,1) tensor (parity tests)
+        self._graph = None
+
+    # ---- helpers
+    def _tables(self):
+        return {k: getattr(self, k) for k in ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                                              "posterior_mean_coef1", "posterior_mean_coef2",
+                                              "posterior_log_variance_clipped")}
+
+    def _randn(self, shape, device):
+        if self.noise_source is not None:
+            return self.noise_source(shape, device)
+        return torch.randn(shape, device=device)
+
+    def _is_native(self):
+        return isinstance(self.denoise_fn, Unet)
+
+    # ---- q(x_t | x_0)
+    def q_mean_variance(self, x_start, t):
+        mean = extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start
+        variance = extract(1.0 - self.alphas_cumprod, t, x_start.shape)
+        log_variance = extract(self.log_one_minus_alphas_cumprod, t, x_start.shape)
+        return mean, variance, log_variance
+
+    def q_sample(self, x_start, t, noise=None):
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        _, xt = K.q_sample(x_start.float(), noise.float(), t, self.sqrt_alphas_cumprod,
+                           self.sqrt_one_minus_alphas_cumprod, want_nchw=True)
+        return xt
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
+                - extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = (extract(self.posterior_mean_coef1, t, x_t.shape) * x_start
+                + extract(self.posterior_mean_coef2, t, x_t.shape) * x_t)
+        return mean, extract(self.posterior_variance, t, x_t.shape), extract(self.posterior_log_variance_clipped, t, x_t.shape)
+
+    def p_mean_variance(self, x, t, clip_denoised: bool):
+        x_recon = self.predict_start_from_noise(x, t=t, noise=self.denoise_fn(x, t))
+        if clip_denoised:
+            x_recon.clamp_(-1.0, 1.0)
+        return self.q_posterior(x_start=x_recon, x_t=x, t=t)
+
+    # ---- reverse process
+    @torch.no_grad()
+    def p_sample(self, x, t, clip_denoised=True, repeat_noise=False):
+        """One reverse step (ddpm.py:390-397): UNet + fused posterior update."""
+        x = x.float().contiguous()
+        eps, _ = self.denoise_fn.forward_nhwc(K.nchw_to_nhwc(x), t, record=False)
+        if repeat_noise:
+            z = self._randn((1, *x.shape[1:]), x.device).repeat(x.shape[0], 1, 1, 1)
+        else:
+            z = self._randn(x.shape, x.device)
+        xp, _ = K.p_sample_update(x, eps, z, t, self._tables(), clip=clip_denoised, want_nhwc=False)
+        return xp
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, use_graph: Optional[bool] = None):
+        """x_T ~ N(0, I); T sequential denoise steps (ddpm.py:399-409).  With `use_graph` the
+        denoise iteration is captured once in a hipGraph and replayed T times (device-side t)."""
+        device = self.betas.device
+        from ..runtime.sampler import GraphSampler
+        if use_graph is None:
+            use_graph = self.noise_source is None and os.environ.get("MI_DDPM_GRAPH", "1") == "1"
+        if use_graph:
+            if self._graph is None or self._graph.shape != tuple(shape):
+                self._graph = GraphSampler(self, tuple(shape))
+            return self._graph.run()
+        b = shape[0]
+        img = self._randn(shape, device)
+        for i in reversed(range(self.num_timesteps)):
+            img = self.p_sample(img, torch.full((b,), i, device=device, dtype=torch.long))
+        return img
+
+    @torch.no_grad()
+    def sample(self, batch_size=16):
+        return self.p_sample_loop((batch_size, self.channels, *self.image_size))
+
+    @torch.no_grad()
+    def interpolate(self, x1, x2, t=None, weight=0.5):
+        b, device = x1.shape[0], x1.device
+        t = self.num_timesteps - 1 if t is None else t
+        assert x1.shape == x2.shape
+        tb = torch.full((b,), t, device=device, dtype=torch.long)
+        img = (1 - weight) * self.q_sample(x1, tb) + weight * self.q_sample(x2, tb)
+        for i in reversed(range(0, t)):
+            img = self.p_sample(img, torch.full((b,), i, device=device, dtype=torch.long))
+        return img
+
+    # ---- training objective
+    def p_losses(self, x_start, t, noise=None):
+        """L1/L2 between the noise and the UNet's prediction at x_t (ddpm.py:446-460)."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        net = self.denoise_fn
+        if net._anchor.device != x_start.device:
+            object.__setattr__(net, "_anchor", torch.zeros(1, device=x_start.device, requires_grad=True))
+        anchor = net._anchor if (torch.is_grad_enabled() and net.training) else net._anchor.detach()
+        return _LossFunction.apply(x_start.float().contiguous(), t, noise.float().contiguous(), anchor, self)
+
+    def forward(self, x, *args, **kwargs):
+        b = x.shape[0]
+        t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long()     # t first, then eps (RNG order)
+        return self.p_losses(x, t, *args, **kwargs)
+
+
+# --------------------------------------------------------------------------------------------
+# LightningModule-shaped wrapper
+# --------------------------------------------------------------------------------------------
+class DDPM(BaseModel):
+    """Reference `DDPM` (ddpm.py:469-521): same ctor and hooks; `configure_optimizers` returns the
+    fused flat-buffer Adam (same update rule as torch.optim.Adam)."""
+
+    def __init__(self, datamodule, hidden_dim: int = 64, timesteps: int = 1000, loss_type: str = "l1",
+                 dim_mults: Sequence[int] = (1, 2, 4, 8), lr: float = 0.0002, b1: float = 0.5, b2: float = 0.999,
+                 optim="adam", **kwargs):
+        super().__init__(datamodule)
+        self.save_hyperparameters()
+        self.denoising_model = Unet(dim=hidden_dim, channels=self.channels, dim_mults=tuple(dim_mults))
+        self.diffusion_model = GaussianDiffusion(
+            self.denoising_model, image_size=(self.height, self.width), timesteps=timesteps,
+            loss_type=loss_type, channels=self.channels)
+
+    def training_step(self, batch, batch_idx):
+        imgs, _ = batch
+        loss = self.diffusion_model(imgs)
+        self.log("train_loss/loss", loss)          # logged as a device scalar: no per-step host sync
+        return loss
+
+    def configure_optimizers(self):
+        from ..runtime.optim import FlatAdam
+        hp = self.hparams
+        return FlatAdam(self.denoising_model, lr=hp.lr, betas=(hp.b1, hp.b2))
+
+    def validation_step(self, batch, batch_idx):
+        imgs, labels = batch
+        n = imgs.shape[0]
+        t_last = torch.full((n,), self.hparams.timesteps - 1, device=imgs.device, dtype=torch.long)
+        diffusion_imgs = self.diffusion_model.q_sample(imgs, t=t_last)
+        fake_imgs = self.diffusion_model.sample(64) if batch_idx == 0 else None
+        return ValidationResult(real_image=imgs, fake_image=fake_imgs, others={"diffusion": diffusion_imgs})

@@ -1,0 +1,255 @@
+"""Tensor-level wrappers over the C ABI (include/mi_ddpm.h).
+
+Activations are fp32 NHWC tensors [N, H, W, C] on a HIP device; a channel slice
+``t[..., a:b]`` of a contiguous tensor is a legal activation (pixel stride ld = t.stride(2)).
+Every function launches on torch's current stream and never synchronises.  There is no
+CPU path: a tensor that is not on a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from .lib import MiConvDesc, MiGnDesc, MiWgradDesc, check, load_library
+
+MODE_FP32, MODE_BF16 = 0, 1
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _need_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("libmi_ddpm kernels need tensors on an MI355X (HIP) device; there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32, got {t.dtype}")
+
+
+def ld_of(t: torch.Tensor) -> int:
+    """Pixel stride of an NHWC activation (or row stride of a 2-D [M, C] matrix)."""
+    if t.dim() == 2:
+        assert t.stride(1) == 1
+        return t.stride(0)
+    n, h, w, c = t.shape
+    ld = t.stride(2)
+    assert t.stride(3) == 1 and ld >= c, (t.shape, t.stride())
+    assert (w == 1 or True) and t.stride(1) == w * ld and (n == 1 or t.stride(0) == h * w * ld), (t.shape, t.stride())
+    return ld
+
+
+def new_act(n, h, w, c, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty((n, h, w, c), device=like.device, dtype=torch.float32)
+
+
+# --------------------------------------------------------------------------- conv family
+def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mode, x2=None,
+               bias=None, residual=None, out=None, accumulate=False):
+    """y = conv(x [| x2]) per MiConvDesc.  x: [N,IH,IW,K1], x2: [N,IH,IW,K-K1] or None."""
+    _need_gpu(x)
+    N, IH, IW, K1 = x.shape
+    if x2 is None:
+        K1 = K
+    OH, OW = out_hw
+    if out is None:
+        assert not accumulate
+        out = new_act(N, OH, OW, Nc if Nc % 4 == 0 else (Nc + 3) // 4 * 4, x)
+        if out.shape[3] != Nc:
+            out.zero_()
+            out = out[..., :Nc]
+    d = MiConvDesc(N=N, IH=IH, IW=IW, OH=OH, OW=OW, K=K, Nc=Nc, KH=kh, KW=kw, stride=stride, pad=pad,
+                   transposed=int(transposed), w_kn=int(w_kn), mode=mode, K1=K1, ldx=ld_of(x),
+                   ldx2=ld_of(x2) if x2 is not None else 0, ldy=ld_of(out),
+                   ldr=ld_of(residual) if residual is not None else 0, accumulate=int(accumulate))
+    check(load_library().mi_conv_igemm(C.byref(d), _p(x), _p(x2), _p(w), _p(bias), _p(residual), _p(out), _stream()),
+          "mi_conv_igemm")
+    return out
+
+
+def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_d, mode, P2=None):
+    """dW[tap][i][j] += sum P*Q (see MiWgradDesc).  dW: flat fp32 buffer of kh*kw*Ci*Cj."""
+    _need_gpu(P)
+    N = P.shape[0]
+    I1 = P.shape[3] if P2 is not None else Ci
+    d = MiWgradDesc(N=N, GH=grid_g[0], GW=grid_g[1], DH=grid_d[0], DW=grid_d[1], Ci=Ci, Cj=Cj, KH=kh, KW=kw,
+                    stride=stride, pad=pad, gather_i=int(gather_i), mode=mode, I1=I1, ldp=ld_of(P),
+                    ldp2=ld_of(P2) if P2 is not None else 0, ldq=ld_of(Q))
+    check(load_library().mi_conv_wgrad(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _stream()), "mi_conv_wgrad")
+
+
+def _rows(x):
+    return x.shape[0] * x.shape[1] * x.shape[2] if x.dim() == 4 else x.shape[0]
+
+
+def colsum(x, out):
+    """out[c] += sum over pixels of x[..., c]"""
+    Cc = x.shape[-1]
+    M = _rows(x)
+    check(load_library().mi_colsum(M, Cc, _p(x), ld_of(x), _p(out), _stream()), "mi_colsum")
+
+
+# --------------------------------------------------------------------------- norms
+def gn_mish_fwd(x, gamma, beta, *, groups=8, eps=1e-5, temb=None, residual=None):
+    _need_gpu(x)
+    N, H, W, Cc = x.shape
+    y = new_act(N, H, W, Cc, x)
+    stats = torch.empty((N, groups, 2), device=x.device, dtype=torch.float32)
+    d = MiGnDesc(N=N, HW=H * W, C=Cc, G=groups, eps=eps, ldx=ld_of(x), ldy=ld_of(y),
+                 ldr=ld_of(residual) if residual is not None else 0)
+    check(load_library().mi_gn_mish_fwd(C.byref(d), _p(x), _p(gamma), _p(beta), _p(temb),
+                                        ld_of(temb) if temb is not None else 0, _p(residual), _p(y), _p(stats),
+                                        _stream()), "mi_gn_mish_fwd")
+    return y, stats
+
+
+def gn_mish_bwd(x, stats, gamma, beta, dout, *, groups=8, eps=1e-5, dgamma=None, dbeta=None, dtemb=None, dbias=None):
+    N, H, W, Cc = x.shape
+    dx = new_act(N, H, W, Cc, x)
+    d = MiGnDesc(N=N, HW=H * W, C=Cc, G=groups, eps=eps, ldx=ld_of(x), ldy=0, ldr=0)
+    check(load_library().mi_gn_mish_bwd(C.byref(d), _p(x), _p(stats), _p(gamma), _p(beta), _p(dout), ld_of(dout),
+                                        _p(dx), ld_of(dx), _p(dgamma), _p(dbeta), _p(dtemb),
+                                        ld_of(dtemb) if dtemb is not None else 0, _p(dbias), _stream()),
+          "mi_gn_mish_bwd")
+    return dx
+
+
+def chan_layernorm_fwd(x, g, b, eps=1e-5):
+    _need_gpu(x)
+    N, H, W, Cc = x.shape
+    y = new_act(N, H, W, Cc, x)
+    check(load_library().mi_chan_layernorm_fwd(N * H * W, Cc, _p(x), ld_of(x), _p(g), _p(b), eps, _p(y), ld_of(y),
+                                               _stream()), "mi_chan_layernorm_fwd")
+    return y
+
+
+def chan_layernorm_bwd(x, g, dy, dx, accumulate, dg, db, eps=1e-5):
+    N, H, W, Cc = x.shape
+    check(load_library().mi_chan_layernorm_bwd(N * H * W, Cc, _p(x), ld_of(x), _p(g), eps, _p(dy), ld_of(dy), _p(dx),
+                                               ld_of(dx), int(accumulate), _p(dg), _p(db), _stream()),
+          "mi_chan_layernorm_bwd")
+
+
+# --------------------------------------------------------------------------- attention
+def linattn_fwd(qkv, heads=4):
+    _need_gpu(qkv)
+    N, H, W, C3 = qkv.shape
+    assert C3 == 3 * heads * 32 and qkv.is_contiguous()
+    out = new_act(N, H, W, heads * 32, qkv)
+    ctx = torch.empty((N, heads, 32, 32), device=qkv.device, dtype=torch.float32)
+    kstat = torch.empty((N, heads, 32, 2), device=qkv.device, dtype=torch.float32)
+    check(load_library().mi_linattn_fwd(N, H * W, heads, _p(qkv), _p(out), _p(ctx), _p(kstat), _stream()), "mi_linattn_fwd")
+    return out, ctx, kstat
+
+
+def linattn_bwd(qkv, ctx, kstat, dout, heads=4):
+    N, H, W, C3 = qkv.shape
+    assert dout.is_contiguous()
+    dqkv = torch.empty_like(qkv)
+    check(load_library().mi_linattn_bwd(N, H * W, heads, _p(qkv), _p(ctx), _p(kstat), _p(dout), _p(dqkv), _stream()),
+          "mi_linattn_bwd")
+    return dqkv
+
+
+# --------------------------------------------------------------------------- element-wise
+def time_embed(t, dim):
+    if not t.is_cuda:
+        raise RuntimeError("time_embed needs a GPU tensor")
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty((t.shape[0], dim), device=t.device, dtype=torch.float32)
+    check(load_library().mi_time_embed(t.shape[0], dim, _p(t), _p(out), _stream()), "mi_time_embed")
+    return out
+
+
+def mish_fwd(x):
+    _need_gpu(x)
+    y = torch.empty_like(x)
+    check(load_library().mi_mish_fwd(x.numel(), _p(x), _p(y), _stream()), "mi_mish_fwd")
+    return y
+
+
+def mish_bwd(x, dy):
+    dx = torch.empty_like(x)
+    check(load_library().mi_mish_bwd(x.numel(), _p(x), _p(dy), _p(dx), _stream()), "mi_mish_bwd")
+    return dx
+
+
+def nchw_to_nhwc(x, ld=None):
+    _need_gpu(x)
+    B, Cc, H, W = x.shape
+    ld = ld or (Cc + 3) // 4 * 4
+    x = x.contiguous()
+    y = torch.empty((B, H, W, ld), device=x.device, dtype=torch.float32)
+    check(load_library().mi_nchw_to_nhwc(B, Cc, H * W, _p(x), _p(y), ld, _stream()), "mi_nchw_to_nhwc")
+    return y[..., :Cc]
+
+
+def nhwc_to_nchw(x):
+    B, H, W, Cc = x.shape
+    y = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32)
+    check(load_library().mi_nhwc_to_nchw(B, Cc, H * W, _p(x), ld_of(x), _p(y), _stream()), "mi_nhwc_to_nchw")
+    return y
+
+
+def q_sample(x0, noise, t, sqrt_ac, sqrt_1mac, want_nchw=False):
+    _need_gpu(x0)
+    B, Cc, H, W = x0.shape
+    ld = (Cc + 3) // 4 * 4
+    x0 = x0.contiguous(); noise = noise.contiguous()
+    xt = torch.empty((B, H, W, ld), device=x0.device, dtype=torch.float32)
+    xt_nchw = torch.empty_like(x0) if want_nchw else None
+    check(load_library().mi_q_sample(B, Cc, H * W, _p(x0), _p(noise), _p(t), _p(sqrt_ac), _p(sqrt_1mac), _p(xt), ld,
+                                     _p(xt_nchw), _stream()), "mi_q_sample")
+    return xt[..., :Cc], xt_nchw
+
+
+def eps_loss(pred_nhwc, target_nchw, loss_type=0, want_grad=True, gscale=1.0):
+    B, H, W, Cc = pred_nhwc.shape
+    target_nchw = target_nchw.contiguous()
+    loss = torch.zeros((), device=pred_nhwc.device, dtype=torch.float32)
+    ld = ld_of(pred_nhwc)
+    dpred = torch.empty((B, H, W, ld), device=pred_nhwc.device, dtype=torch.float32) if want_grad else None
+    check(load_library().mi_eps_loss(B, Cc, H * W, _p(pred_nhwc), ld, _p(target_nchw), loss_type, _p(loss), _p(dpred),
+                                     gscale, _stream()), "mi_eps_loss")
+    return loss, (dpred[..., :Cc] if want_grad else None)
+
+
+def p_sample_update(x, eps_nhwc, z, t, tab, clip=True, want_nhwc=True):
+    B, Cc, H, W = x.shape
+    ldo = (Cc + 3) // 4 * 4
+    xp = torch.empty_like(x)
+    xp_nhwc = torch.zeros((B, H, W, ldo), device=x.device, dtype=torch.float32) if want_nhwc else None
+    check(load_library().mi_p_sample_update(
+        B, Cc, H * W, _p(x), _p(eps_nhwc), ld_of(eps_nhwc), _p(z), _p(t), _p(tab["sqrt_recip_alphas_cumprod"]),
+        _p(tab["sqrt_recipm1_alphas_cumprod"]), _p(tab["posterior_mean_coef1"]), _p(tab["posterior_mean_coef2"]),
+        _p(tab["posterior_log_variance_clipped"]), int(clip), _p(xp), _p(xp_nhwc), ldo, _stream()), "mi_p_sample_update")
+    return xp, (xp_nhwc[..., :Cc] if want_nhwc else None)
+
+
+def adam_step(p, g, m, v, lr, b1, b2, eps, step, gscale=1.0):
+    bc1 = 1.0 - b1 ** step
+    bc2 = 1.0 - b2 ** step
+    check(load_library().mi_adam_step(p.numel(), _p(p), _p(g), _p(m), _p(v), lr, b1, b2, eps, bc1, bc2, gscale, _stream()),
+          "mi_adam_step")
+
+
+def axpby(a, x, y, accumulate):
+    """y = a*x (+ y).  x, y: same logical shape; strided channel slices allowed for 4-D."""
+    if x.is_contiguous() and y.is_contiguous():
+        check(load_library().mi_axpby(x.numel(), a, _p(x), int(accumulate), _p(y), _stream()), "mi_axpby")
+    else:
+        Cc = x.shape[-1]
+        M = x.shape[0] * x.shape[1] * x.shape[2] if x.dim() == 4 else x.shape[0]
+        check(load_library().mi_axpby2d(M, Cc, a, _p(x), ld_of(x), int(accumulate), _p(y), ld_of(y), _stream()), "mi_axpby2d")
+
+
+def scale_by_device_scalar(x, s):
+    """x *= s where s is a 0-d/1-element fp32 tensor on the device."""
+    s = s.reshape(1).float()
+    check(load_library().mi_scale_by_device_scalar(_rows(x), x.shape[-1], _p(x), ld_of(x), _p(s), _stream()),
+          "mi_scale_by_device_scalar")

@@ -1,0 +1,93 @@
+"""Loads the gfx950 kernel library and declares its C ABI (include/mi_ddpm.h) for ctypes.
+
+There is no fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_LIB = None
+
+
+def library_path() -> str:
+    return os.environ.get("MI_DDPM_LIB", os.path.join(_PKG_ROOT, "lib", "libmi_ddpm.so"))
+
+
+class MiConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "N", "IH", "IW", "OH", "OW", "K", "Nc", "KH", "KW", "stride", "pad", "transposed", "w_kn", "mode",
+        "K1", "ldx", "ldx2", "ldy", "ldr", "accumulate")]
+
+
+class MiWgradDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "N", "GH", "GW", "DH", "DW", "Ci", "Cj", "KH", "KW", "stride", "pad", "gather_i", "mode", "I1",
+        "ldp", "ldp2", "ldq")]
+
+
+class MiGnDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("G", C.c_int), ("eps", C.c_float),
+                ("ldx", C.c_int), ("ldy", C.c_int), ("ldr", C.c_int)]
+
+
+_P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> argtypes; every function returns int (0 = ok) except the two noted below
+SIGNATURES = {
+    "mi_conv_igemm": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _P],
+    "mi_conv_wgrad": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P],
+    "mi_colsum": [_I, _I, _P, _I, _P, _P],
+    "mi_gn_mish_fwd": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _I, _P, _P, _P, _P],
+    "mi_gn_mish_bwd": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P],
+    "mi_chan_layernorm_fwd": [_I, _I, _P, _I, _P, _P, _F, _P, _I, _P],
+    "mi_chan_layernorm_bwd": [_I, _I, _P, _I, _P, _F, _P, _I, _P, _I, _I, _P, _P, _P],
+    "mi_linattn_fwd": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "mi_linattn_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mi_time_embed": [_I, _I, _P, _P, _P],
+    "mi_mish_fwd": [_Z, _P, _P, _P],
+    "mi_mish_bwd": [_Z, _P, _P, _P, _P],
+    "mi_nchw_to_nhwc": [_I, _I, _I, _P, _P, _I, _P],
+    "mi_nhwc_to_nchw": [_I, _I, _I, _P, _I, _P, _P],
+    "mi_q_sample": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P],
+    "mi_eps_loss": [_I, _I, _I, _P, _I, _P, _I, _P, _P, _F, _P],
+    "mi_p_sample_update": [_I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    "mi_adam_step": [_Z, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P],
+    "mi_axpby": [_Z, _F, _P, _I, _P, _P],
+    "mi_axpby2d": [_I, _I, _F, _P, _I, _I, _P, _I, _P],
+    "mi_scale_by_device_scalar": [_I, _I, _P, _I, _P, _P],
+}
+OTHER = {"mi_abi_version": ([], C.c_int), "mi_last_error": ([], C.c_char_p)}
+ABI_VERSION = 1
+
+
+def load_library():
+    """dlopen libmi_ddpm.so once; raise (never fall back) when it is absent or stale."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `make -C {_PKG_ROOT}` (hipcc --offload-arch=gfx950). "
+            "This package has no CPU or PyTorch fallback.")
+    lib = C.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError -> missing symbol, loudly
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    for name, (argtypes, restype) in OTHER.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if lib.mi_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {lib.mi_abi_version()} != {ABI_VERSION}; rebuild")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load_library().mi_last_error().decode(errors="replace")
+        raise RuntimeError(f"libmi_ddpm {what} failed (rc={rc}): {msg}")

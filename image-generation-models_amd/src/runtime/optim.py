@@ -1,0 +1,43 @@
+"""Fused Adam over the UNet's flat parameter buffer (one kernel launch per step).
+
+Update rule = torch.optim.Adam defaults (eps 1e-8, no weight decay, no amsgrad), which is
+what the reference's configure_optimizers builds (src/models/ddpm.py:502-512)."""
+from __future__ import annotations
+
+import torch
+
+from ..ops import functional as K
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, net, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        self.net = net
+        super().__init__(list(net.parameters()), dict(lr=lr, betas=betas, eps=eps))
+        self.grad_scale = grad_scale
+        self._m = None
+        self._v = None
+        self._step = 0
+
+    def zero_grad(self, set_to_none: bool = False):
+        # backward overwrites the flat gradient buffer (it zeroes it itself); nothing to do.
+        pass
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        p, g = self.net.flat_params, self.net.flat_grads
+        if self._m is None or self._m.device != p.device:
+            self._m = torch.zeros_like(p)
+            self._v = torch.zeros_like(p)
+        grp = self.param_groups[0]
+        self._step += 1
+        K.adam_step(p, g, self._m, self._v, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], self._step,
+                    self.grad_scale)
+        return loss
+
+    def state_dict(self):
+        return {"step": self._step, "m": self._m, "v": self._v, "param_groups": [
+            {k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self._step, self._m, self._v = sd["step"], sd["m"], sd["v"]

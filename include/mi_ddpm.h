@@ -1,0 +1,174 @@
+/*
+ * mi_ddpm.h -- C ABI of the MI355X (gfx950) DDPM hot-path library (libmi_ddpm.so).
+ *
+ * The reference (Victarry/Image-Generation-models) has NO FFI or plugin interface: its
+ * hot path is Python calling stock ATen ops.  This header is
+ * therefore the boundary a maintainer would bind from src/models/ddpm.py (ctypes stub in
+ * INTEGRATION.md); every entry point cites the reference lines it replaces
+ * (paths relative to /root/reference/).
+ *
+ * Contract
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator);
+ *    the library never allocates, frees, retains or synchronises -> hipGraph-capture safe.
+ *  - `stream` is a hipStream_t passed as void*; work is ordered only by that stream.
+ *  - return 0 on success, <0 argument/shape error, >0 a hipError_t; mi_last_error() gives
+ *    the thread-local message.  Nothing throws across the boundary.
+ *  - activations are fp32 NHWC ("pixel-major"): element (n,y,x,c) at ((n*H+y)*W+x)*ld + c,
+ *    ld >= C, ld % 4 == 0, base 16-byte aligned.
+ *  - convolution weights live in tap-major layout  w[ky][kx][Cin][Cout]  (a permuted VIEW of
+ *    the PyTorch [Cout,Cin,kh,kw] / ConvTranspose [Cin,Cout,kh,kw] parameter, see
+ *    image-generation-models_amd/src/models/ddpm.py) so forward, dgrad, wgrad and the
+ *    optimizer all stream the same contiguous buffer with no repack.
+ *  - `mode`: 0 = exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16 MFMA with fp32
+ *    accumulate (v_mfma_f32_32x32x16_bf16; operands rounded to bf16 when staged to LDS).
+ */
+#ifndef MI_DDPM_H
+#define MI_DDPM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ABI_VERSION 1
+#define MI_MODE_FP32 0
+#define MI_MODE_BF16 1
+
+int mi_abi_version(void);
+const char* mi_last_error(void);
+
+/* ---- implicit-GEMM convolution on MFMA ---------------------------------------------
+ * One kernel family for nn.Conv2d k3/k1 (ddpm.py:116,134,151-152,236), stride-2
+ * Downsample (ddpm.py:79), ConvTranspose2d k4 s2 (ddpm.py:70), every data-gradient of
+ * those (aten::convolution_backward) and nn.Linear (ddpm.py:127,190-192; H=W=1).
+ *   y[n,oy,ox,j] (+)= bias[j] + residual[n,oy,ox,j]
+ *                     + sum_{ky,kx,k} src[n,iy,ix,k] * W(ky,kx,k,j)
+ *   transposed=0: iy = oy*stride - pad + ky          (convolution forward)
+ *   transposed=1: iy = (oy + pad - ky)/stride, only where divisible (transposed conv / dgrad)
+ *   src channel k comes from x when k < K1, else from x2 at k-K1 (skip concat ddpm.py:255
+ *   without materialising the cat).
+ *   W(ky,kx,k,j) = w[((ky*KW+kx)*K + k)*Nc + j] if w_kn else w[((ky*KW+kx)*Nc + j)*K + k].
+ */
+typedef struct MiConvDesc {
+    int N;               /* batch */
+    int IH, IW;          /* spatial size of the gathered tensor */
+    int OH, OW;          /* spatial size of the produced tensor */
+    int K;               /* contraction channels */
+    int Nc;              /* produced channels */
+    int KH, KW, stride, pad;
+    int transposed;
+    int w_kn;
+    int mode;
+    int K1;              /* channels taken from x; K1 == K -> single source */
+    int ldx, ldx2, ldy, ldr;
+    int accumulate;      /* y += result instead of y = result */
+} MiConvDesc;
+
+int mi_conv_igemm(const MiConvDesc* d, const float* x, const float* x2, const float* w,
+                  const float* bias, const float* residual, float* y, void* stream);
+
+/* ---- weight gradient (aten::convolution_backward, weight part) -----------------------
+ *   dW[ky][kx][i][j] += sum_{n,y,x} P[n,py,px,i] * Q[n,qy,qx,j]
+ * (y,x) runs over the DH x DW grid of the non-gathered operand; the gathered operand is
+ * read at (y*stride - pad + ky, x*stride - pad + kx) of its GH x GW grid.
+ * gather_i=1: P gathered (Conv2d: P = layer input, Q = grad of output);
+ * gather_i=0: Q gathered (ConvTranspose2d: P = layer input, Q = grad of output).
+ * P channel i comes from P when i < I1 else from P2 at i-I1.  dW is accumulated with
+ * fp32 atomics (split over the pixel axis), so zero it first.
+ */
+typedef struct MiWgradDesc {
+    int N;
+    int GH, GW;          /* gathered operand grid */
+    int DH, DW;          /* direct operand grid (loop grid) */
+    int Ci, Cj;
+    int KH, KW, stride, pad;
+    int gather_i;
+    int mode;
+    int I1;
+    int ldp, ldp2, ldq;
+} MiWgradDesc;
+
+int mi_conv_wgrad(const MiWgradDesc* d, const float* P, const float* P2, const float* Q,
+                  float* dW, void* stream);
+
+/* out[c] += sum_m x[m*ld + c]  (bias gradients) */
+int mi_colsum(int M, int C, const float* x, int ld, float* out, void* stream);
+
+/* ---- GroupNorm(8)+Mish (+time bias, +residual) ---------------------------------------
+ * Block's GroupNorm->Mish (ddpm.py:116,62-64), the time-embedding add `h += mlp(t)`
+ * (ddpm.py:139-140) and ResnetBlock's `h + res_conv(x)` (ddpm.py:143) in one pass:
+ *   y = mish( (x-mean_{n,g}) * rstd_{n,g} * gamma[c] + beta[c] ) + temb[n,c] + residual
+ * stats[n][g] = {mean, rstd} is written for backward.  HW*C/G elements per (n,g).
+ */
+typedef struct MiGnDesc {
+    int N, HW, C, G;
+    float eps;
+    int ldx, ldy, ldr;
+} MiGnDesc;
+
+int mi_gn_mish_fwd(const MiGnDesc* d, const float* x, const float* gamma, const float* beta,
+                   const float* temb, int ldt, const float* residual, float* y, float* stats,
+                   void* stream);
+/* dx = grad wrt x.  dgamma/dbeta/dbias (each [C]) are accumulated atomically; dtemb[n*ldt+c]
+ * is stored (= sum_hw dout) when non-null; dbias (sum_{n,hw} dx, the producing conv's bias
+ * gradient) when non-null.  The residual branch's gradient is dout itself. */
+int mi_gn_mish_bwd(const MiGnDesc* d, const float* x, const float* stats, const float* gamma,
+                   const float* beta, const float* dout, int lddo, float* dx, int lddx,
+                   float* dgamma, float* dbeta, float* dtemb, int ldt, float* dbias,
+                   void* stream);
+
+/* ---- channel LayerNorm (ddpm.py:85-95; eps added to the std) ---------------------------- */
+int mi_chan_layernorm_fwd(int M, int C, const float* x, int ldx, const float* g, const float* b,
+                          float eps, float* y, int ldy, void* stream);
+int mi_chan_layernorm_bwd(int M, int C, const float* x, int ldx, const float* g, float eps,
+                          const float* dy, int lddy, float* dx, int lddx, int accumulate_dx,
+                          float* dg, float* db, void* stream);
+
+/* ---- LinearAttention core (ddpm.py:157-165), heads x 32 channels -------------------------
+ * qkv[b][p][3*heads*32] (q | k | v, head-major inside each), out[b][p][heads*32].
+ * ctx[b][h][32][32] and kstat[b][h][32][2] = {max, sum exp} are saved for backward. */
+int mi_linattn_fwd(int B, int n, int heads, const float* qkv, float* out, float* ctx,
+                   float* kstat, void* stream);
+int mi_linattn_bwd(int B, int n, int heads, const float* qkv, const float* ctx,
+                   const float* kstat, const float* dout, float* dqkv, void* stream);
+
+/* ---- small element-wise pieces ---------------------------------------------------------------- */
+/* SinusoidalPosEmb (ddpm.py:52-59): out[b][dim] = [sin(t f_j) | cos(t f_j)] */
+int mi_time_embed(int B, int dim, const int64_t* t, float* out, void* stream);
+/* Mish on a flat vector (ddpm.py:62-64) and its backward */
+int mi_mish_fwd(size_t n, const float* x, float* y, void* stream);
+int mi_mish_bwd(size_t n, const float* x, const float* dy, float* dx, void* stream);
+/* NCHW <-> NHWC(ld) */
+int mi_nchw_to_nhwc(int B, int C, int HW, const float* x, float* y, int ld, void* stream);
+int mi_nhwc_to_nchw(int B, int C, int HW, const float* x, int ld, float* y, void* stream);
+/* q_sample (ddpm.py:433-444): x_t = a[t] x0 + b[t] eps ; NCHW in, NHWC(ld) out (+NCHW copy if non-null) */
+int mi_q_sample(int B, int C, int HW, const float* x0, const float* noise, const int64_t* t,
+                const float* sqrt_ac, const float* sqrt_1mac, float* xt_nhwc, int ld,
+                float* xt_nchw, void* stream);
+/* loss (ddpm.py:453-456): loss_type 0 = L1 mean, 1 = L2 mean.  pred NHWC(ld), target NCHW.
+ * *loss is accumulated (zero it first); dpred (NHWC, may be null) = d loss / d pred * gscale */
+int mi_eps_loss(int B, int C, int HW, const float* pred, int ld, const float* target, int loss_type,
+                float* loss, float* dpred, float gscale, void* stream);
+/* p_sample posterior update (ddpm.py:359-397), x and z NCHW, eps_hat NHWC(ld);
+ * writes x_{t-1} NCHW and (if non-null) its NHWC(ldo) copy for the next UNet call. */
+int mi_p_sample_update(int B, int C, int HW, const float* x, const float* eps_hat, int ld,
+                       const float* z, const int64_t* t, const float* sqrt_recip_ac,
+                       const float* sqrt_recipm1_ac, const float* coef1, const float* coef2,
+                       const float* logvar, int clip, float* x_prev, float* x_prev_nhwc, int ldo,
+                       void* stream);
+/* Adam (torch.optim.Adam defaults, ddpm.py:507-511) over one flat buffer.
+ * bc1 = 1-b1^step, bc2 = 1-b2^step; grad is multiplied by gscale first (DDP average). */
+int mi_adam_step(size_t n, float* p, const float* g, float* m, float* v, float lr, float b1,
+                 float b2, float eps, float bc1, float bc2, float gscale, void* stream);
+/* y = a*x + (accumulate ? y : 0) */
+int mi_axpby(size_t n, float a, const float* x, int accumulate, float* y, void* stream);
+/* same on M rows of C channels with row strides (gradient accumulation into channel slices) */
+int mi_axpby2d(int M, int C, float a, const float* x, int ldx, int accumulate, float* y, int ldy, void* stream);
+/* x[m*ld + c] *= *scalar (scalar lives on the device: autograd's incoming d(loss), no host sync) */
+int mi_scale_by_device_scalar(int M, int C, float* x, int ld, const float* scalar, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,307 @@
+"""Per-kernel parity: every C-ABI entry point against a float64 CPU evaluation of the same
+reference op (torch CPU = the reference's own arithmetic, ddpm.py line cited per test).
+Tolerances (rel-L2): 2e-5 in exact-fp32 mode, 2e-2 in bf16-MFMA mode (CPU bf16
+autocast of the reference differs from fp64 by 1.6e-2)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import DEV, TOL, conv_w_storage, from_nhwc, max_err, rel_err, to_nhwc_gpu, w_from_storage
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from src.ops import functional
+    return functional
+
+
+def _conv_case(K, mode, N, H, W, Ci, Co, k, s, p, seed=0, bias=True, split=None, residual=False):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)
+    b = torch.randn(Co, generator=g) if bias else None
+    ref = F.conv2d(x.double(), w.double(), b.double() if bias else None, stride=s, padding=p)
+    OH, OW = ref.shape[2], ref.shape[3]
+    r = torch.randn(N, Co, OH, OW, generator=g) if residual else None
+    if residual:
+        ref = ref + r.double()
+    ws = conv_w_storage(w)
+    if split:
+        xa, xb = to_nhwc_gpu(x[:, :split]), to_nhwc_gpu(x[:, split:])
+    else:
+        xa, xb = to_nhwc_gpu(x), None
+    y = K.conv_igemm(xa, ws, kh=k, kw=k, stride=s, pad=p, transposed=False, w_kn=True, K=Ci, Nc=Co, out_hw=(OH, OW),
+                     mode=mode, x2=xb, bias=b.to(DEV) if bias else None,
+                     residual=to_nhwc_gpu(r) if residual else None)
+    torch.cuda.synchronize()
+    return rel_err(from_nhwc(y), ref), (x, w, b, ref, xa, xb, ws)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("cfg", [
+    dict(N=2, H=8, W=8, Ci=32, Co=32, k=3, s=1, p=1),
+    dict(N=2, H=16, W=16, Ci=128, Co=128, k=3, s=1, p=1),
+    dict(N=3, H=8, W=8, Ci=24, Co=40, k=3, s=1, p=1),                 # ragged K and N tiles
+    dict(N=2, H=8, W=8, Ci=3, Co=16, k=3, s=1, p=1),                  # image input, Cin=3
+    dict(N=2, H=8, W=8, Ci=16, Co=3, k=1, s=1, p=0),                  # final conv, Cout=3
+    dict(N=2, H=16, W=16, Ci=64, Co=64, k=3, s=2, p=1),               # Downsample (ddpm.py:79)
+    dict(N=2, H=8, W=8, Ci=64, Co=384, k=1, s=1, p=0, bias=False),    # to_qkv (ddpm.py:151)
+    dict(N=2, H=8, W=8, Ci=64, Co=32, k=3, s=1, p=1, split=32),       # skip concat read in place (ddpm.py:255)
+    dict(N=2, H=8, W=8, Ci=128, Co=64, k=1, s=1, p=0, residual=True), # to_out + Residual (ddpm.py:45,152)
+    dict(N=5, H=7, W=7, Ci=16, Co=16, k=3, s=1, p=1),                 # odd spatial size (MNIST 7x7 level)
+    dict(N=16, H=32, W=32, Ci=128, Co=128, k=3, s=1, p=1),            # 128x128 tiles, many blocks
+])
+def test_conv_forward(K, mode, cfg):
+    err, _ = _conv_case(K, mode, **cfg)
+    assert err < TOL[mode], err
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("cfg", [
+    dict(N=2, H=8, W=8, Ci=32, Co=48, k=3, s=1, p=1),
+    dict(N=2, H=16, W=16, Ci=64, Co=64, k=3, s=2, p=1),
+    dict(N=2, H=8, W=8, Ci=64, Co=24, k=1, s=1, p=0),
+    dict(N=2, H=8, W=8, Ci=16, Co=3, k=1, s=1, p=0),
+    dict(N=4, H=16, W=16, Ci=128, Co=128, k=3, s=1, p=1),
+])
+def test_conv_dgrad_and_wgrad(K, mode, cfg):
+    """aten::convolution_backward (input, weight, bias) for Conv2d."""
+    N, H, W, Ci, Co, k, s, p = (cfg[q] for q in ("N", "H", "W", "Ci", "Co", "k", "s", "p"))
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, Ci, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Co, Ci, k, k, generator=g, dtype=torch.float64) / math.sqrt(Ci * k * k)).requires_grad_(True)
+    b = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, w, b, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    ws = conv_w_storage(w.detach())
+    dyg = to_nhwc_gpu(dy.float())
+    dx = K.conv_igemm(dyg, ws, kh=k, kw=k, stride=s, pad=p, transposed=True, w_kn=False, K=Co, Nc=Ci, out_hw=(H, W), mode=mode)
+    dW = torch.zeros(k * k * Ci * Co, device=DEV)
+    xg = to_nhwc_gpu(x.detach().float())
+    K.conv_wgrad(xg, dyg, dW, kh=k, kw=k, stride=s, pad=p, gather_i=True, Ci=Ci, Cj=Co, grid_g=(H, W),
+                 grid_d=(y.shape[2], y.shape[3]), mode=mode)
+    db = torch.zeros(Co, device=DEV)
+    K.colsum(dyg, db)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dx), x.grad) < TOL[mode]
+    assert rel_err(w_from_storage(dW.view(k, k, Ci, Co)), w.grad) < TOL[mode]
+    assert rel_err(db, b.grad) < 2e-5
+    # accumulate=True adds onto an existing gradient
+    dx2 = K.conv_igemm(dyg, ws, kh=k, kw=k, stride=s, pad=p, transposed=True, w_kn=False, K=Co, Nc=Ci, out_hw=(H, W),
+                       mode=mode, out=dx.clone(), accumulate=True)
+    assert rel_err(from_nhwc(dx2), 2 * x.grad) < TOL[mode]
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("C", [32, 128])
+def test_conv_transpose_all(K, mode, C):
+    """ConvTranspose2d(C, C, 4, 2, 1) (ddpm.py:70): forward, dgrad, wgrad."""
+    g = torch.Generator().manual_seed(5)
+    N, H = 2, 8
+    x = torch.randn(N, C, H, H, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(C, C, 4, 4, generator=g, dtype=torch.float64) / math.sqrt(C * 4)).requires_grad_(True)
+    b = torch.randn(C, generator=g, dtype=torch.float64)
+    y = F.conv_transpose2d(x, w, b, stride=2, padding=1)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    ws = conv_w_storage(w.detach(), transposed=True)
+    xg, dyg = to_nhwc_gpu(x.detach().float()), to_nhwc_gpu(dy.float())
+    yg = K.conv_igemm(xg, ws, kh=4, kw=4, stride=2, pad=1, transposed=True, w_kn=True, K=C, Nc=C, out_hw=(2 * H, 2 * H),
+                      mode=mode, bias=b.float().to(DEV))
+    dx = K.conv_igemm(dyg, ws, kh=4, kw=4, stride=2, pad=1, transposed=False, w_kn=False, K=C, Nc=C, out_hw=(H, H), mode=mode)
+    dW = torch.zeros(16 * C * C, device=DEV)
+    K.conv_wgrad(xg, dyg, dW, kh=4, kw=4, stride=2, pad=1, gather_i=False, Ci=C, Cj=C, grid_g=(2 * H, 2 * H),
+                 grid_d=(H, H), mode=mode)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(yg), y) < TOL[mode]
+    assert rel_err(from_nhwc(dx), x.grad) < TOL[mode]
+    assert rel_err(w_from_storage(dW.view(4, 4, C, C), transposed=True), w.grad) < TOL[mode]
+
+
+def test_wgrad_two_sources(K):
+    g = torch.Generator().manual_seed(6)
+    N, H, C1, C2, Co = 2, 8, 32, 16, 24
+    x = torch.randn(N, C1 + C2, H, H, generator=g, dtype=torch.float64)
+    w = torch.zeros(Co, C1 + C2, 3, 3, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(N, Co, H, H, generator=g, dtype=torch.float64)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    dW = torch.zeros(9 * (C1 + C2) * Co, device=DEV)
+    K.conv_wgrad(to_nhwc_gpu(x[:, :C1].float()), to_nhwc_gpu(dy.float()), dW, kh=3, kw=3, stride=1, pad=1, gather_i=True,
+                 Ci=C1 + C2, Cj=Co, grid_g=(H, H), grid_d=(H, H), mode=0, P2=to_nhwc_gpu(x[:, C1:].float()))
+    torch.cuda.synchronize()
+    assert rel_err(w_from_storage(dW.view(3, 3, C1 + C2, Co)), w.grad) < 2e-5
+
+
+def test_linear_via_igemm(K):
+    """nn.Linear (ddpm.py:127,190-192) as a 1x1 'conv' over a 1x1 image, weights [out,in]."""
+    g = torch.Generator().manual_seed(7)
+    B, I, O = 6, 32, 80
+    x = torch.randn(B, I, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(O, I, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(O, generator=g, dtype=torch.float64)
+    y = F.linear(x, w, b)
+    dy = torch.randn(B, O, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    xg, wg, dyg = x.detach().float().to(DEV), w.detach().float().to(DEV), dy.float().to(DEV)
+    yg = K.conv_igemm(xg.view(B, 1, 1, I), wg, kh=1, kw=1, stride=1, pad=0, transposed=False, w_kn=False, K=I, Nc=O,
+                      out_hw=(1, 1), mode=0, bias=b.float().to(DEV)).view(B, O)
+    dxg = K.conv_igemm(dyg.view(B, 1, 1, O), wg, kh=1, kw=1, stride=1, pad=0, transposed=False, w_kn=True, K=O, Nc=I,
+                       out_hw=(1, 1), mode=0).view(B, I)
+    dW = torch.zeros(O * I, device=DEV)
+    K.conv_wgrad(dyg.view(B, 1, 1, O), xg.view(B, 1, 1, I), dW, kh=1, kw=1, stride=1, pad=0, gather_i=True, Ci=O, Cj=I,
+                 grid_g=(1, 1), grid_d=(1, 1), mode=0)
+    torch.cuda.synchronize()
+    assert rel_err(yg, y) < 2e-5 and rel_err(dxg, x.grad) < 2e-5 and rel_err(dW.view(O, I), w.grad) < 2e-5
+
+
+def _mish64(x):
+    return x * torch.tanh(F.softplus(x))
+
+
+@pytest.mark.parametrize("cfg", [(2, 8, 8, 8), (2, 8, 8, 16), (3, 16, 16, 32), (2, 32, 32, 128), (2, 8, 8, 512),
+                                 (2, 7, 7, 64), (1, 64, 64, 64), (2, 16, 16, 1024)])
+def test_gn_mish_fwd_bwd(K, cfg):
+    """Block's GroupNorm(8)+Mish (ddpm.py:116), + time bias (ddpm.py:140), + residual (ddpm.py:143)."""
+    N, H, W, C = cfg
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(N, C, H, W, generator=g, dtype=torch.float64) * 2 + 0.5).requires_grad_(True)
+    gamma = (torch.randn(C, generator=g, dtype=torch.float64) + 1).requires_grad_(True)
+    beta = torch.randn(C, generator=g, dtype=torch.float64).requires_grad_(True)
+    temb = torch.randn(N, C, generator=g, dtype=torch.float64).requires_grad_(True)
+    res = torch.randn(N, C, H, W, generator=g, dtype=torch.float64)
+    y = _mish64(F.group_norm(x, 8, gamma, beta, eps=1e-5)) + temb[:, :, None, None] + res
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    xg = to_nhwc_gpu(x.detach().float())
+    ga, be = gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+    yg, st = K.gn_mish_fwd(xg, ga, be, temb=temb.detach().float().to(DEV), residual=to_nhwc_gpu(res.float()))
+    dga, dbe, dbias = (torch.zeros(C, device=DEV) for _ in range(3))
+    dtemb = torch.zeros(N, C, device=DEV)
+    dx = K.gn_mish_bwd(xg, st, ga, be, to_nhwc_gpu(dy.float()), dgamma=dga, dbeta=dbe, dtemb=dtemb, dbias=dbias)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(yg), y) < 1e-5
+    assert rel_err(from_nhwc(dx), x.grad) < 5e-5
+    assert rel_err(dga, gamma.grad) < 5e-5 and rel_err(dbe, beta.grad) < 5e-5
+    assert rel_err(dtemb, temb.grad) < 5e-5
+    assert max_err(dbias, x.grad.sum((0, 2, 3))) < 1e-3 * float(x.grad.abs().sum((0, 2, 3)).max())
+
+
+def test_mish_edges(K, golden_dir):
+    """Mish KATs captured from the reference incl. the softplus threshold at 20 (ddpm.py:62-64)."""
+    import os
+    g = dict(np.load(os.path.join(golden_dir, "leaf_kats.npz")))
+    x = torch.from_numpy(g["mish_x"])
+    y = K.mish_fwd(x.to(DEV))
+    ref = torch.from_numpy(g["mish_y"])
+    assert torch.allclose(y.cpu(), ref, rtol=2e-6, atol=1e-12)
+    xd = x.double().requires_grad_(True)
+    _mish64(xd).sum().backward()
+    dx = K.mish_bwd(x.to(DEV), torch.ones_like(x).to(DEV))
+    assert torch.allclose(dx.cpu().double(), xd.grad, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("cfg", [(2, 4, 4, 16), (2, 8, 8, 128), (3, 7, 7, 256), (2, 8, 8, 512), (1, 4, 4, 1024)])
+def test_chan_layernorm(K, cfg):
+    """LayerNorm over channels with eps added to the std (ddpm.py:92-95)."""
+    N, H, W, C = cfg
+    g = torch.Generator().manual_seed(13)
+    x = (torch.randn(N, C, H, W, generator=g, dtype=torch.float64) * 1.7 - 0.3).requires_grad_(True)
+    gg = (torch.randn(1, C, 1, 1, generator=g, dtype=torch.float64) + 1).requires_grad_(True)
+    bb = torch.randn(1, C, 1, 1, generator=g, dtype=torch.float64).requires_grad_(True)
+    std = torch.var(x, dim=1, unbiased=False, keepdim=True).sqrt()
+    y = (x - x.mean(1, keepdim=True)) / (std + 1e-5) * gg + bb
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    xg = to_nhwc_gpu(x.detach().float())
+    g_, b_ = gg.detach().float().reshape(-1).to(DEV), bb.detach().float().reshape(-1).to(DEV)
+    yg = K.chan_layernorm_fwd(xg, g_, b_)
+    dx = torch.empty_like(xg.contiguous())
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    K.chan_layernorm_bwd(xg, g_, to_nhwc_gpu(dy.float()), dx, False, dg, db)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(yg), y) < 1e-5
+    assert rel_err(from_nhwc(dx), x.grad) < 5e-5
+    assert rel_err(dg, gg.grad.reshape(-1)) < 5e-5 and rel_err(db, bb.grad.reshape(-1)) < 5e-5
+
+
+@pytest.mark.parametrize("cfg", [(2, 4, 4), (2, 8, 8), (3, 7, 7), (2, 32, 32), (1, 64, 64)])
+def test_linear_attention_core(K, cfg):
+    """softmax over pixels of k, ctx = k v^T, out = ctx^T q (ddpm.py:157-165)."""
+    N, H, W = cfg
+    n, heads = H * W, 4
+    g = torch.Generator().manual_seed(17)
+    qkv = (torch.randn(N, 384, H, W, generator=g, dtype=torch.float64) * 1.5).requires_grad_(True)
+    q, k, v = qkv.reshape(N, 3, heads, 32, n).unbind(1)
+    ks = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", ks, v)
+    out = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(N, 128, H, W)
+    dout = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    out.backward(dout)
+    qg = to_nhwc_gpu(qkv.detach().float()).contiguous()
+    og, cg, sg = K.linattn_fwd(qg, heads)
+    dq = K.linattn_bwd(qg, cg, sg, to_nhwc_gpu(dout.float()).contiguous(), heads)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(og), out) < 1e-5
+    assert rel_err(cg, ctx) < 1e-5
+    assert rel_err(from_nhwc(dq), qkv.grad) < 5e-5
+
+
+def test_time_embed_and_layouts(K, golden_dir):
+    import os
+    g = dict(np.load(os.path.join(golden_dir, "leaf_kats.npz")))
+    for d in (8, 32, 128):
+        t = torch.from_numpy(g[f"posemb{d}_t"]).to(DEV)
+        y = K.time_embed(t, d).cpu()
+        assert torch.allclose(y, torch.from_numpy(g[f"posemb{d}_y"]), atol=2e-4, rtol=0)   # |arg| up to 999 rad
+    x = torch.randn(3, 3, 5, 7)
+    xh = K.nchw_to_nhwc(x.to(DEV))
+    assert xh.shape == (3, 5, 7, 3) and xh.stride(2) == 4
+    assert torch.equal(K.nhwc_to_nchw(xh).cpu(), x)
+
+
+def test_diffusion_elementwise(K, golden_dir):
+    """q_sample (ddpm.py:441-444), L1/L2 loss (:453-456), posterior update (:359-397), Adam."""
+    from oracle import ddpm_oracle as O
+    tab = O.schedule_tables(1000)
+    tg = {k: v.to(DEV) for k, v in tab.items()}
+    g = torch.Generator().manual_seed(19)
+    B = 5
+    x0 = torch.rand(B, 3, 8, 8, generator=g) * 2 - 1
+    noise = torch.randn(B, 3, 8, 8, generator=g)
+    t = torch.tensor([0, 1, 500, 998, 999])
+    xt_ref = O.q_sample(tab, x0, t, noise)
+    xt_nhwc, xt_nchw = K.q_sample(x0.to(DEV), noise.to(DEV), t.to(DEV), tg["sqrt_alphas_cumprod"],
+                                  tg["sqrt_one_minus_alphas_cumprod"], want_nchw=True)
+    assert torch.allclose(xt_nchw.cpu(), xt_ref, atol=1e-6) and torch.allclose(from_nhwc(xt_nhwc), xt_ref, atol=1e-6)
+    pred = torch.randn(B, 3, 8, 8, generator=g)
+    pred[0, 0, 0, 0] = noise[0, 0, 0, 0]                      # a tie: sign(0) = 0
+    for lt, name in ((0, "l1"), (1, "l2")):
+        pr = pred.clone().requires_grad_(True)
+        ref = (noise - pr).abs().mean() if lt == 0 else F.mse_loss(noise, pr)
+        ref.backward()
+        loss, dpred = K.eps_loss(to_nhwc_gpu(pred), noise.to(DEV), lt)
+        assert abs(float(loss) - float(ref)) < 1e-6
+        assert torch.allclose(from_nhwc(dpred), pr.grad, atol=1e-9)
+    z = torch.randn(B, 3, 8, 8, generator=g)
+    xp_ref = O.p_sample_update(tab, xt_ref, t, pred, z)
+    xp, xp_nhwc = K.p_sample_update(xt_ref.to(DEV), to_nhwc_gpu(pred), z.to(DEV), t.to(DEV), tg)
+    assert torch.allclose(xp.cpu(), xp_ref, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(from_nhwc(xp_nhwc), xp_ref, atol=2e-5, rtol=1e-5)
+    # Adam: 3 steps against torch.optim.Adam
+    p = torch.randn(1003, generator=g)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3, betas=(0.9, 0.999))
+    pg, m, v = torch.zeros(1004, device=DEV), torch.zeros(1004, device=DEV), torch.zeros(1004, device=DEV)
+    pg[:1003] = p.to(DEV)
+    for step in range(1, 4):
+        gr = torch.randn(1003, generator=g)
+        pr.grad = gr.clone(); opt.step()
+        gg = torch.zeros(1004, device=DEV); gg[:1003] = gr.to(DEV)
+        K.adam_step(pg[:1003], gg[:1003], m[:1003], v[:1003], 1e-3, 0.9, 0.999, 1e-8, step)
+    assert torch.allclose(pg[:1003].cpu(), pr.detach(), atol=1e-6)
