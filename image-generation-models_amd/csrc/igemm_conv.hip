@@ -317,3 +317,17 @@ extern "C" int mi_conv_igemm(const MiConvDesc* d, const float* x, const float* x
     MI_LAUNCH_CHECK();
     return 0;
 }
+
+// Which tile instantiation mi_conv_igemm picks for a descriptor (profiling attribution only).
+extern "C" int mi_conv_igemm_tile(const MiConvDesc* d, int* bm, int* bn) {
+    MI_REQUIRE(d && bm && bn, "null argument");
+    int classes = 1, OHc = d->OH, OWc = d->OW;
+    if (d->transposed && d->stride > 1) { classes = d->stride * d->stride; OHc /= d->stride; OWc /= d->stride; }
+    int Mc = d->N * OHc * OWc;
+    long tiles128 = (long)((Mc + 127) / 128) * ((d->Nc + 127) / 128) * classes;
+    bool bn64 = d->Nc <= 64;
+    bool bm64 = tiles128 < 384 || Mc <= 64;
+    if (bn64 == false && bm64 && (long)((Mc + 63) / 64) * ((d->Nc + 127) / 128) * classes < 384) bn64 = true;
+    *bm = bm64 ? 64 : 128; *bn = bn64 ? 64 : 128;
+    return 0;
+}

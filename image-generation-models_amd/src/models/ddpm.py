@@ -154,6 +154,20 @@ class _Arch:
             off = (off + 63) // 64 * 64
             e.offset = off; off += e.numel
         self.flat_numel = (off + 63) // 64 * 64
+        # flat-buffer range owned by each backward record (for bucketed gradient all-reduce)
+        def span(prefixes):
+            es = [e for e in rest if any(e.key.startswith(p) for p in prefixes)]
+            return (min(e.offset for e in es), max(e.offset + e.numel for e in es))
+        for rec in self.res_blocks:
+            rec["range"] = span([rec["pre"] + "block", rec["pre"] + "res_conv"])
+        for lvl in self.downs + self.ups:
+            lvl["attn"]["range"] = span([lvl["attn"]["pre"]])
+            for kind in ("down", "up"):
+                if lvl.get(kind):
+                    lvl[kind]["range"] = span([lvl[kind]["pre"]])
+        self.mid_attn["range"] = span([self.mid_attn["pre"]])
+        self.final_range = span(["final_conv."])
+        self.time_range = (0, span(["time_mlp."])[1])
         col = 0
         for blk, e in zip(self.res_blocks, mlp_w):
             assert e.key == blk["pre"] + "mlp.1.weight"
@@ -229,6 +243,7 @@ class Unet(nn.Module):
         object.__setattr__(self, "_arch", arch)
         self.compute_mode = os.environ.get("MI_DDPM_MODE", "fp32")
         self.accumulate_grads = False
+        self.grad_ready_hook = None        # callable(lo, hi): flat_grads[lo:hi) is final (set by the DDP reducer)
 
         flat = torch.zeros(arch.flat_numel)
         # default torch init drawn in the reference's construction order => same seeded weights
@@ -505,11 +520,14 @@ class Unet(nn.Module):
             buf, acc = G.target(inp)
             K.chan_layernorm_bwd(inp, sv[pre + "fn.norm.g"], dln, buf, acc, gv[pre + "fn.norm.g"], gv[pre + "fn.norm.b"])
 
+        hook = self.grad_ready_hook
         dx_in = None
         for rec in reversed(tape):
             kind = rec[0]
             if kind == "input":
                 continue
+            if hook is not None:
+                rng = (A.final_range if kind == "final" else A.time_range if kind == "time" else rec[1]["range"])
             if kind == "final":
                 _, h, cF, stF, hF, eps = rec
                 conv_bwd(d_eps, hF, "final_conv.1.", 1)
@@ -550,6 +568,8 @@ class Unet(nn.Module):
                 da1 = lin_bwd(dtemb, a1, gv["time_mlp.3.weight"], gv["time_mlp.3.bias"], sv["time_mlp.3.weight"])
                 dt1 = K.mish_bwd(t1, da1)
                 lin_bwd(dt1, te, gv["time_mlp.1.weight"], gv["time_mlp.1.bias"], sv["time_mlp.1.weight"], want_dx=False)
+            if hook is not None:
+                hook(*rng)
         if need_dx:
             dx_in = K.nhwc_to_nchw(G.take(x_in))
         return dx_in

@@ -15,6 +15,7 @@ import torch
 from .lib import MiConvDesc, MiGnDesc, MiWgradDesc, check, load_library
 
 MODE_FP32, MODE_BF16 = 0, 1
+PROBE = None      # bench.py sets this to a list to collect (kernel symbol, algorithmic FLOPs, start, end) per conv launch
 
 
 def _stream() -> C.c_void_p:
@@ -67,8 +68,17 @@ def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mo
                    transposed=int(transposed), w_kn=int(w_kn), mode=mode, K1=K1, ldx=ld_of(x),
                    ldx2=ld_of(x2) if x2 is not None else 0, ldy=ld_of(out),
                    ldr=ld_of(residual) if residual is not None else 0, accumulate=int(accumulate))
+    if PROBE is not None:
+        bm, bn = C.c_int(), C.c_int()
+        load_library().mi_conv_igemm_tile(C.byref(d), C.byref(bm), C.byref(bn))
+        flops = 2.0 * N * OH * OW * Nc * K * (kh * kw if not (transposed and stride > 1) else kh * kw / (stride * stride))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(load_library().mi_conv_igemm(C.byref(d), _p(x), _p(x2), _p(w), _p(bias), _p(residual), _p(out), _stream()),
           "mi_conv_igemm")
+    if PROBE is not None:
+        e1.record()
+        PROBE.append((f"igemm_kernel<{mode},{bm.value},{bn.value}>", flops, e0, e1))
     return out
 
 

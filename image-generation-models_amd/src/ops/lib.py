@@ -37,6 +37,7 @@ _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # name -> argtypes; every function returns int (0 = ok) except the two noted below
 SIGNATURES = {
     "mi_conv_igemm": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _P],
+    "mi_conv_igemm_tile": [C.POINTER(MiConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "mi_conv_wgrad": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P],
     "mi_colsum": [_I, _I, _P, _I, _P, _P],
     "mi_gn_mish_fwd": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _I, _P, _P, _P, _P],
@@ -72,6 +73,9 @@ def load_library():
         raise RuntimeError(
             f"{path} not found: build it with `make -C {_PKG_ROOT}` (hipcc --offload-arch=gfx950). "
             "This package has no CPU or PyTorch fallback.")
+    # PyTorch bundles its own libamdhip64; import it first so this library binds to the SAME HIP
+    # runtime (same SONAME -> the loader reuses it) and stream handles are interchangeable.
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError -> missing symbol, loudly

@@ -1,0 +1,76 @@
+"""Data-parallel gradient averaging over the UNet's flat gradient buffer.
+
+The reference has no distributed code; multi-GPU exists only through Lightning's DDP wrapper
+(SURVEY.md 2d): one process per GPU, per-rank batch fixed, gradients all-reduced (SUM) and
+divided by world size every step.  Here the gradients already live in ONE flat fp32 buffer in
+layer order, and backward finalises it from the back (final conv first, time MLP last), so the
+reducer simply all-reduces contiguous slices of that buffer as they become final -- RCCL
+(`nccl` backend) runs them on its own stream while the remaining backward kernels execute.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU), so buckets are large (default 32 MB,
+~4 per step for the 118 MB cfg-2 gradient) to stay bandwidth- rather than latency-bound.
+The division by world size is folded into the fused Adam kernel (gscale).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class FlatGradReducer:
+    def __init__(self, flat_grads: torch.Tensor, bucket_bytes: int = 32 << 20, group=None):
+        self.flat = flat_grads
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._works: List = []
+        self._lo: Optional[int] = None
+        self._hi: Optional[int] = None
+        self._covered = 0
+        self.launched: List[tuple] = []          # (lo, hi) of every all-reduce of the current step
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def begin(self):
+        self._works.clear(); self.launched.clear()
+        self._lo = self._hi = None
+        self._covered = 0
+
+    def _launch(self):
+        lo, hi = self._lo, self._hi
+        self._lo = self._hi = None
+        if lo is None or hi <= lo:
+            return
+        self.launched.append((lo, hi))
+        if self.world > 1:
+            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def range_ready(self, lo: int, hi: int):
+        """Gradients in flat[lo:hi) are final.  Called in descending address order by backward."""
+        if self._lo is None:
+            self._lo, self._hi = lo, hi
+        else:
+            if hi > self._lo and lo < self._lo:       # overlapping/adjacent below: extend downwards
+                pass
+            self._lo = min(self._lo, lo)
+            self._hi = max(self._hi, hi)
+        if self._hi - self._lo >= self.bucket_elems:
+            self._launch()
+
+    def finish(self):
+        """Flush the last bucket (always extended to offset 0) and make the current stream wait."""
+        if self._lo is not None:
+            self._lo = 0
+            self._launch()
+        for w in self._works:
+            w.wait()
+        self._works.clear()
+
+
+def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, group=None):
+    """DDP construction-time parameter broadcast: one collective over the flat buffer."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_params, src=src, group=group)

@@ -68,6 +68,9 @@ typedef struct MiConvDesc {
 int mi_conv_igemm(const MiConvDesc* d, const float* x, const float* x2, const float* w,
                   const float* bias, const float* residual, float* y, void* stream);
 
+/* tile instantiation mi_conv_igemm will launch for d (BM x BN); used to attribute profiles */
+int mi_conv_igemm_tile(const MiConvDesc* d, int* bm, int* bn);
+
 /* ---- weight gradient (aten::convolution_backward, weight part) -----------------------
  *   dW[ky][kx][i][j] += sum_{n,y,x} P[n,py,px,i] * Q[n,qy,qx,j]
  * (y,x) runs over the DH x DW grid of the non-gathered operand; the gathered operand is
