@@ -259,6 +259,9 @@ class Unet(nn.Module):
                 e.logical_view(flat).fill_(1.0)
         object.__setattr__(self, "_flat", flat)
         object.__setattr__(self, "_gflat", None)
+        object.__setattr__(self, "_dirty", 0)
+        object.__setattr__(self, "_shadow", None)
+        object.__setattr__(self, "_shadow_key", None)
         object.__setattr__(self, "_anchor", torch.zeros(1, requires_grad=True))
         # module tree in the reference's registration order (time_mlp, downs, ups, mid_*, final_conv)
         self._plist: List[Tuple[_Entry, nn.Parameter]] = []
@@ -282,6 +285,8 @@ class Unet(nn.Module):
             p.data = e.logical_view(flat)
             sv[e.key] = e.storage_view(flat)
         object.__setattr__(self, "_sv", sv)
+        object.__setattr__(self, "_offs", {e.key: e.offset for e, _ in self._plist})
+        object.__setattr__(self, "_shadow_key", None)
         g = self._gflat
         if g is not None and (g.device != flat.device or g.dtype != flat.dtype):
             object.__setattr__(self, "_gflat", None)
@@ -299,6 +304,34 @@ class Unet(nn.Module):
     @property
     def flat_params(self) -> torch.Tensor:
         return self._flat
+
+    def mark_params_dirty(self):
+        """Tell the UNet its flat buffer was written behind torch's back (fused Adam, RCCL broadcast)."""
+        object.__setattr__(self, "_dirty", self._dirty + 1)
+
+    def _shadows(self):
+        """bf16 copies of every conv weight for the bf16-MFMA kernels: wd = master layout
+        [tap][Cin][Cout] (dgrad operand), wf = [tap][Cout][Cin] (forward operand).  Rebuilt by one
+        kernel launch whenever the fp32 master buffer changed."""
+        flat = self._flat
+        key = (flat.data_ptr(), flat._version, self._dirty)
+        if self._shadow_key != key:
+            if self._shadow is None or self._shadow[0].device != flat.device:
+                ents = [e for e in self._arch.entries if e.layout in ("conv", "convT")]
+                rec = np.zeros(len(ents), dtype=np.dtype([("off", "<i8"), ("taps", "<i4"), ("ci", "<i4"), ("co", "<i4"), ("tile0", "<i4")]))
+                tile = 0
+                for i, e in enumerate(ents):
+                    kh, kw, ci, co = e.storage_view(flat).shape
+                    rec[i] = (e.offset, kh * kw, ci, co, tile)
+                    tile += kh * kw * ((ci + 31) // 32) * ((co + 31) // 32)
+                table = torch.from_numpy(rec.view(np.uint8).copy()).to(flat.device)
+                wd = torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16)
+                wf = torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16)
+                object.__setattr__(self, "_shadow", (wd, wf, table, len(ents), tile))
+            wd, wf, table, nent, tiles = self._shadow
+            K.pack_weights_bf16(table, nent, tiles, flat, wd, wf)
+            object.__setattr__(self, "_shadow_key", key)
+        return self._shadow[0], self._shadow[1]
 
     @property
     def flat_grads(self) -> torch.Tensor:
@@ -367,9 +400,18 @@ class Unet(nn.Module):
         if record:
             tape.append(("time", te, t1, a1, temb, mt))
 
+        if mode == K.MODE_BF16:
+            wd_sh, wf_sh = self._shadows()
+        offs = self._offs
+
         def conv(inp, pre, k, stride=1, pad=0, x2=None, residual=None, transposed_conv=False, bias=True):
             w = sv[pre + "weight"]
             kh, kw, ci, co = w.shape
+            if mode == K.MODE_BF16 and k == 3 and stride == 1 and not transposed_conv:
+                y = K.conv3x3_bf16w(inp, wf_sh[offs[pre + "weight"]:], K=ci, Nc=co, flip=False, x2=x2,
+                                    bias=sv[pre + "bias"] if bias else None, residual=residual)
+                if y is not None:
+                    return y
             ih, iw = inp.shape[1], inp.shape[2]
             if transposed_conv:
                 oh, ow = ih * stride, iw * stride
@@ -445,6 +487,9 @@ class Unet(nn.Module):
         if not self.accumulate_grads:
             gflat.zero_()                                  # wgrad / norm kernels accumulate atomically
         gv = self._gv
+        offs = self._offs
+        if mode == K.MODE_BF16:
+            wd_sh, wf_sh = self._shadows()
         G = _GradMap()
         x_in = tape[-1][1]
         B = x_in.shape[0]
@@ -466,8 +511,12 @@ class Unet(nn.Module):
                 K.colsum(dy, gv[pre + "bias"])
             if not want_dx:
                 return
+            fast = mode == K.MODE_BF16 and k == 3 and stride == 1 and not transposed_conv
             if x2 is None:
                 buf, acc = G.target(inp)
+                if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, out=buf,
+                                            accumulate=acc) is not None:
+                    return
                 K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=not transposed_conv, w_kn=False,
                              K=co, Nc=ci, out_hw=(ih, iw), mode=mode, out=buf, accumulate=acc)
             else:
@@ -477,6 +526,9 @@ class Unet(nn.Module):
                 if cat is None:
                     cat = torch.empty((B, ih, iw, ci), device=dy.device, dtype=torch.float32)
                     G._g[("cat", id(inp))] = cat
+                if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, out=cat,
+                                            accumulate=acc) is not None:
+                    return
                 K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=True, w_kn=False,
                              K=co, Nc=ci, out_hw=(ih, iw), mode=mode, out=cat, accumulate=acc)
 

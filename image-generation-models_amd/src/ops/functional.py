@@ -82,6 +82,39 @@ def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mo
     return out
 
 
+def conv3x3_bf16w(x, wsh, *, K, Nc, flip, x2=None, bias=None, residual=None, out=None, accumulate=False):
+    """3x3/s1/p1 conv (flip=False) or its data gradient (flip=True) through the halo-tile kernel.
+    wsh: bf16 weights [3][3][Nc][K].  Returns None when the shape is not supported."""
+    _need_gpu(x)
+    N, H, W, K1 = x.shape
+    if x2 is None:
+        K1 = K
+    d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=int(flip),
+                   w_kn=0, mode=MODE_BF16, K1=K1, ldx=ld_of(x), ldx2=ld_of(x2) if x2 is not None else 0, ldy=0,
+                   ldr=ld_of(residual) if residual is not None else 0, accumulate=int(accumulate))
+    lib = load_library()
+    if not lib.mi_conv3x3_bf16w_supported(C.byref(d)):
+        return None
+    if out is None:
+        assert not accumulate
+        out = new_act(N, H, W, Nc, x)
+    d.ldy = ld_of(out)
+    if PROBE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mi_conv3x3_bf16w(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _stream()),
+          "mi_conv3x3_bf16w")
+    if PROBE is not None:
+        e1.record()
+        PROBE.append(("conv3x3_halo_kernel", 2.0 * N * H * W * Nc * K * 9, e0, e1))
+    return out
+
+
+def pack_weights_bf16(table_dev, nent, total_tiles, master, wd, wf):
+    check(load_library().mi_pack_weights_bf16(nent, _p(table_dev), total_tiles, _p(master), _p(wd), _p(wf), _stream()),
+          "mi_pack_weights_bf16")
+
+
 def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_d, mode, P2=None):
     """dW[tap][i][j] += sum P*Q (see MiWgradDesc).  dW: flat fp32 buffer of kh*kw*Ci*Cj."""
     _need_gpu(P)

@@ -73,4 +73,4 @@ class FlatGradReducer:
 def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, group=None):
     """DDP construction-time parameter broadcast: one collective over the flat buffer."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.broadcast(flat_params, src=src, group=group)
+        dist.broadcast(flat_params, src=src, group=group)   # in-place torch op: bumps flat._version for the bf16 shadows

@@ -33,6 +33,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._step += 1
         K.adam_step(p, g, self._m, self._v, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], self._step,
                     self.grad_scale)
+        self.net.mark_params_dirty()
         return loss
 
     def state_dict(self):

@@ -71,6 +71,22 @@ int mi_conv_igemm(const MiConvDesc* d, const float* x, const float* x2, const fl
 /* tile instantiation mi_conv_igemm will launch for d (BM x BN); used to attribute profiles */
 int mi_conv_igemm_tile(const MiConvDesc* d, int* bm, int* bn);
 
+/* ---- 3x3 / stride 1 / pad 1 convolution with an LDS-staged halo tile (bf16 MFMA only) -------
+ * Same contract as mi_conv_igemm for the Block conv (ddpm.py:116) and its data gradient
+ * (d->transposed = 1 selects the flipped-tap form), but activations are staged once per
+ * 9 taps and weights come from a bf16 copy laid out  w[ky][kx][Nc][K]  (k contiguous), made by
+ * mi_pack_weights_bf16.  Returns <0 when the descriptor is not supported
+ * (check with mi_conv3x3_bf16w_supported and fall back to mi_conv_igemm). */
+int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
+                     const float* bias, const float* residual, float* y, void* stream);
+int mi_conv3x3_bf16w_supported(const MiConvDesc* d);
+/* bf16 shadow copies of every conv weight of the flat fp32 parameter buffer (master layout
+ * [tap][Cin][Cout] at float offset `off`): wd = same layout, wf = [tap][Cout][Cin].
+ * entries_dev: device array of {int64 off; int32 taps, ci, co, tile0}, tile0 = first 32x32-tile
+ * index of the entry (prefix sum of taps*ceil(ci/32)*ceil(co/32)); total_tiles = grid size. */
+int mi_pack_weights_bf16(int nent, const void* entries_dev, int total_tiles, const float* master,
+                         void* wd_bf16, void* wf_bf16, void* stream);
+
 /* ---- weight gradient (aten::convolution_backward, weight part) -----------------------
  *   dW[ky][kx][i][j] += sum_{n,y,x} P[n,py,px,i] * Q[n,qy,qx,j]
  * (y,x) runs over the DH x DW grid of the non-gathered operand; the gathered operand is

@@ -305,3 +305,76 @@ def test_diffusion_elementwise(K, golden_dir):
         gg = torch.zeros(1004, device=DEV); gg[:1003] = gr.to(DEV)
         K.adam_step(pg[:1003], gg[:1003], m[:1003], v[:1003], 1e-3, 0.9, 0.999, 1e-8, step)
     assert torch.allclose(pg[:1003].cpu(), pr.detach(), atol=1e-6)
+
+
+def _pack(K, w_storage_list):
+    """fp32 tap-major weights -> (flat master, bf16 wd, bf16 wf, offsets) through mi_pack_weights_bf16."""
+    offs, off = [], 0
+    for w in w_storage_list:
+        offs.append(off); off += (w.numel() + 63) // 64 * 64
+    flat = torch.zeros(off, device=DEV)
+    rec = np.zeros(len(w_storage_list), dtype=np.dtype([("off", "<i8"), ("taps", "<i4"), ("ci", "<i4"), ("co", "<i4"), ("tile0", "<i4")]))
+    tile = 0
+    for i, (w, o) in enumerate(zip(w_storage_list, offs)):
+        kh, kw, ci, co = w.shape
+        flat[o:o + w.numel()] = w.reshape(-1)
+        rec[i] = (o, kh * kw, ci, co, tile)
+        tile += kh * kw * ((ci + 31) // 32) * ((co + 31) // 32)
+    table = torch.from_numpy(rec.view(np.uint8).copy()).to(DEV)
+    wd = torch.zeros(off, device=DEV, dtype=torch.bfloat16)
+    wf = torch.zeros(off, device=DEV, dtype=torch.bfloat16)
+    K.pack_weights_bf16(table, len(w_storage_list), tile, flat, wd, wf)
+    return flat, wd, wf, offs
+
+
+def test_pack_weights_bf16(K):
+    g = torch.Generator().manual_seed(23)
+    ws = [torch.randn(3, 3, 40, 24, generator=g).to(DEV), torch.randn(1, 1, 16, 3, generator=g).to(DEV),
+          torch.randn(4, 4, 32, 32, generator=g).to(DEV)]
+    flat, wd, wf, offs = _pack(K, ws)
+    torch.cuda.synchronize()
+    for w, o in zip(ws, offs):
+        n = w.numel()
+        assert torch.equal(wd[o:o + n].view(w.shape), w.to(torch.bfloat16))
+        assert torch.equal(wf[o:o + n].view(w.shape[0], w.shape[1], w.shape[3], w.shape[2]),
+                           w.permute(0, 1, 3, 2).contiguous().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=2, H=32, Ci=128, Co=128),             # level 0: 4 rows x 32 cols per tile
+    dict(N=4, H=16, Ci=256, Co=128, split=128),  # skip concat, 8 x 16 tiles
+    dict(N=2, H=8, Ci=64, Co=192),               # 64-pixel tiles (one 8x8 image), ragged N tile
+    dict(N=16, H=8, Ci=512, Co=512),             # 128-pixel tiles = two images
+    dict(N=4, H=4, Ci=32, Co=32),                # CK=32 path, 4 images per tile
+    dict(N=40, H=32, Ci=64, Co=128),             # many tiles
+    dict(N=1, H=64, Ci=64, Co=64),               # cfg-3 level 0: 2 rows x 64 cols
+])
+def test_conv3x3_halo_fwd_and_dgrad(K, cfg):
+    """Block's 3x3 conv (ddpm.py:116) and its data gradient through the LDS halo-tile kernel."""
+    N, H, Ci, Co = cfg["N"], cfg["H"], cfg["Ci"], cfg["Co"]
+    split = cfg.get("split")
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(N, Ci, H, H, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g, dtype=torch.float64) / math.sqrt(Ci * 9)).requires_grad_(True)
+    b = torch.randn(Co, generator=g, dtype=torch.float64)
+    r = torch.randn(N, Co, H, H, generator=g, dtype=torch.float64)
+    y = F.conv2d(x, w, b, padding=1) + r
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    flat, wd, wf, offs = _pack(K, [conv_w_storage(w.detach())])
+    if split:
+        xa, xb = to_nhwc_gpu(x.detach()[:, :split].float()), to_nhwc_gpu(x.detach()[:, split:].float())
+    else:
+        xa, xb = to_nhwc_gpu(x.detach().float()), None
+    yg = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Co, flip=False, x2=xb, bias=b.float().to(DEV), residual=to_nhwc_gpu(r.float()))
+    assert yg is not None, "shape should be supported by the halo kernel"
+    dxg = K.conv3x3_bf16w(to_nhwc_gpu(dy.float()), wd, K=Co, Nc=Ci, flip=True)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(yg), y) < 2e-2
+    assert rel_err(from_nhwc(dxg), x.grad) < 2e-2
+    # against the same bf16-rounded operands the error is only fp32 accumulation order
+    xq, wq = x.detach().float().bfloat16().double(), w.detach().float().bfloat16().double()
+    yq = F.conv2d(xq, wq, b, padding=1) + r
+    assert rel_err(from_nhwc(yg), yq) < 1e-5
+    dx2 = K.conv3x3_bf16w(to_nhwc_gpu(dy.float()), wd, K=Co, Nc=Ci, flip=True, out=dxg.clone(), accumulate=True)
+    assert rel_err(from_nhwc(dx2), 2 * x.grad) < 2e-2
