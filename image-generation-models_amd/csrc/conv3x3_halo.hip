@@ -92,8 +92,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             int c4 = (t + 256 * i) % Q;
-            ra[i] = (a_off[i] >= 0) ? *reinterpret_cast<const float4*>(src + (size_t)a_off[i] * ld + cc + c4 * 4)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            // unconditional load from a clamped address, then select (no branch around the load)
+            const bool ok = a_off[i] >= 0;
+            float4 v = *reinterpret_cast<const float4*>(src + (size_t)(ok ? a_off[i] : 0) * ld + cc + c4 * 4);
+            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_a = [&]() {
@@ -109,8 +111,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
             int idx = t + 256 * i;
             int n = idx / (CK / 8), k8 = idx % (CK / 8);
             int ng = n0 + n;
-            rb[i] = (ng < a.Nc) ? *reinterpret_cast<const uint4*>(a.w + ((size_t)wt * a.Nc + ng) * a.K + kc + k8 * 8)
-                                : make_uint4(0, 0, 0, 0);
+            const bool ok = ng < a.Nc;
+            uint4 v = *reinterpret_cast<const uint4*>(a.w + ((size_t)wt * a.Nc + (ok ? ng : 0)) * a.K + kc + k8 * 8);
+            rb[i] = ok ? v : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_b = [&](int buf) {

@@ -1,0 +1,232 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolution on bf16 MFMA:
+//     dW[ky][kx][ci][co] += sum_{n,y,x} X[n, y+ky-1, x+kx-1, ci] * dY[n, y, x, co]
+// The contraction axis (pixels x images) is the strided axis of both NHWC operands.  Instead of
+// transposing pixel runs (which a tap shift would misalign), the 8 consecutive k-elements of an
+// MFMA operand are the SAME pixel of 8 CONSECUTIVE IMAGES: LDS holds Xs[ci][position][8 images]
+// (16 bytes per slot), so a tap shift moves whole 16-byte slots and every fragment read is an
+// aligned ds_read_b128.  One workgroup = one (ci-tile, co-tile, ky, k-slice); per chunk
+// (8 images x 16 pixels) the X row tile (+1 halo column each side) and the dY tile are staged
+// once (fp32 -> bf16 via v_cvt_pk_bf16_f32 across images) and feed the three kx taps, whose
+// accumulators all live in registers.  k-slices are combined with fp32 atomics.
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+struct W3Args {
+    const float* P; const float* P2; const float* Q; float* dW;
+    int N, H, W, Ci, Cj, I1, ldp, ldp2, ldq;
+    int TH, TW;            // spatial tile (TH*TW == 16)
+    int tiles_x, tiles;    // W/TW, tiles per image
+    int total, cps, splits;
+    int gx, gy;
+};
+
+template <int NJ>
+__global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
+    constexpr int BI = 128, BJ = 32 * 2 * NJ;
+    constexpr int YP = 17 * 8;                          // dY pitch per co row (bf16 elems): 16 slots + 1 pad
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];      // BI*XP + BJ*YP bf16
+
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int wi = wv >> 1, wj = wv & 1;
+    // XCD-aware decomposition of a 1-D grid: workgroup b runs on XCD b % 8 (observed dispatch order;
+    // speed only).  All (ci-tile, co-tile, ky) workgroups of one k-slice read the same pixels, so
+    // they are given consecutive slots on ONE XCD and share its L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int gsz = a.gx * a.gy * 3;
+    const int split = (slot / gsz) * 8 + xcd;
+    if (split >= a.splits) return;
+    const int within = slot % gsz;
+    const int ky = within % 3, txy = within / 3;
+    const int ci0 = (txy % a.gx) * BI, co0 = (txy / a.gx) * BJ;
+    const int TW2 = a.TW + 2;
+    const int PX = a.TH * TW2;                          // X positions per chunk (18, 20 or 24)
+    const int XP = (PX | 1) * 8;                        // odd slot count -> conflict-free fragment reads
+    const int npg = (PX + 7) / 8;                       // position groups of 8
+    uint16_t* Xs = lds;
+    uint16_t* Ys = lds + BI * XP;
+    const int HW = a.H * a.W;
+
+    f32x16 acc[3][2][NJ];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[k][i][j][r] = 0.f;
+
+    const int hp_sub = l & 7, c4 = l >> 3;
+    const int cbeg = split * a.cps, cend = min(a.total, cbeg + a.cps);
+
+    // ---- staging assignment (fixed per thread): 3 X units and NJ dY units per wave;
+    //      unit = (8 positions) x (32 channels), one float4 per image per lane
+    int x_pos[3], x_ch[3], x_dst[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int u = wv + 4 * k;
+        const int pg = u % 3, cg = u / 3;
+        x_pos[k] = pg * 8 + hp_sub;
+        x_ch[k] = ci0 + cg * 32 + c4 * 4;
+        x_dst[k] = (cg * 32 + c4 * 4) * XP + x_pos[k] * 8;
+    }
+    int y_pos[NJ], y_ch[NJ], y_dst[NJ];
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        const int u = wv + 4 * k;
+        const int pg = u & 1, cg = u >> 1;
+        y_pos[k] = pg * 8 + hp_sub;
+        y_ch[k] = co0 + cg * 32 + c4 * 4;
+        y_dst[k] = (cg * 32 + c4 * 4) * YP + y_pos[k] * 8;
+    }
+    float4 px[3][8], py[NJ][8];
+
+    auto issue = [&](int c) {          // global -> registers for chunk c (whole chunk in flight at once)
+        const int g = c / a.tiles, tile = c - g * a.tiles;
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int y0 = ty * a.TH, x0 = tx * a.TW, n0 = g * 8;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int r = x_pos[k] / TW2, xx = x_pos[k] - r * TW2;
+            const int iy = y0 + r + ky - 1, ix = x0 + xx - 1;
+            const bool ok = x_pos[k] < PX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && x_ch[k] < a.Ci;
+            const float* src = a.P; int ld = a.ldp; int cc = x_ch[k];
+            if (cc >= a.I1) { src = a.P2; ld = a.ldp2; cc -= a.I1; }
+            // clamped address + select after the load: no branch around the loads, all 8 stay in flight
+            const float* base = ok ? src + ((size_t)n0 * HW + iy * a.W + ix) * ld + cc : src + (size_t)n0 * HW * ld;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * HW * ld);
+                px[k][q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            const int r = y_pos[k] / a.TW, xx = y_pos[k] - r * a.TW;
+            const bool ok = y_ch[k] < a.Cj;
+            const float* base = a.Q + ((size_t)n0 * HW + (y0 + r) * a.W + x0 + xx) * a.ldq + (ok ? y_ch[k] : 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * HW * a.ldq);
+                py[k][q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto put = [&](uint16_t* dst, int pitch, const float4 (&v)[8]) {   // 8 images x 4 channels -> 4 rows of 8 bf16
+        *reinterpret_cast<uint4*>(dst)             = make_uint4(pack_bf16(v[0].x, v[1].x), pack_bf16(v[2].x, v[3].x), pack_bf16(v[4].x, v[5].x), pack_bf16(v[6].x, v[7].x));
+        *reinterpret_cast<uint4*>(dst + pitch)     = make_uint4(pack_bf16(v[0].y, v[1].y), pack_bf16(v[2].y, v[3].y), pack_bf16(v[4].y, v[5].y), pack_bf16(v[6].y, v[7].y));
+        *reinterpret_cast<uint4*>(dst + 2 * pitch) = make_uint4(pack_bf16(v[0].z, v[1].z), pack_bf16(v[2].z, v[3].z), pack_bf16(v[4].z, v[5].z), pack_bf16(v[6].z, v[7].z));
+        *reinterpret_cast<uint4*>(dst + 3 * pitch) = make_uint4(pack_bf16(v[0].w, v[1].w), pack_bf16(v[2].w, v[3].w), pack_bf16(v[4].w, v[5].w), pack_bf16(v[6].w, v[7].w));
+    };
+    auto commit = [&]() {              // registers -> LDS (bf16, image-major 16-byte slots)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (x_pos[k] < PX) put(Xs + x_dst[k], XP, px[k]);
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) put(Ys + y_dst[k], YP, py[k]);
+    };
+
+    if (cbeg < cend) issue(cbeg);
+    for (int c = cbeg; c < cend; ++c) {
+        __syncthreads();                                // previous chunk's fragment reads are done
+        commit();
+        __syncthreads();
+        if (c + 1 < cend) issue(c + 1);                 // next chunk streams in under the MFMAs
+        // ---- 8 k-steps of 16 = (2 positions) x (8 images); 3 kx taps share the dY fragment
+        const int arow = (wi * 64 + (l & 31)) * XP, brow = (wj * (32 * NJ) + (l & 31)) * YP;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int p = 2 * s + (l >> 5);
+            const int r = p / a.TW, xx = p - r * a.TW;
+            bf16x8 bf[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Ys[brow + j * 32 * YP + p * 8]);
+            const int xa = (r * TW2 + xx) * 8;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                bf16x8 af[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&Xs[arow + i * 32 * XP + xa + kx * 8]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[kx][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[kx][i][j], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        float* out = a.dW + (size_t)(ky * 3 + kx) * a.Ci * a.Cj;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = ci0 + wi * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                if (row >= a.Ci) continue;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    int col = co0 + wj * (32 * NJ) + j * 32 + (l & 31);
+                    if (col < a.Cj) atomicAdd(out + (size_t)row * a.Cj + col, acc[kx][i][j][r]);
+                }
+            }
+    }
+}
+
+}  // namespace
+
+static bool w3_ok(const MiWgradDesc* d) {
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || !d->gather_i || d->mode != 1) return false;
+    if (d->GH != d->DH || d->GW != d->DW) return false;
+    if (d->N % 8 || d->Ci % 32 || d->Cj % 32 || d->I1 % 32) return false;
+    int W = d->DW, H = d->DH;
+    if (W >= 16) return W % 16 == 0;
+    if (W == 8) return H % 2 == 0;
+    if (W == 4) return H % 4 == 0;
+    return false;
+}
+
+extern "C" int mi_conv3x3_wgrad_supported(const MiWgradDesc* d) { return (d && w3_ok(d)) ? 1 : 0; }
+
+extern "C" int mi_conv3x3_wgrad(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
+                                void* stream) {
+    MI_REQUIRE(d && P && Q && dW, "null argument");
+    MI_REQUIRE(w3_ok(d), "descriptor not supported by the 3x3 wgrad kernel (use mi_conv_wgrad)");
+    MI_REQUIRE(d->I1 == d->Ci || P2, "two-source split without P2");
+    MI_REQUIRE(d->ldp % 4 == 0 && d->ldq % 4 == 0 && (!P2 || d->ldp2 % 4 == 0) &&
+               (((uintptr_t)P | (uintptr_t)Q | (uintptr_t)(P2 ? P2 : P)) & 15) == 0, "operands must be 16-byte aligned, ld % 4 == 0");
+    W3Args a;
+    a.P = P; a.P2 = P2 ? P2 : P; a.Q = Q; a.dW = dW;
+    a.N = d->N; a.H = d->DH; a.W = d->DW; a.Ci = d->Ci; a.Cj = d->Cj; a.I1 = d->I1;
+    a.ldp = d->ldp; a.ldp2 = P2 ? d->ldp2 : d->ldp; a.ldq = d->ldq;
+    a.TW = a.W >= 16 ? 16 : a.W; a.TH = 16 / a.TW;
+    a.tiles_x = a.W / a.TW; a.tiles = a.tiles_x * (a.H / a.TH);
+    a.total = (a.N / 8) * a.tiles;
+    const bool wide = d->Cj % 128 == 0 || d->Cj > 256;
+    const int BJ = wide ? 128 : 64;
+    long base = (long)((d->Ci + 127) / 128) * ((d->Cj + BJ - 1) / BJ) * 3;
+    static const long target = [] { const char* e = getenv("MI_W3_BLOCKS"); return e ? atol(e) : 768L; }();
+    long splits = (target + base - 1) / base;
+    if (splits > a.total) splits = a.total;
+    if (splits < 1) splits = 1;
+    a.cps = (int)((a.total + splits - 1) / splits);
+    a.splits = (a.total + a.cps - 1) / a.cps;
+    a.gx = (d->Ci + 127) / 128; a.gy = (d->Cj + BJ - 1) / BJ;
+    dim3 grid((unsigned)(a.gx * a.gy * 3 * ((a.splits + 7) / 8 * 8)));
+    hipStream_t st = (hipStream_t)stream;
+    const int XP = ((a.TH * (a.TW + 2)) | 1) * 8;
+    const size_t lds = (size_t)(128 * XP + BJ * 17 * 8) * 2;
+    static bool once = [] {
+        (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+    }();
+    (void)once;
+    if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2>), grid, dim3(256), lds, st, a);
+    else      hipLaunchKernelGGL((wgrad3x3_kernel<1>), grid, dim3(256), lds, st, a);
+    MI_LAUNCH_CHECK();
+    return 0;
+}

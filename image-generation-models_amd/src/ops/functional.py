@@ -123,7 +123,18 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
     d = MiWgradDesc(N=N, GH=grid_g[0], GW=grid_g[1], DH=grid_d[0], DW=grid_d[1], Ci=Ci, Cj=Cj, KH=kh, KW=kw,
                     stride=stride, pad=pad, gather_i=int(gather_i), mode=mode, I1=I1, ldp=ld_of(P),
                     ldp2=ld_of(P2) if P2 is not None else 0, ldq=ld_of(Q))
-    check(load_library().mi_conv_wgrad(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _stream()), "mi_conv_wgrad")
+    lib = load_library()
+    fast = bool(lib.mi_conv3x3_wgrad_supported(C.byref(d)))
+    if PROBE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if fast:
+        check(lib.mi_conv3x3_wgrad(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _stream()), "mi_conv3x3_wgrad")
+    else:
+        check(lib.mi_conv_wgrad(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _stream()), "mi_conv_wgrad")
+    if PROBE is not None:
+        e1.record()
+        PROBE.append(("wgrad3x3_kernel" if fast else f"wgrad_kernel<{mode}>", 2.0 * N * grid_d[0] * grid_d[1] * Ci * Cj * kh * kw, e0, e1))
 
 
 def _rows(x):

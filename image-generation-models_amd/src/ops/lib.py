@@ -42,6 +42,8 @@ SIGNATURES = {
     "mi_conv3x3_bf16w_supported": [C.POINTER(MiConvDesc)],
     "mi_pack_weights_bf16": [_I, _P, _I, _P, _P, _P, _P],
     "mi_conv_wgrad": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P],
+    "mi_conv3x3_wgrad": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P],
+    "mi_conv3x3_wgrad_supported": [C.POINTER(MiWgradDesc)],
     "mi_colsum": [_I, _I, _P, _I, _P, _P],
     "mi_gn_mish_fwd": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "mi_gn_mish_bwd": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P],

@@ -111,6 +111,11 @@ typedef struct MiWgradDesc {
 int mi_conv_wgrad(const MiWgradDesc* d, const float* P, const float* P2, const float* Q,
                   float* dW, void* stream);
 
+/* 3x3 / stride 1 / pad 1 Conv2d weight gradient on bf16 MFMA with image-major contraction vectors
+ * (needs N % 8 == 0, channel counts % 32 == 0; query first, else use mi_conv_wgrad). */
+int mi_conv3x3_wgrad(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW, void* stream);
+int mi_conv3x3_wgrad_supported(const MiWgradDesc* d);
+
 /* out[c] += sum_m x[m*ld + c]  (bias gradients) */
 int mi_colsum(int M, int C, const float* x, int ld, float* out, void* stream);
 

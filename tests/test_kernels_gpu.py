@@ -378,3 +378,41 @@ def test_conv3x3_halo_fwd_and_dgrad(K, cfg):
     assert rel_err(from_nhwc(yg), yq) < 1e-5
     dx2 = K.conv3x3_bf16w(to_nhwc_gpu(dy.float()), wd, K=Co, Nc=Ci, flip=True, out=dxg.clone(), accumulate=True)
     assert rel_err(from_nhwc(dx2), 2 * x.grad) < 2e-2
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=8, H=32, Ci=128, Co=128),
+    dict(N=16, H=16, Ci=256, Co=128, split=128),
+    dict(N=8, H=8, Ci=64, Co=192),
+    dict(N=16, H=8, Ci=512, Co=256),
+    dict(N=8, H=4, Ci=32, Co=32),
+    dict(N=8, H=64, Ci=64, Co=64),
+])
+def test_conv3x3_wgrad_fast(K, cfg):
+    """aten::convolution_backward (weight) of Block's 3x3 conv through the image-major MFMA kernel."""
+    N, H, Ci, Co = cfg["N"], cfg["H"], cfg["Ci"], cfg["Co"]
+    split = cfg.get("split")
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(N, Ci, H, H, generator=g, dtype=torch.float64)
+    w = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(N, Co, H, H, generator=g, dtype=torch.float64)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    dW = torch.zeros(9 * Ci * Co, device=DEV)
+    if split:
+        P, P2 = to_nhwc_gpu(x[:, :split].float()), to_nhwc_gpu(x[:, split:].float())
+    else:
+        P, P2 = to_nhwc_gpu(x.float()), None
+    from src.ops.lib import MiWgradDesc, load_library
+    import ctypes
+    d = MiWgradDesc(N=N, GH=H, GW=H, DH=H, DW=H, Ci=Ci, Cj=Co, KH=3, KW=3, stride=1, pad=1, gather_i=1, mode=1,
+                    I1=split or Ci, ldp=4, ldp2=4, ldq=4)
+    assert load_library().mi_conv3x3_wgrad_supported(ctypes.byref(d)) == 1
+    K.conv_wgrad(P, to_nhwc_gpu(dy.float()), dW, kh=3, kw=3, stride=1, pad=1, gather_i=True, Ci=Ci, Cj=Co,
+                 grid_g=(H, H), grid_d=(H, H), mode=1, P2=P2)
+    torch.cuda.synchronize()
+    got = w_from_storage(dW.view(3, 3, Ci, Co))
+    assert rel_err(got, w.grad) < 2e-2
+    xq, dq = x.float().bfloat16().double(), dy.float().bfloat16().double()
+    wq = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xq, wq, None, padding=1).backward(dq)
+    assert rel_err(got, wq.grad) < 2e-5          # same bf16-rounded operands: only summation order differs

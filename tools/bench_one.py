@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Run ONE kernel configuration a few times (for rocprofv3 counter passes)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "image-generation-models_amd")]
+import torch
+from src.ops import functional as K
+which, B, H, Ci, Co = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+DEV = "cuda"
+x = torch.randn(B, H, H, Ci, device=DEV); w = torch.randn(3, 3, Ci, Co, device=DEV) * 0.05
+dy = torch.randn(B, H, H, Co, device=DEV)
+wd = w.to(torch.bfloat16).reshape(-1); wf = w.permute(0, 1, 3, 2).contiguous().to(torch.bfloat16).reshape(-1)
+y = torch.empty(B, H, H, Co, device=DEV); dW = torch.zeros(9 * Ci * Co, device=DEV)
+for _ in range(5):
+    if which == "wgrad":
+        K.conv_wgrad(x, dy, dW, kh=3, kw=3, stride=1, pad=1, gather_i=True, Ci=Ci, Cj=Co, grid_g=(H, H), grid_d=(H, H), mode=1)
+    elif which == "halo":
+        K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, out=y)
+    elif which == "igemm":
+        K.conv_igemm(x, w, kh=3, kw=3, stride=1, pad=1, transposed=False, w_kn=True, K=Ci, Nc=Co, out_hw=(H, H), mode=1, out=y)
+torch.cuda.synchronize()
