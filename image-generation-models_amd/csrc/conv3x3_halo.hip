@@ -10,6 +10,7 @@
 // each tap streams through a double-buffered LDS slot from a bf16 [tap][n][k] copy of the
 // weights (made once per optimizer step by mi_pack_weights_bf16) with 16-byte loads -- no
 // conversion, no transposition in the loop.  v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -22,58 +23,70 @@ struct HaloArgs {
     int tiles_per_img;   // H/TH when TI == 1
 };
 
+template <int BM> struct HaloCfg {
+    static constexpr int NT = (BM == 256) ? 512 : 256;          // threads
+    static constexpr int MI = (BM >= 128) ? 2 : 1;              // 32-row MFMA tiles per wave (wave tile MI*32 x 64)
+    static constexpr int MAXHP = (BM == 256) ? 400 : (BM == 128 ? 288 : 160);
+};
+
+// Software pipeline, per workgroup.  "Stage" g = chunk*9 + tap.  While tap g runs on the matrix
+// cores out of LDS (A halo buffer chunk&1, weight slot g&1), the registers receive stage g+2:
+// the weight tile of tap g+2 and one ninth of the NEXT chunk's halo tile; at the end of tap g the
+// registers of stage g+1 (fetched one full tap earlier) are written to the other weight slot /
+// the other halo buffer.  Every global load therefore has two taps of MFMA time to land, there
+// is one barrier per tap, and nothing is staged at chunk boundaries.  Taps are unrolled so the
+// two register sets are static.
 template <int BM, int CK>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
+__global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const HaloArgs a) {
     constexpr int BN = 128;
+    constexpr int NT = HaloCfg<BM>::NT, MI = HaloCfg<BM>::MI, NI = 2;
     constexpr int PITCH = CK + 8;                  // bf16 elements; 16-B aligned rows, conflict-free b128 reads
-    constexpr int MAXHP = (BM == 128) ? 288 : 160;
-    constexpr int A_IT = (MAXHP * (CK / 4) + 255) / 256;   // float4 loads per thread per chunk
-    constexpr int B_IT = BN * (CK / 8) / 256;              // 16-B loads per thread per tap
-    constexpr int MI = BM / 64, NI = 2;                    // waves 2(M) x 2(N); wave tile (BM/2) x 64
+    constexpr int MAXHP = HaloCfg<BM>::MAXHP;
+    constexpr int Q = CK / 4;                      // float4 per halo pixel per chunk
+    constexpr int A_IT = (MAXHP * Q + NT - 1) / NT;
+    constexpr int A_SL = (A_IT + 8) / 9;           // float4 per thread per tap (nine slices cover a halo tile)
+    constexpr int B_IT = BN * (CK / 8) / NT;       // 16-B loads per thread per tap
 
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    uint16_t* As = lds;                                    // [MAXHP][PITCH]
-    uint16_t* Bs = lds + MAXHP * PITCH;                    // 2 x [BN][PITCH]
+    uint16_t* As = lds;                                    // 2 x [MAXHP][PITCH]
+    uint16_t* Bs = lds + 2 * MAXHP * PITCH;                // 2 x [BN][PITCH]
+    int* pix = reinterpret_cast<int*>(Bs + 2 * BN * PITCH); // [MAXHP] source pixel index of each halo pixel, -1 = zero
 
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int wm = wv >> 1, wn = wv & 1;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int W2 = a.W + 2, TH2 = a.TH + 2;
 
-    // tile origin
     int img0, y0;
     if (a.TI > 1) { img0 = blockIdx.x * a.TI; y0 = 0; }
     else { img0 = blockIdx.x / a.tiles_per_img; y0 = (blockIdx.x % a.tiles_per_img) * a.TH; }
-
-    // ---- halo staging assignment: thread -> (halo pixel, float4 of the chunk), fixed for all chunks
-    constexpr int Q = CK / 4;                              // float4 per halo pixel per chunk
-    int a_off[A_IT];                                       // pixel offset in floats/ld units, -1 = zero fill
-    int a_lds[A_IT];
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        int idx = t + 256 * i;
-        int hp = idx / Q, c4 = idx % Q;
-        a_lds[i] = -1; a_off[i] = -1;
+    for (int hp = t; hp < MAXHP; hp += NT) {
+        int v = -1;
         if (hp < a.HP) {
             int ti = hp / (TH2 * W2);
             int rem = hp - ti * (TH2 * W2);
             int hy = rem / W2, hx = rem - hy * W2;
             int iy = y0 + hy - 1, ix = hx - 1, img = img0 + ti;
-            a_lds[i] = hp * PITCH + c4 * 4;
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && img < a.N)
-                a_off[i] = (img * a.H + iy) * a.W + ix;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && img < a.N) v = (img * a.H + iy) * a.W + ix;
         }
+        pix[hp] = v;
     }
+    __syncthreads();
+
     // ---- MFMA row -> halo pixel (before the tap shift)
     int a_row[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        int r = wm * (BM / 2) + i * 32 + (l & 31);
+        int r = wm * (MI * 32) + i * 32 + (l & 31);
         int tx = r % a.W, q = r / a.W;
         int ty = q % a.TH, ti = q / a.TH;
         a_row[i] = ((ti * TH2 + ty) * W2 + tx) * PITCH + (l >> 5) * 8;
     }
     const int b_row0 = (wn * 64 + (l & 31)) * PITCH + (l >> 5) * 8;
+    // ---- staging assignments.  halo element e = t + NT*j: pixel e / Q, float4 e % Q
+    const int a_c4 = t % Q, a_hp0 = t / Q;                 // + (NT/Q) pixels per j
+    const int b_n = t / (CK / 8), b_k8 = t % (CK / 8);     // + NT/(CK/8) rows per i
+    const size_t tap_stride = (size_t)a.Nc * a.K;
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -83,88 +96,98 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[A_IT];
-    uint4 rb[B_IT];
+    float4 ra[2][A_SL];
+    uint4 rb[2][B_IT];
+    const int nchunks = a.K / CK;
+    const int ntaps = nchunks * 9;
 
-    auto load_a = [&](int kc) {
+    // fetch slice `sl` (0..8) of chunk `ch`'s halo tile
+    auto load_a = [&](float4 (&r)[A_SL], int ch, int sl) {
+        if (ch >= nchunks) return;
+        const int kc = ch * CK;
         const float* src = a.x; int ld = a.ldx; int cc = kc;
         if (kc >= a.K1) { src = a.x2; ld = a.ldx2; cc = kc - a.K1; }
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            int c4 = (t + 256 * i) % Q;
-            // unconditional load from a clamped address, then select (no branch around the load)
-            const bool ok = a_off[i] >= 0;
-            float4 v = *reinterpret_cast<const float4*>(src + (size_t)(ok ? a_off[i] : 0) * ld + cc + c4 * 4);
-            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < A_SL; ++j) {
+            const int hp = a_hp0 + (sl * A_SL + j) * (NT / Q);
+            const int pv = hp < MAXHP ? pix[hp] : -1;
+            float4 v = *reinterpret_cast<const float4*>(src + (size_t)(pv >= 0 ? pv : 0) * ld + cc + a_c4 * 4);
+            r[j] = pv >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto store_a = [&]() {
+    auto store_a = [&](int buf, const float4 (&r)[A_SL], int sl) {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i)
-            if (a_lds[i] >= 0)
-                *reinterpret_cast<uint2*>(&As[a_lds[i]]) = make_uint2(pack_bf16(ra[i].x, ra[i].y), pack_bf16(ra[i].z, ra[i].w));
+        for (int j = 0; j < A_SL; ++j) {
+            const int hp = a_hp0 + (sl * A_SL + j) * (NT / Q);
+            if (hp < a.HP)
+                *reinterpret_cast<uint2*>(&As[buf * (MAXHP * PITCH) + hp * PITCH + a_c4 * 4]) =
+                    make_uint2(pack_bf16(r[j].x, r[j].y), pack_bf16(r[j].z, r[j].w));
+        }
     };
-    auto load_b = [&](int tap, int kc) {
+    auto load_b = [&](uint4 (&r)[B_IT], int g) {
+        if (g >= ntaps) return;
+        const int ch = g / 9, tap = g - ch * 9;
         const int wt = a.flip ? 8 - tap : tap;
+        const uint16_t* base = a.w + wt * tap_stride + (size_t)ch * CK + b_k8 * 8;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            int idx = t + 256 * i;
-            int n = idx / (CK / 8), k8 = idx % (CK / 8);
-            int ng = n0 + n;
-            const bool ok = ng < a.Nc;
-            uint4 v = *reinterpret_cast<const uint4*>(a.w + ((size_t)wt * a.Nc + (ok ? ng : 0)) * a.K + kc + k8 * 8);
-            rb[i] = ok ? v : make_uint4(0, 0, 0, 0);
+            const int n = n0 + b_n + i * (NT / (CK / 8));
+            uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)(n < a.Nc ? n : 0) * a.K);
+            r[i] = n < a.Nc ? v : make_uint4(0, 0, 0, 0);
         }
     };
-    auto store_b = [&](int buf) {
+    auto store_b = [&](int slot, const uint4 (&r)[B_IT]) {
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            int idx = t + 256 * i;
-            int n = idx / (CK / 8), k8 = idx % (CK / 8);
-            *reinterpret_cast<uint4*>(&Bs[buf * (BN * PITCH) + n * PITCH + k8 * 8]) = rb[i];
+        for (int i = 0; i < B_IT; ++i)
+            *reinterpret_cast<uint4*>(&Bs[slot * (BN * PITCH) + (b_n + i * (NT / (CK / 8))) * PITCH + b_k8 * 8]) = r[i];
+    };
+    auto mma_tap = [&](int abuf, int slot, int tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const uint16_t* At = As + abuf * (MAXHP * PITCH) + (ky * W2 + kx) * PITCH;
+        const uint16_t* Bt = Bs + slot * (BN * PITCH);
+#pragma unroll
+        for (int ks = 0; ks < CK / 16; ++ks) {
+            bf16x8 af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&At[a_row[i] + ks * 16]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Bt[b_row0 + j * 32 * PITCH + ks * 16]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // one chunk; P = parity of its first stage (= chunk & 1 since a chunk has nine stages)
+    auto chunk = [&](auto parity, int ch) {
+        constexpr int P = decltype(parity)::value;
+        const int g0 = ch * 9;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int cur = (P + tp) & 1;                  // static after unrolling
+            // stage g+2 -> registers `cur` (they were drained into LDS at the end of the previous tap)
+            if (cur == 0) { load_b(rb[0], g0 + tp + 2); } else { load_b(rb[1], g0 + tp + 2); }
+            // halo stage g+10 = slice tp+1 of the next chunk (slice 0 of the one after when tp == 8)
+            if (tp < 8) { if (cur == 0) load_a(ra[0], ch + 1, tp + 1); else load_a(ra[1], ch + 1, tp + 1); }
+            else        { if (cur == 0) load_a(ra[0], ch + 2, 0); else load_a(ra[1], ch + 2, 0); }
+            mma_tap(P, cur, tp);
+            // stage g+1 -> other weight slot; halo stage g+9 = slice tp of the next chunk -> other halo buffer
+            if (cur == 0) store_b(1, rb[1]); else store_b(0, rb[0]);
+            if (ch + 1 < nchunks) { if (cur == 0) store_a(P ^ 1, ra[1], tp); else store_a(P ^ 1, ra[0], tp); }
+            __syncthreads();
         }
     };
 
-    const int nchunks = a.K / CK;
-    load_a(0);
-    load_b(0, 0);
-    int buf = 0;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int kc = ch * CK;
-        __syncthreads();                       // everyone done reading the previous chunk's A tile / last B slot
-        store_a();
-        store_b(buf);
-        __syncthreads();
-        if (ch + 1 < nchunks) load_a(kc + CK); // next chunk's halo rides under the 9 taps of MFMAs
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            // prefetch the next weight tile (next tap, or tap 0 of the next chunk)
-            const bool last = (tap == 8);
-            if (!last) load_b(tap + 1, kc);
-            else if (ch + 1 < nchunks) load_b(0, kc + CK);
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int shift = (ky * W2 + kx) * PITCH;
-            const uint16_t* Bt = Bs + buf * (BN * PITCH);
-#pragma unroll
-            for (int ks = 0; ks < CK / 16; ++ks) {
-                bf16x8 af[MI], bf[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[a_row[i] + shift + ks * 16]);
-#pragma unroll
-                for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Bt[b_row0 + j * 32 * PITCH + ks * 16]);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-            }
-            if (!last) {
-                store_b(buf ^ 1);              // other slot: nobody reads it during this tap
-                __syncthreads();
-                buf ^= 1;
-            }
-        }
-        buf ^= 1;                              // tap 0 of the next chunk goes to the other slot (stored above after sync)
+    // ---- prologue: chunk 0's halo tile, weight stages 0 (LDS) and 1 (registers), halo stage 9 (registers)
+    for (int sl = 0; sl < 9; ++sl) { load_a(ra[0], 0, sl); store_a(0, ra[0], sl); }
+    load_b(rb[0], 0); store_b(0, rb[0]);
+    load_b(rb[1], 1);
+    load_a(ra[1], 1, 0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        chunk(std::integral_constant<int, 0>{}, ch);
+        if (ch + 1 < nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
     }
 
     // ---- epilogue
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+            int row = wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
             size_t m = (size_t)m0 + row;
             if (m >= (size_t)Mtot) continue;
 #pragma unroll
@@ -193,15 +216,15 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
 template <int BM, int CK>
 void launch_halo(const HaloArgs& a, hipStream_t st) {
     constexpr int PITCH = CK + 8;
-    constexpr int MAXHP = (BM == 128) ? 288 : 160;
-    size_t lds = (size_t)(MAXHP * PITCH + 2 * 128 * PITCH) * 2;
+    constexpr int MAXHP = HaloCfg<BM>::MAXHP;
+    size_t lds = (size_t)(2 * MAXHP * PITCH + 2 * 128 * PITCH) * 2 + MAXHP * 4;
     dim3 grid((a.N * a.H * a.W + BM - 1) / BM, (a.Nc + 127) / 128);
     static bool once = [] {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK>), grid, dim3(HaloCfg<BM>::NT), lds, st, a);
 }
 
 // fp32 [tap][k][n] master weights -> bf16 Wd[tap][k][n] (same layout) and Wf[tap][n][k] (transposed per tap)
@@ -238,31 +261,40 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __re
 
 }  // namespace
 
+// Tile geometry for BM output pixels: whole image rows (TH rows of one image) or TI whole images.
+static bool halo_geom(const MiConvDesc* d, int BM, int* TH, int* TI) {
+    int W = d->OW, H = d->OH;
+    if (BM % W) return false;
+    int rows = BM / W;
+    if (rows <= H) { if (H % rows) return false; *TH = rows; *TI = 1; }
+    else { if (rows % H) return false; *TH = H; *TI = rows / H; if ((long)d->N % *TI) return false; }
+    int maxhp = BM == 256 ? 400 : (BM == 128 ? 288 : 160);
+    return *TI * (*TH + 2) * (W + 2) <= maxhp;
+}
+
 // Can the halo kernel take this descriptor?  (3x3, stride 1, pad 1, full-width row tiles)
 static bool halo_ok(const MiConvDesc* d, int* bm, int* ck) {
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->mode != 1) return false;
     if (d->IH != d->OH || d->IW != d->OW) return false;
     if (d->K % 32 || d->K1 % 32 || d->Nc % 4) return false;
-    int W = d->OW, H = d->OH;
-    if (W < 4 || W > 64 || (128 % W)) return false;
-    int BM = 128;
-    // smaller tile when the grid would not fill the chip
-    long tiles = ((long)d->N * H * W + 127) / 128 * ((d->Nc + 127) / 128);
-    if (tiles < 320 && (64 % W) == 0) BM = 64;
-    int rows = BM / W;                  // image rows per tile (may exceed H -> several images)
-    if (rows <= H) { if (H % rows) return false; }
-    else { if (rows % H) return false; if ((long)d->N % (rows / H)) return false; }
-    int TH = rows <= H ? rows : H, TI = rows <= H ? 1 : rows / H;
-    if (TI * (TH + 2) * (W + 2) > (BM == 128 ? 288 : 160)) {
-        if (BM == 128) return false;
-        BM = 128; rows = BM / W;                         // retry with the large tile
-        if (rows <= H) { if (H % rows) return false; }
-        else { if (rows % H) return false; if ((long)d->N % (rows / H)) return false; }
-        TH = rows <= H ? rows : H; TI = rows <= H ? 1 : rows / H;
-        if (TI * (TH + 2) * (W + 2) > 288) return false;
+    if (d->OW < 4 || d->OW > 64) return false;
+    static const int force = [] { const char* e = getenv("MI_HALO_BM"); return e ? atoi(e) : 0; }();
+    const long M = (long)d->N * d->OH * d->OW, nt = (d->Nc + 127) / 128;
+    int TH, TI, best = 0;
+    const int cand[3] = {256, 128, 64};
+    const long need[3] = {200, 400, 0};       // workgroups wanted: 256-pixel tiles run 1/CU (8 waves), smaller ones 2-3/CU
+    for (int c = 0; c < 3; ++c) {
+        int BM = cand[c];
+        if (force && BM != force) continue;
+        if (!halo_geom(d, BM, &TH, &TI)) continue;
+        best = BM;                             // smallest legal tile so far (fallback)
+        if ((M + BM - 1) / BM * nt >= need[c] || force) break;
     }
-    *bm = BM;
-    *ck = (d->K % 64 == 0 && d->K1 % 64 == 0) ? 64 : 32;
+    if (!best) return false;
+    *bm = best;
+    static const int force_ck = [] { const char* e = getenv("MI_HALO_CK"); return e ? atoi(e) : 0; }();
+    *ck = (best == 256 && d->K % 64 == 0 && d->K1 % 64 == 0) ? 64 : 32;   // CK=64 only where one workgroup/CU is the plan anyway
+    if (force_ck == 32 || (force_ck == 64 && d->K % 64 == 0 && d->K1 % 64 == 0)) *ck = force_ck;
     return true;
 }
 
@@ -279,14 +311,13 @@ extern "C" int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float
     a.N = d->N; a.H = d->OH; a.W = d->OW; a.K = d->K; a.Nc = d->Nc; a.K1 = d->K1; a.ldx = d->ldx;
     a.ldx2 = x2 ? d->ldx2 : d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.accumulate = d->accumulate;
     a.flip = d->transposed ? 1 : 0;
-    int rows = BM / a.W;
-    if (rows <= a.H) { a.TH = rows; a.TI = 1; a.tiles_per_img = a.H / rows; }
-    else { a.TH = a.H; a.TI = rows / a.H; a.tiles_per_img = 1; }
+    MI_REQUIRE(halo_geom(d, BM, &a.TH, &a.TI), "halo tile geometry");
+    a.tiles_per_img = a.TI > 1 ? 1 : a.H / a.TH;
     a.HP = a.TI * (a.TH + 2) * (a.W + 2);
-    MI_REQUIRE(a.HP <= (BM == 128 ? 288 : 160), "halo tile too large");
     hipStream_t st = (hipStream_t)stream;
-    if (BM == 128) { if (CK == 64) launch_halo<128, 64>(a, st); else launch_halo<128, 32>(a, st); }
-    else           { if (CK == 64) launch_halo<64, 64>(a, st); else launch_halo<64, 32>(a, st); }
+    if (BM == 256)      { if (CK == 64) launch_halo<256, 64>(a, st); else launch_halo<256, 32>(a, st); }
+    else if (BM == 128) { if (CK == 64) launch_halo<128, 64>(a, st); else launch_halo<128, 32>(a, st); }
+    else                { if (CK == 64) launch_halo<64, 64>(a, st); else launch_halo<64, 32>(a, st); }
     MI_LAUNCH_CHECK();
     return 0;
 }

@@ -30,14 +30,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
 
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int wi = wv >> 1, wj = wv & 1;
-    // XCD-aware decomposition of a 1-D grid: workgroup b runs on XCD b % 8 (observed dispatch order;
-    // speed only).  All (ci-tile, co-tile, ky) workgroups of one k-slice read the same pixels, so
-    // they are given consecutive slots on ONE XCD and share its L2.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    // 1-D grid, one workgroup per CU (the kernel runs one wave per SIMD): b -> (k-slice, ky, ci-tile, co-tile)
     const int gsz = a.gx * a.gy * 3;
-    const int split = (slot / gsz) * 8 + xcd;
-    if (split >= a.splits) return;
-    const int within = slot % gsz;
+    const int split = blockIdx.x / gsz;
+    const int within = blockIdx.x % gsz;
     const int ky = within % 3, txy = within / 3;
     const int ci0 = (txy % a.gx) * BI, co0 = (txy / a.gx) * BJ;
     const int TW2 = a.TW + 2;
@@ -81,36 +77,40 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         y_ch[k] = co0 + cg * 32 + c4 * 4;
         y_dst[k] = (cg * 32 + c4 * 4) * YP + y_pos[k] * 8;
     }
-    float4 px[3][8], py[NJ][8];
+    // Pipeline: LDS is double-buffered by chunk.  While the 8 k-steps of chunk c run on the matrix
+    // cores out of buffer c&1, the wave's 3+NJ staging units of chunk c+1 are fetched (one unit per
+    // k-step, three register sets in flight => two k-steps of MFMA time per load) and written to the
+    // other buffer.  One barrier per chunk (96 MFMAs per wave at NJ = 2).
+    constexpr int NU = 3 + NJ;
+    float4 U[3][8];
+    const int BUF = BI * XP + BJ * YP;                 // bf16 elements per LDS buffer
 
-    auto issue = [&](int c) {          // global -> registers for chunk c (whole chunk in flight at once)
+    auto issue_unit = [&](float4 (&r)[8], int j, int c) {     // unit j of chunk c: global -> registers
+        if (c >= cend) return;
         const int g = c / a.tiles, tile = c - g * a.tiles;
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int y0 = ty * a.TH, x0 = tx * a.TW, n0 = g * 8;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int r = x_pos[k] / TW2, xx = x_pos[k] - r * TW2;
-            const int iy = y0 + r + ky - 1, ix = x0 + xx - 1;
-            const bool ok = x_pos[k] < PX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && x_ch[k] < a.Ci;
-            const float* src = a.P; int ld = a.ldp; int cc = x_ch[k];
+        if (j < 3) {
+            const int r_ = x_pos[j] / TW2, xx = x_pos[j] - r_ * TW2;
+            const int iy = y0 + r_ + ky - 1, ix = x0 + xx - 1;
+            const bool ok = x_pos[j] < PX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && x_ch[j] < a.Ci;
+            const float* src = a.P; int ld = a.ldp; int cc = x_ch[j];
             if (cc >= a.I1) { src = a.P2; ld = a.ldp2; cc -= a.I1; }
-            // clamped address + select after the load: no branch around the loads, all 8 stay in flight
             const float* base = ok ? src + ((size_t)n0 * HW + iy * a.W + ix) * ld + cc : src + (size_t)n0 * HW * ld;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * HW * ld);
-                px[k][q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                r[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        }
-#pragma unroll
-        for (int k = 0; k < NJ; ++k) {
-            const int r = y_pos[k] / a.TW, xx = y_pos[k] - r * a.TW;
+        } else {
+            const int k = j - 3;
+            const int r_ = y_pos[k] / a.TW, xx = y_pos[k] - r_ * a.TW;
             const bool ok = y_ch[k] < a.Cj;
-            const float* base = a.Q + ((size_t)n0 * HW + (y0 + r) * a.W + x0 + xx) * a.ldq + (ok ? y_ch[k] : 0);
+            const float* base = a.Q + ((size_t)n0 * HW + (y0 + r_) * a.W + x0 + xx) * a.ldq + (ok ? y_ch[k] : 0);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * HW * a.ldq);
-                py[k][q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                r[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -120,42 +120,50 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         *reinterpret_cast<uint4*>(dst + 2 * pitch) = make_uint4(pack_bf16(v[0].z, v[1].z), pack_bf16(v[2].z, v[3].z), pack_bf16(v[4].z, v[5].z), pack_bf16(v[6].z, v[7].z));
         *reinterpret_cast<uint4*>(dst + 3 * pitch) = make_uint4(pack_bf16(v[0].w, v[1].w), pack_bf16(v[2].w, v[3].w), pack_bf16(v[4].w, v[5].w), pack_bf16(v[6].w, v[7].w));
     };
-    auto commit = [&]() {              // registers -> LDS (bf16, image-major 16-byte slots)
+    auto commit_unit = [&](const float4 (&r)[8], int j, int buf) {     // registers -> LDS buffer `buf`
+        uint16_t* base = lds + buf * BUF;
+        if (j < 3) { if (x_pos[j] < PX) put(base + x_dst[j], XP, r); }
+        else put(base + BI * XP + y_dst[j - 3], YP, r);
+    };
+    auto mma_step = [&](int s, int buf) {
+        const uint16_t* Xb = lds + buf * BUF;
+        const uint16_t* Yb = Xb + BI * XP;
+        const int arow = (wi * 64 + (l & 31)) * XP, brow = (wj * (32 * NJ) + (l & 31)) * YP;
+        const int p = 2 * s + (l >> 5);
+        const int r_ = p / a.TW, xx = p - r_ * a.TW;
+        bf16x8 bf[NJ];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (x_pos[k] < PX) put(Xs + x_dst[k], XP, px[k]);
+        for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Yb[brow + j * 32 * YP + p * 8]);
+        const int xa = (r_ * TW2 + xx) * 8;
 #pragma unroll
-        for (int k = 0; k < NJ; ++k) put(Ys + y_dst[k], YP, py[k]);
+        for (int kx = 0; kx < 3; ++kx) {
+            bf16x8 af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&Xb[arow + i * 32 * XP + xa + kx * 8]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[kx][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[kx][i][j], 0, 0, 0);
+        }
     };
 
-    if (cbeg < cend) issue(cbeg);
+    // prologue: first chunk staged synchronously
+    if (cbeg < cend) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { issue_unit(U[0], j, cbeg); commit_unit(U[0], j, cbeg & 1); }
+    }
+    __syncthreads();
     for (int c = cbeg; c < cend; ++c) {
-        __syncthreads();                                // previous chunk's fragment reads are done
-        commit();
-        __syncthreads();
-        if (c + 1 < cend) issue(c + 1);                 // next chunk streams in under the MFMAs
-        // ---- 8 k-steps of 16 = (2 positions) x (8 images); 3 kx taps share the dY fragment
-        const int arow = (wi * 64 + (l & 31)) * XP, brow = (wj * (32 * NJ) + (l & 31)) * YP;
+        const int buf = c & 1;
+        const bool nxt = c + 1 < cend;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int p = 2 * s + (l >> 5);
-            const int r = p / a.TW, xx = p - r * a.TW;
-            bf16x8 bf[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Ys[brow + j * 32 * YP + p * 8]);
-            const int xa = (r * TW2 + xx) * 8;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                bf16x8 af[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&Xs[arow + i * 32 * XP + xa + kx * 8]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[kx][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[kx][i][j], 0, 0, 0);
-            }
+            if (s < NU) issue_unit(U[s % 3], s, c + 1);
+            mma_step(s, buf);
+            if (s >= 2 && s - 2 < NU && nxt) commit_unit(U[(s - 2) % 3], s - 2, buf ^ 1);
         }
+        __syncthreads();
     }
 
 #pragma unroll
@@ -205,20 +213,22 @@ extern "C" int mi_conv3x3_wgrad(const MiWgradDesc* d, const float* P, const floa
     a.TW = a.W >= 16 ? 16 : a.W; a.TH = 16 / a.TW;
     a.tiles_x = a.W / a.TW; a.tiles = a.tiles_x * (a.H / a.TH);
     a.total = (a.N / 8) * a.tiles;
-    const bool wide = d->Cj % 128 == 0 || d->Cj > 256;
+    static const int force_nj = [] { const char* e = getenv("MI_W3_NJ"); return e ? atoi(e) : 0; }();
+    const bool wide = force_nj ? force_nj == 2 : (d->Cj % 128 == 0 || d->Cj > 256);
     const int BJ = wide ? 128 : 64;
     long base = (long)((d->Ci + 127) / 128) * ((d->Cj + BJ - 1) / BJ) * 3;
-    static const long target = [] { const char* e = getenv("MI_W3_BLOCKS"); return e ? atol(e) : 768L; }();
-    long splits = (target + base - 1) / base;
+    // exactly one round of workgroups: the kernel holds ~480 registers per lane, i.e. one workgroup per CU
+    static const long target = [] { const char* e = getenv("MI_W3_BLOCKS"); return e ? atol(e) : 256L; }();
+    long splits = target / base;
     if (splits > a.total) splits = a.total;
     if (splits < 1) splits = 1;
     a.cps = (int)((a.total + splits - 1) / splits);
     a.splits = (a.total + a.cps - 1) / a.cps;
     a.gx = (d->Ci + 127) / 128; a.gy = (d->Cj + BJ - 1) / BJ;
-    dim3 grid((unsigned)(a.gx * a.gy * 3 * ((a.splits + 7) / 8 * 8)));
+    dim3 grid((unsigned)(a.gx * a.gy * 3 * a.splits));
     hipStream_t st = (hipStream_t)stream;
     const int XP = ((a.TH * (a.TW + 2)) | 1) * 8;
-    const size_t lds = (size_t)(128 * XP + BJ * 17 * 8) * 2;
+    const size_t lds = (size_t)(128 * XP + BJ * 17 * 8) * 2 * 2;      // double-buffered
     static bool once = [] {
         (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

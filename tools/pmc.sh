@@ -6,11 +6,9 @@ i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU" \
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum" \
-           "TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_ATOMIC_sum" \
-           "TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE" \
-           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum"; do
+           "TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_ATOMIC_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmc_$tag/s$i -o p -f csv -- python tools/bench_one.py "$@" > /dev/null 2>&1
+  timeout 90 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmc_$tag/s$i -o p -f csv -- python tools/bench_one.py "$@" > /dev/null 2>&1
 done
 python - <<PY
 import csv, collections, glob
@@ -21,8 +19,10 @@ for d in sorted(glob.glob('gpurun_out/pmc_$tag/s*')):
         agg[(r['Kernel_Name'][:60], r['Counter_Name'])][r['Dispatch_Id']] += float(r['Counter_Value'])
     for (k,c),v in sorted(agg.items()):
         if 'at::' in k or 'rocclr' in k: continue
+        if c in ('SQ_BUSY_CYCLES',): continue
         vals=list(v.values())
         print(k[:48], c, round(vals[-1]))
     for r in csv.DictReader(open(d+'/p_kernel_trace.csv')):
-        pass
+        if 'at::' in r['Kernel_Name'] or 'rocclr' in r['Kernel_Name']: continue
+        print('   dur_us', (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3); break
 PY
