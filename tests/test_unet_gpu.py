@@ -257,3 +257,24 @@ def test_ddpm_module_steps():
     sd = model.state_dict()
     assert "denoising_model.final_conv.1.weight" in sd and "diffusion_model.denoise_fn.final_conv.1.weight" in sd
     assert "diffusion_model.posterior_mean_coef2" in sd
+
+
+def test_run_py_end_to_end(tmp_path):
+    """python run.py experiment=ddpm/synthetic ... : compose -> train -> validate (full sampler) -> checkpoint."""
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "image-generation-models_amd")
+    cmd = [sys.executable, os.path.join(pkg, "run.py"), "experiment=ddpm/synthetic", "model.hidden_dim=16", "model.dim_mults=[1,2]",
+           "model.timesteps=8", "datamodule.train_size=256", "datamodule.val_size=64", "datamodule.batch_size=32",
+           "datamodule.width=16", "datamodule.height=16", "trainer.max_epochs=2", "+trainer.precision=bf16-mixed",
+           f"log_dir={tmp_path}", "seed=1", "print_config=False"]
+    r = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run_dir = tmp_path / "runs" / "ddpm" / "synthetic"
+    assert (run_dir / "results" / "0.jpg").exists() and (run_dir / "results" / "1.jpg").exists()
+    ck = torch.load(next((run_dir / "checkpoints").glob("*.ckpt")))
+    keys = set(ck["state_dict"])
+    assert "denoising_model.downs.0.0.block1.block.0.weight" in keys and "diffusion_model.betas" in keys
+    assert ck["state_dict"]["denoising_model.downs.0.0.block1.block.0.weight"].shape == (16, 3, 3, 3)
+    lines = (run_dir / "tensorboard" / "metrics.jsonl").read_text().strip().splitlines()
+    assert lines and "train_loss/loss" in lines[-1]
