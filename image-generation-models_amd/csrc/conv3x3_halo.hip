@@ -36,15 +36,16 @@ template <int BM> struct HaloCfg {
 // the other halo buffer.  Every global load therefore has two taps of MFMA time to land, there
 // is one barrier per tap, and nothing is staged at chunk boundaries.  Taps are unrolled so the
 // two register sets are static.
-template <int BM, int CK>
+template <int BM, int CK, int KS>
 __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const HaloArgs a) {
     constexpr int BN = 128;
+    constexpr int NTAP = KS * KS;                  // 9, or 1 for the 1x1 convolutions (plain GEMM, no halo)
     constexpr int NT = HaloCfg<BM>::NT, MI = HaloCfg<BM>::MI, NI = 2;
     constexpr int PITCH = CK + 8;                  // bf16 elements; 16-B aligned rows, conflict-free b128 reads
-    constexpr int MAXHP = HaloCfg<BM>::MAXHP;
+    constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
     constexpr int Q = CK / 4;                      // float4 per halo pixel per chunk
     constexpr int A_IT = (MAXHP * Q + NT - 1) / NT;
-    constexpr int A_SL = (A_IT + 8) / 9;           // float4 per thread per tap (nine slices cover a halo tile)
+    constexpr int A_SL = (A_IT + NTAP - 1) / NTAP; // float4 per thread per tap (NTAP slices cover a tile)
     constexpr int B_IT = BN * (CK / 8) / NT;       // 16-B loads per thread per tap
 
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -55,14 +56,16 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int wm = wv >> 1, wn = wv & 1;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int W2 = a.W + 2, TH2 = a.TH + 2;
+    const int W2 = a.W + (KS - 1), TH2 = a.TH + (KS - 1);
 
     int img0, y0;
     if (a.TI > 1) { img0 = blockIdx.x * a.TI; y0 = 0; }
     else { img0 = blockIdx.x / a.tiles_per_img; y0 = (blockIdx.x % a.tiles_per_img) * a.TH; }
     for (int hp = t; hp < MAXHP; hp += NT) {
         int v = -1;
-        if (hp < a.HP) {
+        if (KS == 1) {
+            if (m0 + hp < a.N * a.H * a.W) v = m0 + hp;          // 1x1: the tile is BM consecutive pixels
+        } else if (hp < a.HP) {
             int ti = hp / (TH2 * W2);
             int rem = hp - ti * (TH2 * W2);
             int hy = rem / W2, hx = rem - hy * W2;
@@ -78,6 +81,7 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         int r = wm * (MI * 32) + i * 32 + (l & 31);
+        if (KS == 1) { a_row[i] = r * PITCH + (l >> 5) * 8; continue; }
         int tx = r % a.W, q = r / a.W;
         int ty = q % a.TH, ti = q / a.TH;
         a_row[i] = ((ti * TH2 + ty) * W2 + tx) * PITCH + (l >> 5) * 8;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
     float4 ra[2][A_SL];
     uint4 rb[2][B_IT];
     const int nchunks = a.K / CK;
-    const int ntaps = nchunks * 9;
+    const int ntaps = nchunks * NTAP;
 
     // fetch slice `sl` (0..8) of chunk `ch`'s halo tile
     auto load_a = [&](float4 (&r)[A_SL], int ch, int sl) {
@@ -119,15 +123,15 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
 #pragma unroll
         for (int j = 0; j < A_SL; ++j) {
             const int hp = a_hp0 + (sl * A_SL + j) * (NT / Q);
-            if (hp < a.HP)
+            if (hp < (KS == 1 ? MAXHP : a.HP))
                 *reinterpret_cast<uint2*>(&As[buf * (MAXHP * PITCH) + hp * PITCH + a_c4 * 4]) =
                     make_uint2(pack_bf16(r[j].x, r[j].y), pack_bf16(r[j].z, r[j].w));
         }
     };
     auto load_b = [&](uint4 (&r)[B_IT], int g) {
         if (g >= ntaps) return;
-        const int ch = g / 9, tap = g - ch * 9;
-        const int wt = a.flip ? 8 - tap : tap;
+        const int ch = g / NTAP, tap = g - ch * NTAP;
+        const int wt = a.flip ? NTAP - 1 - tap : tap;
         const uint16_t* base = a.w + wt * tap_stride + (size_t)ch * CK + b_k8 * 8;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
             *reinterpret_cast<uint4*>(&Bs[slot * (BN * PITCH) + (b_n + i * (NT / (CK / 8))) * PITCH + b_k8 * 8]) = r[i];
     };
     auto mma_tap = [&](int abuf, int slot, int tap) {
-        const int ky = tap / 3, kx = tap - ky * 3;
+        const int ky = tap / KS, kx = tap - ky * KS;
         const uint16_t* At = As + abuf * (MAXHP * PITCH) + (ky * W2 + kx) * PITCH;
         const uint16_t* Bt = Bs + slot * (BN * PITCH);
 #pragma unroll
@@ -159,28 +163,28 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     };
-    // one chunk; P = parity of its first stage (= chunk & 1 since a chunk has nine stages)
+    // one chunk; P = parity of its first stage (= chunk & 1 since a chunk has an odd number of stages)
     auto chunk = [&](auto parity, int ch) {
         constexpr int P = decltype(parity)::value;
-        const int g0 = ch * 9;
+        const int g0 = ch * NTAP;
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
+        for (int tp = 0; tp < NTAP; ++tp) {
             const int cur = (P + tp) & 1;                  // static after unrolling
             // stage g+2 -> registers `cur` (they were drained into LDS at the end of the previous tap)
             if (cur == 0) { load_b(rb[0], g0 + tp + 2); } else { load_b(rb[1], g0 + tp + 2); }
-            // halo stage g+10 = slice tp+1 of the next chunk (slice 0 of the one after when tp == 8)
-            if (tp < 8) { if (cur == 0) load_a(ra[0], ch + 1, tp + 1); else load_a(ra[1], ch + 1, tp + 1); }
-            else        { if (cur == 0) load_a(ra[0], ch + 2, 0); else load_a(ra[1], ch + 2, 0); }
+            // halo stage g+NTAP+1 = slice tp+1 of the next chunk (slice 0 of the one after at the last tap)
+            if (tp < NTAP - 1) { if (cur == 0) load_a(ra[0], ch + 1, tp + 1); else load_a(ra[1], ch + 1, tp + 1); }
+            else               { if (cur == 0) load_a(ra[0], ch + 2, 0); else load_a(ra[1], ch + 2, 0); }
             mma_tap(P, cur, tp);
-            // stage g+1 -> other weight slot; halo stage g+9 = slice tp of the next chunk -> other halo buffer
+            // stage g+1 -> other weight slot; halo stage g+NTAP = slice tp of the next chunk -> other halo buffer
             if (cur == 0) store_b(1, rb[1]); else store_b(0, rb[0]);
             if (ch + 1 < nchunks) { if (cur == 0) store_a(P ^ 1, ra[1], tp); else store_a(P ^ 1, ra[0], tp); }
             __syncthreads();
         }
     };
 
-    // ---- prologue: chunk 0's halo tile, weight stages 0 (LDS) and 1 (registers), halo stage 9 (registers)
-    for (int sl = 0; sl < 9; ++sl) { load_a(ra[0], 0, sl); store_a(0, ra[0], sl); }
+    // ---- prologue: chunk 0's tile, weight stages 0 (LDS) and 1 (registers), halo stage NTAP (registers)
+    for (int sl = 0; sl < NTAP; ++sl) { load_a(ra[0], 0, sl); store_a(0, ra[0], sl); }
     load_b(rb[0], 0); store_b(0, rb[0]);
     load_b(rb[1], 1);
     load_a(ra[1], 1, 0);
@@ -213,18 +217,18 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
         }
 }
 
-template <int BM, int CK>
+template <int BM, int CK, int KS = 3>
 void launch_halo(const HaloArgs& a, hipStream_t st) {
     constexpr int PITCH = CK + 8;
-    constexpr int MAXHP = HaloCfg<BM>::MAXHP;
+    constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
     size_t lds = (size_t)(2 * MAXHP * PITCH + 2 * 128 * PITCH) * 2 + MAXHP * 4;
     dim3 grid((a.N * a.H * a.W + BM - 1) / BM, (a.Nc + 127) / 128);
     static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK>), grid, dim3(HaloCfg<BM>::NT), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS>), grid, dim3(HaloCfg<BM>::NT), lds, st, a);
 }
 
 // fp32 [tap][k][n] master weights -> bf16 Wd[tap][k][n] (same layout) and Wf[tap][n][k] (transposed per tap)
@@ -274,9 +278,16 @@ static bool halo_geom(const MiConvDesc* d, int BM, int* TH, int* TI) {
 
 // Can the halo kernel take this descriptor?  (3x3, stride 1, pad 1, full-width row tiles)
 static bool halo_ok(const MiConvDesc* d, int* bm, int* ck) {
-    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->mode != 1) return false;
+    const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1, k1 = d->KH == 1 && d->KW == 1 && d->pad == 0;
+    if (!(k3 || k1) || d->stride != 1 || d->mode != 1) return false;
     if (d->IH != d->OH || d->IW != d->OW) return false;
     if (d->K % 32 || d->K1 % 32 || d->Nc % 4) return false;
+    if (k1) {                                  // 1x1: plain GEMM over M = N*H*W pixels, any geometry
+        const long M = (long)d->N * d->OH * d->OW, nt = (d->Nc + 127) / 128;
+        *bm = (M + 255) / 256 * nt >= 200 ? 256 : ((M + 127) / 128 * nt >= 400 ? 128 : 64);
+        *ck = (*bm == 256 && d->K % 64 == 0 && d->K1 % 64 == 0) ? 64 : 32;
+        return true;
+    }
     if (d->OW < 4 || d->OW > 64) return false;
     static const int force = [] { const char* e = getenv("MI_HALO_BM"); return e ? atoi(e) : 0; }();
     const long M = (long)d->N * d->OH * d->OW, nt = (d->Nc + 127) / 128;
@@ -311,10 +322,18 @@ extern "C" int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float
     a.N = d->N; a.H = d->OH; a.W = d->OW; a.K = d->K; a.Nc = d->Nc; a.K1 = d->K1; a.ldx = d->ldx;
     a.ldx2 = x2 ? d->ldx2 : d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.accumulate = d->accumulate;
     a.flip = d->transposed ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->KH == 1) {
+        a.TH = 1; a.TI = 1; a.tiles_per_img = 1; a.HP = BM;
+        if (BM == 256)      { if (CK == 64) launch_halo<256, 64, 1>(a, st); else launch_halo<256, 32, 1>(a, st); }
+        else if (BM == 128) launch_halo<128, 32, 1>(a, st);
+        else                launch_halo<64, 32, 1>(a, st);
+        MI_LAUNCH_CHECK();
+        return 0;
+    }
     MI_REQUIRE(halo_geom(d, BM, &a.TH, &a.TI), "halo tile geometry");
     a.tiles_per_img = a.TI > 1 ? 1 : a.H / a.TH;
     a.HP = a.TI * (a.TH + 2) * (a.W + 2);
-    hipStream_t st = (hipStream_t)stream;
     if (BM == 256)      { if (CK == 64) launch_halo<256, 64>(a, st); else launch_halo<256, 32>(a, st); }
     else if (BM == 128) { if (CK == 64) launch_halo<128, 64>(a, st); else launch_halo<128, 32>(a, st); }
     else                { if (CK == 64) launch_halo<64, 64>(a, st); else launch_halo<64, 32>(a, st); }

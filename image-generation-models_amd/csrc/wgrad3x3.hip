@@ -22,7 +22,7 @@ struct W3Args {
     int gx, gy;
 };
 
-template <int NJ>
+template <int NJ, int KS>
 __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
     constexpr int BI = 128, BJ = 32 * 2 * NJ;
     constexpr int YP = 17 * 8;                          // dY pitch per co row (bf16 elems): 16 slots + 1 pad
@@ -31,22 +31,23 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int wi = wv >> 1, wj = wv & 1;
     // 1-D grid, one workgroup per CU (the kernel runs one wave per SIMD): b -> (k-slice, ky, ci-tile, co-tile)
-    const int gsz = a.gx * a.gy * 3;
+    const int gsz = a.gx * a.gy * KS;
     const int split = blockIdx.x / gsz;
     const int within = blockIdx.x % gsz;
-    const int ky = within % 3, txy = within / 3;
+    const int ky = within % KS, txy = within / KS;
     const int ci0 = (txy % a.gx) * BI, co0 = (txy / a.gx) * BJ;
-    const int TW2 = a.TW + 2;
-    const int PX = a.TH * TW2;                          // X positions per chunk (18, 20 or 24)
+    constexpr int NUX = KS == 3 ? 3 : 2;                // X staging units per wave (= position groups of 8)
+    const int TW2 = a.TW + (KS - 1);
+    const int PX = a.TH * TW2;                          // X positions per chunk (18, 20 or 24; 16 for 1x1)
     const int XP = (PX | 1) * 8;                        // odd slot count -> conflict-free fragment reads
     const int npg = (PX + 7) / 8;                       // position groups of 8
     uint16_t* Xs = lds;
     uint16_t* Ys = lds + BI * XP;
     const int HW = a.H * a.W;
 
-    f32x16 acc[3][2][NJ];
+    f32x16 acc[KS][2][NJ];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < KS; ++k)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -59,11 +60,11 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
 
     // ---- staging assignment (fixed per thread): 3 X units and NJ dY units per wave;
     //      unit = (8 positions) x (32 channels), one float4 per image per lane
-    int x_pos[3], x_ch[3], x_dst[3];
+    int x_pos[NUX], x_ch[NUX], x_dst[NUX];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < NUX; ++k) {
         const int u = wv + 4 * k;
-        const int pg = u % 3, cg = u / 3;
+        const int pg = u % NUX, cg = u / NUX;
         x_pos[k] = pg * 8 + hp_sub;
         x_ch[k] = ci0 + cg * 32 + c4 * 4;
         x_dst[k] = (cg * 32 + c4 * 4) * XP + x_pos[k] * 8;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
     // cores out of buffer c&1, the wave's 3+NJ staging units of chunk c+1 are fetched (one unit per
     // k-step, three register sets in flight => two k-steps of MFMA time per load) and written to the
     // other buffer.  One barrier per chunk (96 MFMAs per wave at NJ = 2).
-    constexpr int NU = 3 + NJ;
+    constexpr int NU = NUX + NJ;
     float4 U[3][8];
     const int BUF = BI * XP + BJ * YP;                 // bf16 elements per LDS buffer
 
@@ -90,9 +91,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         const int g = c / a.tiles, tile = c - g * a.tiles;
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int y0 = ty * a.TH, x0 = tx * a.TW, n0 = g * 8;
-        if (j < 3) {
+        if (j < NUX) {
             const int r_ = x_pos[j] / TW2, xx = x_pos[j] - r_ * TW2;
-            const int iy = y0 + r_ + ky - 1, ix = x0 + xx - 1;
+            const int iy = y0 + r_ + ky - KS / 2, ix = x0 + xx - KS / 2;
             const bool ok = x_pos[j] < PX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && x_ch[j] < a.Ci;
             const float* src = a.P; int ld = a.ldp; int cc = x_ch[j];
             if (cc >= a.I1) { src = a.P2; ld = a.ldp2; cc -= a.I1; }
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
                 r[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
-            const int k = j - 3;
+            const int k = j - NUX;
             const int r_ = y_pos[k] / a.TW, xx = y_pos[k] - r_ * a.TW;
             const bool ok = y_ch[k] < a.Cj;
             const float* base = a.Q + ((size_t)n0 * HW + (y0 + r_) * a.W + x0 + xx) * a.ldq + (ok ? y_ch[k] : 0);
@@ -122,8 +123,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
     };
     auto commit_unit = [&](const float4 (&r)[8], int j, int buf) {     // registers -> LDS buffer `buf`
         uint16_t* base = lds + buf * BUF;
-        if (j < 3) { if (x_pos[j] < PX) put(base + x_dst[j], XP, r); }
-        else put(base + BI * XP + y_dst[j - 3], YP, r);
+        if (j < NUX) { if (x_pos[j] < PX) put(base + x_dst[j], XP, r); }
+        else put(base + BI * XP + y_dst[j - NUX], YP, r);
     };
     auto mma_step = [&](int s, int buf) {
         const uint16_t* Xb = lds + buf * BUF;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Yb[brow + j * 32 * YP + p * 8]);
         const int xa = (r_ * TW2 + xx) * 8;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
+        for (int kx = 0; kx < KS; ++kx) {
             bf16x8 af[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&Xb[arow + i * 32 * XP + xa + kx * 8]);
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
     }
 
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-        float* out = a.dW + (size_t)(ky * 3 + kx) * a.Ci * a.Cj;
+    for (int kx = 0; kx < KS; ++kx) {
+        float* out = a.dW + (size_t)(ky * KS + kx) * a.Ci * a.Cj;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
 }  // namespace
 
 static bool w3_ok(const MiWgradDesc* d) {
-    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || !d->gather_i || d->mode != 1) return false;
+    const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1, k1 = d->KH == 1 && d->KW == 1 && d->pad == 0;
+    if (!(k3 || k1) || d->stride != 1 || !d->gather_i || d->mode != 1) return false;
     if (d->GH != d->DH || d->GW != d->DW) return false;
     if (d->N % 8 || d->Ci % 32 || d->Cj % 32 || d->I1 % 32) return false;
     int W = d->DW, H = d->DH;
@@ -216,7 +218,8 @@ extern "C" int mi_conv3x3_wgrad(const MiWgradDesc* d, const float* P, const floa
     static const int force_nj = [] { const char* e = getenv("MI_W3_NJ"); return e ? atoi(e) : 0; }();
     const bool wide = force_nj ? force_nj == 2 : (d->Cj % 128 == 0 || d->Cj > 256);
     const int BJ = wide ? 128 : 64;
-    long base = (long)((d->Ci + 127) / 128) * ((d->Cj + BJ - 1) / BJ) * 3;
+    const int KS = d->KH;
+    long base = (long)((d->Ci + 127) / 128) * ((d->Cj + BJ - 1) / BJ) * KS;
     // exactly one round of workgroups: the kernel holds ~480 registers per lane, i.e. one workgroup per CU
     static const long target = [] { const char* e = getenv("MI_W3_BLOCKS"); return e ? atol(e) : 256L; }();
     long splits = target / base;
@@ -225,18 +228,25 @@ extern "C" int mi_conv3x3_wgrad(const MiWgradDesc* d, const float* P, const floa
     a.cps = (int)((a.total + splits - 1) / splits);
     a.splits = (a.total + a.cps - 1) / a.cps;
     a.gx = (d->Ci + 127) / 128; a.gy = (d->Cj + BJ - 1) / BJ;
-    dim3 grid((unsigned)(a.gx * a.gy * 3 * a.splits));
+    dim3 grid((unsigned)(a.gx * a.gy * KS * a.splits));
     hipStream_t st = (hipStream_t)stream;
-    const int XP = ((a.TH * (a.TW + 2)) | 1) * 8;
+    const int XP = ((a.TH * (a.TW + KS - 1)) | 1) * 8;
     const size_t lds = (size_t)(128 * XP + BJ * 17 * 8) * 2 * 2;      // double-buffered
     static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)once;
-    if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2>), grid, dim3(256), lds, st, a);
-    else      hipLaunchKernelGGL((wgrad3x3_kernel<1>), grid, dim3(256), lds, st, a);
+    if (KS == 3) {
+        if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2, 3>), grid, dim3(256), lds, st, a);
+        else      hipLaunchKernelGGL((wgrad3x3_kernel<1, 3>), grid, dim3(256), lds, st, a);
+    } else {
+        if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2, 1>), grid, dim3(256), lds, st, a);
+        else      hipLaunchKernelGGL((wgrad3x3_kernel<1, 1>), grid, dim3(256), lds, st, a);
+    }
     MI_LAUNCH_CHECK();
     return 0;
 }

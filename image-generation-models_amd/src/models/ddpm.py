@@ -407,8 +407,8 @@ class Unet(nn.Module):
         def conv(inp, pre, k, stride=1, pad=0, x2=None, residual=None, transposed_conv=False, bias=True):
             w = sv[pre + "weight"]
             kh, kw, ci, co = w.shape
-            if mode == K.MODE_BF16 and k == 3 and stride == 1 and not transposed_conv:
-                y = K.conv3x3_bf16w(inp, wf_sh[offs[pre + "weight"]:], K=ci, Nc=co, flip=False, x2=x2,
+            if mode == K.MODE_BF16 and k in (1, 3) and stride == 1 and not transposed_conv:
+                y = K.conv3x3_bf16w(inp, wf_sh[offs[pre + "weight"]:], K=ci, Nc=co, flip=False, ksize=k, x2=x2,
                                     bias=sv[pre + "bias"] if bias else None, residual=residual)
                 if y is not None:
                     return y
@@ -511,10 +511,10 @@ class Unet(nn.Module):
                 K.colsum(dy, gv[pre + "bias"])
             if not want_dx:
                 return
-            fast = mode == K.MODE_BF16 and k == 3 and stride == 1 and not transposed_conv
+            fast = mode == K.MODE_BF16 and k in (1, 3) and stride == 1 and not transposed_conv
             if x2 is None:
                 buf, acc = G.target(inp)
-                if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, out=buf,
+                if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, ksize=k, out=buf,
                                             accumulate=acc) is not None:
                     return
                 K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=not transposed_conv, w_kn=False,
@@ -526,7 +526,7 @@ class Unet(nn.Module):
                 if cat is None:
                     cat = torch.empty((B, ih, iw, ci), device=dy.device, dtype=torch.float32)
                     G._g[("cat", id(inp))] = cat
-                if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, out=cat,
+                if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, ksize=k, out=cat,
                                             accumulate=acc) is not None:
                     return
                 K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=True, w_kn=False,

@@ -82,14 +82,14 @@ def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mo
     return out
 
 
-def conv3x3_bf16w(x, wsh, *, K, Nc, flip, x2=None, bias=None, residual=None, out=None, accumulate=False):
-    """3x3/s1/p1 conv (flip=False) or its data gradient (flip=True) through the halo-tile kernel.
-    wsh: bf16 weights [3][3][Nc][K].  Returns None when the shape is not supported."""
+def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=None, out=None, accumulate=False):
+    """3x3/s1/p1 (or 1x1) conv (flip=False) or its data gradient (flip=True) through the pipelined
+    LDS-tile kernel.  wsh: bf16 weights [k][k][Nc][K].  Returns None when the shape is not supported."""
     _need_gpu(x)
     N, H, W, K1 = x.shape
     if x2 is None:
         K1 = K
-    d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=int(flip),
+    d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=ksize, KW=ksize, stride=1, pad=ksize // 2, transposed=int(flip),
                    w_kn=0, mode=MODE_BF16, K1=K1, ldx=ld_of(x), ldx2=ld_of(x2) if x2 is not None else 0, ldy=0,
                    ldr=ld_of(residual) if residual is not None else 0, accumulate=int(accumulate))
     lib = load_library()
@@ -106,7 +106,7 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, x2=None, bias=None, residual=None, out
           "mi_conv3x3_bf16w")
     if PROBE is not None:
         e1.record()
-        PROBE.append(("conv3x3_halo_kernel", 2.0 * N * H * W * Nc * K * 9, e0, e1))
+        PROBE.append((f"conv3x3_halo_kernel<KS={ksize}>", 2.0 * N * H * W * Nc * K * ksize * ksize, e0, e1))
     return out
 
 

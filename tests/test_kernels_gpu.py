@@ -416,3 +416,61 @@ def test_conv3x3_wgrad_fast(K, cfg):
     wq = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(xq, wq, None, padding=1).backward(dq)
     assert rel_err(got, wq.grad) < 2e-5          # same bf16-rounded operands: only summation order differs
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=8, H=32, Ci=128, Co=384),             # to_qkv at level 0 (256-pixel tiles)
+    dict(N=2, H=16, Ci=256, Co=128, split=128),  # res_conv on the skip concat
+    dict(N=3, H=7, Ci=64, Co=96),                # ragged M (147 pixels) and ragged N tile
+    dict(N=4, H=8, Ci=128, Co=512, residual=True),
+])
+def test_conv1x1_bf16w_fwd_and_dgrad(K, cfg):
+    """1x1 convs (to_qkv / to_out / res_conv, ddpm.py:134,151-152) and their dgrad through the pipelined kernel."""
+    N, H, Ci, Co = cfg["N"], cfg["H"], cfg["Ci"], cfg["Co"]
+    split = cfg.get("split")
+    g = torch.Generator().manual_seed(37)
+    x = torch.randn(N, Ci, H, H, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Co, Ci, 1, 1, generator=g, dtype=torch.float64) / math.sqrt(Ci)).requires_grad_(True)
+    b = torch.randn(Co, generator=g, dtype=torch.float64)
+    r = torch.randn(N, Co, H, H, generator=g, dtype=torch.float64) if cfg.get("residual") else None
+    y = F.conv2d(x, w, b) + (r if r is not None else 0)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    flat, wd, wf, offs = _pack(K, [conv_w_storage(w.detach())])
+    if split:
+        xa, xb = to_nhwc_gpu(x.detach()[:, :split].float()), to_nhwc_gpu(x.detach()[:, split:].float())
+    else:
+        xa, xb = to_nhwc_gpu(x.detach().float()), None
+    yg = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Co, flip=False, ksize=1, x2=xb, bias=b.float().to(DEV),
+                         residual=to_nhwc_gpu(r.float()) if r is not None else None)
+    assert yg is not None
+    dxg = K.conv3x3_bf16w(to_nhwc_gpu(dy.float()), wd, K=Co, Nc=Ci, flip=True, ksize=1)
+    torch.cuda.synchronize()
+    xq, wq = x.detach().float().bfloat16().double(), w.detach().float().bfloat16().double()
+    yq = F.conv2d(xq, wq, b) + (r if r is not None else 0)
+    assert rel_err(from_nhwc(yg), yq) < 1e-5 and rel_err(from_nhwc(yg), y) < 2e-2
+    assert rel_err(from_nhwc(dxg), x.grad) < 2e-2
+
+
+@pytest.mark.parametrize("cfg", [dict(N=8, H=32, Ci=128, Co=384), dict(N=16, H=8, Ci=512, Co=128),
+                                 dict(N=8, H=16, Ci=256, Co=64, split=128), dict(N=8, H=4, Ci=32, Co=96)])
+def test_conv1x1_wgrad_fast(K, cfg):
+    """Weight gradient of the 1x1 convs through the image-major MFMA kernel."""
+    N, H, Ci, Co = cfg["N"], cfg["H"], cfg["Ci"], cfg["Co"]
+    split = cfg.get("split")
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(N, Ci, H, H, generator=g, dtype=torch.float64)
+    dy = torch.randn(N, Co, H, H, generator=g, dtype=torch.float64)
+    xq, dq = x.float().bfloat16().double(), dy.float().bfloat16().double()
+    ref = torch.einsum("nchw,nkhw->kc", xq, dq)[:, :, None, None]          # [Co,Ci,1,1]
+    dW = torch.zeros(Ci * Co, device=DEV)
+    P, P2 = (to_nhwc_gpu(x[:, :split].float()), to_nhwc_gpu(x[:, split:].float())) if split else (to_nhwc_gpu(x.float()), None)
+    from src.ops.lib import MiWgradDesc, load_library
+    import ctypes
+    d = MiWgradDesc(N=N, GH=H, GW=H, DH=H, DW=H, Ci=Ci, Cj=Co, KH=1, KW=1, stride=1, pad=0, gather_i=1, mode=1,
+                    I1=split or Ci, ldp=4, ldp2=4, ldq=4)
+    assert load_library().mi_conv3x3_wgrad_supported(ctypes.byref(d)) == 1
+    K.conv_wgrad(P, to_nhwc_gpu(dy.float()), dW, kh=1, kw=1, stride=1, pad=0, gather_i=True, Ci=Ci, Cj=Co,
+                 grid_g=(H, H), grid_d=(H, H), mode=1, P2=P2)
+    torch.cuda.synchronize()
+    assert rel_err(w_from_storage(dW.view(1, 1, Ci, Co)), ref) < 2e-5

@@ -48,8 +48,12 @@ def main():
         x = torch.randn(B, H, H, Ci, device=DEV); w = torch.randn(1, 1, Ci, Co, device=DEV)
         y = torch.empty(B, H, H, Co, device=DEV)
         t = timeit(lambda: K.conv_igemm(x, w, kh=1, kw=1, stride=1, pad=0, transposed=False, w_kn=True, K=Ci, Nc=Co, out_hw=(H, H), mode=1, out=y))
+        wf = w.permute(0, 1, 3, 2).contiguous().to(torch.bfloat16).reshape(-1)
+        t2 = timeit(lambda: K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, ksize=1, out=y))
+        dW = torch.zeros(Ci * Co, device=DEV)
+        t3 = timeit(lambda: K.conv_wgrad(x, y, dW, kh=1, kw=1, stride=1, pad=0, gather_i=True, Ci=Ci, Cj=Co, grid_g=(H, H), grid_d=(H, H), mode=1))
         fl = 2.0 * B * H * H * Ci * Co
-        print(f"B{B} 1x1 {H}x{H} {Ci}->{Co}: {t*1e6:7.1f}us {fl/t/1e12:6.1f}TF  {(x.numel()+y.numel())*4/t/1e9:7.0f}GB/s", flush=True)
+        print(f"B{B} 1x1 {H}x{H} {Ci}->{Co}: igemm {t*1e6:7.1f}us {fl/t/1e12:6.1f}TF | tile {t2*1e6:7.1f}us {fl/t2/1e12:6.1f}TF {(x.numel()+y.numel())*4/t2/1e9:6.0f}GB/s | wgrad {t3*1e6:7.1f}us {fl/t3/1e12:6.1f}TF", flush=True)
     for H, C in [(32, 128), (16, 256), (8, 512)]:
         x = torch.randn(B, H, H, C, device=DEV); ga = torch.ones(C, device=DEV); be = torch.zeros(C, device=DEV)
         t = timeit(lambda: K.gn_mish_fwd(x, ga, be))
