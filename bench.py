@@ -170,7 +170,7 @@ def main():
             train_step(i)
         torch.cuda.synchronize()
         agg = {}
-        for sym, flops, e0, e1 in K.PROBE:
+        for sym, flops, e0, e1, _desc in K.PROBE:
             a = agg.setdefault(sym, [0.0, 0.0, 0])
             a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
         K.PROBE = None

@@ -18,6 +18,7 @@ namespace {
 struct HaloArgs {
     const float* x; const float* x2; const uint16_t* w; const float* bias; const float* res; float* y;
     int N, H, W, K, Nc, K1, ldx, ldx2, ldy, ldr, accumulate, flip;
+    int ksplit;          // K (channel-chunk) slices, gridDim.z; > 1 => results are combined with atomics
     int TH, TI;          // tile = TI images x TH rows x W columns (BM = TI*TH*W)
     int HP;              // halo pixels = TI*(TH+2)*(W+2)
     int tiles_per_img;   // H/TH when TI == 1
@@ -102,13 +103,17 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
 
     float4 ra[2][A_SL];
     uint4 rb[2][B_IT];
-    const int nchunks = a.K / CK;
+    // this workgroup's slice of the channel chunks [ch0, ch0 + nchunks)
+    const int allchunks = a.K / CK;
+    const int per = (allchunks + a.ksplit - 1) / a.ksplit;
+    const int ch0 = blockIdx.z * per;
+    const int nchunks = max(0, min(allchunks, ch0 + per) - ch0);
     const int ntaps = nchunks * NTAP;
 
     // fetch slice `sl` (0..8) of chunk `ch`'s halo tile
     auto load_a = [&](float4 (&r)[A_SL], int ch, int sl) {
         if (ch >= nchunks) return;
-        const int kc = ch * CK;
+        const int kc = (ch0 + ch) * CK;
         const float* src = a.x; int ld = a.ldx; int cc = kc;
         if (kc >= a.K1) { src = a.x2; ld = a.ldx2; cc = kc - a.K1; }
 #pragma unroll
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
         if (g >= ntaps) return;
         const int ch = g / NTAP, tap = g - ch * NTAP;
         const int wt = a.flip ? NTAP - 1 - tap : tap;
-        const uint16_t* base = a.w + wt * tap_stride + (size_t)ch * CK + b_k8 * 8;
+        const uint16_t* base = a.w + wt * tap_stride + (size_t)(ch0 + ch) * CK + b_k8 * 8;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int n = n0 + b_n + i * (NT / (CK / 8));
@@ -160,7 +165,9 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    // weights as the MFMA "A" operand: D rows = output channels, D cols = pixels, so a lane
+                    // ends up with 4 consecutive channels of one pixel per register quad -> 16-byte epilogue
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
     };
     // one chunk; P = parity of its first stage (= chunk & 1 since a chunk has an odd number of stages)
@@ -194,27 +201,31 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
         if (ch + 1 < nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
     }
 
-    // ---- epilogue
+    // ---- epilogue: lane = pixel (l & 31), register quad rq = channels 8*rq + 4*(l >> 5) .. +3
     const int Mtot = a.N * a.H * a.W;
+    const bool first = blockIdx.z == 0;                 // split-K: slice 0 carries bias and residual
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
+        const size_t m = (size_t)m0 + wm * (MI * 32) + i * 32 + (l & 31);
+        if (m >= (size_t)Mtot) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-            size_t m = (size_t)m0 + row;
-            if (m >= (size_t)Mtot) continue;
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                int col = n0 + wn * 64 + j * 32 + (l & 31);
-                if (col >= a.Nc) continue;
-                float v = acc[i][j][r];
-                if (a.bias) v += a.bias[col];
-                if (a.res) v += a.res[m * a.ldr + col];
+            for (int rq = 0; rq < 4; ++rq) {
+                const int col = n0 + wn * 64 + j * 32 + 8 * rq + 4 * (l >> 5);
+                if (col >= a.Nc) continue;              // Nc % 4 == 0: a quad is all in or all out
+                float4 v = make_float4(acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]);
+                if (a.bias && first) { float4 b = *reinterpret_cast<const float4*>(a.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                if (a.res && first) { float4 r = *reinterpret_cast<const float4*>(a.res + m * a.ldr + col); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
                 float* yp = a.y + m * a.ldy + col;
-                if (a.accumulate) v += *yp;
-                *yp = v;
+                if (a.ksplit > 1) {
+                    atomicAdd(yp, v.x); atomicAdd(yp + 1, v.y); atomicAdd(yp + 2, v.z); atomicAdd(yp + 3, v.w);
+                } else {
+                    if (a.accumulate) { float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *reinterpret_cast<float4*>(yp) = v;
+                }
             }
-        }
+    }
 }
 
 template <int BM, int CK, int KS = 3>
@@ -222,7 +233,7 @@ void launch_halo(const HaloArgs& a, hipStream_t st) {
     constexpr int PITCH = CK + 8;
     constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
     size_t lds = (size_t)(2 * MAXHP * PITCH + 2 * 128 * PITCH) * 2 + MAXHP * 4;
-    dim3 grid((a.N * a.H * a.W + BM - 1) / BM, (a.Nc + 127) / 128);
+    dim3 grid((a.N * a.H * a.W + BM - 1) / BM, (a.Nc + 127) / 128, a.ksplit);
     static bool once = [] {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
@@ -323,6 +334,27 @@ extern "C" int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float
     a.ldx2 = x2 ? d->ldx2 : d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.accumulate = d->accumulate;
     a.flip = d->transposed ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
+    // split-K when even the chosen tile leaves most CUs idle (8x8 levels, small batches): slices are
+    // combined with fp32 atomics into a zeroed (or, for accumulate, the existing) output
+    a.ksplit = 1;
+    {
+        static const int force_ks = [] { const char* e = getenv("MI_HALO_KSPLIT"); return e ? atoi(e) : 0; }();
+        const long blocks = ((long)d->N * d->OH * d->OW + BM - 1) / BM * ((d->Nc + 127) / 128);
+        const int chunks = d->K / CK;
+        int ks = 1;
+        const long want = BM == 256 ? 200 : 400;
+        // measured: the pixel-major epilogue makes poorly coalesced atomics (32 rows x 32 B per wave
+        // instruction); split-K lost on every cfg-2 shape, so it is off unless forced for experiments
+        (void)want; (void)blocks;
+        if (force_ks) ks = force_ks <= chunks ? force_ks : 1;
+        if (ks > 1 && (d->accumulate || d->ldy == d->Nc)) {
+            a.ksplit = ks;
+            if (!d->accumulate) {
+                hipError_t e = hipMemsetAsync(y, 0, (size_t)d->N * d->OH * d->OW * d->ldy * sizeof(float), st);
+                if (e != hipSuccess) return mi_set_error((int)e, "mi_conv3x3_bf16w: memset: %s", hipGetErrorString(e));
+            }
+        }
+    }
     if (d->KH == 1) {
         a.TH = 1; a.TI = 1; a.tiles_per_img = 1; a.HP = BM;
         if (BM == 256)      { if (CK == 64) launch_halo<256, 64, 1>(a, st); else launch_halo<256, 32, 1>(a, st); }

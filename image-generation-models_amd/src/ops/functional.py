@@ -78,7 +78,8 @@ def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mo
           "mi_conv_igemm")
     if PROBE is not None:
         e1.record()
-        PROBE.append((f"igemm_kernel<{mode},{bm.value},{bn.value}>", flops, e0, e1))
+        PROBE.append((f"igemm_kernel<{mode},{bm.value},{bn.value}>", flops, e0, e1,
+                      f"N{N} {IH}x{IW}->{OH}x{OW} K{K}->{Nc} k{kh} s{stride} T{int(transposed)} acc{int(accumulate)}"))
     return out
 
 
@@ -106,7 +107,8 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
           "mi_conv3x3_bf16w")
     if PROBE is not None:
         e1.record()
-        PROBE.append((f"conv3x3_halo_kernel<KS={ksize}>", 2.0 * N * H * W * Nc * K * ksize * ksize, e0, e1))
+        PROBE.append((f"conv3x3_halo_kernel<KS={ksize}>", 2.0 * N * H * W * Nc * K * ksize * ksize, e0, e1,
+                      f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}"))
     return out
 
 
@@ -134,7 +136,8 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
         check(lib.mi_conv_wgrad(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _stream()), "mi_conv_wgrad")
     if PROBE is not None:
         e1.record()
-        PROBE.append(("wgrad3x3_kernel" if fast else f"wgrad_kernel<{mode}>", 2.0 * N * grid_d[0] * grid_d[1] * Ci * Cj * kh * kw, e0, e1))
+        PROBE.append(("wgrad3x3_kernel" if fast else f"wgrad_kernel<{mode}>", 2.0 * N * grid_d[0] * grid_d[1] * Ci * Cj * kh * kw, e0, e1,
+                      f"N{N} {grid_d[0]}x{grid_d[1]} Ci{Ci}{'(2src)' if P2 is not None else ''} Cj{Cj} k{kh} s{stride} g{int(gather_i)}"))
 
 
 def _rows(x):
