@@ -37,7 +37,7 @@ template <int BM> struct HaloCfg {
 // the other halo buffer.  Every global load therefore has two taps of MFMA time to land, there
 // is one barrier per tap, and nothing is staged at chunk boundaries.  Taps are unrolled so the
 // two register sets are static.
-template <int BM, int CK, int KS>
+template <int BM, int CK, int KS, bool SK = false>
 __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const HaloArgs a) {
     constexpr int BN = 128;
     constexpr int NTAP = KS * KS;                  // 9, or 1 for the 1x1 convolutions (plain GEMM, no halo)
@@ -167,7 +167,9 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
                 for (int j = 0; j < NI; ++j)
                     // weights as the MFMA "A" operand: D rows = output channels, D cols = pixels, so a lane
                     // ends up with 4 consecutive channels of one pixel per register quad -> 16-byte epilogue
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                    // (the split-K variant keeps pixels as rows: its atomics then cover 128-byte row segments)
+                    acc[i][j] = SK ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
     };
     // one chunk; P = parity of its first stage (= chunk & 1 since a chunk has an odd number of stages)
@@ -204,6 +206,28 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
     // ---- epilogue: lane = pixel (l & 31), register quad rq = channels 8*rq + 4*(l >> 5) .. +3
     const int Mtot = a.N * a.H * a.W;
     const bool first = blockIdx.z == 0;                 // split-K: slice 0 carries bias and residual
+    if constexpr (SK) {
+        // rows = pixels, lanes 0..31 = 32 consecutive channels: one atomic instruction = two 128-byte rows
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t m = (size_t)m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                if (m >= (size_t)Mtot) continue;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int col = n0 + wn * 64 + j * 32 + (l & 31);
+                    if (col >= a.Nc) continue;
+                    float v = acc[i][j][r];
+                    if (first) {
+                        if (a.bias) v += a.bias[col];
+                        if (a.res) v += a.res[m * a.ldr + col];
+                    }
+                    atomicAdd(a.y + m * a.ldy + col, v);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const size_t m = (size_t)m0 + wm * (MI * 32) + i * 32 + (l & 31);
@@ -218,28 +242,24 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
                 if (a.bias && first) { float4 b = *reinterpret_cast<const float4*>(a.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
                 if (a.res && first) { float4 r = *reinterpret_cast<const float4*>(a.res + m * a.ldr + col); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
                 float* yp = a.y + m * a.ldy + col;
-                if (a.ksplit > 1) {
-                    atomicAdd(yp, v.x); atomicAdd(yp + 1, v.y); atomicAdd(yp + 2, v.z); atomicAdd(yp + 3, v.w);
-                } else {
-                    if (a.accumulate) { float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                    *reinterpret_cast<float4*>(yp) = v;
-                }
+                if (a.accumulate) { float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *reinterpret_cast<float4*>(yp) = v;
             }
     }
 }
 
-template <int BM, int CK, int KS = 3>
+template <int BM, int CK, int KS = 3, bool SK = false>
 void launch_halo(const HaloArgs& a, hipStream_t st) {
     constexpr int PITCH = CK + 8;
     constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
     size_t lds = (size_t)(2 * MAXHP * PITCH + 2 * 128 * PITCH) * 2 + MAXHP * 4;
     dim3 grid((a.N * a.H * a.W + BM - 1) / BM, (a.Nc + 127) / 128, a.ksplit);
     static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS>), grid, dim3(HaloCfg<BM>::NT), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS, SK>), grid, dim3(HaloCfg<BM>::NT), lds, st, a);
 }
 
 // fp32 [tap][k][n] master weights -> bf16 Wd[tap][k][n] (same layout) and Wf[tap][n][k] (transposed per tap)
@@ -334,6 +354,30 @@ extern "C" int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float
     a.ldx2 = x2 ? d->ldx2 : d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.accumulate = d->accumulate;
     a.flip = d->transposed ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
+    // Small-M layers (8x8 levels): a 256-pixel x 64-channel-chunk tile with the K loop split over
+    // 2-4 workgroups beats 64-pixel tiles (weights are re-read per M tile); slices are summed with
+    // row-coalesced fp32 atomics.
+    if (d->KH == 3 && BM < 256 && d->K % 64 == 0 && d->K1 % 64 == 0 && (d->accumulate || d->ldy == d->Nc)) {
+        static const int allow = [] { const char* e = getenv("MI_HALO_SPLITK"); return e ? atoi(e) : 1; }();
+        int th, ti;
+        const long b256 = ((long)d->N * d->OH * d->OW + 255) / 256 * ((d->Nc + 127) / 128);
+        const int chunks = d->K / 64;
+        if (allow && chunks >= 8 && halo_geom(d, 256, &th, &ti) && b256 >= 32) {   // measured: loses for K < 512
+            int ks = 2;
+            while (b256 * ks < 200 && ks * 4 <= chunks && ks < 8) ks *= 2;             // >= 2 chunks per slice
+            if (ks * 2 <= chunks) {
+                a.TH = th; a.TI = ti; a.tiles_per_img = ti > 1 ? 1 : a.H / th; a.HP = ti * (th + 2) * (a.W + 2);
+                a.ksplit = ks;
+                if (!d->accumulate) {
+                    hipError_t e = hipMemsetAsync(y, 0, (size_t)d->N * d->OH * d->OW * d->ldy * sizeof(float), st);
+                    if (e != hipSuccess) return mi_set_error((int)e, "mi_conv3x3_bf16w: memset: %s", hipGetErrorString(e));
+                }
+                launch_halo<256, 64, 3, true>(a, st);
+                MI_LAUNCH_CHECK();
+                return 0;
+            }
+        }
+    }
     // split-K when even the chosen tile leaves most CUs idle (8x8 levels, small batches): slices are
     // combined with fp32 atomics into a zeroed (or, for accumulate, the existing) output
     a.ksplit = 1;
@@ -343,8 +387,6 @@ extern "C" int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float
         const int chunks = d->K / CK;
         int ks = 1;
         const long want = BM == 256 ? 200 : 400;
-        // measured: the pixel-major epilogue makes poorly coalesced atomics (32 rows x 32 B per wave
-        // instruction); split-K lost on every cfg-2 shape, so it is off unless forced for experiments
         (void)want; (void)blocks;
         if (force_ks) ks = force_ks <= chunks ? force_ks : 1;
         if (ks > 1 && (d->accumulate || d->ldy == d->Nc)) {
