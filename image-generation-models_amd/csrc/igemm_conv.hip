@@ -21,6 +21,7 @@ struct IgemmArgs {
     int OHc, OWc;     // per-parity-class output grid (== OH, OW unless transposed with stride > 1)
     int Mc;           // rows per class
     int vecA, vecB;   // 16-byte vector loads legal for activations / weights
+    int ksplit;       // slices of the channel axis (blockIdx.z = class * ksplit + slice); > 1 => atomic epilogue
 };
 
 template <int MODE> struct LdsElem { using type = float; static constexpr int PITCH = 36; };
@@ -57,8 +58,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int wm = wv >> 1, wn = wv & 1;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int s = a.stride;
-    const int cls = blockIdx.z;
+    const int cls = blockIdx.z / a.ksplit, slice = blockIdx.z % a.ksplit;
     const int py = a.transposed ? cls / s : 0, px = a.transposed ? cls % s : 0;
+    // channel range of this k-slice (multiples of 32)
+    const int kper = ((a.K + 31) / 32 + a.ksplit - 1) / a.ksplit * 32;
+    const int kbeg = slice * kper, kend = min(a.K, kbeg + kper);
 
     // ---- per-thread A rows: decode once ------------------------------------------------
     const int ac4 = t & 7;                 // which float4 of the 32-channel chunk
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     }
 
     // ---- K-walk state (uniform) -----------------------------------------------------------
-    int ky = 0, kx = -1, kc = 0;
+    int ky = 0, kx = -1, kc = kbeg;
     auto tap_ok = [&](int y, int x) -> bool {
         if (!a.transposed) return true;
         return ((py + a.pad - y + s * a.KH) % s) == 0 && ((px + a.pad - x + s * a.KW) % s) == 0;
@@ -188,14 +192,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    bool more = next_tap();
+    bool more = kbeg < kend && next_tap();
     if (more) { load_step(); store_step(); }
     __syncthreads();
 
     while (more) {
         // advance to the next (tap, channel chunk) and prefetch it into registers
         kc += 32;
-        if (kc >= a.K) { kc = 0; more = next_tap(); }
+        if (kc >= kend) { kc = kbeg; more = next_tap(); }
         if (more) load_step();
 
         const int arow = wm * WM + (l & 31), brow = wn * WN + (l & 31), kh = l >> 5;
@@ -255,9 +259,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
                 int col = n0 + wn * WN + j * 32 + (l & 31);
                 if (col >= a.Nc) continue;
                 float v = acc[i][j][r];
+                float* yp = a.y + opix * a.ldy + col;
+                if (a.ksplit > 1) {                     // output was zeroed (or holds the value to add to)
+                    if (slice == 0) { if (a.bias) v += a.bias[col]; if (a.res) v += a.res[opix * a.ldr + col]; }
+                    atomicAdd(yp, v);
+                    continue;
+                }
                 if (a.bias) v += a.bias[col];
                 if (a.res) v += a.res[opix * a.ldr + col];
-                float* yp = a.y + opix * a.ldy + col;
                 if (a.accumulate) v += *yp;
                 *yp = v;
             }
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
 template <int MODE, int BM, int BN>
 int launch(const IgemmArgs& a, int classes, hipStream_t st) {
-    dim3 grid((a.Mc + BM - 1) / BM, (a.Nc + BN - 1) / BN, classes);
+    dim3 grid((a.Mc + BM - 1) / BM, (a.Nc + BN - 1) / BN, classes * a.ksplit);
     hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN>), grid, dim3(256), 0, st, a);
     return 0;
 }
@@ -301,6 +310,18 @@ extern "C" int mi_conv_igemm(const MiConvDesc* d, const float* x, const float* x
     a.vecB = (((uintptr_t)w & 15) == 0) && (d->w_kn ? (d->Nc % 4 == 0) : (d->K % 4 == 0));
     if (residual) MI_REQUIRE(d->ldr >= d->Nc, "ldr < Nc");
     hipStream_t st = (hipStream_t)stream;
+    a.ksplit = 1;
+    {   // long contraction, almost no tiles (Linear dgrad of the fused time-bias GEMM): split the channel axis
+        long tiles64 = (long)((a.Mc + 63) / 64) * ((d->Nc + 63) / 64) * classes;
+        if (tiles64 <= 16 && d->K >= 1024 && d->KH * d->KW == 1 && (d->accumulate || d->ldy == d->Nc)) {
+            int ks = d->K / 128; if (ks > 32) ks = 32;
+            a.ksplit = ks;
+            if (!d->accumulate) {
+                hipError_t e = hipMemsetAsync(y, 0, (size_t)a.Mc * classes * d->ldy * sizeof(float), st);
+                if (e != hipSuccess) return mi_set_error((int)e, "mi_conv_igemm: memset: %s", hipGetErrorString(e));
+            }
+        }
+    }
 
     // tile choice: keep >= ~2 workgroups per CU when the problem allows it
     long tiles128 = (long)((a.Mc + 127) / 128) * ((d->Nc + 127) / 128) * classes;

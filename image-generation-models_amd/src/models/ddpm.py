@@ -407,6 +407,11 @@ class Unet(nn.Module):
         def conv(inp, pre, k, stride=1, pad=0, x2=None, residual=None, transposed_conv=False, bias=True):
             w = sv[pre + "weight"]
             kh, kw, ci, co = w.shape
+            if x2 is None and residual is None and stride == 1 and not transposed_conv:
+                if k == 3 and ci <= 4 and co % 4 == 0 and 256 % (co // 4) == 0:        # image -> features
+                    return K.conv3x3_small_cin_fwd(inp, w, sv[pre + "bias"] if bias else None, co)
+                if k == 1 and co <= 4 and ci % 4 == 0:                                  # features -> image
+                    return K.conv1x1_small_cout(0, inp, w, bias=sv[pre + "bias"] if bias else None, Cs=co)
             if mode == K.MODE_BF16 and k in (1, 3) and stride == 1 and not transposed_conv:
                 y = K.conv3x3_bf16w(inp, wf_sh[offs[pre + "weight"]:], K=ci, Nc=co, flip=False, ksize=k, x2=x2,
                                     bias=sv[pre + "bias"] if bias else None, residual=residual)
@@ -501,7 +506,18 @@ class Unet(nn.Module):
             kh, kw, ci, co = w.shape
             ih, iw = inp.shape[1], inp.shape[2]
             oh, ow = dy.shape[1], dy.shape[2]
-            if transposed_conv:   # dW[tap][ci][co] = sum over input pixels  x[j] * dy[gather(j, tap)]
+            if x2 is None and stride == 1 and not transposed_conv and k == 1 and co <= 4 and ci % 4 == 0:
+                K.conv1x1_small_cout(2, inp, None, b=dy, out=gv[pre + "weight"])
+                if bias == "colsum":
+                    K.colsum(dy, gv[pre + "bias"])
+                if want_dx:
+                    buf, acc = G.target(inp)
+                    K.conv1x1_small_cout(1, dy, w, out=buf, accumulate=acc)
+                return
+            small_cin = x2 is None and stride == 1 and not transposed_conv and k == 3 and ci <= 4
+            if small_cin:
+                K.conv3x3_small_cin_wgrad(inp, dy, gv[pre + "weight"])
+            elif transposed_conv:   # dW[tap][ci][co] = sum over input pixels  x[j] * dy[gather(j, tap)]
                 K.conv_wgrad(inp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=False,
                              Ci=ci, Cj=co, grid_g=(oh, ow), grid_d=(ih, iw), mode=mode)
             else:

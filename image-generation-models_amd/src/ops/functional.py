@@ -117,6 +117,42 @@ def pack_weights_bf16(table_dev, nent, total_tiles, master, wd, wf):
           "mi_pack_weights_bf16")
 
 
+def conv3x3_small_cin_fwd(x, w, bias, Cout):
+    """Conv2d(Cin<=4, Cout, 3, padding=1) on an NHWC image tensor (first conv of the UNet)."""
+    _need_gpu(x)
+    N, H, W, Cin = x.shape
+    y = new_act(N, H, W, Cout, x)
+    check(load_library().mi_conv3x3_small_cin_fwd(N, H, W, Cin, Cout, _p(x), ld_of(x), _p(w), _p(bias), _p(y), ld_of(y), _stream()),
+          "mi_conv3x3_small_cin_fwd")
+    return y
+
+
+def conv3x3_small_cin_wgrad(x, dy, dW):
+    N, H, W, Cin = x.shape
+    check(load_library().mi_conv3x3_small_cin_wgrad(N, H, W, Cin, dy.shape[3], _p(x), ld_of(x), _p(dy), ld_of(dy), _p(dW), _stream()),
+          "mi_conv3x3_small_cin_wgrad")
+
+
+def conv1x1_small_cout(op, a, w, *, b=None, bias=None, out=None, Cs=None, accumulate=False):
+    """op 0: y[.,Cs] = x w + bias; op 1: dx[.,C] (+)= dy w^T; op 2: dW[C][Cs] += x^T dy.  w: [C][Cs]."""
+    _need_gpu(a)
+    N, H, W = a.shape[:3]
+    M = N * H * W
+    if op == 0:
+        C, Cs = a.shape[3], Cs
+        if out is None:
+            buf = torch.zeros((N, H, W, (Cs + 3) // 4 * 4), device=a.device, dtype=torch.float32)
+            out = buf[..., :Cs]
+    elif op == 1:
+        Cs = a.shape[3]; C = out.shape[3]
+    else:
+        C, Cs = a.shape[3], b.shape[3]
+    check(load_library().mi_conv1x1_small_cout(op, M, C, Cs, _p(a), ld_of(a), _p(b), ld_of(b) if b is not None else 0, _p(w),
+                                               _p(bias), _p(out), ld_of(out) if out.dim() == 4 else Cs, int(accumulate), _stream()),
+          "mi_conv1x1_small_cout")
+    return out
+
+
 def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_d, mode, P2=None):
     """dW[tap][i][j] += sum P*Q (see MiWgradDesc).  dW: flat fp32 buffer of kh*kw*Ci*Cj."""
     _need_gpu(P)

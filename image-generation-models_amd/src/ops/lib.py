@@ -41,6 +41,9 @@ SIGNATURES = {
     "mi_conv3x3_bf16w": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "mi_conv3x3_bf16w_supported": [C.POINTER(MiConvDesc)],
     "mi_pack_weights_bf16": [_I, _P, _I, _P, _P, _P, _P],
+    "mi_conv3x3_small_cin_fwd": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P],
+    "mi_conv3x3_small_cin_wgrad": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P],
+    "mi_conv1x1_small_cout": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "mi_conv_wgrad": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P],
     "mi_conv3x3_wgrad": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P],
     "mi_conv3x3_wgrad_supported": [C.POINTER(MiWgradDesc)],

@@ -87,6 +87,18 @@ int mi_conv3x3_bf16w_supported(const MiConvDesc* d);
 int mi_pack_weights_bf16(int nent, const void* entries_dev, int total_tiles, const float* master,
                          void* wd_bf16, void* wf_bf16, void* stream);
 
+/* ---- the 3-channel ends of the UNet (fp32 VALU, bound by the wide tensor they stream) ------------
+ * Conv2d(Cin<=4, Cout, 3, padding=1) forward and weight gradient (downs.0.0.block1, ddpm.py:116,208);
+ * w / dW in the tap-major layout [3][3][Cin][Cout]. */
+int mi_conv3x3_small_cin_fwd(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w,
+                             const float* bias, float* y, int ldy, void* stream);
+int mi_conv3x3_small_cin_wgrad(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* dy,
+                               int lddy, float* dW, void* stream);
+/* Conv2d(C, Cs<=4, 1) (final_conv.1, ddpm.py:236), weights w[C][Cs].  op 0: y = x w + bias;
+ * op 1: dx (+)= dy w^T; op 2: dW += x^T dy (a = x, b = dy). */
+int mi_conv1x1_small_cout(int op, int M, int C, int Cs, const float* a, int lda, const float* b, int ldb,
+                          const float* w, const float* bias, float* out, int ldo, int accumulate, void* stream);
+
 /* ---- weight gradient (aten::convolution_backward, weight part) -----------------------
  *   dW[ky][kx][i][j] += sum_{n,y,x} P[n,py,px,i] * Q[n,qy,qx,j]
  * (y,x) runs over the DH x DW grid of the non-gathered operand; the gathered operand is

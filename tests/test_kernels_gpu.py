@@ -474,3 +474,43 @@ def test_conv1x1_wgrad_fast(K, cfg):
                  grid_g=(H, H), grid_d=(H, H), mode=1, P2=P2)
     torch.cuda.synchronize()
     assert rel_err(w_from_storage(dW.view(1, 1, Ci, Co)), ref) < 2e-5
+
+
+def test_small_channel_ends(K):
+    """First conv Conv2d(3, C, 3, padding=1) and final Conv2d(C, 3, 1) (ddpm.py:208,236): fwd / dgrad / wgrad."""
+    g = torch.Generator().manual_seed(43)
+    N, H, C = 3, 8, 64
+    x = torch.randn(N, 3, H, H, generator=g, dtype=torch.float64)
+    w = torch.randn(C, 3, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(C, generator=g, dtype=torch.float64)
+    y = F.conv2d(x, w, b, padding=1)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    xg = to_nhwc_gpu(x.float())
+    yg = K.conv3x3_small_cin_fwd(xg, conv_w_storage(w.detach()), b.float().to(DEV), C)
+    dW = torch.zeros(9 * 3 * C, device=DEV)
+    K.conv3x3_small_cin_wgrad(xg, to_nhwc_gpu(dy.float()), dW)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(yg), y) < 1e-5
+    assert rel_err(w_from_storage(dW.view(3, 3, 3, C)), w.grad) < 1e-5
+    # final conv
+    h = torch.randn(N, C, H, H, generator=g, dtype=torch.float64, requires_grad=True)
+    wf = torch.randn(3, C, 1, 1, generator=g, dtype=torch.float64, requires_grad=True)
+    bf = torch.randn(3, generator=g, dtype=torch.float64)
+    e = F.conv2d(h, wf, bf)
+    de = torch.randn(e.shape, generator=g, dtype=torch.float64)
+    e.backward(de)
+    hg, ws = to_nhwc_gpu(h.detach().float()), conv_w_storage(wf.detach())
+    eg = K.conv1x1_small_cout(0, hg, ws, bias=bf.float().to(DEV), Cs=3)
+    assert eg.shape == (N, H, H, 3) and eg.stride(2) == 4
+    deg = to_nhwc_gpu(de.float())
+    dh = torch.empty(N, H, H, C, device=DEV)
+    K.conv1x1_small_cout(1, deg, ws, out=dh)
+    dWf = torch.zeros(C * 3, device=DEV)
+    K.conv1x1_small_cout(2, hg, None, b=deg, out=dWf)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(eg), e) < 1e-5
+    assert rel_err(from_nhwc(dh), h.grad) < 1e-5
+    assert rel_err(w_from_storage(dWf.view(1, 1, C, 3)), wf.grad) < 1e-5
+    K.conv1x1_small_cout(1, deg, ws, out=dh, accumulate=True)
+    assert rel_err(from_nhwc(dh), 2 * h.grad) < 1e-5
