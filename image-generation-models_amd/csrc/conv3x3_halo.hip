@@ -48,6 +48,7 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
     constexpr int A_IT = (MAXHP * Q + NT - 1) / NT;
     constexpr int A_SL = (A_IT + NTAP - 1) / NTAP; // float4 per thread per tap (NTAP slices cover a tile)
     constexpr int B_IT = BN * (CK / 8) / NT;       // 16-B loads per thread per tap
+    constexpr int D = 4;                           // register ring depth: a load has D-1 taps of MFMA time to land
 
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t* As = lds;                                    // 2 x [MAXHP][PITCH]
@@ -101,8 +102,8 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[2][A_SL];
-    uint4 rb[2][B_IT];
+    float4 ra[D][A_SL];
+    uint4 rb[D][B_IT];
     // this workgroup's slice of the channel chunks [ch0, ch0 + nchunks)
     const int allchunks = a.K / CK;
     const int per = (allchunks + a.ksplit - 1) / a.ksplit;
@@ -172,35 +173,54 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
                                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
     };
-    // one chunk; P = parity of its first stage (= chunk & 1 since a chunk has an odd number of stages)
-    auto chunk = [&](auto parity, int ch) {
-        constexpr int P = decltype(parity)::value;
+    // Stage bookkeeping (g = chunk*NTAP + tap, all ring indices static after unrolling):
+    //   weights: stage g+D-1 is loaded at tap g into rb[(g+D-1) % D]; stage g+1 is stored at the end of tap g
+    //            from rb[(g+1) % D] into slot (g+1) & 1;
+    //   halo:    stage h = g+NTAP+D-2 (slice of the next chunks) is loaded at tap g into ra[h % D]; stage
+    //            g+NTAP (slice `tap` of the next chunk) is stored at the end of tap g into the other halo buffer.
+    // P = first stage of the chunk mod D (NTAP is odd, D = 4  =>  P = chunk & 3 and the halo buffer is P & 1).
+    auto ring_load_b = [&](int r, int g) {
+        if (r == 0) load_b(rb[0], g); else if (r == 1) load_b(rb[1], g); else if (r == 2) load_b(rb[2], g); else load_b(rb[3], g);
+    };
+    auto ring_store_b = [&](int r, int slot) {
+        if (r == 0) store_b(slot, rb[0]); else if (r == 1) store_b(slot, rb[1]); else if (r == 2) store_b(slot, rb[2]); else store_b(slot, rb[3]);
+    };
+    auto ring_load_a = [&](int r, int h) {            // h = halo stage = chunk*NTAP + slice
+        const int c = h / NTAP, sl = h - c * NTAP;
+        if (r == 0) load_a(ra[0], c, sl); else if (r == 1) load_a(ra[1], c, sl); else if (r == 2) load_a(ra[2], c, sl); else load_a(ra[3], c, sl);
+    };
+    auto ring_store_a = [&](int r, int buf, int sl) {
+        if (r == 0) store_a(buf, ra[0], sl); else if (r == 1) store_a(buf, ra[1], sl); else if (r == 2) store_a(buf, ra[2], sl); else store_a(buf, ra[3], sl);
+    };
+    auto chunk = [&](auto phase, int ch) {
+        constexpr int P = decltype(phase)::value;
         const int g0 = ch * NTAP;
 #pragma unroll
         for (int tp = 0; tp < NTAP; ++tp) {
-            const int cur = (P + tp) & 1;                  // static after unrolling
-            // stage g+2 -> registers `cur` (they were drained into LDS at the end of the previous tap)
-            if (cur == 0) { load_b(rb[0], g0 + tp + 2); } else { load_b(rb[1], g0 + tp + 2); }
-            // halo stage g+NTAP+1 = slice tp+1 of the next chunk (slice 0 of the one after at the last tap)
-            if (tp < NTAP - 1) { if (cur == 0) load_a(ra[0], ch + 1, tp + 1); else load_a(ra[1], ch + 1, tp + 1); }
-            else               { if (cur == 0) load_a(ra[0], ch + 2, 0); else load_a(ra[1], ch + 2, 0); }
-            mma_tap(P, cur, tp);
-            // stage g+1 -> other weight slot; halo stage g+NTAP = slice tp of the next chunk -> other halo buffer
-            if (cur == 0) store_b(1, rb[1]); else store_b(0, rb[0]);
-            if (ch + 1 < nchunks) { if (cur == 0) store_a(P ^ 1, ra[1], tp); else store_a(P ^ 1, ra[0], tp); }
+            const int gm = (P + tp) % D;                       // g mod D, static
+            ring_load_b((gm + D - 1) % D, g0 + tp + D - 1);
+            ring_load_a((gm + NTAP + D - 2) % D, g0 + tp + NTAP + D - 2);
+            mma_tap(P & 1, (P + tp) & 1, tp);
+            ring_store_b((gm + 1) % D, (P + tp + 1) & 1);
+            if (ch + 1 < nchunks) ring_store_a((gm + NTAP) % D, (P & 1) ^ 1, tp);
             __syncthreads();
         }
     };
 
-    // ---- prologue: chunk 0's tile, weight stages 0 (LDS) and 1 (registers), halo stage NTAP (registers)
+    // ---- prologue: chunk 0's tile and weight stage 0 into LDS; stages 1..D-2 (weights) and the first D-2
+    //      halo stages of chunk 1 into the ring (the steady state loads the (D-1)-th ahead at every tap)
     for (int sl = 0; sl < NTAP; ++sl) { load_a(ra[0], 0, sl); store_a(0, ra[0], sl); }
     load_b(rb[0], 0); store_b(0, rb[0]);
-    load_b(rb[1], 1);
-    load_a(ra[1], 1, 0);
+#pragma unroll
+    for (int k = 1; k <= D - 2; ++k) ring_load_b(k % D, k);
+#pragma unroll
+    for (int k = 0; k < D - 2; ++k) ring_load_a((NTAP + k) % D, NTAP + k);
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ch += 2) {
+    for (int ch = 0; ch < nchunks; ch += 4) {
         chunk(std::integral_constant<int, 0>{}, ch);
         if (ch + 1 < nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
+        if (ch + 2 < nchunks) chunk(std::integral_constant<int, 2>{}, ch + 2);
+        if (ch + 3 < nchunks) chunk(std::integral_constant<int, 3>{}, ch + 3);
     }
 
     // ---- epilogue: lane = pixel (l & 31), register quad rq = channels 8*rq + 4*(l >> 5) .. +3
@@ -316,7 +336,7 @@ static bool halo_ok(const MiConvDesc* d, int* bm, int* ck) {
     if (k1) {                                  // 1x1: plain GEMM over M = N*H*W pixels, any geometry
         const long M = (long)d->N * d->OH * d->OW, nt = (d->Nc + 127) / 128;
         *bm = (M + 255) / 256 * nt >= 200 ? 256 : ((M + 127) / 128 * nt >= 400 ? 128 : 64);
-        *ck = (*bm == 256 && d->K % 64 == 0 && d->K1 % 64 == 0) ? 64 : 32;
+        *ck = 32;                              // 64 would spill: the whole A tile rides in the 4-deep register ring
         return true;
     }
     if (d->OW < 4 || d->OW > 64) return false;
@@ -399,7 +419,7 @@ extern "C" int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float
     }
     if (d->KH == 1) {
         a.TH = 1; a.TI = 1; a.tiles_per_img = 1; a.HP = BM;
-        if (BM == 256)      { if (CK == 64) launch_halo<256, 64, 1>(a, st); else launch_halo<256, 32, 1>(a, st); }
+        if (BM == 256)      launch_halo<256, 32, 1>(a, st);
         else if (BM == 128) launch_halo<128, 32, 1>(a, st);
         else                launch_halo<64, 32, 1>(a, st);
         MI_LAUNCH_CHECK();

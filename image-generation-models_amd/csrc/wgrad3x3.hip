@@ -20,6 +20,9 @@ struct W3Args {
     int tiles_x, tiles;    // W/TW, tiles per image
     int total, cps, splits;
     int gx, gy;
+    int xcd_map;
+    float* ws;           // per-workgroup partial tiles [block][KS][128][BJ] (null -> fp32 atomics into dW)
+    int ablate;          // profiling only: 1 = no MFMA, 2 = no global loads, 4 = no LDS commit, 8 = no fragment reads
 };
 
 template <int NJ, int KS>
@@ -32,8 +35,14 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
     const int wi = wv >> 1, wj = wv & 1;
     // 1-D grid, one workgroup per CU (the kernel runs one wave per SIMD): b -> (k-slice, ky, ci-tile, co-tile)
     const int gsz = a.gx * a.gy * KS;
-    const int split = blockIdx.x / gsz;
-    const int within = blockIdx.x % gsz;
+    int split, within;
+    if (a.xcd_map) {        // workgroup b is dispatched to XCD b % 8 (observed; speed only): keep the gsz workgroups of
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;   // one k-slice on one XCD so its L2 serves the shared dY / X rows
+        split = (slot / gsz) * 8 + xcd; within = slot % gsz;
+        if (split >= a.splits) return;
+    } else {
+        split = blockIdx.x / gsz; within = blockIdx.x % gsz;
+    }
     const int ky = within % KS, txy = within / KS;
     const int ci0 = (txy % a.gx) * BI, co0 = (txy / a.gx) * BJ;
     constexpr int NUX = KS == 3 ? 3 : 2;                // X staging units per wave (= position groups of 8)
@@ -83,11 +92,11 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
     // k-step, three register sets in flight => two k-steps of MFMA time per load) and written to the
     // other buffer.  One barrier per chunk (96 MFMAs per wave at NJ = 2).
     constexpr int NU = NUX + NJ;
-    float4 U[3][8];
+    float4 U[NU][8];                                   // one register set per staging unit: a whole chunk in flight
     const int BUF = BI * XP + BJ * YP;                 // bf16 elements per LDS buffer
 
     auto issue_unit = [&](float4 (&r)[8], int j, int c) {     // unit j of chunk c: global -> registers
-        if (c >= cend) return;
+        if (c >= cend || (a.ablate & 2)) return;
         const int g = c / a.tiles, tile = c - g * a.tiles;
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int y0 = ty * a.TH, x0 = tx * a.TW, n0 = g * 8;
@@ -122,11 +131,13 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         *reinterpret_cast<uint4*>(dst + 3 * pitch) = make_uint4(pack_bf16(v[0].w, v[1].w), pack_bf16(v[2].w, v[3].w), pack_bf16(v[4].w, v[5].w), pack_bf16(v[6].w, v[7].w));
     };
     auto commit_unit = [&](const float4 (&r)[8], int j, int buf) {     // registers -> LDS buffer `buf`
+        if (a.ablate & 4) return;
         uint16_t* base = lds + buf * BUF;
         if (j < NUX) { if (x_pos[j] < PX) put(base + x_dst[j], XP, r); }
         else put(base + BI * XP + y_dst[j - NUX], YP, r);
     };
     auto mma_step = [&](int s, int buf) {
+        if (a.ablate & 1) return;
         const uint16_t* Xb = lds + buf * BUF;
         const uint16_t* Yb = Xb + BI * XP;
         const int arow = (wi * 64 + (l & 31)) * XP, brow = (wj * (32 * NJ) + (l & 31)) * YP;
@@ -149,10 +160,14 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         }
     };
 
-    // prologue: first chunk staged synchronously
+    // Pipeline: registers hold chunk c+1 (fetched during chunk c-1); at k-step s of chunk c, unit s is
+    // converted and written to the other LDS buffer, and the same registers are immediately re-armed
+    // with unit s of chunk c+2 -> every global load has a full chunk (8 k-steps, ~100 MFMAs) to land.
     if (cbeg < cend) {
 #pragma unroll
-        for (int j = 0; j < NU; ++j) { issue_unit(U[0], j, cbeg); commit_unit(U[0], j, cbeg & 1); }
+        for (int j = 0; j < NU; ++j) { issue_unit(U[j], j, cbeg); commit_unit(U[j], j, cbeg & 1); }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) issue_unit(U[j], j, cbeg + 1);
     }
     __syncthreads();
     for (int c = cbeg; c < cend; ++c) {
@@ -160,13 +175,31 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         const bool nxt = c + 1 < cend;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            if (s < NU) issue_unit(U[s % 3], s, c + 1);
+            if (s < NU) {
+                if (nxt) commit_unit(U[s], s, buf ^ 1);
+                issue_unit(U[s], s, c + 2);
+            }
             mma_step(s, buf);
-            if (s >= 2 && s - 2 < NU && nxt) commit_unit(U[(s - 2) % 3], s - 2, buf ^ 1);
         }
         __syncthreads();
     }
 
+    if (a.ws) {
+        // plain coalesced stores of this workgroup's partial tile; wgrad_reduce_kernel sums the k-slices
+        float* tile = a.ws + (size_t)blockIdx.x * (KS * BI * BJ);
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wi * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        tile[(size_t)(kx * BI + row) * BJ + wj * (32 * NJ) + j * 32 + (l & 31)] = acc[kx][i][j][r];
+                }
+        return;
+    }
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) {
         float* out = a.dW + (size_t)(ky * KS + kx) * a.Ci * a.Cj;
@@ -182,6 +215,58 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
                     if (col < a.Cj) atomicAdd(out + (size_t)row * a.Cj + col, acc[kx][i][j][r]);
                 }
             }
+    }
+}
+
+// dW[(ky*KS+kx)][ci][co] += sum over k-slices of the partial tiles written above (fixed order: deterministic).
+// A workgroup owns 32 consecutive outputs; its 8 waves... (8 groups of 32 lanes) each take every 8th slice.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int Ci, int Cj,
+                                                           int KS, int BJ, int gx, int gy, int splits) {
+    __shared__ float red[8][32];
+    const size_t total = (size_t)KS * KS * Ci * Cj;
+    const int gsz = gx * gy * KS;
+    const size_t tile_elems = (size_t)KS * 128 * BJ;
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    for (size_t e0 = (size_t)blockIdx.x * 32; e0 < total; e0 += (size_t)gridDim.x * 32) {
+        const size_t e = e0 + el;
+        float s = 0.f;
+        if (e < total) {
+            const int co = (int)(e % Cj); size_t q = e / Cj;
+            const int ci = (int)(q % Ci); const int tap = (int)(q / Ci);
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const int tx = ci / 128, ty = co / BJ;
+            const int within = (ty * gx + tx) * KS + ky;
+            const float* p = ws + (size_t)within * tile_elems + (size_t)(kx * 128 + (ci - tx * 128)) * BJ + (co - ty * BJ);
+            for (int sp = grp; sp < splits; sp += 8) s += p[(size_t)sp * gsz * tile_elems];
+        }
+        red[grp][el] = s;
+        __syncthreads();
+        if (grp == 0 && e < total) {
+            float v = red[0][el];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) v += red[g][el];
+            dW[e] += v;
+        }
+        __syncthreads();
+    }
+}
+
+// few k-slices, many outputs: one thread per output, slices summed serially
+__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __restrict__ dW, int Ci, int Cj,
+                                                                int KS, int BJ, int gx, int gy, int splits) {
+    const size_t total = (size_t)KS * KS * Ci * Cj;
+    const int gsz = gx * gy * KS;
+    const size_t tile_elems = (size_t)KS * 128 * BJ;
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int co = (int)(e % Cj); size_t q = e / Cj;
+        const int ci = (int)(q % Ci); const int tap = (int)(q / Ci);
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const int tx = ci / 128, ty = co / BJ;
+        const int within = (ty * gx + tx) * KS + ky;
+        const float* p = ws + (size_t)within * tile_elems + (size_t)(kx * 128 + (ci - tx * 128)) * BJ + (co - ty * BJ);
+        float s = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s += p[(size_t)sp * gsz * tile_elems];
+        dW[e] += s;
     }
 }
 
@@ -201,8 +286,25 @@ static bool w3_ok(const MiWgradDesc* d) {
 
 extern "C" int mi_conv3x3_wgrad_supported(const MiWgradDesc* d) { return (d && w3_ok(d)) ? 1 : 0; }
 
+static int w3_plan(const MiWgradDesc* d, W3Args& a, int& BJ, bool& wide);
+
+extern "C" size_t mi_conv3x3_wgrad_workspace(const MiWgradDesc* d) {
+    if (!d || !w3_ok(d)) return 0;
+    W3Args a; int BJ; bool wide;
+    w3_plan(d, a, BJ, wide);
+    return (size_t)a.gx * a.gy * d->KH * a.splits * d->KH * 128 * BJ * sizeof(float);
+}
+
+extern "C" int mi_conv3x3_wgrad_ws(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
+                                   void* workspace, size_t ws_bytes, void* stream);
+
 extern "C" int mi_conv3x3_wgrad(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
                                 void* stream) {
+    return mi_conv3x3_wgrad_ws(d, P, P2, Q, dW, nullptr, 0, stream);
+}
+
+extern "C" int mi_conv3x3_wgrad_ws(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
+                                   void* workspace, size_t ws_bytes, void* stream) {
     MI_REQUIRE(d && P && Q && dW, "null argument");
     MI_REQUIRE(w3_ok(d), "descriptor not supported by the 3x3 wgrad kernel (use mi_conv_wgrad)");
     MI_REQUIRE(d->I1 == d->Ci || P2, "two-source split without P2");
@@ -210,25 +312,14 @@ extern "C" int mi_conv3x3_wgrad(const MiWgradDesc* d, const float* P, const floa
                (((uintptr_t)P | (uintptr_t)Q | (uintptr_t)(P2 ? P2 : P)) & 15) == 0, "operands must be 16-byte aligned, ld % 4 == 0");
     W3Args a;
     a.P = P; a.P2 = P2 ? P2 : P; a.Q = Q; a.dW = dW;
-    a.N = d->N; a.H = d->DH; a.W = d->DW; a.Ci = d->Ci; a.Cj = d->Cj; a.I1 = d->I1;
     a.ldp = d->ldp; a.ldp2 = P2 ? d->ldp2 : d->ldp; a.ldq = d->ldq;
-    a.TW = a.W >= 16 ? 16 : a.W; a.TH = 16 / a.TW;
-    a.tiles_x = a.W / a.TW; a.tiles = a.tiles_x * (a.H / a.TH);
-    a.total = (a.N / 8) * a.tiles;
-    static const int force_nj = [] { const char* e = getenv("MI_W3_NJ"); return e ? atoi(e) : 0; }();
-    const bool wide = force_nj ? force_nj == 2 : (d->Cj % 128 == 0 || d->Cj > 256);
-    const int BJ = wide ? 128 : 64;
+    int BJ; bool wide;
+    w3_plan(d, a, BJ, wide);
     const int KS = d->KH;
-    long base = (long)((d->Ci + 127) / 128) * ((d->Cj + BJ - 1) / BJ) * KS;
-    // exactly one round of workgroups: the kernel holds ~480 registers per lane, i.e. one workgroup per CU
-    static const long target = [] { const char* e = getenv("MI_W3_BLOCKS"); return e ? atol(e) : 256L; }();
-    long splits = target / base;
-    if (splits > a.total) splits = a.total;
-    if (splits < 1) splits = 1;
-    a.cps = (int)((a.total + splits - 1) / splits);
-    a.splits = (a.total + a.cps - 1) / a.cps;
-    a.gx = (d->Ci + 127) / 128; a.gy = (d->Cj + BJ - 1) / BJ;
-    dim3 grid((unsigned)(a.gx * a.gy * KS * a.splits));
+    a.ws = nullptr;
+    if (workspace && ws_bytes >= (size_t)a.gx * a.gy * KS * a.splits * KS * 128 * BJ * sizeof(float) && a.splits > 1 && !a.xcd_map)
+        a.ws = (float*)workspace;
+    dim3 grid((unsigned)(a.gx * a.gy * KS * (a.xcd_map ? (a.splits + 7) / 8 * 8 : a.splits)));
     hipStream_t st = (hipStream_t)stream;
     const int XP = ((a.TH * (a.TW + KS - 1)) | 1) * 8;
     const size_t lds = (size_t)(128 * XP + BJ * 17 * 8) * 2 * 2;      // double-buffered
@@ -247,6 +338,47 @@ extern "C" int mi_conv3x3_wgrad(const MiWgradDesc* d, const float* P, const floa
         if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2, 1>), grid, dim3(256), lds, st, a);
         else      hipLaunchKernelGGL((wgrad3x3_kernel<1, 1>), grid, dim3(256), lds, st, a);
     }
+    if (a.ws) {
+        const size_t total = (size_t)KS * KS * d->Ci * d->Cj;
+        if (a.splits >= 16) {
+            int blocks = (int)((total + 31) / 32); if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, dW, d->Ci, d->Cj, KS, BJ, a.gx, a.gy, a.splits);
+        } else {
+            int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(blocks), dim3(256), 0, st, a.ws, dW, d->Ci, d->Cj, KS, BJ, a.gx, a.gy, a.splits);
+        }
+    }
     MI_LAUNCH_CHECK();
+    return 0;
+}
+
+static int w3_plan(const MiWgradDesc* d, W3Args& a, int& BJ, bool& wide) {
+    a.N = d->N; a.H = d->DH; a.W = d->DW; a.Ci = d->Ci; a.Cj = d->Cj; a.I1 = d->I1;
+    a.TW = a.W >= 16 ? 16 : a.W; a.TH = 16 / a.TW;
+    a.tiles_x = a.W / a.TW; a.tiles = a.tiles_x * (a.H / a.TH);
+    a.total = (a.N / 8) * a.tiles;
+    static const int force_nj = [] { const char* e = getenv("MI_W3_NJ"); return e ? atoi(e) : 0; }();
+    wide = force_nj ? force_nj == 2 : (d->Cj % 128 == 0 || d->Cj > 256);
+    BJ = wide ? 128 : 64;
+    const int KS = d->KH;
+    long base = (long)((d->Ci + 127) / 128) * ((d->Cj + BJ - 1) / BJ) * KS;
+    // exactly one round of workgroups: the kernel holds ~480 registers per lane, i.e. one workgroup per CU
+    static const long target = [] { const char* e = getenv("MI_W3_BLOCKS"); return e ? atol(e) : 256L; }();
+    long splits = target / base;
+    if (splits > a.total) splits = a.total;
+    if (splits < 1) splits = 1;
+    a.cps = (int)((a.total + splits - 1) / splits);
+    a.splits = (a.total + a.cps - 1) / a.cps;
+    a.gx = (d->Ci + 127) / 128; a.gy = (d->Cj + BJ - 1) / BJ;
+    static const int xcd_env = [] { const char* e = getenv("MI_W3_XCD"); return e ? atoi(e) : 0; }();
+    a.xcd_map = xcd_env && a.gx * a.gy * KS <= 12;
+    if (a.xcd_map) {                                    // splits a multiple of 8 so every XCD gets whole k-slices
+        long s8 = (target / base) / 8 * 8; if (s8 < 8) s8 = 8;
+        if (s8 > a.total) s8 = a.total;
+        a.cps = (int)((a.total + s8 - 1) / s8);
+        a.splits = (a.total + a.cps - 1) / a.cps;
+    }
+    static const int abl = [] { const char* e = getenv("MI_W3_ABLATE"); return e ? atoi(e) : 0; }();
+    a.ablate = abl;
     return 0;
 }

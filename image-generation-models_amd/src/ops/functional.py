@@ -167,13 +167,28 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if fast:
-        check(lib.mi_conv3x3_wgrad(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _stream()), "mi_conv3x3_wgrad")
+        need = lib.mi_conv3x3_wgrad_workspace(C.byref(d))
+        ws = _workspace(P.device, need)
+        check(lib.mi_conv3x3_wgrad_ws(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _p(ws), ws.numel() * 4, _stream()),
+              "mi_conv3x3_wgrad_ws")
     else:
         check(lib.mi_conv_wgrad(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _stream()), "mi_conv_wgrad")
     if PROBE is not None:
         e1.record()
         PROBE.append(("wgrad3x3_kernel" if fast else f"wgrad_kernel<{mode}>", 2.0 * N * grid_d[0] * grid_d[1] * Ci * Cj * kh * kw, e0, e1,
                       f"N{N} {grid_d[0]}x{grid_d[1]} Ci{Ci}{'(2src)' if P2 is not None else ''} Cj{Cj} k{kh} s{stride} g{int(gather_i)}"))
+
+
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    """Persistent per-device scratch (static address: safe to reference from a captured hipGraph)."""
+    cur = _WS.get(device)
+    if cur is None or cur.numel() * 4 < nbytes:
+        cur = torch.empty((max(int(nbytes), 64 << 20) + 3) // 4, device=device, dtype=torch.float32)
+        _WS[device] = cur
+    return cur
 
 
 def _rows(x):

@@ -47,6 +47,7 @@ SIGNATURES = {
     "mi_conv_wgrad": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P],
     "mi_conv3x3_wgrad": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P],
     "mi_conv3x3_wgrad_supported": [C.POINTER(MiWgradDesc)],
+    "mi_conv3x3_wgrad_ws": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P, _Z, _P],
     "mi_colsum": [_I, _I, _P, _I, _P, _P],
     "mi_gn_mish_fwd": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "mi_gn_mish_bwd": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P],
@@ -67,7 +68,8 @@ SIGNATURES = {
     "mi_axpby2d": [_I, _I, _F, _P, _I, _I, _P, _I, _P],
     "mi_scale_by_device_scalar": [_I, _I, _P, _I, _P, _P],
 }
-OTHER = {"mi_abi_version": ([], C.c_int), "mi_last_error": ([], C.c_char_p)}
+OTHER = {"mi_abi_version": ([], C.c_int), "mi_last_error": ([], C.c_char_p),
+         "mi_conv3x3_wgrad_workspace": ([C.POINTER(MiWgradDesc)], C.c_size_t)}
 ABI_VERSION = 1
 
 

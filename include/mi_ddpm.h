@@ -127,6 +127,12 @@ int mi_conv_wgrad(const MiWgradDesc* d, const float* P, const float* P2, const f
  * (needs N % 8 == 0, channel counts % 32 == 0; query first, else use mi_conv_wgrad). */
 int mi_conv3x3_wgrad(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW, void* stream);
 int mi_conv3x3_wgrad_supported(const MiWgradDesc* d);
+/* Same, but the k-slices write partial tiles to a caller-provided scratch buffer that a second
+ * (deterministic) kernel sums into dW -- 2.4x cheaper than fp32 atomics here.  Size from
+ * mi_conv3x3_wgrad_workspace(); a null / too small workspace falls back to atomics. */
+size_t mi_conv3x3_wgrad_workspace(const MiWgradDesc* d);
+int mi_conv3x3_wgrad_ws(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
+                        void* workspace, size_t ws_bytes, void* stream);
 
 /* out[c] += sum_m x[m*ld + c]  (bias gradients) */
 int mi_colsum(int M, int C, const float* x, int ld, float* out, void* stream);
