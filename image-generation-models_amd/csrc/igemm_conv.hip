@@ -21,6 +21,7 @@ struct IgemmArgs {
     int OHc, OWc;     // per-parity-class output grid (== OH, OW unless transposed with stride > 1)
     int Mc;           // rows per class
     int vecA, vecB;   // 16-byte vector loads legal for activations / weights
+    const uint16_t* wb; // optional bf16 weights [tap][Nc][K] (k contiguous); used instead of w in bf16 mode
     int ksplit;       // slices of the channel axis (blockIdx.z = class * ksplit + slice); > 1 => atomic epilogue
 };
 
@@ -96,6 +97,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     };
 
     float4 ra[A_IT], rb[B_IT];
+    constexpr int BW_IT = BN / 64;          // 16-byte bf16 weight vectors per thread per step
+    uint4 rbw[BW_IT];
+    const bool usewb = MODE == 1 && a.wb != nullptr;
 
     auto load_step = [&]() {
         const int dy = a.transposed ? (py + a.pad - ky) / s : ky - a.pad;
@@ -114,7 +118,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         }
         // B: 32 k-rows x BN columns of W(tap)
         const int tap = ky * a.KW + kx;
-        if (a.w_kn) {
+        if (usewb) {
+            // pre-converted bf16 [tap][n][k]: 4 x 16-byte vectors per output channel row, no cvt, no transposition
+            const int k8 = t & 3;
+#pragma unroll
+            for (int i = 0; i < BW_IT; ++i) {
+                const int n = n0 + (t >> 2) + 64 * i;
+                const bool ok = n < a.Nc && kc + k8 * 8 < a.K;
+                uint4 v = *reinterpret_cast<const uint4*>(a.wb + ((size_t)tap * a.Nc + (ok ? n : 0)) * a.K + (ok ? kc + k8 * 8 : 0));
+                rbw[i] = ok ? v : make_uint4(0, 0, 0, 0);
+            }
+        } else if (a.w_kn) {
             // memory [tap][k][n]: float4 along n; thread = (k-pair kd, column quad n4).  A half-wave
             // spans 16 k-pairs x 2 quads so the transposing LDS store below is bank-conflict free
             // (pitch 20 dwords: bank = 16*(n4&1) + 20*j + kd mod 32).
@@ -152,7 +166,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
                 *reinterpret_cast<float4*>(&As[r * PITCH + ac4 * 4]) = ra[i];
             }
         }
-        if (a.w_kn) {
+        if (usewb) {
+            if constexpr (MODE == 1) {
+                const int k8 = t & 3;
+#pragma unroll
+                for (int i = 0; i < BW_IT; ++i)
+                    *reinterpret_cast<uint4*>(&Bs[((t >> 2) + 64 * i) * PITCH + k8 * 8]) = rbw[i];
+            }
+        } else if (a.w_kn) {
             const int kd = t & 15;
 #pragma unroll
             for (int p = 0; p < B_IT / 2; ++p) {
@@ -283,15 +304,32 @@ int launch(const IgemmArgs& a, int classes, hipStream_t st) {
 
 }  // namespace
 
+static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, const float* w, const uint16_t* wb,
+                          const float* bias, const float* residual, float* y, void* stream);
+
 extern "C" int mi_conv_igemm(const MiConvDesc* d, const float* x, const float* x2, const float* w,
                              const float* bias, const float* residual, float* y, void* stream) {
+    return igemm_dispatch(d, x, x2, w, nullptr, bias, residual, y, stream);
+}
+
+// Same contract, weights given as the bf16 copy laid out [tap][Nc][K] (mi_pack_weights_bf16): used for
+// the stride-2 / transposed convolutions the tile kernel does not cover.  Needs mode == 1, K % 8 == 0.
+extern "C" int mi_conv_igemm_bf16w(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
+                                   const float* bias, const float* residual, float* y, void* stream) {
+    if (!d || d->mode != 1 || d->K % 8 || !w_nk_bf16 || ((uintptr_t)w_nk_bf16 & 15))
+        return mi_set_error(-1, "mi_conv_igemm_bf16w: needs mode 1, K %% 8 == 0 and 16-byte aligned bf16 weights");
+    return igemm_dispatch(d, x, x2, (const float*)w_nk_bf16, (const uint16_t*)w_nk_bf16, bias, residual, y, stream);
+}
+
+static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, const float* w, const uint16_t* wb,
+                          const float* bias, const float* residual, float* y, void* stream) {
     MI_REQUIRE(d && x && w && y, "null argument");
     MI_REQUIRE(d->N > 0 && d->K > 0 && d->Nc > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0, "bad sizes");
     MI_REQUIRE(d->mode == 0 || d->mode == 1, "mode must be 0 (fp32) or 1 (bf16)");
     MI_REQUIRE(d->K1 == d->K || (x2 && d->K1 > 0 && d->K1 < d->K && d->K1 % 4 == 0), "bad two-source split");
     MI_REQUIRE(d->ldx % 4 == 0 && d->ldy >= d->Nc, "ldx must be a multiple of 4, ldy >= Nc");
     IgemmArgs a;
-    a.x = x; a.x2 = x2 ? x2 : x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
+    a.x = x; a.x2 = x2 ? x2 : x; a.w = w; a.wb = wb; a.bias = bias; a.res = residual; a.y = y;
     a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW; a.K = d->K; a.Nc = d->Nc;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.transposed = d->transposed;
     a.w_kn = d->w_kn; a.K1 = d->K1; a.ldx = d->ldx; a.ldx2 = x2 ? d->ldx2 : d->ldx; a.ldy = d->ldy;

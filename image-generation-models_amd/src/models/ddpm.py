@@ -424,7 +424,8 @@ class Unet(nn.Module):
                 oh, ow = (ih + 2 * pad - kh) // stride + 1, (iw + 2 * pad - kw) // stride + 1
             y = K.conv_igemm(inp, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=transposed_conv, w_kn=True,
                              K=ci, Nc=co, out_hw=(oh, ow), mode=mode, x2=x2,
-                             bias=sv[pre + "bias"] if bias else None, residual=residual)
+                             bias=sv[pre + "bias"] if bias else None, residual=residual,
+                             wb=wf_sh[offs[pre + "weight"]:] if mode == K.MODE_BF16 else None)
             return y
 
         def resblock(blk, inp, x2=None):
@@ -534,7 +535,8 @@ class Unet(nn.Module):
                                             accumulate=acc) is not None:
                     return
                 K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=not transposed_conv, w_kn=False,
-                             K=co, Nc=ci, out_hw=(ih, iw), mode=mode, out=buf, accumulate=acc)
+                             K=co, Nc=ci, out_hw=(ih, iw), mode=mode, out=buf, accumulate=acc,
+                             wb=wd_sh[offs[pre + "weight"]:] if mode == K.MODE_BF16 else None)
             else:
                 # gradient of the (virtual) concat: one buffer, the two sources take channel slices of it
                 cat = G._g.get(("cat", id(inp)))

@@ -51,7 +51,7 @@ def new_act(n, h, w, c, like: torch.Tensor) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- conv family
 def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mode, x2=None,
-               bias=None, residual=None, out=None, accumulate=False):
+               bias=None, residual=None, out=None, accumulate=False, wb=None):
     """y = conv(x [| x2]) per MiConvDesc.  x: [N,IH,IW,K1], x2: [N,IH,IW,K-K1] or None."""
     _need_gpu(x)
     N, IH, IW, K1 = x.shape
@@ -74,8 +74,12 @@ def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mo
         flops = 2.0 * N * OH * OW * Nc * K * (kh * kw if not (transposed and stride > 1) else kh * kw / (stride * stride))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(load_library().mi_conv_igemm(C.byref(d), _p(x), _p(x2), _p(w), _p(bias), _p(residual), _p(out), _stream()),
-          "mi_conv_igemm")
+    if wb is not None and mode == MODE_BF16 and K % 8 == 0:      # bf16 weight copy [tap][Nc][K]
+        check(load_library().mi_conv_igemm_bf16w(C.byref(d), _p(x), _p(x2), _p(wb), _p(bias), _p(residual), _p(out), _stream()),
+              "mi_conv_igemm_bf16w")
+    else:
+        check(load_library().mi_conv_igemm(C.byref(d), _p(x), _p(x2), _p(w), _p(bias), _p(residual), _p(out), _stream()),
+              "mi_conv_igemm")
     if PROBE is not None:
         e1.record()
         PROBE.append((f"igemm_kernel<{mode},{bm.value},{bn.value}>", flops, e0, e1,

@@ -37,6 +37,7 @@ _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # name -> argtypes; every function returns int (0 = ok) except the two noted below
 SIGNATURES = {
     "mi_conv_igemm": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _P],
+    "mi_conv_igemm_bf16w": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "mi_conv_igemm_tile": [C.POINTER(MiConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "mi_conv3x3_bf16w": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "mi_conv3x3_bf16w_supported": [C.POINTER(MiConvDesc)],

@@ -68,6 +68,10 @@ typedef struct MiConvDesc {
 int mi_conv_igemm(const MiConvDesc* d, const float* x, const float* x2, const float* w,
                   const float* bias, const float* residual, float* y, void* stream);
 
+/* same contract with the bf16 weight copy [tap][Nc][K] of mi_pack_weights_bf16 (mode 1, K % 8 == 0);
+ * used for the stride-2 / transposed convolutions */
+int mi_conv_igemm_bf16w(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
+                        const float* bias, const float* residual, float* y, void* stream);
 /* tile instantiation mi_conv_igemm will launch for d (BM x BN); used to attribute profiles */
 int mi_conv_igemm_tile(const MiConvDesc* d, int* bm, int* bn);
 

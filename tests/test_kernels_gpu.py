@@ -514,3 +514,39 @@ def test_small_channel_ends(K):
     assert rel_err(w_from_storage(dWf.view(1, 1, C, 3)), wf.grad) < 1e-5
     K.conv1x1_small_cout(1, deg, ws, out=dh, accumulate=True)
     assert rel_err(from_nhwc(dh), 2 * h.grad) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["down", "down_dgrad", "up", "up_dgrad"])
+def test_igemm_bf16_weight_copy(K, kind):
+    """Stride-2 Downsample / ConvTranspose Upsample (ddpm.py:70,79) through the generic kernel fed by the bf16 weight copy."""
+    g = torch.Generator().manual_seed(47)
+    N, C, H = 2, 64, 16
+    if kind.startswith("down"):
+        x = torch.randn(N, C, H, H, generator=g, dtype=torch.float64, requires_grad=True)
+        w = (torch.randn(C, C, 3, 3, generator=g, dtype=torch.float64) / 24).requires_grad_(True)
+        y = F.conv2d(x, w, None, stride=2, padding=1)
+        ws = conv_w_storage(w.detach()); kk = 3
+    else:
+        x = torch.randn(N, C, H // 2, H // 2, generator=g, dtype=torch.float64, requires_grad=True)
+        w = (torch.randn(C, C, 4, 4, generator=g, dtype=torch.float64) / 32).requires_grad_(True)
+        y = F.conv_transpose2d(x, w, None, stride=2, padding=1)
+        ws = conv_w_storage(w.detach(), transposed=True); kk = 4
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    flat, wd, wf, offs = _pack(K, [ws])
+    xg, dyg = to_nhwc_gpu(x.detach().float()), to_nhwc_gpu(dy.float())
+    ih, oh = x.shape[2], y.shape[2]
+    if kind == "down":
+        out = K.conv_igemm(xg, ws, kh=3, kw=3, stride=2, pad=1, transposed=False, w_kn=True, K=C, Nc=C, out_hw=(oh, oh), mode=1, wb=wf)
+        ref = y
+    elif kind == "down_dgrad":
+        out = K.conv_igemm(dyg, ws, kh=3, kw=3, stride=2, pad=1, transposed=True, w_kn=False, K=C, Nc=C, out_hw=(ih, ih), mode=1, wb=wd)
+        ref = x.grad
+    elif kind == "up":
+        out = K.conv_igemm(xg, ws, kh=4, kw=4, stride=2, pad=1, transposed=True, w_kn=True, K=C, Nc=C, out_hw=(oh, oh), mode=1, wb=wf)
+        ref = y
+    else:
+        out = K.conv_igemm(dyg, ws, kh=4, kw=4, stride=2, pad=1, transposed=False, w_kn=False, K=C, Nc=C, out_hw=(ih, ih), mode=1, wb=wd)
+        ref = x.grad
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(out), ref) < 2e-2
