@@ -21,6 +21,7 @@ struct W3Args {
     int total, cps, splits;
     int gx, gy;
     int xcd_map;
+    float* dbias;        // optional: dbias[co] += sum over pixels of Q (the conv's bias gradient), fused into the dY staging
     float* ws;           // per-workgroup partial tiles [block][KS][128][BJ] (null -> fp32 atomics into dW)
     int ablate;          // profiling only: 1 = no MFMA, 2 = no global loads, 4 = no LDS commit, 8 = no fragment reads
 };
@@ -130,11 +131,24 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         *reinterpret_cast<uint4*>(dst + 2 * pitch) = make_uint4(pack_bf16(v[0].z, v[1].z), pack_bf16(v[2].z, v[3].z), pack_bf16(v[4].z, v[5].z), pack_bf16(v[6].z, v[7].z));
         *reinterpret_cast<uint4*>(dst + 3 * pitch) = make_uint4(pack_bf16(v[0].w, v[1].w), pack_bf16(v[2].w, v[3].w), pack_bf16(v[4].w, v[5].w), pack_bf16(v[6].w, v[7].w));
     };
+    // bias gradient: the workgroups with ci-tile 0 and the centre ky see every dY element exactly once
+    const bool do_bias = a.dbias != nullptr && ci0 == 0 && ky == KS / 2;
+    float4 bsum[NJ];
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) bsum[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     auto commit_unit = [&](const float4 (&r)[8], int j, int buf) {     // registers -> LDS buffer `buf`
         if (a.ablate & 4) return;
         uint16_t* base = lds + buf * BUF;
         if (j < NUX) { if (x_pos[j] < PX) put(base + x_dst[j], XP, r); }
-        else put(base + BI * XP + y_dst[j - NUX], YP, r);
+        else {
+            put(base + BI * XP + y_dst[j - NUX], YP, r);
+            if (do_bias) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    bsum[j - NUX].x += r[q].x; bsum[j - NUX].y += r[q].y; bsum[j - NUX].z += r[q].z; bsum[j - NUX].w += r[q].w;
+                }
+            }
+        }
     };
     auto mma_step = [&](int s, int buf) {
         if (a.ablate & 1) return;
@@ -184,6 +198,21 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         __syncthreads();
     }
 
+    if (do_bias) {
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            float4 v = bsum[k];
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {              // the 8 lanes hp_sub = 0..7 hold the same channel quad
+                v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64);
+                v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+            }
+            if (hp_sub == 0 && y_ch[k] < a.Cj) {
+                atomicAdd(a.dbias + y_ch[k], v.x); atomicAdd(a.dbias + y_ch[k] + 1, v.y);
+                atomicAdd(a.dbias + y_ch[k] + 2, v.z); atomicAdd(a.dbias + y_ch[k] + 3, v.w);
+            }
+        }
+    }
     if (a.ws) {
         // plain coalesced stores of this workgroup's partial tile; wgrad_reduce_kernel sums the k-slices
         float* tile = a.ws + (size_t)blockIdx.x * (KS * BI * BJ);
@@ -295,23 +324,28 @@ extern "C" size_t mi_conv3x3_wgrad_workspace(const MiWgradDesc* d) {
     return (size_t)a.gx * a.gy * d->KH * a.splits * d->KH * 128 * BJ * sizeof(float);
 }
 
+extern "C" int mi_conv3x3_wgrad_bias(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
+                                     float* dbias, void* workspace, size_t ws_bytes, void* stream);
+
 extern "C" int mi_conv3x3_wgrad_ws(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
-                                   void* workspace, size_t ws_bytes, void* stream);
+                                   void* workspace, size_t ws_bytes, void* stream) {
+    return mi_conv3x3_wgrad_bias(d, P, P2, Q, dW, nullptr, workspace, ws_bytes, stream);
+}
 
 extern "C" int mi_conv3x3_wgrad(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
                                 void* stream) {
     return mi_conv3x3_wgrad_ws(d, P, P2, Q, dW, nullptr, 0, stream);
 }
 
-extern "C" int mi_conv3x3_wgrad_ws(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
-                                   void* workspace, size_t ws_bytes, void* stream) {
+extern "C" int mi_conv3x3_wgrad_bias(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
+                                     float* dbias, void* workspace, size_t ws_bytes, void* stream) {
     MI_REQUIRE(d && P && Q && dW, "null argument");
     MI_REQUIRE(w3_ok(d), "descriptor not supported by the 3x3 wgrad kernel (use mi_conv_wgrad)");
     MI_REQUIRE(d->I1 == d->Ci || P2, "two-source split without P2");
     MI_REQUIRE(d->ldp % 4 == 0 && d->ldq % 4 == 0 && (!P2 || d->ldp2 % 4 == 0) &&
                (((uintptr_t)P | (uintptr_t)Q | (uintptr_t)(P2 ? P2 : P)) & 15) == 0, "operands must be 16-byte aligned, ld % 4 == 0");
     W3Args a;
-    a.P = P; a.P2 = P2 ? P2 : P; a.Q = Q; a.dW = dW;
+    a.P = P; a.P2 = P2 ? P2 : P; a.Q = Q; a.dW = dW; a.dbias = dbias;
     a.ldp = d->ldp; a.ldp2 = P2 ? d->ldp2 : d->ldp; a.ldq = d->ldq;
     int BJ; bool wide;
     w3_plan(d, a, BJ, wide);

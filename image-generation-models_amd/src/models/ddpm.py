@@ -523,7 +523,9 @@ class Unet(nn.Module):
                              Ci=ci, Cj=co, grid_g=(oh, ow), grid_d=(ih, iw), mode=mode)
             else:
                 K.conv_wgrad(inp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=True,
-                             Ci=ci, Cj=co, grid_g=(ih, iw), grid_d=(oh, ow), mode=mode, P2=x2)
+                             Ci=ci, Cj=co, grid_g=(ih, iw), grid_d=(oh, ow), mode=mode, P2=x2,
+                             dbias=gv[pre + "bias"] if bias == "colsum" else None)
+                bias = None                                           # handled (fused or by conv_wgrad's fallback)
             if bias == "colsum":
                 K.colsum(dy, gv[pre + "bias"])
             if not want_dx:

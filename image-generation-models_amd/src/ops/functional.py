@@ -157,8 +157,9 @@ def conv1x1_small_cout(op, a, w, *, b=None, bias=None, out=None, Cs=None, accumu
     return out
 
 
-def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_d, mode, P2=None):
-    """dW[tap][i][j] += sum P*Q (see MiWgradDesc).  dW: flat fp32 buffer of kh*kw*Ci*Cj."""
+def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_d, mode, P2=None, dbias=None):
+    """dW[tap][i][j] += sum P*Q (see MiWgradDesc).  dW: flat fp32 buffer of kh*kw*Ci*Cj.
+    dbias (optional): dbias[j] += sum over pixels of Q -- fused when the fast kernel runs, else a colsum pass."""
     _need_gpu(P)
     N = P.shape[0]
     I1 = P.shape[3] if P2 is not None else Ci
@@ -173,10 +174,12 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
     if fast:
         need = lib.mi_conv3x3_wgrad_workspace(C.byref(d))
         ws = _workspace(P.device, need)
-        check(lib.mi_conv3x3_wgrad_ws(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _p(ws), ws.numel() * 4, _stream()),
-              "mi_conv3x3_wgrad_ws")
+        check(lib.mi_conv3x3_wgrad_bias(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _p(dbias), _p(ws), ws.numel() * 4, _stream()),
+              "mi_conv3x3_wgrad_bias")
     else:
         check(lib.mi_conv_wgrad(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _stream()), "mi_conv_wgrad")
+        if dbias is not None:
+            colsum(Q, dbias)
     if PROBE is not None:
         e1.record()
         PROBE.append(("wgrad3x3_kernel" if fast else f"wgrad_kernel<{mode}>", 2.0 * N * grid_d[0] * grid_d[1] * Ci * Cj * kh * kw, e0, e1,

@@ -49,6 +49,7 @@ SIGNATURES = {
     "mi_conv3x3_wgrad": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P],
     "mi_conv3x3_wgrad_supported": [C.POINTER(MiWgradDesc)],
     "mi_conv3x3_wgrad_ws": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P, _Z, _P],
+    "mi_conv3x3_wgrad_bias": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P, _P, _Z, _P],
     "mi_colsum": [_I, _I, _P, _I, _P, _P],
     "mi_gn_mish_fwd": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "mi_gn_mish_bwd": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P],

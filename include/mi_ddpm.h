@@ -137,6 +137,10 @@ int mi_conv3x3_wgrad_supported(const MiWgradDesc* d);
 size_t mi_conv3x3_wgrad_workspace(const MiWgradDesc* d);
 int mi_conv3x3_wgrad_ws(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
                         void* workspace, size_t ws_bytes, void* stream);
+/* ... and additionally dbias[j] += sum over pixels of Q[., j] (the conv's bias gradient) from the
+ * same pass over Q (replaces a separate mi_colsum over the gradient tensor). */
+int mi_conv3x3_wgrad_bias(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
+                          float* dbias, void* workspace, size_t ws_bytes, void* stream);
 
 /* out[c] += sum_m x[m*ld + c]  (bias gradients) */
 int mi_colsum(int M, int C, const float* x, int ld, float* out, void* stream);

@@ -407,9 +407,11 @@ def test_conv3x3_wgrad_fast(K, cfg):
     d = MiWgradDesc(N=N, GH=H, GW=H, DH=H, DW=H, Ci=Ci, Cj=Co, KH=3, KW=3, stride=1, pad=1, gather_i=1, mode=1,
                     I1=split or Ci, ldp=4, ldp2=4, ldq=4)
     assert load_library().mi_conv3x3_wgrad_supported(ctypes.byref(d)) == 1
+    db = torch.zeros(Co, device=DEV)
     K.conv_wgrad(P, to_nhwc_gpu(dy.float()), dW, kh=3, kw=3, stride=1, pad=1, gather_i=True, Ci=Ci, Cj=Co,
-                 grid_g=(H, H), grid_d=(H, H), mode=1, P2=P2)
+                 grid_g=(H, H), grid_d=(H, H), mode=1, P2=P2, dbias=db)
     torch.cuda.synchronize()
+    assert rel_err(db, dy.sum((0, 2, 3))) < 1e-5          # bias gradient fused into the dY staging
     got = w_from_storage(dW.view(3, 3, Ci, Co))
     assert rel_err(got, w.grad) < 2e-2
     xq, dq = x.float().bfloat16().double(), dy.float().bfloat16().double()
@@ -470,9 +472,11 @@ def test_conv1x1_wgrad_fast(K, cfg):
     d = MiWgradDesc(N=N, GH=H, GW=H, DH=H, DW=H, Ci=Ci, Cj=Co, KH=1, KW=1, stride=1, pad=0, gather_i=1, mode=1,
                     I1=split or Ci, ldp=4, ldp2=4, ldq=4)
     assert load_library().mi_conv3x3_wgrad_supported(ctypes.byref(d)) == 1
+    db = torch.zeros(Co, device=DEV)
     K.conv_wgrad(P, to_nhwc_gpu(dy.float()), dW, kh=1, kw=1, stride=1, pad=0, gather_i=True, Ci=Ci, Cj=Co,
-                 grid_g=(H, H), grid_d=(H, H), mode=1, P2=P2)
+                 grid_g=(H, H), grid_d=(H, H), mode=1, P2=P2, dbias=db)
     torch.cuda.synchronize()
+    assert rel_err(db, dy.sum((0, 2, 3))) < 1e-5
     assert rel_err(w_from_storage(dW.view(1, 1, Ci, Co)), ref) < 2e-5
 
 
