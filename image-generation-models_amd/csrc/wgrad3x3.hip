@@ -393,6 +393,10 @@ static int w3_plan(const MiWgradDesc* d, W3Args& a, int& BJ, bool& wide) {
     a.total = (a.N / 8) * a.tiles;
     static const int force_nj = [] { const char* e = getenv("MI_W3_NJ"); return e ? atoi(e) : 0; }();
     wide = force_nj ? force_nj == 2 : (d->Cj % 128 == 0 || d->Cj > 256);
+    {   // the double-buffered LDS image must fit 160 KB: 4x4 images (25 X slots per channel) only fit with 64-wide co tiles
+        const int xp = ((a.TH * (a.TW + d->KH - 1)) | 1) * 8;
+        if ((size_t)(128 * xp + 128 * 17 * 8) * 2 * 2 > 160 * 1024) wide = false;
+    }
     BJ = wide ? 128 : 64;
     const int KS = d->KH;
     long base = (long)((d->Ci + 127) / 128) * ((d->Cj + BJ - 1) / BJ) * KS;

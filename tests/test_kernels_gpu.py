@@ -386,6 +386,7 @@ def test_conv3x3_halo_fwd_and_dgrad(K, cfg):
     dict(N=8, H=8, Ci=64, Co=192),
     dict(N=16, H=8, Ci=512, Co=256),
     dict(N=8, H=4, Ci=32, Co=32),
+    dict(N=8, H=4, Ci=128, Co=128),              # 4x4 images: 25 X slots per channel, LDS forces 64-wide co tiles
     dict(N=8, H=64, Ci=64, Co=64),
 ])
 def test_conv3x3_wgrad_fast(K, cfg):

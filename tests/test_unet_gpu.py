@@ -278,3 +278,71 @@ def test_run_py_end_to_end(tmp_path):
     assert ck["state_dict"]["denoising_model.downs.0.0.block1.block.0.weight"].shape == (16, 3, 3, 3)
     lines = (run_dir / "tensorboard" / "metrics.jsonl").read_text().strip().splitlines()
     assert lines and "train_loss/loss" in lines[-1]
+
+
+@pytest.mark.parametrize("mode,tol,gtol", [("fp32", 1e-4, 3e-3), ("bf16", 3e-2, 2e-1)])
+def test_cfg3_celeba_shape_vs_oracle(mode, tol, gtol):
+    """BASELINE cfg 3 (CelebA 64x64, hidden 64, mults 1-2-4-8, 4 levels): forward, loss and gradients vs the oracle."""
+    from oracle import ddpm_oracle as O
+    from src.models.ddpm import GaussianDiffusion
+    net = _seeded(64, (1, 2, 4, 8), mode)
+    g = torch.Generator().manual_seed(11)
+    B = 8
+    x = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1
+    t = torch.tensor([0, 999, 5, 250, 500, 750, 900, 42])
+    noise = torch.randn(B, 3, 64, 64, generator=g)
+    p = {k: v.detach().cpu().contiguous().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    tab = O.schedule_tables(1000)
+    ref_loss, ref_eps = O.p_losses(p, tab, x, t, noise)
+    ref_loss.backward()
+    gd = GaussianDiffusion(net, image_size=(64, 64), timesteps=1000).to(DEV)
+    net.eval()
+    with torch.no_grad():
+        eps = net(gd.q_sample(x.to(DEV), t.to(DEV), noise.to(DEV)), t.to(DEV))
+    assert rel_err(eps, ref_eps) < tol
+    net.train()
+    loss = gd.p_losses(x.to(DEV), t.to(DEV), noise.to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < (3e-5 if mode == "fp32" else 2e-2)
+    scale = max(float(v.grad.abs().max()) for v in p.values())
+    bad = []
+    for k, q in net.named_parameters():
+        r = p[k].grad
+        err = float((q.grad.cpu() - r).norm()) / (float(r.norm()) + 1e-3 * scale * r.numel() ** 0.5)
+        if err > gtol:
+            bad.append((k, err))
+    assert not bad, bad[:8]
+
+
+def test_rccl_world1_reducer():
+    """The data-parallel step on the real RCCL backend with a 1-rank group: bucketed async all-reduce of the
+    flat gradient slices as backward finalises them, then Adam with the folded 1/world scale."""
+    import torch.distributed as dist
+    from src.models.ddpm import GaussianDiffusion
+    from src.runtime.ddp import FlatGradReducer, broadcast_parameters
+    from src.runtime.optim import FlatAdam
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        net = _seeded(32, (1, 2, 4), "bf16").train()
+        gd = GaussianDiffusion(net, image_size=(16, 16), timesteps=1000).to(DEV)
+        broadcast_parameters(net.flat_params)
+        red = FlatGradReducer(net.flat_grads, bucket_bytes=1 << 20)
+        net.grad_ready_hook = red.range_ready
+        opt = FlatAdam(net, lr=1e-3, betas=(0.9, 0.999), grad_scale=red.grad_scale)
+        x = torch.rand(8, 3, 16, 16, device=DEV) * 2 - 1
+        losses = []
+        for _ in range(4):
+            red.begin()
+            loss = gd(x)
+            loss.backward()
+            red.finish()
+            opt.step()
+            losses.append(float(loss))
+        launched = red.launched
+        assert launched[0][1] >= net._arch.final_range[1] and launched[-1][0] == 0 and len(launched) >= 3
+        assert all(a[0] == b[1] or a[0] <= b[1] for a, b in zip(launched, launched[1:]))
+        assert np.isfinite(losses).all()
+    finally:
+        net.grad_ready_hook = None
+        dist.destroy_process_group()
