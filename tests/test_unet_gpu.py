@@ -346,3 +346,30 @@ def test_rccl_world1_reducer():
     finally:
         net.grad_ready_hook = None
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [5, 12])
+def test_ragged_batch_sizes_vs_oracle(B):
+    """Batch sizes that are not multiples of 8 / of the images-per-tile count take the fallback kernels
+    (the reference's last CIFAR batch has 80 images; B=5 and 12 exercise every fallback): bf16 mode vs the oracle."""
+    from oracle import ddpm_oracle as O
+    from src.models.ddpm import GaussianDiffusion
+    net = _seeded(64, (1, 2, 4), "bf16")
+    g = torch.Generator().manual_seed(B)
+    x = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn(B, 3, 32, 32, generator=g)
+    p = {k: v.detach().cpu().contiguous().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    ref_loss, ref_eps = O.p_losses(p, O.schedule_tables(1000), x, t, noise)
+    ref_loss.backward()
+    gd = GaussianDiffusion(net, image_size=(32, 32), timesteps=1000).to(DEV)
+    net.train()
+    loss = gd.p_losses(x.to(DEV), t.to(DEV), noise.to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 2e-2
+    worst = 0.0
+    for k, q in net.named_parameters():
+        r = p[k].grad
+        if float(r.norm()) > 1e-4:
+            worst = max(worst, float((q.grad.cpu() - r).norm() / r.norm()))
+    assert worst < 0.2, worst
