@@ -24,9 +24,10 @@ struct HaloArgs {
     int tiles_per_img;   // H/TH when TI == 1
 };
 
-template <int BM> struct HaloCfg {
-    static constexpr int NT = (BM == 256) ? 512 : 256;          // threads
-    static constexpr int MI = (BM >= 128) ? 2 : 1;              // 32-row MFMA tiles per wave (wave tile MI*32 x 64)
+// waves are arranged (WAVES/2) along M x 2 along N; a wave owns (MI*32) pixels x 64 channels
+template <int BM, int WAVES = (BM == 256 ? 8 : 4)> struct HaloCfg {
+    static constexpr int NT = 64 * WAVES;                        // threads
+    static constexpr int MI = BM / (16 * WAVES);                 // 32-row MFMA tiles per wave: 256/8 -> 2, 256/4 -> 4, 128/4 -> 2, 64/4 -> 1
     static constexpr int MAXHP = (BM == 256) ? 400 : (BM == 128 ? 288 : 160);
 };
 
@@ -37,11 +38,11 @@ template <int BM> struct HaloCfg {
 // the other halo buffer.  Every global load therefore has two taps of MFMA time to land, there
 // is one barrier per tap, and nothing is staged at chunk boundaries.  Taps are unrolled so the
 // two register sets are static.
-template <int BM, int CK, int KS, bool SK = false>
-__global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const HaloArgs a) {
+template <int BM, int CK, int KS, bool SK = false, int WAVES = (BM == 256 ? 8 : 4)>
+__global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(const HaloArgs a) {
     constexpr int BN = 128;
     constexpr int NTAP = KS * KS;                  // 9, or 1 for the 1x1 convolutions (plain GEMM, no halo)
-    constexpr int NT = HaloCfg<BM>::NT, MI = HaloCfg<BM>::MI, NI = 2;
+    constexpr int NT = HaloCfg<BM, WAVES>::NT, MI = HaloCfg<BM, WAVES>::MI, NI = 2;
     constexpr int PITCH = CK + 8;                  // bf16 elements; 16-B aligned rows, conflict-free b128 reads
     constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
     constexpr int Q = CK / 4;                      // float4 per halo pixel per chunk
@@ -268,18 +269,18 @@ __global__ __launch_bounds__(HaloCfg<BM>::NT) void conv3x3_halo_kernel(const Hal
     }
 }
 
-template <int BM, int CK, int KS = 3, bool SK = false>
+template <int BM, int CK, int KS = 3, bool SK = false, int WAVES = (BM == 256 ? 8 : 4)>
 void launch_halo(const HaloArgs& a, hipStream_t st) {
     constexpr int PITCH = CK + 8;
     constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
     size_t lds = (size_t)(2 * MAXHP * PITCH + 2 * 128 * PITCH) * 2 + MAXHP * 4;
     dim3 grid((a.N * a.H * a.W + BM - 1) / BM, (a.Nc + 127) / 128, a.ksplit);
     static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS, SK>), grid, dim3(HaloCfg<BM>::NT), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS, SK, WAVES>), grid, dim3(HaloCfg<BM, WAVES>::NT), lds, st, a);
 }
 
 // fp32 [tap][k][n] master weights -> bf16 Wd[tap][k][n] (same layout) and Wf[tap][n][k] (transposed per tap)
@@ -428,7 +429,9 @@ extern "C" int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float
     MI_REQUIRE(halo_geom(d, BM, &a.TH, &a.TI), "halo tile geometry");
     a.tiles_per_img = a.TI > 1 ? 1 : a.H / a.TH;
     a.HP = a.TI * (a.TH + 2) * (a.W + 2);
-    if (BM == 256)      { if (CK == 64) launch_halo<256, 64>(a, st); else launch_halo<256, 32>(a, st); }
+    // (a 4-wave variant with 128x64 wave tiles was measured 15 % slower than 8 waves of 64x64: thread-level
+    //  parallelism matters more than LDS bytes per MFMA here)
+    if (BM == 256) { if (CK == 64) launch_halo<256, 64>(a, st); else launch_halo<256, 32>(a, st); }
     else if (BM == 128) { if (CK == 64) launch_halo<128, 64>(a, st); else launch_halo<128, 32>(a, st); }
     else                { if (CK == 64) launch_halo<64, 64>(a, st); else launch_halo<64, 32>(a, st); }
     MI_LAUNCH_CHECK();

@@ -154,6 +154,15 @@ __global__ void scale_dev_kernel(int M, int C, float* __restrict__ x, int ld, co
         x[(i / C) * ld + (i % C)] *= a;
 }
 
+// out[b][:] = table[idx[b]][:]   (time-bias rows for the sampler: the time MLP depends on t only)
+__global__ void gather_rows_kernel(int B, int C, const float* __restrict__ table, const int64_t* __restrict__ idx, float* __restrict__ out) {
+    size_t tot = (size_t)B * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        size_t b = i / C; int c = i % C;
+        out[i] = table[(size_t)idx[b] * C + c];
+    }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -241,6 +250,12 @@ extern "C" int mi_axpby2d(int M, int C, float a, const float* x, int ldx, int ac
 extern "C" int mi_scale_by_device_scalar(int M, int C, float* x, int ld, const float* scalar, void* stream) {
     MI_REQUIRE(M > 0 && C > 0 && x && scalar && ld >= C, "bad argument");
     hipLaunchKernelGGL(scale_dev_kernel, dim3(nblocks((size_t)M * C)), dim3(TPB), 0, ST, M, C, x, ld, scalar);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_gather_rows(int B, int C, const float* table, const int64_t* idx, float* out, void* stream) {
+    MI_REQUIRE(B > 0 && C > 0 && table && idx && out, "bad argument");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nblocks((size_t)B * C)), dim3(TPB), 0, ST, B, C, table, idx, out);
     MI_LAUNCH_CHECK();
     return 0;
 }

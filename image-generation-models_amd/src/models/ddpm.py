@@ -373,8 +373,28 @@ class Unet(nn.Module):
         return K.nhwc_to_nchw(eps), tape
 
     # ------------------------------------------------------------------ kernel-level forward
-    def forward_nhwc(self, x, time, record=False):
-        """x: NHWC activation [B,H,W,channels] (pixel stride 4-aligned) -> NHWC eps prediction + tape."""
+    @torch.no_grad()
+    def time_bias_table(self, timesteps: int) -> torch.Tensor:
+        """Every ResnetBlock's time bias for t = 0..T-1, [T, sum Cout]: the time MLP (ddpm.py:186-193) and the
+        per-block Linear(Mish(.)) (ddpm.py:126-130,139-140) depend on t only, so a T-step sampler computes them
+        once instead of T times (inference only: the table is stale once the weights change)."""
+        A, sv, flat = self._arch, self._sv, self._flat
+        T = int(timesteps)
+        t = torch.arange(T, device=flat.device, dtype=torch.long)
+
+        def lin(inp, w, b):
+            o, i = w.shape
+            return K.conv_igemm(inp.view(T, 1, 1, i), w, kh=1, kw=1, stride=1, pad=0, transposed=False, w_kn=False,
+                                K=i, Nc=o, out_hw=(1, 1), mode=K.MODE_FP32, bias=b).view(T, o)
+        temb = lin(K.mish_fwd(lin(K.time_embed(t, A.dim), sv["time_mlp.1.weight"], sv["time_mlp.1.bias"])),
+                   sv["time_mlp.3.weight"], sv["time_mlp.3.bias"])
+        w_all = flat[A.mlp_w_off:A.mlp_w_off + A.mlp_rows * A.dim].view(A.mlp_rows, A.dim)
+        b_all = flat[A.mlp_b_off:A.mlp_b_off + A.mlp_rows]
+        return lin(K.mish_fwd(temb), w_all, b_all).contiguous()
+
+    def forward_nhwc(self, x, time, record=False, time_bias_table=None):
+        """x: NHWC activation [B,H,W,channels] (pixel stride 4-aligned) -> NHWC eps prediction + tape.
+        time_bias_table (inference only): rows of `time_bias_table(T)` replace the time MLP."""
         A, sv, mode = self._arch, self._sv, _mode_id(self.compute_mode)
         tape: Optional[list] = [] if record else None
         B, H, W, _ = x.shape
@@ -389,16 +409,19 @@ class Unet(nn.Module):
             return y.view(B, o)
 
         # ---- time embedding MLP (ddpm.py:186-193) and every block's time bias (ddpm.py:126-130) in one GEMM
-        te = K.time_embed(time, A.dim)
-        t1 = lin(te, "time_mlp.1.")
-        a1 = K.mish_fwd(t1)
-        temb = lin(a1, "time_mlp.3.")
-        mt = K.mish_fwd(temb)
-        w_all = flat[A.mlp_w_off:A.mlp_w_off + A.mlp_rows * A.dim].view(A.mlp_rows, A.dim)
-        b_all = flat[A.mlp_b_off:A.mlp_b_off + A.mlp_rows]
-        tb_all = lin(mt, None, w=w_all, b=b_all)                       # [B, sum Cout]
-        if record:
-            tape.append(("time", te, t1, a1, temb, mt))
+        if time_bias_table is not None and not record:
+            tb_all = K.gather_rows(time_bias_table, time)                  # sampler: precomputed per timestep
+        else:
+            te = K.time_embed(time, A.dim)
+            t1 = lin(te, "time_mlp.1.")
+            a1 = K.mish_fwd(t1)
+            temb = lin(a1, "time_mlp.3.")
+            mt = K.mish_fwd(temb)
+            w_all = flat[A.mlp_w_off:A.mlp_w_off + A.mlp_rows * A.dim].view(A.mlp_rows, A.dim)
+            b_all = flat[A.mlp_b_off:A.mlp_b_off + A.mlp_rows]
+            tb_all = lin(mt, None, w=w_all, b=b_all)                       # [B, sum Cout]
+            if record:
+                tape.append(("time", te, t1, a1, temb, mt))
 
         if mode == K.MODE_BF16:
             wd_sh, wf_sh = self._shadows()

@@ -368,3 +368,10 @@ def scale_by_device_scalar(x, s):
     s = s.reshape(1).float()
     check(load_library().mi_scale_by_device_scalar(_rows(x), x.shape[-1], _p(x), ld_of(x), _p(s), _stream()),
           "mi_scale_by_device_scalar")
+
+
+def gather_rows(table, idx):
+    """table[T, C] fp32, idx int64 [B] on the device -> [B, C]."""
+    out = torch.empty((idx.shape[0], table.shape[1]), device=table.device, dtype=torch.float32)
+    check(load_library().mi_gather_rows(idx.shape[0], table.shape[1], _p(table), _p(idx), _p(out), _stream()), "mi_gather_rows")
+    return out

@@ -20,15 +20,25 @@ class GraphSampler:
         self.t = torch.zeros((shape[0],), device=dev, dtype=torch.long)
         self.one = torch.ones((shape[0],), device=dev, dtype=torch.long)
         self.graph = None
+        self.tb_table = None          # per-timestep time biases, computed once per capture (weights are frozen while sampling)
 
     def _iteration(self):
         gd = self.gd
-        eps, _ = gd.denoise_fn.forward_nhwc(K.nchw_to_nhwc(self.x), self.t, record=False)
+        eps, _ = gd.denoise_fn.forward_nhwc(K.nchw_to_nhwc(self.x), self.t, record=False, time_bias_table=self.tb_table)
         xp, _ = K.p_sample_update(self.x, eps, self.z, self.t, gd._tables(), clip=True, want_nhwc=False)
         self.x.copy_(xp)
         self.t.sub_(self.one)
 
+    def refresh(self):
+        """Recompute the time-bias table in place (call after the weights changed; the captured graph reads it)."""
+        tab = self.gd.denoise_fn.time_bias_table(self.gd.num_timesteps)
+        if self.tb_table is None:
+            self.tb_table = tab
+        else:
+            self.tb_table.copy_(tab)
+
     def _capture(self):
+        self.refresh()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                      # warm-up outside capture (allocator, lazy init)
@@ -44,6 +54,8 @@ class GraphSampler:
         gd = self.gd
         if self.graph is None:
             self._capture()
+        else:
+            self.refresh()
         self.x.copy_(torch.randn(self.shape, device=self.x.device))
         self.t.fill_(gd.num_timesteps - 1)
         for _ in range(gd.num_timesteps):

@@ -215,6 +215,8 @@ int mi_adam_step(size_t n, float* p, const float* g, float* m, float* v, float l
 int mi_axpby(size_t n, float a, const float* x, int accumulate, float* y, void* stream);
 /* same on M rows of C channels with row strides (gradient accumulation into channel slices) */
 int mi_axpby2d(int M, int C, float a, const float* x, int ldx, int accumulate, float* y, int ldy, void* stream);
+/* out[b][0..C) = table[idx[b]][0..C): per-sample rows of a precomputed table (the sampler's time-bias table) */
+int mi_gather_rows(int B, int C, const float* table, const int64_t* idx, float* out, void* stream);
 /* x[m*ld + c] *= *scalar (scalar lives on the device: autograd's incoming d(loss), no host sync) */
 int mi_scale_by_device_scalar(int M, int C, float* x, int ld, const float* scalar, void* stream);
 

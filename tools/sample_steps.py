@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""N hipGraph denoise steps at B=64 and nothing else (for rocprofv3 --kernel-trace --stats)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "image-generation-models_amd")]
+import torch
+from src.models.ddpm import DDPM
+from src.runtime.sampler import GraphSampler
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+torch.manual_seed(0)
+m = DDPM({"width": 32, "height": 32, "channels": 3, "transforms": {"normalize": True}}, hidden_dim=128, dim_mults=(1, 2, 4)).to("cuda")
+m.denoising_model.compute_mode = os.environ.get("MODE", "bf16"); m.eval()
+gs = GraphSampler(m.diffusion_model, (B, 3, 32, 32)); gs._capture()
+gs.x.normal_(); gs.t.fill_(999)
+for _ in range(n):
+    gs.z.normal_(); gs.graph.replay()
+torch.cuda.synchronize()
