@@ -38,8 +38,11 @@ template <int BM, int WAVES = (BM == 256 ? 8 : 4)> struct HaloCfg {
 // the other halo buffer.  Every global load therefore has two taps of MFMA time to land, there
 // is one barrier per tap, and nothing is staged at chunk boundaries.  Taps are unrolled so the
 // two register sets are static.
-template <int BM, int CK, int KS, bool SK = false, int WAVES = (BM == 256 ? 8 : 4)>
+// IO bit 0: activations x / x2 are stored as bf16 (copied to LDS as they are); bit 1: y is written as bf16.
+template <int BM, int CK, int KS, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4)>
 __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(const HaloArgs a) {
+    constexpr bool IN16 = IO & 1, OUT16 = IO & 2;
+    static_assert(!(SK && OUT16), "split-K accumulates with fp32 atomics");
     constexpr int BN = 128;
     constexpr int NTAP = KS * KS;                  // 9, or 1 for the 1x1 convolutions (plain GEMM, no halo)
     constexpr int NT = HaloCfg<BM, WAVES>::NT, MI = HaloCfg<BM, WAVES>::MI, NI = 2;
@@ -122,7 +125,13 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
         for (int j = 0; j < A_SL; ++j) {
             const int hp = a_hp0 + (sl * A_SL + j) * (NT / Q);
             const int pv = hp < MAXHP ? pix[hp] : -1;
-            float4 v = *reinterpret_cast<const float4*>(src + (size_t)(pv >= 0 ? pv : 0) * ld + cc + a_c4 * 4);
+            float4 v;
+            if constexpr (IN16) {     // 4 bf16 = 8 bytes, carried in .x/.y
+                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(src) + (size_t)(pv >= 0 ? pv : 0) * ld + cc + a_c4 * 4);
+                v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+            } else {
+                v = *reinterpret_cast<const float4*>(src + (size_t)(pv >= 0 ? pv : 0) * ld + cc + a_c4 * 4);
+            }
             r[j] = pv >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -132,7 +141,8 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
             const int hp = a_hp0 + (sl * A_SL + j) * (NT / Q);
             if (hp < (KS == 1 ? MAXHP : a.HP))
                 *reinterpret_cast<uint2*>(&As[buf * (MAXHP * PITCH) + hp * PITCH + a_c4 * 4]) =
-                    make_uint2(pack_bf16(r[j].x, r[j].y), pack_bf16(r[j].z, r[j].w));
+                    IN16 ? make_uint2(__float_as_uint(r[j].x), __float_as_uint(r[j].y))
+                         : make_uint2(pack_bf16(r[j].x, r[j].y), pack_bf16(r[j].z, r[j].w));
         }
     };
     auto load_b = [&](uint4 (&r)[B_IT], int g) {
@@ -262,25 +272,35 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
                 float4 v = make_float4(acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]);
                 if (a.bias && first) { float4 b = *reinterpret_cast<const float4*>(a.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
                 if (a.res && first) { float4 r = *reinterpret_cast<const float4*>(a.res + m * a.ldr + col); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-                float* yp = a.y + m * a.ldy + col;
-                if (a.accumulate) { float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                *reinterpret_cast<float4*>(yp) = v;
+                if constexpr (OUT16) {
+                    uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + m * a.ldy + col;
+                    if (a.accumulate) {
+                        const uint2 o = *reinterpret_cast<const uint2*>(yp);
+                        v.x += __uint_as_float(o.x << 16); v.y += __uint_as_float(o.x & 0xffff0000u);
+                        v.z += __uint_as_float(o.y << 16); v.w += __uint_as_float(o.y & 0xffff0000u);
+                    }
+                    *reinterpret_cast<uint2*>(yp) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+                } else {
+                    float* yp = a.y + m * a.ldy + col;
+                    if (a.accumulate) { float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *reinterpret_cast<float4*>(yp) = v;
+                }
             }
     }
 }
 
-template <int BM, int CK, int KS = 3, bool SK = false, int WAVES = (BM == 256 ? 8 : 4)>
+template <int BM, int CK, int KS = 3, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4)>
 void launch_halo(const HaloArgs& a, hipStream_t st) {
     constexpr int PITCH = CK + 8;
     constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
     size_t lds = (size_t)(2 * MAXHP * PITCH + 2 * 128 * PITCH) * 2 + MAXHP * 4;
     dim3 grid((a.N * a.H * a.W + BM - 1) / BM, (a.Nc + 127) / 128, a.ksplit);
     static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS, SK, WAVES>), grid, dim3(HaloCfg<BM, WAVES>::NT), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES>), grid, dim3(HaloCfg<BM, WAVES>::NT), lds, st, a);
 }
 
 // fp32 [tap][k][n] master weights -> bf16 Wd[tap][k][n] (same layout) and Wf[tap][n][k] (transposed per tap)
@@ -361,8 +381,25 @@ static bool halo_ok(const MiConvDesc* d, int* bm, int* ck) {
     return true;
 }
 
+static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
+                         const float* bias, const float* residual, float* y, int io, void* stream);
+
 extern "C" int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
                                 const float* bias, const float* residual, float* y, void* stream) {
+    return halo_dispatch(d, x, x2, w_nk_bf16, bias, residual, y, 0, stream);
+}
+
+// Same kernel with bf16 activation storage: io bit 0 = x (and x2) are bf16 tensors, bit 1 = y is written as bf16
+// (pixel strides then count bf16 elements).  3x3 only; the split-K variant cannot write bf16 (fp32 atomics), so
+// with bit 1 set small-M layers use the 64/128-pixel tiles instead.
+extern "C" int mi_conv3x3_bf16w_io(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16,
+                                   const float* bias, const float* residual, void* y, int io, void* stream) {
+    if (!d || d->KH != 3 || (io & ~3)) return mi_set_error(-1, "mi_conv3x3_bf16w_io: 3x3 only, io in 0..3");
+    return halo_dispatch(d, (const float*)x, (const float*)x2, w_nk_bf16, bias, residual, (float*)y, io, stream);
+}
+
+static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
+                         const float* bias, const float* residual, float* y, int io, void* stream) {
     MI_REQUIRE(d && x && w_nk_bf16 && y, "null argument");
     int BM, CK;
     MI_REQUIRE(halo_ok(d, &BM, &CK), "descriptor not supported by the halo kernel (use mi_conv_igemm)");
@@ -378,7 +415,7 @@ extern "C" int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float
     // Small-M layers (8x8 levels): a 256-pixel x 64-channel-chunk tile with the K loop split over
     // 2-4 workgroups beats 64-pixel tiles (weights are re-read per M tile); slices are summed with
     // row-coalesced fp32 atomics.
-    if (d->KH == 3 && BM < 256 && d->K % 64 == 0 && d->K1 % 64 == 0 && (d->accumulate || d->ldy == d->Nc)) {
+    if (d->KH == 3 && !(io & 2) && BM < 256 && d->K % 64 == 0 && d->K1 % 64 == 0 && (d->accumulate || d->ldy == d->Nc)) {
         static const int allow = [] { const char* e = getenv("MI_HALO_SPLITK"); return e ? atoi(e) : 1; }();
         int th, ti;
         const long b256 = ((long)d->N * d->OH * d->OW + 255) / 256 * ((d->Nc + 127) / 128);
@@ -393,7 +430,7 @@ extern "C" int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float
                     hipError_t e = hipMemsetAsync(y, 0, (size_t)d->N * d->OH * d->OW * d->ldy * sizeof(float), st);
                     if (e != hipSuccess) return mi_set_error((int)e, "mi_conv3x3_bf16w: memset: %s", hipGetErrorString(e));
                 }
-                launch_halo<256, 64, 3, true>(a, st);
+                if (io & 1) launch_halo<256, 64, 3, true, 1>(a, st); else launch_halo<256, 64, 3, true>(a, st);
                 MI_LAUNCH_CHECK();
                 return 0;
             }
@@ -431,9 +468,12 @@ extern "C" int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float
     a.HP = a.TI * (a.TH + 2) * (a.W + 2);
     // (a 4-wave variant with 128x64 wave tiles was measured 15 % slower than 8 waves of 64x64: thread-level
     //  parallelism matters more than LDS bytes per MFMA here)
-    if (BM == 256) { if (CK == 64) launch_halo<256, 64>(a, st); else launch_halo<256, 32>(a, st); }
-    else if (BM == 128) { if (CK == 64) launch_halo<128, 64>(a, st); else launch_halo<128, 32>(a, st); }
-    else                { if (CK == 64) launch_halo<64, 64>(a, st); else launch_halo<64, 32>(a, st); }
+#define MI_HALO_GO(IOV) \
+    do { if (BM == 256) { if (CK == 64) launch_halo<256, 64, 3, false, IOV>(a, st); else launch_halo<256, 32, 3, false, IOV>(a, st); } \
+         else if (BM == 128) launch_halo<128, 32, 3, false, IOV>(a, st); \
+         else launch_halo<64, 32, 3, false, IOV>(a, st); } while (0)
+    switch (io) { case 0: MI_HALO_GO(0); break; case 1: MI_HALO_GO(1); break; case 2: MI_HALO_GO(2); break; default: MI_HALO_GO(3); break; }
+#undef MI_HALO_GO
     MI_LAUNCH_CHECK();
     return 0;
 }

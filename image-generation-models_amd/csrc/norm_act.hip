@@ -21,6 +21,23 @@ template <> struct V<1> {
     __device__ void store(float* p) const { *p = v[0]; }
 };
 
+// element-type-generic access: T16 = tensor stored as bf16 (offsets count elements)
+template <int VEC, bool T16> __device__ __forceinline__ V<VEC> vload(const void* base, size_t off) {
+    if constexpr (!T16) return V<VEC>::load(reinterpret_cast<const float*>(base) + off);
+    else if constexpr (VEC == 4) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + off);
+        return V<4>{{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)}};
+    } else {
+        return V<1>{{__uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(base)[off] << 16)}};
+    }
+}
+template <int VEC, bool T16> __device__ __forceinline__ void vstore(void* base, size_t off, const V<VEC>& v) {
+    if constexpr (!T16) v.store(reinterpret_cast<float*>(base) + off);
+    else if constexpr (VEC == 4)
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + off) = make_uint2(pack_bf16(v.v[0], v.v[1]), pack_bf16(v.v[2], v.v[3]));
+    else reinterpret_cast<uint16_t*>(base)[off] = (uint16_t)(pack_bf16(v.v[0], 0.f) & 0xffff);
+}
+
 struct GnArgs {
     const float* x; const float* gamma; const float* beta; const float* temb; const float* res;
     float* y; float* stats;
@@ -31,14 +48,15 @@ struct GnArgs {
 
 // thread layout inside a (n,g) slice: W = Cg/VEC channel units per pixel; unit u = t % W handles
 // channels [u*VEC, u*VEC+VEC); pixel rows pr = t / W, step PP = 256 / W.
-template <int VEC, int MAXU>
+template <int VEC, int MAXU, int IO = 0>     // IO bit 0: x is bf16, bit 1: y is bf16
 __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
+    constexpr bool X16 = IO & 1, Y16 = IO & 2;
     __shared__ float red[8];
     const int n = blockIdx.x / a.G, g = blockIdx.x % a.G;
     const int W = a.Cg / VEC, PP = 256 / W;
     const int t = threadIdx.x, u = t % W, pr = t / W;
     const int c0 = g * a.Cg + u * VEC;
-    const float* xb = a.x + (size_t)n * a.HW * a.ldx + c0;
+    const size_t xoff = (size_t)n * a.HW * a.ldx + c0;        // element offsets (x may be fp32 or bf16)
     const float cnt = (float)a.HW * (float)a.Cg;
 
     V<VEC> cache[MAXU > 0 ? MAXU : 1];
@@ -48,14 +66,14 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
         for (int k = 0; k < MAXU; ++k) {
             int p = pr + k * PP;
             if (p < a.HW) {
-                cache[k] = V<VEC>::load(xb + (size_t)p * a.ldx);
+                cache[k] = vload<VEC, X16>(a.x, xoff + (size_t)p * a.ldx);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) s += cache[k].v[j];
             }
         }
     } else {
         for (int p = pr; p < a.HW; p += PP) {
-            V<VEC> q = V<VEC>::load(xb + (size_t)p * a.ldx);
+            V<VEC> q = vload<VEC, X16>(a.x, xoff + (size_t)p * a.ldx);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) s += q.v[j];
         }
@@ -72,7 +90,7 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
         }
     } else {
         for (int p = pr; p < a.HW; p += PP) {
-            V<VEC> q = V<VEC>::load(xb + (size_t)p * a.ldx);
+            V<VEC> q = vload<VEC, X16>(a.x, xoff + (size_t)p * a.ldx);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { float dlt = q.v[j] - mean; s2 += dlt * dlt; }
         }
@@ -88,7 +106,7 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
         be[j] = a.beta[c0 + j] - mean * ga[j];
         tb[j] = a.temb ? a.temb[(size_t)n * a.ldt + c0 + j] : 0.f;
     }
-    float* yb = a.y + (size_t)n * a.HW * a.ldy + c0;
+    const size_t yoff = (size_t)n * a.HW * a.ldy + c0;
     const float* rb = a.res ? a.res + (size_t)n * a.HW * a.ldr + c0 : nullptr;
     auto apply = [&](V<VEC> q, int p) {
         V<VEC> o;
@@ -99,19 +117,20 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o.v[j] += r.v[j];
         }
-        o.store(yb + (size_t)p * a.ldy);
+        vstore<VEC, Y16>(a.y, yoff + (size_t)p * a.ldy, o);
     };
     if constexpr (MAXU > 0) {
 #pragma unroll
         for (int k = 0; k < MAXU; ++k) { int p = pr + k * PP; if (p < a.HW) apply(cache[k], p); }
     } else {
-        for (int p = pr; p < a.HW; p += PP) apply(V<VEC>::load(xb + (size_t)p * a.ldx), p);
+        for (int p = pr; p < a.HW; p += PP) apply(vload<VEC, X16>(a.x, xoff + (size_t)p * a.ldx), p);
     }
 }
 
 // Backward of y = mish(xhat*gamma+beta) + temb + res wrt x (the conv output), gamma, beta, temb.
-template <int VEC, int MAXU>
+template <int VEC, int MAXU, int IO = 0>     // IO bit 0: x is bf16, bit 1: dx is written as bf16, bit 2: dout is bf16
 __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
+    constexpr bool X16 = IO & 1, DX16 = IO & 2, DO16 = IO & 4;
     __shared__ float part[4][256 * VEC];
     __shared__ float chs[4][128];
     __shared__ float s12[2];
@@ -120,8 +139,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
     const int t = threadIdx.x, u = t % W, pr = t / W;
     const int c0 = g * a.Cg + u * VEC;
     const float mean = a.stats[2 * blockIdx.x], rstd = a.stats[2 * blockIdx.x + 1];
-    const float* xb = a.x + (size_t)n * a.HW * a.ldx + c0;
-    const float* db = a.dout + (size_t)n * a.HW * a.lddo + c0;
+    const size_t xoff = (size_t)n * a.HW * a.ldx + c0, dooff = (size_t)n * a.HW * a.lddo + c0;
     const float cnt = (float)a.HW * (float)a.Cg;
     float ga[VEC], be[VEC];
 #pragma unroll
@@ -133,8 +151,8 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
     for (int j = 0; j < VEC; ++j) sA[j] = sD[j] = sT[j] = sB[j] = 0.f;
 
     auto pass1 = [&](int p, V<VEC>& xh, V<VEC>& dz) {
-        V<VEC> q = V<VEC>::load(xb + (size_t)p * a.ldx);
-        V<VEC> d = V<VEC>::load(db + (size_t)p * a.lddo);
+        V<VEC> q = vload<VEC, X16>(a.x, xoff + (size_t)p * a.ldx);
+        V<VEC> d = vload<VEC, DO16>(a.dout, dooff + (size_t)p * a.lddo);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             float h = (q.v[j] - mean) * rstd;
@@ -186,20 +204,20 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
             atomicAdd(a.dbias + c, rstd * (gm * chs[0][t] - ((float)a.HW * s1 + s2 * chs[3][t]) / cnt));
         }
     }
-    float* dxb = a.dx + (size_t)n * a.HW * a.lddx + c0;
+    const size_t dxoff = (size_t)n * a.HW * a.lddx + c0;
     auto pass2 = [&](int p, const V<VEC>& xh, const V<VEC>& dz) {
         V<VEC> o;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o.v[j] = rstd * (dz.v[j] * ga[j] - (s1 + xh.v[j] * s2) / cnt);
-        o.store(dxb + (size_t)p * a.lddx);
+        vstore<VEC, DX16>(a.dx, dxoff + (size_t)p * a.lddx, o);
     };
     if constexpr (MAXU > 0) {
 #pragma unroll
         for (int k = 0; k < MAXU; ++k) { int p = pr + k * PP; if (p < a.HW) pass2(p, cx[k], cd[k]); }
     } else {
         for (int p = pr; p < a.HW; p += PP) {
-            V<VEC> q = V<VEC>::load(xb + (size_t)p * a.ldx);
-            V<VEC> d = V<VEC>::load(db + (size_t)p * a.lddo);
+            V<VEC> q = vload<VEC, X16>(a.x, xoff + (size_t)p * a.ldx);
+            V<VEC> d = vload<VEC, DO16>(a.dout, dooff + (size_t)p * a.lddo);
             V<VEC> xh, dz;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
@@ -358,18 +376,19 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
 
 }  // namespace
 
-#define GN_DISPATCH(KERNEL)                                                                         \
+#define GN_DISPATCH_IO(KERNEL, IOV)                                                                 \
     do {                                                                                            \
         dim3 grid(a.N * a.G), blk(256);                                                             \
         if (vec == 4) {                                                                             \
-            if (units <= 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, blk, 0, st, a);                \
-            else if (units <= 16) hipLaunchKernelGGL((KERNEL<4, 16>), grid, blk, 0, st, a);         \
-            else hipLaunchKernelGGL((KERNEL<4, 0>), grid, blk, 0, st, a);                           \
+            if (units <= 4) hipLaunchKernelGGL((KERNEL<4, 4, IOV>), grid, blk, 0, st, a);           \
+            else if (units <= 16) hipLaunchKernelGGL((KERNEL<4, 16, IOV>), grid, blk, 0, st, a);    \
+            else hipLaunchKernelGGL((KERNEL<4, 0, IOV>), grid, blk, 0, st, a);                      \
         } else {                                                                                    \
-            if (units <= 16) hipLaunchKernelGGL((KERNEL<1, 16>), grid, blk, 0, st, a);              \
-            else hipLaunchKernelGGL((KERNEL<1, 0>), grid, blk, 0, st, a);                           \
+            if (units <= 16) hipLaunchKernelGGL((KERNEL<1, 16, IOV>), grid, blk, 0, st, a);         \
+            else hipLaunchKernelGGL((KERNEL<1, 0, IOV>), grid, blk, 0, st, a);                      \
         }                                                                                           \
     } while (0)
+#define GN_DISPATCH(KERNEL) GN_DISPATCH_IO(KERNEL, 0)
 
 extern "C" int mi_gn_mish_fwd(const MiGnDesc* d, const float* x, const float* gamma, const float* beta,
                               const float* temb, int ldt, const float* residual, float* y, float* stats,
@@ -400,6 +419,55 @@ extern "C" int mi_gn_mish_bwd(const MiGnDesc* d, const float* x, const float* st
     a.dx = dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta; a.dtemb = dtemb; a.ldt = ldt; a.dbias = dbias;
     hipStream_t st = (hipStream_t)stream;
     GN_DISPATCH(gn_mish_bwd_kernel);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- the same two kernels with bf16 storage of the block-internal tensors -------------------------
+// fwd io: bit 0 = x (conv output) is bf16, bit 1 = y is written as bf16.  residual / temb / stats stay fp32.
+extern "C" int mi_gn_mish_fwd_io(const MiGnDesc* d, const void* x, const float* gamma, const float* beta,
+                                 const float* temb, int ldt, const float* residual, void* y, float* stats, int io,
+                                 void* stream) {
+    MI_REQUIRE(x && gamma && beta && y && !(io & ~3), "bad argument");
+    GnArgs a{};
+    int vec, units;
+    int rc = gn_prepare(d, a, vec, units);
+    MI_REQUIRE(rc == 0 && vec == 4, "bf16 storage needs C/G to be a multiple of 4 (power of two <= 128)");
+    MI_REQUIRE(d->ldx % 4 == 0 && d->ldy % 4 == 0 && (!residual || d->ldr % 4 == 0), "ld must be a multiple of 4");
+    a.x = (const float*)x; a.gamma = gamma; a.beta = beta; a.temb = temb; a.ldt = ldt; a.res = residual; a.y = (float*)y; a.stats = stats;
+    hipStream_t st = (hipStream_t)stream;
+    switch (io) {
+        case 0: GN_DISPATCH_IO(gn_mish_fwd_kernel, 0); break;
+        case 1: GN_DISPATCH_IO(gn_mish_fwd_kernel, 1); break;
+        case 2: GN_DISPATCH_IO(gn_mish_fwd_kernel, 2); break;
+        default: GN_DISPATCH_IO(gn_mish_fwd_kernel, 3); break;
+    }
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+// bwd io: bit 0 = x is bf16, bit 1 = dx is written as bf16, bit 2 = dout is bf16.
+extern "C" int mi_gn_mish_bwd_io(const MiGnDesc* d, const void* x, const float* stats, const float* gamma,
+                                 const float* beta, const void* dout, int lddo, void* dx, int lddx,
+                                 float* dgamma, float* dbeta, float* dtemb, int ldt, float* dbias, int io, void* stream) {
+    MI_REQUIRE(x && stats && gamma && beta && dout && dx && !(io & ~7), "bad argument");
+    GnArgs a{};
+    int vec, units;
+    int rc = gn_prepare(d, a, vec, units);
+    MI_REQUIRE(rc == 0 && vec == 4, "bf16 storage needs C/G to be a multiple of 4 (power of two <= 128)");
+    MI_REQUIRE(d->ldx % 4 == 0 && lddo % 4 == 0 && lddx % 4 == 0, "ld must be a multiple of 4");
+    a.x = (const float*)x; a.stats = const_cast<float*>(stats); a.gamma = gamma; a.beta = beta; a.dout = (const float*)dout; a.lddo = lddo;
+    a.dx = (float*)dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta; a.dtemb = dtemb; a.ldt = ldt; a.dbias = dbias;
+    hipStream_t st = (hipStream_t)stream;
+    switch (io) {
+        case 0: GN_DISPATCH_IO(gn_mish_bwd_kernel, 0); break;
+        case 1: GN_DISPATCH_IO(gn_mish_bwd_kernel, 1); break;
+        case 2: GN_DISPATCH_IO(gn_mish_bwd_kernel, 2); break;
+        case 3: GN_DISPATCH_IO(gn_mish_bwd_kernel, 3); break;
+        case 4: GN_DISPATCH_IO(gn_mish_bwd_kernel, 4); break;
+        case 5: GN_DISPATCH_IO(gn_mish_bwd_kernel, 5); break;
+        case 6: GN_DISPATCH_IO(gn_mish_bwd_kernel, 6); break;
+        default: GN_DISPATCH_IO(gn_mish_bwd_kernel, 7); break;
+    }
     MI_LAUNCH_CHECK();
     return 0;
 }

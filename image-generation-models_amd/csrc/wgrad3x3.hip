@@ -26,8 +26,10 @@ struct W3Args {
     int ablate;          // profiling only: 1 = no MFMA, 2 = no global loads, 4 = no LDS commit, 8 = no fragment reads
 };
 
-template <int NJ, int KS>
+// IO bit 0: P (layer input) is stored as bf16, bit 1: Q (output gradient) is stored as bf16.
+template <int NJ, int KS, int IO = 0>
 __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
+    constexpr bool P16 = IO & 1, Q16 = IO & 2;
     constexpr int BI = 128, BJ = 32 * 2 * NJ;
     constexpr int YP = 17 * 8;                          // dY pitch per co row (bf16 elems): 16 slots + 1 pad
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];      // BI*XP + BJ*YP bf16
@@ -107,20 +109,32 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
             const bool ok = x_pos[j] < PX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && x_ch[j] < a.Ci;
             const float* src = a.P; int ld = a.ldp; int cc = x_ch[j];
             if (cc >= a.I1) { src = a.P2; ld = a.ldp2; cc -= a.I1; }
-            const float* base = ok ? src + ((size_t)n0 * HW + iy * a.W + ix) * ld + cc : src + (size_t)n0 * HW * ld;
+            const size_t eoff = ok ? ((size_t)n0 * HW + iy * a.W + ix) * ld + cc : (size_t)n0 * HW * ld;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * HW * ld);
+                float4 v;
+                if constexpr (P16) {      // 4 bf16 channels = 8 bytes, carried in .x/.y
+                    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(src) + eoff + (size_t)q * HW * ld);
+                    v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+                } else {
+                    v = *reinterpret_cast<const float4*>(src + eoff + (size_t)q * HW * ld);
+                }
                 r[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
             const int k = j - NUX;
             const int r_ = y_pos[k] / a.TW, xx = y_pos[k] - r_ * a.TW;
             const bool ok = y_ch[k] < a.Cj;
-            const float* base = a.Q + ((size_t)n0 * HW + (y0 + r_) * a.W + x0 + xx) * a.ldq + (ok ? y_ch[k] : 0);
+            const size_t eoff = ((size_t)n0 * HW + (y0 + r_) * a.W + x0 + xx) * a.ldq + (ok ? y_ch[k] : 0);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * HW * a.ldq);
+                float4 v;
+                if constexpr (Q16) {
+                    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.Q) + eoff + (size_t)q * HW * a.ldq);
+                    v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+                } else {
+                    v = *reinterpret_cast<const float4*>(a.Q + eoff + (size_t)q * HW * a.ldq);
+                }
                 r[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -136,16 +150,37 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
     float4 bsum[NJ];
 #pragma unroll
     for (int k = 0; k < NJ; ++k) bsum[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // bf16 source: v[q].x holds channels {0,1}, v[q].y channels {2,3} of image q; interleave images with v_perm_b32
+    auto put16 = [&](uint16_t* dst, int pitch, const float4 (&v)[8]) {
+        constexpr unsigned LO = 0x05040100u, HI = 0x07060302u;      // result = {a.half, b.half}, a in the upper 16 bits
+        auto row = [&](auto pick, unsigned sel) {
+            return make_uint4(__builtin_amdgcn_perm(pick(v[1]), pick(v[0]), sel), __builtin_amdgcn_perm(pick(v[3]), pick(v[2]), sel),
+                              __builtin_amdgcn_perm(pick(v[5]), pick(v[4]), sel), __builtin_amdgcn_perm(pick(v[7]), pick(v[6]), sel));
+        };
+        auto px = [](const float4& f) { return __float_as_uint(f.x); };
+        auto py = [](const float4& f) { return __float_as_uint(f.y); };
+        *reinterpret_cast<uint4*>(dst)             = row(px, LO);
+        *reinterpret_cast<uint4*>(dst + pitch)     = row(px, HI);
+        *reinterpret_cast<uint4*>(dst + 2 * pitch) = row(py, LO);
+        *reinterpret_cast<uint4*>(dst + 3 * pitch) = row(py, HI);
+    };
     auto commit_unit = [&](const float4 (&r)[8], int j, int buf) {     // registers -> LDS buffer `buf`
         if (a.ablate & 4) return;
         uint16_t* base = lds + buf * BUF;
-        if (j < NUX) { if (x_pos[j] < PX) put(base + x_dst[j], XP, r); }
-        else {
-            put(base + BI * XP + y_dst[j - NUX], YP, r);
+        if (j < NUX) {
+            if (x_pos[j] < PX) { if constexpr (P16) put16(base + x_dst[j], XP, r); else put(base + x_dst[j], XP, r); }
+        } else {
+            if constexpr (Q16) put16(base + BI * XP + y_dst[j - NUX], YP, r); else put(base + BI * XP + y_dst[j - NUX], YP, r);
             if (do_bias) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    bsum[j - NUX].x += r[q].x; bsum[j - NUX].y += r[q].y; bsum[j - NUX].z += r[q].z; bsum[j - NUX].w += r[q].w;
+                    if constexpr (Q16) {
+                        const unsigned ux = __float_as_uint(r[q].x), uy = __float_as_uint(r[q].y);
+                        bsum[j - NUX].x += __uint_as_float(ux << 16); bsum[j - NUX].y += __uint_as_float(ux & 0xffff0000u);
+                        bsum[j - NUX].z += __uint_as_float(uy << 16); bsum[j - NUX].w += __uint_as_float(uy & 0xffff0000u);
+                    } else {
+                        bsum[j - NUX].x += r[q].x; bsum[j - NUX].y += r[q].y; bsum[j - NUX].z += r[q].z; bsum[j - NUX].w += r[q].w;
+                    }
                 }
             }
         }
@@ -326,6 +361,8 @@ extern "C" size_t mi_conv3x3_wgrad_workspace(const MiWgradDesc* d) {
 
 extern "C" int mi_conv3x3_wgrad_bias(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
                                      float* dbias, void* workspace, size_t ws_bytes, void* stream);
+static int w3_dispatch(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
+                       float* dbias, void* workspace, size_t ws_bytes, int io, void* stream);
 
 extern "C" int mi_conv3x3_wgrad_ws(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
                                    void* workspace, size_t ws_bytes, void* stream) {
@@ -339,6 +376,18 @@ extern "C" int mi_conv3x3_wgrad(const MiWgradDesc* d, const float* P, const floa
 
 extern "C" int mi_conv3x3_wgrad_bias(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
                                      float* dbias, void* workspace, size_t ws_bytes, void* stream) {
+    return w3_dispatch(d, P, P2, Q, dW, dbias, workspace, ws_bytes, 0, stream);
+}
+
+// bf16 activation storage: io bit 0 = P (and P2) are bf16 tensors, bit 1 = Q is bf16 (strides count elements). 3x3 only.
+extern "C" int mi_conv3x3_wgrad_io(const MiWgradDesc* d, const void* P, const void* P2, const void* Q, float* dW,
+                                   float* dbias, void* workspace, size_t ws_bytes, int io, void* stream) {
+    if (!d || d->KH != 3 || (io & ~3)) return mi_set_error(-1, "mi_conv3x3_wgrad_io: 3x3 only, io in 0..3");
+    return w3_dispatch(d, (const float*)P, (const float*)P2, (const float*)Q, dW, dbias, workspace, ws_bytes, io, stream);
+}
+
+static int w3_dispatch(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
+                       float* dbias, void* workspace, size_t ws_bytes, int io, void* stream) {
     MI_REQUIRE(d && P && Q && dW, "null argument");
     MI_REQUIRE(w3_ok(d), "descriptor not supported by the 3x3 wgrad kernel (use mi_conv_wgrad)");
     MI_REQUIRE(d->I1 == d->Ci || P2, "two-source split without P2");
@@ -365,7 +414,22 @@ extern "C" int mi_conv3x3_wgrad_bias(const MiWgradDesc* d, const float* P, const
         return true;
     }();
     (void)once;
-    if (KS == 3) {
+    if (KS == 3 && io) {
+        static bool once_io = [] {
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            return true;
+        }();
+        (void)once_io;
+#define MI_W3_GO(IOV) do { if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2, 3, IOV>), grid, dim3(256), lds, st, a); \
+                           else hipLaunchKernelGGL((wgrad3x3_kernel<1, 3, IOV>), grid, dim3(256), lds, st, a); } while (0)
+        if (io == 1) MI_W3_GO(1); else if (io == 2) MI_W3_GO(2); else MI_W3_GO(3);
+#undef MI_W3_GO
+    } else if (KS == 3) {
         if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2, 3>), grid, dim3(256), lds, st, a);
         else      hipLaunchKernelGGL((wgrad3x3_kernel<1, 3>), grid, dim3(256), lds, st, a);
     } else {

@@ -202,7 +202,7 @@ class _GradMap:
         cur = self._g.get(id(t))
         if cur is not None:
             return cur, True
-        buf = torch.empty(t.shape, device=t.device, dtype=torch.float32)
+        buf = torch.empty(t.shape, device=t.device, dtype=t.dtype)     # bf16 for block-internal tensors, else fp32
         self._g[id(t)] = buf; self._keep.append(t)
         return buf, False
 
@@ -242,6 +242,11 @@ class Unet(nn.Module):
         arch = _Arch(dim, tuple(dim_mults), channels, out_dim)
         object.__setattr__(self, "_arch", arch)
         self.compute_mode = os.environ.get("MI_DDPM_MODE", "fp32")
+        # bf16 mode only, opt-in ("bf16"): keep the ResnetBlock-internal tensors (conv output -> GroupNorm -> conv
+        # input, and their gradients) in bf16; the residual stream, attention path and every parameter/statistic
+        # stay fp32.  Measured slower than fp32 storage today (the staging is bound by load
+        # instructions, not bytes, and bf16 outputs rule out the split-K tiles), so the default is "fp32".
+        self.block_storage = os.environ.get("MI_DDPM_STORAGE", "fp32")
         self.accumulate_grads = False
         self.grad_ready_hook = None        # callable(lo, hi): flat_grads[lo:hi) is final (set by the DDP reducer)
 
@@ -427,7 +432,9 @@ class Unet(nn.Module):
             wd_sh, wf_sh = self._shadows()
         offs = self._offs
 
-        def conv(inp, pre, k, stride=1, pad=0, x2=None, residual=None, transposed_conv=False, bias=True):
+        BF = torch.bfloat16
+
+        def conv(inp, pre, k, stride=1, pad=0, x2=None, residual=None, transposed_conv=False, bias=True, out_dtype=torch.float32):
             w = sv[pre + "weight"]
             kh, kw, ci, co = w.shape
             if x2 is None and residual is None and stride == 1 and not transposed_conv:
@@ -437,9 +444,10 @@ class Unet(nn.Module):
                     return K.conv1x1_small_cout(0, inp, w, bias=sv[pre + "bias"] if bias else None, Cs=co)
             if mode == K.MODE_BF16 and k in (1, 3) and stride == 1 and not transposed_conv:
                 y = K.conv3x3_bf16w(inp, wf_sh[offs[pre + "weight"]:], K=ci, Nc=co, flip=False, ksize=k, x2=x2,
-                                    bias=sv[pre + "bias"] if bias else None, residual=residual)
+                                    bias=sv[pre + "bias"] if bias else None, residual=residual, out_dtype=out_dtype)
                 if y is not None:
                     return y
+            assert out_dtype == torch.float32 and inp.dtype == torch.float32, "bf16 block storage needs the tile kernel"
             ih, iw = inp.shape[1], inp.shape[2]
             if transposed_conv:
                 oh, ow = ih * stride, iw * stride
@@ -452,11 +460,18 @@ class Unet(nn.Module):
             return y
 
         def resblock(blk, inp, x2=None):
-            pre, co = blk["pre"], blk["cout"]
-            c1 = conv(inp, pre + "block1.block.0.", 3, 1, 1, x2=x2)
+            pre, co, ci = blk["pre"], blk["cout"], blk["cin"]
+            # bf16 storage of c1 / h1 / c2 when every kernel touching them has a bf16 path for this shape
+            lo16 = False
+            if mode == K.MODE_BF16 and self.block_storage == "bf16" and co % 32 == 0 and B % 8 == 0:
+                ok2 = K.fast3x3_supported(B, inp.shape[1], inp.shape[2], co, co)
+                lo16 = ok2[0] and ok2[1]
+            c1_16 = lo16 and ci % 32 == 0 and all(K.fast3x3_supported(B, inp.shape[1], inp.shape[2], ci, co, inp.shape[3] if x2 is not None else None))
+            c1 = conv(inp, pre + "block1.block.0.", 3, 1, 1, x2=x2, out_dtype=BF if c1_16 else torch.float32)
             tb = tb_all[:, blk["tcol"]:blk["tcol"] + co]
-            h1, st1 = K.gn_mish_fwd(c1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], temb=tb)
-            c2 = conv(h1, pre + "block2.block.0.", 3, 1, 1)
+            h1, st1 = K.gn_mish_fwd(c1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], temb=tb,
+                                    out_dtype=BF if lo16 else torch.float32)
+            c2 = conv(h1, pre + "block2.block.0.", 3, 1, 1, out_dtype=BF if lo16 else torch.float32)
             r = conv(inp, pre + "res_conv.", 1, x2=x2) if blk["res"] else inp
             out, st2 = K.gn_mish_fwd(c2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], residual=r)
             if record:
@@ -525,7 +540,8 @@ class Unet(nn.Module):
         dtb_all = torch.zeros((B, A.mlp_rows), device=x_in.device, dtype=torch.float32)
 
         def conv_bwd(dy, inp, pre, k, stride=1, pad=0, x2=None, transposed_conv=False, bias="colsum", want_dx=True):
-            """Gradients of y = conv(inp [|x2]); dy may be a channel slice."""
+            """Gradients of y = conv(inp [|x2]); dy may be a channel slice.  The gradient wrt inp has inp's dtype
+            (bf16 for the block-internal h1, fp32 for everything on the residual stream)."""
             w = sv[pre + "weight"]
             kh, kw, ci, co = w.shape
             ih, iw = inp.shape[1], inp.shape[2]
@@ -559,6 +575,7 @@ class Unet(nn.Module):
                 if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, ksize=k, out=buf,
                                             accumulate=acc) is not None:
                     return
+                assert dy.dtype == torch.float32 and buf.dtype == torch.float32, "bf16 block storage needs the tile kernel"
                 K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=not transposed_conv, w_kn=False,
                              K=co, Nc=ci, out_hw=(ih, iw), mode=mode, out=buf, accumulate=acc,
                              wb=wd_sh[offs[pre + "weight"]:] if mode == K.MODE_BF16 else None)
@@ -588,13 +605,13 @@ class Unet(nn.Module):
                 G.add(inp, dout)
             dc2 = K.gn_mish_bwd(c2, st2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], dout,
                                 dgamma=gv[pre + "block2.block.1.weight"], dbeta=gv[pre + "block2.block.1.bias"],
-                                dbias=gv[pre + "block2.block.0.bias"])
+                                dbias=gv[pre + "block2.block.0.bias"], out_dtype=c2.dtype)
             conv_bwd(dc2, h1, pre + "block2.block.0.", 3, 1, 1, bias=None)
             dh1 = G.take(h1)
             dtb = dtb_all[:, blk["tcol"]:blk["tcol"] + blk["cout"]]
             dc1 = K.gn_mish_bwd(c1, st1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], dh1,
                                 dgamma=gv[pre + "block1.block.1.weight"], dbeta=gv[pre + "block1.block.1.bias"],
-                                dtemb=dtb, dbias=gv[pre + "block1.block.0.bias"])
+                                dtemb=dtb, dbias=gv[pre + "block1.block.0.bias"], out_dtype=c1.dtype)
             conv_bwd(dc1, inp, pre + "block1.block.0.", 3, 1, 1, x2=x2, bias=None, want_dx=want_dx)
             if x2 is not None:
                 cat = G._g.pop(("cat", id(inp)))

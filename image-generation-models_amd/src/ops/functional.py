@@ -29,8 +29,8 @@ def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
 def _need_gpu(t: torch.Tensor):
     if not t.is_cuda:
         raise RuntimeError("libmi_ddpm kernels need tensors on an MI355X (HIP) device; there is no CPU fallback")
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"expected float32, got {t.dtype}")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"expected float32 (or bf16 block-internal storage), got {t.dtype}")
 
 
 def ld_of(t: torch.Tensor) -> int:
@@ -45,8 +45,12 @@ def ld_of(t: torch.Tensor) -> int:
     return ld
 
 
-def new_act(n, h, w, c, like: torch.Tensor) -> torch.Tensor:
-    return torch.empty((n, h, w, c), device=like.device, dtype=torch.float32)
+def new_act(n, h, w, c, like: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    return torch.empty((n, h, w, c), device=like.device, dtype=dtype)
+
+
+def _b16(t) -> int:
+    return int(t is not None and t.dtype == torch.bfloat16)
 
 
 # --------------------------------------------------------------------------- conv family
@@ -87,7 +91,8 @@ def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mo
     return out
 
 
-def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=None, out=None, accumulate=False):
+def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=None, out=None, accumulate=False,
+                  out_dtype=torch.float32):
     """3x3/s1/p1 (or 1x1) conv (flip=False) or its data gradient (flip=True) through the pipelined
     LDS-tile kernel.  wsh: bf16 weights [k][k][Nc][K].  Returns None when the shape is not supported."""
     _need_gpu(x)
@@ -102,17 +107,24 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
         return None
     if out is None:
         assert not accumulate
-        out = new_act(N, H, W, Nc, x)
+        out = new_act(N, H, W, Nc, x, out_dtype)
     d.ldy = ld_of(out)
+    io = _b16(x) | (_b16(out) << 1)
+    assert x2 is None or x2.dtype == x.dtype
     if PROBE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.mi_conv3x3_bf16w(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _stream()),
-          "mi_conv3x3_bf16w")
+    if io:
+        assert ksize == 3
+        check(lib.mi_conv3x3_bf16w_io(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), io, _stream()),
+              "mi_conv3x3_bf16w_io")
+    else:
+        check(lib.mi_conv3x3_bf16w(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _stream()),
+              "mi_conv3x3_bf16w")
     if PROBE is not None:
         e1.record()
         PROBE.append((f"conv3x3_halo_kernel<KS={ksize}>", 2.0 * N * H * W * Nc * K * ksize * ksize, e0, e1,
-                      f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}"))
+                      f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)} io{io}"))
     return out
 
 
@@ -168,14 +180,21 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
                     ldp2=ld_of(P2) if P2 is not None else 0, ldq=ld_of(Q))
     lib = load_library()
     fast = bool(lib.mi_conv3x3_wgrad_supported(C.byref(d)))
+    if not fast and (_b16(P) or _b16(Q)):
+        raise RuntimeError("bf16-stored operands need the fast wgrad kernel (caller must check wgrad_supported)")
     if PROBE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if fast:
         need = lib.mi_conv3x3_wgrad_workspace(C.byref(d))
         ws = _workspace(P.device, need)
-        check(lib.mi_conv3x3_wgrad_bias(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _p(dbias), _p(ws), ws.numel() * 4, _stream()),
-              "mi_conv3x3_wgrad_bias")
+        io = _b16(P) | (_b16(Q) << 1)
+        if io:
+            check(lib.mi_conv3x3_wgrad_io(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _p(dbias), _p(ws), ws.numel() * 4, io, _stream()),
+                  "mi_conv3x3_wgrad_io")
+        else:
+            check(lib.mi_conv3x3_wgrad_bias(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _p(dbias), _p(ws), ws.numel() * 4, _stream()),
+                  "mi_conv3x3_wgrad_bias")
     else:
         check(lib.mi_conv_wgrad(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _stream()), "mi_conv_wgrad")
         if dbias is not None:
@@ -210,27 +229,39 @@ def colsum(x, out):
 
 
 # --------------------------------------------------------------------------- norms
-def gn_mish_fwd(x, gamma, beta, *, groups=8, eps=1e-5, temb=None, residual=None):
+def gn_mish_fwd(x, gamma, beta, *, groups=8, eps=1e-5, temb=None, residual=None, out_dtype=torch.float32):
     _need_gpu(x)
     N, H, W, Cc = x.shape
-    y = new_act(N, H, W, Cc, x)
+    y = new_act(N, H, W, Cc, x, out_dtype)
     stats = torch.empty((N, groups, 2), device=x.device, dtype=torch.float32)
     d = MiGnDesc(N=N, HW=H * W, C=Cc, G=groups, eps=eps, ldx=ld_of(x), ldy=ld_of(y),
                  ldr=ld_of(residual) if residual is not None else 0)
-    check(load_library().mi_gn_mish_fwd(C.byref(d), _p(x), _p(gamma), _p(beta), _p(temb),
-                                        ld_of(temb) if temb is not None else 0, _p(residual), _p(y), _p(stats),
-                                        _stream()), "mi_gn_mish_fwd")
+    io = _b16(x) | (_b16(y) << 1)
+    ldt = ld_of(temb) if temb is not None else 0
+    if io:
+        check(load_library().mi_gn_mish_fwd_io(C.byref(d), _p(x), _p(gamma), _p(beta), _p(temb), ldt, _p(residual), _p(y),
+                                               _p(stats), io, _stream()), "mi_gn_mish_fwd_io")
+    else:
+        check(load_library().mi_gn_mish_fwd(C.byref(d), _p(x), _p(gamma), _p(beta), _p(temb), ldt, _p(residual), _p(y),
+                                            _p(stats), _stream()), "mi_gn_mish_fwd")
     return y, stats
 
 
-def gn_mish_bwd(x, stats, gamma, beta, dout, *, groups=8, eps=1e-5, dgamma=None, dbeta=None, dtemb=None, dbias=None):
+def gn_mish_bwd(x, stats, gamma, beta, dout, *, groups=8, eps=1e-5, dgamma=None, dbeta=None, dtemb=None, dbias=None,
+                out_dtype=torch.float32):
     N, H, W, Cc = x.shape
-    dx = new_act(N, H, W, Cc, x)
+    dx = new_act(N, H, W, Cc, x, out_dtype)
     d = MiGnDesc(N=N, HW=H * W, C=Cc, G=groups, eps=eps, ldx=ld_of(x), ldy=0, ldr=0)
-    check(load_library().mi_gn_mish_bwd(C.byref(d), _p(x), _p(stats), _p(gamma), _p(beta), _p(dout), ld_of(dout),
-                                        _p(dx), ld_of(dx), _p(dgamma), _p(dbeta), _p(dtemb),
-                                        ld_of(dtemb) if dtemb is not None else 0, _p(dbias), _stream()),
-          "mi_gn_mish_bwd")
+    io = _b16(x) | (_b16(dx) << 1) | (_b16(dout) << 2)
+    ldt = ld_of(dtemb) if dtemb is not None else 0
+    if io:
+        check(load_library().mi_gn_mish_bwd_io(C.byref(d), _p(x), _p(stats), _p(gamma), _p(beta), _p(dout), ld_of(dout),
+                                               _p(dx), ld_of(dx), _p(dgamma), _p(dbeta), _p(dtemb), ldt, _p(dbias), io,
+                                               _stream()), "mi_gn_mish_bwd_io")
+    else:
+        check(load_library().mi_gn_mish_bwd(C.byref(d), _p(x), _p(stats), _p(gamma), _p(beta), _p(dout), ld_of(dout),
+                                            _p(dx), ld_of(dx), _p(dgamma), _p(dbeta), _p(dtemb), ldt, _p(dbias), _stream()),
+              "mi_gn_mish_bwd")
     return dx
 
 
@@ -375,3 +406,13 @@ def gather_rows(table, idx):
     out = torch.empty((idx.shape[0], table.shape[1]), device=table.device, dtype=torch.float32)
     check(load_library().mi_gather_rows(idx.shape[0], table.shape[1], _p(table), _p(idx), _p(out), _stream()), "mi_gather_rows")
     return out
+
+
+def fast3x3_supported(N, H, W, K, Nc, K1=None):
+    """(conv via the LDS-tile kernel?, wgrad via the image-major kernel?) for a 3x3/s1/p1 layer in bf16 mode."""
+    lib = load_library()
+    dc = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0,
+                    mode=MODE_BF16, K1=K1 or K, ldx=4, ldx2=4, ldy=Nc, ldr=0, accumulate=0)
+    dw = MiWgradDesc(N=N, GH=H, GW=W, DH=H, DW=W, Ci=K, Cj=Nc, KH=3, KW=3, stride=1, pad=1, gather_i=1, mode=MODE_BF16,
+                     I1=K1 or K, ldp=4, ldp2=4, ldq=4)
+    return bool(lib.mi_conv3x3_bf16w_supported(C.byref(dc))), bool(lib.mi_conv3x3_wgrad_supported(C.byref(dw)))

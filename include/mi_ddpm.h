@@ -84,6 +84,11 @@ int mi_conv_igemm_tile(const MiConvDesc* d, int* bm, int* bn);
 int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
                      const float* bias, const float* residual, float* y, void* stream);
 int mi_conv3x3_bf16w_supported(const MiConvDesc* d);
+/* bf16 activation storage for the ResnetBlock-internal tensors (conv output -> GroupNorm -> conv input and
+ * their gradients): io bit 0 = x / x2 are bf16 tensors, bit 1 = y is written as bf16; strides count
+ * elements.  3x3 only; with bit 1 the split-K variant (fp32 atomics) is not used. */
+int mi_conv3x3_bf16w_io(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16,
+                        const float* bias, const float* residual, void* y, int io, void* stream);
 /* bf16 shadow copies of every conv weight of the flat fp32 parameter buffer (master layout
  * [tap][Cin][Cout] at float offset `off`): wd = same layout, wf = [tap][Cout][Cin].
  * entries_dev: device array of {int64 off; int32 taps, ci, co, tile0}, tile0 = first 32x32-tile
@@ -141,6 +146,9 @@ int mi_conv3x3_wgrad_ws(const MiWgradDesc* d, const float* P, const float* P2, c
  * same pass over Q (replaces a separate mi_colsum over the gradient tensor). */
 int mi_conv3x3_wgrad_bias(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
                           float* dbias, void* workspace, size_t ws_bytes, void* stream);
+/* ... with bf16-stored operands: io bit 0 = P / P2 bf16, bit 1 = Q bf16 (3x3 only) */
+int mi_conv3x3_wgrad_io(const MiWgradDesc* d, const void* P, const void* P2, const void* Q, float* dW,
+                        float* dbias, void* workspace, size_t ws_bytes, int io, void* stream);
 
 /* out[c] += sum_m x[m*ld + c]  (bias gradients) */
 int mi_colsum(int M, int C, const float* x, int ld, float* out, void* stream);
@@ -167,6 +175,14 @@ int mi_gn_mish_bwd(const MiGnDesc* d, const float* x, const float* stats, const 
                    const float* beta, const float* dout, int lddo, float* dx, int lddx,
                    float* dgamma, float* dbeta, float* dtemb, int ldt, float* dbias,
                    void* stream);
+
+/* bf16 storage variants.  fwd io: bit 0 = x bf16, bit 1 = y bf16.  bwd io: bit 0 = x bf16, bit 1 = dx bf16,
+ * bit 2 = dout bf16.  gamma/beta/temb/residual/stats and all parameter gradients stay fp32. */
+int mi_gn_mish_fwd_io(const MiGnDesc* d, const void* x, const float* gamma, const float* beta, const float* temb,
+                      int ldt, const float* residual, void* y, float* stats, int io, void* stream);
+int mi_gn_mish_bwd_io(const MiGnDesc* d, const void* x, const float* stats, const float* gamma, const float* beta,
+                      const void* dout, int lddo, void* dx, int lddx, float* dgamma, float* dbeta, float* dtemb,
+                      int ldt, float* dbias, int io, void* stream);
 
 /* ---- channel LayerNorm (ddpm.py:85-95; eps added to the std) ---------------------------- */
 int mi_chan_layernorm_fwd(int M, int C, const float* x, int ldx, const float* g, const float* b,

@@ -555,3 +555,60 @@ def test_igemm_bf16_weight_copy(K, kind):
         ref = x.grad
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(out), ref) < 2e-2
+
+
+def test_bf16_block_storage_kernels(K):
+    """bf16-stored block-internal tensors: halo conv (bf16 in/out), GroupNorm+Mish fwd/bwd (bf16 x / y / dout / dx) and
+    the image-major wgrad (bf16 P / Q) against fp64 evaluations of the same bf16-rounded tensors."""
+    g = torch.Generator().manual_seed(53)
+    N, H, C = 8, 16, 64
+    BF = torch.bfloat16
+
+    def q(t):                      # value after bf16 storage
+        return t.float().bfloat16().double()
+    x = torch.randn(N, C, H, H, generator=g, dtype=torch.float64)
+    w = torch.randn(C, C, 3, 3, generator=g, dtype=torch.float64) / 24
+    flat, wd, wf, offs = _pack(K, [conv_w_storage(w)])
+    x16 = to_nhwc_gpu(x.float()).contiguous().to(BF)
+    # conv: bf16 in -> bf16 out, fp32 in -> bf16 out, bf16 in -> fp32 out
+    ref = F.conv2d(q(x), q(w), None, padding=1)
+    for xin, od in ((x16, BF), (to_nhwc_gpu(x.float()), BF), (x16, torch.float32)):
+        y = K.conv3x3_bf16w(xin, wf, K=C, Nc=C, flip=False, out_dtype=od)
+        assert y.dtype == od
+        tol = 6e-3 if od == BF else 1e-5
+        assert rel_err(from_nhwc(y.float()), ref) < tol, (xin.dtype, od)
+    # accumulate into a bf16 gradient buffer
+    y0 = K.conv3x3_bf16w(x16, wd, K=C, Nc=C, flip=True, out_dtype=BF)
+    y1 = K.conv3x3_bf16w(x16, wd, K=C, Nc=C, flip=True, out=y0.clone(), accumulate=True)
+    assert rel_err(y1.float(), 2 * y0.float()) < 6e-3
+    # GroupNorm + Mish
+    c = (torch.randn(N, C, H, H, generator=g, dtype=torch.float64) * 2).requires_grad_(False)
+    gamma = torch.randn(C, generator=g, dtype=torch.float64) + 1
+    beta = torch.randn(C, generator=g, dtype=torch.float64)
+    cq = q(c).requires_grad_(True)
+    yref = (F.group_norm(cq, 8, gamma, beta) * torch.tanh(F.softplus(F.group_norm(cq, 8, gamma, beta))))
+    dy = torch.randn(N, C, H, H, generator=g, dtype=torch.float64)
+    yref.backward(q(dy))
+    c16 = to_nhwc_gpu(c.float()).contiguous().to(BF)
+    ga, be = gamma.float().to(DEV), beta.float().to(DEV)
+    y16, st = K.gn_mish_fwd(c16, ga, be, out_dtype=BF)
+    assert y16.dtype == BF and rel_err(from_nhwc(y16.float()), yref) < 6e-3
+    y32, _ = K.gn_mish_fwd(c16, ga, be)
+    assert y32.dtype == torch.float32 and rel_err(from_nhwc(y32), yref) < 1e-5
+    dy16 = to_nhwc_gpu(dy.float()).contiguous().to(BF)
+    dga, dbe = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx16 = K.gn_mish_bwd(c16, st, ga, be, dy16, dgamma=dga, dbeta=dbe, out_dtype=BF)
+    assert dx16.dtype == BF and rel_err(from_nhwc(dx16.float()), cq.grad) < 8e-3
+    dx32 = K.gn_mish_bwd(c16, st, ga, be, dy16)
+    assert rel_err(from_nhwc(dx32), cq.grad) < 5e-5
+    # wgrad with bf16 P and Q
+    dyq = torch.randn(N, C, H, H, generator=g, dtype=torch.float64)
+    wz = torch.zeros(C, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(q(x), wz, None, padding=1).backward(q(dyq))
+    for P, Q in ((x16, to_nhwc_gpu(dyq.float()).contiguous().to(BF)), (to_nhwc_gpu(x.float()), to_nhwc_gpu(dyq.float()).contiguous().to(BF)),
+                 (x16, to_nhwc_gpu(dyq.float()))):
+        dW = torch.zeros(9 * C * C, device=DEV); db = torch.zeros(C, device=DEV)
+        K.conv_wgrad(P, Q, dW, kh=3, kw=3, stride=1, pad=1, gather_i=True, Ci=C, Cj=C, grid_g=(H, H), grid_d=(H, H), mode=1, dbias=db)
+        torch.cuda.synchronize()
+        assert rel_err(w_from_storage(dW.view(3, 3, C, C)), wz.grad) < 2e-5, (P.dtype, Q.dtype)
+        assert rel_err(db, (q(dyq) if Q.dtype == BF else dyq).sum((0, 2, 3))) < 1e-5     # bias sums use the stored values

@@ -373,3 +373,28 @@ def test_ragged_batch_sizes_vs_oracle(B):
         if float(r.norm()) > 1e-4:
             worst = max(worst, float((q.grad.cpu() - r).norm() / r.norm()))
     assert worst < 0.2, worst
+
+
+def test_bf16_block_storage_end_to_end(golden_dir):
+    """Opt-in bf16 storage of the ResnetBlock-internal tensors (block_storage="bf16"): cfg-2 epsilon prediction,
+    loss and gradients stay within the bf16-mode tolerances."""
+    from src.models.ddpm import GaussianDiffusion
+    g = _load(golden_dir, "cfg2_unet.npz")
+    net = _seeded(128, (1, 2, 4), "bf16")
+    net.block_storage = "bf16"
+    gd = GaussianDiffusion(net, image_size=(32, 32), timesteps=1000).to(DEV)
+    B = 8
+    x = _t(g["x"]).repeat(4, 1, 1, 1).to(DEV); t = _t(g["t"]).repeat(4).to(DEV); noise = _t(g["noise"]).repeat(4, 1, 1, 1).to(DEV)
+    net.eval()
+    with torch.no_grad():
+        eps = net(gd.q_sample(x, t, noise), t)
+    assert rel_err(eps[:2], _t(g["eps_hat"])) < 4e-2
+    net.train()
+    loss = gd.p_losses(x, t, noise)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 2e-2
+    g16 = net.flat_grads.clone()
+    net.block_storage = "fp32"
+    loss2 = gd.p_losses(x, t, noise)
+    loss2.backward()
+    assert rel_err(g16, net.flat_grads) < 0.1
