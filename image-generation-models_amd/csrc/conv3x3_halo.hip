@@ -13,7 +13,30 @@
 #include <stdlib.h>
 #include "common.h"
 
+#ifdef MI_HALO_TIMING
+// profiling build only (make EXTRA=-DMI_HALO_TIMING): per-workgroup phase timestamps, 100 MHz wall clock
+__device__ unsigned long long g_halo_ts[5 * 4096];
+#define MI_TS(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 4096) g_halo_ts[(k) * 4096 + blockIdx.x] = wall_clock64(); } while (0)
+extern "C" int mi_debug_halo_ts(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_halo_ts), sizeof(g_halo_ts));
+}
+#else
+#define MI_TS(k) do {} while (0)
+#endif
+#ifndef MI_ABL
+#define MI_ABL 0      // profiling only: 1 no tap barrier, 2 no global loads, 4 no LDS stores, 8 no MFMA in the main loop
+#endif
+
 namespace {
+
+// compile-time loop: f(integral_constant<int, I>) for I in [0, N) -- ring slots must be static register names
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 struct HaloArgs {
     const float* x; const float* x2; const uint16_t* w; const float* bias; const float* res; float* y;
@@ -31,56 +54,90 @@ template <int BM, int WAVES = (BM == 256 ? 8 : 4)> struct HaloCfg {
     static constexpr int MAXHP = (BM == 256) ? 400 : (BM == 128 ? 288 : 160);
 };
 
-// Software pipeline, per workgroup.  "Stage" g = chunk*9 + tap.  While tap g runs on the matrix
-// cores out of LDS (A halo buffer chunk&1, weight slot g&1), the registers receive stage g+2:
-// the weight tile of tap g+2 and one ninth of the NEXT chunk's halo tile; at the end of tap g the
-// registers of stage g+1 (fetched one full tap earlier) are written to the other weight slot /
-// the other halo buffer.  Every global load therefore has two taps of MFMA time to land, there
-// is one barrier per tap, and nothing is staged at chunk boundaries.  Taps are unrolled so the
-// two register sets are static.
+// Software pipeline, per workgroup.  "Stage" g = chunk*9 + tap (3x3) or the 32-channel chunk index (1x1).
+// While tap g runs on the matrix cores out of LDS (halo buffer chunk&1, weight slot g&1), global loads for
+// later stages are in flight in a ring of R register slots: at tap g the weight tile of stage g+R is
+// requested and, R-1 taps ahead of its LDS store, one ninth of the NEXT chunk's halo tile; at the end of
+// tap g the registers of stage g+1 are written to the other weight slot / the other halo buffer.  A load
+// has R-1 full taps of MFMA time to land and there is one barrier per tap.
+// The loop body is straight-line code: taps are unrolled with TP % R == 0 so every ring index is static,
+// the last group is a separate instantiation instead of a guarded one, padding is applied as an AND mask
+// at the LDS store and out-of-range rows are clamped to valid addresses.  With no branch around a global
+// load the compiler can count outstanding loads exactly (s_waitcnt vmcnt(N)); any conditional load makes
+// it drain the whole ring (vmcnt(0)) at every tap, which is what bounded the first version of this kernel.
 // IO bit 0: activations x / x2 are stored as bf16 (copied to LDS as they are); bit 1: y is written as bf16.
 template <int BM, int CK, int KS, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4)>
 __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(const HaloArgs a) {
     constexpr bool IN16 = IO & 1, OUT16 = IO & 2;
     static_assert(!(SK && OUT16), "split-K accumulates with fp32 atomics");
+    static_assert(KS == 3 || CK == 32, "1x1: 32-channel stages");
     constexpr int BN = 128;
     constexpr int NTAP = KS * KS;                  // 9, or 1 for the 1x1 convolutions (plain GEMM, no halo)
+    constexpr int TP = KS == 3 ? 9 : 4;            // taps per unrolled group: a chunk's 9 taps, or four 32-channel stages
+    constexpr int R = KS == 3 ? 3 : 4;             // ring slots (TP % R == 0)
+    constexpr int NSL = KS == 3 ? 9 : 1;           // slices a halo tile is fetched in
     constexpr int NT = HaloCfg<BM, WAVES>::NT, MI = HaloCfg<BM, WAVES>::MI, NI = 2;
     constexpr int PITCH = CK + 8;                  // bf16 elements; 16-B aligned rows, conflict-free b128 reads
     constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
+    constexpr int ASZ = (MAXHP + 1) * PITCH;       // one halo buffer (+1 dump row for the staging slots past the tile)
     constexpr int Q = CK / 4;                      // float4 per halo pixel per chunk
     constexpr int A_IT = (MAXHP * Q + NT - 1) / NT;
-    constexpr int A_SL = (A_IT + NTAP - 1) / NTAP; // float4 per thread per tap (NTAP slices cover a tile)
+    constexpr int A_SL = (A_IT + NSL - 1) / NSL;   // float4 per thread per slice
     constexpr int B_IT = BN * (CK / 8) / NT;       // 16-B loads per thread per tap
-    constexpr int D = 4;                           // register ring depth: a load has D-1 taps of MFMA time to land
+    static_assert(B_IT >= 1, "weight tile smaller than the workgroup");
 
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    uint16_t* As = lds;                                    // 2 x [MAXHP][PITCH]
-    uint16_t* Bs = lds + 2 * MAXHP * PITCH;                // 2 x [BN][PITCH]
+    uint16_t* As = lds;                                    // 2 x [MAXHP + 1][PITCH]
+    uint16_t* Bs = lds + 2 * ASZ;                          // 2 x [BN][PITCH]
     int* pix = reinterpret_cast<int*>(Bs + 2 * BN * PITCH); // [MAXHP] source pixel index of each halo pixel, -1 = zero
 
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int wm = wv >> 1, wn = wv & 1;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int W2 = a.W + (KS - 1), TH2 = a.TH + (KS - 1);
+    const int Mtot = a.N * a.H * a.W;
 
-    int img0, y0;
-    if (a.TI > 1) { img0 = blockIdx.x * a.TI; y0 = 0; }
-    else { img0 = blockIdx.x / a.tiles_per_img; y0 = (blockIdx.x % a.tiles_per_img) * a.TH; }
-    for (int hp = t; hp < MAXHP; hp += NT) {
-        int v = -1;
-        if (KS == 1) {
-            if (m0 + hp < a.N * a.H * a.W) v = m0 + hp;          // 1x1: the tile is BM consecutive pixels
-        } else if (hp < a.HP) {
-            int ti = hp / (TH2 * W2);
-            int rem = hp - ti * (TH2 * W2);
-            int hy = rem / W2, hx = rem - hy * W2;
-            int iy = y0 + hy - 1, ix = hx - 1, img = img0 + ti;
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && img < a.N) v = (img * a.H + iy) * a.W + ix;
+    // this workgroup's slice of the channel chunks [ch0, ch0 + nchunks)
+    const int allchunks = a.K / CK;
+    const int per = (allchunks + a.ksplit - 1) / a.ksplit;
+    const int ch0 = blockIdx.z * per;
+    const int nchunks = min(allchunks, ch0 + per) - ch0;
+    if (nchunks <= 0) return;
+    const int ngroups = KS == 3 ? nchunks : (nchunks + TP - 1) / TP;   // 1x1: stages past K multiply zeroed weights
+
+    MI_TS(0);
+    const int a_c4 = t % Q, a_hp0 = t / Q;                 // staging element e = t + NT*j: pixel e / Q, float4 e % Q
+    int pofs[NSL][A_SL];                                   // source pixel of each of this thread's staging slots, < 0 = zero
+    if constexpr (KS == 3) {
+        int img0, y0;
+        if (a.TI > 1) { img0 = blockIdx.x * a.TI; y0 = 0; }
+        else { img0 = blockIdx.x / a.tiles_per_img; y0 = (blockIdx.x % a.tiles_per_img) * a.TH; }
+        for (int hp = t; hp < MAXHP; hp += NT) {
+            int v = -1;
+            if (hp < a.HP) {
+                int ti = hp / (TH2 * W2);
+                int rem = hp - ti * (TH2 * W2);
+                int hy = rem / W2, hx = rem - hy * W2;
+                int iy = y0 + hy - 1, ix = hx - 1, img = img0 + ti;
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && img < a.N) v = (img * a.H + iy) * a.W + ix;
+            }
+            pix[hp] = v;
         }
-        pix[hp] = v;
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+            for (int j = 0; j < A_SL; ++j) {
+                const int hp = a_hp0 + (sl * A_SL + j) * (NT / Q);
+                pofs[sl][j] = hp < MAXHP ? pix[hp] : -1;
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < A_SL; ++j) {                   // 1x1: the tile is BM consecutive pixels
+            const int hp = a_hp0 + j * (NT / Q);
+            pofs[0][j] = (hp < MAXHP && m0 + hp < Mtot) ? m0 + hp : -1;
+        }
     }
-    __syncthreads();
 
     // ---- MFMA row -> halo pixel (before the tap shift)
     int a_row[MI];
@@ -93,8 +150,6 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
         a_row[i] = ((ti * TH2 + ty) * W2 + tx) * PITCH + (l >> 5) * 8;
     }
     const int b_row0 = (wn * 64 + (l & 31)) * PITCH + (l >> 5) * 8;
-    // ---- staging assignments.  halo element e = t + NT*j: pixel e / Q, float4 e % Q
-    const int a_c4 = t % Q, a_hp0 = t / Q;                 // + (NT/Q) pixels per j
     const int b_n = t / (CK / 8), b_k8 = t % (CK / 8);     // + NT/(CK/8) rows per i
     const size_t tap_stride = (size_t)a.Nc * a.K;
 
@@ -106,73 +161,68 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[D][A_SL];
-    uint4 rb[D][B_IT];
-    // this workgroup's slice of the channel chunks [ch0, ch0 + nchunks)
-    const int allchunks = a.K / CK;
-    const int per = (allchunks + a.ksplit - 1) / a.ksplit;
-    const int ch0 = blockIdx.z * per;
-    const int nchunks = max(0, min(allchunks, ch0 + per) - ch0);
-    const int ntaps = nchunks * NTAP;
+    f32x4 ra[R][A_SL];
+    u32x4 rb[R][B_IT];
 
-    // fetch slice `sl` (0..8) of chunk `ch`'s halo tile
-    auto load_a = [&](float4 (&r)[A_SL], int ch, int sl) {
-        if (ch >= nchunks) return;
+    // fetch slice `sl` of chunk `ch`'s halo tile (unconditional: padding slots read pixel 0 and are masked at the store)
+    auto load_a = [&](f32x4 (&r)[A_SL], int ch, int sl) {
         const int kc = (ch0 + ch) * CK;
-        const float* src = a.x; int ld = a.ldx; int cc = kc;
-        if (kc >= a.K1) { src = a.x2; ld = a.ldx2; cc = kc - a.K1; }
+        const bool second = kc >= a.K1;
+        const float* src = second ? a.x2 : a.x;
+        const int ld = second ? a.ldx2 : a.ldx;
+        const int cc = second ? kc - a.K1 : kc;
 #pragma unroll
         for (int j = 0; j < A_SL; ++j) {
-            const int hp = a_hp0 + (sl * A_SL + j) * (NT / Q);
-            const int pv = hp < MAXHP ? pix[hp] : -1;
-            float4 v;
+            const size_t e = (size_t)max(pofs[sl][j], 0) * ld + cc + a_c4 * 4;
             if constexpr (IN16) {     // 4 bf16 = 8 bytes, carried in .x/.y
-                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(src) + (size_t)(pv >= 0 ? pv : 0) * ld + cc + a_c4 * 4);
-                v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+                const u32x2 u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(src) + e);
+                r[j] = f32x4{__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f};
             } else {
-                v = *reinterpret_cast<const float4*>(src + (size_t)(pv >= 0 ? pv : 0) * ld + cc + a_c4 * 4);
+                r[j] = *reinterpret_cast<const f32x4*>(src + e);
             }
-            r[j] = pv >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto store_a = [&](int buf, const float4 (&r)[A_SL], int sl) {
+    auto store_a = [&](int buf, const f32x4 (&r)[A_SL], int sl) {
 #pragma unroll
         for (int j = 0; j < A_SL; ++j) {
-            const int hp = a_hp0 + (sl * A_SL + j) * (NT / Q);
-            if (hp < (KS == 1 ? MAXHP : a.HP))
-                *reinterpret_cast<uint2*>(&As[buf * (MAXHP * PITCH) + hp * PITCH + a_c4 * 4]) =
-                    IN16 ? make_uint2(__float_as_uint(r[j].x), __float_as_uint(r[j].y))
-                         : make_uint2(pack_bf16(r[j].x, r[j].y), pack_bf16(r[j].z, r[j].w));
+            const int hp = min(a_hp0 + (sl * A_SL + j) * (NT / Q), MAXHP);   // MAXHP = dump row
+            const uint32_t keep = ~(uint32_t)(pofs[sl][j] >> 31);
+            const u32x2 v = IN16 ? u32x2{__float_as_uint(r[j].x), __float_as_uint(r[j].y)}
+                                 : u32x2{pack_bf16(r[j].x, r[j].y), pack_bf16(r[j].z, r[j].w)};
+            *reinterpret_cast<u32x2*>(&As[buf * ASZ + hp * PITCH + a_c4 * 4]) = u32x2{v.x & keep, v.y & keep};
         }
     };
-    auto load_b = [&](uint4 (&r)[B_IT], int g) {
-        if (g >= ntaps) return;
-        const int ch = g / NTAP, tap = g - ch * NTAP;
+    // weight tile of chunk `ch`, tap `tap`; rows past Nc are clamped (their output columns are never written)
+    auto load_b = [&](u32x4 (&r)[B_IT], int ch, int tap) {
         const int wt = a.flip ? NTAP - 1 - tap : tap;
         const uint16_t* base = a.w + wt * tap_stride + (size_t)(ch0 + ch) * CK + b_k8 * 8;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int n = n0 + b_n + i * (NT / (CK / 8));
-            uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)(n < a.Nc ? n : 0) * a.K);
-            r[i] = n < a.Nc ? v : make_uint4(0, 0, 0, 0);
+            const int n = min(n0 + b_n + i * (NT / (CK / 8)), a.Nc - 1);
+            r[i] = *reinterpret_cast<const u32x4*>(base + (size_t)n * a.K);
         }
     };
-    auto store_b = [&](int slot, const uint4 (&r)[B_IT]) {
+    auto store_b = [&](int slot, const u32x4 (&r)[B_IT], uint32_t keep = ~0u) {
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            *reinterpret_cast<uint4*>(&Bs[slot * (BN * PITCH) + (b_n + i * (NT / (CK / 8))) * PITCH + b_k8 * 8]) = r[i];
+            *reinterpret_cast<u32x4*>(&Bs[slot * (BN * PITCH) + (b_n + i * (NT / (CK / 8))) * PITCH + b_k8 * 8]) =
+                KS == 1 ? r[i] & keep : r[i];
     };
     auto mma_tap = [&](int abuf, int slot, int tap) {
         const int ky = tap / KS, kx = tap - ky * KS;
-        const uint16_t* At = As + abuf * (MAXHP * PITCH) + (ky * W2 + kx) * PITCH;
+        const uint16_t* At = As + abuf * ASZ + (ky * W2 + kx) * PITCH;
         const uint16_t* Bt = Bs + slot * (BN * PITCH);
+        bf16x8 af[2][MI], bf[2][NI];
+        auto frags = [&](int set, int ks) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[set][i] = *reinterpret_cast<const bf16x8*>(&At[a_row[i] + ks * 16]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[set][j] = *reinterpret_cast<const bf16x8*>(&Bt[b_row0 + j * 32 * PITCH + ks * 16]);
+        };
+        frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < CK / 16; ++ks) {
-            bf16x8 af[MI], bf[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&At[a_row[i] + ks * 16]);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Bt[b_row0 + j * 32 * PITCH + ks * 16]);
+            if (ks + 1 < CK / 16) frags((ks + 1) & 1, ks + 1);     // operands of the next k-step ride behind this one's MFMAs
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -180,62 +230,77 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
                     // weights as the MFMA "A" operand: D rows = output channels, D cols = pixels, so a lane
                     // ends up with 4 consecutive channels of one pixel per register quad -> 16-byte epilogue
                     // (the split-K variant keeps pixels as rows: its atomics then cover 128-byte row segments)
-                    acc[i][j] = SK ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0)
-                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = SK ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);
         }
     };
-    // Stage bookkeeping (g = chunk*NTAP + tap, all ring indices static after unrolling):
-    //   weights: stage g+D-1 is loaded at tap g into rb[(g+D-1) % D]; stage g+1 is stored at the end of tap g
-    //            from rb[(g+1) % D] into slot (g+1) & 1;
-    //   halo:    stage h = g+NTAP+D-2 (slice of the next chunks) is loaded at tap g into ra[h % D]; stage
-    //            g+NTAP (slice `tap` of the next chunk) is stored at the end of tap g into the other halo buffer.
-    // P = first stage of the chunk mod D (NTAP is odd, D = 4  =>  P = chunk & 3 and the halo buffer is P & 1).
-    auto ring_load_b = [&](int r, int g) {
-        if (r == 0) load_b(rb[0], g); else if (r == 1) load_b(rb[1], g); else if (r == 2) load_b(rb[2], g); else load_b(rb[3], g);
-    };
-    auto ring_store_b = [&](int r, int slot) {
-        if (r == 0) store_b(slot, rb[0]); else if (r == 1) store_b(slot, rb[1]); else if (r == 2) store_b(slot, rb[2]); else store_b(slot, rb[3]);
-    };
-    auto ring_load_a = [&](int r, int h) {            // h = halo stage = chunk*NTAP + slice
-        const int c = h / NTAP, sl = h - c * NTAP;
-        if (r == 0) load_a(ra[0], c, sl); else if (r == 1) load_a(ra[1], c, sl); else if (r == 2) load_a(ra[2], c, sl); else load_a(ra[3], c, sl);
-    };
-    auto ring_store_a = [&](int r, int buf, int sl) {
-        if (r == 0) store_a(buf, ra[0], sl); else if (r == 1) store_a(buf, ra[1], sl); else if (r == 2) store_a(buf, ra[2], sl); else store_a(buf, ra[3], sl);
-    };
-    auto chunk = [&](auto phase, int ch) {
-        constexpr int P = decltype(phase)::value;
-        const int g0 = ch * NTAP;
-#pragma unroll
-        for (int tp = 0; tp < NTAP; ++tp) {
-            const int gm = (P + tp) % D;                       // g mod D, static
-            ring_load_b((gm + D - 1) % D, g0 + tp + D - 1);
-            ring_load_a((gm + NTAP + D - 2) % D, g0 + tp + NTAP + D - 2);
-            mma_tap(P & 1, (P + tp) & 1, tp);
-            ring_store_b((gm + 1) % D, (P + tp + 1) & 1);
-            if (ch + 1 < nchunks) ring_store_a((gm + NTAP) % D, (P & 1) ^ 1, tp);
-            __syncthreads();
-        }
+    // One group = TP taps.  3x3: group = chunk `gi`; weights stage g+R is loaded at tap g into rb[g % R] and stage
+    // g+1 stored at the end of tap g; halo slice (tp+R-1) % 9 of the next chunk(s) is loaded into ra[(tp+R-1) % R]
+    // and slice tp of chunk gi+1 stored at the end of tap tp.  1x1: stage = 32-channel chunk gi*4 + tp, activations
+    // and weights both ride R taps ahead.  LAST: nothing beyond this group is loaded or stored.
+    auto group = [&](auto lastc, int gi) {
+        constexpr bool LAST = decltype(lastc)::value;
+        static_for<0, TP>([&](auto tpc) {
+            constexpr int tp = decltype(tpc)::value;
+            if constexpr (KS == 3) {
+                if constexpr (!(MI_ABL & 2)) {
+                if constexpr (tp + R < TP) load_b(rb[tp % R], gi, tp + R);
+                else if constexpr (!LAST) load_b(rb[tp % R], gi + 1, tp + R - TP);
+                if constexpr (!LAST) {
+                    constexpr int sl = (tp + R - 1) % TP;
+                    load_a(ra[(tp + R - 1) % R], tp + R - 1 < TP ? gi + 1 : min(gi + 2, nchunks - 1), sl);
+                }
+                }
+                if constexpr (!(MI_ABL & 8)) mma_tap(gi & 1, (gi + tp) & 1, tp);
+                if constexpr (!(MI_ABL & 4)) {
+                if constexpr (tp + 1 < TP || !LAST) store_b(((gi + tp) & 1) ^ 1, rb[(tp + 1) % R]);
+                if constexpr (!LAST) store_a((gi & 1) ^ 1, ra[tp % R], tp);
+                }
+            } else {
+                if constexpr (!LAST) {
+                    const int sn = min(gi * TP + tp + R, nchunks - 1);
+                    load_b(rb[tp % R], sn, 0);
+                    load_a(ra[tp % R], sn, 0);
+                }
+                mma_tap(tp & 1, tp & 1, 0);
+                if constexpr (tp + 1 < TP || !LAST) {
+                    store_b((tp + 1) & 1, rb[(tp + 1) % R], gi * TP + tp + 1 < nchunks ? ~0u : 0u);
+                    store_a((tp + 1) & 1, ra[(tp + 1) % R], 0);
+                }
+            }
+            if constexpr (!(MI_ABL & 1)) __syncthreads();
+        });
     };
 
-    // ---- prologue: chunk 0's tile and weight stage 0 into LDS; stages 1..D-2 (weights) and the first D-2
-    //      halo stages of chunk 1 into the ring (the steady state loads the (D-1)-th ahead at every tap)
-    for (int sl = 0; sl < NTAP; ++sl) { load_a(ra[0], 0, sl); store_a(0, ra[0], sl); }
-    load_b(rb[0], 0); store_b(0, rb[0]);
+    MI_TS(1);
+    // ---- prologue: every load of stage 0 (the whole first halo tile) is issued at once, then the ring is
+    //      primed in the order the steady state would have issued it, then stage 0 goes to LDS
+    {
+        f32x4 p0[NSL][A_SL];
+        u32x4 b0[B_IT];
 #pragma unroll
-    for (int k = 1; k <= D - 2; ++k) ring_load_b(k % D, k);
+        for (int sl = 0; sl < NSL; ++sl) load_a(p0[sl], 0, sl);
+        load_b(b0, 0, 0);
+        if constexpr (KS == 3) {
+            const int c1 = min(1, nchunks - 1);
+            load_b(rb[1], 0, 1); load_a(ra[0], c1, 0);
+            load_b(rb[2], 0, 2); load_a(ra[1], c1, 1);
+        } else {
+            load_b(rb[1], min(1, nchunks - 1), 0); load_a(ra[1], min(1, nchunks - 1), 0);
+            load_b(rb[2], min(2, nchunks - 1), 0); load_a(ra[2], min(2, nchunks - 1), 0);
+            load_b(rb[3], min(3, nchunks - 1), 0); load_a(ra[3], min(3, nchunks - 1), 0);
+        }
 #pragma unroll
-    for (int k = 0; k < D - 2; ++k) ring_load_a((NTAP + k) % D, NTAP + k);
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ch += 4) {
-        chunk(std::integral_constant<int, 0>{}, ch);
-        if (ch + 1 < nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
-        if (ch + 2 < nchunks) chunk(std::integral_constant<int, 2>{}, ch + 2);
-        if (ch + 3 < nchunks) chunk(std::integral_constant<int, 3>{}, ch + 3);
+        for (int sl = 0; sl < NSL; ++sl) store_a(0, p0[sl], sl);
+        store_b(0, b0);
     }
+    __syncthreads();
+    MI_TS(2);
+    for (int gi = 0; gi + 1 < ngroups; ++gi) group(std::false_type{}, gi);
+    group(std::true_type{}, ngroups - 1);
 
+    MI_TS(3);
     // ---- epilogue: lane = pixel (l & 31), register quad rq = channels 8*rq + 4*(l >> 5) .. +3
-    const int Mtot = a.N * a.H * a.W;
     const bool first = blockIdx.z == 0;                 // split-K: slice 0 carries bias and residual
     if constexpr (SK) {
         // rows = pixels, lanes 0..31 = 32 consecutive channels: one atomic instruction = two 128-byte rows
@@ -259,9 +324,65 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
             }
         return;
     }
+    // bias for this lane's 8 channel quads, fetched with one wait; the residual rows likewise per 32-pixel block
+    f32x4 bq[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) bq[j][rq] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias && first) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int col = n0 + wn * 64 + j * 32 + 8 * rq + 4 * (l >> 5);
+                bq[j][rq] = *reinterpret_cast<const f32x4*>(a.bias + min(col, a.Nc - 4));
+            }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const size_t m = (size_t)m0 + wm * (MI * 32) + i * 32 + (l & 31);
+        const size_t mc = min(m, (size_t)Mtot - 1);
+        f32x4 v[NI][4];
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                v[j][rq] = f32x4{acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]} + bq[j][rq];
+        if (a.res && first) {
+            f32x4 rv[NI][4];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int col = n0 + wn * 64 + j * 32 + 8 * rq + 4 * (l >> 5);
+                    rv[j][rq] = *reinterpret_cast<const f32x4*>(a.res + mc * a.ldr + min(col, a.Nc - 4));
+                }
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) v[j][rq] += rv[j][rq];
+        }
+        if (a.accumulate) {
+            f32x4 ov[NI][4];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int col = min(n0 + wn * 64 + j * 32 + 8 * rq + 4 * (l >> 5), a.Nc - 4);
+                    if constexpr (OUT16) {
+                        const u32x2 o = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.y) + mc * a.ldy + col);
+                        ov[j][rq] = f32x4{__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u),
+                                          __uint_as_float(o.y << 16), __uint_as_float(o.y & 0xffff0000u)};
+                    } else {
+                        ov[j][rq] = *reinterpret_cast<const f32x4*>(a.y + mc * a.ldy + col);
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) v[j][rq] += ov[j][rq];
+        }
         if (m >= (size_t)Mtot) continue;
 #pragma unroll
         for (int j = 0; j < NI; ++j)
@@ -269,31 +390,21 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
             for (int rq = 0; rq < 4; ++rq) {
                 const int col = n0 + wn * 64 + j * 32 + 8 * rq + 4 * (l >> 5);
                 if (col >= a.Nc) continue;              // Nc % 4 == 0: a quad is all in or all out
-                float4 v = make_float4(acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]);
-                if (a.bias && first) { float4 b = *reinterpret_cast<const float4*>(a.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                if (a.res && first) { float4 r = *reinterpret_cast<const float4*>(a.res + m * a.ldr + col); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-                if constexpr (OUT16) {
-                    uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + m * a.ldy + col;
-                    if (a.accumulate) {
-                        const uint2 o = *reinterpret_cast<const uint2*>(yp);
-                        v.x += __uint_as_float(o.x << 16); v.y += __uint_as_float(o.x & 0xffff0000u);
-                        v.z += __uint_as_float(o.y << 16); v.w += __uint_as_float(o.y & 0xffff0000u);
-                    }
-                    *reinterpret_cast<uint2*>(yp) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
-                } else {
-                    float* yp = a.y + m * a.ldy + col;
-                    if (a.accumulate) { float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                    *reinterpret_cast<float4*>(yp) = v;
-                }
+                if constexpr (OUT16)
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.y) + m * a.ldy + col) =
+                        u32x2{pack_bf16(v[j][rq].x, v[j][rq].y), pack_bf16(v[j][rq].z, v[j][rq].w)};
+                else
+                    *reinterpret_cast<f32x4*>(a.y + m * a.ldy + col) = v[j][rq];
             }
     }
+    MI_TS(4);
 }
 
 template <int BM, int CK, int KS = 3, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4)>
 void launch_halo(const HaloArgs& a, hipStream_t st) {
     constexpr int PITCH = CK + 8;
     constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
-    size_t lds = (size_t)(2 * MAXHP * PITCH + 2 * 128 * PITCH) * 2 + MAXHP * 4;
+    size_t lds = (size_t)(2 * (MAXHP + 1) * PITCH + 2 * 128 * PITCH) * 2 + MAXHP * 4;
     dim3 grid((a.N * a.H * a.W + BM - 1) / BM, (a.Nc + 127) / 128, a.ksplit);
     static bool once = [] {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -354,7 +465,7 @@ static bool halo_ok(const MiConvDesc* d, int* bm, int* ck) {
     if (!(k3 || k1) || d->stride != 1 || d->mode != 1) return false;
     if (d->IH != d->OH || d->IW != d->OW) return false;
     if (d->K % 32 || d->K1 % 32 || d->Nc % 4) return false;
-    if (k1) {                                  // 1x1: plain GEMM over M = N*H*W pixels, any geometry
+    if (k1) {                                  // 1x1: plain GEMM over M = N*H*W pixels, any geometry; four 32-channel stages per group (K is padded with zero weights)
         const long M = (long)d->N * d->OH * d->OW, nt = (d->Nc + 127) / 128;
         *bm = (M + 255) / 256 * nt >= 200 ? 256 : ((M + 127) / 128 * nt >= 400 ? 128 : 64);
         *ck = 32;                              // 64 would spill: the whole A tile rides in the 4-deep register ring
