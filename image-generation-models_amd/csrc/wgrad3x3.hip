@@ -13,17 +13,24 @@
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// compile-time loop: f(integral_constant<int, I>) for I in [0, N)
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
 struct W3Args {
     const float* P; const float* P2; const float* Q; float* dW;
     int N, H, W, Ci, Cj, I1, ldp, ldp2, ldq;
-    int TH, TW;            // spatial tile (TH*TW == 16)
+    int TH, TW, tw_sh;     // spatial tile (TH*TW == 16), TW = 1 << tw_sh
     int tiles_x, tiles;    // W/TW, tiles per image
     int total, cps, splits;
     int gx, gy;
-    int xcd_map;
     float* dbias;        // optional: dbias[co] += sum over pixels of Q (the conv's bias gradient), fused into the dY staging
-    float* ws;           // per-workgroup partial tiles [block][KS][128][BJ] (null -> fp32 atomics into dW)
-    int ablate;          // profiling only: 1 = no MFMA, 2 = no global loads, 4 = no LDS commit, 8 = no fragment reads
+    float* ws;           // per-workgroup partial tiles in register order (null -> fp32 atomics into dW)
 };
 
 // IO bit 0: P (layer input) is stored as bf16, bit 1: Q (output gradient) is stored as bf16.
@@ -32,29 +39,19 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
     constexpr bool P16 = IO & 1, Q16 = IO & 2;
     constexpr int BI = 128, BJ = 32 * 2 * NJ;
     constexpr int YP = 17 * 8;                          // dY pitch per co row (bf16 elems): 16 slots + 1 pad
-    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];      // BI*XP + BJ*YP bf16
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];      // 2 x (BI*XP + BJ*YP) bf16
 
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int wi = wv >> 1, wj = wv & 1;
     // 1-D grid, one workgroup per CU (the kernel runs one wave per SIMD): b -> (k-slice, ky, ci-tile, co-tile)
     const int gsz = a.gx * a.gy * KS;
-    int split, within;
-    if (a.xcd_map) {        // workgroup b is dispatched to XCD b % 8 (observed; speed only): keep the gsz workgroups of
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;   // one k-slice on one XCD so its L2 serves the shared dY / X rows
-        split = (slot / gsz) * 8 + xcd; within = slot % gsz;
-        if (split >= a.splits) return;
-    } else {
-        split = blockIdx.x / gsz; within = blockIdx.x % gsz;
-    }
+    const int split = blockIdx.x / gsz, within = blockIdx.x % gsz;
     const int ky = within % KS, txy = within / KS;
     const int ci0 = (txy % a.gx) * BI, co0 = (txy / a.gx) * BJ;
     constexpr int NUX = KS == 3 ? 3 : 2;                // X staging units per wave (= position groups of 8)
     const int TW2 = a.TW + (KS - 1);
     const int PX = a.TH * TW2;                          // X positions per chunk (18, 20 or 24; 16 for 1x1)
-    const int XP = (PX | 1) * 8;                        // odd slot count -> conflict-free fragment reads
-    const int npg = (PX + 7) / 8;                       // position groups of 8
-    uint16_t* Xs = lds;
-    uint16_t* Ys = lds + BI * XP;
+    const int XP = (PX | 1) * 8;                        // odd slot count -> conflict-free fragment reads; slot PX is a pad
     const int HW = a.H * a.W;
 
     f32x16 acc[KS][2][NJ];
@@ -68,130 +65,135 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
                 for (int r = 0; r < 16; ++r) acc[k][i][j][r] = 0.f;
 
     const int hp_sub = l & 7, c4 = l >> 3;
-    const int cbeg = split * a.cps, cend = min(a.total, cbeg + a.cps);
+    const int cbeg = split * a.cps, cend = min(a.total, cbeg + a.cps);     // non-empty by construction of `splits`
 
-    // ---- staging assignment (fixed per thread): 3 X units and NJ dY units per wave;
-    //      unit = (8 positions) x (32 channels), one float4 per image per lane
-    int x_pos[NUX], x_ch[NUX], x_dst[NUX];
+    // ---- staging assignment (fixed per thread): NUX X units and NJ dY units per wave;
+    //      unit = (8 positions) x (32 channels), one 16-byte load per image per lane.  Everything that does not
+    //      depend on the chunk is resolved here so that the loop issues loads without any control flow.
+    const char* x_base[NUX]; int x_ld[NUX], x_r[NUX], x_xx[NUX], x_dst[NUX]; bool x_in[NUX];
 #pragma unroll
     for (int k = 0; k < NUX; ++k) {
         const int u = wv + 4 * k;
         const int pg = u % NUX, cg = u / NUX;
-        x_pos[k] = pg * 8 + hp_sub;
-        x_ch[k] = ci0 + cg * 32 + c4 * 4;
-        x_dst[k] = (cg * 32 + c4 * 4) * XP + x_pos[k] * 8;
+        const int pos = pg * 8 + hp_sub;
+        x_in[k] = pos < PX;
+        x_r[k] = pos / TW2; x_xx[k] = pos - x_r[k] * TW2;
+        int ch = min(ci0 + cg * 32 + c4 * 4, a.Ci - 4);               // rows past Ci are never written back
+        const bool second = ch >= a.I1;
+        x_ld[k] = second ? a.ldp2 : a.ldp;
+        x_base[k] = reinterpret_cast<const char*>(second ? a.P2 : a.P) + (size_t)(second ? ch - a.I1 : ch) * (P16 ? 2 : 4);
+        x_dst[k] = (cg * 32 + c4 * 4) * XP + (x_in[k] ? pos : PX) * 8;  // positions past the tile land in the pad slot
     }
-    int y_pos[NJ], y_ch[NJ], y_dst[NJ];
+    const char* y_base[NJ]; int y_pix[NJ], y_dst[NJ], y_ch[NJ];
 #pragma unroll
     for (int k = 0; k < NJ; ++k) {
         const int u = wv + 4 * k;
         const int pg = u & 1, cg = u >> 1;
-        y_pos[k] = pg * 8 + hp_sub;
+        const int pos = pg * 8 + hp_sub;
+        y_pix[k] = (pos >> a.tw_sh) * a.W + (pos & (a.TW - 1));
         y_ch[k] = co0 + cg * 32 + c4 * 4;
-        y_dst[k] = (cg * 32 + c4 * 4) * YP + y_pos[k] * 8;
+        y_base[k] = reinterpret_cast<const char*>(a.Q) + (size_t)min(y_ch[k], a.Cj - 4) * (Q16 ? 2 : 4);
+        y_dst[k] = (cg * 32 + c4 * 4) * YP + pos * 8;
     }
     // Pipeline: LDS is double-buffered by chunk.  While the 8 k-steps of chunk c run on the matrix
-    // cores out of buffer c&1, the wave's 3+NJ staging units of chunk c+1 are fetched (one unit per
-    // k-step, three register sets in flight => two k-steps of MFMA time per load) and written to the
-    // other buffer.  One barrier per chunk (96 MFMAs per wave at NJ = 2).
+    // cores out of buffer c&1, the wave's NUX+NJ staging units of chunk c+1 (fetched during chunk c-1) are
+    // converted and written to the other buffer, one unit per k-step, and the same registers are immediately
+    // re-armed with the unit of chunk c+2: every global load has a full chunk (~100 MFMAs) to land.  One
+    // barrier per chunk.  The loop is straight-line code (clamped addresses, padding as an AND mask at the
+    // LDS store, last chunk peeled) so that the compiler can wait with exact vmcnt counts.
     constexpr int NU = NUX + NJ;
-    float4 U[NU][8];                                   // one register set per staging unit: a whole chunk in flight
+    f32x4 U[NU][8];                                    // one register set per staging unit: a whole chunk in flight
+    uint32_t keep[NUX];                                // all-ones when the unit's position is inside the image
     const int BUF = BI * XP + BJ * YP;                 // bf16 elements per LDS buffer
 
-    auto issue_unit = [&](float4 (&r)[8], int j, int c) {     // unit j of chunk c: global -> registers
-        if (c >= cend || (a.ablate & 2)) return;
+    auto issue_unit = [&](auto jc, int c) {            // unit j of chunk c: global -> registers
+        constexpr int j = decltype(jc)::value;
         const int g = c / a.tiles, tile = c - g * a.tiles;
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int y0 = ty * a.TH, x0 = tx * a.TW, n0 = g * 8;
-        if (j < NUX) {
-            const int r_ = x_pos[j] / TW2, xx = x_pos[j] - r_ * TW2;
-            const int iy = y0 + r_ + ky - KS / 2, ix = x0 + xx - KS / 2;
-            const bool ok = x_pos[j] < PX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && x_ch[j] < a.Ci;
-            const float* src = a.P; int ld = a.ldp; int cc = x_ch[j];
-            if (cc >= a.I1) { src = a.P2; ld = a.ldp2; cc -= a.I1; }
-            const size_t eoff = ok ? ((size_t)n0 * HW + iy * a.W + ix) * ld + cc : (size_t)n0 * HW * ld;
+        if constexpr (j < NUX) {
+            const int iy = y0 + x_r[j] + ky - KS / 2, ix = x0 + x_xx[j] - KS / 2;
+            const bool ok = x_in[j] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            keep[j] = ok ? ~0u : 0u;
+            const size_t img = (size_t)HW * x_ld[j] * (P16 ? 2 : 4);
+            const char* src = x_base[j] + ((size_t)n0 * HW + (ok ? iy * a.W + ix : 0)) * x_ld[j] * (P16 ? 2 : 4);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                float4 v;
                 if constexpr (P16) {      // 4 bf16 channels = 8 bytes, carried in .x/.y
-                    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(src) + eoff + (size_t)q * HW * ld);
-                    v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+                    const u32x2 u = *reinterpret_cast<const u32x2*>(src + q * img);
+                    U[j][q] = f32x4{__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f};
                 } else {
-                    v = *reinterpret_cast<const float4*>(src + eoff + (size_t)q * HW * ld);
+                    U[j][q] = *reinterpret_cast<const f32x4*>(src + q * img);
                 }
-                r[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
-            const int k = j - NUX;
-            const int r_ = y_pos[k] / a.TW, xx = y_pos[k] - r_ * a.TW;
-            const bool ok = y_ch[k] < a.Cj;
-            const size_t eoff = ((size_t)n0 * HW + (y0 + r_) * a.W + x0 + xx) * a.ldq + (ok ? y_ch[k] : 0);
+            constexpr int k = j - NUX;
+            const size_t img = (size_t)HW * a.ldq * (Q16 ? 2 : 4);
+            const char* src = y_base[k] + ((size_t)n0 * HW + y0 * a.W + x0 + y_pix[k]) * a.ldq * (Q16 ? 2 : 4);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                float4 v;
                 if constexpr (Q16) {
-                    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.Q) + eoff + (size_t)q * HW * a.ldq);
-                    v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
+                    const u32x2 u = *reinterpret_cast<const u32x2*>(src + q * img);
+                    U[j][q] = f32x4{__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f};
                 } else {
-                    v = *reinterpret_cast<const float4*>(a.Q + eoff + (size_t)q * HW * a.ldq);
+                    U[j][q] = *reinterpret_cast<const f32x4*>(src + q * img);
                 }
-                r[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
-    auto put = [&](uint16_t* dst, int pitch, const float4 (&v)[8]) {   // 8 images x 4 channels -> 4 rows of 8 bf16
-        *reinterpret_cast<uint4*>(dst)             = make_uint4(pack_bf16(v[0].x, v[1].x), pack_bf16(v[2].x, v[3].x), pack_bf16(v[4].x, v[5].x), pack_bf16(v[6].x, v[7].x));
-        *reinterpret_cast<uint4*>(dst + pitch)     = make_uint4(pack_bf16(v[0].y, v[1].y), pack_bf16(v[2].y, v[3].y), pack_bf16(v[4].y, v[5].y), pack_bf16(v[6].y, v[7].y));
-        *reinterpret_cast<uint4*>(dst + 2 * pitch) = make_uint4(pack_bf16(v[0].z, v[1].z), pack_bf16(v[2].z, v[3].z), pack_bf16(v[4].z, v[5].z), pack_bf16(v[6].z, v[7].z));
-        *reinterpret_cast<uint4*>(dst + 3 * pitch) = make_uint4(pack_bf16(v[0].w, v[1].w), pack_bf16(v[2].w, v[3].w), pack_bf16(v[4].w, v[5].w), pack_bf16(v[6].w, v[7].w));
+    // 8 images x 4 channels -> 4 rows of 8 bf16 (ANDed with the padding mask)
+    auto put = [&](uint16_t* dst, int pitch, const f32x4 (&v)[8], uint32_t m) {
+        *reinterpret_cast<u32x4*>(dst)             = u32x4{pack_bf16(v[0].x, v[1].x), pack_bf16(v[2].x, v[3].x), pack_bf16(v[4].x, v[5].x), pack_bf16(v[6].x, v[7].x)} & m;
+        *reinterpret_cast<u32x4*>(dst + pitch)     = u32x4{pack_bf16(v[0].y, v[1].y), pack_bf16(v[2].y, v[3].y), pack_bf16(v[4].y, v[5].y), pack_bf16(v[6].y, v[7].y)} & m;
+        *reinterpret_cast<u32x4*>(dst + 2 * pitch) = u32x4{pack_bf16(v[0].z, v[1].z), pack_bf16(v[2].z, v[3].z), pack_bf16(v[4].z, v[5].z), pack_bf16(v[6].z, v[7].z)} & m;
+        *reinterpret_cast<u32x4*>(dst + 3 * pitch) = u32x4{pack_bf16(v[0].w, v[1].w), pack_bf16(v[2].w, v[3].w), pack_bf16(v[4].w, v[5].w), pack_bf16(v[6].w, v[7].w)} & m;
     };
     // bias gradient: the workgroups with ci-tile 0 and the centre ky see every dY element exactly once
     const bool do_bias = a.dbias != nullptr && ci0 == 0 && ky == KS / 2;
-    float4 bsum[NJ];
+    f32x4 bsum[NJ];
 #pragma unroll
-    for (int k = 0; k < NJ; ++k) bsum[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < NJ; ++k) bsum[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     // bf16 source: v[q].x holds channels {0,1}, v[q].y channels {2,3} of image q; interleave images with v_perm_b32
-    auto put16 = [&](uint16_t* dst, int pitch, const float4 (&v)[8]) {
+    auto put16 = [&](uint16_t* dst, int pitch, const f32x4 (&v)[8], uint32_t m) {
         constexpr unsigned LO = 0x05040100u, HI = 0x07060302u;      // result = {a.half, b.half}, a in the upper 16 bits
-        auto row = [&](auto pick, unsigned sel) {
-            return make_uint4(__builtin_amdgcn_perm(pick(v[1]), pick(v[0]), sel), __builtin_amdgcn_perm(pick(v[3]), pick(v[2]), sel),
-                              __builtin_amdgcn_perm(pick(v[5]), pick(v[4]), sel), __builtin_amdgcn_perm(pick(v[7]), pick(v[6]), sel));
+        auto row = [&](int comp, unsigned sel) {
+            auto pick = [&](const f32x4& f) { return __float_as_uint(comp ? f.y : f.x); };
+            return u32x4{__builtin_amdgcn_perm(pick(v[1]), pick(v[0]), sel), __builtin_amdgcn_perm(pick(v[3]), pick(v[2]), sel),
+                         __builtin_amdgcn_perm(pick(v[5]), pick(v[4]), sel), __builtin_amdgcn_perm(pick(v[7]), pick(v[6]), sel)} & m;
         };
-        auto px = [](const float4& f) { return __float_as_uint(f.x); };
-        auto py = [](const float4& f) { return __float_as_uint(f.y); };
-        *reinterpret_cast<uint4*>(dst)             = row(px, LO);
-        *reinterpret_cast<uint4*>(dst + pitch)     = row(px, HI);
-        *reinterpret_cast<uint4*>(dst + 2 * pitch) = row(py, LO);
-        *reinterpret_cast<uint4*>(dst + 3 * pitch) = row(py, HI);
+        *reinterpret_cast<u32x4*>(dst)             = row(0, LO);
+        *reinterpret_cast<u32x4*>(dst + pitch)     = row(0, HI);
+        *reinterpret_cast<u32x4*>(dst + 2 * pitch) = row(1, LO);
+        *reinterpret_cast<u32x4*>(dst + 3 * pitch) = row(1, HI);
     };
-    auto commit_unit = [&](const float4 (&r)[8], int j, int buf) {     // registers -> LDS buffer `buf`
-        if (a.ablate & 4) return;
+    auto commit_unit = [&](auto jc, int buf) {         // registers -> LDS buffer `buf`
+        constexpr int j = decltype(jc)::value;
         uint16_t* base = lds + buf * BUF;
-        if (j < NUX) {
-            if (x_pos[j] < PX) { if constexpr (P16) put16(base + x_dst[j], XP, r); else put(base + x_dst[j], XP, r); }
+        if constexpr (j < NUX) {
+            if constexpr (P16) put16(base + x_dst[j], XP, U[j], keep[j]); else put(base + x_dst[j], XP, U[j], keep[j]);
         } else {
-            if constexpr (Q16) put16(base + BI * XP + y_dst[j - NUX], YP, r); else put(base + BI * XP + y_dst[j - NUX], YP, r);
+            constexpr int k = j - NUX;
+            if constexpr (Q16) put16(base + BI * XP + y_dst[k], YP, U[j], ~0u); else put(base + BI * XP + y_dst[k], YP, U[j], ~0u);
             if (do_bias) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if constexpr (Q16) {
-                        const unsigned ux = __float_as_uint(r[q].x), uy = __float_as_uint(r[q].y);
-                        bsum[j - NUX].x += __uint_as_float(ux << 16); bsum[j - NUX].y += __uint_as_float(ux & 0xffff0000u);
-                        bsum[j - NUX].z += __uint_as_float(uy << 16); bsum[j - NUX].w += __uint_as_float(uy & 0xffff0000u);
+                        const unsigned ux = __float_as_uint(U[j][q].x), uy = __float_as_uint(U[j][q].y);
+                        bsum[k] += f32x4{__uint_as_float(ux << 16), __uint_as_float(ux & 0xffff0000u),
+                                         __uint_as_float(uy << 16), __uint_as_float(uy & 0xffff0000u)};
                     } else {
-                        bsum[j - NUX].x += r[q].x; bsum[j - NUX].y += r[q].y; bsum[j - NUX].z += r[q].z; bsum[j - NUX].w += r[q].w;
+                        bsum[k] += U[j][q];
                     }
                 }
             }
         }
     };
+    const int arow = (wi * 64 + (l & 31)) * XP, brow = (wj * (32 * NJ) + (l & 31)) * YP;
     auto mma_step = [&](int s, int buf) {
-        if (a.ablate & 1) return;
         const uint16_t* Xb = lds + buf * BUF;
         const uint16_t* Yb = Xb + BI * XP;
-        const int arow = (wi * 64 + (l & 31)) * XP, brow = (wj * (32 * NJ) + (l & 31)) * YP;
         const int p = 2 * s + (l >> 5);
-        const int r_ = p / a.TW, xx = p - r_ * a.TW;
+        const int r_ = p >> a.tw_sh, xx = p & (a.TW - 1);
         bf16x8 bf[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Yb[brow + j * 32 * YP + p * 8]);
@@ -209,34 +211,27 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         }
     };
 
-    // Pipeline: registers hold chunk c+1 (fetched during chunk c-1); at k-step s of chunk c, unit s is
-    // converted and written to the other LDS buffer, and the same registers are immediately re-armed
-    // with unit s of chunk c+2 -> every global load has a full chunk (8 k-steps, ~100 MFMAs) to land.
-    if (cbeg < cend) {
-#pragma unroll
-        for (int j = 0; j < NU; ++j) { issue_unit(U[j], j, cbeg); commit_unit(U[j], j, cbeg & 1); }
-#pragma unroll
-        for (int j = 0; j < NU; ++j) issue_unit(U[j], j, cbeg + 1);
-    }
+    // ---- prologue: chunk cbeg through registers into buffer cbeg&1, then chunk cbeg+1 into the registers
+    static_for<0, NU>([&](auto jc) { issue_unit(jc, cbeg); });
+    static_for<0, NU>([&](auto jc) { commit_unit(jc, cbeg & 1); });
+    static_for<0, NU>([&](auto jc) { issue_unit(jc, min(cbeg + 1, cend - 1)); });
     __syncthreads();
-    for (int c = cbeg; c < cend; ++c) {
+    for (int c = cbeg; c + 1 < cend; ++c) {
         const int buf = c & 1;
-        const bool nxt = c + 1 < cend;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            if (s < NU) {
-                if (nxt) commit_unit(U[s], s, buf ^ 1);
-                issue_unit(U[s], s, c + 2);
-            }
+        const int c2 = min(c + 2, cend - 1);           // past the end: a harmless re-read of the last chunk
+        static_for<0, 8>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (s < NU) { commit_unit(sc, buf ^ 1); issue_unit(sc, c2); }
             mma_step(s, buf);
-        }
+        });
         __syncthreads();
     }
+    static_for<0, 8>([&](auto sc) { mma_step(decltype(sc)::value, (cend - 1) & 1); });
 
     if (do_bias) {
 #pragma unroll
         for (int k = 0; k < NJ; ++k) {
-            float4 v = bsum[k];
+            f32x4 v = bsum[k];
 #pragma unroll
             for (int o = 1; o < 8; o <<= 1) {              // the 8 lanes hp_sub = 0..7 hold the same channel quad
                 v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64);
@@ -249,19 +244,20 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         }
     }
     if (a.ws) {
-        // plain coalesced stores of this workgroup's partial tile; wgrad_reduce_kernel sums the k-slices
-        float* tile = a.ws + (size_t)blockIdx.x * (KS * BI * BJ);
+        // this workgroup's partial tile in register order: slot ((kx*2+i)*NJ+j)*4+rq holds, for thread t, the four
+        // accumulator values of register quad rq -> every store instruction writes 1 KB contiguous per wave;
+        // wgrad_reduce_kernel sums the k-slices and undoes the permutation
+        float* tile = a.ws + (size_t)blockIdx.x * (KS * BI * BJ) + t * 4;
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wi * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        tile[(size_t)(kx * BI + row) * BJ + wj * (32 * NJ) + j * 32 + (l & 31)] = acc[kx][i][j][r];
-                }
+                    for (int rq = 0; rq < 4; ++rq)
+                        *reinterpret_cast<f32x4*>(tile + (((kx * 2 + i) * NJ + j) * 4 + rq) * 1024) =
+                            f32x4{acc[kx][i][j][4 * rq], acc[kx][i][j][4 * rq + 1], acc[kx][i][j][4 * rq + 2], acc[kx][i][j][4 * rq + 3]};
         return;
     }
 #pragma unroll
@@ -283,55 +279,36 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
 }
 
 // dW[(ky*KS+kx)][ci][co] += sum over k-slices of the partial tiles written above (fixed order: deterministic).
-// A workgroup owns 32 consecutive outputs; its 8 waves... (8 groups of 32 lanes) each take every 8th slice.
+// grid = (G thread-slices, register slots, tiles); a workgroup sums 256/G threads' float4 of one slot, its G
+// thread groups each taking every G-th k-slice with coalesced 16-byte loads (G = 16 when there are many k-slices).
+template <int G>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int Ci, int Cj,
-                                                           int KS, int BJ, int gx, int gy, int splits) {
-    __shared__ float red[8][32];
-    const size_t total = (size_t)KS * KS * Ci * Cj;
+                                                           int KS, int NJ, int gx, int gy, int splits) {
+    constexpr int IB = 256 / G;
+    __shared__ f32x4 red[G][IB];
+    const int BJ = 64 * NJ;
     const int gsz = gx * gy * KS;
     const size_t tile_elems = (size_t)KS * 128 * BJ;
-    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    for (size_t e0 = (size_t)blockIdx.x * 32; e0 < total; e0 += (size_t)gridDim.x * 32) {
-        const size_t e = e0 + el;
-        float s = 0.f;
-        if (e < total) {
-            const int co = (int)(e % Cj); size_t q = e / Cj;
-            const int ci = (int)(q % Ci); const int tap = (int)(q / Ci);
-            const int ky = tap / KS, kx = tap - ky * KS;
-            const int tx = ci / 128, ty = co / BJ;
-            const int within = (ty * gx + tx) * KS + ky;
-            const float* p = ws + (size_t)within * tile_elems + (size_t)(kx * 128 + (ci - tx * 128)) * BJ + (co - ty * BJ);
-            for (int sp = grp; sp < splits; sp += 8) s += p[(size_t)sp * gsz * tile_elems];
-        }
-        red[grp][el] = s;
-        __syncthreads();
-        if (grp == 0 && e < total) {
-            float v = red[0][el];
+    const int it = threadIdx.x % IB, grp = threadIdx.x / IB;
+    const int tt = blockIdx.x * IB + it, wv = tt >> 6, l = tt & 63;       // thread of the producing workgroup
+    const int slot = blockIdx.y, within = blockIdx.z;
+    const float* p = ws + (size_t)within * tile_elems + (size_t)slot * 1024 + tt * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = grp; sp < splits; sp += G) s += *reinterpret_cast<const f32x4*>(p + (size_t)sp * gsz * tile_elems);
+    red[grp][it] = s;
+    __syncthreads();
+    if (grp != 0) return;
 #pragma unroll
-            for (int g = 1; g < 8; ++g) v += red[g][el];
-            dW[e] += v;
-        }
-        __syncthreads();
-    }
-}
-
-// few k-slices, many outputs: one thread per output, slices summed serially
-__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __restrict__ dW, int Ci, int Cj,
-                                                                int KS, int BJ, int gx, int gy, int splits) {
-    const size_t total = (size_t)KS * KS * Ci * Cj;
-    const int gsz = gx * gy * KS;
-    const size_t tile_elems = (size_t)KS * 128 * BJ;
-    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int co = (int)(e % Cj); size_t q = e / Cj;
-        const int ci = (int)(q % Ci); const int tap = (int)(q / Ci);
-        const int ky = tap / KS, kx = tap - ky * KS;
-        const int tx = ci / 128, ty = co / BJ;
-        const int within = (ty * gx + tx) * KS + ky;
-        const float* p = ws + (size_t)within * tile_elems + (size_t)(kx * 128 + (ci - tx * 128)) * BJ + (co - ty * BJ);
-        float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += p[(size_t)sp * gsz * tile_elems];
-        dW[e] += s;
-    }
+    for (int g = 1; g < G; ++g) s += red[g][it];
+    const int rq = slot & 3, j = (slot >> 2) % NJ, i = ((slot >> 2) / NJ) & 1, kx = (slot >> 2) / NJ / 2;
+    const int ky = within % KS, txy = within / KS;
+    const int ci = (txy % gx) * 128 + (wv >> 1) * 64 + i * 32 + 8 * rq + 4 * (l >> 5);
+    const int co = (txy / gx) * BJ + (wv & 1) * (32 * NJ) + j * 32 + (l & 31);
+    if (co >= Cj) return;
+    float* out = dW + ((size_t)(ky * KS + kx) * Ci + ci) * Cj + co;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (ci + e < Ci) out[(size_t)e * Cj] += s[e];
 }
 
 }  // namespace
@@ -400,9 +377,9 @@ static int w3_dispatch(const MiWgradDesc* d, const float* P, const float* P2, co
     w3_plan(d, a, BJ, wide);
     const int KS = d->KH;
     a.ws = nullptr;
-    if (workspace && ws_bytes >= (size_t)a.gx * a.gy * KS * a.splits * KS * 128 * BJ * sizeof(float) && a.splits > 1 && !a.xcd_map)
+    if (workspace && ws_bytes >= (size_t)a.gx * a.gy * KS * a.splits * KS * 128 * BJ * sizeof(float) && a.splits > 1)
         a.ws = (float*)workspace;
-    dim3 grid((unsigned)(a.gx * a.gy * KS * (a.xcd_map ? (a.splits + 7) / 8 * 8 : a.splits)));
+    dim3 grid((unsigned)(a.gx * a.gy * KS * a.splits));
     hipStream_t st = (hipStream_t)stream;
     const int XP = ((a.TH * (a.TW + KS - 1)) | 1) * 8;
     const size_t lds = (size_t)(128 * XP + BJ * 17 * 8) * 2 * 2;      // double-buffered
@@ -437,14 +414,11 @@ static int w3_dispatch(const MiWgradDesc* d, const float* P, const float* P2, co
         else      hipLaunchKernelGGL((wgrad3x3_kernel<1, 1>), grid, dim3(256), lds, st, a);
     }
     if (a.ws) {
-        const size_t total = (size_t)KS * KS * d->Ci * d->Cj;
-        if (a.splits >= 16) {
-            int blocks = (int)((total + 31) / 32); if (blocks > 8192) blocks = 8192;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.ws, dW, d->Ci, d->Cj, KS, BJ, a.gx, a.gy, a.splits);
-        } else {
-            int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3(blocks), dim3(256), 0, st, a.ws, dW, d->Ci, d->Cj, KS, BJ, a.gx, a.gy, a.splits);
-        }
+        const dim3 rg(1, KS * 2 * (BJ / 64) * 4, a.gx * a.gy * KS);
+        if (a.splits >= 128)
+            hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(16, rg.y, rg.z), dim3(256), 0, st, a.ws, dW, d->Ci, d->Cj, KS, BJ / 64, a.gx, a.gy, a.splits);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(4, rg.y, rg.z), dim3(256), 0, st, a.ws, dW, d->Ci, d->Cj, KS, BJ / 64, a.gx, a.gy, a.splits);
     }
     MI_LAUNCH_CHECK();
     return 0;
@@ -453,6 +427,7 @@ static int w3_dispatch(const MiWgradDesc* d, const float* P, const float* P2, co
 static int w3_plan(const MiWgradDesc* d, W3Args& a, int& BJ, bool& wide) {
     a.N = d->N; a.H = d->DH; a.W = d->DW; a.Ci = d->Ci; a.Cj = d->Cj; a.I1 = d->I1;
     a.TW = a.W >= 16 ? 16 : a.W; a.TH = 16 / a.TW;
+    a.tw_sh = a.TW == 16 ? 4 : (a.TW == 8 ? 3 : 2);
     a.tiles_x = a.W / a.TW; a.tiles = a.tiles_x * (a.H / a.TH);
     a.total = (a.N / 8) * a.tiles;
     static const int force_nj = [] { const char* e = getenv("MI_W3_NJ"); return e ? atoi(e) : 0; }();
@@ -472,15 +447,5 @@ static int w3_plan(const MiWgradDesc* d, W3Args& a, int& BJ, bool& wide) {
     a.cps = (int)((a.total + splits - 1) / splits);
     a.splits = (a.total + a.cps - 1) / a.cps;
     a.gx = (d->Ci + 127) / 128; a.gy = (d->Cj + BJ - 1) / BJ;
-    static const int xcd_env = [] { const char* e = getenv("MI_W3_XCD"); return e ? atoi(e) : 0; }();
-    a.xcd_map = xcd_env && a.gx * a.gy * KS <= 12;
-    if (a.xcd_map) {                                    // splits a multiple of 8 so every XCD gets whole k-slices
-        long s8 = (target / base) / 8 * 8; if (s8 < 8) s8 = 8;
-        if (s8 > a.total) s8 = a.total;
-        a.cps = (int)((a.total + s8 - 1) / s8);
-        a.splits = (a.total + a.cps - 1) / a.cps;
-    }
-    static const int abl = [] { const char* e = getenv("MI_W3_ABLATE"); return e ? atoi(e) : 0; }();
-    a.ablate = abl;
     return 0;
 }
