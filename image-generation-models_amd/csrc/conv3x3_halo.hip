@@ -495,6 +495,28 @@ static bool halo_ok(const MiConvDesc* d, int* bm, int* ck) {
 static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
                          const float* bias, const float* residual, float* y, int io, void* stream);
 
+// k-slices of the split-K plan for this layer (0 = none).  Small-M layers (8x8 levels): a 256-pixel x
+// 64-channel-chunk tile with the K loop split over 2-8 workgroups beats 64-pixel tiles (weights are re-read
+// per M tile); slices are summed with row-coalesced fp32 atomics, so the output must be fp32.
+static int halo_splitk(const MiConvDesc* d, int BM, int* th, int* ti) {
+    if (d->KH != 3 || BM >= 256 || d->K % 64 || d->K1 % 64 || !(d->accumulate || d->ldy == d->Nc)) return 0;
+    static const int allow = [] { const char* e = getenv("MI_HALO_SPLITK"); return e ? atoi(e) : 1; }();
+    const long b256 = ((long)d->N * d->OH * d->OW + 255) / 256 * ((d->Nc + 127) / 128);
+    const int chunks = d->K / 64;
+    if (!(allow && chunks >= 8 && halo_geom(d, 256, th, ti) && b256 >= 32)) return 0;   // measured: loses for K < 512
+    int ks = 2;
+    while (b256 * ks < 200 && ks * 4 <= chunks && ks < 8) ks *= 2;                      // >= 2 chunks per slice
+    return ks * 2 <= chunks ? ks : 0;
+}
+
+// 1 when mi_conv3x3_bf16w would take the split-K plan for this descriptor (fp32 output only): callers that can
+// choose the output type use it to keep such layers in fp32.
+extern "C" int mi_conv3x3_bf16w_uses_splitk(const MiConvDesc* d) {
+    int bm, ck, th, ti;
+    if (!d || !halo_ok(d, &bm, &ck)) return 0;
+    return halo_splitk(d, bm, &th, &ti) ? 1 : 0;
+}
+
 extern "C" int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
                                 const float* bias, const float* residual, float* y, void* stream) {
     return halo_dispatch(d, x, x2, w_nk_bf16, bias, residual, y, 0, stream);
@@ -526,15 +548,11 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
     // Small-M layers (8x8 levels): a 256-pixel x 64-channel-chunk tile with the K loop split over
     // 2-4 workgroups beats 64-pixel tiles (weights are re-read per M tile); slices are summed with
     // row-coalesced fp32 atomics.
-    if (d->KH == 3 && !(io & 2) && BM < 256 && d->K % 64 == 0 && d->K1 % 64 == 0 && (d->accumulate || d->ldy == d->Nc)) {
-        static const int allow = [] { const char* e = getenv("MI_HALO_SPLITK"); return e ? atoi(e) : 1; }();
+    if (!(io & 2)) {
         int th, ti;
-        const long b256 = ((long)d->N * d->OH * d->OW + 255) / 256 * ((d->Nc + 127) / 128);
-        const int chunks = d->K / 64;
-        if (allow && chunks >= 8 && halo_geom(d, 256, &th, &ti) && b256 >= 32) {   // measured: loses for K < 512
-            int ks = 2;
-            while (b256 * ks < 200 && ks * 4 <= chunks && ks < 8) ks *= 2;             // >= 2 chunks per slice
-            if (ks * 2 <= chunks) {
+        const int ks = halo_splitk(d, BM, &th, &ti);
+        if (ks) {
+            {
                 a.TH = th; a.TI = ti; a.tiles_per_img = ti > 1 ? 1 : a.H / th; a.HP = ti * (th + 2) * (a.W + 2);
                 a.ksplit = ks;
                 if (!d->accumulate) {

@@ -442,7 +442,9 @@ static int w3_plan(const MiWgradDesc* d, W3Args& a, int& BJ, bool& wide) {
     // exactly one round of workgroups: the kernel holds ~480 registers per lane, i.e. one workgroup per CU
     static const long target = [] { const char* e = getenv("MI_W3_BLOCKS"); return e ? atol(e) : 256L; }();
     long splits = target / base;
-    if (splits > a.total) splits = a.total;
+    // a k-slice costs a prologue, a partial-tile store and a share of the reduce: keep >= MINC chunks per slice
+    static const long minc = [] { const char* e = getenv("MI_W3_MINC"); return e ? atol(e) : 1L; }();
+    if (splits > a.total / minc) splits = a.total / minc;
     if (splits < 1) splits = 1;
     a.cps = (int)((a.total + splits - 1) / splits);
     a.splits = (a.total + a.cps - 1) / a.cps;

@@ -416,3 +416,10 @@ def fast3x3_supported(N, H, W, K, Nc, K1=None):
     dw = MiWgradDesc(N=N, GH=H, GW=W, DH=H, DW=W, Ci=K, Cj=Nc, KH=3, KW=3, stride=1, pad=1, gather_i=1, mode=MODE_BF16,
                      I1=K1 or K, ldp=4, ldp2=4, ldq=4)
     return bool(lib.mi_conv3x3_bf16w_supported(C.byref(dc))), bool(lib.mi_conv3x3_wgrad_supported(C.byref(dw)))
+
+
+def conv3x3_uses_splitk(N, H, W, K, Nc, K1=None):
+    """Would the 3x3 LDS-tile kernel run this layer with the split-K plan (fp32 output only)?"""
+    dc = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0,
+                    mode=MODE_BF16, K1=K1 or K, ldx=4, ldx2=4, ldy=Nc, ldr=0, accumulate=0)
+    return bool(load_library().mi_conv3x3_bf16w_uses_splitk(C.byref(dc)))

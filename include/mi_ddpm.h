@@ -84,6 +84,9 @@ int mi_conv_igemm_tile(const MiConvDesc* d, int* bm, int* bn);
 int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
                      const float* bias, const float* residual, float* y, void* stream);
 int mi_conv3x3_bf16w_supported(const MiConvDesc* d);
+/* 1 when the layer would run the split-K plan (small-M levels; partial sums are combined with fp32 atomics, so
+ * the output has to be fp32): the caller keeps such layers' block-internal tensors in fp32. */
+int mi_conv3x3_bf16w_uses_splitk(const MiConvDesc* d);
 /* bf16 activation storage for the ResnetBlock-internal tensors (conv output -> GroupNorm -> conv input and
  * their gradients): io bit 0 = x / x2 are bf16 tensors, bit 1 = y is written as bf16; strides count
  * elements.  3x3 only; with bit 1 the split-K variant (fp32 atomics) is not used. */
