@@ -10,7 +10,19 @@
 // v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32 with fp32 accumulation.
 // Replaces aten::convolution / convolution_backward(input) / addmm for ddpm.py:70,79,116,
 // 127,134,151-152,190-192,236 (see include/mi_ddpm.h).
+#include <stdlib.h>
 #include "common.h"
+
+#ifdef MI_HALO_TIMING
+// profiling build only (make EXTRA=-DMI_HALO_TIMING): per-workgroup phase timestamps of igemm_fast_kernel
+__device__ unsigned long long g_igemm_ts[4 * 4096];
+#define MI_TSI(k) do { if (threadIdx.x == 0 && blockIdx.y == 0) { const unsigned b_ = blockIdx.z * gridDim.x + blockIdx.x; if (b_ < 4096) g_igemm_ts[(k) * 4096 + b_] = wall_clock64(); } } while (0)
+extern "C" int mi_debug_igemm_ts(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_igemm_ts), sizeof(g_igemm_ts));
+}
+#else
+#define MI_TSI(k) do {} while (0)
+#endif
 
 namespace {
 
@@ -302,6 +314,233 @@ int launch(const IgemmArgs& a, int classes, hipStream_t st) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast path of the same implicit GEMM for the aligned bf16 cases that matter for throughput: the
+// stride-2 Downsample conv, the ConvTranspose2d Upsample and their data gradients (ddpm.py:70,79).
+// Requirements: bf16 weight copy [tap][Nc][K], K % 32 == 0, 16-byte aligned activation rows.
+// Differences from igemm_kernel: the valid taps of a parity class come from a table in the
+// arguments (no tap search in the loop); row validity per tap is a bit mask computed once; the
+// K walk is straight-line code over a ring of three register stages (stage s+3 is requested
+// while stage s runs on the matrix cores and stage s+1 is written to the other LDS buffer) with
+// clamped addresses, padding applied as an AND mask at the LDS store and the tail handled by
+// zeroed weight tiles -- so every s_waitcnt is an exact vmcnt(N) and there is one barrier per
+// 32-channel step instead of two.
+struct FastTaps {                   // dwords, so that the uniform lookups in the loop are scalar loads
+    int dy[64], dx[64];             // [class * 16 + i]: input offset of the i-th valid tap of the class
+    int dpix[64];                   // dy * IW + dx
+    int tap[64];                    // its index ky * KW + kx into the weights
+    int ntap[4];
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_fast_kernel(const IgemmArgs a, const FastTaps tt) {
+    constexpr int PITCH = 40;
+    constexpr int A_IT = BM / 32;          // 16-byte activation loads per thread per stage (BM rows x 32 channels)
+    constexpr int B_IT = BN / 64;          // 16-byte weight loads per thread per stage (BN rows x 32 k, bf16)
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int ABUF = (BM + BN) * PITCH;
+
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2 * ABUF];
+
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int s = a.stride, cls = blockIdx.z;
+    const int py = a.transposed ? cls / s : 0, px = a.transposed ? cls % s : 0;
+    const int ntap = tt.ntap[cls];
+    const int nchunks = a.K / 32;
+    const int nsteps = ntap * nchunks;
+
+    MI_TSI(0);
+    // ---- per-thread A rows: base pixel and a validity bit per tap, decoded once
+    const int ac4 = t & 7;
+    int apix[A_IT]; uint32_t amask[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + (t >> 3) + 32 * i;
+        const bool ok = m < a.Mc;
+        const int mm = ok ? m : 0;
+        const int n = mm / (a.OHc * a.OWc);
+        const int rem = mm - n * (a.OHc * a.OWc);
+        const int yy = rem / a.OWc, xx = rem - yy * a.OWc;
+        const int yb = a.transposed ? yy : yy * s, xb = a.transposed ? xx : xx * s;
+        apix[i] = (n * a.IH + yb) * a.IW + xb;
+        uint32_t mk = 0;
+        for (int ti = 0; ti < ntap; ++ti) {
+            const int iy = yb + tt.dy[cls * 16 + ti], ix = xb + tt.dx[cls * 16 + ti];
+            if (ok && iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) mk |= 1u << ti;
+        }
+        amask[i] = mk;
+    }
+    const int b_row = t >> 2, b_k8 = t & 3;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[3][A_IT]; u32x4 rb[3][B_IT]; uint32_t rk[3];
+    int lti = 0, lkc = 0;                   // load cursor: (tap index in the class, channel offset) of the next stage
+
+    auto load_stage = [&](f32x4 (&A)[A_IT], u32x4 (&B)[B_IT], uint32_t& keep) {
+        const int dpix = tt.dpix[cls * 16 + lti];
+        const bool second = lkc >= a.K1;
+        const float* src = (second ? a.x2 : a.x) + (second ? lkc - a.K1 : lkc) + ac4 * 4;
+        const int ld = second ? a.ldx2 : a.ldx;
+        uint32_t kp = 0;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const uint32_t ok = (amask[i] >> lti) & 1u;
+            kp |= ok << i;
+            const int pix = ok ? apix[i] + dpix : 0;
+            A[i] = *reinterpret_cast<const f32x4*>(src + (size_t)pix * ld);
+        }
+        keep = kp;
+        const uint16_t* wsrc = a.wb + (size_t)tt.tap[cls * 16 + lti] * a.Nc * a.K + lkc + b_k8 * 8;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int n = min(n0 + b_row + 64 * i, a.Nc - 1);          // rows past Nc: their columns are never written
+            B[i] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)n * a.K);
+        }
+        // advance the cursor; past the end it stays on the last stage (a harmless re-read)
+        lkc += 32;
+        if (lkc >= a.K) { lkc = 0; ++lti; }
+        if (lti >= ntap) { lti = ntap - 1; lkc = a.K - 32; }
+    };
+    auto store_stage = [&](int buf, const f32x4 (&A)[A_IT], const u32x4 (&B)[B_IT], uint32_t keep, uint32_t live) {
+        uint16_t* As = lds + buf * ABUF;
+        uint16_t* Bs = As + BM * PITCH;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const uint32_t m = 0u - ((keep >> i) & 1u);
+            *reinterpret_cast<u32x2*>(&As[((t >> 3) + 32 * i) * PITCH + ac4 * 4]) =
+                u32x2{pack_bf16(A[i].x, A[i].y) & m, pack_bf16(A[i].z, A[i].w) & m};
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            *reinterpret_cast<u32x4*>(&Bs[(b_row + 64 * i) * PITCH + b_k8 * 8]) = B[i] & live;
+    };
+    const int arow = (wm * WM + (l & 31)) * PITCH + (l >> 5) * 8, brow = (wn * WN + (l & 31)) * PITCH + (l >> 5) * 8;
+    // one step = fragment reads of the current buffer, then the LDS stores of the next stage (they drain under the
+    // MFMAs), then the MFMAs
+    bf16x8 af[2][MI], bf[2][NI];
+    auto read_frags = [&](int buf) {
+        const uint16_t* As = lds + buf * ABUF;
+        const uint16_t* Bs = As + BM * PITCH;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(&As[arow + 32 * i * PITCH + ks * 16]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf[ks][j] = *reinterpret_cast<const bf16x8*>(&Bs[brow + 32 * j * PITCH + ks * 16]);
+        }
+    };
+    auto mma_frags = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+    };
+
+    // prologue: stage 0 to LDS buffer 0, stages 1 and 2 into the ring
+    load_stage(ra[0], rb[0], rk[0]);
+    load_stage(ra[1], rb[1], rk[1]);
+    load_stage(ra[2], rb[2], rk[2]);
+    store_stage(0, ra[0], rb[0], rk[0], ~0u);
+    __syncthreads();
+    MI_TSI(1);
+    for (int s0 = 0; s0 < nsteps; s0 += 3) {
+        // step s0 (slot 0 is free: stage s0 already sits in LDS)
+        read_frags(s0 & 1);
+        store_stage((s0 + 1) & 1, ra[1], rb[1], rk[1], s0 + 1 < nsteps ? ~0u : 0u);
+        load_stage(ra[0], rb[0], rk[0]);                                   // stage s0 + 3
+        mma_frags();
+        __syncthreads();
+        read_frags((s0 + 1) & 1);
+        store_stage(s0 & 1, ra[2], rb[2], rk[2], s0 + 2 < nsteps ? ~0u : 0u);
+        load_stage(ra[1], rb[1], rk[1]);                                   // stage s0 + 4
+        mma_frags();
+        __syncthreads();
+        read_frags(s0 & 1);
+        store_stage((s0 + 1) & 1, ra[0], rb[0], rk[0], s0 + 3 < nsteps ? ~0u : 0u);
+        load_stage(ra[2], rb[2], rk[2]);                                   // stage s0 + 5
+        mma_frags();
+        __syncthreads();
+    }
+
+    MI_TSI(2);
+    // ---- epilogue: bias, residual, accumulate; 128-byte row segments.  The optional operands are fetched in
+    //      batches (one wait per 32-row block) instead of one dependent load per element.
+    const bool remap = a.transposed && s > 1;
+    float bcol[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = min(n0 + wn * WN + j * 32 + (l & 31), a.Nc - 1);
+        bcol[j] = a.bias ? a.bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        int opix[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = min(m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), a.Mc - 1);
+            opix[r] = m;
+            if (remap) {
+                const int n = m / (a.OHc * a.OWc);
+                const int rem = m - n * (a.OHc * a.OWc);
+                const int yy = rem / a.OWc, xx = rem - yy * a.OWc;
+                opix[r] = (n * a.OH + yy * s + py) * a.OW + xx * s + px;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wn * WN + j * 32 + (l & 31);
+            const int colc = min(col, a.Nc - 1);
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bcol[j];
+            if (a.res) {
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = a.res[(size_t)opix[r] * a.ldr + colc];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += rv[r];
+            }
+            if (a.accumulate) {
+                float ov[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ov[r] = a.y[(size_t)opix[r] * a.ldy + colc];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += ov[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                if (m < a.Mc && col < a.Nc) a.y[(size_t)opix[r] * a.ldy + col] = v[r];
+            }
+        }
+    }
+    MI_TSI(3);
+}
+
+template <int BM, int BN>
+int launch_fast(const IgemmArgs& a, const FastTaps& tt, int classes, hipStream_t st) {
+    dim3 grid((a.Mc + BM - 1) / BM, (a.Nc + BN - 1) / BN, classes);
+    hipLaunchKernelGGL((igemm_fast_kernel<BM, BN>), grid, dim3(256), 0, st, a, tt);
+    return 0;
+}
+
 }  // namespace
 
 static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, const float* w, const uint16_t* wb,
@@ -366,6 +605,40 @@ static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, 
     bool bn64 = d->Nc <= 64;
     bool bm64 = tiles128 < 384 || a.Mc <= 64;
     if (bn64 == false && bm64 && (long)((a.Mc + 63) / 64) * ((d->Nc + 127) / 128) * classes < 384) bn64 = true;
+    // aligned bf16 layers with few taps per class: the straight-line ring kernel
+    static const int allow_fast = [] { const char* e = getenv("MI_IGEMM_FAST"); return e ? atoi(e) : 1; }();
+    if (allow_fast && d->mode == 1 && wb && a.ksplit == 1 && d->K % 32 == 0 && d->K1 % 32 == 0 && a.vecA && classes <= 4 &&
+        d->KH * d->KW <= 16) {
+        FastTaps tt;
+        bool ok = true;
+        for (int c = 0; c < classes && ok; ++c) {
+            const int py = d->transposed ? c / d->stride : 0, px = d->transposed ? c % d->stride : 0;
+            int nt = 0;
+            for (int ky = 0; ky < d->KH; ++ky)
+                for (int kx = 0; kx < d->KW; ++kx) {
+                    int dy, dx;
+                    if (d->transposed) {
+                        const int ny = py + d->pad - ky, nx = px + d->pad - kx;
+                        if (((ny % d->stride) + d->stride) % d->stride || ((nx % d->stride) + d->stride) % d->stride) continue;
+                        dy = ny / d->stride; dx = nx / d->stride;
+                    } else { dy = ky - d->pad; dx = kx - d->pad; }
+                    if (nt >= 16) { ok = false; break; }
+                    tt.dy[c * 16 + nt] = dy; tt.dx[c * 16 + nt] = dx; tt.dpix[c * 16 + nt] = dy * d->IW + dx;
+                    tt.tap[c * 16 + nt] = ky * d->KW + kx;
+                    ++nt;
+                }
+            tt.ntap[c] = nt;
+            if (nt == 0) ok = false;
+        }
+        if (ok) {
+            if (!bm64 && !bn64) launch_fast<128, 128>(a, tt, classes, st);
+            else if (!bm64 && bn64) launch_fast<128, 64>(a, tt, classes, st);
+            else if (bm64 && !bn64) launch_fast<64, 128>(a, tt, classes, st);
+            else launch_fast<64, 64>(a, tt, classes, st);
+            MI_LAUNCH_CHECK();
+            return 0;
+        }
+    }
 #define MI_GO(MODE) \
     do { if (!bm64 && !bn64) launch<MODE, 128, 128>(a, classes, st); \
          else if (!bm64 && bn64) launch<MODE, 128, 64>(a, classes, st); \
