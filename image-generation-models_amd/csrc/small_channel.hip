@@ -1,185 +1,349 @@
-// The two 3-channel ends of the UNet: Conv2d(3, C, 3, padding=1) of downs.0.0.block1 (ddpm.py:116,208)
-// and final_conv's Conv2d(C, 3, 1) (ddpm.py:236), forward / dgrad / wgrad.  With 3 (or 3x9 = 27)
-// contraction elements an MFMA tile would be 90 % padding, so these are plain fp32 VALU kernels
-// bound by the one large tensor they stream (the C-channel activation or its gradient).
+// The 3-channel ends of the UNet: Conv2d(3, C, 3, padding=1) and the 1x1 res_conv of downs.0.0
+// (ddpm.py:116,134,208) and final_conv's Conv2d(C, 3, 1) (ddpm.py:236), forward / dgrad / wgrad.
+// With 3 (or 3x9 = 27) contraction elements an MFMA tile would be 90 % padding, so these are fp32
+// VALU kernels bound by the one wide tensor they stream (the C-channel activation or its gradient).
+// Layout of every kernel: a thread owns one channel quad of the wide side (16-byte loads / stores, 512-byte
+// rows per 32 lanes) and a pixel lane; the small side is a broadcast load; weights live in registers.
+// Weight gradients are reduced per workgroup (shuffle + LDS) and leave as one partial tile per workgroup
+// (summed by partial_sum_kernel) -- or as one atomic per output and workgroup when no workspace is given.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
 
-// y[px][co] = b[co] + sum_{tap,ci<Cin} x[px+tap][ci] * w[tap][ci][co];   x has pixel stride ldx (>= 4), Cin <= 4
-__global__ __launch_bounds__(256) void conv3x3_small_cin_fwd(int N, int H, int W, int Cin, int Cout, const float* __restrict__ x,
-                                                             int ldx, const float* __restrict__ w, const float* __restrict__ bias,
-                                                             float* __restrict__ y, int ldy) {
-    extern __shared__ float wl[];                         // [9*Cin][Cout]
-    for (int i = threadIdx.x; i < 9 * Cin * Cout; i += 256) wl[i] = w[i];
-    __syncthreads();
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WG_BLOCKS = 768;          // weight-gradient workgroups (3 per CU): the number of partial tiles
+
+// m -> (image, row, column); POW2: W and H*W are powers of two (shifts), else divisions
+template <bool POW2>
+__device__ __forceinline__ void decode_px(int m, int H, int W, int w_sh, int hw_sh, int& n, int& yy, int& xx) {
+    if constexpr (POW2) {
+        n = m >> hw_sh; const int rem = m & ((1 << hw_sh) - 1);
+        yy = rem >> w_sh; xx = rem & ((1 << w_sh) - 1);
+    } else {
+        n = m / (H * W); const int rem = m - n * (H * W);
+        yy = rem / W; xx = rem - yy * W;
+    }
+}
+
+// the <= 4 input channels of one pixel (zero when the tap falls outside the image)
+template <int CIN>
+__device__ __forceinline__ f32x4 load_small(const float* __restrict__ x, int ldx, int n, int iy, int ix, int H, int W, bool vec) {
+    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const float* p = x + (size_t)((n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * ldx;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (vec) v = *reinterpret_cast<const f32x4*>(p);
+    else { v.x = p[0]; if (CIN > 1) v.y = p[1]; if (CIN > 2) v.z = p[2]; if (CIN > 3) v.w = p[3]; }
+    const float k = ok ? 1.f : 0.f;
+    return v * k;
+}
+
+// y[px][co] = b[co] + sum_{tap,ci<CIN} x[px+tap][ci] * w[tap][ci][co];   KS = 3 (pad 1) or 1
+template <int CIN, int KS, bool POW2>
+__global__ __launch_bounds__(256) void small_cin_fwd_kernel(int N, int H, int W, int Cout, const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int ldy, int w_sh, int hw_sh, int vec) {
+    constexpr int NT = KS * KS;
     const int nq = Cout / 4;                              // channel quads
     const int q = threadIdx.x % nq, psub = threadIdx.x / nq, pp = 256 / nq;
+    f32x4 wr[NT * CIN];
+#pragma unroll
+    for (int i = 0; i < NT * CIN; ++i) wr[i] = *reinterpret_cast<const f32x4*>(w + (size_t)i * Cout + 4 * q);
+    const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
     const int M = N * H * W;
     for (int m = blockIdx.x * pp + psub; m < M; m += gridDim.x * pp) {
-        const int n = m / (H * W), rem = m - n * (H * W);
-        const int yy = rem / W, xx = rem - yy * W;
-        float4 acc = bias ? *reinterpret_cast<const float4*>(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        int n, yy, xx;
+        decode_px<POW2>(m, H, W, w_sh, hw_sh, n, yy, xx);
+        f32x4 xv[NT];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int tp = 0; tp < NT; ++tp) xv[tp] = load_small<CIN>(x, ldx, n, yy + tp / KS - KS / 2, xx + tp % KS - KS / 2, H, W, vec);
+        f32x4 acc = b4;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = yy + ky - 1, ix = xx + kx - 1;
-                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const float* xp = x + (size_t)((n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * ldx;
-                for (int ci = 0; ci < Cin; ++ci) {
-                    const float xv = ok ? xp[ci] : 0.f;
-                    const float4 wv = *reinterpret_cast<const float4*>(&wl[((ky * 3 + kx) * Cin + ci) * Cout + 4 * q]);
-                    acc.x += xv * wv.x; acc.y += xv * wv.y; acc.z += xv * wv.z; acc.w += xv * wv.w;
-                }
-            }
-        *reinterpret_cast<float4*>(y + (size_t)m * ldy + 4 * q) = acc;
+        for (int tp = 0; tp < NT; ++tp)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) acc += xv[tp][ci] * wr[tp * CIN + ci];
+        *reinterpret_cast<f32x4*>(y + (size_t)m * ldy + 4 * q) = acc;
     }
 }
 
-// dW[tap][ci][co] += sum_px x[px+tap][ci] * dy[px][co]   (Cin <= 4): thread = co, 9*Cin accumulators
-template <int CIN>
-__global__ __launch_bounds__(256) void conv3x3_small_cin_wgrad(int N, int H, int W, int Cout, const float* __restrict__ x, int ldx,
-                                                               const float* __restrict__ dy, int lddy, float* __restrict__ dW,
-                                                               int px_per_block) {
+// Sum of a per-thread array of NA float4 over the pixel lanes of a workgroup (threads with equal t % nq), result in
+// threads 0..nq-1.  nq is 16, 32 or 64: the pixel lanes inside a wave are combined by shuffles, the four waves via LDS.
+template <int NA>
+__device__ __forceinline__ void block_reduce_quads(f32x4 (&a)[NA], int nq, float* red /* [3][NA][nq][4] */) {
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    for (int o = nq; o < 64; o <<= 1) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            a[i].x += __shfl_xor(a[i].x, o, 64); a[i].y += __shfl_xor(a[i].y, o, 64);
+            a[i].z += __shfl_xor(a[i].z, o, 64); a[i].w += __shfl_xor(a[i].w, o, 64);
+        }
+    }
+    if (wv > 0 && l < nq) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&red[(((wv - 1) * NA + i) * nq + l) * 4]) = a[i];
+    }
+    __syncthreads();
+    if (wv == 0 && l < nq) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a[i] += *reinterpret_cast<const f32x4*>(&red[((k * NA + i) * nq + l) * 4]);
+    }
+}
+
+// dW[tap][ci][co] += sum_px x[px+tap][ci] * dy[px][co]: thread = (co quad, pixel lane), KS*KS*CIN float4 accumulators
+template <int CIN, int KS, bool POW2>
+__global__ __launch_bounds__(256) void small_cin_wgrad_kernel(int N, int H, int W, int Cout, const float* __restrict__ x, int ldx,
+                                                              const float* __restrict__ dy, int lddy, float* __restrict__ dW,
+                                                              float* __restrict__ ws, int w_sh, int hw_sh, int vec) {
+    constexpr int NT = KS * KS, NA = NT * CIN;
+    extern __shared__ float red[];
+    const int nq = Cout / 4;
+    const int q = threadIdx.x % nq, psub = threadIdx.x / nq, pp = 256 / nq;
+    f32x4 acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int M = N * H * W;
-    const int co = blockIdx.y * 256 + threadIdx.x;
-    if (co >= Cout) return;
-    float acc[9 * CIN];
+    const int per = (M + gridDim.x - 1) / gridDim.x;
+    const int mb = blockIdx.x * per, me = min(M, mb + per);
+    int m = mb + psub;
+    f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)min(m, M - 1) * lddy + 4 * q);
+    for (; m < me; m += pp) {
+        const f32x4 gnext = *reinterpret_cast<const f32x4*>(dy + (size_t)min(m + pp, M - 1) * lddy + 4 * q);   // one pixel ahead
+        int n, yy, xx;
+        decode_px<POW2>(m, H, W, w_sh, hw_sh, n, yy, xx);
 #pragma unroll
-    for (int i = 0; i < 9 * CIN; ++i) acc[i] = 0.f;
-    const int mb = blockIdx.x * px_per_block, me = min(M, mb + px_per_block);
-    for (int m = mb; m < me; ++m) {
-        const int n = m / (H * W), rem = m - n * (H * W);
-        const int yy = rem / W, xx = rem - yy * W;
-        const float g = dy[(size_t)m * lddy + co];
+        for (int tp = 0; tp < NT; ++tp) {
+            const f32x4 xv = load_small<CIN>(x, ldx, n, yy + tp / KS - KS / 2, xx + tp % KS - KS / 2, H, W, vec);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = yy + ky - 1, ix = xx + kx - 1;
-                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;          // wave-uniform (m is per block)
-                const float* xp = x + (size_t)((n * H + iy) * W + ix) * ldx;  // same address in every lane: broadcast
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) acc[(ky * 3 + kx) * CIN + ci] += xp[ci] * g;
-            }
+            for (int ci = 0; ci < CIN; ++ci) acc[tp * CIN + ci] += xv[ci] * g;
+        }
+        g = gnext;
     }
+    block_reduce_quads<NA>(acc, nq, red);
+    if (threadIdx.x < nq) {
+        if (ws) {
+            float* out = ws + (size_t)blockIdx.x * NA * Cout;
 #pragma unroll
-    for (int i = 0; i < 9 * CIN; ++i) atomicAdd(dW + (size_t)i * Cout + co, acc[i]);
+            for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(out + (size_t)i * Cout + 4 * q) = acc[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(dW + (size_t)i * Cout + 4 * q + k, acc[i][k]);
+        }
+    }
 }
 
-// ---- 1x1 conv to/from a few channels (Cs <= 4 "small" side, C large side), weights w[c][j] (c < C, j < Cs)
-// forward: y[px][j] = b[j] + sum_c x[px][c] w[c][j]; one wave per pixel pair, shuffle reduction
-__global__ __launch_bounds__(256) void conv1x1_small_cout_fwd(int M, int C, int Cs, const float* __restrict__ x, int ldx,
-                                                              const float* __restrict__ w, const float* __restrict__ bias,
-                                                              float* __restrict__ y, int ldy) {
-    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int m = blockIdx.x * 4 + wv; m < M; m += gridDim.x * 4) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int c = 4 * l; c < C; c += 256) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + c);
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+// out[map(o)] += sum_p ws[p * nout + o]; rows4 > 0: the partial tiles are [rows][4] and out is [rows][rows4] (rows4 <= 4)
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ ws, int nparts, int nout, float* __restrict__ out, int rows4) {
+    __shared__ float red[8][32];
+    const int ol = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int o = blockIdx.x * 32 + ol;
+    float s = 0.f;
+    if (o < nout)
+        for (int p = grp; p < nparts; p += 8) s += ws[(size_t)p * nout + o];
+    red[grp][ol] = s;
+    __syncthreads();
+    if (grp == 0 && o < nout) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float* wr = w + (size_t)(c + k) * Cs;
-                a0 += xs[k] * wr[0];
-                if (Cs > 1) a1 += xs[k] * wr[1];
-                if (Cs > 2) a2 += xs[k] * wr[2];
-                if (Cs > 3) a3 += xs[k] * wr[3];
-            }
+        for (int g = 1; g < 8; ++g) s += red[g][ol];
+        if (rows4 > 0) { if ((o & 3) < rows4) out[(o >> 2) * rows4 + (o & 3)] += s; }
+        else out[o] += s;
+    }
+}
+
+// ---- 1x1 conv to/from a few channels (Cs <= 4 "small" side, C wide side), weights w[c][j] (c < C, j < Cs)
+// forward: y[px][j] = b[j] + sum_c x[px][c] w[c][j]; 8 lanes per pixel, each 4*CK channels, weights in registers
+template <int CK>
+__global__ __launch_bounds__(256) void small_cout_fwd_kernel(int M, int Cs, const float* __restrict__ x, int ldx,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ y, int ldy) {
+    const int sub = threadIdx.x & 7, pl = threadIdx.x >> 3;          // 32 pixels per workgroup and iteration
+    f32x4 wr[CK][4];                                                 // wr[k][e][j] = w[c = 4*(sub+8k)+e][j]
+#pragma unroll
+    for (int k = 0; k < CK; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* wp = w + (size_t)(4 * (sub + 8 * k) + e) * Cs;
+            wr[k][e] = f32x4{wp[0], Cs > 1 ? wp[1] : 0.f, Cs > 2 ? wp[2] : 0.f, Cs > 3 ? wp[3] : 0.f};
         }
-        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-        if (l < Cs) {
-            float v = l == 0 ? a0 : l == 1 ? a1 : l == 2 ? a2 : a3;
-            y[(size_t)m * ldy + l] = v + (bias ? bias[l] : 0.f);
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias) { b4.x = bias[0]; if (Cs > 1) b4.y = bias[1]; if (Cs > 2) b4.z = bias[2]; if (Cs > 3) b4.w = bias[3]; }
+    for (int m0 = blockIdx.x * 32; m0 < M; m0 += gridDim.x * 32) {
+        const int m = min(m0 + pl, M - 1);
+        f32x4 xv[CK];
+#pragma unroll
+        for (int k = 0; k < CK; ++k) xv[k] = *reinterpret_cast<const f32x4*>(x + (size_t)m * ldx + 4 * (sub + 8 * k));
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < CK; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a += xv[k][e] * wr[k][e];
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64);
+            a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+        }
+        if (sub == 0 && m0 + pl < M) {
+            a += b4;
+            float* yp = y + (size_t)m * ldy;
+            yp[0] = a.x; if (Cs > 1) yp[1] = a.y; if (Cs > 2) yp[2] = a.z; if (Cs > 3) yp[3] = a.w;
         }
     }
 }
-// dgrad: dx[px][c] (+)= sum_j dy[px][j] w[c][j]
-__global__ __launch_bounds__(256) void conv1x1_small_cout_dgrad(int M, int C, int Cs, const float* __restrict__ dy, int lddy,
-                                                                const float* __restrict__ w, float* __restrict__ dx, int lddx, int acc) {
+// dgrad: dx[px][c] (+)= sum_j dy[px][j] w[c][j]; thread = (channel quad, pixel lane)
+__global__ __launch_bounds__(256) void small_cout_dgrad_kernel(int M, int C, int Cs, const float* __restrict__ dy, int lddy,
+                                                               const float* __restrict__ w, float* __restrict__ dx, int lddx, int acc) {
     const int nq = C / 4;
-    const size_t tot = (size_t)M * nq;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
-        const size_t m = i / nq; const int c = (int)(i % nq) * 4;
-        float g[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < Cs; ++j) g[j] = dy[m * lddy + j];
-        float o[4];
+    const int q = threadIdx.x % nq, psub = threadIdx.x / nq, pp = 256 / nq;
+    f32x4 wr[4];                                                     // wr[e][j] = w[4q+e][j]
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float* wr = w + (size_t)(c + k) * Cs;
-            float v = 0.f;
-            for (int j = 0; j < Cs; ++j) v += g[j] * wr[j];
-            o[k] = v;
+    for (int e = 0; e < 4; ++e) {
+        const float* wp = w + (size_t)(4 * q + e) * Cs;
+        wr[e] = f32x4{wp[0], Cs > 1 ? wp[1] : 0.f, Cs > 2 ? wp[2] : 0.f, Cs > 3 ? wp[3] : 0.f};
+    }
+    for (int m = blockIdx.x * pp + psub; m < M; m += gridDim.x * pp) {
+        const float* gp = dy + (size_t)m * lddy;
+        f32x4 g = {gp[0], Cs > 1 ? gp[1] : 0.f, Cs > 2 ? gp[2] : 0.f, Cs > 3 ? gp[3] : 0.f};
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const f32x4 pr = g * wr[e]; o[e] = (pr.x + pr.y) + (pr.z + pr.w); }
+        float* p = dx + (size_t)m * lddx + 4 * q;
+        if (acc) o += *reinterpret_cast<const f32x4*>(p);
+        *reinterpret_cast<f32x4*>(p) = o;
+    }
+}
+// wgrad: dW[c][j] += sum_px x[px][c] dy[px][j]; thread = (channel quad, pixel lane), partial tile [C][4]
+__global__ __launch_bounds__(256) void small_cout_wgrad_kernel(int M, int C, int Cs, const float* __restrict__ x, int ldx,
+                                                               const float* __restrict__ dy, int lddy, float* __restrict__ dW,
+                                                               float* __restrict__ ws) {
+    extern __shared__ float red[];
+    const int nq = C / 4;
+    const int q = threadIdx.x % nq, psub = threadIdx.x / nq, pp = 256 / nq;
+    f32x4 acc[4];                                                    // acc[e][j] for channel 4q+e
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int per = (M + gridDim.x - 1) / gridDim.x;
+    const int mb = blockIdx.x * per, me = min(M, mb + per);
+    int m = mb + psub;
+    f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)min(m, M - 1) * ldx + 4 * q);
+    for (; m < me; m += pp) {
+        const f32x4 xnext = *reinterpret_cast<const f32x4*>(x + (size_t)min(m + pp, M - 1) * ldx + 4 * q);
+        const float* gp = dy + (size_t)m * lddy;
+        const f32x4 g = {gp[0], Cs > 1 ? gp[1] : 0.f, Cs > 2 ? gp[2] : 0.f, Cs > 3 ? gp[3] : 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += xv[e] * g;
+        xv = xnext;
+    }
+    block_reduce_quads<4>(acc, nq, red);
+    if (threadIdx.x < nq) {
+        if (ws) {
+            float* out = ws + (size_t)blockIdx.x * C * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4*>(out + (size_t)(4 * q + e) * 4) = acc[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                for (int j = 0; j < Cs; ++j) atomicAdd(dW + (size_t)(4 * q + e) * Cs + j, acc[e][j]);
         }
-        float* p = dx + m * lddx + c;
-        if (acc) { float4 prev = *reinterpret_cast<const float4*>(p); o[0] += prev.x; o[1] += prev.y; o[2] += prev.z; o[3] += prev.w; }
-        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
-// wgrad: dW[c][j] += sum_px x[px][c] dy[px][j]; thread = c
-__global__ __launch_bounds__(256) void conv1x1_small_cout_wgrad(int M, int C, int Cs, const float* __restrict__ x, int ldx,
-                                                                const float* __restrict__ dy, int lddy, float* __restrict__ dW,
-                                                                int px_per_block) {
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= C) return;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    const int mb = blockIdx.x * px_per_block, me = min(M, mb + px_per_block);
-    for (int m = mb; m < me; ++m) {
-        const float xv = x[(size_t)m * ldx + c];
-        for (int j = 0; j < Cs; ++j) a[j] += xv * dy[(size_t)m * lddy + j];
-    }
-    for (int j = 0; j < Cs; ++j) atomicAdd(dW + (size_t)c * Cs + j, a[j]);
-}
+
+int log2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; }
 
 }  // namespace
 
-extern "C" int mi_conv3x3_small_cin_fwd(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w,
-                                        const float* bias, float* y, int ldy, void* stream) {
-    MI_REQUIRE(x && w && y && Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0 && ldy % 4 == 0,
-               "needs Cin <= 4, Cout a multiple of 4 with Cout/4 dividing 256");
+extern "C" size_t mi_conv_small_wgrad_workspace(int outputs) { return (size_t)WG_BLOCKS * (size_t)outputs * sizeof(float); }
+
+extern "C" int mi_conv_small_cin_fwd(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w,
+                                     const float* bias, float* y, int ldy, void* stream) {
+    MI_REQUIRE(x && w && y && (ks == 1 || ks == 3) && Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0 &&
+               ldy % 4 == 0 && (((uintptr_t)y | (uintptr_t)w) & 15) == 0,
+               "needs ks 1|3, Cin <= 4, Cout a multiple of 4 with Cout/4 dividing 256, 16-byte aligned y / w");
     const int pp = 256 / (Cout / 4);
     long blocks = ((long)N * H * W + pp - 1) / pp; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(conv3x3_small_cin_fwd, dim3((unsigned)blocks), dim3(256), (size_t)9 * Cin * Cout * 4, (hipStream_t)stream,
-                       N, H, W, Cin, Cout, x, ldx, w, bias, y, ldy);
+    const int w_sh = log2_exact(W), hw_sh = log2_exact(H * W);
+    const bool pow2 = w_sh >= 0 && hw_sh >= 0;
+    const int vec = ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    hipStream_t st = (hipStream_t)stream;
+#define MI_GO(CIN, KS) do { \
+        if (pow2) hipLaunchKernelGGL((small_cin_fwd_kernel<CIN, KS, true>), dim3((unsigned)blocks), dim3(256), 0, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, w_sh, hw_sh, vec); \
+        else hipLaunchKernelGGL((small_cin_fwd_kernel<CIN, KS, false>), dim3((unsigned)blocks), dim3(256), 0, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, 0, 0, vec); } while (0)
+#define MI_GO_CIN(KS) do { switch (Cin) { case 1: MI_GO(1, KS); break; case 2: MI_GO(2, KS); break; case 3: MI_GO(3, KS); break; default: MI_GO(4, KS); break; } } while (0)
+    if (ks == 3) MI_GO_CIN(3); else MI_GO_CIN(1);
+#undef MI_GO
     MI_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mi_conv_small_cin_wgrad(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* dy,
+                                       int lddy, float* dW, void* workspace, size_t ws_bytes, void* stream) {
+    const int na = ks * ks * Cin;
+    MI_REQUIRE(x && dy && dW && (ks == 1 || ks == 3) && Cin >= 1 && Cin <= 4 && (Cout == 64 || Cout == 128 || Cout == 256) && lddy % 4 == 0 &&
+               ((uintptr_t)dy & 15) == 0 && (size_t)3 * na * (Cout / 4) * 16 <= 48 * 1024,
+               "needs ks 1|3, Cin <= 4, Cout in {64, 128, 256} (3x3: {64, 128}), 16-byte aligned dy rows");
+    float* ws = (workspace && ws_bytes >= mi_conv_small_wgrad_workspace(na * Cout)) ? (float*)workspace : nullptr;
+    const int w_sh = log2_exact(W), hw_sh = log2_exact(H * W);
+    const bool pow2 = w_sh >= 0 && hw_sh >= 0;
+    const int vec = ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    const size_t lds = (size_t)3 * na * (Cout / 4) * 4 * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define MI_GO(CIN, KS) do { \
+        if (pow2) hipLaunchKernelGGL((small_cin_wgrad_kernel<CIN, KS, true>), dim3(WG_BLOCKS), dim3(256), lds, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, w_sh, hw_sh, vec); \
+        else hipLaunchKernelGGL((small_cin_wgrad_kernel<CIN, KS, false>), dim3(WG_BLOCKS), dim3(256), lds, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, 0, 0, vec); } while (0)
+    if (ks == 3) MI_GO_CIN(3); else MI_GO_CIN(1);
+#undef MI_GO
+#undef MI_GO_CIN
+    if (ws) hipLaunchKernelGGL(partial_sum_kernel, dim3((na * Cout + 31) / 32), dim3(256), 0, st, ws, WG_BLOCKS, na * Cout, dW, 0);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+// the 3x3 forms of the two entry points above (kept for callers of ABI version 1)
+extern "C" int mi_conv3x3_small_cin_fwd(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w,
+                                        const float* bias, float* y, int ldy, void* stream) {
+    return mi_conv_small_cin_fwd(3, N, H, W, Cin, Cout, x, ldx, w, bias, y, ldy, stream);
 }
 extern "C" int mi_conv3x3_small_cin_wgrad(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* dy,
                                           int lddy, float* dW, void* stream) {
-    MI_REQUIRE(x && dy && dW && Cin >= 1 && Cin <= 4, "needs Cin <= 4");
-    const int M = N * H * W, per = (M + 1023) / 1024;
-    dim3 grid((M + per - 1) / per, (Cout + 255) / 256);
-    hipStream_t st = (hipStream_t)stream;
-    switch (Cin) {
-        case 1: hipLaunchKernelGGL(conv3x3_small_cin_wgrad<1>, grid, dim3(256), 0, st, N, H, W, Cout, x, ldx, dy, lddy, dW, per); break;
-        case 2: hipLaunchKernelGGL(conv3x3_small_cin_wgrad<2>, grid, dim3(256), 0, st, N, H, W, Cout, x, ldx, dy, lddy, dW, per); break;
-        case 3: hipLaunchKernelGGL(conv3x3_small_cin_wgrad<3>, grid, dim3(256), 0, st, N, H, W, Cout, x, ldx, dy, lddy, dW, per); break;
-        default: hipLaunchKernelGGL(conv3x3_small_cin_wgrad<4>, grid, dim3(256), 0, st, N, H, W, Cout, x, ldx, dy, lddy, dW, per); break;
-    }
-    MI_LAUNCH_CHECK();
-    return 0;
+    return mi_conv_small_cin_wgrad(3, N, H, W, Cin, Cout, x, ldx, dy, lddy, dW, nullptr, 0, stream);
 }
-extern "C" int mi_conv1x1_small_cout(int op, int M, int C, int Cs, const float* a, int lda, const float* b, int ldb,
-                                     const float* w, const float* bias, float* out, int ldo, int accumulate, void* stream) {
+
+extern "C" int mi_conv1x1_small_cout_ws(int op, int M, int C, int Cs, const float* a, int lda, const float* b, int ldb,
+                                        const float* w, const float* bias, float* out, int ldo, int accumulate,
+                                        void* workspace, size_t ws_bytes, void* stream) {
     // op 0: forward  (a = x[M][C], out = y[M][Cs], bias)        op 1: dgrad (a = dy[M][Cs], out = dx[M][C])
-    // op 2: wgrad    (a = x[M][C], b = dy[M][Cs], out = dW[C][Cs], accumulated atomically)
-    MI_REQUIRE(a && out && (op == 2 || w) && Cs >= 1 && Cs <= 4 && C % 4 == 0 && M > 0, "needs Cs <= 4, C % 4 == 0");
+    // op 2: wgrad    (a = x[M][C], b = dy[M][Cs], out = dW[C][Cs])
+    MI_REQUIRE(a && out && (op == 2 || w) && Cs >= 1 && Cs <= 4 && (C == 32 || C == 64 || C == 128 || C == 256) && M > 0,
+               "needs Cs <= 4 and C in {32, 64, 128, 256}");
     hipStream_t st = (hipStream_t)stream;
     if (op == 0) {
-        int blocks = (M + 3) / 4; if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(conv1x1_small_cout_fwd, dim3(blocks), dim3(256), 0, st, M, C, Cs, a, lda, w, bias, out, ldo);
+        MI_REQUIRE(C <= 128 && lda % 4 == 0 && ((uintptr_t)a & 15) == 0, "forward: C <= 128, 16-byte aligned x rows");
+        int blocks = (M + 31) / 32; if (blocks > 4096) blocks = 4096;
+        if (C == 128) hipLaunchKernelGGL(small_cout_fwd_kernel<4>, dim3(blocks), dim3(256), 0, st, M, Cs, a, lda, w, bias, out, ldo);
+        else if (C == 64) hipLaunchKernelGGL(small_cout_fwd_kernel<2>, dim3(blocks), dim3(256), 0, st, M, Cs, a, lda, w, bias, out, ldo);
+        else hipLaunchKernelGGL(small_cout_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, M, Cs, a, lda, w, bias, out, ldo);
     } else if (op == 1) {
-        long blocks = ((long)M * (C / 4) + 255) / 256; if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(conv1x1_small_cout_dgrad, dim3((unsigned)blocks), dim3(256), 0, st, M, C, Cs, a, lda, w, out, ldo, accumulate);
+        MI_REQUIRE(ldo % 4 == 0 && ((uintptr_t)out & 15) == 0, "dgrad: 16-byte aligned dx rows");
+        const int pp = 256 / (C / 4);
+        long blocks = ((long)M + pp - 1) / pp; if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(small_cout_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, M, C, Cs, a, lda, w, out, ldo, accumulate);
     } else if (op == 2) {
-        MI_REQUIRE(b, "wgrad needs dy");
-        const int per = (M + 1023) / 1024;
-        dim3 grid((M + per - 1) / per, (C + 255) / 256);
-        hipLaunchKernelGGL(conv1x1_small_cout_wgrad, grid, dim3(256), 0, st, M, C, Cs, a, lda, b, ldb, out, per);
+        MI_REQUIRE(b && C >= 64 && lda % 4 == 0 && ((uintptr_t)a & 15) == 0, "wgrad: needs dy, C in {64, 128, 256}, aligned x rows");
+        float* ws = (workspace && ws_bytes >= mi_conv_small_wgrad_workspace(C * 4)) ? (float*)workspace : nullptr;
+        hipLaunchKernelGGL(small_cout_wgrad_kernel, dim3(WG_BLOCKS), dim3(256), (size_t)3 * 4 * (C / 4) * 4 * sizeof(float), st,
+                           M, C, Cs, a, lda, b, ldb, out, ws);
+        if (ws) hipLaunchKernelGGL(partial_sum_kernel, dim3((C * 4 + 31) / 32), dim3(256), 0, st, ws, WG_BLOCKS, C * 4, out, Cs);
     } else {
         return mi_set_error(-1, "mi_conv1x1_small_cout: op must be 0, 1 or 2");
     }
     MI_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mi_conv1x1_small_cout(int op, int M, int C, int Cs, const float* a, int lda, const float* b, int ldb,
+                                     const float* w, const float* bias, float* out, int ldo, int accumulate, void* stream) {
+    return mi_conv1x1_small_cout_ws(op, M, C, Cs, a, lda, b, ldb, w, bias, out, ldo, accumulate, nullptr, 0, stream);
 }

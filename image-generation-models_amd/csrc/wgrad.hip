@@ -8,6 +8,7 @@
 // j-tile, pixel-slice); slices are combined with fp32 atomics.
 // Replaces aten::convolution_backward (weight) and addmm-backward for the layers listed in
 // include/mi_ddpm.h.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -197,6 +198,169 @@ void launch(const WgradArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_kernel<MODE, BI, BJ>), grid, dim3(256), 0, st, a);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fast path of the same weight gradient for the aligned bf16 layers that matter for throughput
+// (the stride-2 Downsample conv and the ConvTranspose2d Upsample, ddpm.py:70,79): power-of-two
+// dense grid, 16-byte aligned rows, channel counts that are multiples of 4.  Same LDS layout and MFMA
+// schedule as wgrad_kernel, but the pixel walk is straight-line code over a ring of three
+// register stages with clamped addresses (padding and the slice tail are AND masks at the LDS
+// store), LDS is double-buffered and there is one barrier per 32-pixel step -- every s_waitcnt
+// is an exact vmcnt(N).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int BI, int BJ>
+__global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WgradArgs a, int dw_sh, int dhw_sh) {
+    constexpr int PITCH = 40;
+    constexpr int P_IT = BI / 64, Q_IT = BJ / 64;      // channel quads per thread
+    constexpr int WI = BI / 2, WJ = BJ / 2;
+    constexpr int MI = WI / 32, NJ = WJ / 32;
+    constexpr int BUF = (BI + BJ) * PITCH;
+
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2 * BUF];
+
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int wi = wv >> 1, wj = wv & 1;
+    const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;
+    const int tap = blockIdx.z / a.splits, split = blockIdx.z % a.splits;
+    const int ky = tap / a.KW, kx = tap % a.KW;
+    const int mbeg = split * a.chunk;
+    const int mend = min(a.Mtot, mbeg + a.chunk);
+    const int nsteps = (mend - mbeg + 31) / 32;
+    const int kd = t & 15, cq = t >> 4;
+
+    // channel sources of this thread's quads (clamped: rows / columns past the extent are never written back)
+    const float* p_src[P_IT]; int p_ld[P_IT];
+#pragma unroll
+    for (int p = 0; p < P_IT; ++p) {
+        const int c = min(i0 + (cq + 16 * p) * 4, a.Ci - 4);
+        const bool second = c >= a.I1;
+        p_src[p] = (second ? a.P2 : a.P) + (second ? c - a.I1 : c);
+        p_ld[p] = second ? a.ldp2 : a.ldp;
+    }
+    const float* q_src[Q_IT];
+#pragma unroll
+    for (int p = 0; p < Q_IT; ++p) q_src[p] = a.Q + min(j0 + (cq + 16 * p) * 4, a.Cj - 4);
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 rp[3][2 * P_IT], rq[3][2 * Q_IT]; uint32_t rk[3];
+    int lm = mbeg + 2 * kd;                  // first of the two pixels this thread stages in the next stage
+
+    auto load_stage = [&](f32x4 (&RP)[2 * P_IT], f32x4 (&RQ)[2 * Q_IT], uint32_t& keep) {
+        uint32_t kp = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = lm + h;
+            const bool inr = m < mend;
+            const int mm = inr ? m : mbeg;
+            const int n = mm >> dhw_sh, rem = mm & ((1 << dhw_sh) - 1);
+            const int yy = rem >> dw_sh, xx = rem & ((1 << dw_sh) - 1);
+            const int gy = yy * a.stride - a.pad + ky, gx = xx * a.stride - a.pad + kx;
+            const bool gok = inr && gy >= 0 && gy < a.GH && gx >= 0 && gx < a.GW;
+            const int gpix = gok ? (n * a.GH + gy) * a.GW + gx : 0;
+            const int ppix = a.gather_i ? gpix : mm;
+            const int qpix = a.gather_i ? mm : gpix;
+            kp |= (gok ? 1u : 0u) << h;      // one operand zero is enough: the product vanishes
+#pragma unroll
+            for (int p = 0; p < P_IT; ++p) RP[2 * p + h] = *reinterpret_cast<const f32x4*>(p_src[p] + (size_t)ppix * p_ld[p]);
+#pragma unroll
+            for (int p = 0; p < Q_IT; ++p) RQ[2 * p + h] = *reinterpret_cast<const f32x4*>(q_src[p] + (size_t)qpix * a.ldq);
+        }
+        keep = kp;
+        lm += 32;
+    };
+    auto store_stage = [&](int buf, const f32x4 (&RP)[2 * P_IT], const f32x4 (&RQ)[2 * Q_IT], uint32_t keep) {
+        uint16_t* Ps = lds + buf * BUF;
+        uint16_t* Qs = Ps + BI * PITCH;
+        // lo half = pixel 2*kd, hi half = pixel 2*kd + 1; mask each half separately
+        const uint32_t m = ((keep & 1u) ? 0x0000ffffu : 0u) | ((keep & 2u) ? 0xffff0000u : 0u);
+#pragma unroll
+        for (int p = 0; p < P_IT; ++p) {
+            const int row = (cq + 16 * p) * 4;
+            const f32x4 lo = RP[2 * p], hi = RP[2 * p + 1];
+            *reinterpret_cast<uint32_t*>(&Ps[(row + 0) * PITCH + 2 * kd]) = pack_bf16(lo.x, hi.x) & m;
+            *reinterpret_cast<uint32_t*>(&Ps[(row + 1) * PITCH + 2 * kd]) = pack_bf16(lo.y, hi.y) & m;
+            *reinterpret_cast<uint32_t*>(&Ps[(row + 2) * PITCH + 2 * kd]) = pack_bf16(lo.z, hi.z) & m;
+            *reinterpret_cast<uint32_t*>(&Ps[(row + 3) * PITCH + 2 * kd]) = pack_bf16(lo.w, hi.w) & m;
+        }
+#pragma unroll
+        for (int p = 0; p < Q_IT; ++p) {
+            const int row = (cq + 16 * p) * 4;
+            const f32x4 lo = RQ[2 * p], hi = RQ[2 * p + 1];
+            *reinterpret_cast<uint32_t*>(&Qs[(row + 0) * PITCH + 2 * kd]) = pack_bf16(lo.x, hi.x);
+            *reinterpret_cast<uint32_t*>(&Qs[(row + 1) * PITCH + 2 * kd]) = pack_bf16(lo.y, hi.y);
+            *reinterpret_cast<uint32_t*>(&Qs[(row + 2) * PITCH + 2 * kd]) = pack_bf16(lo.z, hi.z);
+            *reinterpret_cast<uint32_t*>(&Qs[(row + 3) * PITCH + 2 * kd]) = pack_bf16(lo.w, hi.w);
+        }
+    };
+    const int arow = (wi * WI + (l & 31)) * PITCH + (l >> 5) * 8, brow = (wj * WJ + (l & 31)) * PITCH + (l >> 5) * 8;
+    auto mma_stage = [&](int buf) {
+        const uint16_t* Ps = lds + buf * BUF;
+        const uint16_t* Qs = Ps + BI * PITCH;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[MI], bf[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&Ps[arow + 32 * i * PITCH + ks * 16]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Qs[brow + 32 * j * PITCH + ks * 16]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    load_stage(rp[0], rq[0], rk[0]);
+    load_stage(rp[1], rq[1], rk[1]);
+    load_stage(rp[2], rq[2], rk[2]);
+    store_stage(0, rp[0], rq[0], rk[0]);
+    __syncthreads();
+    for (int s0 = 0; s0 < nsteps; s0 += 3) {       // stages past the slice are all-zero (m >= mend): up to two idle steps
+        load_stage(rp[0], rq[0], rk[0]);
+        mma_stage(s0 & 1);
+        store_stage((s0 + 1) & 1, rp[1], rq[1], rk[1]);
+        __syncthreads();
+        load_stage(rp[1], rq[1], rk[1]);
+        mma_stage((s0 + 1) & 1);
+        store_stage(s0 & 1, rp[2], rq[2], rk[2]);
+        __syncthreads();
+        load_stage(rp[2], rq[2], rk[2]);
+        mma_stage(s0 & 1);
+        store_stage((s0 + 1) & 1, rp[0], rq[0], rk[0]);
+        __syncthreads();
+    }
+
+    float* out = a.dW + (size_t)tap * a.Ci * a.Cj;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = i0 + wi * WI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+            if (row >= a.Ci) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                int col = j0 + wj * WJ + j * 32 + (l & 31);
+                if (col >= a.Cj) continue;
+                atomicAdd(out + (size_t)row * a.Cj + col, acc[i][j][r]);
+            }
+        }
+}
+
+template <int BI, int BJ>
+void launch_fast(const WgradArgs& a, int dw_sh, int dhw_sh, hipStream_t st) {
+    dim3 grid((a.Ci + BI - 1) / BI, (a.Cj + BJ - 1) / BJ, a.KH * a.KW * a.splits);
+    hipLaunchKernelGGL((wgrad_fast_kernel<BI, BJ>), grid, dim3(256), 0, st, a, dw_sh, dhw_sh);
+}
+
 // out[c] += sum_m x[m*ld + c]
 __global__ __launch_bounds__(256) void colsum_kernel(int M, int C, const float* __restrict__ x, int ld,
                                                      float* __restrict__ out, int rows_per_block) {
@@ -244,6 +408,17 @@ extern "C" int mi_conv_wgrad(const MiWgradDesc* d, const float* P, const float* 
     a.chunk = (int)(((a.Mtot + splits - 1) / splits + 31) / 32 * 32);
     a.splits = (a.Mtot + a.chunk - 1) / a.chunk;
     hipStream_t st = (hipStream_t)stream;
+    {   // aligned bf16 layers on a power-of-two dense grid: the straight-line ring kernel
+        static const int allow_fast = [] { const char* e = getenv("MI_WGRAD_FAST"); return e ? atoi(e) : 1; }();
+        auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+        const int dw_sh = lg(d->DW), dhw_sh = lg(d->DH * d->DW);
+        if (allow_fast && d->mode == 1 && a.vec && dw_sh >= 0 && dhw_sh >= 0 && d->Ci % 4 == 0 && d->Cj % 4 == 0 && d->I1 % 4 == 0 &&
+            d->Ci >= 4 && d->Cj >= 4) {
+            if (big) launch_fast<128, 128>(a, dw_sh, dhw_sh, st); else launch_fast<64, 64>(a, dw_sh, dhw_sh, st);
+            MI_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (d->mode == 1) { if (big) launch<1, 128, 128>(a, st); else launch<1, 64, 64>(a, st); }
     else              { if (big) launch<0, 128, 128>(a, st); else launch<0, 64, 64>(a, st); }
     MI_LAUNCH_CHECK();

@@ -439,9 +439,9 @@ class Unet(nn.Module):
             w = sv[pre + "weight"]
             kh, kw, ci, co = w.shape
             if x2 is None and residual is None and stride == 1 and not transposed_conv:
-                if k == 3 and ci <= 4 and co % 4 == 0 and 256 % (co // 4) == 0:        # image -> features
-                    return K.conv3x3_small_cin_fwd(inp, w, sv[pre + "bias"] if bias else None, co)
-                if k == 1 and co <= 4 and ci % 4 == 0:                                  # features -> image
+                if K.small_cin_supported(k, ci, co):                                    # image -> features
+                    return K.conv_small_cin_fwd(inp, w, sv[pre + "bias"] if bias else None, co, k)
+                if k == 1 and K.small_cout_supported(0, ci, co):                        # features -> image
                     return K.conv1x1_small_cout(0, inp, w, bias=sv[pre + "bias"] if bias else None, Cs=co)
             if mode == K.MODE_BF16 and k in (1, 3) and stride == 1 and not transposed_conv:
                 y = K.conv3x3_bf16w(inp, wf_sh[offs[pre + "weight"]:], K=ci, Nc=co, flip=False, ksize=k, x2=x2,
@@ -550,7 +550,8 @@ class Unet(nn.Module):
             kh, kw, ci, co = w.shape
             ih, iw = inp.shape[1], inp.shape[2]
             oh, ow = dy.shape[1], dy.shape[2]
-            if x2 is None and stride == 1 and not transposed_conv and k == 1 and co <= 4 and ci % 4 == 0:
+            if (x2 is None and stride == 1 and not transposed_conv and k == 1 and K.small_cout_supported(2, ci, co)
+                    and K.small_cout_supported(1, ci, co)):
                 K.conv1x1_small_cout(2, inp, None, b=dy, out=gv[pre + "weight"])
                 if bias == "colsum":
                     K.colsum(dy, gv[pre + "bias"])
@@ -558,9 +559,9 @@ class Unet(nn.Module):
                     buf, acc = G.target(inp)
                     K.conv1x1_small_cout(1, dy, w, out=buf, accumulate=acc)
                 return
-            small_cin = x2 is None and stride == 1 and not transposed_conv and k == 3 and ci <= 4
+            small_cin = x2 is None and stride == 1 and not transposed_conv and K.small_cin_supported(k, ci, co, wgrad=True)
             if small_cin:
-                K.conv3x3_small_cin_wgrad(inp, dy, gv[pre + "weight"])
+                K.conv_small_cin_wgrad(inp, dy, gv[pre + "weight"], k)
             elif transposed_conv:   # dW[tap][ci][co] = sum over input pixels  x[j] * dy[gather(j, tap)]
                 K.conv_wgrad(inp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=False,
                              Ci=ci, Cj=co, grid_g=(oh, ow), grid_d=(ih, iw), mode=mode)

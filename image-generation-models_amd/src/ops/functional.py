@@ -133,20 +133,39 @@ def pack_weights_bf16(table_dev, nent, total_tiles, master, wd, wf):
           "mi_pack_weights_bf16")
 
 
-def conv3x3_small_cin_fwd(x, w, bias, Cout):
-    """Conv2d(Cin<=4, Cout, 3, padding=1) on an NHWC image tensor (first conv of the UNet)."""
+def small_cin_supported(ks, Cin, Cout, wgrad=False):
+    """The 3-channel-input kernels (mi_conv_small_cin_*): which (kernel size, Cin, Cout) they take."""
+    if ks not in (1, 3) or not 1 <= Cin <= 4:
+        return False
+    if wgrad:
+        return Cout in (64, 128, 256) and 3 * ks * ks * Cin * (Cout // 4) * 16 <= 48 * 1024
+    return Cout % 4 == 0 and Cout <= 1024 and 256 % (Cout // 4) == 0
+
+
+def conv_small_cin_fwd(x, w, bias, Cout, ks):
+    """Conv2d(Cin<=4, Cout, ks, padding=ks//2) on an NHWC image tensor (first convs of the UNet)."""
     _need_gpu(x)
     N, H, W, Cin = x.shape
     y = new_act(N, H, W, Cout, x)
-    check(load_library().mi_conv3x3_small_cin_fwd(N, H, W, Cin, Cout, _p(x), ld_of(x), _p(w), _p(bias), _p(y), ld_of(y), _stream()),
-          "mi_conv3x3_small_cin_fwd")
+    check(load_library().mi_conv_small_cin_fwd(ks, N, H, W, Cin, Cout, _p(x), ld_of(x), _p(w), _p(bias), _p(y), ld_of(y), _stream()),
+          "mi_conv_small_cin_fwd")
     return y
 
 
-def conv3x3_small_cin_wgrad(x, dy, dW):
+def conv_small_cin_wgrad(x, dy, dW, ks):
     N, H, W, Cin = x.shape
-    check(load_library().mi_conv3x3_small_cin_wgrad(N, H, W, Cin, dy.shape[3], _p(x), ld_of(x), _p(dy), ld_of(dy), _p(dW), _stream()),
-          "mi_conv3x3_small_cin_wgrad")
+    lib = load_library()
+    need = lib.mi_conv_small_wgrad_workspace(ks * ks * Cin * dy.shape[3])
+    ws = _workspace(x.device, need)
+    check(lib.mi_conv_small_cin_wgrad(ks, N, H, W, Cin, dy.shape[3], _p(x), ld_of(x), _p(dy), ld_of(dy), _p(dW), _p(ws), need, _stream()),
+          "mi_conv_small_cin_wgrad")
+
+
+def small_cout_supported(op, C, Cs):
+    """Conv2d(C, Cs<=4, 1) kernels (mi_conv1x1_small_cout): op 0 forward, 1 dgrad, 2 wgrad."""
+    if not 1 <= Cs <= 4 or C not in (32, 64, 128, 256):
+        return False
+    return C <= 128 if op == 0 else (C >= 64 if op == 2 else True)
 
 
 def conv1x1_small_cout(op, a, w, *, b=None, bias=None, out=None, Cs=None, accumulate=False):
@@ -163,8 +182,11 @@ def conv1x1_small_cout(op, a, w, *, b=None, bias=None, out=None, Cs=None, accumu
         Cs = a.shape[3]; C = out.shape[3]
     else:
         C, Cs = a.shape[3], b.shape[3]
-    check(load_library().mi_conv1x1_small_cout(op, M, C, Cs, _p(a), ld_of(a), _p(b), ld_of(b) if b is not None else 0, _p(w),
-                                               _p(bias), _p(out), ld_of(out) if out.dim() == 4 else Cs, int(accumulate), _stream()),
+    lib = load_library()
+    need = lib.mi_conv_small_wgrad_workspace(4 * C) if op == 2 else 0
+    ws = _workspace(a.device, need) if op == 2 else None
+    check(lib.mi_conv1x1_small_cout_ws(op, M, C, Cs, _p(a), ld_of(a), _p(b), ld_of(b) if b is not None else 0, _p(w),
+                                       _p(bias), _p(out), ld_of(out) if out.dim() == 4 else Cs, int(accumulate), _p(ws), need, _stream()),
           "mi_conv1x1_small_cout")
     return out
 

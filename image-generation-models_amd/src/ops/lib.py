@@ -50,6 +50,9 @@ SIGNATURES = {
     "mi_conv3x3_small_cin_fwd": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P],
     "mi_conv3x3_small_cin_wgrad": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P],
     "mi_conv1x1_small_cout": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
+    "mi_conv1x1_small_cout_ws": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P, _Z, _P],
+    "mi_conv_small_cin_fwd": [_I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P],
+    "mi_conv_small_cin_wgrad": [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _Z, _P],
     "mi_conv_wgrad": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P],
     "mi_conv3x3_wgrad": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P],
     "mi_conv3x3_wgrad_supported": [C.POINTER(MiWgradDesc)],
@@ -77,7 +80,8 @@ SIGNATURES = {
     "mi_scale_by_device_scalar": [_I, _I, _P, _I, _P, _P],
 }
 OTHER = {"mi_abi_version": ([], C.c_int), "mi_last_error": ([], C.c_char_p),
-         "mi_conv3x3_wgrad_workspace": ([C.POINTER(MiWgradDesc)], C.c_size_t)}
+         "mi_conv3x3_wgrad_workspace": ([C.POINTER(MiWgradDesc)], C.c_size_t),
+         "mi_conv_small_wgrad_workspace": ([_I], C.c_size_t)}
 ABI_VERSION = 1
 
 

@@ -100,16 +100,29 @@ int mi_pack_weights_bf16(int nent, const void* entries_dev, int total_tiles, con
                          void* wd_bf16, void* wf_bf16, void* stream);
 
 /* ---- the 3-channel ends of the UNet (fp32 VALU, bound by the wide tensor they stream) ------------
- * Conv2d(Cin<=4, Cout, 3, padding=1) forward and weight gradient (downs.0.0.block1, ddpm.py:116,208);
- * w / dW in the tap-major layout [3][3][Cin][Cout]. */
+ * Conv2d(Cin<=4, Cout, ks, padding=ks/2), ks = 3 (downs.0.0.block1, ddpm.py:116,208) or 1 (its res_conv,
+ * ddpm.py:134): forward and weight gradient; w / dW in the tap-major layout [ks][ks][Cin][Cout].
+ * Forward: Cout % 4 == 0 and Cout/4 divides 256.  Weight gradient: Cout in {64, 128, 256} ({64, 128} for ks = 3);
+ * with a workspace of mi_conv_small_wgrad_workspace(ks*ks*Cin*Cout) bytes the per-workgroup partial tiles are
+ * summed in a fixed order (deterministic), without one they are added with fp32 atomics. */
+int mi_conv_small_cin_fwd(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w,
+                          const float* bias, float* y, int ldy, void* stream);
+int mi_conv_small_cin_wgrad(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* dy,
+                            int lddy, float* dW, void* workspace, size_t ws_bytes, void* stream);
+size_t mi_conv_small_wgrad_workspace(int outputs);
+/* the 3x3 forms without workspace */
 int mi_conv3x3_small_cin_fwd(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w,
                              const float* bias, float* y, int ldy, void* stream);
 int mi_conv3x3_small_cin_wgrad(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* dy,
                                int lddy, float* dW, void* stream);
-/* Conv2d(C, Cs<=4, 1) (final_conv.1, ddpm.py:236), weights w[C][Cs].  op 0: y = x w + bias;
- * op 1: dx (+)= dy w^T; op 2: dW += x^T dy (a = x, b = dy). */
+/* Conv2d(C, Cs<=4, 1) (final_conv.1, ddpm.py:236), weights w[C][Cs], C in {32, 64, 128, 256}.  op 0: y = x w + bias
+ * (C <= 128); op 1: dx (+)= dy w^T; op 2: dW += x^T dy (a = x, b = dy; C >= 64; workspace of
+ * mi_conv_small_wgrad_workspace(4*C) bytes as above). */
 int mi_conv1x1_small_cout(int op, int M, int C, int Cs, const float* a, int lda, const float* b, int ldb,
                           const float* w, const float* bias, float* out, int ldo, int accumulate, void* stream);
+int mi_conv1x1_small_cout_ws(int op, int M, int C, int Cs, const float* a, int lda, const float* b, int ldb,
+                             const float* w, const float* bias, float* out, int ldo, int accumulate,
+                             void* workspace, size_t ws_bytes, void* stream);
 
 /* ---- weight gradient (aten::convolution_backward, weight part) -----------------------
  *   dW[ky][kx][i][j] += sum_{n,y,x} P[n,py,px,i] * Q[n,qy,qx,j]

@@ -481,23 +481,29 @@ def test_conv1x1_wgrad_fast(K, cfg):
     assert rel_err(w_from_storage(dW.view(1, 1, Ci, Co)), ref) < 2e-5
 
 
-def test_small_channel_ends(K):
-    """First conv Conv2d(3, C, 3, padding=1) and final Conv2d(C, 3, 1) (ddpm.py:208,236): fwd / dgrad / wgrad."""
+@pytest.mark.parametrize("cfg", [dict(N=3, H=8, C=64, ks=3), dict(N=8, H=16, C=128, ks=3), dict(N=4, H=8, C=128, ks=1),
+                                 dict(N=2, H=7, C=64, ks=3), dict(N=5, H=8, C=256, ks=1)])
+def test_small_channel_ends(K, cfg):
+    """First convs Conv2d(3, C, 3, padding=1) / res_conv Conv2d(3, C, 1) and final Conv2d(C, 3, 1) (ddpm.py:134,208,236):
+    fwd / dgrad / wgrad; H = 7 exercises the non-power-of-two pixel decode."""
     g = torch.Generator().manual_seed(43)
-    N, H, C = 3, 8, 64
+    N, H, C, ks = cfg["N"], cfg["H"], cfg["C"], cfg["ks"]
     x = torch.randn(N, 3, H, H, generator=g, dtype=torch.float64)
-    w = torch.randn(C, 3, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(C, 3, ks, ks, generator=g, dtype=torch.float64, requires_grad=True)
     b = torch.randn(C, generator=g, dtype=torch.float64)
-    y = F.conv2d(x, w, b, padding=1)
+    y = F.conv2d(x, w, b, padding=ks // 2)
     dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
     y.backward(dy)
     xg = to_nhwc_gpu(x.float())
-    yg = K.conv3x3_small_cin_fwd(xg, conv_w_storage(w.detach()), b.float().to(DEV), C)
-    dW = torch.zeros(9 * 3 * C, device=DEV)
-    K.conv3x3_small_cin_wgrad(xg, to_nhwc_gpu(dy.float()), dW)
+    assert K.small_cin_supported(ks, 3, C) and K.small_cin_supported(ks, 3, C, wgrad=True)
+    yg = K.conv_small_cin_fwd(xg, conv_w_storage(w.detach()), b.float().to(DEV), C, ks)
+    dW = torch.full((ks * ks * 3 * C,), 0.5, device=DEV)          # the kernel accumulates
+    K.conv_small_cin_wgrad(xg, to_nhwc_gpu(dy.float()), dW, ks)
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(yg), y) < 1e-5
-    assert rel_err(w_from_storage(dW.view(3, 3, 3, C)), w.grad) < 1e-5
+    assert rel_err(w_from_storage((dW - 0.5).view(ks, ks, 3, C)), w.grad) < 1e-5
+    if C > 128:
+        return
     # final conv
     h = torch.randn(N, C, H, H, generator=g, dtype=torch.float64, requires_grad=True)
     wf = torch.randn(3, C, 1, 1, generator=g, dtype=torch.float64, requires_grad=True)
