@@ -51,6 +51,21 @@ __device__ __forceinline__ float mish_f(float x) {
     float w = e * (e + 2.f);
     return x * (w / (w + 2.f));
 }
+// The same two functions for tensors that are stored as bf16 anyway (8 mantissa bits): approximate reciprocal
+// (v_rcp_f32, 1 ulp) instead of IEEE division and no branch -- about 40 % fewer VALU cycles per element, which is
+// what bounds the GroupNorm kernels.  exp is clamped at 20: tanh(softplus(x)) == 1 in fp32 beyond that.
+__device__ __forceinline__ float mish_fast_f(float x) {
+    const float e = __expf(fminf(x, 20.f));
+    const float w = e * (e + 2.f);
+    return x * w * __builtin_amdgcn_rcpf(w + 2.f);
+}
+__device__ __forceinline__ float mish_grad_fast_f(float x) {
+    const float e = __expf(fminf(x, 20.f));
+    const float w = e * (e + 2.f);
+    const float r = __builtin_amdgcn_rcpf((w + 2.f) * (1.f + e));       // one reciprocal for tanh and sigmoid
+    const float th = w * (1.f + e) * r, sg = e * (w + 2.f) * r;
+    return th + x * (1.f - th * th) * sg;
+}
 // d mish / dx = tanh(sp) + x * (1 - tanh(sp)^2) * sigmoid(x)   (sigmoid -> 1 above threshold)
 __device__ __forceinline__ float mish_grad_f(float x) {
     if (x > 20.f) { float th = tanhf(x); return th + x * (1.f - th * th); }

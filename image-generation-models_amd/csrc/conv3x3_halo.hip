@@ -500,7 +500,9 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
 // per M tile); slices are summed with row-coalesced fp32 atomics, so the output must be fp32.
 static int halo_splitk(const MiConvDesc* d, int BM, int* th, int* ti) {
     if (d->KH != 3 || BM >= 256 || d->K % 64 || d->K1 % 64 || !(d->accumulate || d->ldy == d->Nc)) return 0;
-    static const int allow = [] { const char* e = getenv("MI_HALO_SPLITK"); return e ? atoi(e) : 1; }();
+    // off by default: since the staging ring runs with exact waits the 64-pixel tiles (2-3 workgroups per CU) are
+    // faster than split-K for every cfg-2 / cfg-3 layer (measured 14.17k vs 13.95k images/s); MI_HALO_SPLITK=1 enables it
+    static const int allow = [] { const char* e = getenv("MI_HALO_SPLITK"); return e ? atoi(e) : 0; }();
     const long b256 = ((long)d->N * d->OH * d->OW + 255) / 256 * ((d->Nc + 127) / 128);
     const int chunks = d->K / 64;
     if (!(allow && chunks >= 8 && halo_geom(d, 256, th, ti) && b256 >= 32)) return 0;   // measured: loses for K < 512

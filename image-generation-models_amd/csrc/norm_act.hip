@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
     auto apply = [&](V<VEC> q, int p) {
         V<VEC> o;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o.v[j] = mish_f(q.v[j] * ga[j] + be[j]) + tb[j];
+        for (int j = 0; j < VEC; ++j) o.v[j] = (X16 ? mish_fast_f(q.v[j] * ga[j] + be[j]) : mish_f(q.v[j] * ga[j] + be[j])) + tb[j];
         if (rb) {
             V<VEC> r = V<VEC>::load(rb + (size_t)p * a.ldr);
 #pragma unroll
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
         for (int j = 0; j < VEC; ++j) {
             float h = (q.v[j] - mean) * rstd;
             float z = h * ga[j] + be[j];
-            float dzz = d.v[j] * mish_grad_f(z);
+            float dzz = d.v[j] * (X16 ? mish_grad_fast_f(z) : mish_grad_f(z));
             xh.v[j] = h; dz.v[j] = dzz;
             sA[j] += dzz; sD[j] += dzz * h; sT[j] += d.v[j]; sB[j] += h;
         }
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 xh.v[j] = (q.v[j] - mean) * rstd;
-                dz.v[j] = d.v[j] * mish_grad_f(xh.v[j] * ga[j] + be[j]);
+                dz.v[j] = d.v[j] * (X16 ? mish_grad_fast_f(xh.v[j] * ga[j] + be[j]) : mish_grad_f(xh.v[j] * ga[j] + be[j]));
             }
             pass2(p, xh, dz);
         }
