@@ -529,7 +529,7 @@ extern "C" int mi_conv3x3_bf16w(const MiConvDesc* d, const float* x, const float
 // with bit 1 set small-M layers use the 64/128-pixel tiles instead.
 extern "C" int mi_conv3x3_bf16w_io(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16,
                                    const float* bias, const float* residual, void* y, int io, void* stream) {
-    if (!d || d->KH != 3 || (io & ~3)) return mi_set_error(-1, "mi_conv3x3_bf16w_io: 3x3 only, io in 0..3");
+    if (!d || (d->KH != 3 && d->KH != 1) || (io & ~3)) return mi_set_error(-1, "mi_conv3x3_bf16w_io: 3x3 or 1x1, io in 0..3");
     return halo_dispatch(d, (const float*)x, (const float*)x2, w_nk_bf16, bias, residual, (float*)y, io, stream);
 }
 
@@ -588,9 +588,12 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
     }
     if (d->KH == 1) {
         a.TH = 1; a.TI = 1; a.tiles_per_img = 1; a.HP = BM;
-        if (BM == 256)      launch_halo<256, 32, 1>(a, st);
-        else if (BM == 128) launch_halo<128, 32, 1>(a, st);
-        else                launch_halo<64, 32, 1>(a, st);
+#define MI_HALO1_GO(IOV) \
+    do { if (BM == 256) launch_halo<256, 32, 1, false, IOV>(a, st); \
+         else if (BM == 128) launch_halo<128, 32, 1, false, IOV>(a, st); \
+         else launch_halo<64, 32, 1, false, IOV>(a, st); } while (0)
+        switch (io) { case 0: MI_HALO1_GO(0); break; case 1: MI_HALO1_GO(1); break; case 2: MI_HALO1_GO(2); break; default: MI_HALO1_GO(3); break; }
+#undef MI_HALO1_GO
         MI_LAUNCH_CHECK();
         return 0;
     }

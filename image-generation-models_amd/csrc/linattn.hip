@@ -19,11 +19,29 @@ struct AttnArgs {
     int B, n, heads, ldq;        // ldq = 3*heads*32
 };
 
+// element access for the activation tensors (qkv, out, dout, dqkv): fp32, or bf16 when T16 (offsets count elements)
+template <bool T16> __device__ __forceinline__ float ldx(const float* base, size_t i) {
+    if constexpr (T16) return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(base)[i] << 16);
+    else return base[i];
+}
+template <bool T16> __device__ __forceinline__ void stx(float* base, size_t i, float v) {
+    if constexpr (T16) reinterpret_cast<uint16_t*>(base)[i] = (uint16_t)(pack_bf16(v, 0.f) & 0xffffu);
+    else base[i] = v;
+}
+template <bool T16> __device__ __forceinline__ const float* offs(const float* base, size_t i) {
+    if constexpr (T16) return reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(base) + i);
+    else return base + i;
+}
+template <bool T16> __device__ __forceinline__ float* offs(float* base, size_t i) {
+    if constexpr (T16) return reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(base) + i);
+    else return base + i;
+}
+
 // acc[r] of a 32x32 MFMA tile <-> (row, col): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
 __device__ __forceinline__ int tile_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // S[d][e] = sum_p f(A[p][d]) * Bm[p][e] over this block's pixels, waves split p, result in sm[32][33]
-template <bool EXP>
+template <bool EXP, bool T16>
 __device__ __forceinline__ void reduce_outer(const float* A, const float* Bm, int ldA, int ldB, int n,
                                              const float* kmax, float* sm, float* wsum, float* scratch) {
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
@@ -37,8 +55,8 @@ __device__ __forceinline__ void reduce_outer(const float* A, const float* Bm, in
         int p = p0 + kk;
         float av = 0.f, bv = 0.f;
         if (p < n) {
-            av = A[(size_t)p * ldA + i];
-            bv = Bm[(size_t)p * ldB + i];
+            av = ldx<T16>(A, (size_t)p * ldA + i);
+            bv = ldx<T16>(Bm, (size_t)p * ldB + i);
             if (EXP) { av = __expf(av - mx); ssum += av; }
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
@@ -64,23 +82,25 @@ __device__ __forceinline__ void reduce_outer(const float* A, const float* Bm, in
 
 // T[p][j] = sum_k A[p][k] * Bs[k][j] for one 32-pixel tile, A from global (row stride ldA), Bs from LDS
 // with element (k, j) at Bs[k*sk + j*sj].
+template <bool T16>
 __device__ __forceinline__ f32x16 tile_mm(const float* A, int ldA, int p0, int n, const float* Bs, int sk, int sj) {
     const int l = threadIdx.x & 63, i = l & 31, kk = l >> 5;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int p = p0 + i;
-    const float* ap = A + (size_t)(p < n ? p : 0) * ldA;
+    const size_t ap = (size_t)(p < n ? p : 0) * ldA;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         int k = 2 * s + kk;
-        float av = (p < n) ? ap[k] : 0.f;
+        float av = (p < n) ? ldx<T16>(A, ap + k) : 0.f;
         float bv = Bs[k * sk + i * sj];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
     return acc;
 }
 
+template <bool T16>     // T16: qkv and out are stored as bf16
 __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
     __shared__ float scratch[4 * 32 * 33];
     __shared__ float ctx_s[32 * 33];
@@ -88,15 +108,15 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int hid = a.heads * DH;
-    const float* q = a.qkv + (size_t)b * a.n * a.ldq + h * DH;
-    const float* k = q + hid;
-    const float* v = q + 2 * hid;
+    const float* q = offs<T16>(a.qkv, (size_t)b * a.n * a.ldq + h * DH);
+    const float* k = offs<T16>(q, hid);
+    const float* v = offs<T16>(q, 2 * hid);
 
     // column max of k over pixels
     {
         int d = t & 31, pr = t >> 5;
         float m = -INFINITY;
-        for (int p = pr; p < a.n; p += 8) m = fmaxf(m, k[(size_t)p * a.ldq + d]);
+        for (int p = pr; p < a.n; p += 8) m = fmaxf(m, ldx<T16>(k, (size_t)p * a.ldq + d));
         pmax[pr * 32 + d] = m;
         __syncthreads();
         if (t < 32) {
@@ -107,7 +127,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
         }
         __syncthreads();
     }
-    reduce_outer<true>(k, v, a.ldq, a.ldq, a.n, kmax_s, ctx_s, wsum, scratch);
+    reduce_outer<true, T16>(k, v, a.ldq, a.ldq, a.n, kmax_s, ctx_s, wsum, scratch);
     if (t < 32) ksum_s[t] = wsum[t] + wsum[32 + t] + wsum[64 + t] + wsum[96 + t];
     __syncthreads();
     float* ctx_g = a.ctx + (size_t)blockIdx.x * 32 * 32;
@@ -123,19 +143,20 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
     }
     __syncthreads();
     // out[p][e] = sum_d q[p][d] ctx[d][e]
-    float* o = a.out + (size_t)b * a.n * hid + h * DH;
+    float* o = offs<T16>(a.out, (size_t)b * a.n * hid + h * DH);
     for (int p0 = 32 * w; p0 < a.n; p0 += 128) {
-        f32x16 acc = tile_mm(q, a.ldq, p0, a.n, ctx_s, 33, 1);
+        f32x16 acc = tile_mm<T16>(q, a.ldq, p0, a.n, ctx_s, 33, 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int p = p0 + tile_row(r, l);
-            if (p < a.n) o[(size_t)p * hid + (l & 31)] = acc[r];
+            if (p < a.n) stx<T16>(o, (size_t)p * hid + (l & 31), acc[r]);
         }
     }
 }
 
 // Backward.  With P = softmax_p(k), ctx = P^T v (saved), r[d] = sum_e ctx[d,e] dctx[d,e]:
 //   dctx = q^T dout ; dq = dout ctx^T ; dv = P dctx ; dP = v dctx^T ; dk = P * (dP - r)
+template <bool T16>     // T16: qkv, dout and dqkv are stored as bf16
 __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
     __shared__ float scratch[4 * 32 * 33];
     __shared__ float ctx_s[32 * 33], dctx_s[32 * 33];
@@ -143,13 +164,13 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int hid = a.heads * DH;
-    const float* q = a.qkv + (size_t)b * a.n * a.ldq + h * DH;
-    const float* k = q + hid;
-    const float* v = q + 2 * hid;
-    const float* dout = a.dout + (size_t)b * a.n * hid + h * DH;
-    float* dq = a.dqkv + (size_t)b * a.n * a.ldq + h * DH;
-    float* dk = dq + hid;
-    float* dv = dq + 2 * hid;
+    const float* q = offs<T16>(a.qkv, (size_t)b * a.n * a.ldq + h * DH);
+    const float* k = offs<T16>(q, hid);
+    const float* v = offs<T16>(q, 2 * hid);
+    const float* dout = offs<T16>(a.dout, (size_t)b * a.n * hid + h * DH);
+    float* dq = offs<T16>(a.dqkv, (size_t)b * a.n * a.ldq + h * DH);
+    float* dk = offs<T16>(dq, hid);
+    float* dv = offs<T16>(dq, 2 * hid);
 
     const float* ctx_g = a.ctx + (size_t)blockIdx.x * 32 * 32;
     for (int idx = t; idx < 32 * 32; idx += 256) ctx_s[(idx >> 5) * 33 + (idx & 31)] = ctx_g[idx];
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
         const float* ks = a.kstat + (size_t)blockIdx.x * 64;
         kmax_s[t] = ks[2 * t]; kinv_s[t] = 1.0f / ks[2 * t + 1];
     }
-    reduce_outer<false>(q, dout, a.ldq, hid, a.n, nullptr, dctx_s, nullptr, scratch);   // syncs inside
+    reduce_outer<false, T16>(q, dout, a.ldq, hid, a.n, nullptr, dctx_s, nullptr, scratch);   // syncs inside
     if (t < 32) {
         float s = 0.f;
 #pragma unroll
@@ -170,14 +191,14 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
     for (int p0 = 32 * w; p0 < a.n; p0 += 128) {
         const int col = l & 31;
         // dq[p][d] = sum_e dout[p][e] ctx[d][e]      (B(k=e, j=d) = ctx_s[d*33+e])
-        f32x16 acc = tile_mm(dout, hid, p0, a.n, ctx_s, 1, 33);
+        f32x16 acc = tile_mm<T16>(dout, hid, p0, a.n, ctx_s, 1, 33);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < a.n) dq[(size_t)p * a.ldq + col] = acc[r]; }
+        for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < a.n) stx<T16>(dq, (size_t)p * a.ldq + col, acc[r]); }
         // P tile into LDS (rows = pixels) so it can serve as the A operand of dv
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = tile_row(r, l), p = p0 + row;
-            float pv = (p < a.n) ? __expf(k[(size_t)p * a.ldq + col] - kmax_s[col]) * kinv_s[col] : 0.f;
+            float pv = (p < a.n) ? __expf(ldx<T16>(k, (size_t)p * a.ldq + col) - kmax_s[col]) * kinv_s[col] : 0.f;
             pt[row * 33 + col] = pv;
         }
         // (wave-private LDS region: the wave's own ds_write -> ds_read ordering is enough)
@@ -193,37 +214,56 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
                 a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pt[i * 33 + kd], dctx_s[kd * 33 + i], a2, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < a.n) dv[(size_t)p * a.ldq + col] = a2[r]; }
+            for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < a.n) stx<T16>(dv, (size_t)p * a.ldq + col, a2[r]); }
         }
         // dP[p][d] = sum_e v[p][e] dctx[d][e]        (B(k=e, j=d) = dctx_s[d*33+e]) ; dk = P*(dP - r)
-        acc = tile_mm(v, a.ldq, p0, a.n, dctx_s, 1, 33);
+        acc = tile_mm<T16>(v, a.ldq, p0, a.n, dctx_s, 1, 33);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = tile_row(r, l), p = p0 + row;
-            if (p < a.n) dk[(size_t)p * a.ldq + col] = pt[row * 33 + col] * (acc[r] - r_s[col]);
+            if (p < a.n) stx<T16>(dk, (size_t)p * a.ldq + col, pt[row * 33 + col] * (acc[r] - r_s[col]));
         }
     }
 }
 
 }  // namespace
 
-extern "C" int mi_linattn_fwd(int B, int n, int heads, const float* qkv, float* out, float* ctx, float* kstat,
-                              void* stream) {
+static int linattn_fwd_go(int B, int n, int heads, const void* qkv, void* out, float* ctx, float* kstat, int b16, void* stream) {
     MI_REQUIRE(B > 0 && n > 0 && heads > 0 && qkv && out && ctx && kstat, "bad argument");
     AttnArgs a{};
-    a.qkv = qkv; a.out = out; a.ctx = ctx; a.kstat = kstat; a.B = B; a.n = n; a.heads = heads; a.ldq = 3 * heads * DH;
-    hipLaunchKernelGGL(linattn_fwd_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
+    a.qkv = (const float*)qkv; a.out = (float*)out; a.ctx = ctx; a.kstat = kstat; a.B = B; a.n = n; a.heads = heads; a.ldq = 3 * heads * DH;
+    if (b16) hipLaunchKernelGGL(linattn_fwd_kernel<true>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
+    else     hipLaunchKernelGGL(linattn_fwd_kernel<false>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+static int linattn_bwd_go(int B, int n, int heads, const void* qkv, const float* ctx, const float* kstat,
+                          const void* dout, void* dqkv, int b16, void* stream) {
+    MI_REQUIRE(B > 0 && n > 0 && heads > 0 && qkv && ctx && kstat && dout && dqkv, "bad argument");
+    AttnArgs a{};
+    a.qkv = (const float*)qkv; a.ctx = const_cast<float*>(ctx); a.kstat = const_cast<float*>(kstat); a.dout = (const float*)dout; a.dqkv = (float*)dqkv;
+    a.B = B; a.n = n; a.heads = heads; a.ldq = 3 * heads * DH;
+    if (b16) hipLaunchKernelGGL(linattn_bwd_kernel<true>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
+    else     hipLaunchKernelGGL(linattn_bwd_kernel<false>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
     MI_LAUNCH_CHECK();
     return 0;
 }
 
+extern "C" int mi_linattn_fwd(int B, int n, int heads, const float* qkv, float* out, float* ctx, float* kstat,
+                              void* stream) {
+    return linattn_fwd_go(B, n, heads, qkv, out, ctx, kstat, 0, stream);
+}
 extern "C" int mi_linattn_bwd(int B, int n, int heads, const float* qkv, const float* ctx, const float* kstat,
                               const float* dout, float* dqkv, void* stream) {
-    MI_REQUIRE(B > 0 && n > 0 && heads > 0 && qkv && ctx && kstat && dout && dqkv, "bad argument");
-    AttnArgs a{};
-    a.qkv = qkv; a.ctx = const_cast<float*>(ctx); a.kstat = const_cast<float*>(kstat); a.dout = dout; a.dqkv = dqkv;
-    a.B = B; a.n = n; a.heads = heads; a.ldq = 3 * heads * DH;
-    hipLaunchKernelGGL(linattn_bwd_kernel, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
-    MI_LAUNCH_CHECK();
-    return 0;
+    return linattn_bwd_go(B, n, heads, qkv, ctx, kstat, dout, dqkv, 0, stream);
+}
+// bf16 storage of the attention-internal activations: b16 != 0 -> qkv, out (forward) and qkv, dout, dqkv (backward)
+// are bf16 tensors; ctx / kstat and all arithmetic stay fp32.
+extern "C" int mi_linattn_fwd_io(int B, int n, int heads, const void* qkv, void* out, float* ctx, float* kstat, int b16,
+                                 void* stream) {
+    return linattn_fwd_go(B, n, heads, qkv, out, ctx, kstat, b16, stream);
+}
+extern "C" int mi_linattn_bwd_io(int B, int n, int heads, const void* qkv, const float* ctx, const float* kstat,
+                                 const void* dout, void* dqkv, int b16, void* stream) {
+    return linattn_bwd_go(B, n, heads, qkv, ctx, kstat, dout, dqkv, b16, stream);
 }

@@ -251,6 +251,7 @@ struct LnArgs {
 };
 constexpr int LN_MAXV = 4;
 
+template <bool Y16>      // Y16: y is written as bf16 (it only feeds the to_qkv 1x1 conv)
 __global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const LnArgs a) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nq = a.C / 4;
@@ -274,17 +275,16 @@ __global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const LnArgs a) {
         }
         const float var = wave_sum(s2) / (float)a.C;
         const float inv = 1.0f / (sqrtf(var) + a.eps);
-        float* yp = a.y + (size_t)m * a.ldy;
 #pragma unroll
         for (int k = 0; k < LN_MAXV; ++k) {
             int q = l + 64 * k;
             if (q < nq) {
                 float4 gg = *reinterpret_cast<const float4*>(a.g + 4 * q);
                 float4 bb = *reinterpret_cast<const float4*>(a.b + 4 * q);
-                float4 o;
-                o.x = (c[k].x - mean) * inv * gg.x + bb.x; o.y = (c[k].y - mean) * inv * gg.y + bb.y;
-                o.z = (c[k].z - mean) * inv * gg.z + bb.z; o.w = (c[k].w - mean) * inv * gg.w + bb.w;
-                *reinterpret_cast<float4*>(yp + 4 * q) = o;
+                V<4> o;
+                o.v[0] = (c[k].x - mean) * inv * gg.x + bb.x; o.v[1] = (c[k].y - mean) * inv * gg.y + bb.y;
+                o.v[2] = (c[k].z - mean) * inv * gg.z + bb.z; o.v[3] = (c[k].w - mean) * inv * gg.w + bb.w;
+                vstore<4, Y16>(a.y, (size_t)m * a.ldy + 4 * q, o);
             }
         }
     }
@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const LnArgs a) {
 
 // y = xc * inv * g + b,  inv = 1/(sqrt(var)+eps).  dx_i = inv*(dh_i - mean(dh)) - inv^2 * S * xc_i / (sigma*C),
 // dh = dy*g, S = sum dh*xc.
+template <bool DY16>     // DY16: dy (the gradient of the LayerNorm output) is stored as bf16
 __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
     __shared__ float red[2][4][1024];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -305,7 +306,6 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
     }
     for (int m = blockIdx.x * 4 + w; m < a.M; m += gridDim.x * 4) {
         const float* xp = a.x + (size_t)m * a.ldx;
-        const float* dp = a.dy + (size_t)m * a.lddy;
         float4 c[LN_MAXV], d[LN_MAXV];
         float s = 0.f;
 #pragma unroll
@@ -313,7 +313,8 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
             int q = l + 64 * k;
             if (q < nq) {
                 c[k] = *reinterpret_cast<const float4*>(xp + 4 * q);
-                d[k] = *reinterpret_cast<const float4*>(dp + 4 * q);
+                const V<4> dv = vload<4, DY16>(a.dy, (size_t)m * a.lddy + 4 * q);
+                d[k] = make_float4(dv.v[0], dv.v[1], dv.v[2], dv.v[3]);
                 s += c[k].x + c[k].y + c[k].z + c[k].w;
             }
         }
@@ -472,28 +473,53 @@ extern "C" int mi_gn_mish_bwd_io(const MiGnDesc* d, const void* x, const float* 
     return 0;
 }
 
+static int ln_fwd_go(int M, int C, const float* x, int ldx, const float* g, const float* b, float eps, void* yv, int ldy, int y16, void* stream);
 extern "C" int mi_chan_layernorm_fwd(int M, int C, const float* x, int ldx, const float* g, const float* b,
                                      float eps, float* y, int ldy, void* stream) {
+    return ln_fwd_go(M, C, x, ldx, g, b, eps, y, ldy, 0, stream);
+}
+// y16 != 0: y is a bf16 tensor (ldy counts elements)
+extern "C" int mi_chan_layernorm_fwd_io(int M, int C, const float* x, int ldx, const float* g, const float* b,
+                                        float eps, void* y, int ldy, int y16, void* stream) {
+    return ln_fwd_go(M, C, x, ldx, g, b, eps, y, ldy, y16, stream);
+}
+static int ln_fwd_go(int M, int C, const float* x, int ldx, const float* g, const float* b, float eps, void* yv, int ldy, int y16, void* stream) {
+    float* y = (float*)yv;
     MI_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0, "C must be a multiple of 4, <= 1024");
     MI_REQUIRE(x && g && b && y, "null argument");
     LnArgs a{};
     a.x = x; a.g = g; a.b = b; a.y = y; a.M = M; a.C = C; a.ldx = ldx; a.ldy = ldy; a.eps = eps;
     int blocks = (M + 3) / 4; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(chan_ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (y16) hipLaunchKernelGGL(chan_ln_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else     hipLaunchKernelGGL(chan_ln_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     MI_LAUNCH_CHECK();
     return 0;
 }
 
+static int ln_bwd_go(int M, int C, const float* x, int ldx, const float* g, float eps, const void* dyv, int lddy, float* dx, int lddx,
+                     int accumulate_dx, float* dg, float* db, int dy16, void* stream);
 extern "C" int mi_chan_layernorm_bwd(int M, int C, const float* x, int ldx, const float* g, float eps,
                                      const float* dy, int lddy, float* dx, int lddx, int accumulate_dx,
                                      float* dg, float* db, void* stream) {
+    return ln_bwd_go(M, C, x, ldx, g, eps, dy, lddy, dx, lddx, accumulate_dx, dg, db, 0, stream);
+}
+// dy16 != 0: dy is a bf16 tensor (lddy counts elements)
+extern "C" int mi_chan_layernorm_bwd_io(int M, int C, const float* x, int ldx, const float* g, float eps,
+                                        const void* dy, int lddy, float* dx, int lddx, int accumulate_dx,
+                                        float* dg, float* db, int dy16, void* stream) {
+    return ln_bwd_go(M, C, x, ldx, g, eps, dy, lddy, dx, lddx, accumulate_dx, dg, db, dy16, stream);
+}
+static int ln_bwd_go(int M, int C, const float* x, int ldx, const float* g, float eps, const void* dyv, int lddy, float* dx, int lddx,
+                     int accumulate_dx, float* dg, float* db, int dy16, void* stream) {
+    const float* dy = (const float*)dyv;
     MI_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "C must be a multiple of 4, <= 1024");
     MI_REQUIRE(x && g && dy && dx, "null argument");
     LnArgs a{};
     a.x = x; a.g = g; a.dy = dy; a.dx = dx; a.dg = dg; a.db = db; a.M = M; a.C = C; a.ldx = ldx; a.lddy = lddy;
     a.lddx = lddx; a.accumulate = accumulate_dx; a.eps = eps;
     int blocks = (M + 3) / 4; if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(chan_ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (dy16) hipLaunchKernelGGL(chan_ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else      hipLaunchKernelGGL(chan_ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     MI_LAUNCH_CHECK();
     return 0;
 }

@@ -359,7 +359,7 @@ extern "C" int mi_conv3x3_wgrad_bias(const MiWgradDesc* d, const float* P, const
 // bf16 activation storage: io bit 0 = P (and P2) are bf16 tensors, bit 1 = Q is bf16 (strides count elements). 3x3 only.
 extern "C" int mi_conv3x3_wgrad_io(const MiWgradDesc* d, const void* P, const void* P2, const void* Q, float* dW,
                                    float* dbias, void* workspace, size_t ws_bytes, int io, void* stream) {
-    if (!d || d->KH != 3 || (io & ~3)) return mi_set_error(-1, "mi_conv3x3_wgrad_io: 3x3 only, io in 0..3");
+    if (!d || (d->KH != 3 && d->KH != 1) || (io & ~3)) return mi_set_error(-1, "mi_conv3x3_wgrad_io: 3x3 or 1x1, io in 0..3");
     return w3_dispatch(d, (const float*)P, (const float*)P2, (const float*)Q, dW, dbias, workspace, ws_bytes, io, stream);
 }
 
@@ -409,6 +409,21 @@ static int w3_dispatch(const MiWgradDesc* d, const float* P, const float* P2, co
     } else if (KS == 3) {
         if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2, 3>), grid, dim3(256), lds, st, a);
         else      hipLaunchKernelGGL((wgrad3x3_kernel<1, 3>), grid, dim3(256), lds, st, a);
+    } else if (io) {
+        static bool once_io1 = [] {
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            return true;
+        }();
+        (void)once_io1;
+#define MI_W1_GO(IOV) do { if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2, 1, IOV>), grid, dim3(256), lds, st, a); \
+                           else hipLaunchKernelGGL((wgrad3x3_kernel<1, 1, IOV>), grid, dim3(256), lds, st, a); } while (0)
+        if (io == 1) MI_W1_GO(1); else if (io == 2) MI_W1_GO(2); else MI_W1_GO(3);
+#undef MI_W1_GO
     } else {
         if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2, 1>), grid, dim3(256), lds, st, a);
         else      hipLaunchKernelGGL((wgrad3x3_kernel<1, 1>), grid, dim3(256), lds, st, a);

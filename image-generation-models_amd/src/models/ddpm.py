@@ -484,8 +484,15 @@ class Unet(nn.Module):
 
         def attention(at, inp):
             pre = at["pre"]
-            ln = K.chan_layernorm_fwd(inp, sv[pre + "fn.norm.g"], sv[pre + "fn.norm.b"])
-            qkv = conv(ln, pre + "fn.fn.to_qkv.", 1, bias=False)
+            # bf16 storage of the attention-internal tensors (LayerNorm output, qkv, attention output and their
+            # gradients) when the 1x1 tile kernels take both projections; the residual stream stays fp32
+            c = inp.shape[3]
+            a16 = (mode == K.MODE_BF16 and self.block_storage in ("bf16", "auto") and B % 8 == 0
+                   and all(K.fast1x1_supported(B, inp.shape[1], inp.shape[2], c, 3 * _HEADS * _DHEAD))
+                   and all(K.fast1x1_supported(B, inp.shape[1], inp.shape[2], _HEADS * _DHEAD, c)))
+            dt = BF if a16 else torch.float32
+            ln = K.chan_layernorm_fwd(inp, sv[pre + "fn.norm.g"], sv[pre + "fn.norm.b"], out_dtype=dt)
+            qkv = conv(ln, pre + "fn.fn.to_qkv.", 1, bias=False, out_dtype=dt)
             ao, ctx, kstat = K.linattn_fwd(qkv, _HEADS)
             out = conv(ao, pre + "fn.fn.to_out.", 1, residual=inp)
             if record:

@@ -115,7 +115,6 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if io:
-        assert ksize == 3
         check(lib.mi_conv3x3_bf16w_io(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), io, _stream()),
               "mi_conv3x3_bf16w_io")
     else:
@@ -287,19 +286,19 @@ def gn_mish_bwd(x, stats, gamma, beta, dout, *, groups=8, eps=1e-5, dgamma=None,
     return dx
 
 
-def chan_layernorm_fwd(x, g, b, eps=1e-5):
+def chan_layernorm_fwd(x, g, b, eps=1e-5, out_dtype=torch.float32):
     _need_gpu(x)
     N, H, W, Cc = x.shape
-    y = new_act(N, H, W, Cc, x)
-    check(load_library().mi_chan_layernorm_fwd(N * H * W, Cc, _p(x), ld_of(x), _p(g), _p(b), eps, _p(y), ld_of(y),
-                                               _stream()), "mi_chan_layernorm_fwd")
+    y = new_act(N, H, W, Cc, x, out_dtype)
+    check(load_library().mi_chan_layernorm_fwd_io(N * H * W, Cc, _p(x), ld_of(x), _p(g), _p(b), eps, _p(y), ld_of(y), _b16(y),
+                                                  _stream()), "mi_chan_layernorm_fwd")
     return y
 
 
 def chan_layernorm_bwd(x, g, dy, dx, accumulate, dg, db, eps=1e-5):
     N, H, W, Cc = x.shape
-    check(load_library().mi_chan_layernorm_bwd(N * H * W, Cc, _p(x), ld_of(x), _p(g), eps, _p(dy), ld_of(dy), _p(dx),
-                                               ld_of(dx), int(accumulate), _p(dg), _p(db), _stream()),
+    check(load_library().mi_chan_layernorm_bwd_io(N * H * W, Cc, _p(x), ld_of(x), _p(g), eps, _p(dy), ld_of(dy), _p(dx),
+                                                  ld_of(dx), int(accumulate), _p(dg), _p(db), _b16(dy), _stream()),
           "mi_chan_layernorm_bwd")
 
 
@@ -308,18 +307,18 @@ def linattn_fwd(qkv, heads=4):
     _need_gpu(qkv)
     N, H, W, C3 = qkv.shape
     assert C3 == 3 * heads * 32 and qkv.is_contiguous()
-    out = new_act(N, H, W, heads * 32, qkv)
+    out = new_act(N, H, W, heads * 32, qkv, qkv.dtype)        # bf16 qkv -> bf16 output (attention-internal storage)
     ctx = torch.empty((N, heads, 32, 32), device=qkv.device, dtype=torch.float32)
     kstat = torch.empty((N, heads, 32, 2), device=qkv.device, dtype=torch.float32)
-    check(load_library().mi_linattn_fwd(N, H * W, heads, _p(qkv), _p(out), _p(ctx), _p(kstat), _stream()), "mi_linattn_fwd")
+    check(load_library().mi_linattn_fwd_io(N, H * W, heads, _p(qkv), _p(out), _p(ctx), _p(kstat), _b16(qkv), _stream()), "mi_linattn_fwd")
     return out, ctx, kstat
 
 
 def linattn_bwd(qkv, ctx, kstat, dout, heads=4):
     N, H, W, C3 = qkv.shape
-    assert dout.is_contiguous()
+    assert dout.is_contiguous() and dout.dtype == qkv.dtype
     dqkv = torch.empty_like(qkv)
-    check(load_library().mi_linattn_bwd(N, H * W, heads, _p(qkv), _p(ctx), _p(kstat), _p(dout), _p(dqkv), _stream()),
+    check(load_library().mi_linattn_bwd_io(N, H * W, heads, _p(qkv), _p(ctx), _p(kstat), _p(dout), _p(dqkv), _b16(qkv), _stream()),
           "mi_linattn_bwd")
     return dqkv
 
@@ -438,6 +437,19 @@ def fast3x3_supported(N, H, W, K, Nc, K1=None):
     dw = MiWgradDesc(N=N, GH=H, GW=W, DH=H, DW=W, Ci=K, Cj=Nc, KH=3, KW=3, stride=1, pad=1, gather_i=1, mode=MODE_BF16,
                      I1=K1 or K, ldp=4, ldp2=4, ldq=4)
     return bool(lib.mi_conv3x3_bf16w_supported(C.byref(dc))), bool(lib.mi_conv3x3_wgrad_supported(C.byref(dw)))
+
+
+def fast1x1_supported(N, H, W, K, Nc):
+    """(conv + dgrad via the LDS-tile kernel?, wgrad via the image-major kernel?) for a 1x1 layer in bf16 mode."""
+    lib = load_library()
+    ok = True
+    for k, n in ((K, Nc), (Nc, K)):             # forward and data gradient
+        dc = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=k, Nc=n, KH=1, KW=1, stride=1, pad=0, transposed=0, w_kn=0,
+                        mode=MODE_BF16, K1=k, ldx=8, ldx2=8, ldy=n, ldr=0, accumulate=0)
+        ok = ok and bool(lib.mi_conv3x3_bf16w_supported(C.byref(dc)))
+    dw = MiWgradDesc(N=N, GH=H, GW=W, DH=H, DW=W, Ci=K, Cj=Nc, KH=1, KW=1, stride=1, pad=0, gather_i=1, mode=MODE_BF16,
+                     I1=K, ldp=8, ldp2=8, ldq=8)
+    return ok, bool(lib.mi_conv3x3_wgrad_supported(C.byref(dw)))
 
 
 def conv3x3_uses_splitk(N, H, W, K, Nc, K1=None):

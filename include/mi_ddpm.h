@@ -89,7 +89,7 @@ int mi_conv3x3_bf16w_supported(const MiConvDesc* d);
 int mi_conv3x3_bf16w_uses_splitk(const MiConvDesc* d);
 /* bf16 activation storage for the ResnetBlock-internal tensors (conv output -> GroupNorm -> conv input and
  * their gradients): io bit 0 = x / x2 are bf16 tensors, bit 1 = y is written as bf16; strides count
- * elements.  3x3 only; with bit 1 the split-K variant (fp32 atomics) is not used. */
+ * elements.  3x3 and 1x1; with bit 1 the split-K variant (fp32 atomics) is not used. */
 int mi_conv3x3_bf16w_io(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16,
                         const float* bias, const float* residual, void* y, int io, void* stream);
 /* bf16 shadow copies of every conv weight of the flat fp32 parameter buffer (master layout
@@ -206,6 +206,12 @@ int mi_chan_layernorm_fwd(int M, int C, const float* x, int ldx, const float* g,
 int mi_chan_layernorm_bwd(int M, int C, const float* x, int ldx, const float* g, float eps,
                           const float* dy, int lddy, float* dx, int lddx, int accumulate_dx,
                           float* dg, float* db, void* stream);
+/* the same with the LayerNorm output (y16) / its gradient (dy16) stored as bf16; x and dx stay fp32 */
+int mi_chan_layernorm_fwd_io(int M, int C, const float* x, int ldx, const float* g, const float* b,
+                             float eps, void* y, int ldy, int y16, void* stream);
+int mi_chan_layernorm_bwd_io(int M, int C, const float* x, int ldx, const float* g, float eps,
+                             const void* dy, int lddy, float* dx, int lddx, int accumulate_dx,
+                             float* dg, float* db, int dy16, void* stream);
 
 /* ---- LinearAttention core (ddpm.py:157-165), heads x 32 channels -------------------------
  * qkv[b][p][3*heads*32] (q | k | v, head-major inside each), out[b][p][heads*32].
@@ -214,6 +220,12 @@ int mi_linattn_fwd(int B, int n, int heads, const float* qkv, float* out, float*
                    float* kstat, void* stream);
 int mi_linattn_bwd(int B, int n, int heads, const float* qkv, const float* ctx,
                    const float* kstat, const float* dout, float* dqkv, void* stream);
+/* bf16 storage of the attention-internal activations: b16 != 0 -> qkv and out (forward), qkv, dout and dqkv
+ * (backward) are bf16 tensors; ctx, kstat and all arithmetic stay fp32. */
+int mi_linattn_fwd_io(int B, int n, int heads, const void* qkv, void* out, float* ctx, float* kstat, int b16,
+                      void* stream);
+int mi_linattn_bwd_io(int B, int n, int heads, const void* qkv, const float* ctx, const float* kstat,
+                      const void* dout, void* dqkv, int b16, void* stream);
 
 /* ---- small element-wise pieces ---------------------------------------------------------------- */
 /* SinusoidalPosEmb (ddpm.py:52-59): out[b][dim] = [sin(t f_j) | cos(t f_j)] */

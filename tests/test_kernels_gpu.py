@@ -618,3 +618,50 @@ def test_bf16_block_storage_kernels(K):
         torch.cuda.synchronize()
         assert rel_err(w_from_storage(dW.view(3, 3, C, C)), wz.grad) < 2e-5, (P.dtype, Q.dtype)
         assert rel_err(db, (q(dyq) if Q.dtype == BF else dyq).sum((0, 2, 3))) < 1e-5     # bias sums use the stored values
+
+
+def test_bf16_attention_storage_kernels(K):
+    """bf16 storage of the attention-internal tensors: the 1x1 tile kernel / 1x1 weight gradient with bf16 operands,
+    LayerNorm writing bf16 / reading a bf16 gradient, and the LinearAttention core on bf16 qkv -- each against the
+    fp32-storage kernel on the same (bf16-rounded) values."""
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(53)
+    N, H, C, HID = 8, 8, 128, 128
+    q = lambda t: t.float().bfloat16().float()
+    # LayerNorm
+    x = to_nhwc_gpu(torch.randn(N, C, H, H, generator=g))
+    gam, bet = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    y32 = K.chan_layernorm_fwd(x, gam, bet)
+    y16 = K.chan_layernorm_fwd(x, gam, bet, out_dtype=BF)
+    assert y16.dtype == BF and rel_err(y16.float(), y32) < 4e-3
+    dy = to_nhwc_gpu(torch.randn(N, C, H, H, generator=g))
+    dy16 = dy.to(BF)
+    dx_a, dx_b = torch.empty_like(x), torch.empty_like(x)
+    dg_a, db_a, dg_b, db_b = (torch.zeros(C, device=DEV) for _ in range(4))
+    K.chan_layernorm_bwd(x, gam, dy16.float(), dx_a, False, dg_a, db_a)
+    K.chan_layernorm_bwd(x, gam, dy16, dx_b, False, dg_b, db_b)
+    assert rel_err(dx_b, dx_a) < 1e-6 and rel_err(dg_b, dg_a) < 1e-5 and rel_err(db_b, db_a) < 1e-5
+    # 1x1 conv C -> 3*HID with every storage combination, and its weight gradient
+    w = torch.randn(3 * HID, C, 1, 1, generator=g, dtype=torch.float64) / math.sqrt(C)
+    flat, wd, wf, offs = _pack(K, [conv_w_storage(w)])
+    ref = K.conv3x3_bf16w(q(x), wf, K=C, Nc=3 * HID, flip=False, ksize=1)
+    for xin, od in ((x.to(BF), BF), (x.to(BF), torch.float32), (q(x), BF)):
+        y = K.conv3x3_bf16w(xin, wf, K=C, Nc=3 * HID, flip=False, ksize=1, out_dtype=od)
+        assert y.dtype == od and rel_err(y.float(), ref) < (4e-3 if od == BF else 1e-6)
+    dq = to_nhwc_gpu(torch.randn(N, 3 * HID, H, H, generator=g))
+    dW_ref = torch.zeros(C * 3 * HID, device=DEV)
+    K.conv_wgrad(q(x), q(dq), dW_ref, kh=1, kw=1, stride=1, pad=0, gather_i=True, Ci=C, Cj=3 * HID, grid_g=(H, H), grid_d=(H, H), mode=1)
+    for P, Q in ((x.to(BF), dq.to(BF)), (x.to(BF), q(dq)), (q(x), dq.to(BF))):
+        dW = torch.zeros(C * 3 * HID, device=DEV)
+        K.conv_wgrad(P, Q, dW, kh=1, kw=1, stride=1, pad=0, gather_i=True, Ci=C, Cj=3 * HID, grid_g=(H, H), grid_d=(H, H), mode=1)
+        assert rel_err(dW, dW_ref) < 2e-5, (P.dtype, Q.dtype)
+    # LinearAttention core
+    qkv = to_nhwc_gpu(torch.randn(N, 3 * HID, H, H, generator=g))
+    qkv16 = qkv.to(BF)
+    o32, ctx32, ks32 = K.linattn_fwd(qkv16.float())
+    o16, ctx16, ks16 = K.linattn_fwd(qkv16)
+    assert o16.dtype == BF and rel_err(ctx16, ctx32) < 1e-6 and rel_err(o16.float(), o32) < 4e-3
+    do = to_nhwc_gpu(torch.randn(N, HID, H, H, generator=g)).to(BF)
+    d32 = K.linattn_bwd(qkv16.float(), ctx32, ks32, do.float())
+    d16 = K.linattn_bwd(qkv16, ctx16, ks16, do)
+    assert d16.dtype == BF and rel_err(d16.float(), d32) < 4e-3
