@@ -81,19 +81,37 @@ __device__ __forceinline__ void reduce_outer(const float* A, const float* Bm, in
 }
 
 // T[p][j] = sum_k A[p][k] * Bs[k][j] for one 32-pixel tile, A from global (row stride ldA), Bs from LDS
-// with element (k, j) at Bs[k*sk + j*sj].
+// with element (k, j) at Bs[k*sk + j*sj].  The 32x32 A tile is fetched with coalesced 16-byte (bf16: 8-byte) loads --
+// 8 lanes per pixel row -- into the wave-private LDS area `stage` ([32][33] floats), from where the MFMA operand
+// column (one pixel row per lane) is read conflict-free; a row-per-lane global read would touch 32 lines per load.
 template <bool T16>
-__device__ __forceinline__ f32x16 tile_mm(const float* A, int ldA, int p0, int n, const float* Bs, int sk, int sj) {
+__device__ __forceinline__ f32x16 tile_mm(const float* A, int ldA, int p0, int n, const float* Bs, int sk, int sj, float* stage) {
     const int l = threadIdx.x & 63, i = l & 31, kk = l >> 5;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int p = p0 + i;
-    const size_t ap = (size_t)(p < n ? p : 0) * ldA;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (l >> 3) + 8 * j, c4 = (l & 7) * 4, p = p0 + row;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (p < n) {
+            if constexpr (T16) {
+                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(A) + (size_t)p * ldA + c4);
+                v0 = __uint_as_float(u.x << 16); v1 = __uint_as_float(u.x & 0xffff0000u);
+                v2 = __uint_as_float(u.y << 16); v3 = __uint_as_float(u.y & 0xffff0000u);
+            } else {
+                const float4 u = *reinterpret_cast<const float4*>(A + (size_t)p * ldA + c4);
+                v0 = u.x; v1 = u.y; v2 = u.z; v3 = u.w;
+            }
+        }
+        float* sp = stage + row * 33 + c4;
+        sp[0] = v0; sp[1] = v1; sp[2] = v2; sp[3] = v3;
+    }
+    // (wave-private LDS region: the wave's own ds_write -> ds_read ordering is enough)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         int k = 2 * s + kk;
-        float av = (p < n) ? ldx<T16>(A, ap + k) : 0.f;
+        float av = stage[i * 33 + k];
         float bv = Bs[k * sk + i * sj];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
@@ -145,7 +163,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
     // out[p][e] = sum_d q[p][d] ctx[d][e]
     float* o = offs<T16>(a.out, (size_t)b * a.n * hid + h * DH);
     for (int p0 = 32 * w; p0 < a.n; p0 += 128) {
-        f32x16 acc = tile_mm<T16>(q, a.ldq, p0, a.n, ctx_s, 33, 1);
+        f32x16 acc = tile_mm<T16>(q, a.ldq, p0, a.n, ctx_s, 33, 1, scratch + w * (32 * 33));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int p = p0 + tile_row(r, l);
@@ -160,6 +178,7 @@ template <bool T16>     // T16: qkv, dout and dqkv are stored as bf16
 __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
     __shared__ float scratch[4 * 32 * 33];
     __shared__ float ctx_s[32 * 33], dctx_s[32 * 33];
+    __shared__ float stage_s[4 * 32 * 33];
     __shared__ float kmax_s[32], kinv_s[32], r_s[32];
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
@@ -188,10 +207,11 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
     __syncthreads();
 
     float* pt = scratch + w * (32 * 33);        // this wave's P tile [pixel][d]
+    float* stg = stage_s + w * (32 * 33);       // this wave's operand staging tile
     for (int p0 = 32 * w; p0 < a.n; p0 += 128) {
         const int col = l & 31;
         // dq[p][d] = sum_e dout[p][e] ctx[d][e]      (B(k=e, j=d) = ctx_s[d*33+e])
-        f32x16 acc = tile_mm<T16>(dout, hid, p0, a.n, ctx_s, 1, 33);
+        f32x16 acc = tile_mm<T16>(dout, hid, p0, a.n, ctx_s, 1, 33, stg);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < a.n) stx<T16>(dq, (size_t)p * a.ldq + col, acc[r]); }
         // P tile into LDS (rows = pixels) so it can serve as the A operand of dv
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
             for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < a.n) stx<T16>(dv, (size_t)p * a.ldq + col, a2[r]); }
         }
         // dP[p][d] = sum_e v[p][e] dctx[d][e]        (B(k=e, j=d) = dctx_s[d*33+e]) ; dk = P*(dP - r)
-        acc = tile_mm<T16>(v, a.ldq, p0, a.n, dctx_s, 1, 33);
+        acc = tile_mm<T16>(v, a.ldq, p0, a.n, dctx_s, 1, 33, stg);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = tile_row(r, l), p = p0 + row;

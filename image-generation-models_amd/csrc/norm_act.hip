@@ -5,6 +5,7 @@
 // Replaces aten::native_group_norm(+backward), softplus/tanh/mul (Mish, ddpm.py:62-64), the
 // broadcast add at ddpm.py:140, the residual add at ddpm.py:143 and the 7-op LayerNorm
 // at ddpm.py:92-95.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -251,34 +252,45 @@ struct LnArgs {
 };
 constexpr int LN_MAXV = 4;
 
-template <bool Y16>      // Y16: y is written as bf16 (it only feeds the to_qkv 1x1 conv)
+// sum over the LPX lanes that share a pixel
+template <int LPX> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPX / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// LPX lanes per pixel (32 when C <= 128: two pixels per wave, else 64), up to MAXV float4 per lane
+template <bool Y16, int LPX, int MAXV>      // Y16: y is written as bf16 (it only feeds the to_qkv 1x1 conv)
 __global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const LnArgs a) {
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int PPW = 64 / LPX;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lp = l % LPX;
     const int nq = a.C / 4;
-    for (int m = blockIdx.x * 4 + w; m < a.M; m += gridDim.x * 4) {
+    for (int m0 = (blockIdx.x * 4 + w) * PPW; m0 < a.M; m0 += gridDim.x * 4 * PPW) {
+        const int m = min(m0 + l / LPX, a.M - 1);
+        const bool live = m0 + l / LPX < a.M;
         const float* xp = a.x + (size_t)m * a.ldx;
-        float4 c[LN_MAXV];
+        float4 c[MAXV];
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
-            int q = l + 64 * k;
+        for (int k = 0; k < MAXV; ++k) {
+            int q = lp + LPX * k;
             if (q < nq) { c[k] = *reinterpret_cast<const float4*>(xp + 4 * q); s += c[k].x + c[k].y + c[k].z + c[k].w; }
         }
-        const float mean = wave_sum(s) / (float)a.C;
+        const float mean = group_sum<LPX>(s) / (float)a.C;
         float s2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
-            if (l + 64 * k < nq) {
+        for (int k = 0; k < MAXV; ++k) {
+            if (lp + LPX * k < nq) {
                 float d0 = c[k].x - mean, d1 = c[k].y - mean, d2 = c[k].z - mean, d3 = c[k].w - mean;
                 s2 += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
             }
         }
-        const float var = wave_sum(s2) / (float)a.C;
+        const float var = group_sum<LPX>(s2) / (float)a.C;
         const float inv = 1.0f / (sqrtf(var) + a.eps);
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
-            int q = l + 64 * k;
-            if (q < nq) {
+        for (int k = 0; k < MAXV; ++k) {
+            int q = lp + LPX * k;
+            if (q < nq && live) {
                 float4 gg = *reinterpret_cast<const float4*>(a.g + 4 * q);
                 float4 bb = *reinterpret_cast<const float4*>(a.b + 4 * q);
                 V<4> o;
@@ -292,37 +304,40 @@ __global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const LnArgs a) {
 
 // y = xc * inv * g + b,  inv = 1/(sqrt(var)+eps).  dx_i = inv*(dh_i - mean(dh)) - inv^2 * S * xc_i / (sigma*C),
 // dh = dy*g, S = sum dh*xc.
-template <bool DY16>     // DY16: dy (the gradient of the LayerNorm output) is stored as bf16
+template <bool DY16, int LPX, int MAXV>     // DY16: dy (the gradient of the LayerNorm output) is stored as bf16
 __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
-    __shared__ float red[2][4][1024];
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int PPW = 64 / LPX;
+    __shared__ float red[2][4][LPX * MAXV * 4];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lp = l % LPX;
     const int nq = a.C / 4;
-    float4 ag[LN_MAXV], ab[LN_MAXV], gg[LN_MAXV];
+    float4 ag[MAXV], ab[MAXV], gg[MAXV];
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < MAXV; ++k) {
         ag[k] = ab[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        int q = l + 64 * k;
+        int q = lp + LPX * k;
         gg[k] = (q < nq) ? *reinterpret_cast<const float4*>(a.g + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int m = blockIdx.x * 4 + w; m < a.M; m += gridDim.x * 4) {
+    for (int m0 = (blockIdx.x * 4 + w) * PPW; m0 < a.M; m0 += gridDim.x * 4 * PPW) {
+        const int m = min(m0 + l / LPX, a.M - 1);
+        const float live = m0 + l / LPX < a.M ? 1.f : 0.f;
         const float* xp = a.x + (size_t)m * a.ldx;
-        float4 c[LN_MAXV], d[LN_MAXV];
+        float4 c[MAXV], d[MAXV];
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
-            int q = l + 64 * k;
+        for (int k = 0; k < MAXV; ++k) {
+            int q = lp + LPX * k;
             if (q < nq) {
                 c[k] = *reinterpret_cast<const float4*>(xp + 4 * q);
                 const V<4> dv = vload<4, DY16>(a.dy, (size_t)m * a.lddy + 4 * q);
-                d[k] = make_float4(dv.v[0], dv.v[1], dv.v[2], dv.v[3]);
+                d[k] = make_float4(dv.v[0] * live, dv.v[1] * live, dv.v[2] * live, dv.v[3] * live);
                 s += c[k].x + c[k].y + c[k].z + c[k].w;
             }
         }
-        const float mean = wave_sum(s) / (float)a.C;
+        const float mean = group_sum<LPX>(s) / (float)a.C;
         float s2 = 0.f, sh = 0.f, sS = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
-            if (l + 64 * k < nq) {
+        for (int k = 0; k < MAXV; ++k) {
+            if (lp + LPX * k < nq) {
                 c[k].x -= mean; c[k].y -= mean; c[k].z -= mean; c[k].w -= mean;
                 s2 += c[k].x * c[k].x + c[k].y * c[k].y + c[k].z * c[k].z + c[k].w * c[k].w;
                 float h0 = d[k].x * gg[k].x, h1 = d[k].y * gg[k].y, h2 = d[k].z * gg[k].z, h3 = d[k].w * gg[k].w;
@@ -330,38 +345,44 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
                 sS += h0 * c[k].x + h1 * c[k].y + h2 * c[k].z + h3 * c[k].w;
             }
         }
-        const float var = wave_sum(s2) / (float)a.C;
-        const float mh = wave_sum(sh) / (float)a.C;
-        const float S = wave_sum(sS);
+        const float var = group_sum<LPX>(s2) / (float)a.C;
+        const float mh = group_sum<LPX>(sh) / (float)a.C;
+        const float S = group_sum<LPX>(sS);
         const float sigma = sqrtf(var);
         const float inv = 1.0f / (sigma + a.eps);
         const float k2 = sigma > 0.f ? inv * inv * S / (sigma * (float)a.C) : 0.f;
         float* op = a.dx + (size_t)m * a.lddx;
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
-            int q = l + 64 * k;
+        for (int k = 0; k < MAXV; ++k) {
+            int q = lp + LPX * k;
             if (q < nq) {
                 float4 o;
                 o.x = inv * (d[k].x * gg[k].x - mh) - k2 * c[k].x;
                 o.y = inv * (d[k].y * gg[k].y - mh) - k2 * c[k].y;
                 o.z = inv * (d[k].z * gg[k].z - mh) - k2 * c[k].z;
                 o.w = inv * (d[k].w * gg[k].w - mh) - k2 * c[k].w;
-                if (a.accumulate) {
-                    float4 prev = *reinterpret_cast<const float4*>(op + 4 * q);
-                    o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
+                if (live != 0.f) {
+                    if (a.accumulate) {
+                        float4 prev = *reinterpret_cast<const float4*>(op + 4 * q);
+                        o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
+                    }
+                    *reinterpret_cast<float4*>(op + 4 * q) = o;
                 }
-                *reinterpret_cast<float4*>(op + 4 * q) = o;
                 ag[k].x += d[k].x * c[k].x * inv; ag[k].y += d[k].y * c[k].y * inv;
                 ag[k].z += d[k].z * c[k].z * inv; ag[k].w += d[k].w * c[k].w * inv;
                 ab[k].x += d[k].x; ab[k].y += d[k].y; ab[k].z += d[k].z; ab[k].w += d[k].w;
             }
         }
     }
-    // combine the 4 waves' per-channel partials, one atomic per channel per block
+    // combine the pixel halves of a wave, then the 4 waves' per-channel partials: one atomic per channel per block
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
-        int q = l + 64 * k;
-        if (q < nq) {
+    for (int k = 0; k < MAXV; ++k) {
+        if constexpr (PPW == 2) {
+            ag[k].x += __shfl_xor(ag[k].x, 32, 64); ag[k].y += __shfl_xor(ag[k].y, 32, 64); ag[k].z += __shfl_xor(ag[k].z, 32, 64); ag[k].w += __shfl_xor(ag[k].w, 32, 64);
+            ab[k].x += __shfl_xor(ab[k].x, 32, 64); ab[k].y += __shfl_xor(ab[k].y, 32, 64); ab[k].z += __shfl_xor(ab[k].z, 32, 64); ab[k].w += __shfl_xor(ab[k].w, 32, 64);
+        }
+        int q = lp + LPX * k;
+        if (q < nq && l < LPX) {
             red[0][w][4 * q + 0] = ag[k].x; red[0][w][4 * q + 1] = ag[k].y; red[0][w][4 * q + 2] = ag[k].z; red[0][w][4 * q + 3] = ag[k].w;
             red[1][w][4 * q + 0] = ab[k].x; red[1][w][4 * q + 1] = ab[k].y; red[1][w][4 * q + 2] = ab[k].z; red[1][w][4 * q + 3] = ab[k].w;
         }
@@ -489,9 +510,13 @@ static int ln_fwd_go(int M, int C, const float* x, int ldx, const float* g, cons
     MI_REQUIRE(x && g && b && y, "null argument");
     LnArgs a{};
     a.x = x; a.g = g; a.b = b; a.y = y; a.M = M; a.C = C; a.ldx = ldx; a.ldy = ldy; a.eps = eps;
-    int blocks = (M + 3) / 4; if (blocks > 4096) blocks = 4096;
-    if (y16) hipLaunchKernelGGL(chan_ln_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    else     hipLaunchKernelGGL(chan_ln_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    const bool half = C <= 128;                       // two pixels per wave
+    int blocks = (M + (half ? 7 : 3)) / (half ? 8 : 4); if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (half) { if (y16) hipLaunchKernelGGL((chan_ln_fwd_kernel<true, 32, 1>), dim3(blocks), dim3(256), 0, st, a);
+                else     hipLaunchKernelGGL((chan_ln_fwd_kernel<false, 32, 1>), dim3(blocks), dim3(256), 0, st, a); }
+    else      { if (y16) hipLaunchKernelGGL((chan_ln_fwd_kernel<true, 64, 4>), dim3(blocks), dim3(256), 0, st, a);
+                else     hipLaunchKernelGGL((chan_ln_fwd_kernel<false, 64, 4>), dim3(blocks), dim3(256), 0, st, a); }
     MI_LAUNCH_CHECK();
     return 0;
 }
@@ -517,9 +542,16 @@ static int ln_bwd_go(int M, int C, const float* x, int ldx, const float* g, floa
     LnArgs a{};
     a.x = x; a.g = g; a.dy = dy; a.dx = dx; a.dg = dg; a.db = db; a.M = M; a.C = C; a.ldx = ldx; a.lddy = lddy;
     a.lddx = lddx; a.accumulate = accumulate_dx; a.eps = eps;
-    int blocks = (M + 3) / 4; if (blocks > 1024) blocks = 1024;
-    if (dy16) hipLaunchKernelGGL(chan_ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    else      hipLaunchKernelGGL(chan_ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    const bool half = C <= 128;                       // two pixels per wave
+    // every workgroup ends with 2*C atomics on the same C addresses: fewer, longer-running workgroups for wide layers
+    static const int capenv = [] { const char* e = getenv("MI_LN_BLOCKS"); return e ? atoi(e) : 0; }();
+    int cap = capenv ? capenv : 512;            // measured best of 256..2048 on the cfg-2 shapes
+    int blocks = (M + (half ? 7 : 3)) / (half ? 8 : 4); if (blocks > cap) blocks = cap;
+    hipStream_t st = (hipStream_t)stream;
+    if (half) { if (dy16) hipLaunchKernelGGL((chan_ln_bwd_kernel<true, 32, 1>), dim3(blocks), dim3(256), 0, st, a);
+                else      hipLaunchKernelGGL((chan_ln_bwd_kernel<false, 32, 1>), dim3(blocks), dim3(256), 0, st, a); }
+    else      { if (dy16) hipLaunchKernelGGL((chan_ln_bwd_kernel<true, 64, 4>), dim3(blocks), dim3(256), 0, st, a);
+                else      hipLaunchKernelGGL((chan_ln_bwd_kernel<false, 64, 4>), dim3(blocks), dim3(256), 0, st, a); }
     MI_LAUNCH_CHECK();
     return 0;
 }
