@@ -612,6 +612,17 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
     return 0;
 }
 
+// Which instantiation conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES> mi_conv3x3_bf16w(_io) launches for a descriptor
+// (profiling attribution only): *sk = 1 for the split-K plan.
+extern "C" int mi_conv3x3_bf16w_tile(const MiConvDesc* d, int io, int* bm, int* ck, int* sk) {
+    MI_REQUIRE(d && bm && ck && sk, "null argument");
+    MI_REQUIRE(halo_ok(d, bm, ck), "descriptor not supported by the halo kernel");
+    int th, ti;
+    *sk = (!(io & 2) && halo_splitk(d, *bm, &th, &ti)) ? 1 : 0;
+    if (*sk) { *bm = 256; *ck = 64; }
+    return 0;
+}
+
 extern "C" int mi_conv3x3_bf16w_supported(const MiConvDesc* d) {
     int bm, ck;
     return (d && halo_ok(d, &bm, &ck)) ? 1 : 0;

@@ -329,6 +329,15 @@ extern "C" int mi_conv3x3_wgrad_supported(const MiWgradDesc* d) { return (d && w
 
 static int w3_plan(const MiWgradDesc* d, W3Args& a, int& BJ, bool& wide);
 
+// Which instantiation wgrad3x3_kernel<NJ, KS, IO> runs for a descriptor and how many k-slices (profiling attribution only)
+extern "C" int mi_conv3x3_wgrad_tile(const MiWgradDesc* d, int* nj, int* splits) {
+    MI_REQUIRE(d && nj && splits && w3_ok(d), "unsupported descriptor");
+    W3Args a; int BJ; bool wide;
+    w3_plan(d, a, BJ, wide);
+    *nj = wide ? 2 : 1; *splits = a.splits;
+    return 0;
+}
+
 extern "C" size_t mi_conv3x3_wgrad_workspace(const MiWgradDesc* d) {
     if (!d || !w3_ok(d)) return 0;
     W3Args a; int BJ; bool wide;

@@ -122,7 +122,10 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
               "mi_conv3x3_bf16w")
     if PROBE is not None:
         e1.record()
-        PROBE.append((f"conv3x3_halo_kernel<KS={ksize}>", 2.0 * N * H * W * Nc * K * ksize * ksize, e0, e1,
+        bm, ck, sk = C.c_int(), C.c_int(), C.c_int()
+        lib.mi_conv3x3_bf16w_tile(C.byref(d), io, C.byref(bm), C.byref(ck), C.byref(sk))
+        PROBE.append((f"conv3x3_halo_kernel<{bm.value}, {ck.value}, {ksize}, {'true' if sk.value else 'false'}, {io}, {8 if bm.value == 256 else 4}>",
+                      2.0 * N * H * W * Nc * K * ksize * ksize, e0, e1,
                       f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)} io{io}"))
     return out
 
@@ -222,7 +225,12 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
             colsum(Q, dbias)
     if PROBE is not None:
         e1.record()
-        PROBE.append(("wgrad3x3_kernel" if fast else f"wgrad_kernel<{mode}>", 2.0 * N * grid_d[0] * grid_d[1] * Ci * Cj * kh * kw, e0, e1,
+        sym = f"wgrad_kernel<{mode}>"
+        if fast:
+            nj, sp = C.c_int(), C.c_int()
+            lib.mi_conv3x3_wgrad_tile(C.byref(d), C.byref(nj), C.byref(sp))
+            sym = f"wgrad3x3_kernel<{nj.value}, {kh}, {_b16(P) | (_b16(Q) << 1)}> (+reduce)"
+        PROBE.append((sym, 2.0 * N * grid_d[0] * grid_d[1] * Ci * Cj * kh * kw, e0, e1,
                       f"N{N} {grid_d[0]}x{grid_d[1]} Ci{Ci}{'(2src)' if P2 is not None else ''} Cj{Cj} k{kh} s{stride} g{int(gather_i)}"))
 
 

@@ -87,6 +87,9 @@ int mi_conv3x3_bf16w_supported(const MiConvDesc* d);
 /* 1 when the layer would run the split-K plan (small-M levels; partial sums are combined with fp32 atomics, so
  * the output has to be fp32): the caller keeps such layers' block-internal tensors in fp32. */
 int mi_conv3x3_bf16w_uses_splitk(const MiConvDesc* d);
+/* profiling attribution: the template arguments of the kernel instantiation a descriptor runs on
+ * (conv3x3_halo_kernel<bm, ck, KH, sk, io, bm == 256 ? 8 : 4>) */
+int mi_conv3x3_bf16w_tile(const MiConvDesc* d, int io, int* bm, int* ck, int* sk);
 /* bf16 activation storage for the ResnetBlock-internal tensors (conv output -> GroupNorm -> conv input and
  * their gradients): io bit 0 = x / x2 are bf16 tensors, bit 1 = y is written as bf16; strides count
  * elements.  3x3 and 1x1; with bit 1 the split-K variant (fp32 atomics) is not used. */
@@ -152,6 +155,8 @@ int mi_conv_wgrad(const MiWgradDesc* d, const float* P, const float* P2, const f
  * (needs N % 8 == 0, channel counts % 32 == 0; query first, else use mi_conv_wgrad). */
 int mi_conv3x3_wgrad(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW, void* stream);
 int mi_conv3x3_wgrad_supported(const MiWgradDesc* d);
+/* profiling attribution: wgrad3x3_kernel<nj, KH, io> and the number of k-slices (= partial tiles per output tile) */
+int mi_conv3x3_wgrad_tile(const MiWgradDesc* d, int* nj, int* splits);
 /* Same, but the k-slices write partial tiles to a caller-provided scratch buffer that a second
  * (deterministic) kernel sums into dW -- 2.4x cheaper than fp32 atomics here.  Size from
  * mi_conv3x3_wgrad_workspace(); a null / too small workspace falls back to atomics. */

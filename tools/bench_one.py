@@ -6,11 +6,12 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "image-generation-models_amd")]
 import torch
 from src.ops import functional as K
 which, B, H, Ci, Co = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+DT = torch.bfloat16 if len(sys.argv) > 6 and sys.argv[6] == "bf16" else torch.float32     # activation storage
 DEV = "cuda"
-x = torch.randn(B, H, H, Ci, device=DEV); w = torch.randn(3, 3, Ci, Co, device=DEV) * 0.05
-dy = torch.randn(B, H, H, Co, device=DEV)
+x = torch.randn(B, H, H, Ci, device=DEV).to(DT); w = torch.randn(3, 3, Ci, Co, device=DEV) * 0.05
+dy = torch.randn(B, H, H, Co, device=DEV).to(DT)
 wd = w.to(torch.bfloat16).reshape(-1); wf = w.permute(0, 1, 3, 2).contiguous().to(torch.bfloat16).reshape(-1)
-y = torch.empty(B, H, H, Co, device=DEV); dW = torch.zeros(9 * Ci * Co, device=DEV)
+y = torch.empty(B, H, H, Co, device=DEV, dtype=DT); dW = torch.zeros(9 * Ci * Co, device=DEV)
 for _ in range(5):
     if which == "wgrad":
         K.conv_wgrad(x, dy, dW, kh=3, kw=3, stride=1, pad=1, gather_i=True, Ci=Ci, Cj=Co, grid_g=(H, H), grid_d=(H, H), mode=1)
