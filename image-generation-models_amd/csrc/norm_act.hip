@@ -45,6 +45,7 @@ struct GnArgs {
     int N, HW, C, G, Cg; float eps; int ldx, ldy, ldr, ldt;
     // backward
     const float* dout; float* dx; float* dgamma; float* dbeta; float* dtemb; float* dbias; int lddo, lddx;
+    int xcd_map;
 };
 
 // thread layout inside a (n,g) slice: W = Cg/VEC channel units per pixel; unit u = t % W handles
@@ -53,7 +54,15 @@ template <int VEC, int MAXU, int IO = 0>     // IO bit 0: x is bf16, bit 1: y is
 __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
     constexpr bool X16 = IO & 1, Y16 = IO & 2;
     __shared__ float red[8];
-    const int n = blockIdx.x / a.G, g = blockIdx.x % a.G;
+    // Workgroup -> (sample, group).  Consecutive workgroup ids go to different XCDs (id % 8), each with its own L2, while
+    // the groups of one sample share cache lines (C/G channels are 32..128 bytes of a pixel row): keep a sample's
+    // groups on ONE XCD -- ids xcd + 8*slot with slot = g + G*m are sample xcd + 8*m.
+    int n = blockIdx.x / a.G, g = blockIdx.x % a.G;
+    if (a.N % 8 == 0 && a.xcd_map) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        g = slot % a.G; n = xcd + 8 * (slot / a.G);
+    }
+    const int ng = n * a.G + g;
     const int W = a.Cg / VEC, PP = 256 / W;
     const int t = threadIdx.x, u = t % W, pr = t / W;
     const int c0 = g * a.Cg + u * VEC;
@@ -64,13 +73,12 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
     float s = 0.f;
     if constexpr (MAXU > 0) {
 #pragma unroll
-        for (int k = 0; k < MAXU; ++k) {
-            int p = pr + k * PP;
-            if (p < a.HW) {
-                cache[k] = vload<VEC, X16>(a.x, xoff + (size_t)p * a.ldx);
+        for (int k = 0; k < MAXU; ++k) cache[k] = vload<VEC, X16>(a.x, xoff + (size_t)min(pr + k * PP, a.HW - 1) * a.ldx);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) s += cache[k].v[j];
-            }
+        for (int k = 0; k < MAXU; ++k) {
+            const float live = pr + k * PP < a.HW ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s += cache[k].v[j] * live;
         }
     } else {
         for (int p = pr; p < a.HW; p += PP) {
@@ -84,10 +92,9 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
     if constexpr (MAXU > 0) {
 #pragma unroll
         for (int k = 0; k < MAXU; ++k) {
-            if (pr + k * PP < a.HW) {
+            const float live = pr + k * PP < a.HW ? 1.f : 0.f;
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) { float dlt = cache[k].v[j] - mean; s2 += dlt * dlt; }
-            }
+            for (int j = 0; j < VEC; ++j) { float dlt = (cache[k].v[j] - mean) * live; s2 += dlt * dlt; }
         }
     } else {
         for (int p = pr; p < a.HW; p += PP) {
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
     }
     const float var = block_sum_256(s2, red + 4) / cnt;
     const float rstd = 1.0f / sqrtf(var + a.eps);
-    if (t == 0 && a.stats) { a.stats[2 * blockIdx.x] = mean; a.stats[2 * blockIdx.x + 1] = rstd; }
+    if (t == 0 && a.stats) { a.stats[2 * ng] = mean; a.stats[2 * ng + 1] = rstd; }
 
     float ga[VEC], be[VEC], tb[VEC];
 #pragma unroll
@@ -135,11 +142,19 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
     __shared__ float part[4][256 * VEC];
     __shared__ float chs[4][128];
     __shared__ float s12[2];
-    const int n = blockIdx.x / a.G, g = blockIdx.x % a.G;
+    // Workgroup -> (sample, group).  Consecutive workgroup ids go to different XCDs (id % 8), each with its own L2, while
+    // the groups of one sample share cache lines (C/G channels are 32..128 bytes of a pixel row): keep a sample's
+    // groups on ONE XCD -- ids xcd + 8*slot with slot = g + G*m are sample xcd + 8*m.
+    int n = blockIdx.x / a.G, g = blockIdx.x % a.G;
+    if (a.N % 8 == 0 && a.xcd_map) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        g = slot % a.G; n = xcd + 8 * (slot / a.G);
+    }
+    const int ng = n * a.G + g;
     const int W = a.Cg / VEC, PP = 256 / W;
     const int t = threadIdx.x, u = t % W, pr = t / W;
     const int c0 = g * a.Cg + u * VEC;
-    const float mean = a.stats[2 * blockIdx.x], rstd = a.stats[2 * blockIdx.x + 1];
+    const float mean = a.stats[2 * ng], rstd = a.stats[2 * ng + 1];
     const size_t xoff = (size_t)n * a.HW * a.ldx + c0, dooff = (size_t)n * a.HW * a.lddo + c0;
     const float cnt = (float)a.HW * (float)a.Cg;
     float ga[VEC], be[VEC];
@@ -233,6 +248,8 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
 int gn_prepare(const MiGnDesc* d, GnArgs& a, int& vec, int& units) {
     if (!d || d->N <= 0 || d->HW <= 0 || d->C <= 0 || d->G <= 0 || d->C % d->G) return -1;
     a.N = d->N; a.HW = d->HW; a.C = d->C; a.G = d->G; a.Cg = d->C / d->G; a.eps = d->eps;
+    static const int xcd_env = [] { const char* e = getenv("MI_GN_XCD"); return e ? atoi(e) : 1; }();
+    a.xcd_map = xcd_env;
     a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr;
     int cg = a.Cg;
     if (cg & (cg - 1)) return -2;                 // power of two channel groups only
