@@ -123,7 +123,15 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
     __shared__ float scratch[4 * 32 * 33];
     __shared__ float ctx_s[32 * 33];
     __shared__ float kmax_s[32], ksum_s[32], wsum[4 * 32], pmax[8 * 32];
-    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    // (batch, head) of this workgroup.  The heads of one batch element share cache lines (32 channels = 64..128 bytes of
+    // a pixel row) and consecutive workgroup ids land on different XCDs, so ids xcd + 8*slot with slot = h + heads*m
+    // are batch element xcd + 8*m: its heads stay on one XCD / one L2.
+    int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    if (a.B % 8 == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        h = slot % a.heads; b = xcd + 8 * (slot / a.heads);
+    }
+    const int bh = b * a.heads + h;
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int hid = a.heads * DH;
     const float* q = offs<T16>(a.qkv, (size_t)b * a.n * a.ldq + h * DH);
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
     reduce_outer<true, T16>(k, v, a.ldq, a.ldq, a.n, kmax_s, ctx_s, wsum, scratch);
     if (t < 32) ksum_s[t] = wsum[t] + wsum[32 + t] + wsum[64 + t] + wsum[96 + t];
     __syncthreads();
-    float* ctx_g = a.ctx + (size_t)blockIdx.x * 32 * 32;
+    float* ctx_g = a.ctx + (size_t)bh * 32 * 32;
     for (int idx = t; idx < 32 * 32; idx += 256) {
         int d = idx >> 5, e = idx & 31;
         float c = ctx_s[d * 33 + e] / ksum_s[d];
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
         ctx_g[idx] = c;
     }
     if (t < 32) {
-        float* ks = a.kstat + (size_t)blockIdx.x * 64;
+        float* ks = a.kstat + (size_t)bh * 64;
         ks[2 * t] = kmax_s[t]; ks[2 * t + 1] = ksum_s[t];
     }
     __syncthreads();
@@ -180,7 +188,15 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
     __shared__ float ctx_s[32 * 33], dctx_s[32 * 33];
     __shared__ float stage_s[4 * 32 * 33];
     __shared__ float kmax_s[32], kinv_s[32], r_s[32];
-    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    // (batch, head) of this workgroup.  The heads of one batch element share cache lines (32 channels = 64..128 bytes of
+    // a pixel row) and consecutive workgroup ids land on different XCDs, so ids xcd + 8*slot with slot = h + heads*m
+    // are batch element xcd + 8*m: its heads stay on one XCD / one L2.
+    int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    if (a.B % 8 == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        h = slot % a.heads; b = xcd + 8 * (slot / a.heads);
+    }
+    const int bh = b * a.heads + h;
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int hid = a.heads * DH;
     const float* q = offs<T16>(a.qkv, (size_t)b * a.n * a.ldq + h * DH);
@@ -191,10 +207,10 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
     float* dk = offs<T16>(dq, hid);
     float* dv = offs<T16>(dq, 2 * hid);
 
-    const float* ctx_g = a.ctx + (size_t)blockIdx.x * 32 * 32;
+    const float* ctx_g = a.ctx + (size_t)bh * 32 * 32;
     for (int idx = t; idx < 32 * 32; idx += 256) ctx_s[(idx >> 5) * 33 + (idx & 31)] = ctx_g[idx];
     if (t < 32) {
-        const float* ks = a.kstat + (size_t)blockIdx.x * 64;
+        const float* ks = a.kstat + (size_t)bh * 64;
         kmax_s[t] = ks[2 * t]; kinv_s[t] = 1.0f / ks[2 * t + 1];
     }
     reduce_outer<false, T16>(q, dout, a.ldq, hid, a.n, nullptr, dctx_s, nullptr, scratch);   // syncs inside

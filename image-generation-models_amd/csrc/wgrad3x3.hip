@@ -29,6 +29,7 @@ struct W3Args {
     int tiles_x, tiles;    // W/TW, tiles per image
     int total, cps, splits;
     int gx, gy;
+    int xcd_map;         // workgroup id -> (k-slice, tile) such that the tiles of one k-slice share an XCD (one L2)
     float* dbias;        // optional: dbias[co] += sum over pixels of Q (the conv's bias gradient), fused into the dY staging
     float* ws;           // per-workgroup partial tiles in register order (null -> fp32 atomics into dW)
 };
@@ -45,7 +46,14 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
     const int wi = wv >> 1, wj = wv & 1;
     // 1-D grid, one workgroup per CU (the kernel runs one wave per SIMD): b -> (k-slice, ky, ci-tile, co-tile)
     const int gsz = a.gx * a.gy * KS;
-    const int split = blockIdx.x / gsz, within = blockIdx.x % gsz;
+    // The gsz workgroups of one k-slice (3 ky x tiles) read the same X / dY rows.  Consecutive workgroup ids go to
+    // different XCDs, so with xcd_map ids xcd + 8*slot, slot = within + gsz*m, are k-slice xcd + 8*m: one L2 serves them.
+    int split = blockIdx.x / gsz, within = blockIdx.x % gsz;
+    if (a.xcd_map) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        within = slot % gsz; split = xcd + 8 * (slot / gsz);
+        if (split >= a.splits) return;
+    }
     const int ky = within % KS, txy = within / KS;
     const int ci0 = (txy % a.gx) * BI, co0 = (txy / a.gx) * BJ;
     constexpr int NUX = KS == 3 ? 3 : 2;                // X staging units per wave (= position groups of 8)
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         // this workgroup's partial tile in register order: slot ((kx*2+i)*NJ+j)*4+rq holds, for thread t, the four
         // accumulator values of register quad rq -> every store instruction writes 1 KB contiguous per wave;
         // wgrad_reduce_kernel sums the k-slices and undoes the permutation
-        float* tile = a.ws + (size_t)blockIdx.x * (KS * BI * BJ) + t * 4;
+        float* tile = a.ws + (size_t)(split * gsz + within) * (KS * BI * BJ) + t * 4;
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
@@ -388,7 +396,7 @@ static int w3_dispatch(const MiWgradDesc* d, const float* P, const float* P2, co
     a.ws = nullptr;
     if (workspace && ws_bytes >= (size_t)a.gx * a.gy * KS * a.splits * KS * 128 * BJ * sizeof(float) && a.splits > 1)
         a.ws = (float*)workspace;
-    dim3 grid((unsigned)(a.gx * a.gy * KS * a.splits));
+    dim3 grid((unsigned)(a.gx * a.gy * KS * (a.xcd_map ? (a.splits + 7) / 8 * 8 : a.splits)));
     hipStream_t st = (hipStream_t)stream;
     const int XP = ((a.TH * (a.TW + KS - 1)) | 1) * 8;
     const size_t lds = (size_t)(128 * XP + BJ * 17 * 8) * 2 * 2;      // double-buffered
@@ -473,5 +481,9 @@ static int w3_plan(const MiWgradDesc* d, W3Args& a, int& BJ, bool& wide) {
     a.cps = (int)((a.total + splits - 1) / splits);
     a.splits = (a.total + a.cps - 1) / a.cps;
     a.gx = (d->Ci + 127) / 128; a.gy = (d->Cj + BJ - 1) / BJ;
+    // measured: helps the HBM-bound 1x1 gradients with many k-slices (77 -> 64 us for 128->384 at 32x32), neutral or
+    // harmful for the 3x3 ones (not traffic-bound; rounding the k-slices up to a multiple of 8 idles workgroups)
+    static const int xcd_env = [] { const char* e = getenv("MI_W3_XCD"); return e ? atoi(e) : 1; }();
+    a.xcd_map = xcd_env == 2 || (xcd_env == 1 && KS == 1 && a.splits >= 32);
     return 0;
 }
