@@ -45,6 +45,7 @@ struct HaloArgs {
     int TH, TI;          // tile = TI images x TH rows x W columns (BM = TI*TH*W)
     int HP;              // halo pixels = TI*(TH+2)*(W+2)
     int tiles_per_img;   // H/TH when TI == 1
+    int xmap;            // XCD-aware tile order (3x3, several row tiles per image, N % 8 == 0)
 };
 
 // waves are arranged (WAVES/2) along M x 2 along N; a wave owns (MI*32) pixels x 64 channels
@@ -93,7 +94,15 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
 
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int wm = wv >> 1, wn = wv & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // M tile of this workgroup.  Row tiles of one image share their halo rows and consecutive workgroup ids go to
+    // different XCDs (separate L2s), so with xmap ids xcd + 8*slot, slot = tile_in_image + tiles_per_img*m, belong to
+    // image xcd + 8*m: an image's tiles meet in one L2 and the halo rows come from HBM once.
+    int bx = blockIdx.x;
+    if (KS == 3 && a.xmap) {
+        const int xcd = bx & 7, slot = bx >> 3;
+        bx = (xcd + 8 * (slot / a.tiles_per_img)) * a.tiles_per_img + slot % a.tiles_per_img;
+    }
+    const int m0 = bx * BM, n0 = blockIdx.y * BN;
     const int W2 = a.W + (KS - 1), TH2 = a.TH + (KS - 1);
     const int Mtot = a.N * a.H * a.W;
 
@@ -110,8 +119,8 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     int pofs[NSL][A_SL];                                   // source pixel of each of this thread's staging slots, < 0 = zero
     if constexpr (KS == 3) {
         int img0, y0;
-        if (a.TI > 1) { img0 = blockIdx.x * a.TI; y0 = 0; }
-        else { img0 = blockIdx.x / a.tiles_per_img; y0 = (blockIdx.x % a.tiles_per_img) * a.TH; }
+        if (a.TI > 1) { img0 = bx * a.TI; y0 = 0; }
+        else { img0 = bx / a.tiles_per_img; y0 = (bx % a.tiles_per_img) * a.TH; }
         for (int hp = t; hp < MAXHP; hp += NT) {
             int v = -1;
             if (hp < a.HP) {
@@ -556,7 +565,7 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
         if (ks) {
             {
                 a.TH = th; a.TI = ti; a.tiles_per_img = ti > 1 ? 1 : a.H / th; a.HP = ti * (th + 2) * (a.W + 2);
-                a.ksplit = ks;
+                a.ksplit = ks; a.xmap = 0;
                 if (!d->accumulate) {
                     hipError_t e = hipMemsetAsync(y, 0, (size_t)d->N * d->OH * d->OW * d->ldy * sizeof(float), st);
                     if (e != hipSuccess) return mi_set_error((int)e, "mi_conv3x3_bf16w: memset: %s", hipGetErrorString(e));
@@ -587,7 +596,7 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
         }
     }
     if (d->KH == 1) {
-        a.TH = 1; a.TI = 1; a.tiles_per_img = 1; a.HP = BM;
+        a.TH = 1; a.TI = 1; a.tiles_per_img = 1; a.HP = BM; a.xmap = 0;
 #define MI_HALO1_GO(IOV) \
     do { if (BM == 256) launch_halo<256, 32, 1, false, IOV>(a, st); \
          else if (BM == 128) launch_halo<128, 32, 1, false, IOV>(a, st); \
@@ -599,6 +608,8 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
     }
     MI_REQUIRE(halo_geom(d, BM, &a.TH, &a.TI), "halo tile geometry");
     a.tiles_per_img = a.TI > 1 ? 1 : a.H / a.TH;
+    static const int xmap_env = [] { const char* e = getenv("MI_HALO_XCD"); return e ? atoi(e) : 1; }();
+    a.xmap = xmap_env && a.TI == 1 && a.tiles_per_img > 1 && a.N % 8 == 0;
     a.HP = a.TI * (a.TH + 2) * (a.W + 2);
     // (a 4-wave variant with 128x64 wave tiles was measured 15 % slower than 8 waves of 64x64: thread-level
     //  parallelism matters more than LDS bytes per MFMA here)

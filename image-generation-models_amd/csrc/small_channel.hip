@@ -28,22 +28,23 @@ __device__ __forceinline__ void decode_px(int m, int H, int W, int w_sh, int hw_
 }
 
 // the <= 4 input channels of one pixel (zero when the tap falls outside the image)
-template <int CIN>
-__device__ __forceinline__ f32x4 load_small(const float* __restrict__ x, int ldx, int n, int iy, int ix, int H, int W, bool vec) {
+template <int CIN, bool VEC>      // VEC: 16-byte aligned pixels (ldx % 4 == 0) -> one load per tap, no branch around it
+__device__ __forceinline__ f32x4 load_small(const float* __restrict__ x, int ldx, int n, int iy, int ix, int H, int W) {
     const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
     const float* p = x + (size_t)((n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * ldx;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (vec) v = *reinterpret_cast<const f32x4*>(p);
+    if constexpr (VEC) v = *reinterpret_cast<const f32x4*>(p);
     else { v.x = p[0]; if (CIN > 1) v.y = p[1]; if (CIN > 2) v.z = p[2]; if (CIN > 3) v.w = p[3]; }
     const float k = ok ? 1.f : 0.f;
     return v * k;
 }
 
-// y[px][co] = b[co] + sum_{tap,ci<CIN} x[px+tap][ci] * w[tap][ci][co];   KS = 3 (pad 1) or 1
-template <int CIN, int KS, bool POW2>
+// y[px][co] = b[co] + sum_{tap,ci<CIN} x[px+tap][ci] * w[tap][ci][co];   KS = 3 (pad 1) or 1.  Two pixels per
+// iteration: both pixels' tap loads are in flight before the first FMA.
+template <int CIN, int KS, bool POW2, bool VEC>
 __global__ __launch_bounds__(256) void small_cin_fwd_kernel(int N, int H, int W, int Cout, const float* __restrict__ x, int ldx,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
-                                                            float* __restrict__ y, int ldy, int w_sh, int hw_sh, int vec) {
+                                                            float* __restrict__ y, int ldy, int w_sh, int hw_sh) {
     constexpr int NT = KS * KS;
     const int nq = Cout / 4;                              // channel quads
     const int q = threadIdx.x % nq, psub = threadIdx.x / nq, pp = 256 / nq;
@@ -51,19 +52,25 @@ __global__ __launch_bounds__(256) void small_cin_fwd_kernel(int N, int H, int W,
 #pragma unroll
     for (int i = 0; i < NT * CIN; ++i) wr[i] = *reinterpret_cast<const f32x4*>(w + (size_t)i * Cout + 4 * q);
     const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const int M = N * H * W;
-    for (int m = blockIdx.x * pp + psub; m < M; m += gridDim.x * pp) {
-        int n, yy, xx;
-        decode_px<POW2>(m, H, W, w_sh, hw_sh, n, yy, xx);
-        f32x4 xv[NT];
+    const int M = N * H * W, step = gridDim.x * pp;
+    for (int m0 = blockIdx.x * pp + psub; m0 < M; m0 += 2 * step) {
+        f32x4 xv[2][NT];
 #pragma unroll
-        for (int tp = 0; tp < NT; ++tp) xv[tp] = load_small<CIN>(x, ldx, n, yy + tp / KS - KS / 2, xx + tp % KS - KS / 2, H, W, vec);
-        f32x4 acc = b4;
+        for (int u = 0; u < 2; ++u) {
+            int n, yy, xx;
+            decode_px<POW2>(min(m0 + u * step, M - 1), H, W, w_sh, hw_sh, n, yy, xx);
 #pragma unroll
-        for (int tp = 0; tp < NT; ++tp)
+            for (int tp = 0; tp < NT; ++tp) xv[u][tp] = load_small<CIN, VEC>(x, ldx, n, yy + tp / KS - KS / 2, xx + tp % KS - KS / 2, H, W);
+        }
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) acc += xv[tp][ci] * wr[tp * CIN + ci];
-        *reinterpret_cast<f32x4*>(y + (size_t)m * ldy + 4 * q) = acc;
+        for (int u = 0; u < 2; ++u) {
+            f32x4 acc = b4;
+#pragma unroll
+            for (int tp = 0; tp < NT; ++tp)
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) acc += xv[u][tp][ci] * wr[tp * CIN + ci];
+            if (m0 + u * step < M) *reinterpret_cast<f32x4*>(y + (size_t)(m0 + u * step) * ldy + 4 * q) = acc;
+        }
     }
 }
 
@@ -93,10 +100,10 @@ __device__ __forceinline__ void block_reduce_quads(f32x4 (&a)[NA], int nq, float
 }
 
 // dW[tap][ci][co] += sum_px x[px+tap][ci] * dy[px][co]: thread = (co quad, pixel lane), KS*KS*CIN float4 accumulators
-template <int CIN, int KS, bool POW2>
+template <int CIN, int KS, bool POW2, bool VEC>
 __global__ __launch_bounds__(256) void small_cin_wgrad_kernel(int N, int H, int W, int Cout, const float* __restrict__ x, int ldx,
                                                               const float* __restrict__ dy, int lddy, float* __restrict__ dW,
-                                                              float* __restrict__ ws, int w_sh, int hw_sh, int vec) {
+                                                              float* __restrict__ ws, int w_sh, int hw_sh) {
     constexpr int NT = KS * KS, NA = NT * CIN;
     extern __shared__ float red[];
     const int nq = Cout / 4;
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256) void small_cin_wgrad_kernel(int N, int H, int 
         decode_px<POW2>(m, H, W, w_sh, hw_sh, n, yy, xx);
 #pragma unroll
         for (int tp = 0; tp < NT; ++tp) {
-            const f32x4 xv = load_small<CIN>(x, ldx, n, yy + tp / KS - KS / 2, xx + tp % KS - KS / 2, H, W, vec);
+            const f32x4 xv = load_small<CIN, VEC>(x, ldx, n, yy + tp / KS - KS / 2, xx + tp % KS - KS / 2, H, W);
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) acc[tp * CIN + ci] += xv[ci] * g;
         }
@@ -263,14 +270,15 @@ extern "C" int mi_conv_small_cin_fwd(int ks, int N, int H, int W, int Cin, int C
                ldy % 4 == 0 && (((uintptr_t)y | (uintptr_t)w) & 15) == 0,
                "needs ks 1|3, Cin <= 4, Cout a multiple of 4 with Cout/4 dividing 256, 16-byte aligned y / w");
     const int pp = 256 / (Cout / 4);
-    long blocks = ((long)N * H * W + pp - 1) / pp; if (blocks > 4096) blocks = 4096;
+    long blocks = ((long)N * H * W + 2 * pp - 1) / (2 * pp); if (blocks > 4096) blocks = 4096;
     const int w_sh = log2_exact(W), hw_sh = log2_exact(H * W);
     const bool pow2 = w_sh >= 0 && hw_sh >= 0;
-    const int vec = ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    const bool vec = ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
 #define MI_GO(CIN, KS) do { \
-        if (pow2) hipLaunchKernelGGL((small_cin_fwd_kernel<CIN, KS, true>), dim3((unsigned)blocks), dim3(256), 0, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, w_sh, hw_sh, vec); \
-        else hipLaunchKernelGGL((small_cin_fwd_kernel<CIN, KS, false>), dim3((unsigned)blocks), dim3(256), 0, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, 0, 0, vec); } while (0)
+        if (pow2 && vec) hipLaunchKernelGGL((small_cin_fwd_kernel<CIN, KS, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, w_sh, hw_sh); \
+        else if (vec) hipLaunchKernelGGL((small_cin_fwd_kernel<CIN, KS, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, 0, 0); \
+        else hipLaunchKernelGGL((small_cin_fwd_kernel<CIN, KS, false, false>), dim3((unsigned)blocks), dim3(256), 0, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, 0, 0); } while (0)
 #define MI_GO_CIN(KS) do { switch (Cin) { case 1: MI_GO(1, KS); break; case 2: MI_GO(2, KS); break; case 3: MI_GO(3, KS); break; default: MI_GO(4, KS); break; } } while (0)
     if (ks == 3) MI_GO_CIN(3); else MI_GO_CIN(1);
 #undef MI_GO
@@ -287,12 +295,13 @@ extern "C" int mi_conv_small_cin_wgrad(int ks, int N, int H, int W, int Cin, int
     float* ws = (workspace && ws_bytes >= mi_conv_small_wgrad_workspace(na * Cout)) ? (float*)workspace : nullptr;
     const int w_sh = log2_exact(W), hw_sh = log2_exact(H * W);
     const bool pow2 = w_sh >= 0 && hw_sh >= 0;
-    const int vec = ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    const bool vec = ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
     const size_t lds = (size_t)3 * na * (Cout / 4) * 4 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
 #define MI_GO(CIN, KS) do { \
-        if (pow2) hipLaunchKernelGGL((small_cin_wgrad_kernel<CIN, KS, true>), dim3(WG_BLOCKS), dim3(256), lds, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, w_sh, hw_sh, vec); \
-        else hipLaunchKernelGGL((small_cin_wgrad_kernel<CIN, KS, false>), dim3(WG_BLOCKS), dim3(256), lds, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, 0, 0, vec); } while (0)
+        if (pow2 && vec) hipLaunchKernelGGL((small_cin_wgrad_kernel<CIN, KS, true, true>), dim3(WG_BLOCKS), dim3(256), lds, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, w_sh, hw_sh); \
+        else if (vec) hipLaunchKernelGGL((small_cin_wgrad_kernel<CIN, KS, false, true>), dim3(WG_BLOCKS), dim3(256), lds, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, 0, 0); \
+        else hipLaunchKernelGGL((small_cin_wgrad_kernel<CIN, KS, false, false>), dim3(WG_BLOCKS), dim3(256), lds, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, 0, 0); } while (0)
     if (ks == 3) MI_GO_CIN(3); else MI_GO_CIN(1);
 #undef MI_GO
 #undef MI_GO_CIN
