@@ -51,15 +51,24 @@ __device__ __forceinline__ void reduce_outer(const float* A, const float* Bm, in
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float mx = EXP ? kmax[i] : 0.f;
     float ssum = 0.f;
-    for (int p0 = 2 * w; p0 < n; p0 += 8) {
-        int p = p0 + kk;
-        float av = 0.f, bv = 0.f;
-        if (p < n) {
-            av = ldx<T16>(A, (size_t)p * ldA + i);
-            bv = ldx<T16>(Bm, (size_t)p * ldB + i);
-            if (EXP) { av = __expf(av - mx); ssum += av; }
+    // four pixel pairs per trip, all eight loads issued before the first use and none of them inside a branch (a
+    // guarded load is followed by s_waitcnt vmcnt(0): one memory round trip per pair); rows past n are clamped + masked
+    constexpr int UN = 4;
+    for (int p0 = 2 * w; p0 < n; p0 += 8 * UN) {
+        float av[UN], bv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const size_t p = (size_t)min(p0 + 8 * u + kk, n - 1);
+            av[u] = ldx<T16>(A, p * ldA + i);
+            bv[u] = ldx<T16>(Bm, p * ldB + i);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const float live = p0 + 8 * u + kk < n ? 1.f : 0.f;
+            float x = av[u];
+            if (EXP) { x = __expf(x - mx) * live; ssum += x; } else x *= live;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bv[u], acc, 0, 0, 0);
+        }
     }
     // combine the four waves through LDS
     float* mine = scratch + w * (32 * 33);
@@ -90,22 +99,27 @@ __device__ __forceinline__ f32x16 tile_mm(const float* A, int ldA, int p0, int n
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // unconditional loads (rows past n re-read row n-1 and are zeroed by `live`): the four fetches overlap
+    float v[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int row = (l >> 3) + 8 * j, c4 = (l & 7) * 4, p = p0 + row;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        if (p < n) {
-            if constexpr (T16) {
-                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(A) + (size_t)p * ldA + c4);
-                v0 = __uint_as_float(u.x << 16); v1 = __uint_as_float(u.x & 0xffff0000u);
-                v2 = __uint_as_float(u.y << 16); v3 = __uint_as_float(u.y & 0xffff0000u);
-            } else {
-                const float4 u = *reinterpret_cast<const float4*>(A + (size_t)p * ldA + c4);
-                v0 = u.x; v1 = u.y; v2 = u.z; v3 = u.w;
-            }
+        const int row = (l >> 3) + 8 * j, c4 = (l & 7) * 4;
+        const size_t p = (size_t)min(p0 + row, n - 1);
+        if constexpr (T16) {
+            const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(A) + p * ldA + c4);
+            v[j][0] = __uint_as_float(u.x << 16); v[j][1] = __uint_as_float(u.x & 0xffff0000u);
+            v[j][2] = __uint_as_float(u.y << 16); v[j][3] = __uint_as_float(u.y & 0xffff0000u);
+        } else {
+            const float4 u = *reinterpret_cast<const float4*>(A + p * ldA + c4);
+            v[j][0] = u.x; v[j][1] = u.y; v[j][2] = u.z; v[j][3] = u.w;
         }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (l >> 3) + 8 * j, c4 = (l & 7) * 4;
+        const float live = p0 + row < n ? 1.f : 0.f;
         float* sp = stage + row * 33 + c4;
-        sp[0] = v0; sp[1] = v1; sp[2] = v2; sp[3] = v3;
+        sp[0] = v[j][0] * live; sp[1] = v[j][1] * live; sp[2] = v[j][2] * live; sp[3] = v[j][3] * live;
     }
     // (wave-private LDS region: the wave's own ds_write -> ds_read ordering is enough)
 #pragma unroll
@@ -142,7 +156,12 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
     {
         int d = t & 31, pr = t >> 5;
         float m = -INFINITY;
-        for (int p = pr; p < a.n; p += 8) m = fmaxf(m, ldx<T16>(k, (size_t)p * a.ldq + d));
+        for (int p = pr; p < a.n; p += 32) {              // four rows in flight; rows past n repeat the last row (max-neutral)
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ldx<T16>(k, (size_t)min(p + 8 * u, a.n - 1) * a.ldq + d);
+            m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+        }
         pmax[pr * 32 + d] = m;
         __syncthreads();
         if (t < 32) {
@@ -231,11 +250,15 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < a.n) stx<T16>(dq, (size_t)p * a.ldq + col, acc[r]); }
         // P tile into LDS (rows = pixels) so it can serve as the A operand of dv
+        {
+            float kv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = tile_row(r, l), p = p0 + row;
-            float pv = (p < a.n) ? __expf(ldx<T16>(k, (size_t)p * a.ldq + col) - kmax_s[col]) * kinv_s[col] : 0.f;
-            pt[row * 33 + col] = pv;
+            for (int r = 0; r < 16; ++r) kv[r] = ldx<T16>(k, (size_t)min(p0 + tile_row(r, l), a.n - 1) * a.ldq + col);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tile_row(r, l);
+                pt[row * 33 + col] = p0 + row < a.n ? __expf(kv[r] - kmax_s[col]) * kinv_s[col] : 0.f;
+            }
         }
         // (wave-private LDS region: the wave's own ds_write -> ds_read ordering is enough)
         // dv[p][e] = sum_d P[p][d] dctx[d][e]
