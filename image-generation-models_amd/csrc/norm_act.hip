@@ -437,18 +437,21 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
 
 }  // namespace
 
-#define GN_DISPATCH_IO(KERNEL, IOV)                                                                 \
+#define GN_DISPATCH_IO_(KERNEL, IOV, FWD)                                                                 \
     do {                                                                                            \
         dim3 grid(a.N * a.G), blk(256);                                                             \
         if (vec == 4) {                                                                             \
             if (units <= 4) hipLaunchKernelGGL((KERNEL<4, 4, IOV>), grid, blk, 0, st, a);           \
             else if (units <= 16) hipLaunchKernelGGL((KERNEL<4, 16, IOV>), grid, blk, 0, st, a);    \
+            else if (units <= 32 && FWD) hipLaunchKernelGGL((KERNEL<4, 32, IOV>), grid, blk, 0, st, a); \
             else hipLaunchKernelGGL((KERNEL<4, 0, IOV>), grid, blk, 0, st, a);                      \
         } else {                                                                                    \
             if (units <= 16) hipLaunchKernelGGL((KERNEL<1, 16, IOV>), grid, blk, 0, st, a);         \
             else hipLaunchKernelGGL((KERNEL<1, 0, IOV>), grid, blk, 0, st, a);                      \
         }                                                                                           \
     } while (0)
+#define GN_DISPATCH_IO(KERNEL, IOV) GN_DISPATCH_IO_(KERNEL, IOV, false)
+#define GN_DISPATCH_FWD_IO(KERNEL, IOV) GN_DISPATCH_IO_(KERNEL, IOV, true)   /* forward also caches 32-unit slices (64x64 images, C/G = 8) */
 #define GN_DISPATCH(KERNEL) GN_DISPATCH_IO(KERNEL, 0)
 
 extern "C" int mi_gn_mish_fwd(const MiGnDesc* d, const float* x, const float* gamma, const float* beta,
@@ -462,7 +465,7 @@ extern "C" int mi_gn_mish_fwd(const MiGnDesc* d, const float* x, const float* ga
     MI_REQUIRE(vec == 1 || (d->ldx % 4 == 0 && d->ldy % 4 == 0 && (!residual || d->ldr % 4 == 0)), "ld must be a multiple of 4");
     a.x = x; a.gamma = gamma; a.beta = beta; a.temb = temb; a.ldt = ldt; a.res = residual; a.y = y; a.stats = stats;
     hipStream_t st = (hipStream_t)stream;
-    GN_DISPATCH(gn_mish_fwd_kernel);
+    GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 0);
     MI_LAUNCH_CHECK();
     return 0;
 }
@@ -498,10 +501,10 @@ extern "C" int mi_gn_mish_fwd_io(const MiGnDesc* d, const void* x, const float* 
     a.x = (const float*)x; a.gamma = gamma; a.beta = beta; a.temb = temb; a.ldt = ldt; a.res = residual; a.y = (float*)y; a.stats = stats;
     hipStream_t st = (hipStream_t)stream;
     switch (io) {
-        case 0: GN_DISPATCH_IO(gn_mish_fwd_kernel, 0); break;
-        case 1: GN_DISPATCH_IO(gn_mish_fwd_kernel, 1); break;
-        case 2: GN_DISPATCH_IO(gn_mish_fwd_kernel, 2); break;
-        default: GN_DISPATCH_IO(gn_mish_fwd_kernel, 3); break;
+        case 0: GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 0); break;
+        case 1: GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 1); break;
+        case 2: GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 2); break;
+        default: GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 3); break;
     }
     MI_LAUNCH_CHECK();
     return 0;

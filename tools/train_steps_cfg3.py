@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""N training steps of cfg 3 (CelebA 64x64, hidden_dim 64, mults 1-2-4-8) at per-GPU batch B, timed (no profiler needed)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "image-generation-models_amd")]
+import torch
+from src.models.ddpm import DDPM
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+torch.manual_seed(0)
+m = DDPM({"width": 64, "height": 64, "channels": 3, "transforms": {"normalize": True}}, hidden_dim=64, dim_mults=(1, 2, 4, 8),
+         lr=1e-4, b1=0.9, b2=0.999).to("cuda")
+m.denoising_model.compute_mode = os.environ.get("MODE", "bf16"); m.train()
+opt = m.configure_optimizers()
+x = torch.rand(B, 3, 64, 64, device="cuda") * 2 - 1
+for i in range(3):
+    loss = m.training_step((x, None), i); loss.backward(); opt.step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(n):
+    loss = m.training_step((x, None), i); loss.backward(); opt.step()
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f"cfg3 B={B}: {dt / n * 1e3:.2f} ms/step, {B * n / dt:.0f} images/s, {B * n / dt * 26.278 / 1e3:.1f} TFLOP/s, loss {float(loss):.4f}")
