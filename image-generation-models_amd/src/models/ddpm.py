@@ -390,6 +390,9 @@ class Unet(nn.Module):
 
         def lin(inp, w, b):
             o, i = w.shape
+            y = K.small_gemm(False, True, inp, w, bias=b)
+            if y is not None:
+                return y
             return K.conv_igemm(inp.view(T, 1, 1, i), w, kh=1, kw=1, stride=1, pad=0, transposed=False, w_kn=False,
                                 K=i, Nc=o, out_hw=(1, 1), mode=K.MODE_FP32, bias=b).view(T, o)
         temb = lin(K.mish_fwd(lin(K.time_embed(t, A.dim), sv["time_mlp.1.weight"], sv["time_mlp.1.bias"])),
@@ -410,6 +413,9 @@ class Unet(nn.Module):
             w = sv[wkey + "weight"] if w is None else w
             b = sv[wkey + "bias"] if b is None else b
             o, i = w.shape
+            y = K.small_gemm(False, True, inp, w, bias=b)                  # y = x W^T + b, exact fp32
+            if y is not None:
+                return y
             y = K.conv_igemm(inp.view(B, 1, 1, i), w, kh=1, kw=1, stride=1, pad=0, transposed=False, w_kn=False,
                              K=i, Nc=o, out_hw=(1, 1), mode=K.MODE_FP32, bias=b)
             return y.view(B, o)
@@ -676,11 +682,15 @@ class Unet(nn.Module):
 
                 def lin_bwd(dy, inp, gw, gb, w, want_dx=True):
                     o, i = w.shape
-                    K.conv_wgrad(dy.view(B, 1, 1, o), inp.view(B, 1, 1, i), gw, kh=1, kw=1, stride=1, pad=0,
-                                 gather_i=True, Ci=o, Cj=i, grid_g=(1, 1), grid_d=(1, 1), mode=K.MODE_FP32)
+                    if K.small_gemm(True, False, dy, inp, out=gw.view(o, i), accumulate=True, allow_split=True) is None:     # dW += dy^T x
+                        K.conv_wgrad(dy.view(B, 1, 1, o), inp.view(B, 1, 1, i), gw, kh=1, kw=1, stride=1, pad=0,
+                                     gather_i=True, Ci=o, Cj=i, grid_g=(1, 1), grid_d=(1, 1), mode=K.MODE_FP32)
                     K.colsum(dy, gb)
                     if not want_dx:
                         return None
+                    dx = K.small_gemm(False, False, dy, w, allow_split=True)                               # dx = dy W
+                    if dx is not None:
+                        return dx
                     dx = K.conv_igemm(dy.view(B, 1, 1, o), w, kh=1, kw=1, stride=1, pad=0, transposed=False, w_kn=True,
                                       K=o, Nc=i, out_hw=(1, 1), mode=K.MODE_FP32)
                     return dx.view(B, i)

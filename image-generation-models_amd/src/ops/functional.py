@@ -310,6 +310,26 @@ def chan_layernorm_bwd(x, g, dy, dx, accumulate, dg, db, eps=1e-5):
           "mi_chan_layernorm_bwd")
 
 
+# --------------------------------------------------------------------------- nn.Linear of the time MLP (exact fp32)
+def small_gemm(ta, tb, A, B, *, bias=None, out=None, accumulate=False, allow_split=False):
+    """out[i][j] (+)= bias[j] + sum_k opA(i,k) opB(k,j) (mi_small_gemm); returns None when the shape is not supported.
+    allow_split: long contractions may be split and combined with atomics (gradients; not bit-reproducible)."""
+    _need_gpu(A)
+    I = A.shape[1] if ta else A.shape[0]
+    Kc = A.shape[0] if ta else A.shape[1]
+    J = B.shape[0] if tb else B.shape[1]
+    lib = load_library()
+    if (A.dtype != torch.float32 or B.dtype != torch.float32 or A.stride(1) != 1 or B.stride(1) != 1 or
+            (A.data_ptr() | B.data_ptr()) & 15 or not lib.mi_small_gemm_supported(int(ta), int(tb), I, J, Kc, A.stride(0), B.stride(0))):
+        return None
+    if out is None:
+        assert not accumulate
+        out = torch.empty((I, J), device=A.device, dtype=torch.float32)
+    check(lib.mi_small_gemm(int(ta), int(tb), I, J, Kc, _p(A), A.stride(0), _p(B), B.stride(0), _p(bias), _p(out), out.stride(0),
+                            int(accumulate), int(allow_split), _stream()), "mi_small_gemm")
+    return out
+
+
 # --------------------------------------------------------------------------- attention
 def linattn_fwd(qkv, heads=4):
     _need_gpu(qkv)

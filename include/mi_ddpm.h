@@ -232,6 +232,16 @@ int mi_linattn_fwd_io(int B, int n, int heads, const void* qkv, void* out, float
 int mi_linattn_bwd_io(int B, int n, int heads, const void* qkv, const float* ctx, const float* kstat,
                       const void* dout, void* dqkv, int b16, void* stream);
 
+/* ---- small exact-fp32 GEMM: nn.Linear of the time-embedding MLP (ddpm.py:126-130,186-193), forward, input
+ * gradient and weight gradient ---------------------------------------------------------------------
+ *   C[i][j] (+)= bias[j] + sum_k opA(i,k) * opB(k,j),   opA = ta ? A[k*lda+i] : A[i*lda+k],  opB = tb ? B[j*ldb+k] : B[k*ldb+j]
+ * forward y = x W^T + b: ta 0, tb 1;  dx = dy W: ta 0, tb 0;  dW += dy^T x: ta 1, tb 0, accumulate 1.
+ * Needs K % 32 == 0, ld % 4 == 0, 16-byte aligned A / B (mi_small_gemm_supported); with allow_split long contractions are
+ * split and combined with fp32 atomics (used for the gradients only: the forward stays bit-reproducible). */
+int mi_small_gemm(int ta, int tb, int I, int J, int K, const float* A, int lda, const float* B, int ldb,
+                  const float* bias, float* C, int ldc, int accumulate, int allow_split, void* stream);
+int mi_small_gemm_supported(int ta, int tb, int I, int J, int K, int lda, int ldb);
+
 /* ---- small element-wise pieces ---------------------------------------------------------------- */
 /* SinusoidalPosEmb (ddpm.py:52-59): out[b][dim] = [sin(t f_j) | cos(t f_j)] */
 int mi_time_embed(int B, int dim, const int64_t* t, float* out, void* stream);

@@ -665,3 +665,30 @@ def test_bf16_attention_storage_kernels(K):
     d32 = K.linattn_bwd(qkv16.float(), ctx32, ks32, do.float())
     d16 = K.linattn_bwd(qkv16, ctx16, ks16, do)
     assert d16.dtype == BF and rel_err(d16.float(), d32) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,Kc", [(128, 512, 128), (128, 128, 512), (128, 3584, 128), (96, 200, 64)])
+def test_small_gemm_linear(K, M, N, Kc):
+    """nn.Linear of the time MLP through mi_small_gemm: forward, input gradient, weight gradient (exact fp32)."""
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(M, Kc, generator=g, dtype=torch.float64)
+    w = torch.randn(N, Kc, generator=g, dtype=torch.float64) / math.sqrt(Kc)
+    b = torch.randn(N, generator=g, dtype=torch.float64)
+    dy = torch.randn(M, N, generator=g, dtype=torch.float64)
+    xg, wg, bg, dyg = (t.float().to(DEV) for t in (x, w, b, dy))
+    y = K.small_gemm(False, True, xg, wg, bias=bg)
+    assert y is not None and rel_err(y, x @ w.t() + b) < 2e-6
+    y2 = K.small_gemm(False, True, xg, wg, bias=bg)
+    assert torch.equal(y, y2)                                                         # forward: no split, bit-reproducible
+    dx = K.small_gemm(False, False, dyg, wg, allow_split=True)
+    if N % 32:
+        assert dx is None                                                             # contraction not a multiple of 32
+    else:
+        assert rel_err(dx, dy @ w) < 2e-6
+    dW = torch.full((N, Kc), 0.25, device=DEV)
+    got = K.small_gemm(True, False, dyg, xg, out=dW, accumulate=True, allow_split=True)
+    if M % 32 or N % 4:
+        assert got is None
+    else:
+        assert rel_err(dW - 0.25, dy.t() @ x) < 2e-6
+    assert K.small_gemm(False, True, xg[:, :Kc - 1], wg[:, :Kc - 1]) is None          # K % 32 != 0 -> caller falls back

@@ -1,0 +1,21 @@
+import os, sys, time
+ROOT = "/root/repo"
+sys.path[:0] = [ROOT, os.path.join(ROOT, "image-generation-models_amd")]
+import torch
+from src.models.ddpm import DDPM
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+torch.manual_seed(0)
+m = DDPM({"width": 32, "height": 32, "channels": 3, "transforms": {"normalize": True}}, hidden_dim=128, dim_mults=(1, 2, 4), lr=1e-4, b1=0.9, b2=0.999).to("cuda")
+m.denoising_model.compute_mode = "bf16"; m.train()
+opt = m.configure_optimizers()
+x = torch.rand(B, 3, 32, 32, device="cuda") * 2 - 1
+for i in range(5):
+    loss = m.training_step((x, None), i); loss.backward(); opt.step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(10):
+    loss = m.training_step((x, None), i); loss.backward(); opt.step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"B={B}: enqueue {1e3*(t1-t0)/10:.2f} ms/step, total {1e3*(t2-t0)/10:.2f} ms/step")
