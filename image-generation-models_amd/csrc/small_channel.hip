@@ -149,8 +149,18 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restric
     const int ol = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int o = blockIdx.x * 32 + ol;
     float s = 0.f;
-    if (o < nout)
-        for (int p = grp; p < nparts; p += 8) s += ws[(size_t)p * nout + o];
+    if (o < nout) {                                       // eight independent loads in flight per thread
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = grp;
+        for (; p + 56 < nparts; p += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(p + 8 * u) * nout + o];
+            s0 += v[0] + v[4]; s1 += v[1] + v[5]; s2 += v[2] + v[6]; s3 += v[3] + v[7];
+        }
+        for (; p < nparts; p += 8) s0 += ws[(size_t)p * nout + o];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[grp][ol] = s;
     __syncthreads();
     if (grp == 0 && o < nout) {

@@ -302,7 +302,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int slot = blockIdx.y, within = blockIdx.z;
     const float* p = ws + (size_t)within * tile_elems + (size_t)slot * 1024 + tt * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int sp = grp; sp < splits; sp += G) s += *reinterpret_cast<const f32x4*>(p + (size_t)sp * gsz * tile_elems);
+    {                                                    // four independent 16-byte loads in flight per thread
+        const size_t stride = (size_t)gsz * tile_elems;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+        int sp = grp;
+        for (; sp + 3 * G < splits; sp += 4 * G) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)sp * stride);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + G) * stride);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + 2 * G) * stride);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + 3 * G) * stride);
+            s += v0 + v2; s1 += v1 + v3;
+        }
+        for (; sp < splits; sp += G) s += *reinterpret_cast<const f32x4*>(p + (size_t)sp * stride);
+        s += s1;
+    }
     red[grp][it] = s;
     __syncthreads();
     if (grp != 0) return;
