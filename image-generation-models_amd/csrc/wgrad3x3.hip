@@ -11,6 +11,10 @@
 #include <stdlib.h>
 #include "common.h"
 
+#ifndef MI_W3_ABL
+#define MI_W3_ABL 0      // profiling only: 1 no MFMA, 2 no global loads, 4 no LDS commit (cvt + ds_write), 8 no fragment reads
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -204,18 +208,20 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         const int r_ = p >> a.tw_sh, xx = p & (a.TW - 1);
         bf16x8 bf[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Yb[brow + j * 32 * YP + p * 8]);
+        for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(&Yb[brow + j * 32 * YP + ((MI_W3_ABL & 8) ? 0 : p * 8)]);
         const int xa = (r_ * TW2 + xx) * 8;
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
             bf16x8 af[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&Xb[arow + i * 32 * XP + xa + kx * 8]);
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&Xb[arow + i * 32 * XP + ((MI_W3_ABL & 8) ? 0 : xa + kx * 8)]);
+            if constexpr (!(MI_W3_ABL & 1)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[kx][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[kx][i][j], 0, 0, 0);
+            } else { acc[kx][0][0][0] += (float)af[0][0] + (float)bf[0][0] + (float)af[1][0] + (float)bf[NJ - 1][0]; }
         }
     };
 
@@ -229,7 +235,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_kernel(const W3Args a) {
         const int c2 = min(c + 2, cend - 1);           // past the end: a harmless re-read of the last chunk
         static_for<0, 8>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            if constexpr (s < NU) { commit_unit(sc, buf ^ 1); issue_unit(sc, c2); }
+            if constexpr (s < NU) {
+                if constexpr (!(MI_W3_ABL & 4)) commit_unit(sc, buf ^ 1);
+                if constexpr (!(MI_W3_ABL & 2)) issue_unit(sc, c2);
+            }
             mma_step(s, buf);
         });
         __syncthreads();
