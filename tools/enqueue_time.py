@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""CPU enqueue time vs wall time of a cfg-2 training step (is the step launch-bound?)."""
 import os, sys, time
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "image-generation-models_amd")]
 import torch
 from src.models.ddpm import DDPM
