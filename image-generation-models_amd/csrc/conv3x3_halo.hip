@@ -613,6 +613,26 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
     a.HP = a.TI * (a.TH + 2) * (a.W + 2);
     // (a 4-wave variant with 128x64 wave tiles was measured 15 % slower than 8 waves of 64x64: thread-level
     //  parallelism matters more than LDS bytes per MFMA here)
+    // 8x8-level layers (too few pixels for 256-pixel tiles): 128-pixel tiles with 8 waves and 64-channel chunks -- the
+    // weight tile is shared by 8 waves and read once per 128 pixels, 8 MFMAs per wave between barriers -- when that
+    // still gives every CU a workgroup; else the 64-pixel / 4-wave tiles.
+    {
+        static const int w8 = [] { const char* e = getenv("MI_HALO_W8"); return e ? atoi(e) : 200; }();   // min workgroups (0 = off)
+        int th8, ti8;
+        const long b128 = ((long)d->N * d->OH * d->OW + 127) / 128 * ((d->Nc + 127) / 128);
+        if (w8 && BM == 64 && d->K % 64 == 0 && d->K1 % 64 == 0 && b128 >= w8 && halo_geom(d, 128, &th8, &ti8)) {
+            a.TH = th8; a.TI = ti8; a.tiles_per_img = ti8 > 1 ? 1 : a.H / th8; a.HP = ti8 * (th8 + 2) * (a.W + 2);
+            a.xmap = a.xmap && a.TI == 1 && a.tiles_per_img > 1;
+            switch (io) {
+                case 0: launch_halo<128, 64, 3, false, 0, 8>(a, st); break;
+                case 1: launch_halo<128, 64, 3, false, 1, 8>(a, st); break;
+                case 2: launch_halo<128, 64, 3, false, 2, 8>(a, st); break;
+                default: launch_halo<128, 64, 3, false, 3, 8>(a, st); break;
+            }
+            MI_LAUNCH_CHECK();
+            return 0;
+        }
+    }
 #define MI_HALO_GO(IOV) \
     do { if (BM == 256) { if (CK == 64) launch_halo<256, 64, 3, false, IOV>(a, st); else launch_halo<256, 32, 3, false, IOV>(a, st); } \
          else if (BM == 128) launch_halo<128, 32, 3, false, IOV>(a, st); \
