@@ -513,7 +513,9 @@ static int halo_splitk(const MiConvDesc* d, int BM, int* th, int* ti) {
     // faster than split-K for every cfg-2 / cfg-3 layer (measured 14.17k vs 13.95k images/s); MI_HALO_SPLITK=1 enables it
     static const int allow = [] { const char* e = getenv("MI_HALO_SPLITK"); return e ? atoi(e) : 0; }();
     const long b256 = ((long)d->N * d->OH * d->OW + 255) / 256 * ((d->Nc + 127) / 128);
+    const long b128 = ((long)d->N * d->OH * d->OW + 127) / 128 * ((d->Nc + 127) / 128);
     const int chunks = d->K / 64;
+    if (allow == 2 && b128 >= 200) return 0;                                             // 2: only where the 128-pixel / 8-wave tiles do not apply
     if (!(allow && chunks >= 8 && halo_geom(d, 256, th, ti) && b256 >= 32)) return 0;   // measured: loses for K < 512
     int ks = 2;
     while (b256 * ks < 200 && ks * 4 <= chunks && ks < 8) ks *= 2;                      // >= 2 chunks per slice
@@ -633,9 +635,15 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
             return 0;
         }
     }
+    // 64-pixel tiles that cannot fill the chip twice anyway (<= 256 workgroups): 64-channel chunks, i.e. twice the MFMAs
+    // per barrier; the larger LDS footprint (one workgroup per CU) costs nothing then
+    static const int ck64 = [] { const char* e = getenv("MI_HALO_CK64"); return e ? atoi(e) : 1; }();
+    const bool wide64 = ck64 && BM == 64 && d->K % 64 == 0 && d->K1 % 64 == 0 &&
+                        ((long)d->N * d->OH * d->OW + 63) / 64 * ((d->Nc + 127) / 128) <= 256;
 #define MI_HALO_GO(IOV) \
     do { if (BM == 256) { if (CK == 64) launch_halo<256, 64, 3, false, IOV>(a, st); else launch_halo<256, 32, 3, false, IOV>(a, st); } \
          else if (BM == 128) launch_halo<128, 32, 3, false, IOV>(a, st); \
+         else if (wide64) launch_halo<64, 64, 3, false, IOV>(a, st); \
          else launch_halo<64, 32, 3, false, IOV>(a, st); } while (0)
     switch (io) { case 0: MI_HALO_GO(0); break; case 1: MI_HALO_GO(1); break; case 2: MI_HALO_GO(2); break; default: MI_HALO_GO(3); break; }
 #undef MI_HALO_GO
