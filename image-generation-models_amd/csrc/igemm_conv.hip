@@ -631,6 +631,8 @@ static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, 
             if (nt == 0) ok = false;
         }
         if (ok) {
+            static const int force = [] { const char* e = getenv("MI_IGEMM_TILE"); return e ? atoi(e) : 0; }();   // 11 / 10 / 01 / 00 = bm64,bn64 (profiling)
+            if (force) { bm64 = (force / 10) % 10 == 1; bn64 = force % 10 == 1; if (force == 100) { bm64 = false; bn64 = false; } }
             if (!bm64 && !bn64) launch_fast<128, 128>(a, tt, classes, st);
             else if (!bm64 && bn64) launch_fast<128, 64>(a, tt, classes, st);
             else if (bm64 && !bn64) launch_fast<64, 128>(a, tt, classes, st);

@@ -15,7 +15,7 @@ tail -1 $OUT/bench_stdout.txt > $OUT/bench.json
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_t -o t -- python $GRAFT_REPO_ROOT/tools/train_steps.py 10 > /dev/null 2>&1
 cp /tmp/prof_t/*kernel_stats.csv $OUT/train_step_kernel_stats.csv
 cd $GRAFT_REPO_ROOT
-for cfg in "halo 128 32 128 128 bf16" "halo 128 32 128 128 fp32" "wgrad 128 32 128 128 bf16" "wgrad 128 32 128 128 fp32" "halo 128 16 256 256 bf16" "halo 128 8 512 512 bf16"; do
+for cfg in "halo 128 32 128 128 bf16" "halo 128 32 128 128 fp32" "wgrad 128 32 128 128 bf16" "wgrad 128 32 128 128 fp32" "halo 128 16 256 256 bf16" "halo 128 8 512 512 bf16" "halo 128 8 1024 256 bf16"; do
   name=$(echo $cfg | tr ' ' '_')
   timeout 400 bash tools/pmc_traffic.sh ${tag}_$name $cfg > $OUT/pmc_traffic_$name.txt 2>&1
 done
