@@ -522,6 +522,22 @@ static int halo_splitk(const MiConvDesc* d, int BM, int* th, int* ti) {
     return ks * 2 <= chunks ? ks : 0;
 }
 
+// 8x8-level layers (too few pixels for 256-pixel tiles): 128-pixel tiles with 8 waves and 64-channel chunks -- the weight
+// tile is shared by 8 waves and read once per 128 pixels, 8 MFMAs per wave between barriers -- when that still gives
+// (almost) every CU a workgroup.  MI_HALO_W8 = minimum number of workgroups (0 = never).
+static bool halo_w8(const MiConvDesc* d, int BM, int* th, int* ti) {
+    static const int w8 = [] { const char* e = getenv("MI_HALO_W8"); return e ? atoi(e) : 200; }();
+    const long b128 = ((long)d->N * d->OH * d->OW + 127) / 128 * ((d->Nc + 127) / 128);
+    return w8 && d->KH == 3 && BM == 64 && d->K % 64 == 0 && d->K1 % 64 == 0 && b128 >= w8 && halo_geom(d, 128, th, ti);
+}
+// 64-pixel tiles that cannot fill the chip twice anyway (<= 256 workgroups): 64-channel chunks, i.e. twice the MFMAs per
+// barrier; the larger LDS footprint (one workgroup per CU) costs nothing then
+static bool halo_wide64(const MiConvDesc* d, int BM) {
+    static const int ck64 = [] { const char* e = getenv("MI_HALO_CK64"); return e ? atoi(e) : 1; }();
+    return ck64 && d->KH == 3 && BM == 64 && d->K % 64 == 0 && d->K1 % 64 == 0 &&
+           ((long)d->N * d->OH * d->OW + 63) / 64 * ((d->Nc + 127) / 128) <= 256;
+}
+
 // 1 when mi_conv3x3_bf16w would take the split-K plan for this descriptor (fp32 output only): callers that can
 // choose the output type use it to keep such layers in fp32.
 extern "C" int mi_conv3x3_bf16w_uses_splitk(const MiConvDesc* d) {
@@ -615,14 +631,9 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
     a.HP = a.TI * (a.TH + 2) * (a.W + 2);
     // (a 4-wave variant with 128x64 wave tiles was measured 15 % slower than 8 waves of 64x64: thread-level
     //  parallelism matters more than LDS bytes per MFMA here)
-    // 8x8-level layers (too few pixels for 256-pixel tiles): 128-pixel tiles with 8 waves and 64-channel chunks -- the
-    // weight tile is shared by 8 waves and read once per 128 pixels, 8 MFMAs per wave between barriers -- when that
-    // still gives every CU a workgroup; else the 64-pixel / 4-wave tiles.
     {
-        static const int w8 = [] { const char* e = getenv("MI_HALO_W8"); return e ? atoi(e) : 200; }();   // min workgroups (0 = off)
         int th8, ti8;
-        const long b128 = ((long)d->N * d->OH * d->OW + 127) / 128 * ((d->Nc + 127) / 128);
-        if (w8 && BM == 64 && d->K % 64 == 0 && d->K1 % 64 == 0 && b128 >= w8 && halo_geom(d, 128, &th8, &ti8)) {
+        if (halo_w8(d, BM, &th8, &ti8)) {
             a.TH = th8; a.TI = ti8; a.tiles_per_img = ti8 > 1 ? 1 : a.H / th8; a.HP = ti8 * (th8 + 2) * (a.W + 2);
             a.xmap = a.xmap && a.TI == 1 && a.tiles_per_img > 1;
             switch (io) {
@@ -635,11 +646,7 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
             return 0;
         }
     }
-    // 64-pixel tiles that cannot fill the chip twice anyway (<= 256 workgroups): 64-channel chunks, i.e. twice the MFMAs
-    // per barrier; the larger LDS footprint (one workgroup per CU) costs nothing then
-    static const int ck64 = [] { const char* e = getenv("MI_HALO_CK64"); return e ? atoi(e) : 1; }();
-    const bool wide64 = ck64 && BM == 64 && d->K % 64 == 0 && d->K1 % 64 == 0 &&
-                        ((long)d->N * d->OH * d->OW + 63) / 64 * ((d->Nc + 127) / 128) <= 256;
+    const bool wide64 = halo_wide64(d, BM);
 #define MI_HALO_GO(IOV) \
     do { if (BM == 256) { if (CK == 64) launch_halo<256, 64, 3, false, IOV>(a, st); else launch_halo<256, 32, 3, false, IOV>(a, st); } \
          else if (BM == 128) launch_halo<128, 32, 3, false, IOV>(a, st); \
@@ -659,6 +666,8 @@ extern "C" int mi_conv3x3_bf16w_tile(const MiConvDesc* d, int io, int* bm, int* 
     int th, ti;
     *sk = (!(io & 2) && halo_splitk(d, *bm, &th, &ti)) ? 1 : 0;
     if (*sk) { *bm = 256; *ck = 64; }
+    else if (halo_w8(d, *bm, &th, &ti)) { *bm = 128; *ck = 64; }     // 8 waves (the only 128-pixel / 64-channel form)
+    else if (halo_wide64(d, *bm)) *ck = 64;
     return 0;
 }
 

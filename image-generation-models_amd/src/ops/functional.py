@@ -124,7 +124,7 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
         e1.record()
         bm, ck, sk = C.c_int(), C.c_int(), C.c_int()
         lib.mi_conv3x3_bf16w_tile(C.byref(d), io, C.byref(bm), C.byref(ck), C.byref(sk))
-        PROBE.append((f"conv3x3_halo_kernel<{bm.value}, {ck.value}, {ksize}, {'true' if sk.value else 'false'}, {io}, {8 if bm.value == 256 else 4}>",
+        PROBE.append((f"conv3x3_halo_kernel<{bm.value}, {ck.value}, {ksize}, {'true' if sk.value else 'false'}, {io}, {8 if bm.value == 256 or (bm.value == 128 and ck.value == 64) else 4}>",
                       2.0 * N * H * W * Nc * K * ksize * ksize, e0, e1,
                       f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)} io{io}"))
     return out

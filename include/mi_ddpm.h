@@ -88,7 +88,7 @@ int mi_conv3x3_bf16w_supported(const MiConvDesc* d);
  * the output has to be fp32): the caller keeps such layers' block-internal tensors in fp32. */
 int mi_conv3x3_bf16w_uses_splitk(const MiConvDesc* d);
 /* profiling attribution: the template arguments of the kernel instantiation a descriptor runs on
- * (conv3x3_halo_kernel<bm, ck, KH, sk, io, bm == 256 ? 8 : 4>) */
+ * (conv3x3_halo_kernel<bm, ck, KH, sk, io, waves>, waves = 8 for bm == 256 and for the bm 128 / ck 64 form, else 4) */
 int mi_conv3x3_bf16w_tile(const MiConvDesc* d, int io, int* bm, int* ck, int* sk);
 /* bf16 activation storage for the ResnetBlock-internal tensors (conv output -> GroupNorm -> conv input and
  * their gradients): io bit 0 = x / x2 are bf16 tensors, bit 1 = y is written as bf16; strides count
