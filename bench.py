@@ -3,6 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode bf16|fp32] [--batch B]
 
+W warm-up steps (after `--prewarm` set-up steps that absorb the process's cold start), then exactly K timed steps.
 A "step" is one full training step of BASELINE cfg 2 (DDPM on CIFAR-10 32x32, UNet base 128,
 mults 1-2-4, T=1000, L1 loss, Adam lr 1e-4) on a synthetic batch of B=128 images per GPU that is
 already resident in HBM: draw t and eps on the device, q_sample, UNet forward, loss, UNet
@@ -66,8 +67,11 @@ def cpu_baseline(seconds_budget: float = 20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm", type=int, default=25,
+                    help="untimed set-up steps before the W warm-up steps: on a fresh box the first ~20 steps of a process are "
+                         "CPU-bound (HIP lazy module loads, caching-allocator growth), see tools/coldstart.py")
     ap.add_argument("--mode", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (reference default 128)")
     ap.add_argument("--denoise-steps", type=int, default=40)
@@ -124,7 +128,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(args.prewarm + args.warmup):
         train_step(i)
     sync()
     t0 = time.perf_counter()
