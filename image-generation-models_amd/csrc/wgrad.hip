@@ -18,6 +18,7 @@ struct WgradArgs {
     int N, GH, GW, DH, DW, Ci, Cj, KH, KW, stride, pad, gather_i, I1, ldp, ldp2, ldq;
     int Mtot, chunk, splits;
     int vec;
+    int xcd_map, gx, gy;       // fast kernel: XCD-aware 1-D grid (gx, gy = tiles along Ci, Cj)
 };
 
 template <int MODE> struct WElem { using type = float; static constexpr int PITCH = 36; };
@@ -221,8 +222,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WgradArgs a, i
 
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int wi = wv >> 1, wj = wv & 1;
-    const int i0 = blockIdx.x * BI, j0 = blockIdx.y * BJ;
-    const int tap = blockIdx.z / a.splits, split = blockIdx.z % a.splits;
+    // Workgroup -> (i tile, j tile, tap, pixel slice).  All taps and tiles of one pixel slice read the same rows of P and
+    // Q; consecutive workgroup ids go to different XCDs (separate L2s), so with xcd_map the 1-D id xcd + 8*slot is
+    // slice xcd + 8*(slot / inner), inner index slot % inner: a slice's workgroups share one L2.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (a.xcd_map) {
+        const int inner = a.gx * a.gy * a.KH * a.KW;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int split_ = xcd + 8 * (slot / inner), in_ = slot % inner;
+        if (split_ >= a.splits) return;
+        bx = in_ % a.gx; by = (in_ / a.gx) % a.gy; bz = (in_ / (a.gx * a.gy)) * a.splits + split_;
+    }
+    const int i0 = bx * BI, j0 = by * BJ;
+    const int tap = bz / a.splits, split = bz % a.splits;
     const int ky = tap / a.KW, kx = tap % a.KW;
     const int mbeg = split * a.chunk;
     const int mend = min(a.Mtot, mbeg + a.chunk);
@@ -356,8 +368,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WgradArgs a, i
 }
 
 template <int BI, int BJ>
-void launch_fast(const WgradArgs& a, int dw_sh, int dhw_sh, hipStream_t st) {
-    dim3 grid((a.Ci + BI - 1) / BI, (a.Cj + BJ - 1) / BJ, a.KH * a.KW * a.splits);
+void launch_fast(WgradArgs a, int dw_sh, int dhw_sh, hipStream_t st) {
+    static const int xcd_env = [] { const char* e = getenv("MI_WGRAD_XCD"); return e ? atoi(e) : 1; }();
+    a.gx = (a.Ci + BI - 1) / BI; a.gy = (a.Cj + BJ - 1) / BJ;
+    a.xcd_map = xcd_env && a.splits >= 8;
+    dim3 grid(a.gx, a.gy, a.KH * a.KW * a.splits);
+    if (a.xcd_map) grid = dim3((unsigned)(a.gx * a.gy * a.KH * a.KW * ((a.splits + 7) / 8 * 8)), 1, 1);
     hipLaunchKernelGGL((wgrad_fast_kernel<BI, BJ>), grid, dim3(256), 0, st, a, dw_sh, dhw_sh);
 }
 
@@ -396,6 +412,7 @@ extern "C" int mi_conv_wgrad(const MiWgradDesc* d, const float* P, const float* 
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.gather_i = d->gather_i;
     a.I1 = d->I1; a.ldp = d->ldp; a.ldp2 = P2 ? d->ldp2 : d->ldp; a.ldq = d->ldq;
     a.Mtot = d->N * d->DH * d->DW;
+    a.xcd_map = 0; a.gx = a.gy = 0;
     a.vec = (d->ldp % 4 == 0) && (a.ldp2 % 4 == 0) && (d->ldq % 4 == 0) && (((uintptr_t)P & 15) == 0) &&
             (((uintptr_t)a.P2 & 15) == 0) && (((uintptr_t)Q & 15) == 0);
     const bool big = d->Ci >= 128 && d->Cj >= 128;
