@@ -330,6 +330,36 @@ def small_gemm(ta, tb, A, B, *, bias=None, out=None, accumulate=False, allow_spl
     return out
 
 
+# --------------------------------------------------------------------------- VQ-VAE codebook step (vqvae.py:24-43)
+def vq_nearest(z_rows, codebook):
+    """z_rows [M, D] (row stride % 4 == 0), codebook [K, D] -> (idx int32 [M], zq [M, D], sum ||z - zq||^2 as a 0-dim tensor)."""
+    _need_gpu(z_rows)
+    M, D = z_rows.shape
+    Kc = codebook.shape[0]
+    assert z_rows.stride(1) == 1 and codebook.is_contiguous() and codebook.shape[1] == D
+    idx = torch.empty(M, device=z_rows.device, dtype=torch.int32)
+    zq = torch.empty((M, D), device=z_rows.device, dtype=torch.float32)
+    part = torch.empty(load_library().mi_vq_partials(M), device=z_rows.device, dtype=torch.float32)
+    check(load_library().mi_vq_nearest_fwd(M, D, Kc, _p(z_rows), z_rows.stride(0), _p(codebook), _p(idx), _p(zq), D, _p(part), _stream()),
+          "mi_vq_nearest_fwd")
+    return idx, zq, part.sum()
+
+
+def vq_backward(z_rows, codebook, idx, g_vq, g_commit, dz=None, accumulate=False, dcodebook=None, g_dev=None):
+    """Adds the gradients of g_vq * vq_loss + g_commit * mean((z - sg(q))^2) into dz / dcodebook (either may be None);
+    g_dev: optional 2-float device tensor multiplied into (g_vq, g_commit)."""
+    M, D = z_rows.shape
+    check(load_library().mi_vq_bwd(M, D, codebook.shape[0], _p(z_rows), z_rows.stride(0), _p(codebook), _p(idx), float(g_vq), float(g_commit),
+                                   _p(g_dev), _p(dz), dz.stride(0) if dz is not None else 0, int(accumulate), _p(dcodebook), _stream()), "mi_vq_bwd")
+
+
+def vq_scatter_rows(src_rows, idx, table):
+    """table[idx[m]] += src_rows[m]."""
+    M, D = src_rows.shape
+    check(load_library().mi_vq_scatter_rows(M, D, table.shape[0], _p(src_rows), src_rows.stride(0), _p(idx), _p(table), _stream()),
+          "mi_vq_scatter_rows")
+
+
 # --------------------------------------------------------------------------- attention
 def linattn_fwd(qkv, heads=4):
     _need_gpu(qkv)

@@ -67,6 +67,10 @@ SIGNATURES = {
     "mi_chan_layernorm_bwd": [_I, _I, _P, _I, _P, _F, _P, _I, _P, _I, _I, _P, _P, _P],
     "mi_linattn_fwd": [_I, _I, _I, _P, _P, _P, _P, _P],
     "mi_linattn_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mi_vq_partials": [_I],
+    "mi_vq_nearest_fwd": [_I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P],
+    "mi_vq_bwd": [_I, _I, _I, _P, _I, _P, _P, _F, _F, _P, _P, _I, _I, _P, _P],
+    "mi_vq_scatter_rows": [_I, _I, _I, _P, _I, _P, _P, _P],
     "mi_small_gemm": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P],
     "mi_small_gemm_supported": [_I, _I, _I, _I, _I, _I, _I],
     "mi_linattn_fwd_io": [_I, _I, _I, _P, _P, _P, _P, _I, _P],

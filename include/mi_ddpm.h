@@ -242,6 +242,23 @@ int mi_small_gemm(int ta, int tb, int I, int J, int K, const float* A, int lda, 
                   const float* bias, float* C, int ldc, int accumulate, int allow_split, void* stream);
 int mi_small_gemm_supported(int ta, int tb, int I, int J, int K, int lda, int ldb);
 
+/* ---- VQ-VAE codebook step (reference src/models/vqvae.py:24-43) ---------------
+ * Forward: for each of the M latent rows z[m][0..D) (row stride ldz) the nearest of the K codebook rows
+ * (torch.cdist + argmin: squared distances ||z||^2 + ||e||^2 - 2 z.e on the exact-fp32 matrix cores, lowest
+ * index on ties), idx[m], the gathered rows zq[m][0..D), and loss_partial[b] = sum over workgroup b's rows of
+ * ||z - zq||^2 (mi_vq_partials(M) floats; vq_loss = sum / (M*D), commit_loss = weight * the same).  D % 4 == 0, D <= 128.
+ * Backward of g_vq * mean((sg(z) - q)^2) + g_commit * mean((z - sg(q))^2):
+ *   dz (+)= g_commit * 2 (z - q) / (M D)   (dz may be null),   dcodebook[idx[m]] += g_vq * 2 (q - z_m) / (M D);
+ * g_dev (nullable) points at two device floats multiplied into (g_vq, g_commit): the upstream loss gradients without a
+ * host round trip.  mi_vq_scatter_rows: table[idx[m]] += src[m] -- what the gather `embedding[z_index]` (vqvae.py:37)
+ * passes back to the codebook when quant_z itself is differentiated. */
+int mi_vq_partials(int M);
+int mi_vq_nearest_fwd(int M, int D, int K, const float* z, int ldz, const float* codebook, int* idx, float* zq, int ldq,
+                      float* loss_partial, void* stream);
+int mi_vq_bwd(int M, int D, int K, const float* z, int ldz, const float* codebook, const int* idx, float g_vq, float g_commit,
+              const float* g_dev, float* dz, int lddz, int accumulate_dz, float* dcodebook, void* stream);
+int mi_vq_scatter_rows(int M, int D, int K, const float* src, int ld, const int* idx, float* table, void* stream);
+
 /* ---- small element-wise pieces ---------------------------------------------------------------- */
 /* SinusoidalPosEmb (ddpm.py:52-59): out[b][dim] = [sin(t f_j) | cos(t f_j)] */
 int mi_time_embed(int B, int dim, const int64_t* t, float* out, void* stream);

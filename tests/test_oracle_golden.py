@@ -152,3 +152,28 @@ def test_cfg2_eps_prediction(golden_dir):
     ref = _t(g["eps_hat"])
     rel = float((y - ref).norm() / ref.norm())
     assert rel < 1e-6, rel
+
+
+def test_vq_oracle_matches_reference_vectors(golden_dir):
+    """oracle/vq_oracle.py against the reference VectorQuantizer (vqvae.py:24-43) run by tools/gen_golden_vq.py."""
+    import numpy as np
+    from oracle import vq_oracle as V
+    g = np.load(os.path.join(golden_dir, "vq_kats.npz"))
+    for tag in ("small", "cfg4", "ragged"):
+        z = torch.from_numpy(g[f"{tag}.z"]).requires_grad_(True)
+        cb = torch.from_numpy(g[f"{tag}.codebook"]).requires_grad_(True)
+        beta = float(g[f"{tag}.beta"])
+        quant, vq_loss, commit_loss, idx = V.vq_forward(z, cb, beta)
+        assert torch.equal(idx, torch.from_numpy(g[f"{tag}.idx"])), tag
+        assert torch.equal(quant.detach(), torch.from_numpy(g[f"{tag}.quant"]))
+        assert abs(float(vq_loss) - float(g[f"{tag}.vq_loss"])) < 1e-6 * max(1.0, abs(float(vq_loss)))
+        assert abs(float(commit_loss) - float(g[f"{tag}.commit_loss"])) < 1e-6 * max(1.0, abs(float(commit_loss)))
+        (vq_loss + beta * commit_loss).backward()
+        assert torch.allclose(z.grad, torch.from_numpy(g[f"{tag}.dz"]), rtol=1e-5, atol=1e-9)
+        assert torch.allclose(cb.grad, torch.from_numpy(g[f"{tag}.dcodebook"]), rtol=1e-5, atol=1e-9)
+        # the explicit backward formulas the kernel implements
+        rows = V.rows_of(z.detach())
+        drows, dcode = V.vq_backward(rows, cb.detach(), idx, 1.0, beta * beta)
+        n, d, h, w = z.shape
+        assert torch.allclose(drows.reshape(n, h * w, d).permute(0, 2, 1).reshape(n, d, h, w), z.grad, rtol=1e-5, atol=1e-9)
+        assert torch.allclose(dcode, cb.grad, rtol=1e-5, atol=1e-9)
