@@ -29,6 +29,27 @@ __global__ void mish_bwd_kernel(size_t n, const float* __restrict__ x, const flo
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dx[i] = dy[i] * mish_grad_f(x[i]);
 }
 
+// ReLU on a flat vector, float4 body + scalar tail; y may alias x, dx may alias dy (VQ-VAE networks, src/networks/vqvae.py)
+__global__ void relu_fwd_kernel(size_t n, const float* __restrict__ x, float* __restrict__ y) {
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (size_t i = i0; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+    for (size_t i = 4 * n4 + i0; i < n; i += stride) y[i] = fmaxf(x[i], 0.f);
+}
+__global__ void relu_bwd_kernel(size_t n, const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, int accumulate) {
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (size_t i = i0; i < n4; i += stride) {
+        const float4 o = reinterpret_cast<const float4*>(y)[i], g = reinterpret_cast<const float4*>(dy)[i];
+        float4 r = {o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f};
+        if (accumulate) { const float4 a = reinterpret_cast<const float4*>(dx)[i]; r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w; }
+        reinterpret_cast<float4*>(dx)[i] = r;
+    }
+    for (size_t i = 4 * n4 + i0; i < n; i += stride) dx[i] = (accumulate ? dx[i] : 0.f) + (y[i] > 0.f ? dy[i] : 0.f);
+}
+
 __global__ void nchw_to_nhwc_kernel(int B, int C, int HW, const float* __restrict__ x, float* __restrict__ y, int ld) {
     size_t tot = (size_t)B * HW * ld;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
@@ -183,6 +204,18 @@ extern "C" int mi_mish_fwd(size_t n, const float* x, float* y, void* stream) {
 extern "C" int mi_mish_bwd(size_t n, const float* x, const float* dy, float* dx, void* stream) {
     MI_REQUIRE(n > 0 && x && dy && dx, "bad argument");
     hipLaunchKernelGGL(mish_bwd_kernel, dim3(nblocks(n)), dim3(TPB), 0, ST, n, x, dy, dx);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_relu_fwd(size_t n, const float* x, float* y, void* stream) {
+    MI_REQUIRE(n > 0 && x && y && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "bad argument");
+    hipLaunchKernelGGL(relu_fwd_kernel, dim3(nblocks((n + 3) / 4)), dim3(TPB), 0, ST, n, x, y);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_relu_bwd(size_t n, const float* y, const float* dy, float* dx, int accumulate, void* stream) {
+    MI_REQUIRE(n > 0 && y && dy && dx && (((uintptr_t)y | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0, "bad argument");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(nblocks((n + 3) / 4)), dim3(TPB), 0, ST, n, y, dy, dx, accumulate);
     MI_LAUNCH_CHECK();
     return 0;
 }

@@ -404,6 +404,23 @@ def mish_bwd(x, dy):
     return dx
 
 
+def relu_fwd(x, inplace=False):
+    """max(x, 0) on a dense tensor (any shape); inplace mirrors nn.ReLU(True)."""
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    y = x if inplace else torch.empty_like(x)
+    check(load_library().mi_relu_fwd(x.numel(), _p(x), _p(y), _stream()), "mi_relu_fwd")
+    return y
+
+
+def relu_bwd(y, dy, out=None, accumulate=False):
+    """dx (+)= dy where the ReLU OUTPUT y is positive; out=None allocates, out=dy works in place."""
+    assert y.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(dy) if out is None else out
+    check(load_library().mi_relu_bwd(y.numel(), _p(y), _p(dy), _p(dx), int(accumulate), _stream()), "mi_relu_bwd")
+    return dx
+
+
 def nchw_to_nhwc(x, ld=None):
     _need_gpu(x)
     B, Cc, H, W = x.shape

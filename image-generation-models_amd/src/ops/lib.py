@@ -78,6 +78,8 @@ SIGNATURES = {
     "mi_chan_layernorm_fwd_io": [_I, _I, _P, _I, _P, _P, _F, _P, _I, _I, _P],
     "mi_chan_layernorm_bwd_io": [_I, _I, _P, _I, _P, _F, _P, _I, _P, _I, _I, _P, _P, _I, _P],
     "mi_time_embed": [_I, _I, _P, _P, _P],
+    "mi_relu_fwd": [_Z, _P, _P, _P],
+    "mi_relu_bwd": [_Z, _P, _P, _P, _I, _P],
     "mi_mish_fwd": [_Z, _P, _P, _P],
     "mi_mish_bwd": [_Z, _P, _P, _P, _P],
     "mi_nchw_to_nhwc": [_I, _I, _I, _P, _P, _I, _P],

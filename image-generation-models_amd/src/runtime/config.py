@@ -208,7 +208,12 @@ _ALIASES = {
 }
 
 
+_ROOT = __name__.rsplit(".src.runtime", 1)[0] if ".src.runtime" in __name__ else ""
+
+
 def locate(path: str):
+    if _ROOT and path.startswith("src."):          # package imported under a parent name (tests): keep ONE copy of each module
+        path = _ROOT + "." + path
     try:
         mod, _, name = path.rpartition(".")
         return getattr(importlib.import_module(mod), name)

@@ -10,9 +10,12 @@ from ..ops import functional as K
 
 
 class FlatAdam(torch.optim.Optimizer):
+    """`net` is one module exposing flat_params / flat_grads / mark_params_dirty, or a list of them (one launch each)."""
+
     def __init__(self, net, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
-        self.net = net
-        super().__init__(list(net.parameters()), dict(lr=lr, betas=betas, eps=eps))
+        self.nets = list(net) if isinstance(net, (list, tuple)) else [net]
+        self.net = self.nets[0]
+        super().__init__([p for n in self.nets for p in n.parameters()], dict(lr=lr, betas=betas, eps=eps))
         self.grad_scale = grad_scale
         self._m = None
         self._v = None
@@ -25,15 +28,24 @@ class FlatAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        p, g = self.net.flat_params, self.net.flat_grads
-        if self._m is None or self._m.device != p.device:
-            self._m = torch.zeros_like(p)
-            self._v = torch.zeros_like(p)
         grp = self.param_groups[0]
         self._step += 1
-        K.adam_step(p, g, self._m, self._v, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], self._step,
-                    self.grad_scale)
-        self.net.mark_params_dirty()
+        if len(self.nets) == 1:
+            p, g = self.net.flat_params, self.net.flat_grads
+            if self._m is None or self._m.device != p.device:
+                self._m = torch.zeros_like(p)
+                self._v = torch.zeros_like(p)
+            K.adam_step(p, g, self._m, self._v, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], self._step,
+                        self.grad_scale)
+            self.net.mark_params_dirty()
+            return loss
+        if self._m is None or self._m[0].device != self.nets[0].flat_params.device:
+            self._m = [torch.zeros_like(n.flat_params) for n in self.nets]
+            self._v = [torch.zeros_like(n.flat_params) for n in self.nets]
+        for n, m, v in zip(self.nets, self._m, self._v):
+            K.adam_step(n.flat_params, n.flat_grads, m, v, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], self._step,
+                        self.grad_scale)
+            n.mark_params_dirty()
         return loss
 
     def state_dict(self):

@@ -33,6 +33,26 @@ class _Checkpoint:
         self.best_model_path = ""
 
 
+class _ReducerGroup:
+    """begin / finish / grad_scale over several FlatGradReducers (no overlap hooks: finish() reduces each buffer whole)."""
+
+    def __init__(self, reducers):
+        self.reducers = reducers
+
+    @property
+    def grad_scale(self):
+        return self.reducers[0].grad_scale
+
+    def begin(self):
+        for r in self.reducers:
+            r.begin()
+
+    def finish(self):
+        for r in self.reducers:
+            r.range_ready(0, r.flat.numel())           # the whole buffer is final once backward returned
+            r.finish()
+
+
 class Trainer:
     def __init__(self, devices=1, max_epochs: int = 20, check_val_every_n_epoch: int = 1, enable_model_summary: bool = False,
                  callbacks: Optional[List[Callback]] = None, logger=None, precision: str = "32", accelerator: str = "auto",
@@ -107,6 +127,10 @@ class Trainer:
             broadcast_parameters(net.flat_params)
             self._reducer = FlatGradReducer(net.flat_grads)
             net.grad_ready_hook = self._reducer.range_ready
+        elif hasattr(model, "flat_nets"):              # several small flat buffers (VQ-VAE): reduced when backward is done
+            self._reducer = _ReducerGroup([FlatGradReducer(n.flat_grads) for n in model.flat_nets()])
+            for n in model.flat_nets():
+                broadcast_parameters(n.flat_params)
 
     # ------------------------------------------------------------------ loops
     def fit(self, model, datamodule=None, train_dataloaders=None, val_dataloaders=None):

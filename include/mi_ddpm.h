@@ -265,6 +265,10 @@ int mi_time_embed(int B, int dim, const int64_t* t, float* out, void* stream);
 /* Mish on a flat vector (ddpm.py:62-64) and its backward */
 int mi_mish_fwd(size_t n, const float* x, float* y, void* stream);
 int mi_mish_bwd(size_t n, const float* x, const float* dy, float* dx, void* stream);
+/* ReLU on a flat (dense) vector: y = max(x, 0), y may alias x (nn.ReLU(True), src/networks/vqvae.py:16-20,48,76);
+ * backward from the OUTPUT: dx (+)= y > 0 ? dy : 0, dx may alias dy.  16-byte aligned pointers. */
+int mi_relu_fwd(size_t n, const float* x, float* y, void* stream);
+int mi_relu_bwd(size_t n, const float* y, const float* dy, float* dx, int accumulate, void* stream);
 /* NCHW <-> NHWC(ld) */
 int mi_nchw_to_nhwc(int B, int C, int HW, const float* x, float* y, int ld, void* stream);
 int mi_nhwc_to_nchw(int B, int C, int HW, const float* x, int ld, float* y, void* stream);

@@ -157,3 +157,33 @@ def test_flat_grad_reducer_gloo_world2():
         assert launched[0][1] == n and launched[-1][0] == 0      # covers [0, n) back to front
         assert all(a[0] == b[1] for a, b in zip(launched, launched[1:]))
         assert len(launched) > 3                                 # really bucketed
+
+
+def test_compose_vqvae_and_multi_buffer_reducer_gloo_world2():
+    """experiment=vqvae/cifar10 composes to the reference's values; the trainer's reducer group averages several flat
+    gradient buffers across 2 gloo ranks."""
+    from src.runtime.config import Composer
+    c = Composer(os.path.join(PKG, "configs")).compose("config", ["experiment=vqvae/cifar10"])
+    assert c.model._target_ == "src.models.vqvae.VQVAE" and c.model.latent_dim == 64 and c.model.beta == 0.25 and c.model.lr == 0.001
+    assert c.model.encoder._target_ == "src.networks.vqvae.Encoder" and c.model.decoder._target_ == "src.networks.vqvae.Decoder"
+    assert c.model.encoder.input_channel is None and c.datamodule.batch_size == 128 and c.exp_name == "vqvae/cifar10"
+    import torch.multiprocessing as mp
+    mp.spawn(_reducer_group_worker, args=(2, 31500 + os.getpid() % 2000), nprocs=2, join=True)
+
+
+def _reducer_group_worker(rank, world, port):
+    import torch.distributed as dist
+    from src.runtime.ddp import FlatGradReducer
+    from src.runtime.trainer import _ReducerGroup
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bufs = [torch.full((n,), float(rank + 1)) * torch.arange(1, n + 1) for n in (1000, 37, 4096)]
+        grp = _ReducerGroup([FlatGradReducer(b) for b in bufs])
+        grp.begin()
+        grp.finish()
+        for b in bufs:
+            assert torch.equal(b, 3.0 * torch.arange(1, b.numel() + 1))          # SUM over ranks (1 + 2); the optimizer divides
+        assert grp.grad_scale == 0.5
+    finally:
+        dist.destroy_process_group()

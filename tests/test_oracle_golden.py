@@ -177,3 +177,40 @@ def test_vq_oracle_matches_reference_vectors(golden_dir):
         n, d, h, w = z.shape
         assert torch.allclose(drows.reshape(n, h * w, d).permute(0, 2, 1).reshape(n, d, h, w), z.grad, rtol=1e-5, atol=1e-9)
         assert torch.allclose(dcode, cb.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_vqvae_oracle_matches_reference_vectors(golden_dir):
+    """oracle/vqvae_oracle.py against the reference VQVAE.training_step / forward run by tools/gen_golden_vqvae.py."""
+    import importlib
+    import numpy as np
+    from oracle import vqvae_oracle as VO
+    g = np.load(os.path.join(golden_dir, "vqvae_kats.npz"))
+    # tiny: stored state_dict
+    sd = {k[len("tiny.sd."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("tiny.sd.")}
+    imgs = torch.from_numpy(g["tiny.imgs"])
+    (total, recon, vq, commit, idx), grads = VO.training_grads(sd, imgs, 0.25)
+    for name, val in (("total", total), ("recon", recon), ("vq", vq), ("commit", commit)):
+        assert abs(float(val) - float(g["tiny." + name])) <= 1e-6 * abs(float(g["tiny." + name])), name
+    assert torch.equal(idx, torch.from_numpy(g["tiny.idx"]))
+    assert torch.allclose(VO.forward(sd, imgs, 0.25), torch.from_numpy(g["tiny.forward"]), rtol=1e-5, atol=1e-6)
+    for k, gr in grads.items():
+        assert torch.allclose(gr, torch.from_numpy(g["tiny.grad." + k]), rtol=1e-4, atol=1e-7), k
+    # cfg4: weights are the seeded default init, reproduced by the host-side modules (construction order and init rule)
+    M = importlib.import_module("image-generation-models_amd.src.models.vqvae")
+    torch.manual_seed(1236)
+    m = M.VQVAE({"width": 32, "height": 32, "channels": 3, "transforms": {"normalize": True}},
+                encoder={"_target_": "src.networks.vqvae.Encoder"}, decoder={"_target_": "src.networks.vqvae.Decoder"},
+                latent_dim=64, beta=0.25)
+    with torch.no_grad():
+        m.vector_quntizer.embedding.mul_(512 * 0.05)
+    assert [k for k, _ in m.named_parameters()] == list(g["cfg4.names"])
+    ws = np.array([[float(p.detach().double().sum()), float(p.detach().double().abs().sum())] for _, p in m.named_parameters()])
+    assert np.array_equal(ws, g["cfg4.wstats"])                       # same seeded weights, bit for bit
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    imgs = torch.from_numpy(g["cfg4.imgs"])
+    (total, recon, vq, commit, idx), grads = VO.training_grads(sd, imgs, 0.25)
+    for name, val in (("total", total), ("recon", recon), ("vq", vq), ("commit", commit)):
+        assert abs(float(val) - float(g["cfg4." + name])) <= 1e-6 * abs(float(g["cfg4." + name])), name
+    assert torch.equal(idx, torch.from_numpy(g["cfg4.idx"]))
+    for (k, gr), ref in zip(grads.items(), g["cfg4.gstats"]):
+        assert abs(float(gr.double().norm()) - ref[1]) <= 1e-4 * ref[1], k
