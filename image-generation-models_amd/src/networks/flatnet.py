@@ -53,6 +53,11 @@ class FlatNet(nn.Module):
         if bias:
             self._entries.append(_Entry(pre + "bias", (o,), "plain", "ubias", fan, 0))
 
+    def _norm_params(self, pre, c):
+        """nn.GroupNorm affine pair (weight = 1, bias = 0: no random draw)."""
+        self._entries.append(_Entry(pre + "weight", (c,), "plain", "one", 0, 0))
+        self._entries.append(_Entry(pre + "bias", (c,), "plain", "zero", 0, 0))
+
     def _alias(self, parent: str, name: str, target: str):
         """Register module `parent.target` a second time as `parent.name` (the reference's `[layer] * n`)."""
         self._aliases.append((parent, name, target))
@@ -72,6 +77,8 @@ class FlatNet(nn.Module):
             elif e.init == "ubias":
                 bound = 1 / math.sqrt(e.fan_in) if e.fan_in > 0 else 0
                 e.logical_view(flat).copy_(torch.empty(e.shape).uniform_(-bound, bound))
+            elif e.init == "one":
+                e.logical_view(flat).fill_(1.0)
         object.__setattr__(self, "_gflat", None)
         object.__setattr__(self, "_dirty", 0)
         object.__setattr__(self, "_anchor", torch.zeros(1, requires_grad=True))
@@ -171,12 +178,18 @@ class FlatNet(nn.Module):
                             out_hw=(oh, ow), mode=_mode_id(self.compute_mode), bias=self._sv[pre + "bias"] if bias else None,
                             residual=residual)
 
-    def _conv_bwd(self, dy, inp, pre, k, stride=1, pad=0, transposed=False, bias=True, want_dx=True, dx_out=None, accumulate=False):
-        w, gv, mode = self._sv[pre + "weight"], self._gv, _mode_id(self.compute_mode)
+    def _conv_bwd(self, dy, inp, pre, k, stride=1, pad=0, transposed=False, bias=True, want_dx=True, dx_out=None, accumulate=False,
+                  want_dw=True, in_hw=None):
+        """Gradients of y = conv(inp): weight/bias gradients accumulate into the flat gradient buffer (want_dw), the input
+        gradient is returned (want_dx).  inp may be None when only the input gradient is wanted (pass in_hw)."""
+        w, mode = self._sv[pre + "weight"], _mode_id(self.compute_mode)
         kh, kw, ci, co = w.shape
-        ih, iw = inp.shape[1], inp.shape[2]
+        ih, iw = in_hw if inp is None else (inp.shape[1], inp.shape[2])
         oh, ow = dy.shape[1], dy.shape[2]
-        if transposed:       # dW[tap][ci][co] = sum over input pixels x[j] * dy[scatter(j, tap)]
+        gv = self._gv if want_dw else None
+        if not want_dw:
+            pass
+        elif transposed:       # dW[tap][ci][co] = sum over input pixels x[j] * dy[scatter(j, tap)]
             K.conv_wgrad(inp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=False, Ci=ci, Cj=co,
                          grid_g=(oh, ow), grid_d=(ih, iw), mode=mode)
             if bias:

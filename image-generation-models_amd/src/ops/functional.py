@@ -421,6 +421,86 @@ def relu_bwd(y, dy, out=None, accumulate=False):
     return dx
 
 
+# --------------------------------------------------------------------------- WGAN-GP operators (critic_ops.hip)
+def _dense(*ts):
+    for t in ts:
+        assert t is None or (t.is_contiguous() and t.dtype == torch.float32), "dense fp32 tensor expected"
+
+
+def sample_norm_fwd(x, gamma, beta, eps=1e-5):
+    """nn.GroupNorm(1, C) on a dense NHWC tensor -> (y, stats[N,2])."""
+    _need_gpu(x); _dense(x)
+    N, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty((N, 2), device=x.device, dtype=torch.float32)
+    check(load_library().mi_sample_norm_fwd(N, H * W, Cc, _p(x), _p(gamma), _p(beta), _p(y), _p(stats), eps, _stream()), "mi_sample_norm_fwd")
+    return y, stats
+
+
+def sample_norm_bwd(x, stats, gamma, dy, dgamma=None, dbeta=None, extra=None, out=None):
+    _dense(x, dy, extra, out)
+    N, H, W, Cc = x.shape
+    dx = torch.empty_like(x) if out is None else out
+    check(load_library().mi_sample_norm_bwd(N, H * W, Cc, _p(x), _p(stats), _p(gamma), _p(dy), _p(extra), _p(dx), _p(dgamma), _p(dbeta),
+                                            _stream()), "mi_sample_norm_bwd")
+    return dx
+
+
+def sample_norm_bwd2(x, stats, gamma, dy, u, dgamma=None):
+    """Backward of sample_norm_bwd: (adjoint wrt dy, adjoint wrt x); dgamma accumulated."""
+    _dense(x, dy, u)
+    N, H, W, Cc = x.shape
+    adj_dy, adj_x = torch.empty_like(x), torch.empty_like(x)
+    check(load_library().mi_sample_norm_bwd2(N, H * W, Cc, _p(x), _p(stats), _p(gamma), _p(dy), _p(u), _p(adj_dy), _p(adj_x), _p(dgamma),
+                                             _stream()), "mi_sample_norm_bwd2")
+    return adj_dy, adj_x
+
+
+def leaky_relu_fwd(x, slope=0.2, inplace=False):
+    _need_gpu(x); _dense(x)
+    y = x if inplace else torch.empty_like(x)
+    check(load_library().mi_leaky_relu_fwd(x.numel(), _p(x), _p(y), slope, _stream()), "mi_leaky_relu_fwd")
+    return y
+
+
+def leaky_relu_bwd(y, dy, slope=0.2, out=None):
+    _dense(y, dy, out)
+    dx = torch.empty_like(dy) if out is None else out
+    check(load_library().mi_leaky_relu_bwd(y.numel(), _p(y), _p(dy), _p(dx), slope, _stream()), "mi_leaky_relu_bwd")
+    return dx
+
+
+def tanh_fwd(x, inplace=False):
+    _need_gpu(x); _dense(x)
+    y = x if inplace else torch.empty_like(x)
+    check(load_library().mi_tanh_fwd(x.numel(), _p(x), _p(y), _stream()), "mi_tanh_fwd")
+    return y
+
+
+def tanh_bwd(y, dy, out=None):
+    _dense(y, dy, out)
+    dx = torch.empty_like(dy) if out is None else out
+    check(load_library().mi_tanh_bwd(y.numel(), _p(y), _p(dy), _p(dx), _stream()), "mi_tanh_bwd")
+    return dx
+
+
+def lerp_rows(a, b, e):
+    """e[s] * a[s] + (1 - e[s]) * b[s] over the leading dimension."""
+    _need_gpu(a); _dense(a, b)
+    out = torch.empty_like(a)
+    check(load_library().mi_lerp_rows(a.shape[0], a[0].numel(), _p(a), _p(b), _p(e), _p(out), _stream()), "mi_lerp_rows")
+    return out
+
+
+def gp_penalty(g, want_grad=True, scale=1.0, scale_dev=None):
+    """(mean_s (||g_s|| - 1)^2, scale * d penalty / d g) for a dense [N, ...] gradient tensor."""
+    _need_gpu(g); _dense(g)
+    pen = torch.zeros((), device=g.device, dtype=torch.float32)
+    u = torch.empty_like(g) if want_grad else None
+    check(load_library().mi_gp_penalty(g.shape[0], g[0].numel(), _p(g), _p(pen), _p(u), scale, _p(scale_dev), _stream()), "mi_gp_penalty")
+    return pen, u
+
+
 def nchw_to_nhwc(x, ld=None):
     _need_gpu(x)
     B, Cc, H, W = x.shape

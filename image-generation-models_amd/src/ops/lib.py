@@ -78,6 +78,16 @@ SIGNATURES = {
     "mi_chan_layernorm_fwd_io": [_I, _I, _P, _I, _P, _P, _F, _P, _I, _I, _P],
     "mi_chan_layernorm_bwd_io": [_I, _I, _P, _I, _P, _F, _P, _I, _P, _I, _I, _P, _P, _I, _P],
     "mi_time_embed": [_I, _I, _P, _P, _P],
+    "mi_sample_norm_supported": [_I, _I, _I],
+    "mi_sample_norm_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P],
+    "mi_sample_norm_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mi_sample_norm_bwd2": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mi_leaky_relu_fwd": [_Z, _P, _P, _F, _P],
+    "mi_leaky_relu_bwd": [_Z, _P, _P, _P, _F, _P],
+    "mi_tanh_fwd": [_Z, _P, _P, _P],
+    "mi_tanh_bwd": [_Z, _P, _P, _P, _P],
+    "mi_lerp_rows": [_I, _Z, _P, _P, _P, _P, _P],
+    "mi_gp_penalty": [_I, _Z, _P, _P, _P, _F, _P, _P],
     "mi_relu_fwd": [_Z, _P, _P, _P],
     "mi_relu_bwd": [_Z, _P, _P, _P, _I, _P],
     "mi_mish_fwd": [_Z, _P, _P, _P],

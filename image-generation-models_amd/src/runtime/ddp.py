@@ -74,3 +74,13 @@ def broadcast_parameters(flat_params: torch.Tensor, src: int = 0, group=None):
     """DDP construction-time parameter broadcast: one collective over the flat buffer."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat_params, src=src, group=group)   # in-place torch op: bumps flat._version for the bf16 shadows
+
+
+def allreduce_flat_grads(nets, group=None):
+    """Sum the flat gradient buffers of `nets` over the ranks (models that step their own optimizers call this between
+    backward and step; the fused Adam divides by the world size through its grad_scale)."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    works = [dist.all_reduce(n.flat_grads, op=dist.ReduceOp.SUM, group=group, async_op=True) for n in nets]
+    for w in works:
+        w.wait()

@@ -50,6 +50,20 @@ class LightningModule(nn.Module):
             return p.device
         return torch.device("cpu")
 
+    # manual optimization (automatic_optimization = False): the two calls the reference's GAN models use
+    automatic_optimization = True
+
+    def optimizers(self):
+        opts = getattr(self, "_optimizers", None)
+        if opts is None:
+            cfg = self.configure_optimizers()
+            opts = list(cfg) if isinstance(cfg, (list, tuple)) else [cfg]
+            object.__setattr__(self, "_optimizers", opts)
+        return opts if len(opts) > 1 else opts[0]
+
+    def manual_backward(self, loss, *args, **kwargs):
+        loss.backward(*args, **kwargs)
+
     def log(self, name, value, **_):
         self._logged[name] = value
         if self.trainer is not None:

@@ -128,9 +128,10 @@ class Trainer:
             self._reducer = FlatGradReducer(net.flat_grads)
             net.grad_ready_hook = self._reducer.range_ready
         elif hasattr(model, "flat_nets"):              # several small flat buffers (VQ-VAE): reduced when backward is done
-            self._reducer = _ReducerGroup([FlatGradReducer(n.flat_grads) for n in model.flat_nets()])
             for n in model.flat_nets():
                 broadcast_parameters(n.flat_params)
+            if getattr(model, "automatic_optimization", True):     # manual-optimization models reduce their own gradients
+                self._reducer = _ReducerGroup([FlatGradReducer(n.flat_grads) for n in model.flat_nets()])
 
     # ------------------------------------------------------------------ loops
     def fit(self, model, datamodule=None, train_dataloaders=None, val_dataloaders=None):
@@ -153,7 +154,14 @@ class Trainer:
             train_dataloaders = datamodule.train_dataloader()
             val_dataloaders = datamodule.val_dataloader()
         optimizer = model.configure_optimizers()
-        if self._reducer is not None and hasattr(optimizer, "grad_scale"):
+        manual = not getattr(model, "automatic_optimization", True)
+        if manual:                                     # the model steps its own optimizers (GANs); it also averages its gradients
+            opts = list(optimizer) if isinstance(optimizer, (list, tuple)) else [optimizer]
+            object.__setattr__(model, "_optimizers", opts)
+            for o in opts:
+                if self.world_size > 1 and hasattr(o, "grad_scale"):
+                    o.grad_scale = 1.0 / self.world_size
+        elif self._reducer is not None and hasattr(optimizer, "grad_scale"):
             optimizer.grad_scale = self._reducer.grad_scale
         self.optimizer = optimizer
         bar = next((c for c in self.callbacks if isinstance(c, ProgressBar)), None)
@@ -174,14 +182,17 @@ class Trainer:
                 if self.limit_train_batches is not None and i >= self.limit_train_batches:
                     break
                 batch = self._to_device(batch, device)
-                optimizer.zero_grad()
-                if self._reducer is not None:
-                    self._reducer.begin()
-                loss = model.training_step(batch, i)
-                loss.backward()
-                if self._reducer is not None:
-                    self._reducer.finish()
-                optimizer.step()
+                if manual:
+                    model.training_step(batch, i)
+                else:
+                    optimizer.zero_grad()
+                    if self._reducer is not None:
+                        self._reducer.begin()
+                    loss = model.training_step(batch, i)
+                    loss.backward()
+                    if self._reducer is not None:
+                        self._reducer.finish()
+                    optimizer.step()
                 self.global_step += 1
                 if self.global_step % self.log_every_n_steps == 0:
                     self._flush_metrics()
@@ -232,8 +243,9 @@ class Trainer:
         ckpt = {"state_dict": sd, "epoch": self.current_epoch, "global_step": self.global_step,
                 "hyper_parameters": plain(dict(getattr(model, "hparams", {})))}
         opt = getattr(self, "optimizer", None)
-        if opt is not None and hasattr(opt, "state_dict"):
-            ckpt["optimizer_states"] = [opt.state_dict()]
+        opts = list(opt) if isinstance(opt, (list, tuple)) else [opt]
+        if all(o is not None and hasattr(o, "state_dict") for o in opts):
+            ckpt["optimizer_states"] = [o.state_dict() for o in opts]
         torch.save(ckpt, path)
         self.checkpoint_callback.best_model_path = os.path.abspath(path)
 

@@ -259,6 +259,31 @@ int mi_vq_bwd(int M, int D, int K, const float* z, int ldz, const float* codeboo
               const float* g_dev, float* dz, int lddz, int accumulate_dz, float* dcodebook, void* stream);
 int mi_vq_scatter_rows(int M, int D, int K, const float* src, int ld, const int* idx, float* table, void* stream);
 
+/* ---- WGAN-GP operators (reference src/models/wgan_gp.py:62-107, src/networks/basic.py:9-40) -------------
+ * Sample norm = nn.GroupNorm(1, C) (`norm_type="layer"`, forced at wgan_gp.py:30-31) on dense NHWC tensors [N][P][C],
+ * C % 4 == 0 and 2048 % C == 0; stats = [N][2] (mean, rstd).
+ *   fwd : y = gamma (x - mean) rstd + beta
+ *   bwd : dx = dL/dx (+ extra_dx when non-null; dx may alias dy); dgamma, dbeta accumulated (nullable)
+ *   bwd2: the backward of bwd, for the gradient penalty's create_graph=True (wgan_gp.py:89-96): given the adjoint u of dx,
+ *         adj_dy = d<u,dx>/d dy, adj_x = d<u,dx>/d x, dgamma += d<u,dx>/d gamma. */
+int mi_sample_norm_supported(int N, int P, int C);
+int mi_sample_norm_fwd(int N, int P, int C, const float* x, const float* gamma, const float* beta, float* y, float* stats, float eps,
+                       void* stream);
+int mi_sample_norm_bwd(int N, int P, int C, const float* x, const float* stats, const float* gamma, const float* dy, const float* extra_dx,
+                       float* dx, float* dgamma, float* dbeta, void* stream);
+int mi_sample_norm_bwd2(int N, int P, int C, const float* x, const float* stats, const float* gamma, const float* dy, const float* u,
+                        float* adj_dy, float* adj_x, float* dgamma, void* stream);
+/* LeakyReLU(slope) / Tanh on dense vectors (n % 4 == 0); backward from the OUTPUT y; in-place allowed (y == x, dx == dy). */
+int mi_leaky_relu_fwd(size_t n, const float* x, float* y, float slope, void* stream);
+int mi_leaky_relu_bwd(size_t n, const float* y, const float* dy, float* dx, float slope, void* stream);
+int mi_tanh_fwd(size_t n, const float* x, float* y, void* stream);
+int mi_tanh_bwd(size_t n, const float* y, const float* dy, float* dx, void* stream);
+/* out[s][i] = e[s] a[s][i] + (1 - e[s]) b[s][i], s < N, i < per (wgan_gp.py:84-87) */
+int mi_lerp_rows(int N, size_t per, const float* a, const float* b, const float* e, float* out, void* stream);
+/* gradient penalty (wgan_gp.py:95-97): *penalty += mean_s (||g_s||_2 - 1)^2 (nullable) and, when u is non-null,
+ * u_s = scale * (scale_dev ? *scale_dev : 1) * d penalty / d g_s. */
+int mi_gp_penalty(int N, size_t per, const float* g, float* penalty, float* u, float scale, const float* scale_dev, void* stream);
+
 /* ---- small element-wise pieces ---------------------------------------------------------------- */
 /* SinusoidalPosEmb (ddpm.py:52-59): out[b][dim] = [sin(t f_j) | cos(t f_j)] */
 int mi_time_embed(int B, int dim, const int64_t* t, float* out, void* stream);

@@ -133,7 +133,7 @@ def _ddp_worker(rank, world, port, q):
         lo = max(0, hi - 7919)
         red.range_ready(lo, hi); hi = lo
     red.finish()
-    q.put((rank, float(params.sum()), flat.clone(), list(red.launched), red.grad_scale))
+    q.put((rank, float(params.sum()), flat.numpy().copy(), list(red.launched), red.grad_scale))   # by value: the worker may exit first
     dist.destroy_process_group()
 
 
@@ -153,7 +153,7 @@ def test_flat_grad_reducer_gloo_world2():
     want = torch.arange(n, dtype=torch.float32) * 3            # sum over ranks; Adam applies grad_scale = 1/2
     for rank, psum, flat, launched, scale in res:
         assert psum == n * 1.0                                   # parameters broadcast from rank 0
-        assert torch.equal(flat, want) and scale == 0.5
+        assert torch.equal(torch.from_numpy(flat), want) and scale == 0.5
         assert launched[0][1] == n and launched[-1][0] == 0      # covers [0, n) back to front
         assert all(a[0] == b[1] for a, b in zip(launched, launched[1:]))
         assert len(launched) > 3                                 # really bucketed

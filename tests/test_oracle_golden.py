@@ -214,3 +214,31 @@ def test_vqvae_oracle_matches_reference_vectors(golden_dir):
     assert torch.equal(idx, torch.from_numpy(g["cfg4.idx"]))
     for (k, gr), ref in zip(grads.items(), g["cfg4.gstats"]):
         assert abs(float(gr.double().norm()) - ref[1]) <= 1e-4 * ref[1], k
+
+
+def test_wgan_oracle_matches_reference_vectors(golden_dir):
+    """oracle/wgan_oracle.py against the reference WGAN.training_step (both branches) run by tools/gen_golden_wgan.py."""
+    import numpy as np
+    from oracle import wgan_oracle as WO
+    g = np.load(os.path.join(golden_dir, "wgan_kats.npz"))
+    for tag, k0 in (("c64", 4), ("c32", 2)):
+        sd = {k[len(tag) + 5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".sd0.")}
+        sd_g = {k[len("generator."):]: v for k, v in sd.items() if k.startswith("generator.")}
+        sd_d = {k[len("discriminator."):]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("discriminator.")}
+        imgs = torch.from_numpy(g[tag + ".imgs"])
+        d_loss, real_loss, fake_loss, pen = WO.critic_step(sd_g, sd_d, imgs, torch.from_numpy(g[tag + ".z_c"]), torch.from_numpy(g[tag + ".lerp"]))
+        d_loss.backward()
+        for key, val in (("train_loss/d_loss", d_loss), ("train_log/real_logit", -real_loss), ("train_log/fake_logit", fake_loss),
+                         ("train_log/gradient_panelty", pen)):
+            ref = float(g[f"{tag}.log.{key}"])
+            assert abs(float(val) - ref) <= 1e-5 * max(1.0, abs(ref)), (tag, key)
+        for k, v in sd_d.items():
+            assert torch.allclose(v.grad, torch.from_numpy(g[f"{tag}.dgrad.{k}"]), rtol=1e-4, atol=1e-6), (tag, k)
+        post = {k: torch.from_numpy(g[f"{tag}.dpost.{k}"]) for k in sd_d}
+        leaf_g = {k: v.clone().requires_grad_(True) for k, v in sd_g.items()}
+        g_loss = WO.generator_step(leaf_g, post, torch.from_numpy(g[tag + ".z_g"]))
+        g_loss.backward()
+        ref = float(g[f"{tag}.log.train_loss/g_loss"])
+        assert abs(float(g_loss) - ref) <= 1e-5 * max(1.0, abs(ref))
+        for k, v in leaf_g.items():
+            assert torch.allclose(v.grad, torch.from_numpy(g[f"{tag}.ggrad.{k}"]), rtol=1e-4, atol=1e-7), (tag, k)
