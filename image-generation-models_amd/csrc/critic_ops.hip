@@ -24,10 +24,17 @@ constexpr int SN_T = 512;
 
 __device__ __forceinline__ float hsum(f32x4 v) { return v.x + v.y + v.z + v.w; }
 
-// sum over the workgroup of NV values per thread; every thread gets the results.  red: NV * 8 floats.
-template <int NV> __device__ __forceinline__ void block_sums(float (&v)[NV], float* red) {
+// Sum over the workgroup of NV values per thread; every thread gets the results.  red: NV * 8 doubles.
+// The sample statistics are accumulated in fp64: the second-order formulas subtract nearly equal sums (A below, and
+// E[x^2] - mean^2), and an fp32 accumulation of 32k terms loses exactly the digits those differences keep.
+__device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int NV> __device__ __forceinline__ void block_sums(double (&v)[NV], double* red) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum_d(v[i]);
     __syncthreads();
     if ((threadIdx.x & 63) == 0)
 #pragma unroll
@@ -35,7 +42,7 @@ template <int NV> __device__ __forceinline__ void block_sums(float (&v)[NV], flo
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        float s = 0.f;
+        double s = 0.0;
 #pragma unroll
         for (int w = 0; w < SN_T / 64; ++w) s += red[i * 8 + w];
         v[i] = s;
@@ -58,15 +65,15 @@ __device__ __forceinline__ void channel_reduce(f32x4 acc, int Q, float* lds4 /* 
 __global__ __launch_bounds__(SN_T) void sample_norm_fwd_kernel(int P, int C, const float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ y,
                                                               float* __restrict__ stats, float eps) {
-    __shared__ float red[16];
+    __shared__ double red[16];
     const int Q = C / 4, n4 = P * Q, t = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * P * C;
     const f32x4* xs = reinterpret_cast<const f32x4*>(x + base);
-    float s[2] = {0.f, 0.f};
-    for (int e = t; e < n4; e += SN_T) { const f32x4 v = xs[e]; s[0] += hsum(v); s[1] += hsum(v * v); }
+    double s[2] = {0.0, 0.0};
+    for (int e = t; e < n4; e += SN_T) { const f32x4 v = xs[e]; s[0] += (double)hsum(v); s[1] += (double)hsum(v * v); }
     block_sums<2>(s, red);
-    const float n = (float)P * C, mean = s[0] / n;
-    const float var = fmaxf(s[1] / n - mean * mean, 0.f), rstd = rsqrtf(var + eps);
+    const double nd = (double)P * C, meand = s[0] / nd, vard = fmax(s[1] / nd - meand * meand, 0.0);
+    const float mean = (float)meand, rstd = (float)(1.0 / sqrt(vard + (double)eps));
     if (t == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
     const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[t % Q], b = reinterpret_cast<const f32x4*>(beta)[t % Q];
     f32x4* ys = reinterpret_cast<f32x4*>(y + base);
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(SN_T) void sample_norm_fwd_kernel(int P, int C, con
 __global__ __launch_bounds__(SN_T) void sample_norm_bwd_kernel(int P, int C, const float* __restrict__ x, const float* __restrict__ stats,
                                                               const float* __restrict__ gamma, const float* dy, const float* __restrict__ extra,
                                                               float* dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float red[16];
+    __shared__ double red[16];
     __shared__ __attribute__((aligned(16))) float lds4[SN_T * 4];
     const int Q = C / 4, n4 = P * Q, t = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * P * C;
@@ -85,15 +92,16 @@ __global__ __launch_bounds__(SN_T) void sample_norm_bwd_kernel(int P, int C, con
     const f32x4* xs = reinterpret_cast<const f32x4*>(x + base);
     const f32x4* ds = reinterpret_cast<const f32x4*>(dy + base);
     const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[t % Q];
-    float s[2] = {0.f, 0.f};
+    double s[2] = {0.0, 0.0};
     f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
     for (int e = t; e < n4; e += SN_T) {
         const f32x4 xh = (xs[e] - mean) * rstd, d = ds[e], gh = g * d;
-        s[0] += hsum(gh); s[1] += hsum(gh * xh);
+        s[0] += (double)hsum(gh); s[1] += (double)hsum(gh * xh);
         ag += d * xh; ab += d;
     }
     block_sums<2>(s, red);
-    const float n = (float)P * C, gb = s[0] / n, mg = s[1] / n;
+    const double nd = (double)P * C;
+    const float gb = (float)(s[0] / nd), mg = (float)(s[1] / nd);
     const f32x4* ex = extra ? reinterpret_cast<const f32x4*>(extra + base) : nullptr;
     f32x4* os = reinterpret_cast<f32x4*>(dx + base);
     for (int e = t; e < n4; e += SN_T) {
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(SN_T) void sample_norm_bwd2_kernel(int P, int C, co
                                                                const float* __restrict__ gamma, const float* __restrict__ dy,
                                                                const float* __restrict__ u, float* __restrict__ adj_dy, float* __restrict__ adj_x,
                                                                float* __restrict__ dgamma) {
-    __shared__ float red[40];
+    __shared__ double red[40];
     __shared__ __attribute__((aligned(16))) float lds4[SN_T * 4];
     const int Q = C / 4, n4 = P * Q, t = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * P * C;
@@ -119,15 +127,17 @@ __global__ __launch_bounds__(SN_T) void sample_norm_bwd2_kernel(int P, int C, co
     const f32x4* ds = reinterpret_cast<const f32x4*>(dy + base);
     const f32x4* us = reinterpret_cast<const f32x4*>(u + base);
     const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[t % Q];
-    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (int e = t; e < n4; e += SN_T) {
         const f32x4 xh = (xs[e] - mean) * rstd, gh = g * ds[e], uv = us[e];
-        s[0] += hsum(gh); s[1] += hsum(gh * xh); s[2] += hsum(uv); s[3] += hsum(uv * xh); s[4] += hsum(uv * gh);
+        s[0] += (double)hsum(gh); s[1] += (double)hsum(gh * xh); s[2] += (double)hsum(uv); s[3] += (double)hsum(uv * xh);
+        s[4] += (double)hsum(uv * gh);
     }
     block_sums<5>(s, red);
-    const float n = (float)P * C, gb = s[0] / n, mg = s[1] / n, ub = s[2] / n, mu_ = s[3] / n;
-    const float A = s[4] - n * ub * gb - n * mu_ * mg;
-    const float r2 = rstd * rstd, ca = -A * r2 / n;
+    const double nd = (double)P * C, gbd = s[0] / nd, mgd = s[1] / nd, ubd = s[2] / nd, mud = s[3] / nd;
+    const double Ad = s[4] - nd * ubd * gbd - nd * mud * mgd;
+    const float gb = (float)gbd, mg = (float)mgd, ub = (float)ubd, mu_ = (float)mud;
+    const float r2 = rstd * rstd, ca = (float)(-Ad * (double)r2 / nd);
     f32x4 ag = {0.f, 0.f, 0.f, 0.f};
     f32x4* ty = reinterpret_cast<f32x4*>(adj_dy + base);
     f32x4* rx = reinterpret_cast<f32x4*>(adj_x + base);

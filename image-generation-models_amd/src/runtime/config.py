@@ -49,15 +49,34 @@ def _merge(dst: dict, src: dict):
             dst[k] = v
 
 
+class _Loader(yaml.SafeLoader):
+    """YAML 1.1 reads `1e-4` as a string (a float needs a dot there); OmegaConf, which the reference's configs are written
+    for, reads it as a float.  Same implicit resolver here so `lrG: 1e-4` (configs/model/wgan_gp.yaml) is a number."""
+
+
+_Loader.add_implicit_resolver(
+    "tag:yaml.org,2002:float",
+    re.compile(r"""^(?:[-+]?(?:[0-9][0-9_]*)\.[0-9_]*(?:[eE][-+]?[0-9]+)?
+                    |[-+]?(?:[0-9][0-9_]*)(?:[eE][-+]?[0-9]+)
+                    |\.[0-9_]+(?:[eE][-+][0-9]+)?
+                    |[-+]?\.(?:inf|Inf|INF)
+                    |\.(?:nan|NaN|NAN))$""", re.X),
+    list("-+0123456789."))
+
+
+def _yaml(text: str):
+    return yaml.load(text, Loader=_Loader)
+
+
 def _load(path: str) -> Tuple[dict, bool]:
     text = open(path).read()
     is_global = bool(re.match(r"\s*#\s*@package\s+_global_", text))
-    return (yaml.safe_load(text) or {}), is_global
+    return (_yaml(text) or {}), is_global
 
 
 def _parse_value(s: str):
     try:
-        return yaml.safe_load(s)
+        return _yaml(s)
     except yaml.YAMLError:
         return s
 
