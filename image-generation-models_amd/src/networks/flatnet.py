@@ -174,6 +174,19 @@ class FlatNet(nn.Module):
             oh, ow = (ih - 1) * stride - 2 * pad + kh, (iw - 1) * stride - 2 * pad + kw
         else:
             oh, ow = (ih + 2 * pad - kh) // stride + 1, (iw + 2 * pad - kw) // stride + 1
+        if (not transposed and pad == 0 and (ih, iw) == (kh, kw) and residual is None and inp.is_contiguous()
+                and self.compute_mode == "fp32" and (co == 1 or co % 4 == 0)):
+            # the kernel covers the whole input: a plain GEMM [N, kh*kw*ci] x [kh*kw*ci, co] with a long contraction and few rows
+            # (the critic's last layer: 8192 -> 1).  One generic-kernel workgroup would walk that contraction alone (510 us);
+            # the split-K small GEMM spreads it over the chip.
+            n = inp.shape[0]
+            out = torch.zeros((n, 1, 1, (co + 3) // 4 * 4), device=inp.device, dtype=torch.float32)
+            a = inp.view(n, kh * kw * ci)
+            b = w.view(1, kh * kw * ci) if co == 1 else w.view(kh * kw * ci, co)
+            y = K.small_gemm(False, co == 1, a, b, bias=self._sv[pre + "bias"] if bias else None, out=out.view(n, -1)[:, :co],
+                             accumulate=True, allow_split=True)
+            if y is not None:
+                return out[..., :co]
         return K.conv_igemm(inp, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=transposed, w_kn=True, K=ci, Nc=co,
                             out_hw=(oh, ow), mode=_mode_id(self.compute_mode), bias=self._sv[pre + "bias"] if bias else None,
                             residual=residual)
