@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
                 int n = m / (a.OHc * a.OWc);
                 int rem = m - n * (a.OHc * a.OWc);
                 int yy = rem / a.OWc, xx = rem - yy * a.OWc;
+                if (yy * s + py >= a.OH || xx * s + px >= a.OW) continue;        // partial last cell of a ragged output grid
                 opix = (size_t)(n * a.OH + yy * s + py) * a.OW + xx * s + px;
             }
 #pragma unroll
@@ -575,11 +576,12 @@ static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, 
     a.ldr = d->ldr; a.accumulate = d->accumulate;
     int classes = 1;
     a.OHc = d->OH; a.OWc = d->OW;
-    if (d->transposed && d->stride > 1) {
-        MI_REQUIRE(d->OH % d->stride == 0 && d->OW % d->stride == 0, "transposed: OH, OW must be multiples of stride");
+    bool ragged = false;                      // output extent not a multiple of the stride (7x7 from 4x4, stride 2): rows of the
+    if (d->transposed && d->stride > 1) {     // last partial class cell are computed and dropped at the store
         MI_REQUIRE(d->KH >= d->stride && d->KW >= d->stride, "transposed: kernel smaller than stride");
         classes = d->stride * d->stride;
-        a.OHc = d->OH / d->stride; a.OWc = d->OW / d->stride;
+        a.OHc = (d->OH + d->stride - 1) / d->stride; a.OWc = (d->OW + d->stride - 1) / d->stride;
+        ragged = d->OH % d->stride != 0 || d->OW % d->stride != 0;
     }
     a.Mc = d->N * a.OHc * a.OWc;
     // activations: rows are 16-B aligned when ld % 4 == 0; a chunk may still be ragged at the end
@@ -594,7 +596,7 @@ static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, 
             int ks = d->K / 128; if (ks > 32) ks = 32;
             a.ksplit = ks;
             if (!d->accumulate) {
-                hipError_t e = hipMemsetAsync(y, 0, (size_t)a.Mc * classes * d->ldy * sizeof(float), st);
+                hipError_t e = hipMemsetAsync(y, 0, (size_t)d->N * d->OH * d->OW * d->ldy * sizeof(float), st);
                 if (e != hipSuccess) return mi_set_error((int)e, "mi_conv_igemm: memset: %s", hipGetErrorString(e));
             }
         }
@@ -607,7 +609,7 @@ static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, 
     if (bn64 == false && bm64 && (long)((a.Mc + 63) / 64) * ((d->Nc + 127) / 128) * classes < 384) bn64 = true;
     // aligned bf16 layers with few taps per class: the straight-line ring kernel
     static const int allow_fast = [] { const char* e = getenv("MI_IGEMM_FAST"); return e ? atoi(e) : 1; }();
-    if (allow_fast && d->mode == 1 && wb && a.ksplit == 1 && d->K % 32 == 0 && d->K1 % 32 == 0 && a.vecA && classes <= 4 &&
+    if (allow_fast && !ragged && d->mode == 1 && wb && a.ksplit == 1 && d->K % 32 == 0 && d->K1 % 32 == 0 && a.vecA && classes <= 4 &&
         d->KH * d->KW <= 16) {
         FastTaps tt;
         bool ok = true;
@@ -656,7 +658,7 @@ static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, 
 extern "C" int mi_conv_igemm_tile(const MiConvDesc* d, int* bm, int* bn) {
     MI_REQUIRE(d && bm && bn, "null argument");
     int classes = 1, OHc = d->OH, OWc = d->OW;
-    if (d->transposed && d->stride > 1) { classes = d->stride * d->stride; OHc /= d->stride; OWc /= d->stride; }
+    if (d->transposed && d->stride > 1) { classes = d->stride * d->stride; OHc = (OHc + d->stride - 1) / d->stride; OWc = (OWc + d->stride - 1) / d->stride; }
     int Mc = d->N * OHc * OWc;
     long tiles128 = (long)((Mc + 127) / 128) * ((d->Nc + 127) / 128) * classes;
     bool bn64 = d->Nc <= 64;

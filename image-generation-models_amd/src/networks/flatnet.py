@@ -42,6 +42,7 @@ class FlatNet(nn.Module):
         super().__init__()
         object.__setattr__(self, "_entries", [])
         object.__setattr__(self, "_aliases", [])
+        object.__setattr__(self, "_bn", [])
         self.compute_mode = os.environ.get("MI_DDPM_MODE", "fp32")
         self.accumulate_grads = False
 
@@ -57,6 +58,11 @@ class FlatNet(nn.Module):
         """nn.GroupNorm affine pair (weight = 1, bias = 0: no random draw)."""
         self._entries.append(_Entry(pre + "weight", (c,), "plain", "one", 0, 0))
         self._entries.append(_Entry(pre + "bias", (c,), "plain", "zero", 0, 0))
+
+    def _batchnorm_params(self, pre, c):
+        """nn.BatchNorm2d: affine pair in the flat buffer + running_mean / running_var / num_batches_tracked buffers."""
+        self._norm_params(pre, c)
+        self._bn.append((pre, c))
 
     def _alias(self, parent: str, name: str, target: str):
         """Register module `parent.target` a second time as `parent.name` (the reference's `[layer] * n`)."""
@@ -93,6 +99,13 @@ class FlatNet(nn.Module):
             p = nn.Parameter(e.logical_view(flat))
             node.register_parameter(parts[-1], p)
             plist.append((e, p))
+        for pre, c in self._bn:                               # buffers in torch's order, after the module's parameters
+            node = self
+            for name in pre.rstrip(".").split("."):
+                node = node._modules[name]
+            node.register_buffer("running_mean", torch.zeros(c))
+            node.register_buffer("running_var", torch.ones(c))
+            node.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         for parent, name, target in self._aliases:
             node = self
             for part in parent.split("."):
@@ -121,7 +134,28 @@ class FlatNet(nn.Module):
             raise RuntimeError("fp32 master weights only; set compute_mode='bf16' for bf16 matrix math")
         if new is not self._flat:
             self._bind(new)
+        for mod in self.modules():                            # the few real buffers (batch-norm running statistics)
+            for key, buf in mod._buffers.items():
+                if buf is not None:
+                    mod._buffers[key] = fn(buf)
         return self
+
+    def _buffer(self, key: str) -> torch.Tensor:
+        node = self
+        parts = key.split(".")
+        for name in parts[:-1]:
+            node = node._modules[name]
+        return node._buffers[parts[-1]]
+
+    def _bn_fwd(self, x, pre, momentum=0.1, eps=1e-5):
+        """nn.BatchNorm2d forward in the module's current mode; returns (y, mean, rstd)."""
+        sv = self._sv
+        training = self.training
+        y, mean, rstd = K.batchnorm_fwd(x, sv[pre + "weight"], sv[pre + "bias"], self._buffer(pre + "running_mean"),
+                                        self._buffer(pre + "running_var"), momentum, eps, training)
+        if training:
+            self._buffer(pre + "num_batches_tracked").add_(1)
+        return y, mean, rstd
 
     @property
     def flat_params(self) -> torch.Tensor:

@@ -421,6 +421,61 @@ def relu_bwd(y, dy, out=None, accumulate=False):
     return dx
 
 
+# --------------------------------------------------------------------------- VAE operators (vae_ops.hip)
+_BN_WS = {}
+
+
+def _bn_ws(device, C):
+    ws = _BN_WS.get(device)
+    if ws is None or ws.numel() < 2 * C:
+        ws = torch.zeros(max(2 * C, 4096), device=device, dtype=torch.float64)     # kept zero by the kernels
+        _BN_WS[device] = ws
+    return ws
+
+
+def batchnorm_fwd(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, training=True):
+    """nn.BatchNorm2d on a dense NHWC tensor -> (y, mean[C], rstd[C]); updates the running statistics in training mode."""
+    _need_gpu(x); _dense(x)
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    y = torch.empty_like(x)
+    mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    check(load_library().mi_batchnorm_fwd(M, Cc, _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+                                          momentum, eps, int(training), _p(_bn_ws(x.device, Cc)), _stream()), "mi_batchnorm_fwd")
+    return y, mean, rstd
+
+
+def batchnorm_bwd(x, mean, rstd, gamma, dy, dgamma=None, dbeta=None, out=None):
+    _dense(x, dy, out)
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    dx = torch.empty_like(x) if out is None else out
+    check(load_library().mi_batchnorm_bwd(M, Cc, _p(x), _p(mean), _p(rstd), _p(gamma), _p(dy), _p(dx), _p(dgamma), _p(dbeta),
+                                          _p(_bn_ws(x.device, Cc)), _stream()), "mi_batchnorm_bwd")
+    return dx
+
+
+def vae_latent_fwd(h, eps):
+    """h [N, 2L] = [mu | log_sigma], eps [N, L] -> (z [N, L], kld scalar)."""
+    _need_gpu(h)
+    N, L2 = h.shape
+    L = L2 // 2
+    z = torch.empty((N, L), device=h.device, dtype=torch.float32)
+    kld = torch.zeros((), device=h.device, dtype=torch.float32)
+    eps = eps.float().contiguous()
+    check(load_library().mi_vae_latent_fwd(N, L, _p(h), h.stride(0), _p(eps), _p(z), _p(kld), _stream()), "mi_vae_latent_fwd")
+    return z, kld
+
+
+def vae_latent_bwd(h, eps, dz, g_kld, g_dev=None):
+    N, L2 = h.shape
+    dh = torch.empty((N, L2), device=h.device, dtype=torch.float32)
+    check(load_library().mi_vae_latent_bwd(N, L2 // 2, _p(h), h.stride(0), _p(eps.float().contiguous()), _p(dz.contiguous()), float(g_kld), _p(g_dev),
+                                           _p(dh), L2, _stream()), "mi_vae_latent_bwd")
+    return dh
+
+
 # --------------------------------------------------------------------------- WGAN-GP operators (critic_ops.hip)
 def _dense(*ts):
     for t in ts:

@@ -88,6 +88,11 @@ SIGNATURES = {
     "mi_tanh_bwd": [_Z, _P, _P, _P, _P],
     "mi_lerp_rows": [_I, _Z, _P, _P, _P, _P, _P],
     "mi_gp_penalty": [_I, _Z, _P, _P, _P, _F, _P, _P],
+    "mi_batchnorm_workspace": [_I],
+    "mi_batchnorm_fwd": [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P],
+    "mi_batchnorm_bwd": [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mi_vae_latent_fwd": [_I, _I, _P, _I, _P, _P, _P, _P],
+    "mi_vae_latent_bwd": [_I, _I, _P, _I, _P, _P, _F, _P, _P, _I, _P],
     "mi_relu_fwd": [_Z, _P, _P, _P],
     "mi_relu_bwd": [_Z, _P, _P, _P, _I, _P],
     "mi_mish_fwd": [_Z, _P, _P, _P],

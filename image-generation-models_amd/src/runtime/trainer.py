@@ -154,6 +154,12 @@ class Trainer:
             train_dataloaders = datamodule.train_dataloader()
             val_dataloaders = datamodule.val_dataloader()
         optimizer = model.configure_optimizers()
+        schedulers = []
+        if (isinstance(optimizer, (list, tuple)) and len(optimizer) == 2 and all(isinstance(o, (list, tuple)) for o in optimizer)):
+            optimizer, schedulers = list(optimizer[0]), list(optimizer[1])     # Lightning's ([optimizers], [lr_schedulers]) form
+            if len(optimizer) == 1:
+                optimizer = optimizer[0]
+        self.lr_schedulers = schedulers
         manual = not getattr(model, "automatic_optimization", True)
         if manual:                                     # the model steps its own optimizers (GANs); it also averages its gradients
             opts = list(optimizer) if isinstance(optimizer, (list, tuple)) else [optimizer]
@@ -205,6 +211,8 @@ class Trainer:
             self._flush_metrics()
             if bar is not None and self.is_global_zero:
                 print()
+            for sch in self.lr_schedulers:                     # epoch-interval schedulers (Lightning's default)
+                sch.step()
             for cb in self.callbacks:
                 cb.on_train_epoch_end(self, model)
             if val_dataloaders is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:

@@ -284,6 +284,23 @@ int mi_lerp_rows(int N, size_t per, const float* a, const float* b, const float*
  * u_s = scale * (scale_dev ? *scale_dev : 1) * d penalty / d g_s. */
 int mi_gp_penalty(int N, size_t per, const float* g, float* penalty, float* u, float scale, const float* scale_dev, void* stream);
 
+/* ---- VAE operators (BASELINE cfg 1; reference src/models/vae.py:46-72, src/networks/basic.py:147-204, src/utils/losses.py:30-32) ----
+ * nn.BatchNorm2d on a dense NHWC tensor of M = N*H*W rows and C channels (C % 4 == 0, C/4 a power of two <= 256).
+ * training != 0: batch statistics (left in mean / rstd for the backward), running statistics updated like torch (momentum,
+ * unbiased variance) when non-null; training == 0: mean / rstd come from the running statistics.
+ * ws: mi_batchnorm_workspace(C) bytes, zero on entry, left zero on exit.  bwd: dx may alias dy, dgamma / dbeta accumulated. */
+int mi_batchnorm_workspace(int C);
+int mi_batchnorm_fwd(int M, int C, const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                     float* running_mean, float* running_var, float momentum, float eps, int training, void* ws, void* stream);
+int mi_batchnorm_bwd(int M, int C, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dy,
+                     float* dx, float* dgamma, float* dbeta, void* ws, void* stream);
+/* latent block: h = [mu | log_sigma] (rows of ldh >= 2L floats), z = mu + exp(log_sigma) * eps (vae.py:46-55, eps drawn by the
+ * caller), *kld += mean over rows of -0.5 sum(1 + 2 log_sigma - mu^2 - exp(2 log_sigma)) (losses.py:30-32; nullable).
+ * bwd: dh = dL/dh from dz = dL/dz and g_kld * (g_dev ? *g_dev : 1) = dL/d kld. */
+int mi_vae_latent_fwd(int N, int L, const float* h, int ldh, const float* eps, float* z, float* kld, void* stream);
+int mi_vae_latent_bwd(int N, int L, const float* h, int ldh, const float* eps, const float* dz, float g_kld, const float* g_dev,
+                      float* dh, int lddh, void* stream);
+
 /* ---- small element-wise pieces ---------------------------------------------------------------- */
 /* SinusoidalPosEmb (ddpm.py:52-59): out[b][dim] = [sin(t f_j) | cos(t f_j)] */
 int mi_time_embed(int B, int dim, const int64_t* t, float* out, void* stream);

@@ -242,3 +242,46 @@ def test_wgan_oracle_matches_reference_vectors(golden_dir):
         assert abs(float(g_loss) - ref) <= 1e-5 * max(1.0, abs(ref))
         for k, v in leaf_g.items():
             assert torch.allclose(v.grad, torch.from_numpy(g[f"{tag}.ggrad.{k}"]), rtol=1e-4, atol=1e-7), (tag, k)
+
+
+def _vae_model(ndf, latent, seed=None):
+    import importlib
+    M = importlib.import_module("image-generation-models_amd.src.models.vae")
+    if seed is not None:
+        torch.manual_seed(seed)
+    dm = {"width": 28, "height": 28, "channels": 1, "transforms": {"normalize": True}}
+    return M.VAE(dm, encoder={"_target_": "src.networks.basic.ConvEncoder", "ndf": ndf, "norm_type": "batch"},
+                 decoder={"_target_": "src.networks.basic.ConvDecoder", "ngf": ndf, "norm_type": "batch"}, latent_dim=latent, decoder_dist="gaussian")
+
+
+def test_vae_oracle_matches_reference_vectors(golden_dir):
+    """oracle/vae_oracle.py against the reference VAE.training_step run by tools/gen_golden_vae.py (BASELINE cfg 1)."""
+    import numpy as np
+    from oracle import vae_oracle as AO
+    g = np.load(os.path.join(golden_dir, "vae_kats.npz"))
+    sd = {k[len("tiny.sd0."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("tiny.sd0.")}
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v) for k, v in sd.items()}
+    loss, kld, log_p, z, recon = AO.training_losses(leaf, torch.from_numpy(g["tiny.imgs"]), torch.from_numpy(g["tiny.eps"]))
+    loss.backward()
+    assert abs(float(loss) - float(g["tiny.loss"])) <= 1e-5 * abs(float(g["tiny.loss"]))
+    assert abs(float(kld) - float(g["tiny.log.train_log/kl_divergence"])) <= 1e-5 * abs(float(kld))
+    assert abs(float(log_p) - float(g["tiny.log.train_log/log_p_x_of_z"])) <= 1e-5 * abs(float(log_p))
+    for k in list(g["tiny.names"]):
+        assert torch.allclose(leaf[k].grad, torch.from_numpy(g["tiny.grad." + k]), rtol=2e-4, atol=2e-5), k
+    # evaluation mode with the post-step running statistics
+    sd1 = dict(sd)
+    sd1.update({k[len("tiny.buf1."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("tiny.buf1.")})
+    dec = AO.decoder(sd1, torch.from_numpy(g["tiny.zfix"]), training=False)
+    assert torch.allclose(dec, torch.from_numpy(g["tiny.decode_eval"]), rtol=1e-4, atol=1e-5)
+    # cfg 1 sizes: the host-side modules reproduce the reference's seeded default init bit for bit
+    m = _vae_model(32, 128, seed=32)
+    assert [k for k, _ in m.named_parameters()] == list(g["cfg1.names"])
+    ws = np.array([[float(p.detach().double().sum()), float(p.detach().double().abs().sum())] for _, p in m.named_parameters()])
+    assert np.array_equal(ws, g["cfg1.wstats"])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    leaf = {k: (v.requires_grad_(True) if k in set(g["cfg1.names"]) else v) for k, v in sd.items()}
+    loss, kld, log_p, _, _ = AO.training_losses(leaf, torch.from_numpy(g["cfg1.imgs"]), torch.from_numpy(g["cfg1.eps"]))
+    loss.backward()
+    assert abs(float(loss) - float(g["cfg1.loss"])) <= 1e-5 * abs(float(g["cfg1.loss"]))
+    for k, ref in zip(list(g["cfg1.names"]), g["cfg1.gstats"]):
+        assert abs(float(leaf[k].grad.double().norm()) - ref[1]) <= 2e-4 * ref[1] + 1e-5, k      # biases in front of a batch norm have an exactly-zero gradient: rounding noise only

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""VAE on MNIST shapes (BASELINE cfg 1: 1x28x28, latent 128, conv_mnist nets with batch norm, B=128) training-step throughput on
+one GPU with the oracle's CPU rate beside it (the reference runs this config with trainer=cpu).
+
+    python tools/bench_vae.py [--batch 128] [--steps 100] [--mode fp32|bf16]
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+M = importlib.import_module("image-generation-models_amd.src.models.vae")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    dm = {"width": 28, "height": 28, "channels": 1, "transforms": {"normalize": True}}
+    m = M.VAE(dm, encoder={"_target_": "src.networks.basic.ConvEncoder", "ndf": 32, "norm_type": "batch"},
+              decoder={"_target_": "src.networks.basic.ConvDecoder", "ngf": 32, "norm_type": "batch"}, latent_dim=128, decoder_dist="gaussian").to(dev)
+    m.encoder.compute_mode = m.decoder.compute_mode = a.mode
+    m.train()
+    (opt,), _ = m.configure_optimizers()
+    imgs = torch.rand(a.batch, 1, 28, 28, device=dev) * 2 - 1
+
+    def step(i):
+        loss = m.training_step((imgs, None), i)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {"metric": "vae_mnist_28x28_train_images_per_sec", "value": round(a.batch * a.steps / el, 1), "unit": "images/s",
+           "ms_per_step": round(el / a.steps * 1e3, 3), "batch": a.batch, "dtype": a.mode, "final_loss": round(float(loss.detach()), 3)}
+    if a.cpu_steps > 0:
+        from oracle import vae_oracle as AO
+        sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        names = {k for k, _ in m.named_parameters()}
+        x = imgs.cpu()
+        def cpu_step():
+            leaf = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+            AO.training_losses(leaf, x, torch.randn(a.batch, 128))[0].backward()
+        cpu_step()
+        t0 = time.perf_counter()
+        for _ in range(a.cpu_steps):
+            cpu_step()
+        ce = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(a.batch * a.cpu_steps / ce, 1), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{a.cpu_steps} forward+backward steps of the oracle at B={a.batch} (no optimizer step)"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
