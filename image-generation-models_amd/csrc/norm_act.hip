@@ -136,11 +136,10 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
 }
 
 // Backward of y = mish(xhat*gamma+beta) + temb + res wrt x (the conv output), gamma, beta, temb.
-template <int VEC, int MAXU, int IO = 0, int NT = 256>     // IO bit 0: x is bf16, bit 1: dx is written as bf16, bit 2: dout is bf16
-__global__ __launch_bounds__(NT) void gn_mish_bwd_kernel(const GnArgs a) {
+template <int VEC, int MAXU, int IO = 0>     // IO bit 0: x is bf16, bit 1: dx is written as bf16, bit 2: dout is bf16
+__global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
     constexpr bool X16 = IO & 1, DX16 = IO & 2, DO16 = IO & 4;
-    constexpr int NW = NT / 64;
-    __shared__ float part[4][NW * 32 * VEC];             // per-wave, per-channel partial sums (W <= 32 channel lanes)
+    __shared__ float part[4][256 * VEC];
     __shared__ float chs[4][128];
     __shared__ float s12[2];
     // Workgroup -> (sample, group).  Consecutive workgroup ids go to different XCDs (id % 8), each with its own L2, while
@@ -152,7 +151,7 @@ __global__ __launch_bounds__(NT) void gn_mish_bwd_kernel(const GnArgs a) {
         g = slot % a.G; n = xcd + 8 * (slot / a.G);
     }
     const int ng = n * a.G + g;
-    const int W = a.Cg / VEC, PP = NT / W;
+    const int W = a.Cg / VEC, PP = 256 / W;
     const int t = threadIdx.x, u = t % W, pr = t / W;
     const int c0 = g * a.Cg + u * VEC;
     const float mean = a.stats[2 * ng], rstd = a.stats[2 * ng + 1];
@@ -207,30 +206,18 @@ __global__ __launch_bounds__(NT) void gn_mish_bwd_kernel(const GnArgs a) {
     } else {
         for (int p = pr; p < a.HW; p += PP) { V<VEC> xh, dz; pass1(p, xh, dz); }
     }
-    // lanes l, l + W, l + 2W, ... of a wave hold the same channels (W is a power of two <= 32): combine them by shuffles, then
-    // one row of W*VEC channel sums per wave goes through LDS
-    {
-        const int l = t & 63, wv = t >> 6;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            float v0 = sA[j], v1 = sD[j], v2 = sT[j], v3 = sB[j];
-            for (int o = W; o < 64; o <<= 1) {
-                v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); v3 += __shfl_xor(v3, o, 64);
-            }
-            if (l < W) {
-                const int slot = (wv * W + l) * VEC + j;
-                part[0][slot] = v0; part[1][slot] = v1; part[2][slot] = v2; part[3][slot] = v3;
-            }
-        }
+    for (int j = 0; j < VEC; ++j) {
+        part[0][t * VEC + j] = sA[j]; part[1][t * VEC + j] = sD[j];
+        part[2][t * VEC + j] = sT[j]; part[3][t * VEC + j] = sB[j];
     }
     __syncthreads();
-    // per-channel totals: thread (k, c) for k < 4, c < Cg
-    for (int idx = t; idx < 4 * a.Cg; idx += NT) {
+    // per-channel totals: thread (k, c) for k < 4, c < Cg  (Cg <= 64 -> one pass; Cg == 128 -> two)
+    for (int idx = t; idx < 4 * a.Cg; idx += 256) {
         int k = idx / a.Cg, c = idx % a.Cg;
         int uu = c / VEC, jj = c % VEC;
         float tot = 0.f;
-#pragma unroll
-        for (int r = 0; r < NW; ++r) tot += part[k][(r * W + uu) * VEC + jj];
+        for (int r = 0; r < PP; ++r) tot += part[k][(r * W + uu) * VEC + jj];
         chs[k][c] = tot;
     }
     __syncthreads();
@@ -450,7 +437,6 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
 
 }  // namespace
 
-static bool gn_wide() { static const int v = [] { const char* e = getenv("MI_GN_WIDE"); return e ? atoi(e) : 1; }(); return v != 0; }
 #define GN_DISPATCH_IO_(KERNEL, IOV, FWD)                                                                 \
     do {                                                                                            \
         dim3 grid(a.N * a.G), blk(256);                                                             \
@@ -464,16 +450,7 @@ static bool gn_wide() { static const int v = [] { const char* e = getenv("MI_GN_
             else hipLaunchKernelGGL((KERNEL<1, 0, IOV>), grid, blk, 0, st, a);                      \
         }                                                                                           \
     } while (0)
-// backward, fp32 x, 16 units per 256 threads (level 0 of the 32x32 configs): 1024-thread workgroups with 4 units per thread --
-// the short form issues every load up front and unconditionally, and 16 waves hide what one 260-register wave per SIMD
-// cannot (76 -> 60 us for [128,32,32,128] fp32).  Measured and NOT used: the same for bf16 x (38.7 -> 41.9 us: those slices
-// are VALU-bound, the extra barrier traffic costs more) and for partly filled slots (16x16: 22.7 -> 31.7 us).
-#define GN_DISPATCH_IO(KERNEL, IOV)                                                                       \
-    do {                                                                                            \
-        if (vec == 4 && units == 16 && !((IOV) & 1) && gn_wide()) {                                 \
-            hipLaunchKernelGGL((KERNEL<4, 4, IOV, 1024>), dim3(a.N * a.G), dim3(1024), 0, st, a);   \
-        } else GN_DISPATCH_IO_(KERNEL, IOV, false);                                                 \
-    } while (0)
+#define GN_DISPATCH_IO(KERNEL, IOV) GN_DISPATCH_IO_(KERNEL, IOV, false)
 #define GN_DISPATCH_FWD_IO(KERNEL, IOV) GN_DISPATCH_IO_(KERNEL, IOV, true)   /* forward also caches 32-unit slices (64x64 images, C/G = 8) */
 #define GN_DISPATCH(KERNEL) GN_DISPATCH_IO(KERNEL, 0)
 
