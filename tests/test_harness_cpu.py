@@ -187,3 +187,57 @@ def _reducer_group_worker(rank, world, port):
         assert grp.grad_scale == 0.5
     finally:
         dist.destroy_process_group()
+
+
+class _ToyManual(__import__("src.runtime.lightning_lite", fromlist=["LightningModule"]).LightningModule):
+    """Two optimizers stepped by the model itself (the GAN pattern of src/models/wgan_gp.py:52-107)."""
+
+    def __init__(self):
+        super().__init__()
+        self.automatic_optimization = False
+        self.a = torch.nn.Linear(4, 1)
+        self.b = torch.nn.Linear(4, 1)
+        self.steps = [0, 0]
+
+    def configure_optimizers(self):
+        return torch.optim.SGD(self.a.parameters(), lr=0.1), torch.optim.SGD(self.b.parameters(), lr=0.1)
+
+    def training_step(self, batch, i):
+        x, y = batch
+        opt_a, opt_b = self.optimizers()
+        which = i % 3 == 2
+        net, opt = (self.b, opt_b) if which else (self.a, opt_a)
+        loss = ((net(x).squeeze(-1) - y) ** 2).mean()
+        opt.zero_grad()
+        self.manual_backward(loss)
+        opt.step()
+        self.steps[which] += 1
+        self.log("train_loss/which", float(which))
+
+
+class _ToySched(_Toy):
+    def configure_optimizers(self):
+        opt = torch.optim.SGD(self.parameters(), lr=0.1)
+        return [opt], [torch.optim.lr_scheduler.StepLR(opt, 1, gamma=0.5)]
+
+
+def test_trainer_manual_optimization_and_schedulers(tmp_path, monkeypatch):
+    """The two Lightning conventions the widened models rely on: `automatic_optimization = False` with `self.optimizers()` /
+    `manual_backward` (WGAN-GP) and `configure_optimizers` returning ([optimizers], [schedulers]) (VAE: StepLR per epoch)."""
+    from src.runtime.trainer import Trainer
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    x = torch.randn(48, 4); y = x @ torch.tensor([1.0, -2.0, 0.5, 3.0])
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x, y), batch_size=8)
+    m = _ToyManual()
+    a0, b0 = m.a.weight.detach().clone(), m.b.weight.detach().clone()
+    tr = Trainer(accelerator="cpu", max_epochs=2, enable_checkpointing=True, num_sanity_val_steps=0)
+    tr.fit(m, train_dataloaders=loader)
+    assert tr.global_step == 12 and m.steps == [8, 4]                       # the trainer never stepped anything itself
+    assert not torch.equal(m.a.weight, a0) and not torch.equal(m.b.weight, b0)
+    ck = torch.load(tr.checkpoint_callback.best_model_path)
+    assert len(ck["optimizer_states"]) == 2
+    s = _ToySched()
+    tr = Trainer(accelerator="cpu", max_epochs=3, enable_checkpointing=False, num_sanity_val_steps=0)
+    tr.fit(s, train_dataloaders=loader)
+    assert abs(tr.optimizer.param_groups[0]["lr"] - 0.1 * 0.5 ** 3) < 1e-12   # one scheduler step per epoch
