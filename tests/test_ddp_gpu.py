@@ -1,0 +1,89 @@
+"""Data-parallel training step on real kernels: two ranks (gloo, both on cuda:0 -- the GPU box has one device, RCCL refuses two
+ranks on one GPU) run the DDPM step on different half-batches with the bucketed flat-gradient reducer hooked into backward; the
+averaged gradients and the weights after the fused Adam step must equal a single process on the whole batch (the loss is a mean
+and every normalisation is per sample, so the average of the two half-batch gradients IS the full-batch gradient)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "image-generation-models_amd")
+
+
+def _build(mode):
+    from src.models.ddpm import DDPM
+    torch.manual_seed(0)
+    m = DDPM({"width": 16, "height": 16, "channels": 3, "transforms": {"normalize": True}}, hidden_dim=32, dim_mults=(1, 2), timesteps=50,
+             lr=1e-3, b1=0.9, b2=0.999).to("cuda")
+    m.denoising_model.compute_mode = mode
+    m.train()
+    return m
+
+
+def _data(n):
+    g = torch.Generator().manual_seed(123)
+    return torch.rand(n, 3, 16, 16, generator=g) * 2 - 1, torch.randint(0, 50, (n,), generator=g), torch.randn(n, 3, 16, 16, generator=g)
+
+
+def _worker(rank, world, port, mode, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path[:0] = [ROOT, PKG]
+    import torch.distributed as dist
+    from src.runtime.ddp import FlatGradReducer, broadcast_parameters
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = _build(mode)
+        net = m.denoising_model
+        if rank == 1:
+            net.flat_params.mul_(1.5)                     # rank 1 starts from different weights: the broadcast must fix that
+        broadcast_parameters(net.flat_params)
+        red = FlatGradReducer(net.flat_grads, bucket_bytes=256 * 1024)
+        net.grad_ready_hook = red.range_ready
+        opt = m.configure_optimizers()
+        opt.grad_scale = red.grad_scale
+        x, t, noise = _data(16)
+        sl = slice(rank * 8, rank * 8 + 8)
+        for _ in range(2):
+            red.begin()
+            loss = m.diffusion_model.p_losses(x[sl].cuda(), t[sl].cuda(), noise[sl].cuda())
+            loss.backward()
+            red.finish()
+            opt.step()
+        torch.cuda.synchronize()
+        q.put((rank, net.flat_params.cpu().numpy().copy(), (net.flat_grads * red.grad_scale).cpu().numpy().copy(), len(red.launched)))
+    finally:
+        dist.destroy_process_group()
+
+
+# bf16: weight-gradient split orders differ between the two layouts and Adam (+-lr per step) amplifies it in step 2
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
+def test_two_rank_step_equals_full_batch(mode, tol):
+    import torch.multiprocessing as mp
+    sys.path[:0] = [ROOT, PKG]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 23500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    p0, g0, n0 = torch.from_numpy(res[0][1]), torch.from_numpy(res[0][2]), res[0][3]
+    p1, g1 = torch.from_numpy(res[1][1]), torch.from_numpy(res[1][2])
+    assert torch.equal(p0, p1) and torch.equal(g0, g1)              # both ranks hold the same averaged gradients and weights
+    assert n0 >= 2                                                   # the flat buffer really went out in several buckets
+    m = _build(mode)
+    opt = m.configure_optimizers()
+    x, t, noise = _data(16)
+    for _ in range(2):
+        m.diffusion_model.p_losses(x.cuda(), t.cuda(), noise.cuda()).backward()
+        opt.step()
+    ref_p, ref_g = m.denoising_model.flat_params.cpu(), m.denoising_model.flat_grads.cpu()
+    scale = float(ref_g.abs().max())
+    assert float((g0 - ref_g).abs().max()) <= tol * scale
+    assert float((p0 - ref_p).abs().max()) <= max(tol, 2.1e-3 if mode == "bf16" else 0) * float(ref_p.abs().max())    # bf16: an Adam step is +-lr = 1e-3
