@@ -292,3 +292,31 @@ extern "C" int mi_gather_rows(int B, int C, const float* table, const int64_t* i
     MI_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- measurement aid (tools/cu_hog.py): `blocks` workgroups that spin for `usec` microseconds of wall clock on `stream`, to see how a
+// training step behaves while another stream's kernel (a collective, in production) holds part of the chip.  Not part of the ABI.
+namespace {
+// mode 0: ALU spin (worst case for co-resident waves); mode 1: streaming copy loop over `buf` (2 x bytes per workgroup), which is
+// closer to what a collective's kernel does: mostly waiting on memory
+__global__ __launch_bounds__(256) void spin_kernel(unsigned long long ticks, float* buf, size_t per_wg, int mode) {
+    const unsigned long long t0 = wall_clock64();
+    if (mode == 0) {
+        float v = threadIdx.x;
+        while (wall_clock64() - t0 < ticks) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) v = v * 1.0000001f + 0.5f;
+        }
+        if (v == 12345.678f) buf[0] = v;
+        return;
+    }
+    float4* src = reinterpret_cast<float4*>(buf + (size_t)blockIdx.x * 2 * per_wg);
+    float4* dst = src + per_wg / 4;
+    while (wall_clock64() - t0 < ticks)
+        for (size_t i = threadIdx.x; i < per_wg / 4; i += 256) { float4 v = src[i]; v.x += 1.f; dst[i] = v; }
+}
+}  // namespace
+extern "C" int mi_debug_spin(int blocks, int usec, float* buf, size_t per_wg_floats, int mode, void* stream) {
+    hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long)usec * 100ull, buf, per_wg_floats, mode);   // 100 MHz clock
+    MI_LAUNCH_CHECK();
+    return 0;
+}
