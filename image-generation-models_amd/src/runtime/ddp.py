@@ -19,9 +19,13 @@ import torch.distributed as dist
 
 
 class FlatGradReducer:
-    def __init__(self, flat_grads: torch.Tensor, bucket_bytes: int = 32 << 20, group=None):
+    def __init__(self, flat_grads: torch.Tensor, bucket_bytes: int = 32 << 20, group=None, tail_bytes: Optional[int] = None):
         self.flat = flat_grads
         self.bucket_elems = max(1, bucket_bytes // 4)
+        # The LAST all-reduce of a step cannot overlap anything (backward is over), so it should be small: once the part of the
+        # buffer that is still to come is below `tail_bytes` (default min(4 MB, a quarter bucket)), whatever is pending goes out at once instead
+        # of waiting to be merged with it.  cfg 2: the final flush shrinks from the 22 MB remainder to the 2.4 MB time-MLP block.
+        self.tail_elems = max(1, (min(4 << 20, bucket_bytes // 4) if tail_bytes is None else tail_bytes) // 4)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._works: List = []
@@ -57,7 +61,7 @@ class FlatGradReducer:
                 pass
             self._lo = min(self._lo, lo)
             self._hi = max(self._hi, hi)
-        if self._hi - self._lo >= self.bucket_elems:
+        if self._hi - self._lo >= self.bucket_elems or self._lo <= self.tail_elems:
             self._launch()
 
     def finish(self):

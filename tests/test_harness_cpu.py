@@ -157,6 +157,8 @@ def test_flat_grad_reducer_gloo_world2():
         assert launched[0][1] == n and launched[-1][0] == 0      # covers [0, n) back to front
         assert all(a[0] == b[1] for a, b in zip(launched, launched[1:]))
         assert len(launched) > 3                                 # really bucketed
+        assert launched[-1][1] - launched[-1][0] <= 7919 + 4096  # the final, non-overlappable flush is small (tail rule)
+        assert max(b - a for a, b in launched) >= 16384            # ... while the others are full buckets
 
 
 def test_compose_vqvae_and_multi_buffer_reducer_gloo_world2():
