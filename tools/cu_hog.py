@@ -49,6 +49,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         child(int(sys.argv[1]))
     else:
-        for mode in ("1", "0"):                                 # 1 = streaming copy (collective-like), 0 = ALU spin (worst case)
-            for hog in (0, 8, 32, 64):
-                subprocess.run([sys.executable, __file__, str(hog)], env={**os.environ, "HOG_MODE": mode}, check=False)
+        blocks = os.environ.get("HOG_W3_BLOCKS", "256").split(",")
+        for mode in os.environ.get("HOG_MODES", "1,0").split(","):   # 1 = streaming copy (collective-like), 0 = ALU spin (worst case)
+            for b in blocks:
+                for hog in (0, 8, 32, 64):
+                    subprocess.run([sys.executable, __file__, str(hog)], env={**os.environ, "HOG_MODE": mode, "MI_W3_BLOCKS": b}, check=False)
