@@ -38,6 +38,7 @@ def _check_norm(norm_type):
 class ConvDecoder(FlatNet, _NormMixin):
     """z [N, C_in] -> [N, C_out, 28, 28]: ConvT(4,1,0) -> ConvT(3,2,1) -> ConvT(4,2,1) -> ConvT(4,2,1), norm + ReLU between, output act."""
     GEOM = ((4, 1, 0), (3, 2, 1), (4, 2, 1), (4, 2, 1))
+    BF16_SHADOWS = False
 
     def __init__(self, input_channel, output_channel, ngf, norm_type="batch", output_act="tanh"):
         super().__init__()
@@ -96,6 +97,7 @@ class ConvDecoder(FlatNet, _NormMixin):
 class ConvEncoder(FlatNet, _NormMixin):
     """[N, C_in, 28, 28] -> [N, C_out]: Conv(4,2,1)+LeakyReLU, Conv(4,2,1)+norm+LeakyReLU, Conv(3,2,1)+norm+LeakyReLU, Conv(4,1,0)."""
     CONVS = (("network.0.", 4, 2, 1, None), ("network.2.", 4, 2, 1, "network.3."), ("network.5.", 3, 2, 1, "network.6."))
+    BF16_SHADOWS = False
 
     def __init__(self, input_channel, output_channel, ndf, norm_type="batch", return_features=False):
         super().__init__()

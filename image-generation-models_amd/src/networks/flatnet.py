@@ -9,6 +9,8 @@ There is no torch fallback: a CPU tensor raises in the first kernel wrapper.
 """
 import math
 import os
+
+import numpy as np
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -37,6 +39,11 @@ class _NetFunction(torch.autograd.Function):
 
 class FlatNet(nn.Module):
     """Subclasses call `_declare(...)` for each parameter in the reference's construction order, then `_finish()`."""
+
+    # bf16 mode: keep bf16 weight copies (one pack launch per optimizer step) and route convolutions to the ring / halo-tile kernels
+    # that need them.  Off for nets whose shapes those kernels do not cover (28x28 MNIST: odd extents) -- there the extra launch
+    # only costs (measured: 100.8k -> 90.3k images/s for the VAE).
+    BF16_SHADOWS = True
 
     def __init__(self):
         super().__init__()
@@ -180,6 +187,38 @@ class FlatNet(nn.Module):
         if self._gflat is not None:
             self._gflat.zero_()
 
+    def _shadows(self):
+        """bf16 copies of every conv weight for the bf16 matrix-core kernels (same scheme as the UNet): wd = master layout
+        [tap][Cin][Cout] (input-gradient operand), wf = [tap][Cout][Cin] (forward operand); one pack launch whenever the fp32
+        master buffer changed."""
+        flat = self._flat
+        key = (flat.data_ptr(), flat._version, self._dirty)
+        if getattr(self, "_shadow_key", None) != key:
+            sh = getattr(self, "_shadow", None)
+            if sh is None or sh[0].device != flat.device:
+                ents = [e for e in self._entries if e.layout in ("conv", "convT")]
+                rec = np.zeros(len(ents), dtype=np.dtype([("off", "<i8"), ("taps", "<i4"), ("ci", "<i4"), ("co", "<i4"), ("tile0", "<i4")]))
+                tile = 0
+                for i, e in enumerate(ents):
+                    kh, kw, ci, co = e.storage_view(flat).shape
+                    rec[i] = (e.offset, kh * kw, ci, co, tile)
+                    tile += kh * kw * ((ci + 31) // 32) * ((co + 31) // 32)
+                table = torch.from_numpy(rec.view(np.uint8).copy()).to(flat.device)
+                sh = (torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16),
+                      torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16), table, len(ents), tile)
+                object.__setattr__(self, "_shadow", sh)
+            wd, wf, table, nent, tiles = sh
+            K.pack_weights_bf16(table, nent, tiles, flat, wd, wf)
+            object.__setattr__(self, "_shadow_key", key)
+        return self._shadow[0], self._shadow[1]
+
+    def _off(self, key: str) -> int:
+        offs = getattr(self, "_offs", None)
+        if offs is None:
+            offs = {e.key: e.offset for e in self._entries}
+            object.__setattr__(self, "_offs", offs)
+        return offs[key]
+
     # ------------------------------------------------------------------ execution
     def forward(self, x):
         if self._anchor.device != x.device:
@@ -209,7 +248,7 @@ class FlatNet(nn.Module):
         else:
             oh, ow = (ih + 2 * pad - kh) // stride + 1, (iw + 2 * pad - kw) // stride + 1
         if (not transposed and pad == 0 and (ih, iw) == (kh, kw) and residual is None and inp.is_contiguous()
-                and self.compute_mode == "fp32" and (co == 1 or co % 4 == 0)):
+                and (co == 1 or co % 4 == 0)):
             # the kernel covers the whole input: a plain GEMM [N, kh*kw*ci] x [kh*kw*ci, co] with a long contraction and few rows
             # (the critic's last layer: 8192 -> 1).  One generic-kernel workgroup would walk that contraction alone (510 us);
             # the split-K small GEMM spreads it over the chip.
@@ -221,9 +260,17 @@ class FlatNet(nn.Module):
                              accumulate=True, allow_split=True)
             if y is not None:
                 return out[..., :co]
+        b = self._sv[pre + "bias"] if bias else None
+        wb = None
+        if self.compute_mode == "bf16" and self.BF16_SHADOWS and ci % 8 == 0:
+            _, wf = self._shadows()
+            wb = wf[self._off(pre + "weight"):]
+            if k in (1, 3) and stride == 1 and not transposed and pad == k // 2:       # the LDS halo-tile kernel
+                y = K.conv3x3_bf16w(inp, wb, K=ci, Nc=co, flip=False, ksize=k, bias=b, residual=residual)
+                if y is not None:
+                    return y
         return K.conv_igemm(inp, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=transposed, w_kn=True, K=ci, Nc=co,
-                            out_hw=(oh, ow), mode=_mode_id(self.compute_mode), bias=self._sv[pre + "bias"] if bias else None,
-                            residual=residual)
+                            out_hw=(oh, ow), mode=_mode_id(self.compute_mode), bias=b, residual=residual, wb=wb)
 
     def _conv_bwd(self, dy, inp, pre, k, stride=1, pad=0, transposed=False, bias=True, want_dx=True, dx_out=None, accumulate=False,
                   want_dw=True, in_hw=None):
@@ -246,5 +293,13 @@ class FlatNet(nn.Module):
                          grid_g=(ih, iw), grid_d=(oh, ow), mode=mode, dbias=gv[pre + "bias"] if bias else None)
         if not want_dx:
             return None
+        wb = None
+        if self.compute_mode == "bf16" and self.BF16_SHADOWS and co % 8 == 0:
+            wd, _ = self._shadows()
+            wb = wd[self._off(pre + "weight"):]
+            if k in (1, 3) and stride == 1 and not transposed and pad == k // 2 and kh == k:
+                y = K.conv3x3_bf16w(dy, wb, K=co, Nc=ci, flip=True, ksize=k, out=dx_out, accumulate=accumulate)
+                if y is not None:
+                    return y
         return K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=not transposed, w_kn=False, K=co, Nc=ci,
-                            out_hw=(ih, iw), mode=mode, out=dx_out, accumulate=accumulate)
+                            out_hw=(ih, iw), mode=mode, out=dx_out, accumulate=accumulate, wb=wb)
