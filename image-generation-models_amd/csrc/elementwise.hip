@@ -154,6 +154,38 @@ __global__ void adam_kernel(size_t n4, size_t n, float* __restrict__ p, const fl
     }
 }
 
+// The same update with the step count and learning rate read from device memory, so that a captured hipGraph of
+// (forward, backward, optimizer step) replays correctly: state[0] = step count (float, incremented by adam_tick_kernel before the
+// update), state[1] = learning rate (written by the host when a scheduler changes it).
+__global__ void adam_tick_kernel(float* state) { state[0] += 1.f; }
+__global__ void adam_dev_kernel(size_t n4, size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, const float* __restrict__ state, float b1, float b2, float eps, float gs) {
+    const float t = state[0], lr = state[1];
+    const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+    const float step = lr / bc1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gr = G[j] * gs;
+            M[j] = M[j] + (1.f - b1) * (gr - M[j]);
+            V[j] = b2 * V[j] + (1.f - b2) * gr * gr;
+            P[j] -= step * M[j] / (sqrtf(V[j]) / bc2s + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    size_t i = n4 * 4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        float gr = g[i] * gs;
+        float mj = m[i] + (1.f - b1) * (gr - m[i]);
+        float vj = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mj; v[i] = vj;
+        p[i] -= step * mj / (sqrtf(vj) / bc2s + eps);
+    }
+}
+
 __global__ void axpby_kernel(size_t n, float a, const float* __restrict__ x, int acc, float* __restrict__ y) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         y[i] = a * x[i] + (acc ? y[i] : 0.f);
@@ -265,6 +297,21 @@ extern "C" int mi_adam_step(size_t n, float* p, const float* g, float* m, float*
     size_t n4 = n / 4;
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n4 ? n4 : 1, TPB, 4096)), dim3(TPB), 0, ST, n4, n, p, g, m, v, lr, b1, b2,
                        eps, bc1, sqrtf(bc2), gscale);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_adam_tick(float* state, void* stream) {
+    MI_REQUIRE(state, "bad argument");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, ST, state);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int mi_adam_step_dev(size_t n, float* p, const float* g, float* m, float* v, const float* state, float b1, float b2,
+                                float eps, float gscale, void* stream) {
+    MI_REQUIRE(n > 0 && p && g && m && v && state, "bad argument");
+    MI_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "buffers must be 16-byte aligned");
+    size_t n4 = n / 4;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(nblocks(n4 ? n4 : 1, TPB, 4096)), dim3(TPB), 0, ST, n4, n, p, g, m, v, state, b1, b2, eps, gscale);
     MI_LAUNCH_CHECK();
     return 0;
 }

@@ -615,6 +615,15 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step, gscale=1.0):
           "mi_adam_step")
 
 
+def adam_tick(state):
+    check(load_library().mi_adam_tick(_p(state), _stream()), "mi_adam_tick")
+
+
+def adam_step_dev(p, g, m, v, state, b1, b2, eps, gscale=1.0):
+    """Adam with step count / learning rate in `state` (device float[2]): graph-capturable."""
+    check(load_library().mi_adam_step_dev(p.numel(), _p(p), _p(g), _p(m), _p(v), _p(state), b1, b2, eps, gscale, _stream()), "mi_adam_step_dev")
+
+
 def axpby(a, x, y, accumulate):
     """y = a*x (+ y).  x, y: same logical shape; strided channel slices allowed for 4-D."""
     if x.is_contiguous() and y.is_contiguous():

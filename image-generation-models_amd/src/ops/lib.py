@@ -93,6 +93,8 @@ SIGNATURES = {
     "mi_batchnorm_bwd": [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mi_vae_latent_fwd": [_I, _I, _P, _I, _P, _P, _P, _P],
     "mi_vae_latent_bwd": [_I, _I, _P, _I, _P, _P, _F, _P, _P, _I, _P],
+    "mi_adam_tick": [_P, _P],
+    "mi_adam_step_dev": [_Z, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P],
     "mi_relu_fwd": [_Z, _P, _P, _P],
     "mi_relu_bwd": [_Z, _P, _P, _P, _I, _P],
     "mi_mish_fwd": [_Z, _P, _P, _P],

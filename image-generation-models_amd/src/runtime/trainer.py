@@ -58,7 +58,10 @@ class Trainer:
                  callbacks: Optional[List[Callback]] = None, logger=None, precision: str = "32", accelerator: str = "auto",
                  max_steps: int = -1, limit_train_batches: Optional[int] = None, limit_val_batches: Optional[int] = None,
                  num_sanity_val_steps: int = 2, log_every_n_steps: int = 50, enable_checkpointing: bool = True,
-                 default_root_dir: str = ".", fast_dev_run: bool = False, strategy: str = "auto", **unused):
+                 default_root_dir: str = ".", fast_dev_run: bool = False, strategy: str = "auto", graph_step: bool = False, **unused):
+        # graph_step (not a Lightning argument; `+trainer.graph_step=true`): replay training_step + backward + optimizer step as one
+        # hipGraph for the launch-bound models (src/runtime/graphed.py).  Single process, automatic optimization, fused Adam only.
+        self.graph_step = bool(graph_step)
         self.devices = devices
         self.max_epochs, self.max_steps = max_epochs, max_steps
         self.check_val_every_n_epoch = check_val_every_n_epoch
@@ -170,6 +173,12 @@ class Trainer:
         elif self._reducer is not None and hasattr(optimizer, "grad_scale"):
             optimizer.grad_scale = self._reducer.grad_scale
         self.optimizer = optimizer
+        from .optim import FlatAdam
+        use_graph = (self.graph_step and not manual and isinstance(optimizer, FlatAdam) and device.type == "cuda"
+                     and self._reducer is None and self.world_size == 1)
+        gstep = None
+        if use_graph:
+            optimizer.device_state = True
         bar = next((c for c in self.callbacks if isinstance(c, ProgressBar)), None)
 
         if self.num_sanity_val_steps and val_dataloaders is not None:
@@ -190,6 +199,19 @@ class Trainer:
                 batch = self._to_device(batch, device)
                 if manual:
                     model.training_step(batch, i)
+                elif use_graph and gstep is not None and batch[0].shape == gstep.x.shape:
+                    gstep(batch)
+                    for k_, v_ in gstep.logged.items():
+                        self._log_metric(k_, v_)
+                elif use_graph and self.global_step >= 1 and gstep is None:
+                    # step 0 ran eagerly (lazy module loads, workspaces, Adam state); capture on this batch and replay it once
+                    from .graphed import GraphedTrainStep
+                    model._logged.clear()
+                    gstep = GraphedTrainStep(model, optimizer, batch, warmup=0)
+                    gstep.logged = dict(model._logged)
+                    gstep(batch)
+                    for k_, v_ in gstep.logged.items():
+                        self._log_metric(k_, v_)
                 else:
                     optimizer.zero_grad()
                     if self._reducer is not None:
@@ -213,6 +235,8 @@ class Trainer:
                 print()
             for sch in self.lr_schedulers:                     # epoch-interval schedulers (Lightning's default)
                 sch.step()
+            if use_graph:
+                optimizer.sync_lr()                            # the captured Adam reads its learning rate from device memory
             for cb in self.callbacks:
                 cb.on_train_epoch_end(self, model)
             if val_dataloaders is not None and (epoch + 1) % self.check_val_every_n_epoch == 0:

@@ -154,3 +154,19 @@ def test_refuses_cpu_and_unknown_decoder():
     with pytest.raises(NotImplementedError):
         M.VAE(DM, encoder={"_target_": "src.networks.basic.ConvEncoder", "ndf": 8}, decoder={"_target_": "src.networks.basic.ConvDecoder", "ngf": 8},
               latent_dim=16)                                     # the constructor default "guassian" is rejected by the reference as well
+
+
+def test_graphed_vae_step_draws_fresh_noise():
+    """The VAE step under hipGraph replay: the reparameterisation noise comes from torch's graph-safe device generator, so two replays on
+    the same batch see different eps (different KL / loss), and the loss goes down over replays."""
+    G = importlib.import_module("image-generation-models_amd.src.runtime.graphed")
+    OPT = importlib.import_module("image-generation-models_amd.src.runtime.optim")
+    m = _model(32, 128, seed=3).cuda().train()
+    m.log = lambda *a, **k: None
+    opt = OPT.FlatAdam(m.flat_nets(), lr=1e-3, betas=(0.9, 0.999), device_state=True)
+    x = torch.rand(64, 1, 28, 28, device="cuda") * 2 - 1
+    step = G.GraphedTrainStep(m, opt, (x, None))
+    losses = [float(step((x, None)).detach()) for _ in range(40)]
+    assert len(set(round(v, 3) for v in losses[:4])) == 4                     # fresh noise (and fresh weights) every replay
+    assert sum(losses[-5:]) < sum(losses[:5])
+    assert int(m.encoder._buffer("network.3.num_batches_tracked")) == 43      # 3 warm-up + 40 replays: buffers advance inside the graph

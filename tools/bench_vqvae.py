@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--mode", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--size", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--graph", action="store_true", help="capture the step in a hipGraph (src/runtime/graphed.py)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -46,8 +47,15 @@ def main():
     m.train()
     opt = m.configure_optimizers()
     imgs = torch.rand(a.batch, 3, a.size, a.size, device=dev) * 2 - 1
+    if a.graph:
+        OPT = importlib.import_module("image-generation-models_amd.src.runtime.optim")
+        G = importlib.import_module("image-generation-models_amd.src.runtime.graphed")
+        opt = OPT.FlatAdam(m.flat_nets(), lr=1e-3, betas=(0.9, 0.999), device_state=True)
+        gstep = G.GraphedTrainStep(m, opt, (imgs, None))
 
     def step(i):
+        if a.graph:
+            return gstep((imgs, None))
         loss = m.training_step((imgs, None), i)
         loss.backward()
         opt.step()
@@ -65,6 +73,9 @@ def main():
     out = {"metric": "vqvae_cifar10_32x32_train_images_per_sec", "value": round(a.batch * a.steps / el, 1), "unit": "images/s",
            "ms_per_step": round(el / a.steps * 1e3, 3), "batch": a.batch, "dtype": a.mode, "final_loss": round(float(loss.detach()), 5),
            "train_tflops": round((3 * conv_f + vq_f) * a.batch * a.steps / el / 1e12, 2)}
+    out["graph"] = bool(a.graph)
+    if a.graph:
+        print(json.dumps(out)); return
     # per-kernel GPU time of one further step (HIP events on the launch stream around every conv-family launch)
     K.PROBE = []
     step(0)
