@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Robustness check: three DDPM training steps at batch sizes the fast kernels do not tile evenly (5, 13, 210), fp32 vs bf16 losses.
+   python tools/odd_batch.py"""
 import os, sys, torch
-ROOT = "/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "image-generation-models_amd")]
 from src.models.ddpm import DDPM
 for B in (5, 13, 210):
