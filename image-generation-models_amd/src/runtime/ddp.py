@@ -48,6 +48,8 @@ class FlatGradReducer:
         self._lo = self._hi = None
         if lo is None or hi <= lo:
             return
+        if self.launched and hi < self.launched[-1][0]:
+            hi = self.launched[-1][0]             # alignment padding between two ranges: keep the launches gap-free
         self.launched.append((lo, hi))
         if self.world > 1:
             self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))

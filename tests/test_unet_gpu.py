@@ -340,7 +340,7 @@ def test_rccl_world1_reducer():
             opt.step()
             losses.append(float(loss))
         launched = red.launched
-        assert launched[0][1] >= net._arch.final_range[1] and launched[-1][0] == 0 and len(launched) >= 3
+        assert launched[0][1] >= net._arch.final_range[1] and launched[-1][0] == 0 and len(launched) >= 3, (launched, net._arch.final_range, net._arch.time_range)
         assert all(a[0] == b[1] or a[0] <= b[1] for a, b in zip(launched, launched[1:]))
         assert np.isfinite(losses).all()
     finally:
