@@ -155,13 +155,16 @@ __global__ void adam_kernel(size_t n4, size_t n, float* __restrict__ p, const fl
 }
 
 // The same update with the step count and learning rate read from device memory, so that a captured hipGraph of
-// (forward, backward, optimizer step) replays correctly: state[0] = step count (float, incremented by adam_tick_kernel before the
-// update), state[1] = learning rate (written by the host when a scheduler changes it).
-__global__ void adam_tick_kernel(float* state) { state[0] += 1.f; }
+// (forward, backward, optimizer step) replays correctly: state[0] = step count (the BITS of a uint32, incremented by
+// adam_tick_kernel before the update), state[1] = learning rate (float, written by the host when a scheduler changes it).
+// The bias corrections 1 - b^t are evaluated in double from the double-precision betas, exactly like the host does for
+// adam_kernel (1 - 0.999^t cancels ~4 digits in fp32 for small t), so eager and replayed steps apply the same update.
+__global__ void adam_tick_kernel(float* state) { reinterpret_cast<unsigned*>(state)[0] += 1u; }
 __global__ void adam_dev_kernel(size_t n4, size_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                float* __restrict__ v, const float* __restrict__ state, float b1, float b2, float eps, float gs) {
-    const float t = state[0], lr = state[1];
-    const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+                                float* __restrict__ v, const float* __restrict__ state, double b1d, double b2d, float eps, float gs) {
+    const double t = (double)reinterpret_cast<const unsigned*>(state)[0];
+    const float lr = state[1], b1 = (float)b1d, b2 = (float)b2d;
+    const float bc1 = (float)(1.0 - pow(b1d, t)), bc2s = sqrtf((float)(1.0 - pow(b2d, t)));
     const float step = lr / bc1;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
@@ -306,7 +309,7 @@ extern "C" int mi_adam_tick(float* state, void* stream) {
     MI_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int mi_adam_step_dev(size_t n, float* p, const float* g, float* m, float* v, const float* state, float b1, float b2,
+extern "C" int mi_adam_step_dev(size_t n, float* p, const float* g, float* m, float* v, const float* state, double b1, double b2,
                                 float eps, float gscale, void* stream) {
     MI_REQUIRE(n > 0 && p && g && m && v && state, "bad argument");
     MI_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "buffers must be 16-byte aligned");

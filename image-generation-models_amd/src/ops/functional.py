@@ -19,6 +19,9 @@ PROBE = None      # bench.py sets this to a list to collect (kernel symbol, algo
 
 
 def _stream() -> C.c_void_p:
+    """torch's current stream on the CURRENT device: kernels launch on the current HIP device, so every wrapper first checks
+    (`_need_gpu`) that its tensors live there -- a rank that forgot `torch.cuda.set_device(LOCAL_RANK)` raises instead of
+    launching on GPU 0 against another GPU's memory."""
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -31,6 +34,9 @@ def _need_gpu(t: torch.Tensor):
         raise RuntimeError("libmi_ddpm kernels need tensors on an MI355X (HIP) device; there is no CPU fallback")
     if t.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError(f"expected float32 (or bf16 block-internal storage), got {t.dtype}")
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"tensor is on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}; "
+                           "call torch.cuda.set_device(tensor.device) first (one process per GPU)")
 
 
 def ld_of(t: torch.Tensor) -> int:
@@ -235,12 +241,16 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
 
 
 _WS = {}
+_WS_RETIRED = []      # outgrown workspaces stay allocated: a captured hipGraph may still write its partial tiles there
 
 
 def _workspace(device, nbytes):
-    """Persistent per-device scratch (static address: safe to reference from a captured hipGraph)."""
+    """Persistent per-device scratch.  The address a launch saw stays valid for the life of the process (captured hipGraphs
+    keep referencing it): when a later call needs more, a larger buffer is added and the old one is retired, never freed."""
     cur = _WS.get(device)
     if cur is None or cur.numel() * 4 < nbytes:
+        if cur is not None:
+            _WS_RETIRED.append(cur)
         cur = torch.empty((max(int(nbytes), 64 << 20) + 3) // 4, device=device, dtype=torch.float32)
         _WS[device] = cur
     return cur

@@ -94,7 +94,7 @@ SIGNATURES = {
     "mi_vae_latent_fwd": [_I, _I, _P, _I, _P, _P, _P, _P],
     "mi_vae_latent_bwd": [_I, _I, _P, _I, _P, _P, _F, _P, _P, _I, _P],
     "mi_adam_tick": [_P, _P],
-    "mi_adam_step_dev": [_Z, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P],
+    "mi_adam_step_dev": [_Z, _P, _P, _P, _P, _P, C.c_double, C.c_double, _F, _F, _P],
     "mi_relu_fwd": [_Z, _P, _P, _P],
     "mi_relu_bwd": [_Z, _P, _P, _P, _I, _P],
     "mi_mish_fwd": [_Z, _P, _P, _P],

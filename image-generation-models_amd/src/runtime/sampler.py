@@ -30,8 +30,14 @@ class GraphSampler:
         self.t.sub_(self.one)
 
     def refresh(self):
-        """Recompute the time-bias table in place (call after the weights changed; the captured graph reads it)."""
-        tab = self.gd.denoise_fn.time_bias_table(self.gd.num_timesteps)
+        """Bring everything the captured graph reads from static buffers up to date with the current weights: the time-bias
+        table, and in bf16 mode the bf16 weight copies (the pack launch runs from Python in forward_nhwc only when the master
+        buffer changed, so it is NOT part of the captured iteration -- without this a replay after an optimizer step or
+        load_state_dict would convolve with the old weights)."""
+        net = self.gd.denoise_fn
+        if getattr(net, "compute_mode", "fp32") == "bf16":
+            net._shadows()
+        tab = net.time_bias_table(self.gd.num_timesteps)
         if self.tb_table is None:
             self.tb_table = tab
         else:

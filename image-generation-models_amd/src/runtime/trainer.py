@@ -139,6 +139,8 @@ class Trainer:
     # ------------------------------------------------------------------ loops
     def fit(self, model, datamodule=None, train_dataloaders=None, val_dataloaders=None):
         device = self._device()
+        if device.type == "cuda":
+            torch.cuda.set_device(device)      # kernels launch on the CURRENT HIP device / its current stream (one process per GPU)
         model.trainer = self
         model.to(device)
         if self.precision.startswith("bf16"):

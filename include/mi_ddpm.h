@@ -333,11 +333,12 @@ int mi_p_sample_update(int B, int C, int HW, const float* x, const float* eps_ha
  * bc1 = 1-b1^step, bc2 = 1-b2^step; grad is multiplied by gscale first (DDP average). */
 int mi_adam_step(size_t n, float* p, const float* g, float* m, float* v, float lr, float b1,
                  float b2, float eps, float bc1, float bc2, float gscale, void* stream);
-/* The same update with its step count and learning rate in device memory (state[0] = steps taken, state[1] = lr), so that a
- * captured hipGraph of forward + backward + optimizer step replays correctly: mi_adam_tick increments state[0] (call it once
- * per optimizer step, before the update of every buffer of that step); bias corrections are 1 - b^state[0]. */
+/* The same update with its step count and learning rate in device memory (state[0] = steps taken, stored as the bits of a
+ * uint32; state[1] = lr as float), so that a captured hipGraph of forward + backward + optimizer step replays correctly:
+ * mi_adam_tick increments state[0] (call it once per optimizer step, before the update of every buffer of that step); the bias
+ * corrections 1 - b^state[0] are evaluated in double from the double betas, as the host does for mi_adam_step. */
 int mi_adam_tick(float* state, void* stream);
-int mi_adam_step_dev(size_t n, float* p, const float* g, float* m, float* v, const float* state, float b1, float b2,
+int mi_adam_step_dev(size_t n, float* p, const float* g, float* m, float* v, const float* state, double b1, double b2,
                      float eps, float gscale, void* stream);
 /* y = a*x + (accumulate ? y : 0) */
 int mi_axpby(size_t n, float a, const float* x, int accumulate, float* y, void* stream);
