@@ -169,6 +169,6 @@ def test_two_gpu_nccl_fit_through_trainer(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", os.path.join(PKG, "run.py"), "experiment=ddpm/synthetic", "datamodule.train_size=64",
            "datamodule.val_size=8", "datamodule.batch_size=8", "trainer.max_epochs=1", "trainer.devices=2", "model.hidden_dim=16",
-           "+trainer.num_sanity_val_steps=0", "+trainer.check_val_every_n_epoch=100", f"log_dir={tmp_path}", "print_config=False"]
+           "+trainer.num_sanity_val_steps=0", "trainer.check_val_every_n_epoch=100", f"log_dir={tmp_path}", "print_config=False"]
     r = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
