@@ -62,10 +62,12 @@ class GraphSampler:
             self._capture()
         else:
             self.refresh()
-        self.x.copy_(torch.randn(self.shape, device=self.x.device))
+        # noise: device Philox by default; `gd.noise_source` (parity runs) supplies a host tape in the reference's draw order --
+        # randn(shape) for x_T, then one draw per step (ddpm.py:404-408,268-273)
+        self.x.copy_(gd._randn(self.shape, self.x.device))
         self.t.fill_(gd.num_timesteps - 1)
         for _ in range(gd.num_timesteps):
-            self.z.copy_(torch.randn(self.shape, device=self.x.device))
+            self.z.copy_(gd._randn(self.shape, self.x.device))
             self.graph.replay()
             if record is not None:
                 record.append(self.x.clone())

@@ -1,0 +1,27 @@
+"""Measured parity errors of the bf16-MFMA mode, recorded while the GPU tests run.
+
+Every bf16-mode test calls `record(case, metric=value, ...)` with what it measured before asserting its tolerance; the values
+are merged into gpurun_out/r02_parity.json on the GPU box (committed as profiles/r02_parity.json), so a tolerance in a test can be
+read next to the error it bounds (the rule: tolerance <= 2x the recorded worst case)."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATH = os.path.join(ROOT, "gpurun_out", "r02_parity.json")
+
+
+def record(case: str, **metrics):
+    vals = {k: (float(v) if isinstance(v, (int, float)) else v) for k, v in metrics.items()}
+    print(f"[parity] {case}: " + ", ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in vals.items()))
+    try:
+        os.makedirs(os.path.dirname(PATH), exist_ok=True)
+        data = {}
+        if os.path.exists(PATH):
+            with open(PATH) as f:
+                data = json.load(f)
+        data[case] = vals
+        with open(PATH, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    return vals

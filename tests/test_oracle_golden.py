@@ -121,6 +121,33 @@ def test_tiny_sampler_T8(golden_dir):
     assert torch.equal(torch.randn(2, 3, 8, 8), tape[0])
 
 
+def _tape(shape, seed, n, sha):
+    """The reference's host noise tape re-drawn from torch's CPU generator; refuses a tape that is not the recorded one."""
+    import hashlib
+    torch.manual_seed(seed)
+    tape = [torch.randn(shape) for _ in range(n)]
+    h = hashlib.sha256()
+    for z in tape:
+        h.update(z.numpy().tobytes())
+    assert h.hexdigest() == sha, "torch's CPU generator drew a different tape than the one the golden images were made with"
+    return tape
+
+
+def test_tiny_sampler_T1000(golden_dir):
+    """Full-length reverse process (ddpm.py:399-415), T=1000, against the reference's sampled images and three way-points."""
+    g, p = _tiny(golden_dir)
+    s = _load(golden_dir, "t1000_sampler.npz")
+    T = int(s["T"])
+    tab = O.schedule_tables(T)
+    tape = _tape((2, 3, 8, 8), int(s["seed"]), T + 1, str(s["tiny.tape_sha256"]))
+    it = iter(tape)
+    way = []
+    out = O.p_sample_loop(p, tab, (2, 3, 8, 8), lambda shape: next(it), record=way)
+    for m in s["marks"]:
+        assert torch.allclose(way[int(m) - 1], _t(s[f"tiny.after{int(m)}"]), atol=2e-5, rtol=0), int(m)
+    assert torch.allclose(out, _t(s["tiny.sample"]), atol=2e-5, rtol=0)
+
+
 def test_mid_unet(golden_dir):
     g = _load(golden_dir, "mid_unet.npz")
     torch.manual_seed(0)
@@ -213,6 +240,24 @@ def test_vqvae_oracle_matches_reference_vectors(golden_dir):
         assert abs(float(val) - float(g["cfg4." + name])) <= 1e-6 * abs(float(g["cfg4." + name])), name
     assert torch.equal(idx, torch.from_numpy(g["cfg4.idx"]))
     for (k, gr), ref in zip(grads.items(), g["cfg4.gstats"]):
+        assert abs(float(gr.double().norm()) - ref[1]) <= 1e-4 * ref[1], k
+    # cfg4_64: BASELINE configs[3] at its own size (3x64x64), seeded default init of the reference
+    torch.manual_seed(1240)
+    m = M.VQVAE({"width": 64, "height": 64, "channels": 3, "transforms": {"normalize": True}},
+                encoder={"_target_": "src.networks.vqvae.Encoder"}, decoder={"_target_": "src.networks.vqvae.Decoder"},
+                latent_dim=64, beta=0.25)
+    with torch.no_grad():
+        m.vector_quntizer.embedding.mul_(512 * 0.05)
+    ws = np.array([[float(p.detach().double().sum()), float(p.detach().double().abs().sum())] for _, p in m.named_parameters()])
+    assert np.array_equal(ws, g["cfg4_64.wstats"])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    imgs = torch.from_numpy(g["cfg4_64.imgs"])
+    (total, recon, vq, commit, idx), grads = VO.training_grads(sd, imgs, 0.25)
+    for name, val in (("total", total), ("recon", recon), ("vq", vq), ("commit", commit)):
+        assert abs(float(val) - float(g["cfg4_64." + name])) <= 1e-6 * abs(float(g["cfg4_64." + name])), name
+    assert torch.equal(idx, torch.from_numpy(g["cfg4_64.idx"]))
+    assert torch.allclose(VO.forward(sd, imgs, 0.25), torch.from_numpy(g["cfg4_64.forward"]), rtol=1e-5, atol=1e-6)
+    for (k, gr), ref in zip(grads.items(), g["cfg4_64.gstats"]):
         assert abs(float(gr.double().norm()) - ref[1]) <= 1e-4 * ref[1], k
 
 

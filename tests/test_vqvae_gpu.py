@@ -84,6 +84,69 @@ def test_cfg4_training_step_matches_reference(golden_dir):
         _close(params[k].grad, gr, 1e-4, k)
 
 
+def _cfg4_64(mode="fp32"):
+    torch.manual_seed(1240)
+    m = M.VQVAE({**DM, "width": 64, "height": 64}, encoder=ENC, decoder=DEC, latent_dim=64, beta=0.25)
+    with torch.no_grad():
+        m.vector_quntizer.embedding.mul_(512 * 0.05)
+    for net in (m.encoder, m.decoder):
+        net.compute_mode = mode
+    return m.cuda()
+
+
+def test_cfg4_at_64x64_matches_reference(golden_dir):
+    """BASELINE configs[3] at its OWN size: VQ-VAE on 3x64x64 (CelebA) images, configs/model/vqvae.yaml sizes, the reference's
+    seeded default init; vectors from the reference's VQVAE.training_step / forward (tools/gen_golden_vqvae.py, case cfg4_64)."""
+    g = np.load(os.path.join(golden_dir, "vqvae_kats.npz"))
+    m = _cfg4_64()
+    imgs = torch.from_numpy(g["cfg4_64.imgs"]).cuda()
+    m.eval()
+    _close(m(imgs), torch.from_numpy(g["cfg4_64.forward"]), 2e-5, "forward")
+    assert torch.equal(m.vector_quntizer.indices(m.encoder(imgs)).flatten().cpu().long(), torch.from_numpy(g["cfg4_64.idx"]))
+    m.train()
+    logged = {}
+    m.log = lambda k, v, *a, **kw: logged.__setitem__(k, float(v))
+    total = m.training_step((imgs, None), 0)
+    total.backward()
+    assert abs(float(total) - float(g["cfg4_64.total"])) <= 2e-6 * abs(float(g["cfg4_64.total"]))
+    for key, name in (("train_loss/recon_loss", "recon"), ("train_loss/vq_loss", "vq"), ("train_loss/commit_loss", "commit")):
+        assert abs(logged[key] - float(g["cfg4_64." + name])) <= 2e-6 * abs(float(g["cfg4_64." + name])), key
+    params = dict(m.named_parameters())
+    for k, ref in zip(list(g["cfg4.names"]), g["cfg4_64.gstats"]):
+        gr = params[k].grad.double()
+        assert abs(float(gr.norm()) - ref[1]) <= 1e-4 * ref[1], k
+        assert abs(float(gr.sum()) - ref[0]) <= 1e-4 * ref[1] * gr.numel() ** 0.5, k
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    _, grads = VO.training_grads(sd, imgs.cpu(), 0.25)
+    for k, gr in grads.items():
+        _close(params[k].grad, gr, 1e-4, k)
+
+
+def test_cfg4_at_64x64_bf16_mode(golden_dir):
+    """The benchmarked (bf16-MFMA) mode at 64x64 against the same reference vectors, with the measured errors recorded
+    (tolerances = 2x what profiles/r02_parity.json holds)."""
+    from _parity import record
+    g = np.load(os.path.join(golden_dir, "vqvae_kats.npz"))
+    m = _cfg4_64("bf16")
+    imgs = torch.from_numpy(g["cfg4_64.imgs"]).cuda()
+    m.eval()
+    fwd = m(imgs).float().cpu()
+    ref = torch.from_numpy(g["cfg4_64.forward"])
+    e_fwd = float((fwd - ref).norm() / ref.norm())
+    idx = m.vector_quntizer.indices(m.encoder(imgs)).flatten().cpu().long()
+    mismatch = float((idx != torch.from_numpy(g["cfg4_64.idx"])).float().mean())
+    m.train()
+    total = m.training_step((imgs, None), 0)
+    total.backward()
+    e_loss = abs(float(total) - float(g["cfg4_64.total"])) / abs(float(g["cfg4_64.total"]))
+    params = dict(m.named_parameters())
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    _, grads = VO.training_grads(sd, imgs.cpu(), 0.25)
+    e_grad = max(float((params[k].grad.cpu() - gr).norm() / (gr.norm() + 1e-30)) for k, gr in grads.items() if float(gr.norm()) > 1e-8)
+    record("vqvae_cfg4_64_bf16", forward_rel_l2=e_fwd, index_mismatch_frac=mismatch, loss_rel=e_loss, worst_grad_rel_l2=e_grad)
+    assert e_fwd <= 2e-2 and e_loss <= 2e-2 and mismatch <= 0.05 and e_grad <= 0.2, (e_fwd, e_loss, mismatch, e_grad)
+
+
 def test_encoder_decoder_standalone_autograd():
     """The networks API: NCHW in, NCHW out, torch autograd on both sides (src/networks/base.py contract)."""
     torch.manual_seed(5)

@@ -12,6 +12,8 @@ tests/golden/vqvae_kats.npz.
          by 512 * 0.05 (smallest relative argmin gap 4.8e-4: no near-ties) -- images, per-parameter (sum, |sum|) of the weights, losses,
          indices, per-parameter gradient (sum, L2 norm), forward output.
 
+  cfg4_64 : the same at BASELINE configs[3]'s own size, 4x3x64x64 images (seed 1240, smallest relative argmin gap 1.6e-4): same fields as cfg4.
+
     python tools/gen_golden_vqvae.py
 """
 import importlib
@@ -115,6 +117,19 @@ def main():
     out.update({"cfg4.total": np.float64(total), "cfg4.recon": np.float64(recon), "cfg4.vq": np.float64(vq_loss),
                 "cfg4.commit": np.float64(commit_loss), "cfg4.idx": idx.numpy().astype(np.int64),
                 "cfg4.forward": fwd.numpy().astype(np.float32)})
+    # ---- cfg4_64: BASELINE configs[3] at its own size (CelebA 64x64 -> 16x16 latents, 256 rows per image)
+    torch.manual_seed(1240)
+    m = build(ref, 64, 64, 512, 0.25, {}, {})
+    with torch.no_grad():
+        m.vector_quntizer.embedding.mul_(512 * 0.05)
+    imgs = torch.rand(4, 3, 64, 64) * 2 - 1
+    total, recon, vq_loss, commit_loss, idx, fwd = run(m, imgs)
+    out["cfg4_64.imgs"] = imgs.numpy()
+    out["cfg4_64.wstats"] = np.array([[float(p.detach().double().sum()), float(p.detach().double().abs().sum())] for _, p in m.named_parameters()])
+    out["cfg4_64.gstats"] = np.array([[float(p.grad.double().sum()), float(p.grad.double().norm())] for _, p in m.named_parameters()])
+    out.update({"cfg4_64.total": np.float64(total), "cfg4_64.recon": np.float64(recon), "cfg4_64.vq": np.float64(vq_loss),
+                "cfg4_64.commit": np.float64(commit_loss), "cfg4_64.idx": idx.numpy().astype(np.int64),
+                "cfg4_64.forward": fwd.numpy().astype(np.float32)})
     np.savez_compressed(os.path.join(OUT, "vqvae_kats.npz"), **out)
     print("wrote vqvae_kats.npz:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if not k.startswith("tiny.sd.") and not k.startswith("tiny.grad.")})
     print("names:", names)
