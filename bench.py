@@ -11,11 +11,15 @@ backward, gradient all-reduce (N>1, RCCL, overlapped with backward), fused Adam.
 skipped or cached between steps.  The denoise rate (hipGraph-replayed p_sample at B=64) is
 reported beside it.  One JSON line is printed by rank 0.
 
-For N>1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
+N>1: one process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks come from
+the environment; a bare `python bench.py --gpus N` (no RANK in the environment) re-launches itself under torch.distributed.run
+(--standalone, 127.0.0.1) and relays rank 0's JSON line.  `--dry-run-cpu` exercises exactly that launch / rendezvous / max-over-
+ranks plumbing with gloo and a stand-in step on the host (no GPU, no kernels; the line says "dry_run": true).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,13 +32,17 @@ import torch
 import torch.distributed as dist
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X_MICROARCH.md: dense bf16 MFMA / fp32-input MFMA
+PEAK_HBM_GBS = 8000.0                              # HBM3E spec
 TRAIN_GFLOP_PER_IMAGE = 19.424                     # SURVEY.md 8(d), cfg 2: fwd 6.4748 x 3
 FWD_GFLOP_PER_IMAGE = 6.4748
+NAMED_GFLOP = 38.65                                # level-0 fused GN-apply+Mish(+temb)+Conv3x3 [128,32,32,128]->128
+NAMED_MB = {"fp32": 134.9, "bf16": 67.5}           # its algorithmic HBM bytes by activation storage
 
 
-def cpu_baseline(seconds_budget: float = 20.0):
-    """The CPU oracle (proven equal to the reference in the build container, tests/golden) timed on
-    this box's host cores: same UNet/config, fp32, B=16 training steps (fwd+bwd+Adam)."""
+def cpu_baseline(budget_s: float = 28.0):
+    """The CPU oracle (proven equal to the reference in the build container, tests/golden) timed on this box's host cores,
+    fp32, the three legs of BASELINE.md section 4: train steps (fwd+bwd+Adam) at B=16 and at B=128 (the GPU line's batch), one
+    p_sample at B=64.  Each leg: 1 warm-up call, then timed calls until its share of the budget is spent (at least 1)."""
     from oracle import ddpm_oracle as O
     threads = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(threads)
@@ -42,32 +50,146 @@ def cpu_baseline(seconds_budget: float = 20.0):
     p = {k: v.requires_grad_(True) for k, v in O.init_unet_params(128, (1, 2, 4), 3).items()}
     tab = O.schedule_tables(1000)
     opt = torch.optim.Adam(list(p.values()), lr=1e-4, betas=(0.9, 0.999))
-    B = 16
-    x = torch.rand(B, 3, 32, 32) * 2 - 1
+
+    def timed(fn, share, max_calls):
+        fn()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fn(); n += 1
+            el = time.perf_counter() - t0
+            if el > share or n >= max_calls:
+                return n, el
+
+    def train_leg(B, share, max_calls):
+        x = torch.rand(B, 3, 32, 32) * 2 - 1
+
+        def step():
+            t = torch.randint(0, 1000, (B,))
+            noise = torch.randn_like(x)
+            opt.zero_grad()
+            loss, _ = O.p_losses(p, tab, x, t, noise)
+            loss.backward()
+            opt.step()
+        n, el = timed(step, share, max_calls)
+        return {"value": round(B * n / el, 2), "unit": "images/s", "batch": B, "calls": n, "seconds": round(el, 1)}
+
+    def sample_leg(B, share, max_calls):
+        x = torch.randn(B, 3, 32, 32)
+        t = torch.full((B,), 500, dtype=torch.long)
+        pd = {k: v.detach() for k, v in p.items()}
+
+        def step():
+            with torch.no_grad():
+                O.p_sample_update(tab, x, t, O.unet_forward(pd, x, t), torch.randn_like(x))
+        n, el = timed(step, share, max_calls)
+        return {"value": round(n / el, 3), "unit": "denoise steps/s", "batch": B, "calls": n, "seconds": round(el, 1),
+                "image_steps_per_sec": round(B * n / el, 1)}
+
+    legs = {"train_b16": train_leg(16, budget_s * 0.2, 8), "train_b128": train_leg(128, budget_s * 0.3, 3),
+            "p_sample_b64": sample_leg(64, budget_s * 0.1, 3)}
+    main = legs["train_b128"]
+    return {"value": main["value"], "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{main['calls']} fp32 train steps (fwd+bwd+Adam) of the cfg-2 UNet at B=128 (the GPU line's batch) after 1 warm-up "
+                      f"step, {main['seconds']} s; legs: B=16 train, B=128 train, one p_sample at B=64 (BASELINE.md section 4)",
+            "legs": legs}
+
+
+def relaunch(args):
+    """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run and relay the line."""
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MI_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run_cpu(args, world, rank):
+    """Launch plumbing on the host: gloo ranks, a stand-in step (bucketed all-reduce over a small flat buffer + a sleep),
+    barrier-bracketed timing, MAX over ranks, rank 0 prints the line.  No kernels run; nothing here is a measurement."""
+    from src.runtime.ddp import FlatGradReducer
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    flat = torch.ones(1 << 16)
+    red = FlatGradReducer(flat, bucket_bytes=1 << 16) if world > 1 else None
+    ones = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(ones)
 
     def step():
-        t = torch.randint(0, 1000, (B,))
-        noise = torch.randn_like(x)
-        opt.zero_grad()
-        loss, _ = O.p_losses(p, tab, x, t, noise)
-        loss.backward()
-        opt.step()
+        if red is not None:
+            red.begin()
+            for hi in range(flat.numel(), 0, -(1 << 13)):
+                red.range_ready(hi - (1 << 13), hi)
+            red.finish()
+        time.sleep(0.002)
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "ddpm_cifar10_32x32_train_images_per_sec", "dry_run": True, "value": None, "unit": "images/s",
+                          "n_gpus": world, "rccl_ranks": int(ones.item()), "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(el) / args.steps * 1e3, 3), "scaling": "weak", "higher_is_better": True,
+                          "buckets_bytes": [4 * (hi - lo) for lo, hi in red.launched] if red else [],
+                          "self_launched": os.environ.get("MI_BENCH_SELF_LAUNCHED") == "1"}))
+    if world > 1:
+        dist.destroy_process_group()
 
-    step()
-    n, t0 = 0, time.perf_counter()
-    while True:
-        step(); n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 40:
-            break
-    return {"value": round(B * n / el, 2), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{n} fp32 train steps (fwd+bwd+Adam) of the cfg-2 UNet at B={B} after 1 warm-up step, {el:.1f} s"}
+
+def named_kernel_line(K, dev):
+    """north_star's named unit at its canonical shape: GroupNorm-apply + Mish (+ time bias) + Conv3x3 on
+    X = [128,32,32,128] NHWC -> 128 channels, level 0 of cfg 2.  Timed standalone with HIP events on the launch stream, for both
+    activation storages of the bf16-MFMA mode; `unit_us` is the whole unit (every launch it takes: today the GN pass and the conv),
+    hbm_frac = algorithmic bytes / unit time / 8 TB/s, mfma_frac = 38.65 GFLOP / unit time / 2.5 PFLOP/s."""
+    from src.ops.lib import load_library
+    out = {"shape": "[128,32,32,128] NHWC -> 128, 3x3/s1/p1", "gflop": NAMED_GFLOP}
+    N, H, W, Cc = 128, 32, 32, 128
+    g = torch.Generator(device=dev).manual_seed(7)
+    gamma = torch.ones(Cc, device=dev); beta = torch.zeros(Cc, device=dev)
+    temb = torch.randn(N, Cc, device=dev, generator=g) * 0.1
+    w = (torch.randn(9 * Cc * Cc, device=dev, generator=g) * 0.03).to(torch.bfloat16)
+    bias = torch.zeros(Cc, device=dev)
+    for sto, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        x = torch.randn(N, H, W, Cc, device=dev, generator=g).to(dt)
+
+        def unit():
+            h, _ = K.gn_mish_fwd(x, gamma, beta, temb=temb, out_dtype=dt)
+            return K.conv3x3_bf16w(h, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt)
+        for _ in range(5):
+            unit()
+        K.PROBE = []
+        for _ in range(20):
+            unit()
+        torch.cuda.synchronize()
+        per = {}
+        for sym, fl, e0, e1, desc, nb in K.PROBE:
+            per.setdefault(sym, []).append(e0.elapsed_time(e1) * 1e3)
+        K.PROBE = None
+        launches = {k: round(sorted(v)[len(v) // 2], 2) for k, v in per.items()}         # median us per launch
+        unit_us = sum(launches.values())
+        out[sto + "_storage"] = {"launches_us": launches, "unit_us": round(unit_us, 2), "algorithmic_mb": NAMED_MB[sto],
+                                 "hbm_gbs": round(NAMED_MB[sto] * 1e6 / (unit_us * 1e-6) / 1e9, 1),
+                                 "hbm_frac": round(NAMED_MB[sto] * 1e6 / (unit_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+                                 "tflops": round(NAMED_GFLOP * 1e9 / (unit_us * 1e-6) / 1e12, 1),
+                                 "mfma_frac": round(NAMED_GFLOP * 1e9 / (unit_us * 1e-6) / 1e12 / PEAK_TFLOPS["bf16"], 4)}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--prewarm", type=int, default=25,
                     help="untimed set-up steps before the W warm-up steps: on a fresh box the first ~20 steps of a process are "
@@ -76,32 +198,46 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (reference default 128)")
     ap.add_argument("--denoise-steps", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32-mode leg, the named-kernel microbenchmark and the CPU baseline")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("MI_BENCH_GRAPH", "-1")),
+                    help="1: replay the training step as a hipGraph (single GPU), 0: eager, -1: the trainer's default for this config")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="launch/rendezvous plumbing only (gloo, host stand-in step)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(relaunch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, world, rank)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or (os.environ.get("MI_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)   # the latter: 1-rank RCCL dry run
+    rccl_ranks = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                           # how many ranks RCCL really connected
+        rccl_ranks = int(ones.item())
 
     from src.models.ddpm import DDPM
     from src.ops import functional as K
     from src.runtime.ddp import FlatGradReducer, broadcast_parameters
 
-    torch.manual_seed(0)
-    dm_cfg = {"width": 32, "height": 32, "channels": 3, "transforms": {"normalize": True}}
-    model = DDPM(dm_cfg, hidden_dim=128, dim_mults=(1, 2, 4), timesteps=1000, loss_type="l1",
+    def build(mode):
+        torch.manual_seed(0)
+        dm_cfg = {"width": 32, "height": 32, "channels": 3, "transforms": {"normalize": True}}
+        m = DDPM(dm_cfg, hidden_dim=128, dim_mults=(1, 2, 4), timesteps=1000, loss_type="l1",
                  lr=1e-4, b1=0.9, b2=0.999).to(dev)                      # configs/model/ddpm.yaml values
-    net = model.denoising_model
-    net.compute_mode = args.mode
-    model.train()
-    opt = model.configure_optimizers()
+        m.denoising_model.compute_mode = mode
+        m.train()
+        return m, m.denoising_model, m.configure_optimizers()
+
+    model, net, opt = build(args.mode)
     reducer = None
     if use_dist:
         broadcast_parameters(net.flat_params)
@@ -114,15 +250,27 @@ def main():
     imgs = torch.rand(B, 3, 32, 32, device=dev, generator=gen) * 2 - 1    # synthetic [-1,1] batch, HBM resident
     batch = (imgs, None)
 
-    def train_step(i):
+    def eager_step(i, m=None, o=None):
+        m, o = m or model, o or opt
         if reducer is not None:
             reducer.begin()
-        loss = model.training_step(batch, i)       # randint(t) -> randn(eps) -> q_sample -> UNet -> L1
+        loss = m.training_step(batch, i)           # randint(t) -> randn(eps) -> q_sample -> UNet -> L1
         loss.backward()                            # UNet backward (+ bucketed RCCL all-reduce)
         if reducer is not None:
             reducer.finish()
-        opt.step()                                 # fused Adam over the flat buffer
+        o.step()                                   # fused Adam over the flat buffer
         return loss
+
+    # hipGraph replay of the whole step (single process): same kernels, same order, one graph launch per step
+    use_graph = args.graph == 1 and not use_dist
+    train_step = eager_step
+    if use_graph:
+        from src.runtime.graphed import GraphedTrainStep
+        opt.device_state = True
+        for i in range(3):
+            eager_step(i)
+        gstep = GraphedTrainStep(model, opt, batch, warmup=0)
+        train_step = lambda i: gstep(batch)        # noqa: E731
 
     def sync():
         if use_dist:
@@ -145,6 +293,25 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     images_per_s = world * B * args.steps / elapsed
 
+    # ---- exposed all-reduce time: GPU time on the compute stream between the end of backward and the start of Adam
+    comm = None
+    if reducer is not None:
+        waits = []
+        for i in range(5):
+            reducer.begin()
+            loss = model.training_step(batch, i); loss.backward()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); reducer.finish(); e1.record()
+            opt.step()
+            waits.append((e0, e1))
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in waits)
+        comm = {"allreduce_ms_exposed": round(ms[len(ms) // 2], 3), "buckets_bytes": [4 * (hi - lo) for lo, hi in reducer.launched]}
+        if use_dist:
+            t = torch.tensor([comm["allreduce_ms_exposed"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            comm["allreduce_ms_exposed"] = round(float(t), 3)
+
     # ---- denoise rate: hipGraph-replayed reverse step at B=64 (ddpm.py:520 samples 64 images)
     from src.runtime.sampler import GraphSampler
     model.eval()
@@ -166,50 +333,83 @@ def main():
     denoise_steps_per_s = world * args.denoise_steps / den
     model.train()
 
-    # ---- roofline of the dominant kernel: HIP events around every conv-family launch of two further
-    #      training steps (on the stream the kernels run on); a launch's time is the smaller of its two
-    #      measurements, symbols carry the template arguments rocprofv3 prints for the same instantiation
+    # ---- per-kernel times of the step: HIP events (on the launch stream) around every library launch of three further EAGER
+    #      training steps; a launch's time is the smallest of its measurements; symbols carry the template arguments rocprofv3
+    #      prints.  The contraction and the partial-tile reduce of the weight-gradient kernel are timed as separate launches.
     roof = None
     if rank == 0:
         runs = []
-        for i in range(2):
+        for i in range(3):
             K.PROBE = []
-            train_step(i)
+            eager_step(i)
             torch.cuda.synchronize()
-            runs.append([(sym, flops, e0.elapsed_time(e1) * 1e-3, desc) for sym, flops, e0, e1, desc in K.PROBE])
+            runs.append([(sym, fl, e0.elapsed_time(e1) * 1e-3, desc, nb) for sym, fl, e0, e1, desc, nb in K.PROBE])
         K.PROBE = None
-        agg = {}
-        if len(runs[0]) == len(runs[1]):
-            launches = [(a[0], a[1], min(a[2], b[2])) for a, b in zip(runs[0], runs[1])]
+        if len({len(r) for r in runs}) == 1:
+            launches = [(a[0], a[1], min(x[2] for x in grp), a[4]) for grp in zip(*runs) for a in (grp[0],)]
         else:
-            launches = [(a[0], a[1], a[2]) for a in runs[1]]
-        for sym, flops, sec in launches:
-            v = agg.setdefault(sym, [0.0, 0.0, 0])
-            v[0] += flops; v[1] += sec; v[2] += 1
-        single = {k: v for k, v in agg.items() if "+reduce" not in k}         # symbols that are exactly one kernel
-        sym, (fl, sec, cnt) = max(single.items(), key=lambda kv: kv[1][1])
+            launches = [(a[0], a[1], a[2], a[4]) for a in runs[-1]]
+        agg = {}
+        for sym, fl, sec, nb in launches:
+            v = agg.setdefault(sym, [0.0, 0.0, 0, 0.0])
+            v[0] += fl; v[1] += sec; v[2] += 1; v[3] += nb
+        sym, (fl, sec, cnt, nb) = max(agg.items(), key=lambda kv: kv[1][1])          # the symbol with the most time per step
         peak = PEAK_TFLOPS[args.mode]
-        ach = fl / sec / 1e12
         traffic, tnote = None, None
-        try:                                                                   # PMC passes are separate runs (profiles/)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                ent = json.load(f).get(sym)
-            if ent:
-                traffic, tnote = ent["hbm_bytes_per_launch"], ent["note"]
-        except OSError:
-            pass
-        roof = {"kernel": sym, "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": tnote, "launches_per_step": cnt,
-                "avg_launch_us": round(sec / cnt * 1e6, 2), "avg_gflop_per_launch": round(fl / cnt / 1e9, 3),
-                "all_conv_kernels": {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "launches_per_step": v[2],
-                                         "ms_per_step": round(v[1] * 1e3, 3)} for k, v in sorted(agg.items())}}
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):               # PMC passes are separate runs (profiles/)
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    ent = json.load(f).get(sym)
+                if ent:
+                    traffic, tnote = ent["hbm_bytes_per_launch"], ent["note"] + f" ({name})"
+                    break
+            except OSError:
+                pass
+        mfma_bound = fl > 0 and fl / max(nb, 1.0) > 312.0                            # bf16 machine balance, SURVEY 8(d)
+        ach = fl / sec / 1e12 if mfma_bound else nb / sec / 1e9
+        pk = peak if mfma_bound else PEAK_HBM_GBS
+        table = {}
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            ent = {"launches_per_step": v[2], "ms_per_step": round(v[1] * 1e3, 3)}
+            if v[0] > 0:
+                ent["tflops"] = round(v[0] / v[1] / 1e12, 1)
+            if v[3] > 0:
+                ent["algorithmic_gbs"] = round(v[3] / v[1] / 1e9, 1)
+            table[k] = ent
+        roof = {"kernel": sym, "bound": "mfma" if mfma_bound else "hbm", "achieved": round(ach, 1), "peak": pk,
+                "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": round(ach / pk, 4), "traffic": traffic, "traffic_note": tnote,
+                "launches_per_step": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
+                "avg_gflop_per_launch": round(fl / cnt / 1e9, 3), "avg_algorithmic_mb_per_launch": round(nb / cnt / 1e6, 2),
+                "probed_ms_per_step": round(sum(v[1] for v in agg.values()) * 1e3, 3),
+                "all_kernels": table}
+        if not args.no_extras:
+            roof["named_kernel"] = named_kernel_line(K, dev)
     elif world > 1:
-        for i in range(2):
-            train_step(i)
+        for i in range(3):
+            eager_step(i)
     sync()
 
+    # ---- the parity-carrying fp32 mode (exact-fp32 MFMA), a short driver-timed leg
+    fp32_mode = None
+    if rank == 0 and world == 1 and not args.no_extras and args.mode != "fp32":
+        del gs
+        m32, n32, o32 = build("fp32")
+        for i in range(6):
+            eager_step(i, m32, o32)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for i in range(n):
+            eager_step(i, m32, o32)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        fp32_mode = {"value": round(B * n / el, 1), "unit": "images/s", "ms_per_step": round(el / n * 1e3, 3), "steps": n,
+                     "train_tflops": round(B * n / el * TRAIN_GFLOP_PER_IMAGE / 1e3, 1), "peak_tflops": PEAK_TFLOPS["fp32"],
+                     "note": "exact-fp32 MFMA mode (v_mfma_f32_32x32x2_f32): the mode that carries the <=1e-4 epsilon-prediction bar"}
+        del m32, n32, o32
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_extras:
         cpu = cpu_baseline()
 
     if rank == 0:
@@ -221,13 +421,15 @@ def main():
             "config": {"workload": "DDPM CIFAR-10 32x32 train step (q_sample+UNet fwd+L1+bwd+allreduce+Adam), "
                                    "UNet base_ch=128 mults 1-2-4, T=1000 (BASELINE configs[1])",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "step_launch": "hipGraph replay" if use_graph else "eager",
                        "activations": "NHWC; fp32 residual stream, bf16 block- and attention-internal tensors" if args.mode == "bf16" else "fp32 NHWC", "matmul": "bf16 MFMA, fp32 accumulate" if args.mode == "bf16" else "fp32 MFMA"},
+            "rccl_ranks": rccl_ranks, "comm": comm,
             "denoise_steps_per_sec": round(denoise_steps_per_s, 2), "denoise_batch": 64,
             "denoise_image_steps_per_sec": round(denoise_steps_per_s * 64, 1),
             "train_tflops": round(images_per_s * TRAIN_GFLOP_PER_IMAGE / 1e3, 1),
             "denoise_tflops": round(denoise_steps_per_s * 64 * FWD_GFLOP_PER_IMAGE / 1e3, 1),
             "final_loss": round(final_loss, 5),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "fp32_mode": fp32_mode, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if use_dist:

@@ -402,6 +402,15 @@ extern "C" int mi_conv3x3_wgrad_io(const MiWgradDesc* d, const void* P, const vo
     return w3_dispatch(d, (const float*)P, (const float*)P2, (const float*)Q, dW, dbias, workspace, ws_bytes, io, stream);
 }
 
+// Measurement aid (bench.py's per-kernel HIP-event timing): 0 = both kernels (normal), 1 = the contraction kernel only,
+// 2 = the partial-tile reduce only.  Calling a launch once with 1 and once with 2 is equivalent to one normal call.
+static int g_w3_phase = 0;
+extern "C" int mi_debug_wgrad3x3_phase(int phase) {
+    if (phase < 0 || phase > 2) return mi_set_error(-1, "mi_debug_wgrad3x3_phase: phase in 0..2");
+    g_w3_phase = phase;
+    return 0;
+}
+
 static int w3_dispatch(const MiWgradDesc* d, const float* P, const float* P2, const float* Q, float* dW,
                        float* dbias, void* workspace, size_t ws_bytes, int io, void* stream) {
     MI_REQUIRE(d && P && Q && dW, "null argument");
@@ -430,7 +439,9 @@ static int w3_dispatch(const MiWgradDesc* d, const float* P, const float* P2, co
         return true;
     }();
     (void)once;
-    if (KS == 3 && io) {
+    if (g_w3_phase == 2) {
+        MI_REQUIRE(a.ws, "phase 2 needs the split plan");
+    } else if (KS == 3 && io) {
         static bool once_io = [] {
             (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -467,7 +478,7 @@ static int w3_dispatch(const MiWgradDesc* d, const float* P, const float* P2, co
         if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2, 1>), grid, dim3(256), lds, st, a);
         else      hipLaunchKernelGGL((wgrad3x3_kernel<1, 1>), grid, dim3(256), lds, st, a);
     }
-    if (a.ws) {
+    if (a.ws && g_w3_phase != 1) {
         const dim3 rg(1, KS * 2 * (BJ / 64) * 4, a.gx * a.gy * KS);
         if (a.splits >= 128)
             hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(16, rg.y, rg.z), dim3(256), 0, st, a.ws, dW, d->Ci, d->Cj, KS, BJ / 64, a.gx, a.gy, a.splits);

@@ -15,7 +15,26 @@ import torch
 from .lib import MiConvDesc, MiGnDesc, MiWgradDesc, check, load_library
 
 MODE_FP32, MODE_BF16 = 0, 1
-PROBE = None      # bench.py sets this to a list to collect (kernel symbol, algorithmic FLOPs, start, end) per conv launch
+PROBE = None      # bench.py sets this to a list: (kernel symbol, algorithmic FLOPs, start event, end event, shape note, algorithmic
+                  # HBM bytes) per launch, events recorded on the launch stream
+
+
+def _probe_open():
+    if PROBE is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _probe_close(e0, sym, flops, desc, nbytes=0.0):
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROBE.append((sym, float(flops), e0, e1, desc, float(nbytes)))
+
+
+def _esz(t) -> int:
+    return 0 if t is None else t.element_size()
 
 
 def _stream() -> C.c_void_p:
@@ -82,8 +101,7 @@ def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mo
         bm, bn = C.c_int(), C.c_int()
         load_library().mi_conv_igemm_tile(C.byref(d), C.byref(bm), C.byref(bn))
         flops = 2.0 * N * OH * OW * Nc * K * (kh * kw if not (transposed and stride > 1) else kh * kw / (stride * stride))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0 = _probe_open()
     if wb is not None and mode == MODE_BF16 and K % 8 == 0:      # bf16 weight copy [tap][Nc][K]
         check(load_library().mi_conv_igemm_bf16w(C.byref(d), _p(x), _p(x2), _p(wb), _p(bias), _p(residual), _p(out), _stream()),
               "mi_conv_igemm_bf16w")
@@ -91,9 +109,10 @@ def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mo
         check(load_library().mi_conv_igemm(C.byref(d), _p(x), _p(x2), _p(w), _p(bias), _p(residual), _p(out), _stream()),
               "mi_conv_igemm")
     if PROBE is not None:
-        e1.record()
-        PROBE.append((f"igemm_kernel<{mode},{bm.value},{bn.value}>", flops, e0, e1,
-                      f"N{N} {IH}x{IW}->{OH}x{OW} K{K}->{Nc} k{kh} s{stride} T{int(transposed)} acc{int(accumulate)}"))
+        fast = wb is not None and mode == MODE_BF16 and K % 8 == 0
+        nb = N * IH * IW * K * _esz(x) + N * OH * OW * Nc * _esz(out) * (2 if accumulate else 1) + kh * kw * K * Nc * (2 if fast else 4)
+        _probe_close(e0, f"igemm{'_fast' if fast else ''}_kernel<{mode},{bm.value},{bn.value}>", flops,
+                     f"N{N} {IH}x{IW}->{OH}x{OW} K{K}->{Nc} k{kh} s{stride} T{int(transposed)} acc{int(accumulate)}", nb)
     return out
 
 
@@ -117,28 +136,30 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
     d.ldy = ld_of(out)
     io = _b16(x) | (_b16(out) << 1)
     assert x2 is None or x2.dtype == x.dtype
-    if PROBE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    e0 = _probe_open()
     if io:
         check(lib.mi_conv3x3_bf16w_io(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), io, _stream()),
               "mi_conv3x3_bf16w_io")
     else:
         check(lib.mi_conv3x3_bf16w(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _stream()),
               "mi_conv3x3_bf16w")
-    if PROBE is not None:
-        e1.record()
+    if e0 is not None:
         bm, ck, sk = C.c_int(), C.c_int(), C.c_int()
         lib.mi_conv3x3_bf16w_tile(C.byref(d), io, C.byref(bm), C.byref(ck), C.byref(sk))
-        PROBE.append((f"conv3x3_halo_kernel<{bm.value}, {ck.value}, {ksize}, {'true' if sk.value else 'false'}, {io}, {8 if bm.value == 256 or (bm.value == 128 and ck.value == 64) else 4}>",
-                      2.0 * N * H * W * Nc * K * ksize * ksize, e0, e1,
-                      f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)} io{io}"))
+        nb = (N * H * W * K * _esz(x) + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual))
+              + ksize * ksize * K * Nc * 2)
+        _probe_close(e0, f"conv3x3_halo_kernel<{bm.value}, {ck.value}, {ksize}, {'true' if sk.value else 'false'}, {io}, {8 if bm.value == 256 or (bm.value == 128 and ck.value == 64) else 4}>",
+                     2.0 * N * H * W * Nc * K * ksize * ksize,
+                     f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)} io{io}", nb)
     return out
 
 
 def pack_weights_bf16(table_dev, nent, total_tiles, master, wd, wf):
+    e0 = _probe_open()
     check(load_library().mi_pack_weights_bf16(nent, _p(table_dev), total_tiles, _p(master), _p(wd), _p(wf), _stream()),
           "mi_pack_weights_bf16")
+    if e0 is not None:
+        _probe_close(e0, "pack_weights_kernel", 0.0, f"{master.numel()} params", master.numel() * 8.0)
 
 
 def small_cin_supported(ks, Cin, Cout, wgrad=False):
@@ -212,32 +233,46 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
     fast = bool(lib.mi_conv3x3_wgrad_supported(C.byref(d)))
     if not fast and (_b16(P) or _b16(Q)):
         raise RuntimeError("bf16-stored operands need the fast wgrad kernel (caller must check wgrad_supported)")
-    if PROBE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    flops = 2.0 * N * grid_d[0] * grid_d[1] * Ci * Cj * kh * kw
+    nb_in = N * grid_g[0] * grid_g[1] * Ci * _esz(P) + N * grid_d[0] * grid_d[1] * Cj * _esz(Q)
+    desc = f"N{N} {grid_d[0]}x{grid_d[1]} Ci{Ci}{'(2src)' if P2 is not None else ''} Cj{Cj} k{kh} s{stride} g{int(gather_i)}"
     if fast:
         need = lib.mi_conv3x3_wgrad_workspace(C.byref(d))
         ws = _workspace(P.device, need)
         io = _b16(P) | (_b16(Q) << 1)
-        if io:
-            check(lib.mi_conv3x3_wgrad_io(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _p(dbias), _p(ws), ws.numel() * 4, io, _stream()),
-                  "mi_conv3x3_wgrad_io")
-        else:
-            check(lib.mi_conv3x3_wgrad_bias(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _p(dbias), _p(ws), ws.numel() * 4, _stream()),
-                  "mi_conv3x3_wgrad_bias")
-    else:
-        check(lib.mi_conv_wgrad(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _stream()), "mi_conv_wgrad")
-        if dbias is not None:
-            colsum(Q, dbias)
-    if PROBE is not None:
-        e1.record()
-        sym = f"wgrad_kernel<{mode}>"
-        if fast:
+
+        def go():
+            if io:
+                check(lib.mi_conv3x3_wgrad_io(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _p(dbias), _p(ws), ws.numel() * 4, io, _stream()),
+                      "mi_conv3x3_wgrad_io")
+            else:
+                check(lib.mi_conv3x3_wgrad_bias(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _p(dbias), _p(ws), ws.numel() * 4, _stream()),
+                      "mi_conv3x3_wgrad_bias")
+        if PROBE is None:
+            go()
+        else:                         # time the contraction kernel and the partial-tile reduce under separate events
             nj, sp = C.c_int(), C.c_int()
             lib.mi_conv3x3_wgrad_tile(C.byref(d), C.byref(nj), C.byref(sp))
-            sym = f"wgrad3x3_kernel<{nj.value}, {kh}, {_b16(P) | (_b16(Q) << 1)}> (+reduce)"
-        PROBE.append((sym, 2.0 * N * grid_d[0] * grid_d[1] * Ci * Cj * kh * kw, e0, e1,
-                      f"N{N} {grid_d[0]}x{grid_d[1]} Ci{Ci}{'(2src)' if P2 is not None else ''} Cj{Cj} k{kh} s{stride} g{int(gather_i)}"))
+            sym = f"wgrad3x3_kernel<{nj.value}, {kh}, {io}>"
+            part = kh * kw * Ci * Cj * 4.0 * sp.value
+            if sp.value > 1:
+                try:
+                    lib.mi_debug_wgrad3x3_phase(1)
+                    e0 = _probe_open(); go(); _probe_close(e0, sym, flops, desc, nb_in + part)
+                    lib.mi_debug_wgrad3x3_phase(2)
+                    e0 = _probe_open(); go()
+                    _probe_close(e0, f"wgrad_reduce_kernel<{16 if sp.value >= 128 else 4}>", 0.0, desc + f" splits{sp.value}", part + kh * kw * Ci * Cj * 8.0)
+                finally:
+                    lib.mi_debug_wgrad3x3_phase(0)
+            else:
+                e0 = _probe_open(); go(); _probe_close(e0, sym, flops, desc, nb_in + kh * kw * Ci * Cj * 8.0)
+    else:
+        e0 = _probe_open()
+        check(lib.mi_conv_wgrad(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _stream()), "mi_conv_wgrad")
+        if e0 is not None:
+            _probe_close(e0, f"wgrad_kernel<{mode}>", flops, desc, nb_in + kh * kw * Ci * Cj * 8.0)
+        if dbias is not None:
+            colsum(Q, dbias)
 
 
 _WS = {}
@@ -264,7 +299,10 @@ def colsum(x, out):
     """out[c] += sum over pixels of x[..., c]"""
     Cc = x.shape[-1]
     M = _rows(x)
+    e0 = _probe_open()
     check(load_library().mi_colsum(M, Cc, _p(x), ld_of(x), _p(out), _stream()), "mi_colsum")
+    if e0 is not None:
+        _probe_close(e0, "colsum_kernel", 0.0, f"M{M} C{Cc}", M * Cc * _esz(x))
 
 
 # --------------------------------------------------------------------------- norms
@@ -277,12 +315,16 @@ def gn_mish_fwd(x, gamma, beta, *, groups=8, eps=1e-5, temb=None, residual=None,
                  ldr=ld_of(residual) if residual is not None else 0)
     io = _b16(x) | (_b16(y) << 1)
     ldt = ld_of(temb) if temb is not None else 0
+    e0 = _probe_open()
     if io:
         check(load_library().mi_gn_mish_fwd_io(C.byref(d), _p(x), _p(gamma), _p(beta), _p(temb), ldt, _p(residual), _p(y),
                                                _p(stats), io, _stream()), "mi_gn_mish_fwd_io")
     else:
         check(load_library().mi_gn_mish_fwd(C.byref(d), _p(x), _p(gamma), _p(beta), _p(temb), ldt, _p(residual), _p(y),
                                             _p(stats), _stream()), "mi_gn_mish_fwd")
+    if e0 is not None:
+        _probe_close(e0, f"gn_mish_fwd_kernel<io{io}>", 0.0, f"N{N} HW{H * W} C{Cc} res{int(residual is not None)}",
+                     N * H * W * Cc * (_esz(x) + _esz(y) + _esz(residual)))
     return y, stats
 
 
@@ -293,6 +335,7 @@ def gn_mish_bwd(x, stats, gamma, beta, dout, *, groups=8, eps=1e-5, dgamma=None,
     d = MiGnDesc(N=N, HW=H * W, C=Cc, G=groups, eps=eps, ldx=ld_of(x), ldy=0, ldr=0)
     io = _b16(x) | (_b16(dx) << 1) | (_b16(dout) << 2)
     ldt = ld_of(dtemb) if dtemb is not None else 0
+    e0 = _probe_open()
     if io:
         check(load_library().mi_gn_mish_bwd_io(C.byref(d), _p(x), _p(stats), _p(gamma), _p(beta), _p(dout), ld_of(dout),
                                                _p(dx), ld_of(dx), _p(dgamma), _p(dbeta), _p(dtemb), ldt, _p(dbias), io,
@@ -301,6 +344,8 @@ def gn_mish_bwd(x, stats, gamma, beta, dout, *, groups=8, eps=1e-5, dgamma=None,
         check(load_library().mi_gn_mish_bwd(C.byref(d), _p(x), _p(stats), _p(gamma), _p(beta), _p(dout), ld_of(dout),
                                             _p(dx), ld_of(dx), _p(dgamma), _p(dbeta), _p(dtemb), ldt, _p(dbias), _stream()),
               "mi_gn_mish_bwd")
+    if e0 is not None:
+        _probe_close(e0, f"gn_mish_bwd_kernel<io{io}>", 0.0, f"N{N} HW{H * W} C{Cc}", N * H * W * Cc * (_esz(x) + _esz(dout) + _esz(dx)))
     return dx
 
 
@@ -308,16 +353,23 @@ def chan_layernorm_fwd(x, g, b, eps=1e-5, out_dtype=torch.float32):
     _need_gpu(x)
     N, H, W, Cc = x.shape
     y = new_act(N, H, W, Cc, x, out_dtype)
+    e0 = _probe_open()
     check(load_library().mi_chan_layernorm_fwd_io(N * H * W, Cc, _p(x), ld_of(x), _p(g), _p(b), eps, _p(y), ld_of(y), _b16(y),
                                                   _stream()), "mi_chan_layernorm_fwd")
+    if e0 is not None:
+        _probe_close(e0, f"chan_ln_fwd_kernel<io{_b16(y)}>", 0.0, f"M{N * H * W} C{Cc}", N * H * W * Cc * (_esz(x) + _esz(y)))
     return y
 
 
 def chan_layernorm_bwd(x, g, dy, dx, accumulate, dg, db, eps=1e-5):
     N, H, W, Cc = x.shape
+    e0 = _probe_open()
     check(load_library().mi_chan_layernorm_bwd_io(N * H * W, Cc, _p(x), ld_of(x), _p(g), eps, _p(dy), ld_of(dy), _p(dx),
                                                   ld_of(dx), int(accumulate), _p(dg), _p(db), _b16(dy), _stream()),
           "mi_chan_layernorm_bwd")
+    if e0 is not None:
+        _probe_close(e0, f"chan_ln_bwd_kernel<io{_b16(dy)}>", 0.0, f"M{N * H * W} C{Cc} acc{int(accumulate)}",
+                     N * H * W * Cc * (_esz(x) + _esz(dy) + _esz(dx) * (2 if accumulate else 1)))
 
 
 # --------------------------------------------------------------------------- nn.Linear of the time MLP (exact fp32)
@@ -378,7 +430,11 @@ def linattn_fwd(qkv, heads=4):
     out = new_act(N, H, W, heads * 32, qkv, qkv.dtype)        # bf16 qkv -> bf16 output (attention-internal storage)
     ctx = torch.empty((N, heads, 32, 32), device=qkv.device, dtype=torch.float32)
     kstat = torch.empty((N, heads, 32, 2), device=qkv.device, dtype=torch.float32)
+    e0 = _probe_open()
     check(load_library().mi_linattn_fwd_io(N, H * W, heads, _p(qkv), _p(out), _p(ctx), _p(kstat), _b16(qkv), _stream()), "mi_linattn_fwd")
+    if e0 is not None:
+        _probe_close(e0, f"linattn_fwd_kernel<io{_b16(qkv)}>", 4.0 * N * heads * 32 * 32 * H * W, f"N{N} n{H * W}",
+                     N * H * W * heads * 32 * 4 * _esz(qkv))
     return out, ctx, kstat
 
 
@@ -386,8 +442,12 @@ def linattn_bwd(qkv, ctx, kstat, dout, heads=4):
     N, H, W, C3 = qkv.shape
     assert dout.is_contiguous() and dout.dtype == qkv.dtype
     dqkv = torch.empty_like(qkv)
+    e0 = _probe_open()
     check(load_library().mi_linattn_bwd_io(N, H * W, heads, _p(qkv), _p(ctx), _p(kstat), _p(dout), _p(dqkv), _b16(qkv), _stream()),
           "mi_linattn_bwd")
+    if e0 is not None:
+        _probe_close(e0, f"linattn_bwd_kernel<io{_b16(qkv)}>", 12.0 * N * heads * 32 * 32 * H * W, f"N{N} n{H * W}",
+                     N * H * W * heads * 32 * 7 * _esz(qkv))
     return dqkv
 
 
@@ -621,8 +681,11 @@ def p_sample_update(x, eps_nhwc, z, t, tab, clip=True, want_nhwc=True):
 def adam_step(p, g, m, v, lr, b1, b2, eps, step, gscale=1.0):
     bc1 = 1.0 - b1 ** step
     bc2 = 1.0 - b2 ** step
+    e0 = _probe_open()
     check(load_library().mi_adam_step(p.numel(), _p(p), _p(g), _p(m), _p(v), lr, b1, b2, eps, bc1, bc2, gscale, _stream()),
           "mi_adam_step")
+    if e0 is not None:
+        _probe_close(e0, "adam_kernel", 0.0, f"{p.numel()} params", p.numel() * 28.0)
 
 
 def adam_tick(state):

@@ -44,6 +44,7 @@ SIGNATURES = {
     "mi_conv3x3_bf16w_uses_splitk": [C.POINTER(MiConvDesc)],
     "mi_conv3x3_bf16w_tile": [C.POINTER(MiConvDesc), _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "mi_conv3x3_wgrad_tile": [C.POINTER(MiWgradDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "mi_debug_wgrad3x3_phase": [_I],
     "mi_conv3x3_bf16w_io": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
     "mi_conv3x3_wgrad_io": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P, _P, _Z, _I, _P],
     "mi_gn_mish_fwd_io": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P],

@@ -36,4 +36,8 @@ class GraphedTrainStep:
     def __call__(self, batch):
         self.x.copy_(batch[0], non_blocking=True)
         self.graph.replay()
+        # the replayed Adam rewrote the flat parameter buffers behind Python's back: anything derived from them that is built
+        # OUTSIDE the graph (an eager forward's bf16 weight copies, the sampler's time-bias table) must see a new version
+        for n in getattr(self.opt, "nets", ()):
+            n.mark_params_dirty()
         return self.loss

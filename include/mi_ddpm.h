@@ -157,6 +157,9 @@ int mi_conv3x3_wgrad(const MiWgradDesc* d, const float* P, const float* P2, cons
 int mi_conv3x3_wgrad_supported(const MiWgradDesc* d);
 /* profiling attribution: wgrad3x3_kernel<nj, KH, io> and the number of k-slices (= partial tiles per output tile) */
 int mi_conv3x3_wgrad_tile(const MiWgradDesc* d, int* nj, int* splits);
+/* measurement aid for per-kernel event timing: 0 = normal, 1 = launch only the contraction kernel, 2 = only the partial-tile
+ * reduce (one call with 1 followed by one with 2 == one normal call).  Process-global; reset to 0 after use. */
+int mi_debug_wgrad3x3_phase(int phase);
 /* Same, but the k-slices write partial tiles to a caller-provided scratch buffer that a second
  * (deterministic) kernel sums into dW -- 2.4x cheaper than fp32 atomics here.  Size from
  * mi_conv3x3_wgrad_workspace(); a null / too small workspace falls back to atomics. */

@@ -243,3 +243,22 @@ def test_trainer_manual_optimization_and_schedulers(tmp_path, monkeypatch):
     tr = Trainer(accelerator="cpu", max_epochs=3, enable_checkpointing=False, num_sanity_val_steps=0)
     tr.fit(s, train_dataloaders=loader)
     assert abs(tr.optimizer.param_groups[0]["lr"] - 0.1 * 0.5 ** 3) < 1e-12   # one scheduler step per epoch
+
+
+def test_bench_self_launches_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with no launcher in the environment starts two ranks itself (torch.distributed.run, 127.0.0.1)
+    and rank 0 prints ONE line with n_gpus = 2 and the number of ranks the backend really connected.  The host dry run swaps
+    RCCL for gloo and the kernels for a stand-in step; launch, rendezvous, barrier and max-over-ranks code is the real one."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["self_launched"] and out["dry_run"] and out["steps"] == 3
+    assert out["buckets_bytes"] and out["scaling"] == "weak"

@@ -81,7 +81,7 @@ def main():
     step(0)
     torch.cuda.synchronize()
     agg = {}
-    for sym, fl, e0, e1, _ in K.PROBE:
+    for sym, fl, e0, e1, *_ in K.PROBE:
         v = agg.setdefault(sym, [0.0, 0.0, 0])
         v[0] += fl; v[1] += e0.elapsed_time(e1) * 1e-3; v[2] += 1
     K.PROBE = None

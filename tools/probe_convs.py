@@ -37,7 +37,7 @@ def main():
         K.PROBE = []
         s()
         torch.cuda.synchronize()
-        rows = sorted(((e0.elapsed_time(e1) * 1e3, fl, sym, desc) for sym, fl, e0, e1, desc in K.PROBE), reverse=True)
+        rows = sorted(((e0.elapsed_time(e1) * 1e3, fl, sym, desc) for sym, fl, e0, e1, desc, *_ in K.PROBE), reverse=True)
         K.PROBE = None
         print(f"== step kind {i}: {len(rows)} conv launches, {sum(r[0] for r in rows):.0f} us")
         for us, fl, sym, desc in rows[:14]:

@@ -20,7 +20,7 @@ K.PROBE = []
 loss = m.training_step((x, None), 0); loss.backward(); opt.step()
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
-for sym, fl, e0, e1, desc in K.PROBE:
+for sym, fl, e0, e1, desc, *_ in K.PROBE:
     a = agg.setdefault((sym, desc), [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e3; a[2] += fl
 tot = sum(v[1] for v in agg.values())
 print(f"total conv-family {tot/1e3:.2f} ms")
