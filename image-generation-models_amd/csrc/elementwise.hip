@@ -219,9 +219,34 @@ __global__ void gather_rows_kernel(int B, int C, const float* __restrict__ table
     }
 }
 
+// Device-resident data path (src/datamodules/base.py::DeviceBatchLoader): the whole uint8 dataset [N][H][W][C] lives in HBM; one
+// launch gathers the batch's rows and applies the reference transform chain ToTensor -> RandomHorizontalFlip -> Normalize(0.5, 0.5)
+// (reference src/datamodules/base.py:37-71) with the same fp32 operations torch performs: u/255, then (v-0.5)/0.5.  Output NCHW.
+__global__ void u8_gather_norm_kernel(int B, int C, int H, int W, const uint8_t* __restrict__ data, const int64_t* __restrict__ idx,
+                                      const uint8_t* __restrict__ flip, int normalize, float* __restrict__ out) {
+    const size_t HW = (size_t)H * W, tot = (size_t)B * C * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / (C * HW), r = i % (C * HW);
+        const int c = (int)(r / HW), p = (int)(r % HW), y = p / W, x = p % W;
+        const int xs = (flip && flip[b]) ? W - 1 - x : x;
+        float v = (float)data[((size_t)idx[b] * HW + (size_t)y * W + xs) * C + c] / 255.0f;
+        if (normalize) v = (v - 0.5f) / 0.5f;
+        out[i] = v;
+    }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int mi_u8_gather_normalize(int B, int C, int H, int W, const uint8_t* data, const int64_t* idx, const uint8_t* flip,
+                                      int normalize, float* out_nchw, void* stream) {
+    MI_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && data && idx && out_nchw, "bad argument");
+    hipLaunchKernelGGL(u8_gather_norm_kernel, dim3(nblocks((size_t)B * C * H * W)), dim3(TPB), 0, ST, B, C, H, W, data, idx, flip,
+                       normalize, out_nchw);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int mi_time_embed(int B, int dim, const int64_t* t, float* out, void* stream) {
     MI_REQUIRE(B > 0 && dim >= 4 && dim % 2 == 0 && t && out, "bad argument");

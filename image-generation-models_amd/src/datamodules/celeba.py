@@ -17,6 +17,11 @@ class _JpgFolder(Dataset):
     def __len__(self):
         return len(self.files)
 
+    def load_uint8(self, i) -> np.ndarray:
+        """decoded RGB jpg, resized as the config asks (BICUBIC, no crop): uint8 [height, width, 3]"""
+        from PIL import Image
+        return self._tf.resized(np.asarray(Image.open(self.files[i]).convert("RGB")))
+
     def __getitem__(self, i):
         from PIL import Image
         img = np.asarray(Image.open(self.files[i]).convert("RGB"))
@@ -27,7 +32,7 @@ class _JpgFolder(Dataset):
 class CelebADataModule(BaseDatamodule):
     def __init__(self, data_dir: str = "./data", width=64, height=64, channels=3, batch_size: int = 64,
                  num_workers: int = 8, transforms=None, **kargs):
-        super().__init__(width, height, channels, batch_size, num_workers)
+        super().__init__(width, height, channels, batch_size, num_workers, kargs.get("device_resident", "auto"))
         self.data_dir, self.transforms = data_dir, transforms
 
     def _files(self):

@@ -25,7 +25,7 @@ def _read_batches(root, names):
 class CIFAR10DataModule(BaseDatamodule):
     def __init__(self, data_dir: str = "./data", width=64, height=64, channels=3, batch_size: int = 64,
                  num_workers: int = 8, transforms=None, **kargs):
-        super().__init__(width, height, channels, batch_size, num_workers)
+        super().__init__(width, height, channels, batch_size, num_workers, kargs.get("device_resident", "auto"))
         self.data_dir, self.transforms = data_dir, transforms
 
     def prepare_data(self):

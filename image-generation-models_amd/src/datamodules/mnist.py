@@ -29,7 +29,7 @@ def _find(root, stem):
 class MNISTDataModule(BaseDatamodule):
     def __init__(self, data_dir: str = "./data", width=28, height=28, channels=1, batch_size: int = 64,
                  num_workers: int = 8, transforms=None, **kargs):
-        super().__init__(width, height, channels, batch_size, num_workers)
+        super().__init__(width, height, channels, batch_size, num_workers, kargs.get("device_resident", "auto"))
         self.data_dir, self.transforms = data_dir, transforms
 
     def prepare_data(self):

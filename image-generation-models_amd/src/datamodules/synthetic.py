@@ -8,7 +8,7 @@ from .base import ArrayImageDataset, BaseDatamodule
 class SyntheticDataModule(BaseDatamodule):
     def __init__(self, width=32, height=32, channels=3, batch_size: int = 128, num_workers: int = 0,
                  train_size: int = 1024, val_size: int = 128, transforms=None, seed: int = 0, **kargs):
-        super().__init__(width, height, channels, batch_size, num_workers)
+        super().__init__(width, height, channels, batch_size, num_workers, kargs.get("device_resident", "auto"))
         self.train_size, self.val_size, self.transforms, self.seed = train_size, val_size, transforms, seed
 
     def setup(self, stage=None):

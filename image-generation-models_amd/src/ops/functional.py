@@ -721,6 +721,23 @@ def gather_rows(table, idx):
     return out
 
 
+def u8_gather_normalize(data_u8, idx, flip=None, normalize=True):
+    """data_u8: uint8 [N,H,W,C] on the device, idx: int64 [B], flip: uint8/bool [B] or None -> fp32 NCHW batch [B,C,H,W] with the
+    reference transform chain applied (ToTensor, flip, Normalize(0.5, 0.5))."""
+    if not data_u8.is_cuda or data_u8.dtype != torch.uint8 or not data_u8.is_contiguous():
+        raise RuntimeError("u8_gather_normalize needs a contiguous uint8 dataset tensor on the HIP device")
+    if data_u8.device.index != torch.cuda.current_device():
+        raise RuntimeError("dataset tensor is not on the current HIP device")
+    N, H, W, Cc = data_u8.shape
+    idx = idx.to(device=data_u8.device, dtype=torch.int64).contiguous()
+    if flip is not None:
+        flip = flip.to(device=data_u8.device, dtype=torch.uint8).contiguous()
+    out = torch.empty((idx.shape[0], Cc, H, W), device=data_u8.device, dtype=torch.float32)
+    check(load_library().mi_u8_gather_normalize(idx.shape[0], Cc, H, W, _p(data_u8), _p(idx), _p(flip), int(normalize), _p(out), _stream()),
+          "mi_u8_gather_normalize")
+    return out
+
+
 def fast3x3_supported(N, H, W, K, Nc, K1=None):
     """(conv via the LDS-tile kernel?, wgrad via the image-major kernel?) for a 3x3/s1/p1 layer in bf16 mode."""
     lib = load_library()

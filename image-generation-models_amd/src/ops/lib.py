@@ -109,6 +109,7 @@ SIGNATURES = {
     "mi_axpby": [_Z, _F, _P, _I, _P, _P],
     "mi_axpby2d": [_I, _I, _F, _P, _I, _I, _P, _I, _P],
     "mi_gather_rows": [_I, _I, _P, _P, _P, _P],
+    "mi_u8_gather_normalize": [_I, _I, _I, _I, _P, _P, _P, _I, _P, _P],
     "mi_scale_by_device_scalar": [_I, _I, _P, _I, _P, _P],
 }
 OTHER = {"mi_abi_version": ([], C.c_int), "mi_last_error": ([], C.c_char_p),

@@ -156,6 +156,8 @@ class Trainer:
             datamodule.setup("fit")
             if self.world_size > 1 and hasattr(datamodule, "set_shard"):
                 datamodule.set_shard(self.global_rank, self.world_size)    # DistributedSampler semantics
+            if hasattr(datamodule, "bind_device"):
+                datamodule.bind_device(device)                             # device-resident dataset / pinned prefetch
             train_dataloaders = datamodule.train_dataloader()
             val_dataloaders = datamodule.val_dataloader()
         optimizer = model.configure_optimizers()

@@ -343,6 +343,12 @@ int mi_adam_step(size_t n, float* p, const float* g, float* m, float* v, float l
 int mi_adam_tick(float* state, void* stream);
 int mi_adam_step_dev(size_t n, float* p, const float* g, float* m, float* v, const float* state, double b1, double b2,
                      float eps, float gscale, void* stream);
+/* Device-resident data path: gather B images out of a uint8 dataset [N][H][W][C] that lives in HBM and apply the reference's
+ * transform chain (ToTensor, optional per-sample horizontal flip, optional Normalize(0.5, 0.5); reference
+ * src/datamodules/base.py:37-71) in torch's own fp32 operation order (u/255, then (v-0.5)/0.5): NCHW fp32 out.
+ * idx: int64[B] rows of the dataset; flip: uint8[B] or null. */
+int mi_u8_gather_normalize(int B, int C, int H, int W, const uint8_t* data, const int64_t* idx, const uint8_t* flip,
+                           int normalize, float* out_nchw, void* stream);
 /* y = a*x + (accumulate ? y : 0) */
 int mi_axpby(size_t n, float a, const float* x, int accumulate, float* y, void* stream);
 /* same on M rows of C channels with row strides (gradient accumulation into channel slices) */

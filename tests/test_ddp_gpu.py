@@ -85,5 +85,8 @@ def test_two_rank_step_equals_full_batch(mode, tol):
         opt.step()
     ref_p, ref_g = m.denoising_model.flat_params.cpu(), m.denoising_model.flat_grads.cpu()
     scale = float(ref_g.abs().max())
+    from _parity import record
+    record(f"ddp_two_rank_vs_full_batch_{mode}", grad_max_abs_over_max=float((g0 - ref_g).abs().max()) / scale,
+           weight_max_abs_over_max=float((p0 - ref_p).abs().max()) / float(ref_p.abs().max()))
     assert float((g0 - ref_g).abs().max()) <= tol * scale
     assert float((p0 - ref_p).abs().max()) <= max(tol, 2.1e-3 if mode == "bf16" else 0) * float(ref_p.abs().max())    # bf16: an Adam step is +-lr = 1e-3

@@ -207,10 +207,12 @@ def test_ddpm_graphed_training_step(mode):
         l = m1.training_step((x, None), i); l.backward(); o1.step(); warm.append(float(l))
     gs = GraphedTrainStep(m1, o1, (x, None), warmup=0)
     graphed = warm + [float(gs((x, None))) for _ in range(steps - 2)]
-    assert o1.device_step_count() == steps - 0 + 0 or o1.device_step_count() == steps + 1    # capture itself does not execute
+    assert o1.device_step_count() == steps                    # 2 eager + 22 replays (the capture itself executes nothing)
     assert all(torch.isfinite(torch.tensor(graphed)))
-    e_mean, g_mean = sum(eager[-8:]) / 8, sum(graphed[-8:]) / 8
-    assert g_mean < 0.9 * graphed[0] and abs(g_mean - e_mean) < 0.25 * e_mean, (eager, graphed)
+    # same seed, same draws (torch's graph-safe Philox offsets advance per replay exactly like eager calls): same loss curve
+    worst = max(abs(a - b) for a, b in zip(eager, graphed))
+    assert worst < (2e-4 if mode == "fp32" else 5e-3), (worst, eager, graphed)
+    assert min(graphed[-8:]) < graphed[0]
     # an eager forward after the replays must use the replayed weights
     net = m1.denoising_model.eval()
     t = torch.full((16,), 10, device=DEV, dtype=torch.long)
@@ -219,3 +221,51 @@ def test_ddpm_graphed_training_step(mode):
         net.mark_params_dirty()                      # forces a repack: must change nothing if the copies were current
         y2 = net(x, t)
     assert torch.equal(y1, y2)
+
+
+def test_device_batch_loader_equals_host_chain():
+    """HBM-resident uint8 dataset + mi_u8_gather_normalize == the per-access host chain, bit for bit: epoch coverage, ragged last
+    batch, labels, ToTensor/Normalize arithmetic; flips are per-sample mirror images; data-parallel shards are disjoint."""
+    import numpy as np
+    from src.datamodules.base import ArrayImageDataset, DeviceBatchLoader, ShardSampler
+    rng = np.random.default_rng(0)
+    imgs = rng.integers(0, 256, (37, 12, 20, 3), dtype=np.uint8)
+    labels = np.arange(37)
+    ds = ArrayImageDataset(imgs, labels, {"convert": True, "normalize": True})
+    dev = torch.device("cuda", torch.cuda.current_device())
+    seen = []
+    torch.manual_seed(4)
+    for x, y in DeviceBatchLoader(ds, 8, dev, shuffle=True):
+        assert x.is_cuda and x.dtype == torch.float32 and x.shape[1:] == (3, 12, 20)
+        for xi, yi in zip(x.cpu(), y.cpu()):
+            assert torch.equal(xi, ds[int(yi)][0])
+            seen.append(int(yi))
+    assert sorted(seen) == list(range(37)) and seen != list(range(37))
+    assert [x.shape[0] for x, _ in DeviceBatchLoader(ds, 8, dev, shuffle=False)] == [8, 8, 8, 8, 5]
+    # un-normalised chain
+    ds01 = ArrayImageDataset(imgs, labels, {"convert": True, "normalize": False})
+    x, y = next(iter(DeviceBatchLoader(ds01, 4, dev, shuffle=False)))
+    assert torch.equal(x.cpu(), torch.from_numpy(imgs[:4]).permute(0, 3, 1, 2).float() / 255)
+    # flip: every sample is the image or its mirror, and both occur
+    dsf = ArrayImageDataset(imgs, labels, {"convert": True, "normalize": True, "flip": True})
+    kinds = []
+    for x, y in DeviceBatchLoader(dsf, 37, dev, shuffle=False):
+        for xi, yi in zip(x.cpu(), y.cpu()):
+            ref = ds[int(yi)][0]
+            kinds.append(0 if torch.equal(xi, ref) else 1 if torch.equal(xi, ref.flip(-1)) else 2)
+    assert set(kinds) == {0, 1}
+    # shards
+    a = [int(v) for _, y in DeviceBatchLoader(ds, 8, dev, True, ShardSampler(37, 0, 2)) for v in y.cpu()]
+    b = [int(v) for _, y in DeviceBatchLoader(ds, 8, dev, True, ShardSampler(37, 1, 2)) for v in y.cpu()]
+    assert len(a) == len(b) == 19 and set(a) | set(b) == set(range(37))
+
+
+def test_device_prefetcher_delivers_the_loader_batches():
+    from torch.utils.data import DataLoader, TensorDataset
+    from src.datamodules.base import DevicePrefetcher
+    x = torch.arange(50 * 6, dtype=torch.float32).reshape(50, 6)
+    y = torch.arange(50)
+    loader = DataLoader(TensorDataset(x, y), batch_size=8, pin_memory=True)
+    got = list(DevicePrefetcher(loader, torch.device("cuda", torch.cuda.current_device())))
+    assert len(got) == 7 and all(b[0].is_cuda for b in got)
+    assert torch.equal(torch.cat([b[0].cpu() for b in got]), x) and torch.equal(torch.cat([b[1].cpu() for b in got]), y)

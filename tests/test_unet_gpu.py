@@ -1,8 +1,11 @@
 """End-to-end parity of the HIP path (Unet / GaussianDiffusion / DDPM in
 image-generation-models_amd/src/models/ddpm.py) against (a) golden vectors captured from the
 reference and (b) the CPU oracle on the same seeded inputs.
-Stated tolerances: epsilon-prediction rel-L2 <= 1e-4 in exact-fp32 mode (north_star), <= 3e-2 in
-bf16-MFMA mode; parameter gradients rel-L2 <= 1e-3 (fp32 atomics reorder sums)."""
+Stated tolerances: epsilon-prediction rel-L2 <= 1e-4 in exact-fp32 mode (north_star; measured 3e-6); parameter gradients
+rel-L2 <= 1e-3 in fp32 mode (fp32 atomics reorder sums; measured 4e-6).  The bf16-MFMA mode's tolerances are each <= 2x the
+worst error MEASURED on the MI355X and recorded by these tests in profiles/r02_parity.json (epsilon 0.9-1.1e-2 -> 2e-2; loss
+3e-5..7e-5 -> 2e-4; per-tensor gradient rel-L2 0.05-0.10 -> 0.1-0.2; whole flat gradient 1.5e-2 -> 3e-2); the reference itself
+under CPU bf16 autocast sits at 1.6e-2 on the epsilon prediction."""
 import os
 
 import numpy as np
@@ -131,7 +134,7 @@ def _seeded(dim, mults, mode):
     return net.to(DEV)
 
 
-@pytest.mark.parametrize("mode,tol,gtol", [("fp32", 1e-4, 2e-3), ("bf16", 3e-2, 1.5e-1)])
+@pytest.mark.parametrize("mode,tol,gtol", [("fp32", 1e-4, 2e-3), ("bf16", 2e-2, 2e-1)])      # bf16 measured: 9.3e-3 / 9.9e-2
 def test_mid_unet_golden(golden_dir, mode, tol, gtol):
     from src.models.ddpm import GaussianDiffusion
     g = _load(golden_dir, "mid_unet.npz")
@@ -154,13 +157,14 @@ def test_mid_unet_golden(golden_dir, mode, tol, gtol):
     record(f"mid_unet_golden_{mode}", eps_rel_l2=e_eps, loss_abs=e_loss, worst_grad_rel_l2=max(gerr.values()),
            worst_grad_key=max(gerr, key=gerr.get), worst_gradnorm_rel=e_norm)
     assert e_eps < tol
-    assert e_loss < (3e-5 if mode == "fp32" else 2e-2)
+    assert e_loss < (3e-5 if mode == "fp32" else 1e-4)                     # bf16 measured 2.6e-5
     assert max(gerr.values()) < gtol, gerr
+    assert e_norm < (1e-4 if mode == "fp32" else 0.1)                     # bf16 measured 4.9e-2
     ok = np.abs(norms - ref) <= gtol * 2 * np.maximum(ref, 1e-6) + 1e-7
     assert ok.all(), [(k, a, b) for (k, _), a, b, o in zip(net.named_parameters(), norms, ref, ok) if not o]
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-4), ("bf16", 2e-2)])                        # bf16 measured: 8.9e-3
 def test_cfg2_eps_prediction_golden(golden_dir, mode, tol):
     """BASELINE cfg 2 (dim 128, mults 1-2-4, 32x32): epsilon prediction vs the reference's output."""
     from src.models.ddpm import GaussianDiffusion
@@ -186,12 +190,12 @@ def test_cfg2_eps_prediction_golden(golden_dir, mode, tol):
     record(f"cfg2_eps_prediction_golden_{mode}", eps_rel_l2=e_eps, loss_abs=e_loss, worst_gradnorm_rel=e_norm,
            grad_final_conv_rel_l2=e_g1, grad_time_mlp3_bias_rel_l2=e_g2)
     assert e_eps < tol
-    assert e_loss < (3e-5 if mode == "fp32" else 2e-2)
+    assert e_loss < (3e-5 if mode == "fp32" else 1e-4)                     # bf16 measured 1.6e-5
     if mode == "fp32":
         assert np.all(np.abs(norms - ref) <= 4e-3 * np.maximum(ref, 1e-6) + 1e-7)
         assert e_g1 < 2e-3
     else:
-        assert e_g1 < 0.1 and e_g2 < 0.2 and e_norm < 0.2
+        assert e_g1 < 4e-2 and e_g2 < 6.4e-2 and e_norm < 4.4e-2          # measured 2.0e-2 / 3.2e-2 / 2.2e-2
 
 
 def test_cfg2_vs_oracle_random_batch():
@@ -224,7 +228,9 @@ def test_full_batch_properties():
         assert rel_err(ys, y[5:9]) < 1e-5
         net.compute_mode = "bf16"
         yb = net(x, t)
-    assert torch.isfinite(y).all() and rel_err(yb, y) < 3e-2
+    e = rel_err(yb, y)
+    record("cfg2_B128_forward_bf16_vs_fp32", eps_rel_l2=e)
+    assert torch.isfinite(y).all() and e < 2e-2
 
 
 def test_full_batch_backward_properties():
@@ -259,10 +265,10 @@ def test_full_batch_backward_properties():
         assert torch.isfinite(full).all()
     out["bf16_vs_fp32_flat_grad_rel_l2"] = rel_err(grads["bf16"], grads["fp32"])
     record("cfg2_B128_backward_properties", **out)
-    assert out["fp32_rerun_rel_l2"] < 1e-5 and out["bf16_rerun_rel_l2"] < 1e-5
-    assert out["fp32_slices_vs_full_rel_l2"] < 1e-4
-    assert out["bf16_slices_vs_full_rel_l2"] < 5e-2       # slices round their bf16 tensors independently of the full batch
-    assert out["bf16_vs_fp32_flat_grad_rel_l2"] < 0.1
+    assert out["fp32_rerun_rel_l2"] < 1e-6 and out["bf16_rerun_rel_l2"] < 1e-6        # measured 1.3e-7 / 5e-8 (atomics order)
+    assert out["fp32_slices_vs_full_rel_l2"] < 1e-6                                    # measured 2.6e-7
+    assert out["bf16_slices_vs_full_rel_l2"] < 1.1e-2     # measured 5.5e-3: slices round their bf16 tensors independently of the full batch
+    assert out["bf16_vs_fp32_flat_grad_rel_l2"] < 1.8e-2                               # measured 8.8e-3
 
 
 def _host_tape(shape, seed, n, sha):
@@ -318,9 +324,10 @@ def test_sampler_T1000_golden(golden_dir, case, hw):
     errs["bf16_final_rel_l2"] = rel_err(g16, ref)
     errs["bf16_final_max_abs"] = float((g16.cpu() - ref).abs().max())
     record(f"sampler_T1000_{case}", **errs)
-    assert errs["eager_final_max_abs"] < 2e-4 and errs["graph_final_max_abs"] < 2e-4, errs
-    assert all(errs[f"graph_after{m}_max_abs"] < 2e-4 for m in marks), errs
+    assert errs["eager_final_max_abs"] < 2e-5 and errs["graph_final_max_abs"] < 2e-5, errs       # measured 3.6e-6 / 4.7e-6
+    assert all(errs[f"graph_after{m}_max_abs"] < 2e-5 for m in marks), errs
     assert torch.isfinite(g16).all() and float(g16.abs().max()) <= 1.0
+    assert errs["bf16_final_rel_l2"] < 1e-2, errs                                                # measured 4.0e-3 / 4.9e-3
 
 
 def test_graph_sampler_matches_eager():
@@ -390,7 +397,7 @@ def test_run_py_end_to_end(tmp_path):
     assert lines and "train_loss/loss" in lines[-1]
 
 
-@pytest.mark.parametrize("mode,tol,gtol", [("fp32", 1e-4, 3e-3), ("bf16", 3e-2, 2e-1)])
+@pytest.mark.parametrize("mode,tol,gtol", [("fp32", 1e-4, 3e-3), ("bf16", 2e-2, 1e-1)])      # bf16 measured: 1.1e-2 / 4.9e-2
 def test_cfg3_celeba_shape_vs_oracle(mode, tol, gtol):
     """BASELINE cfg 3 (CelebA 64x64, hidden 64, mults 1-2-4-8, 4 levels): forward, loss and gradients vs the oracle."""
     from oracle import ddpm_oracle as O
@@ -424,7 +431,8 @@ def test_cfg3_celeba_shape_vs_oracle(mode, tol, gtol):
     record(f"cfg3_celeba_shape_vs_oracle_{mode}", eps_rel_l2=e_eps, loss_abs=e_loss, worst_grad_rel_l2=max(errs.values()),
            worst_grad_key=max(errs, key=errs.get), whole_grad_rel_l2=rel_err(flat_got, flat_ref))
     assert e_eps < tol
-    assert e_loss < (3e-5 if mode == "fp32" else 2e-2)
+    assert e_loss < (3e-5 if mode == "fp32" else 1e-4)                     # bf16 measured 3.4e-5
+    assert rel_err(flat_got, flat_ref) < (1e-4 if mode == "fp32" else 3e-2)     # whole gradient; bf16 measured 1.5e-2
     bad = [(k, e) for k, e in errs.items() if e > gtol]
     assert not bad, bad[:8]
 
@@ -489,8 +497,8 @@ def test_ragged_batch_sizes_vs_oracle(B):
             if e > worst:
                 worst, wkey = e, k
     record(f"ragged_batch_B{B}_bf16", loss_abs=abs(float(loss) - float(ref_loss)), worst_grad_rel_l2=worst, worst_grad_key=wkey)
-    assert abs(float(loss) - float(ref_loss)) < 2e-2
-    assert worst < 0.2, worst
+    assert abs(float(loss) - float(ref_loss)) < 1.5e-4                    # measured 3.7e-5 / 7.3e-5
+    assert worst < 0.14, worst                                            # measured 6.7e-2 / 7.0e-2
 
 
 def test_bf16_block_storage_end_to_end(golden_dir):
@@ -522,4 +530,4 @@ def test_bf16_block_storage_end_to_end(golden_dir):
     e_full = rel_err(g16, net.flat_grads)
     record("cfg2_bf16_block_storage", eps_rel_l2=e_eps, loss_abs=e_loss, flat_grad_rel_l2_vs_fp32_storage=e_sto,
            flat_grad_rel_l2_vs_fp32_mode=e_full)
-    assert e_eps < 4e-2 and e_loss < 2e-2 and e_sto < 0.1 and e_full < 0.1
+    assert e_eps < 2.1e-2 and e_loss < 1e-4 and e_sto < 8.4e-2 and e_full < 0.1       # measured 1.03e-2 / 4.9e-5 / 4.2e-2 / 5.2e-2
