@@ -235,9 +235,27 @@ __global__ void u8_gather_norm_kernel(int B, int C, int H, int W, const uint8_t*
     }
 }
 
+// fp32 [M][C] (row stride ldx) -> bf16 [M][C] (row stride ldy), round-to-nearest-even: the rounding every bf16-MFMA kernel applies
+// when it stages an fp32 activation, applied once for all of its consumers
+__global__ void f32_to_bf16_kernel(size_t M, int C4, const float* __restrict__ x, int ldx, uint16_t* __restrict__ y, int ldy) {
+    const size_t tot = M * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / C4; const int c = (int)(i % C4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + m * ldx + c);
+        *reinterpret_cast<uint2*>(y + m * ldy + c) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+    }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int mi_f32_to_bf16(size_t M, int C, const float* x, int ldx, void* y_bf16, int ldy, void* stream) {
+    MI_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && x && y_bf16, "bad argument (C, ld % 4 == 0)");
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(nblocks(M * (C / 4))), dim3(TPB), 0, ST, M, C / 4, x, ldx, (uint16_t*)y_bf16, ldy);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int mi_u8_gather_normalize(int B, int C, int H, int W, const uint8_t* data, const int64_t* idx, const uint8_t* flip,
                                       int normalize, float* out_nchw, void* stream) {

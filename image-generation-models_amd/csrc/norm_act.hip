@@ -42,6 +42,7 @@ template <int VEC, bool T16> __device__ __forceinline__ void vstore(void* base, 
 struct GnArgs {
     const float* x; const float* gamma; const float* beta; const float* temb; const float* res;
     float* y; float* stats;
+    uint16_t* y16; int ldy16;      // optional second copy of y rounded to bf16 (the conv / weight-gradient operand of the next layer)
     int N, HW, C, G, Cg; float eps; int ldx, ldy, ldr, ldt;
     // backward
     const float* dout; float* dx; float* dgamma; float* dbeta; float* dtemb; float* dbias; int lddo, lddx;
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
             for (int j = 0; j < VEC; ++j) o.v[j] += r.v[j];
         }
         vstore<VEC, Y16>(a.y, yoff + (size_t)p * a.ldy, o);
+        if (a.y16) vstore<VEC, true>(a.y16, (size_t)n * a.HW * a.ldy16 + c0 + (size_t)p * a.ldy16, o);
     };
     if constexpr (MAXU > 0) {
 #pragma unroll
@@ -499,6 +501,30 @@ extern "C" int mi_gn_mish_fwd_io(const MiGnDesc* d, const void* x, const float* 
     MI_REQUIRE(rc == 0 && vec == 4, "bf16 storage needs C/G to be a multiple of 4 (power of two <= 128)");
     MI_REQUIRE(d->ldx % 4 == 0 && d->ldy % 4 == 0 && (!residual || d->ldr % 4 == 0), "ld must be a multiple of 4");
     a.x = (const float*)x; a.gamma = gamma; a.beta = beta; a.temb = temb; a.ldt = ldt; a.res = residual; a.y = (float*)y; a.stats = stats;
+    hipStream_t st = (hipStream_t)stream;
+    switch (io) {
+        case 0: GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 0); break;
+        case 1: GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 1); break;
+        case 2: GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 2); break;
+        default: GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 3); break;
+    }
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+// ... and additionally a bf16-rounded copy of y (y16, pixel stride ldy16 elements): the residual stream stays fp32 (y) while the
+// next layer's MFMA operands (conv input, weight-gradient operand) are read from the copy -- the rounding the consumers would
+// apply when staging is applied once, here, and they fetch half the bytes.
+extern "C" int mi_gn_mish_fwd_dual(const MiGnDesc* d, const void* x, const float* gamma, const float* beta,
+                                   const float* temb, int ldt, const float* residual, void* y, void* y16, int ldy16,
+                                   float* stats, int io, void* stream) {
+    MI_REQUIRE(x && gamma && beta && y && y16 && !(io & ~3), "bad argument");
+    GnArgs a{};
+    int vec, units;
+    int rc = gn_prepare(d, a, vec, units);
+    MI_REQUIRE(rc == 0 && vec == 4, "the bf16 copy needs C/G to be a multiple of 4 (power of two <= 128)");
+    MI_REQUIRE(d->ldx % 4 == 0 && d->ldy % 4 == 0 && ldy16 % 4 == 0 && (!residual || d->ldr % 4 == 0), "ld must be a multiple of 4");
+    a.x = (const float*)x; a.gamma = gamma; a.beta = beta; a.temb = temb; a.ldt = ldt; a.res = residual; a.y = (float*)y; a.stats = stats;
+    a.y16 = (uint16_t*)y16; a.ldy16 = ldy16;
     hipStream_t st = (hipStream_t)stream;
     switch (io) {
         case 0: GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 0); break;

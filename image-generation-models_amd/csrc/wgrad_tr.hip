@@ -1,0 +1,457 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolution (Block's conv, reference src/models/ddpm.py:116) for bf16-stored
+// operands, built on the two gfx950 LDS instructions that make the register staging of wgrad3x3.hip unnecessary:
+//
+//     dW[ky][kx][ci][co] += sum_{n,y,x} X[n, y+ky-1, x+kx-1, ci] * dY[n, y, x, co]
+//
+//   * LDS-DMA (global_load_lds_dwordx4): the NHWC rows of X and dY go from L2 straight into LDS, 1 KB per wave instruction, no
+//     VGPRs, no VALU, no ds_write.  The destination is wave-uniform base + 16 * lane, so the LDS image is chosen through the
+//     per-lane SOURCE address: X is kept as [row][8-pixel block][32-channel half][pixel][32 ch] and dY as
+//     [4-pixel block][32-channel quarter][pixel][32 ch] -- consecutive pixels of one channel group are 64 bytes apart, which
+//     spreads the four pixels of a transposing read over the four quarters of a bank row (conflict-free).
+//   * ds_read_b64_tr_b16: the contraction axis (pixels) is the strided axis of both NHWC operands; the transposing read hands each
+//     lane 4 consecutive PIXELS of its own channel (a 16-lane group reads a [4 pixels][16 channels] block, every lane giving the
+//     address of its own 8-byte piece), so a tap shift (kx, ky) is nothing but a different address: all nine taps read the
+//     same staged rows.
+//
+// One workgroup (8 waves, two per SIMD) owns a 64 (ci) x 128 (co) tile of ALL NINE taps for one slice of the pixel axis:
+// a wave accumulates 32 ci x 32 co x 9 taps = 9 MFMA tiles (144 accumulator registers; 18 tiles per wave do not fit the 256
+// accumulation registers and hipcc then shuttles them through v_accvgpr moves), so per 16-pixel k-step it issues at most 20
+// transposing reads for 9 v_mfma_f32_32x32x16_bf16 (fewer: the row a tap (ky) of one output row reads is the row tap (ky-1) of the
+// next output row reads, and the compiler keeps such fragments in registers).  The pixel axis is walked in steps of 64 pixels
+// (TR = 64 / W image rows);
+// X rows live in a ring of 4 steps (a step's halo rows are its neighbours' rows: every X row is fetched once), dY in a ring of 3.
+// Step s+2 is requested while step s runs on the matrix cores; one s_waitcnt vmcnt(0) + s_barrier per step (36 MFMAs per wave).
+// Image borders are a never-written zero row / zero pixel blocks in LDS.  Slices leave as partial tiles in register order (1 KB
+// contiguous per wave and store) and wgrad_tr_reduce_kernel sums them in a fixed order (deterministic) into dW.
+#include <stdlib.h>
+#include "common.h"
+
+#ifndef MI_WTR_ABL
+#define MI_WTR_ABL 0     // profiling only: 1 no partial-tile stores, 2 no main loop
+#endif
+
+#ifdef MI_WTR_TIMING
+// profiling build only (-DMI_WTR_TIMING): per-workgroup phase timestamps, 100 MHz wall clock (tools/wtr_timeline.py)
+__device__ unsigned long long g_wtr_ts[6 * 1024];
+#define MI_TS(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_wtr_ts[(k) * 1024 + blockIdx.x] = wall_clock64(); } while (0)
+extern "C" int mi_debug_wtr_ts(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wtr_ts), sizeof(g_wtr_ts));
+}
+#else
+#define MI_TS(k) do {} while (0)
+#endif
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+struct TrArgs {
+    const uint16_t* P; const uint16_t* P2; const uint16_t* Q;
+    float* ws;          // this problem's partial tiles (splits > 1)
+    float* dW;          // [3][3][Ci][Cj], accumulated into directly when splits == 1
+    int W, H, Ci, Cj, I1, ldp, ldp2, ldq;
+    int total;          // steps of 64 pixels over the whole batch: N*H*W / 64
+    int sps, splits;    // steps per k-slice, k-slices
+    int gx, gy;         // ci tiles (64), co tiles (128)
+    int wg0;            // first workgroup of this problem in the launch
+    int tile0;          // first tile of this problem in the reduce launch
+};
+constexpr int MAXP = 8;
+// One launch = up to MAXP independent weight-gradient problems, each on its own share of the workgroups.  A layer's partial-tile
+// volume is (its workgroups) x 288 KB: eight layers side by side on 32 CUs each write an eighth of what one layer on 256 CUs
+// writes (75 MB) for the same MFMA work, and layers with >= 32 tiles need no k-slices at all (they add into dW directly).
+struct TrBatch { TrArgs p[MAXP]; int n; };
+
+// LDS-DMA: 16 bytes per lane from each lane's own global address to LDS byte address lds_dst (wave-uniform) + 16 * lane.
+// M0 carries the LDS base and is compiler-reserved: it is saved, set and restored inside the one statement.  The compiler does
+// not know this is a load: completion is waited for with explicit s_waitcnt vmcnt(N) below.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ bf16x8 tr_pair(uint32_t a0, uint32_t a1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)a1);
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// W = image width (8, 16, 32 or 64); a step is TR = 64 / W rows of one image (H % TR == 0).  wg = workgroup index within the problem.
+template <int W>
+__device__ __forceinline__ void wgrad_tr_body(const TrArgs& a, const int wg, uint8_t* lds_raw) {
+    constexpr int TR = 64 / W;
+    constexpr int NBLK = W / 8;                    // interior 8-pixel blocks of a row
+    constexpr int ROWB = (NBLK + 2) * 1024;        // bytes of an X row in LDS: zero block | interior | zero block
+    constexpr int NR = 4 * TR;                     // X ring: rows of 4 steps
+    constexpr int XRING = ROWB;                    // byte offsets: [zero row][X ring][dY ring]
+    constexpr int YRING = XRING + NR * ROWB;
+    constexpr int YSTEP = 64 * 256;                // 64 pixels x 128 channels of bf16
+    constexpr int JPR = W >= 16 ? W / 16 : 1;      // 16-pixel k-steps per image row (W = 8: a k-step is two rows)
+    constexpr int NRI = (W == 8 ? 6 : TR - 1) + 3; // X rows a step's taps touch, counted from relative row -1
+    constexpr int NU = NRI * JPR * 3;              // X fragments per step
+    constexpr int PD = 4;                          // fragments fetched ahead of the MFMAs that consume them
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
+
+    const int t = threadIdx.x, l = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wi = wv >> 2, wj = wv & 3;             // 2 ci halves x 4 co quarters
+    const int ntiles = a.gx * a.gy;
+    const int split = wg / ntiles, tile = wg - split * ntiles;
+    const int ci0 = (tile % a.gx) * 64, co0 = (tile / a.gx) * 128;
+    const int sb = split * a.sps, se = min(a.total, sb + a.sps);
+
+    MI_TS(0);
+    // ---- zero the X area once: the halo pixel blocks and the zero row are never written again
+    for (int i = t * 16; i < YRING; i += 512 * 16) *reinterpret_cast<u32x4*>(lds_raw + i) = u32x4{0u, 0u, 0u, 0u};
+
+    // ---- DMA sources.  X block (8 pixels x 64 ch): lane -> half h = lane >> 5, pixel (lane >> 2) & 7, 8-channel chunk lane & 3.
+    //      dY block (4 pixels x 128 ch): quarter lane >> 4, pixel (lane >> 2) & 3, chunk lane & 3.
+    const bool second = ci0 >= a.I1;
+    const int ldx = second ? a.ldp2 : a.ldp;
+    const uint16_t* xsrc = (second ? a.P2 : a.P) + (size_t)((l >> 2) & 7) * ldx +
+                           min((second ? ci0 - a.I1 : ci0) + (l >> 5) * 32 + (l & 3) * 8, (second ? a.Ci - a.I1 : a.I1) - 8);
+    const uint16_t* ysrc = a.Q + (size_t)((l >> 2) & 3) * a.ldq + min(co0 + (l >> 4) * 32 + (l & 3) * 8, a.Cj - 8);
+    const int last = a.total - 1;
+    auto stage = [&](int step) {                   // X rows and dY pixels of `step` -> ring slots (sources clamped to the batch)
+        const size_t pix0 = (size_t)min(step, last) * 64;
+        const int sm = step & 3;
+        {
+            const int i = wv;                      // X block i of the step (8 per step, one per wave): row i / NBLK, block i % NBLK
+            const int rr = i / NBLK, b = i % NBLK;
+            glds16(xsrc + (pix0 + i * 8) * ldx, lds0 + XRING + (sm * TR + rr) * ROWB + (b + 1) * 1024);
+        }
+        const int ys = step % 3;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = wv + 8 * k;              // dY block i (16 per step): pixels 4i .. 4i+3
+            glds16(ysrc + (pix0 + i * 4) * a.ldq, lds0 + YRING + ys * YSTEP + i * 1024);
+        }
+    };
+
+    // ---- per-lane fragment offsets (bytes).  Lane l of a transposing read: 16-lane group (l >> 4) & 1 = channels 0-15 / 16-31 of
+    //      the wave's 32, piece row (l & 15) >> 2 = pixel within the 4-pixel block, piece column 4 * (l & 3) channels.
+    //      Pixel of the step read by (k-step j, read r): p = 16j + 8*half + 4r + psub.  Everything that depends on j is a
+    //      compile-time constant; the lane-dependent part of an X address is fa[r][kx] (pixel m = 4r + psub of an 8-pixel block
+    //      shifted by kx - 1: the shift may cross into the neighbouring block) and, for W >= 16, 1 KB for the upper half-wave.
+    const int half = l >> 5, psub = (l & 15) >> 2;
+    const int lane_b = ((l >> 4) & 1) * 32 + (l & 3) * 8;
+    int fa[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int mm = r * 4 + psub + 7 + kx;                    // physical pixel within/after the block that holds x = 8q
+            fa[r][kx] = (mm >> 3) * 1024 + (mm & 7) * 64 + wi * 512 + lane_b + (W >= 16 ? half * 1024 : 0);
+        }
+    const int fb = half * 2048 + psub * 64 + wj * 256 + lane_b;      // dY: 4-pixel block 4j + 2*half + r, channel quarter wj
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+
+    __syncthreads();
+    MI_TS(1);
+    if (sb > 0) {                                  // the row above the slice's first step (X only matters; dY slot is overwritten later)
+        const int step = sb - 1;
+        const size_t pix0 = (size_t)step * 64;
+        const int i = wv;
+        glds16(xsrc + (pix0 + i * 8) * ldx, lds0 + XRING + ((step & 3) * TR + i / NBLK) * ROWB + (i % NBLK + 1) * 1024);
+    }
+    stage(sb);
+    stage(sb + 1);
+#ifdef MI_WTR_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MI_TS(2);
+#endif
+
+    for (int s = sb; s < ((MI_WTR_ABL & 2) ? sb + 1 : se); ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // everything requested so far (steps <= s+1) has landed ...
+        __builtin_amdgcn_s_barrier();                         // ... for every wave, and every wave is done reading step s-1
+        asm volatile("" ::: "memory");
+        stage(s + 2);
+        const int sm = s & 3, y0 = (s * TR) % a.H;
+        // row bases of relative rows -1 .. TR (ring slot, or the zero row at the image border)
+        int RB[TR + 2];
+        RB[0] = y0 == 0 ? 0 : XRING + ((sm * TR + NR - 1) % NR) * ROWB;
+#pragma unroll
+        for (int rr = 0; rr < TR; ++rr) RB[rr + 1] = XRING + (sm * TR + rr) * ROWB;
+        RB[TR + 1] = y0 + TR == a.H ? 0 : XRING + (((sm + 1) & 3) * TR) * ROWB;
+        const uint32_t yb = lds0 + YRING + (s % 3) * YSTEP;
+        // The step's 36 MFMAs per wave, ordered by the X fragment they consume: a fragment = (X row ri, 16-pixel column group,
+        // tap column kx); it serves every output row whose tap ky lands on that X row (up to three MFMAs).  Fragments are
+        // fetched PD units ahead of their MFMAs through a ring of PD + 1 register sets.
+        bf16x8 bfr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = tr_pair(yb + fb + j * 4 * 1024, yb + fb + (j * 4 + 1) * 1024);
+        auto load_unit = [&](auto uc) -> bf16x8 {
+            constexpr int u = decltype(uc)::value;
+            constexpr int ri = u / (JPR * 3), qidx = (u / 3) % JPR, kx = u % 3;
+            uint32_t rb;
+            if constexpr (W == 8) rb = lds0 + (half ? RB[ri + 1] : RB[ri]);          // lanes 32-63 read the next row
+            else rb = lds0 + RB[ri] + qidx * 2048;                                    // 16 pixels = two 8-pixel blocks
+            return tr_pair(rb + fa[0][kx], rb + fa[1][kx]);
+        };
+        bf16x8 F[PD + 1];
+        static_for<0, PD>([&](auto uc) { F[decltype(uc)::value] = load_unit(uc); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, NU>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int ri = u / (JPR * 3), qidx = (u / 3) % JPR, kx = u % 3;
+            if constexpr (u + PD < NU) F[(u + PD) % (PD + 1)] = load_unit(std::integral_constant<int, u + PD>{});
+            static_for<0, 4>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int r0 = W == 8 ? 2 * j : j / JPR, jq = W == 8 ? 0 : j % JPR;
+                constexpr int ky = ri - r0;
+                if constexpr (jq == qidx && ky >= 0 && ky <= 2)
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[u % (PD + 1)], bfr[j], acc[ky * 3 + kx], 0, 0, 0);
+            });
+            // pin the software pipeline: hipcc otherwise sinks every fragment read to just before its MFMA (read, wait for it,
+            // one MFMA, next read ...), which runs at half the MFMA rate; nothing may move across a unit boundary
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // nothing may still be writing LDS when the workgroup retires
+    MI_TS(3);
+
+#if MI_WTR_ABL & 1      // profiling only: no partial-tile stores (one store keeps the accumulators live)
+    {
+        float v = 0.f;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v += acc[tp][r];
+        if (v == 123.456f) a.ws[t] = v;
+        return;
+    }
+#endif
+    if (a.splits == 1) {
+        // the only k-slice of its tile: add into dW (lanes 0-31 = 32 consecutive co: 128-byte row segments)
+        const int ci = ci0 + wi * 32 + 4 * (l >> 5), co = co0 + wj * 32 + (l & 31);
+        if (co < a.Cj) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                float* o = a.dW + ((size_t)tp * a.Ci + ci) * a.Cj + co;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * a.Cj] += acc[tp][r];
+            }
+        }
+        return;
+    }
+    // ---- partial tile in register order: slot tap*4 + rq holds, for thread t (of 512), accumulator registers 4rq .. 4rq+3
+    float* out = a.ws + (size_t)(split * ntiles + tile) * (36 * 2048) + t * 4;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+            *reinterpret_cast<f32x4*>(out + (tp * 4 + rq) * 2048) =
+                f32x4{acc[tp][4 * rq], acc[tp][4 * rq + 1], acc[tp][4 * rq + 2], acc[tp][4 * rq + 3]};
+#ifdef MI_WTR_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MI_TS(4);
+#endif
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const TrBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < MAXP; ++q)
+        if (q < b.n && (int)blockIdx.x >= b.p[q].wg0) p = q;
+    const TrArgs& a = b.p[p];
+    const int wg = blockIdx.x - a.wg0;
+    switch (a.W) {
+        case 8:  wgrad_tr_body<8>(a, wg, lds_raw); break;
+        case 16: wgrad_tr_body<16>(a, wg, lds_raw); break;
+        case 32: wgrad_tr_body<32>(a, wg, lds_raw); break;
+        default: wgrad_tr_body<64>(a, wg, lds_raw); break;
+    }
+}
+
+// dW[tap][ci][co] += sum over k-slices of the partial tiles (fixed order).  grid = (2G position groups, 36 slots, tiles of all
+// problems that have k-slices); a workgroup = G slice groups x (256 / G) float4 positions of one slot; each thread keeps 8
+// independent 16-byte loads in flight.
+template <int G>
+__global__ __launch_bounds__(256) void wgrad_tr_reduce_kernel(const TrBatch b) {
+    constexpr int IB = 256 / G;
+    __shared__ f32x4 red[G][IB];
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < MAXP; ++q)
+        if (q < b.n && b.p[q].splits > 1 && (int)blockIdx.z >= b.p[q].tile0) pi = q;
+    const TrArgs& a = b.p[pi];
+    const int ntiles = a.gx * a.gy, splits = a.splits;
+    const int it = threadIdx.x % IB, grp = threadIdx.x / IB;
+    const int tt = blockIdx.x * IB + it;                       // thread of the producing workgroup
+    const int slot = blockIdx.y, tile = blockIdx.z - a.tile0;
+    const float* p = a.ws + (size_t)tile * (36 * 2048) + (size_t)slot * 2048 + tt * 4;
+    const size_t stride = (size_t)ntiles * (36 * 2048);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int sp = grp;
+    for (; sp + 7 * G < splits; sp += 8 * G) {
+        f32x4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + q * G) * stride);
+        s0 += v[0] + v[4]; s1 += v[1] + v[5]; s2 += v[2] + v[6]; s3 += v[3] + v[7];
+    }
+    for (; sp < splits; sp += G) s0 += *reinterpret_cast<const f32x4*>(p + (size_t)sp * stride);
+    f32x4 s = (s0 + s1) + (s2 + s3);
+    red[grp][it] = s;
+    __syncthreads();
+    if (grp != 0) return;
+#pragma unroll
+    for (int g = 1; g < G; ++g) s += red[g][it];
+    const int wv = tt >> 6, l = tt & 63;
+    const int rq = slot & 3, tap = slot >> 2;
+    const int ci = (tile % a.gx) * 64 + (wv >> 2) * 32 + 8 * rq + 4 * (l >> 5);
+    const int co = (tile / a.gx) * 128 + (wv & 3) * 32 + (l & 31);
+    if (co >= a.Cj) return;
+    float* out = a.dW + ((size_t)tap * a.Ci + ci) * a.Cj + co;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (ci + e < a.Ci) out[(size_t)e * a.Cj] += s[e];
+}
+
+bool tr_ok(const MiWgradDesc* d) {
+    if (d->KH != 3 || d->KW != 3 || d->pad != 1 || d->stride != 1 || !d->gather_i || d->mode != 1) return false;
+    if (d->GH != d->DH || d->GW != d->DW) return false;
+    const int W = d->DW, H = d->DH;
+    if (W != 8 && W != 16 && W != 32 && W != 64) return false;
+    if (H % (64 / W)) return false;
+    if (((long)d->N * H * W) % 64) return false;
+    if (d->Ci % 64 || d->I1 % 64 || d->Cj % 32 || d->Cj < 32) return false;
+    if (d->ldp % 8 || d->ldq % 8 || (d->I1 != d->Ci && d->ldp2 % 8)) return false;
+    return true;
+}
+
+int g_wtr_blocks = 0;       // mi_debug_wgrad_tr_blocks: workgroups wanted per launch (0 = one per CU)
+
+long tr_target() {
+    static const long env_target = [] { const char* e = getenv("MI_WTR_BLOCKS"); return e ? atol(e) : 256L; }();
+    return g_wtr_blocks > 0 ? g_wtr_blocks : env_target;
+}
+
+// k-slices of one problem that is given `wgs` workgroups
+void tr_plan(const MiWgradDesc* d, TrArgs& a, long wgs) {
+    a.W = d->DW; a.H = d->DH; a.Ci = d->Ci; a.Cj = d->Cj; a.I1 = d->I1;
+    a.gx = d->Ci / 64; a.gy = (d->Cj + 127) / 128;
+    a.total = (int)((long)d->N * d->DH * d->DW / 64);
+    const int ntiles = a.gx * a.gy;
+    long splits = wgs / ntiles;
+    if (splits < 1) splits = 1;
+    if (splits > a.total) splits = a.total;
+    a.sps = (int)((a.total + splits - 1) / splits);
+    a.splits = (a.total + a.sps - 1) / a.sps;
+}
+
+// workgroups per problem in proportion to the MFMA work (N*H*W*Ci*Cj rounded up to whole tiles), every problem at least its tiles
+void tr_shares(int n, const MiWgradDesc* d, long* wgs) {
+    double tot = 0, fl[MAXP];
+    for (int i = 0; i < n; ++i) { fl[i] = (double)d[i].N * d[i].DH * d[i].DW * d[i].Ci * ((d[i].Cj + 127) / 128 * 128); tot += fl[i]; }
+    const long target = tr_target();
+    for (int i = 0; i < n; ++i) {
+        const long tiles = (long)(d[i].Ci / 64) * ((d[i].Cj + 127) / 128);
+        long w = (long)(target * fl[i] / tot + 0.5);
+        w = w / tiles * tiles;                                  // whole k-slices
+        wgs[i] = w < tiles ? tiles : w;
+    }
+}
+
+size_t tr_lds(int W) { return (size_t)((W / 8 + 2) * 1024) * (1 + 4 * (64 / W)) + 3 * 64 * 256; }
+
+size_t tr_ws_floats(const TrArgs& a) { return a.splits > 1 ? (size_t)a.splits * a.gx * a.gy * 36 * 2048 : 0; }
+
+}  // namespace
+
+extern "C" int mi_conv3x3_wgrad_tr_supported(const MiWgradDesc* d) { return (d && tr_ok(d)) ? 1 : 0; }
+
+// Scratch bytes for a batch of n problems (n = 1: a single layer on every CU)
+extern "C" size_t mi_conv3x3_wgrad_tr_batch_workspace(int n, const MiWgradDesc* descs) {
+    if (!descs || n < 1 || n > MAXP) return 0;
+    long wgs[MAXP];
+    for (int i = 0; i < n; ++i) if (!tr_ok(&descs[i])) return 0;
+    tr_shares(n, descs, wgs);
+    size_t fl = 0;
+    for (int i = 0; i < n; ++i) { TrArgs a; tr_plan(&descs[i], a, wgs[i]); fl += tr_ws_floats(a); }
+    return fl * sizeof(float) + 256;
+}
+extern "C" size_t mi_conv3x3_wgrad_tr_workspace(const MiWgradDesc* d) { return mi_conv3x3_wgrad_tr_batch_workspace(1, d); }
+
+extern "C" int mi_conv3x3_wgrad_tr_splits(const MiWgradDesc* d) {
+    if (!d || !tr_ok(d)) return 0;
+    TrArgs a; tr_plan(d, a, tr_target());
+    return a.splits;
+}
+
+// tests: plan for `blocks` workgroups instead of one per CU (odd slice boundaries); 0 restores the default
+extern "C" int mi_debug_wgrad_tr_blocks(int blocks) { g_wtr_blocks = blocks > 0 ? blocks : 0; return 0; }
+
+// phase: 0 = contraction + reduce, 1 = contraction only, 2 = reduce only (per-kernel event timing, as mi_debug_wgrad3x3_phase)
+static int g_wtr_phase = 0;
+extern "C" int mi_debug_wgrad_tr_phase(int phase) {
+    if (phase < 0 || phase > 2) return mi_set_error(-1, "mi_debug_wgrad_tr_phase: phase in 0..2");
+    g_wtr_phase = phase;
+    return 0;
+}
+
+extern "C" int mi_conv3x3_wgrad_tr_batch(int n, const MiWgradDesc* descs, const void* const* P, const void* const* P2,
+                                         const void* const* Q, float* const* dW, void* workspace, size_t ws_bytes, void* stream) {
+    MI_REQUIRE(n >= 1 && n <= MAXP && descs && P && Q && dW, "1..8 problems, non-null arrays");
+    TrBatch b;
+    b.n = n;
+    long wgs[MAXP];
+    for (int i = 0; i < n; ++i) {
+        MI_REQUIRE(tr_ok(&descs[i]), "descriptor not supported by the LDS-DMA weight-gradient kernel (use mi_conv3x3_wgrad_io)");
+        MI_REQUIRE(P[i] && Q[i] && dW[i], "null operand");
+        MI_REQUIRE(descs[i].I1 == descs[i].Ci || (P2 && P2[i]), "two-source split without P2");
+        MI_REQUIRE((((uintptr_t)P[i] | (uintptr_t)Q[i] | (uintptr_t)((P2 && P2[i]) ? P2[i] : P[i])) & 15) == 0, "operands must be 16-byte aligned");
+    }
+    tr_shares(n, descs, wgs);
+    size_t off = 0, lds = 0;
+    int wg = 0, tile = 0, max_splits = 1;
+    for (int i = 0; i < n; ++i) {
+        TrArgs& a = b.p[i];
+        tr_plan(&descs[i], a, wgs[i]);
+        a.P = (const uint16_t*)P[i]; a.P2 = (const uint16_t*)((P2 && P2[i]) ? P2[i] : P[i]); a.Q = (const uint16_t*)Q[i];
+        a.dW = dW[i];
+        a.ldp = descs[i].ldp; a.ldp2 = (P2 && P2[i]) ? descs[i].ldp2 : descs[i].ldp; a.ldq = descs[i].ldq;
+        a.ws = (float*)workspace + off;
+        off += tr_ws_floats(a);
+        a.wg0 = wg; wg += a.gx * a.gy * a.splits;
+        a.tile0 = tile; if (a.splits > 1) tile += a.gx * a.gy;
+        if (a.splits > max_splits) max_splits = a.splits;
+        const size_t l = tr_lds(a.W);
+        if (l > lds) lds = l;
+    }
+    MI_REQUIRE(off == 0 || (workspace && ((uintptr_t)workspace & 15) == 0 && ws_bytes >= off * sizeof(float)),
+               "workspace too small (mi_conv3x3_wgrad_tr_batch_workspace)");
+    hipStream_t st = (hipStream_t)stream;
+    static bool once = [] {
+        (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+    }();
+    (void)once;
+    if (g_wtr_phase != 2) hipLaunchKernelGGL(wgrad_tr_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);
+    if (g_wtr_phase != 1 && tile > 0) {
+        if (max_splits >= 64) hipLaunchKernelGGL(wgrad_tr_reduce_kernel<8>, dim3(16, 36, tile), dim3(256), 0, st, b);
+        else hipLaunchKernelGGL(wgrad_tr_reduce_kernel<2>, dim3(4, 36, tile), dim3(256), 0, st, b);
+    }
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi_conv3x3_wgrad_tr(const MiWgradDesc* d, const void* P, const void* P2, const void* Q, float* dW,
+                                   void* workspace, size_t ws_bytes, void* stream) {
+    return mi_conv3x3_wgrad_tr_batch(1, d, &P, &P2, &Q, &dW, workspace, ws_bytes, stream);
+}

@@ -440,6 +440,19 @@ class Unet(nn.Module):
         offs = self._offs
 
         BF = torch.bfloat16
+        # bf16 copies of residual-stream tensors (fp32) that feed a Block conv: the conv and its weight gradient read the copy --
+        # the rounding they would apply while staging, applied once (bit-identical results, half the bytes, and both kernels
+        # can take their operands by LDS-DMA).  A ResnetBlock output is copied by the GroupNorm kernel that writes it
+        # (want16), everything else by mi_f32_to_bf16 on first use.
+        sh: Dict[int, torch.Tensor] = {}
+        use_sh = mode == K.MODE_BF16 and self.block_storage in ("bf16", "auto") and os.environ.get("MI_DDPM_SHADOW", "1") == "1"
+
+        def shadow(t):
+            s16 = sh.get(id(t))
+            if s16 is None:
+                s16 = K.to_bf16(t)
+                sh[id(t)] = s16
+            return s16
 
         def conv(inp, pre, k, stride=1, pad=0, x2=None, residual=None, transposed_conv=False, bias=True, out_dtype=torch.float32):
             w = sv[pre + "weight"]
@@ -466,7 +479,7 @@ class Unet(nn.Module):
                              wb=wf_sh[offs[pre + "weight"]:] if mode == K.MODE_BF16 else None)
             return y
 
-        def resblock(blk, inp, x2=None):
+        def resblock(blk, inp, x2=None, want_out16=False):
             pre, co, ci = blk["pre"], blk["cout"], blk["cin"]
             # bf16 storage of c1 / h1 / c2 when every kernel touching them has a bf16 path for this shape
             lo16 = False
@@ -477,15 +490,22 @@ class Unet(nn.Module):
             k1 = inp.shape[3] if x2 is not None else None
             c1_16 = (lo16 and ci % 32 == 0 and all(K.fast3x3_supported(B, inp.shape[1], inp.shape[2], ci, co, k1))
                      and not (auto and K.conv3x3_uses_splitk(B, inp.shape[1], inp.shape[2], ci, co, k1)))
-            c1 = conv(inp, pre + "block1.block.0.", 3, 1, 1, x2=x2, out_dtype=BF if c1_16 else torch.float32)
+            inp_c, x2_c = inp, x2
+            if c1_16 and use_sh and inp.dtype == torch.float32 and inp.shape[3] % 8 == 0:
+                inp_c, x2_c = shadow(inp), (shadow(x2) if x2 is not None else None)
+            c1 = conv(inp_c, pre + "block1.block.0.", 3, 1, 1, x2=x2_c, out_dtype=BF if c1_16 else torch.float32)
             tb = tb_all[:, blk["tcol"]:blk["tcol"] + co]
             h1, st1 = K.gn_mish_fwd(c1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], temb=tb,
                                     out_dtype=BF if lo16 else torch.float32)
             c2 = conv(h1, pre + "block2.block.0.", 3, 1, 1, out_dtype=BF if lo16 else torch.float32)
             r = conv(inp, pre + "res_conv.", 1, x2=x2) if blk["res"] else inp
-            out, st2 = K.gn_mish_fwd(c2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], residual=r)
+            if want_out16 and use_sh and co % 32 == 0:
+                out, st2, out16 = K.gn_mish_fwd(c2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], residual=r, want16=True)
+                sh[id(out)] = out16
+            else:
+                out, st2 = K.gn_mish_fwd(c2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], residual=r)
             if record:
-                tape.append(("res", blk, inp, x2, c1, st1, h1, c2, st2, out))
+                tape.append(("res", blk, inp, x2, c1, st1, h1, c2, st2, out, inp_c, x2_c))
             return out
 
         def attention(at, inp):
@@ -508,7 +528,7 @@ class Unet(nn.Module):
         skips = []
         h = x
         for lvl in A.downs:
-            h = resblock(lvl["res1"], h)
+            h = resblock(lvl["res1"], h, want_out16=True)        # feeds res2's first conv
             h = resblock(lvl["res2"], h)
             h = attention(lvl["attn"], h)
             skips.append(h)
@@ -519,9 +539,9 @@ class Unet(nn.Module):
                     tape.append(("down", lvl["down"], inp, h))
         h = resblock(A.mid1, h)
         h = attention(A.mid_attn, h)
-        h = resblock(A.mid2, h)
+        h = resblock(A.mid2, h, want_out16=True)                  # feeds the first up block's conv
         for lvl in A.ups:
-            h = resblock(lvl["res1"], h, x2=skips.pop())          # cat((x, skip)) read in place (ddpm.py:255)
+            h = resblock(lvl["res1"], h, x2=skips.pop(), want_out16=True)          # cat((x, skip)) read in place (ddpm.py:255)
             h = resblock(lvl["res2"], h)
             h = attention(lvl["attn"], h)
             inp = h
@@ -552,17 +572,21 @@ class Unet(nn.Module):
         if mode == K.MODE_BF16:
             wd_sh, wf_sh = self._shadows()
         G = _GradMap()
+        wq = K.WgradQueue(group=int(os.environ.get("MI_DDPM_WGRAD_GROUP", "8")))
         x_in = tape[-1][1]
         B = x_in.shape[0]
         dtb_all = torch.zeros((B, A.mlp_rows), device=x_in.device, dtype=torch.float32)
 
-        def conv_bwd(dy, inp, pre, k, stride=1, pad=0, x2=None, transposed_conv=False, bias="colsum", want_dx=True):
+        def conv_bwd(dy, inp, pre, k, stride=1, pad=0, x2=None, transposed_conv=False, bias="colsum", want_dx=True, winp=None, wx2=None):
             """Gradients of y = conv(inp [|x2]); dy may be a channel slice.  The gradient wrt inp has inp's dtype
-            (bf16 for the block-internal h1, fp32 for everything on the residual stream)."""
+            (bf16 for the block-internal h1, fp32 for everything on the residual stream).  winp / wx2: the tensors the forward
+            conv actually read (bf16 copies of inp / x2), used as the weight-gradient operand."""
             w = sv[pre + "weight"]
             kh, kw, ci, co = w.shape
             ih, iw = inp.shape[1], inp.shape[2]
             oh, ow = dy.shape[1], dy.shape[2]
+            winp = inp if winp is None else winp
+            wx2 = x2 if wx2 is None else wx2
             if (x2 is None and stride == 1 and not transposed_conv and k == 1 and K.small_cout_supported(2, ci, co)
                     and K.small_cout_supported(1, ci, co)):
                 K.conv1x1_small_cout(2, inp, None, b=dy, out=gv[pre + "weight"])
@@ -578,9 +602,12 @@ class Unet(nn.Module):
             elif transposed_conv:   # dW[tap][ci][co] = sum over input pixels  x[j] * dy[gather(j, tap)]
                 K.conv_wgrad(inp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=False,
                              Ci=ci, Cj=co, grid_g=(oh, ow), grid_d=(ih, iw), mode=mode)
+            elif k == 3 and stride == 1 and bias != "colsum" and mode == K.MODE_BF16:
+                # Block conv: deferred, several layers per launch (K.WgradQueue)
+                wq.push(winp, dy, gv[pre + "weight"], Ci=ci, Cj=co, hw=(ih, iw), mode=mode, P2=wx2)
             else:
-                K.conv_wgrad(inp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=True,
-                             Ci=ci, Cj=co, grid_g=(ih, iw), grid_d=(oh, ow), mode=mode, P2=x2,
+                K.conv_wgrad(winp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=True,
+                             Ci=ci, Cj=co, grid_g=(ih, iw), grid_d=(oh, ow), mode=mode, P2=wx2,
                              dbias=gv[pre + "bias"] if bias == "colsum" else None)
                 bias = None                                           # handled (fused or by conv_wgrad's fallback)
             if bias == "colsum":
@@ -611,7 +638,7 @@ class Unet(nn.Module):
                              K=co, Nc=ci, out_hw=(ih, iw), mode=mode, out=cat, accumulate=acc)
 
         def res_bwd(rec):
-            _, blk, inp, x2, c1, st1, h1, c2, st2, out = rec
+            _, blk, inp, x2, c1, st1, h1, c2, st2, out, inp_c, x2_c = rec
             pre = blk["pre"]
             dout = G.take(out)
             # residual branch first: its gradient is dout itself (read before anything accumulates into it)
@@ -630,7 +657,7 @@ class Unet(nn.Module):
             dc1 = K.gn_mish_bwd(c1, st1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], dh1,
                                 dgamma=gv[pre + "block1.block.1.weight"], dbeta=gv[pre + "block1.block.1.bias"],
                                 dtemb=dtb, dbias=gv[pre + "block1.block.0.bias"], out_dtype=c1.dtype)
-            conv_bwd(dc1, inp, pre + "block1.block.0.", 3, 1, 1, x2=x2, bias=None, want_dx=want_dx)
+            conv_bwd(dc1, inp, pre + "block1.block.0.", 3, 1, 1, x2=x2, bias=None, want_dx=want_dx, winp=inp_c, wx2=x2_c)
             if x2 is not None:
                 cat = G._g.pop(("cat", id(inp)))
                 k1 = inp.shape[3]
@@ -652,6 +679,14 @@ class Unet(nn.Module):
 
         hook = self.grad_ready_hook
         dx_in = None
+        # a record's flat-gradient range is final once the weight gradients it deferred have been issued: ranges are reported
+        # in tape order, each after the flush that covers it
+        fifo: List[tuple] = []
+
+        def drain():
+            while fifo and fifo[0][1] <= wq.flushed:
+                hook(*fifo.pop(0)[0])
+        wq.on_flush = drain if hook is not None else None
         for rec in reversed(tape):
             kind = rec[0]
             if kind == "input":
@@ -703,7 +738,11 @@ class Unet(nn.Module):
                 dt1 = K.mish_bwd(t1, da1)
                 lin_bwd(dt1, te, gv["time_mlp.1.weight"], gv["time_mlp.1.bias"], sv["time_mlp.1.weight"], want_dx=False)
             if hook is not None:
-                hook(*rng)
+                fifo.append((rng, wq.pushed))
+                drain()
+        wq.flush()
+        if hook is not None:
+            drain()
         if need_dx:
             dx_in = K.nhwc_to_nchw(G.take(x_in))
         return dx_in

@@ -8,6 +8,7 @@ CPU path: a tensor that is not on a GPU raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -17,6 +18,9 @@ from .lib import MiConvDesc, MiGnDesc, MiWgradDesc, check, load_library
 MODE_FP32, MODE_BF16 = 0, 1
 PROBE = None      # bench.py sets this to a list: (kernel symbol, algorithmic FLOPs, start event, end event, shape note, algorithmic
                   # HBM bytes) per launch, events recorded on the launch stream
+
+
+USE_WGRAD_TR = os.environ.get("MI_W3_TR", "1") != "0"      # A/B switch for the LDS-DMA weight-gradient kernel (csrc/wgrad_tr.hip)
 
 
 def _probe_open():
@@ -231,11 +235,34 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
                     ldp2=ld_of(P2) if P2 is not None else 0, ldq=ld_of(Q))
     lib = load_library()
     fast = bool(lib.mi_conv3x3_wgrad_supported(C.byref(d)))
-    if not fast and (_b16(P) or _b16(Q)):
+    use_tr = bool(USE_WGRAD_TR and dbias is None and kh == 3 and _b16(P) and _b16(Q) and (P2 is None or _b16(P2))
+                  and lib.mi_conv3x3_wgrad_tr_supported(C.byref(d)))
+    if not fast and not use_tr and (_b16(P) or _b16(Q)):
         raise RuntimeError("bf16-stored operands need the fast wgrad kernel (caller must check wgrad_supported)")
     flops = 2.0 * N * grid_d[0] * grid_d[1] * Ci * Cj * kh * kw
     nb_in = N * grid_g[0] * grid_g[1] * Ci * _esz(P) + N * grid_d[0] * grid_d[1] * Cj * _esz(Q)
     desc = f"N{N} {grid_d[0]}x{grid_d[1]} Ci{Ci}{'(2src)' if P2 is not None else ''} Cj{Cj} k{kh} s{stride} g{int(gather_i)}"
+    if use_tr:
+        # both operands bf16-stored: LDS-DMA + transposing-read kernel, all nine taps per workgroup
+        need = lib.mi_conv3x3_wgrad_tr_workspace(C.byref(d))
+        ws = _workspace(P.device, need)
+
+        def go_tr():
+            check(lib.mi_conv3x3_wgrad_tr(C.byref(d), _p(P), _p(P2), _p(Q), _p(dW), _p(ws), ws.numel() * 4, _stream()), "mi_conv3x3_wgrad_tr")
+        if PROBE is None:
+            go_tr()
+        else:
+            sp = lib.mi_conv3x3_wgrad_tr_splits(C.byref(d))
+            part = 9.0 * 64 * 128 * 4 * sp * (Ci // 64) * ((Cj + 127) // 128)
+            try:
+                lib.mi_debug_wgrad_tr_phase(1)
+                e0 = _probe_open(); go_tr(); _probe_close(e0, "wgrad_tr_kernel", flops, desc, nb_in + part)
+                lib.mi_debug_wgrad_tr_phase(2)
+                e0 = _probe_open(); go_tr()
+                _probe_close(e0, "wgrad_tr_reduce_kernel", 0.0, desc + f" splits{sp}", part + 9.0 * Ci * Cj * 8)
+            finally:
+                lib.mi_debug_wgrad_tr_phase(0)
+        return
     if fast:
         need = lib.mi_conv3x3_wgrad_workspace(C.byref(d))
         ws = _workspace(P.device, need)
@@ -275,6 +302,65 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
             colsum(Q, dbias)
 
 
+class WgradQueue:
+    """Deferred weight gradients of the 3x3 Block convs.  Backward pushes (X, dY, dW) here instead of launching one full-chip
+    kernel per layer; every `group` layers go out as ONE launch of mi_conv3x3_wgrad_tr_batch, each layer on its share of the CUs
+    (see include/mi_ddpm.h: an eighth of the partial-tile traffic, an eighth of the launches).  Layers the LDS-DMA kernel cannot take
+    run at once through conv_wgrad.  `pushed` / `flushed` count the deferred layers and how many of them have been issued;
+    `on_flush()` is called after every flush."""
+
+    def __init__(self, group: int = 8, on_flush=None):
+        self.group, self.on_flush = max(1, min(8, int(group))), on_flush
+        self.items = []
+        self.pushed = self.flushed = 0
+
+    def push(self, P, Q, dW, *, Ci, Cj, hw, mode, P2=None):
+        N = P.shape[0]
+        I1 = P.shape[3] if P2 is not None else Ci
+        d = MiWgradDesc(N=N, GH=hw[0], GW=hw[1], DH=hw[0], DW=hw[1], Ci=Ci, Cj=Cj, KH=3, KW=3, stride=1, pad=1, gather_i=1, mode=mode,
+                        I1=I1, ldp=ld_of(P), ldp2=ld_of(P2) if P2 is not None else 0, ldq=ld_of(Q))
+        ok = (USE_WGRAD_TR and self.group > 1 and _b16(P) and _b16(Q) and (P2 is None or _b16(P2))
+              and load_library().mi_conv3x3_wgrad_tr_supported(C.byref(d)))
+        if not ok:
+            conv_wgrad(P, Q, dW, kh=3, kw=3, stride=1, pad=1, gather_i=True, Ci=Ci, Cj=Cj, grid_g=hw, grid_d=hw, mode=mode, P2=P2)
+            return
+        self.items.append((d, P, P2, Q, dW))
+        self.pushed += 1
+        if len(self.items) >= self.group:
+            self.flush()
+
+    def flush(self):
+        items = self.items
+        self.items = []
+        self.flushed += len(items)
+        if items:
+            _need_gpu(items[0][1])
+            n = len(items)
+            lib = load_library()
+            descs = (MiWgradDesc * n)(*[it[0] for it in items])
+            arr = lambda k: (C.c_void_p * n)(*[(it[k].data_ptr() if it[k] is not None else 0) for it in items])   # noqa: E731
+            need = lib.mi_conv3x3_wgrad_tr_batch_workspace(n, descs)
+            ws = _workspace(items[0][1].device, need)
+
+            def go():
+                check(lib.mi_conv3x3_wgrad_tr_batch(n, descs, arr(1), arr(2), arr(3), arr(4), _p(ws), ws.numel() * 4, _stream()),
+                      "mi_conv3x3_wgrad_tr_batch")
+            if PROBE is None:
+                go()
+            else:
+                flops = sum(2.0 * it[0].N * it[0].DH * it[0].DW * it[0].Ci * it[0].Cj * 9 for it in items)
+                nb = sum(it[0].N * it[0].DH * it[0].DW * (it[0].Ci + it[0].Cj) * 2.0 for it in items)
+                try:
+                    lib.mi_debug_wgrad_tr_phase(1)
+                    e0 = _probe_open(); go(); _probe_close(e0, "wgrad_tr_kernel", flops, f"{n} layers", nb + need)
+                    lib.mi_debug_wgrad_tr_phase(2)
+                    e0 = _probe_open(); go(); _probe_close(e0, "wgrad_tr_reduce_kernel", 0.0, f"{n} layers", float(need))
+                finally:
+                    lib.mi_debug_wgrad_tr_phase(0)
+        if self.on_flush is not None:
+            self.on_flush()
+
+
 _WS = {}
 _WS_RETIRED = []      # outgrown workspaces stay allocated: a captured hipGraph may still write its partial tiles there
 
@@ -306,10 +392,37 @@ def colsum(x, out):
 
 
 # --------------------------------------------------------------------------- norms
-def gn_mish_fwd(x, gamma, beta, *, groups=8, eps=1e-5, temb=None, residual=None, out_dtype=torch.float32):
+def to_bf16(x):
+    """bf16 copy (round-to-nearest-even) of an fp32 NHWC activation or channel slice: the MFMA operand of the next conv /
+    weight gradient, rounded once for all of its consumers."""
+    _need_gpu(x)
+    N, H, W, Cc = x.shape
+    y = new_act(N, H, W, Cc, x, torch.bfloat16)
+    e0 = _probe_open()
+    check(load_library().mi_f32_to_bf16(N * H * W, Cc, _p(x), ld_of(x), _p(y), Cc, _stream()), "mi_f32_to_bf16")
+    if e0 is not None:
+        _probe_close(e0, "f32_to_bf16_kernel", 0.0, f"M{N * H * W} C{Cc}", N * H * W * Cc * 6.0)
+    return y
+
+
+def gn_mish_fwd(x, gamma, beta, *, groups=8, eps=1e-5, temb=None, residual=None, out_dtype=torch.float32, want16=False):
+    """-> (y, stats), or (y, stats, y16) with want16: y16 = y rounded to bf16, written by the same pass."""
     _need_gpu(x)
     N, H, W, Cc = x.shape
     y = new_act(N, H, W, Cc, x, out_dtype)
+    if want16:
+        y16 = new_act(N, H, W, Cc, x, torch.bfloat16)
+        stats = torch.empty((N, groups, 2), device=x.device, dtype=torch.float32)
+        d = MiGnDesc(N=N, HW=H * W, C=Cc, G=groups, eps=eps, ldx=ld_of(x), ldy=ld_of(y),
+                     ldr=ld_of(residual) if residual is not None else 0)
+        io = _b16(x) | (_b16(y) << 1)
+        e0 = _probe_open()
+        check(load_library().mi_gn_mish_fwd_dual(C.byref(d), _p(x), _p(gamma), _p(beta), _p(temb), ld_of(temb) if temb is not None else 0,
+                                                 _p(residual), _p(y), _p(y16), Cc, _p(stats), io, _stream()), "mi_gn_mish_fwd_dual")
+        if e0 is not None:
+            _probe_close(e0, f"gn_mish_fwd_kernel<io{io}>", 0.0, f"N{N} HW{H * W} C{Cc} res{int(residual is not None)} +bf16 copy",
+                         N * H * W * Cc * (_esz(x) + _esz(y) + _esz(residual) + 2))
+        return y, stats, y16
     stats = torch.empty((N, groups, 2), device=x.device, dtype=torch.float32)
     d = MiGnDesc(N=N, HW=H * W, C=Cc, G=groups, eps=eps, ldx=ld_of(x), ldy=ld_of(y),
                  ldr=ld_of(residual) if residual is not None else 0)

@@ -174,6 +174,29 @@ int mi_conv3x3_wgrad_bias(const MiWgradDesc* d, const float* P, const float* P2,
 int mi_conv3x3_wgrad_io(const MiWgradDesc* d, const void* P, const void* P2, const void* Q, float* dW,
                         float* dbias, void* workspace, size_t ws_bytes, int io, void* stream);
 
+/* 3x3 / stride 1 / pad 1 Conv2d weight gradient (ddpm.py:116) for bf16-STORED operands (P / P2 / Q are bf16 tensors, strides in
+ * elements, % 8 == 0): rows go L2 -> LDS by LDS-DMA, MFMA operands come out of LDS through the transposing ds_read_b64_tr_b16, one
+ * workgroup accumulates all nine taps of a 64 x 128 (ci x co) tile over its slice of the pixel axis; slices are summed in a fixed
+ * order by a second kernel through `workspace` (mi_conv3x3_wgrad_tr_workspace bytes).  dW += result, layout [3][3][Ci][Cj].
+ * Needs W in {8,16,32,64}, H % (64/W) == 0, N*H*W % 64 == 0, Ci % 64 == 0, I1 % 64 == 0, Cj % 32 == 0 (query _supported). */
+int mi_conv3x3_wgrad_tr_supported(const MiWgradDesc* d);
+size_t mi_conv3x3_wgrad_tr_workspace(const MiWgradDesc* d);
+int mi_conv3x3_wgrad_tr_splits(const MiWgradDesc* d);
+int mi_conv3x3_wgrad_tr(const MiWgradDesc* d, const void* P, const void* P2, const void* Q, float* dW,
+                        void* workspace, size_t ws_bytes, void* stream);
+/* Up to 8 independent layers in ONE launch, each on a share of the workgroups proportional to its MFMA work.  The partial-tile
+ * volume of a layer is (its workgroups) x 288 KB, so eight layers side by side write an eighth of what eight full-chip launches
+ * write, and layers with at least as many tiles as workgroups accumulate straight into dW (no k-slices, no reduce).  descs: array
+ * of n descriptors; P / P2 / Q / dW: arrays of n device pointers (P2 entries may be null); the layers' weight gradients must not
+ * alias each other.  Backward defers the Block convs' weight gradients and flushes them through this entry point. */
+size_t mi_conv3x3_wgrad_tr_batch_workspace(int n, const MiWgradDesc* descs);
+int mi_conv3x3_wgrad_tr_batch(int n, const MiWgradDesc* descs, const void* const* P, const void* const* P2,
+                              const void* const* Q, float* const* dW, void* workspace, size_t ws_bytes, void* stream);
+/* measurement aid, as mi_debug_wgrad3x3_phase: 1 = contraction kernel only, 2 = reduce only, 0 = both */
+int mi_debug_wgrad_tr_phase(int phase);
+/* test aid: plan the k-slices for `blocks` workgroups instead of one per CU (0 = default) */
+int mi_debug_wgrad_tr_blocks(int blocks);
+
 /* out[c] += sum_m x[m*ld + c]  (bias gradients) */
 int mi_colsum(int M, int C, const float* x, int ld, float* out, void* stream);
 
@@ -204,6 +227,11 @@ int mi_gn_mish_bwd(const MiGnDesc* d, const float* x, const float* stats, const 
  * bit 2 = dout bf16.  gamma/beta/temb/residual/stats and all parameter gradients stay fp32. */
 int mi_gn_mish_fwd_io(const MiGnDesc* d, const void* x, const float* gamma, const float* beta, const float* temb,
                       int ldt, const float* residual, void* y, float* stats, int io, void* stream);
+/* mi_gn_mish_fwd_io that also writes y rounded to bf16 into y16 (pixel stride ldy16 elements): the residual stream stays fp32 in y,
+ * the next layer's bf16-MFMA kernels read the copy (ddpm.py:116,143: the ResnetBlock output feeds the next block's convs). */
+int mi_gn_mish_fwd_dual(const MiGnDesc* d, const void* x, const float* gamma, const float* beta,
+                        const float* temb, int ldt, const float* residual, void* y, void* y16, int ldy16,
+                        float* stats, int io, void* stream);
 int mi_gn_mish_bwd_io(const MiGnDesc* d, const void* x, const float* stats, const float* gamma, const float* beta,
                       const void* dout, int lddo, void* dx, int lddx, float* dgamma, float* dbeta, float* dtemb,
                       int ldt, float* dbias, int io, void* stream);
@@ -349,6 +377,9 @@ int mi_adam_step_dev(size_t n, float* p, const float* g, float* m, float* v, con
  * idx: int64[B] rows of the dataset; flip: uint8[B] or null. */
 int mi_u8_gather_normalize(int B, int C, int H, int W, const uint8_t* data, const int64_t* idx, const uint8_t* flip,
                            int normalize, float* out_nchw, void* stream);
+/* fp32 [M][C] (row stride ldx) -> bf16 [M][C] (row stride ldy), round-to-nearest-even: the bf16 copy of a residual-stream tensor
+ * that the next layer's conv / weight-gradient kernels read as their MFMA operand (C, ldx, ldy % 4 == 0). */
+int mi_f32_to_bf16(size_t M, int C, const float* x, int ldx, void* y_bf16, int ldy, void* stream);
 /* y = a*x + (accumulate ? y : 0) */
 int mi_axpby(size_t n, float a, const float* x, int accumulate, float* y, void* stream);
 /* same on M rows of C channels with row strides (gradient accumulation into channel slices) */

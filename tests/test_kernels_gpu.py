@@ -3,6 +3,7 @@ reference op (torch CPU = the reference's own arithmetic, ddpm.py line cited per
 Tolerances (rel-L2): 2e-5 in exact-fp32 mode, 2e-2 in bf16-MFMA mode (CPU bf16
 autocast of the reference differs from fp64 by 1.6e-2)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -419,6 +420,99 @@ def test_conv3x3_wgrad_fast(K, cfg):
     wq = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(xq, wq, None, padding=1).backward(dq)
     assert rel_err(got, wq.grad) < 2e-5          # same bf16-rounded operands: only summation order differs
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=2, H=32, W=32, Ci=128, Co=128),                 # level 0: 2 rows per step, 2 ci tiles
+    dict(N=8, H=32, W=32, Ci=64, Co=256),                  # 2 co tiles, long k-slices
+    dict(N=4, H=16, W=16, Ci=256, Co=256),                 # level 1: 4 rows per step
+    dict(N=8, H=8, W=8, Ci=128, Co=128),                   # 8x8: a step is a whole image (half-waves read different rows)
+    dict(N=16, H=8, W=8, Ci=512, Co=512),                  # level 2, 32 tiles
+    dict(N=1, H=64, W=64, Ci=64, Co=64),                   # cfg 3 level 0: one row per step, co tile half empty
+    dict(N=2, H=16, W=16, Ci=192, Co=96, split=128),       # skip concat (two sources) and a ragged co tile
+    dict(N=1, H=16, W=8, Ci=64, Co=32),                    # non-square: halo rows inside an image at W = 8
+    dict(N=3, H=32, W=32, Ci=64, Co=128, blocks=7),        # slices that start and end in the middle of an image
+])
+def test_conv3x3_wgrad_lds_dma(K, cfg):
+    """aten::convolution_backward (weight) of Block's 3x3 conv for bf16-stored operands through the LDS-DMA + transposing-read
+    kernel (mi_conv3x3_wgrad_tr): against an fp64 evaluation on the same bf16-rounded operands (only the summation order
+    differs: <= 2e-5) and against the image-major register-staged kernel; twice into the same buffer = 2x (accumulate)."""
+    from src.ops.lib import MiWgradDesc, load_library
+    import ctypes
+    N, H, W, Ci, Co = cfg["N"], cfg["H"], cfg["W"], cfg["Ci"], cfg["Co"]
+    split = cfg.get("split")
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16()
+    dy = torch.randn(N, Co, H, W, generator=g).bfloat16()
+    wq = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wq, None, padding=1).backward(dy.double())
+
+    def nhwc16(t):
+        return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    if split:
+        P, P2 = nhwc16(x[:, :split]), nhwc16(x[:, split:])
+    else:
+        P, P2 = nhwc16(x), None
+    Q = nhwc16(dy)
+    d = MiWgradDesc(N=N, GH=H, GW=W, DH=H, DW=W, Ci=Ci, Cj=Co, KH=3, KW=3, stride=1, pad=1, gather_i=1, mode=1,
+                    I1=split or Ci, ldp=P.shape[3], ldp2=P2.shape[3] if P2 is not None else 0, ldq=Co)
+    lib = load_library()
+    assert lib.mi_conv3x3_wgrad_tr_supported(ctypes.byref(d)) == 1
+    lib.mi_debug_wgrad_tr_blocks(cfg.get("blocks", 0))
+    dW = torch.zeros(9 * Ci * Co, device=DEV)
+    assert K.USE_WGRAD_TR
+    try:
+        K.conv_wgrad(P, Q, dW, kh=3, kw=3, stride=1, pad=1, gather_i=True, Ci=Ci, Cj=Co, grid_g=(H, W), grid_d=(H, W), mode=1, P2=P2)
+        torch.cuda.synchronize()
+    finally:
+        lib.mi_debug_wgrad_tr_blocks(0)
+    got = w_from_storage(dW.view(3, 3, Ci, Co))
+    assert rel_err(got, wq.grad) < 2e-5
+    worst = float((got.double() - wq.grad).abs().max() / wq.grad.abs().max())
+    assert worst < 1e-4, worst
+    K.conv_wgrad(P, Q, dW, kh=3, kw=3, stride=1, pad=1, gather_i=True, Ci=Ci, Cj=Co, grid_g=(H, W), grid_d=(H, W), mode=1, P2=P2)
+    torch.cuda.synchronize()
+    assert rel_err(w_from_storage(dW.view(3, 3, Ci, Co)), 2 * wq.grad) < 2e-5
+    # the register-staged kernel on the same operands
+    if lib.mi_conv3x3_wgrad_supported(ctypes.byref(d)):
+        K.USE_WGRAD_TR = False
+        try:
+            dW2 = torch.zeros(9 * Ci * Co, device=DEV)
+            K.conv_wgrad(P, Q, dW2, kh=3, kw=3, stride=1, pad=1, gather_i=True, Ci=Ci, Cj=Co, grid_g=(H, W), grid_d=(H, W), mode=1, P2=P2)
+            torch.cuda.synchronize()
+        finally:
+            K.USE_WGRAD_TR = True
+        assert rel_err(dW2, dW / 2) < 2e-5
+
+
+@pytest.mark.parametrize("group", [8, 3])
+def test_conv3x3_wgrad_queue_batches_layers(K, group):
+    """K.WgradQueue: several Block convs' weight gradients in ONE launch (mi_conv3x3_wgrad_tr_batch), each on its share of the
+    workgroups -- mixed image sizes, a two-source layer, a layer with as many tiles as workgroups (adds into dW directly, no
+    k-slices) and one the LDS-DMA kernel cannot take (odd width: runs at once) -- against fp64 on the same bf16 operands."""
+    g = torch.Generator().manual_seed(43)
+    layers = [dict(N=8, H=32, W=32, Ci=128, Co=128), dict(N=8, H=16, W=16, Ci=256, Co=256), dict(N=8, H=8, W=8, Ci=512, Co=512),
+              dict(N=8, H=8, W=8, Ci=1024, Co=256, split=512), dict(N=8, H=16, W=16, Ci=128, Co=256), dict(N=2, H=12, W=12, Ci=64, Co=64),
+              dict(N=8, H=32, W=32, Ci=64, Co=128), dict(N=8, H=8, W=8, Ci=256, Co=512), dict(N=8, H=16, W=16, Ci=512, Co=128, split=256)]
+    flushes = []
+    q = K.WgradQueue(group=group, on_flush=lambda: flushes.append(q.flushed))
+    refs, outs = [], []
+    for L in layers:
+        N, H, W, Ci, Co, split = L["N"], L["H"], L["W"], L["Ci"], L["Co"], L.get("split")
+        x = torch.randn(N, Ci, H, W, generator=g).bfloat16()
+        dy = torch.randn(N, Co, H, W, generator=g).bfloat16()
+        wq = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x.double(), wq, None, padding=1).backward(dy.double())
+        nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+        P, P2 = (nh(x[:, :split]), nh(x[:, split:])) if split else (nh(x), None)
+        dW = torch.zeros(9 * Ci * Co, device=DEV)
+        q.push(P, nh(dy), dW, Ci=Ci, Cj=Co, hw=(H, W), mode=1, P2=P2)
+        refs.append(wq.grad); outs.append((dW, Ci, Co))
+    q.flush()
+    torch.cuda.synchronize()
+    assert q.pushed == q.flushed == 8 and flushes[-1] == 8 and len(flushes) >= (2 if group == 8 else 3)
+    for (dW, Ci, Co), ref in zip(outs, refs):
+        assert rel_err(w_from_storage(dW.view(3, 3, Ci, Co)), ref) < 2e-5, (Ci, Co)
 
 
 @pytest.mark.parametrize("cfg", [
