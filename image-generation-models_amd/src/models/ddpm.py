@@ -444,15 +444,15 @@ class Unet(nn.Module):
         # the rounding they would apply while staging, applied once (bit-identical results, half the bytes, and both kernels
         # can take their operands by LDS-DMA).  A ResnetBlock output is copied by the GroupNorm kernel that writes it
         # (want16), everything else by mi_f32_to_bf16 on first use.
-        sh: Dict[int, torch.Tensor] = {}
+        sh: Dict[int, tuple] = {}          # id(tensor) -> (tensor, copy): holding the tensor keeps its id from being reused
         use_sh = mode == K.MODE_BF16 and self.block_storage in ("bf16", "auto") and os.environ.get("MI_DDPM_SHADOW", "1") == "1"
 
         def shadow(t):
-            s16 = sh.get(id(t))
-            if s16 is None:
-                s16 = K.to_bf16(t)
-                sh[id(t)] = s16
-            return s16
+            ent = sh.get(id(t))
+            if ent is None:
+                ent = (t, K.to_bf16(t))
+                sh[id(t)] = ent
+            return ent[1]
 
         def conv(inp, pre, k, stride=1, pad=0, x2=None, residual=None, transposed_conv=False, bias=True, out_dtype=torch.float32):
             w = sv[pre + "weight"]
@@ -501,7 +501,7 @@ class Unet(nn.Module):
             r = conv(inp, pre + "res_conv.", 1, x2=x2) if blk["res"] else inp
             if want_out16 and use_sh and co % 32 == 0:
                 out, st2, out16 = K.gn_mish_fwd(c2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], residual=r, want16=True)
-                sh[id(out)] = out16
+                sh[id(out)] = (out, out16)
             else:
                 out, st2 = K.gn_mish_fwd(c2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], residual=r)
             if record:
