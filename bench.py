@@ -202,6 +202,9 @@ def main():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("MI_BENCH_GRAPH", "-1")),
                     help="1: replay the training step as a hipGraph (single GPU), 0: eager, -1: the trainer's default for this config")
     ap.add_argument("--dry-run-cpu", action="store_true", help="launch/rendezvous plumbing only (gloo, host stand-in step)")
+    ap.add_argument("--cfg", type=int, default=2, choices=[2, 3],
+                    help="2 (default, the metric's configuration): CIFAR-10 32x32, UNet 128 / 1-2-4; 3: BASELINE configs[2], CelebA 64x64, "
+                         "UNet 64 / 1-2-4-8 (use --batch 32 for its per-GPU batch at 8 GPUs); the line's metric name and workload say which")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -228,11 +231,15 @@ def main():
     from src.ops import functional as K
     from src.runtime.ddp import FlatGradReducer, broadcast_parameters
 
+    SIDE = 32 if args.cfg == 2 else 64
+    TRAIN_GF = TRAIN_GFLOP_PER_IMAGE if args.cfg == 2 else 26.278
+    FWD_GF = FWD_GFLOP_PER_IMAGE if args.cfg == 2 else 8.7593
+
     def build(mode):
         torch.manual_seed(0)
-        dm_cfg = {"width": 32, "height": 32, "channels": 3, "transforms": {"normalize": True}}
-        m = DDPM(dm_cfg, hidden_dim=128, dim_mults=(1, 2, 4), timesteps=1000, loss_type="l1",
-                 lr=1e-4, b1=0.9, b2=0.999).to(dev)                      # configs/model/ddpm.yaml values
+        dm_cfg = {"width": SIDE, "height": SIDE, "channels": 3, "transforms": {"normalize": True}}
+        m = DDPM(dm_cfg, hidden_dim=128 if args.cfg == 2 else 64, dim_mults=(1, 2, 4) if args.cfg == 2 else (1, 2, 4, 8), timesteps=1000,
+                 loss_type="l1", lr=1e-4, b1=0.9, b2=0.999).to(dev)      # configs/model/ddpm.yaml values
         m.denoising_model.compute_mode = mode
         m.train()
         return m, m.denoising_model, m.configure_optimizers()
@@ -247,7 +254,7 @@ def main():
 
     B = args.batch
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    imgs = torch.rand(B, 3, 32, 32, device=dev, generator=gen) * 2 - 1    # synthetic [-1,1] batch, HBM resident
+    imgs = torch.rand(B, 3, SIDE, SIDE, device=dev, generator=gen) * 2 - 1    # synthetic [-1,1] batch, HBM resident
     batch = (imgs, None)
 
     def eager_step(i, m=None, o=None):
@@ -315,7 +322,7 @@ def main():
     # ---- denoise rate: hipGraph-replayed reverse step at B=64 (ddpm.py:520 samples 64 images)
     from src.runtime.sampler import GraphSampler
     model.eval()
-    gs = GraphSampler(model.diffusion_model, (64, 3, 32, 32))
+    gs = GraphSampler(model.diffusion_model, (64, 3, SIDE, SIDE))
     gs._capture()
     gs.x.normal_(); gs.t.fill_(999)
     for _ in range(5):
@@ -382,7 +389,7 @@ def main():
                 "avg_gflop_per_launch": round(fl / cnt / 1e9, 3), "avg_algorithmic_mb_per_launch": round(nb / cnt / 1e6, 2),
                 "probed_ms_per_step": round(sum(v[1] for v in agg.values()) * 1e3, 3),
                 "all_kernels": table}
-        if not args.no_extras:
+        if not args.no_extras and args.cfg == 2:
             roof["named_kernel"] = named_kernel_line(K, dev)
     elif world > 1:
         for i in range(3):
@@ -404,30 +411,33 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         fp32_mode = {"value": round(B * n / el, 1), "unit": "images/s", "ms_per_step": round(el / n * 1e3, 3), "steps": n,
-                     "train_tflops": round(B * n / el * TRAIN_GFLOP_PER_IMAGE / 1e3, 1), "peak_tflops": PEAK_TFLOPS["fp32"],
+                     "train_tflops": round(B * n / el * TRAIN_GF / 1e3, 1), "peak_tflops": PEAK_TFLOPS["fp32"],
                      "note": "exact-fp32 MFMA mode (v_mfma_f32_32x32x2_f32): the mode that carries the <=1e-4 epsilon-prediction bar"}
         del m32, n32, o32
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_extras and args.cfg == 2:
         cpu = cpu_baseline()
 
     if rank == 0:
         out = {
-            "metric": "ddpm_cifar10_32x32_train_images_per_sec", "value": round(images_per_s, 1), "unit": "images/s",
+            "metric": "ddpm_cifar10_32x32_train_images_per_sec" if args.cfg == 2 else "ddpm_celeba_64x64_train_images_per_sec",
+            "value": round(images_per_s, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.mode,
             "data": "synthetic",
-            "config": {"workload": "DDPM CIFAR-10 32x32 train step (q_sample+UNet fwd+L1+bwd+allreduce+Adam), "
-                                   "UNet base_ch=128 mults 1-2-4, T=1000 (BASELINE configs[1])",
+            "config": {"workload": ("DDPM CIFAR-10 32x32 train step (q_sample+UNet fwd+L1+bwd+allreduce+Adam), "
+                                    "UNet base_ch=128 mults 1-2-4, T=1000 (BASELINE configs[1])") if args.cfg == 2 else
+                                   ("DDPM CelebA 64x64 train step (q_sample+UNet fwd+L1+bwd+allreduce+Adam), UNet hidden 64 mults 1-2-4-8, "
+                                    "T=1000 (BASELINE configs[2]; its per-GPU batch at 8 GPUs is 32)"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "step_launch": "hipGraph replay" if use_graph else "eager",
                        "activations": "NHWC; fp32 residual stream, bf16 block- and attention-internal tensors" if args.mode == "bf16" else "fp32 NHWC", "matmul": "bf16 MFMA, fp32 accumulate" if args.mode == "bf16" else "fp32 MFMA"},
             "rccl_ranks": rccl_ranks, "comm": comm,
             "denoise_steps_per_sec": round(denoise_steps_per_s, 2), "denoise_batch": 64,
             "denoise_image_steps_per_sec": round(denoise_steps_per_s * 64, 1),
-            "train_tflops": round(images_per_s * TRAIN_GFLOP_PER_IMAGE / 1e3, 1),
-            "denoise_tflops": round(denoise_steps_per_s * 64 * FWD_GFLOP_PER_IMAGE / 1e3, 1),
+            "train_tflops": round(images_per_s * TRAIN_GF / 1e3, 1),
+            "denoise_tflops": round(denoise_steps_per_s * 64 * FWD_GF / 1e3, 1),
             "final_loss": round(final_loss, 5),
             "roofline": roof, "fp32_mode": fp32_mode, "cpu_baseline": cpu,
         }

@@ -23,8 +23,7 @@
 // Step s+2 is requested while step s runs on the matrix cores; one s_waitcnt vmcnt(0) + s_barrier per step (36 MFMAs per wave).
 // Image borders are a never-written zero row / zero pixel blocks in LDS.  Slices leave as partial tiles in register order (1 KB
 // contiguous per wave and store) and wgrad_tr_reduce_kernel sums them in a fixed order (deterministic) into dW.
-#include <stdlib.h>
-#include "common.h"
+#include "tr_common.h"
 
 #ifndef MI_WTR_ABL
 #define MI_WTR_ABL 0     // profiling only: 1 no partial-tile stores, 2 no main loop
@@ -42,49 +41,6 @@ extern "C" int mi_debug_wtr_ts(unsigned long long* host_out) {
 #endif
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-
-struct TrArgs {
-    const uint16_t* P; const uint16_t* P2; const uint16_t* Q;
-    float* ws;          // this problem's partial tiles (splits > 1)
-    float* dW;          // [3][3][Ci][Cj], accumulated into directly when splits == 1
-    int W, H, Ci, Cj, I1, ldp, ldp2, ldq;
-    int total;          // steps of 64 pixels over the whole batch: N*H*W / 64
-    int sps, splits;    // steps per k-slice, k-slices
-    int gx, gy;         // ci tiles (64), co tiles (128)
-    int wg0;            // first workgroup of this problem in the launch
-    int tile0;          // first tile of this problem in the reduce launch
-};
-constexpr int MAXP = 8;
-// One launch = up to MAXP independent weight-gradient problems, each on its own share of the workgroups.  A layer's partial-tile
-// volume is (its workgroups) x 288 KB: eight layers side by side on 32 CUs each write an eighth of what one layer on 256 CUs
-// writes (75 MB) for the same MFMA work, and layers with >= 32 tiles need no k-slices at all (they add into dW directly).
-struct TrBatch { TrArgs p[MAXP]; int n; };
-
-// LDS-DMA: 16 bytes per lane from each lane's own global address to LDS byte address lds_dst (wave-uniform) + 16 * lane.
-// M0 carries the LDS base and is compiler-reserved: it is saved, set and restored inside the one statement.  The compiler does
-// not know this is a load: completion is waited for with explicit s_waitcnt vmcnt(N) below.
-__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-__device__ __forceinline__ bf16x8 tr_pair(uint32_t a0, uint32_t a1) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)a0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)a1);
-    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
 
 // W = image width (8, 16, 32 or 64); a step is TR = 64 / W rows of one image (H % TR == 0).  wg = workgroup index within the problem.
 template <int W>

@@ -605,6 +605,13 @@ class Unet(nn.Module):
             elif k == 3 and stride == 1 and bias != "colsum" and mode == K.MODE_BF16:
                 # Block conv: deferred, several layers per launch (K.WgradQueue)
                 wq.push(winp, dy, gv[pre + "weight"], Ci=ci, Cj=co, hw=(ih, iw), mode=mode, P2=wx2)
+            elif k == 1 and stride == 1 and mode == K.MODE_BF16 and winp.dtype == torch.bfloat16:
+                # to_qkv / to_out / res_conv: deferred too; the bias gradient rides along when dy is the fp32 stream gradient
+                fuse_b = bias == "colsum" and dy.dtype == torch.float32
+                wq.push1x1(winp, dy, gv[pre + "weight"], Ci=ci, Cj=co, hw=(ih, iw), mode=mode, P2=wx2,
+                           dbias=gv[pre + "bias"] if fuse_b else None)
+                if fuse_b:
+                    bias = None
             else:
                 K.conv_wgrad(winp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=True,
                              Ci=ci, Cj=co, grid_g=(ih, iw), grid_d=(oh, ow), mode=mode, P2=wx2,
@@ -645,7 +652,7 @@ class Unet(nn.Module):
             is_first = inp is x_in
             want_dx = (not is_first) or need_dx
             if blk["res"]:
-                conv_bwd(dout, inp, pre + "res_conv.", 1, x2=x2, want_dx=want_dx)
+                conv_bwd(dout, inp, pre + "res_conv.", 1, x2=x2, want_dx=want_dx, winp=inp_c, wx2=x2_c)
             else:
                 G.add(inp, dout)
             dc2 = K.gn_mish_bwd(c2, st2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], dout,
@@ -674,6 +681,9 @@ class Unet(nn.Module):
             dqkv = K.linattn_bwd(qkv, ctx, kstat, dao, _HEADS)
             conv_bwd(dqkv, ln, pre + "fn.fn.to_qkv.", 1, bias=None)
             dln = G.take(ln)
+            # the LayerNorm gradient accumulates INTO dout (grad[inp] aliases it, above): the deferred to_out weight gradient
+            # that reads dout has to be issued first
+            wq.flush(kinds=(1,))
             buf, acc = G.target(inp)
             K.chan_layernorm_bwd(inp, sv[pre + "fn.norm.g"], dln, buf, acc, gv[pre + "fn.norm.g"], gv[pre + "fn.norm.b"])
 

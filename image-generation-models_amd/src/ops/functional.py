@@ -303,62 +303,98 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
 
 
 class WgradQueue:
-    """Deferred weight gradients of the 3x3 Block convs.  Backward pushes (X, dY, dW) here instead of launching one full-chip
-    kernel per layer; every `group` layers go out as ONE launch of mi_conv3x3_wgrad_tr_batch, each layer on its share of the CUs
-    (see include/mi_ddpm.h: an eighth of the partial-tile traffic, an eighth of the launches).  Layers the LDS-DMA kernel cannot take
-    run at once through conv_wgrad.  `pushed` / `flushed` count the deferred layers and how many of them have been issued;
-    `on_flush()` is called after every flush."""
+    """Deferred weight gradients of the Block convs (3x3) and of the 1x1 convs.  Backward pushes (X, dY, dW) here instead of
+    launching one full-chip kernel per layer; every `group` layers of a kind go out as ONE launch (mi_conv3x3_wgrad_tr_batch /
+    mi_conv1x1_wgrad_tr_batch), each layer on its share of the CUs (see include/mi_ddpm.h: an eighth of the partial-tile traffic,
+    an eighth of the launches).  Layers the LDS-DMA kernels cannot take run at once through conv_wgrad.  `pushed` / `flushed` count
+    the deferred layers and how many of them have been issued; `on_flush()` is called after every flush."""
 
     def __init__(self, group: int = 8, on_flush=None):
         self.group, self.on_flush = max(1, min(8, int(group))), on_flush
-        self.items = []
+        self.items3, self.items1 = [], []
         self.pushed = self.flushed = 0
 
-    def push(self, P, Q, dW, *, Ci, Cj, hw, mode, P2=None):
-        N = P.shape[0]
+    def _desc(self, P, Q, k, Ci, Cj, hw, mode, P2):
         I1 = P.shape[3] if P2 is not None else Ci
-        d = MiWgradDesc(N=N, GH=hw[0], GW=hw[1], DH=hw[0], DW=hw[1], Ci=Ci, Cj=Cj, KH=3, KW=3, stride=1, pad=1, gather_i=1, mode=mode,
-                        I1=I1, ldp=ld_of(P), ldp2=ld_of(P2) if P2 is not None else 0, ldq=ld_of(Q))
+        return MiWgradDesc(N=P.shape[0], GH=hw[0], GW=hw[1], DH=hw[0], DW=hw[1], Ci=Ci, Cj=Cj, KH=k, KW=k, stride=1, pad=k // 2, gather_i=1,
+                           mode=mode, I1=I1, ldp=ld_of(P), ldp2=ld_of(P2) if P2 is not None else 0, ldq=ld_of(Q))
+
+    def push(self, P, Q, dW, *, Ci, Cj, hw, mode, P2=None):
+        """3x3 / stride 1 / pad 1"""
+        d = self._desc(P, Q, 3, Ci, Cj, hw, mode, P2)
         ok = (USE_WGRAD_TR and self.group > 1 and _b16(P) and _b16(Q) and (P2 is None or _b16(P2))
               and load_library().mi_conv3x3_wgrad_tr_supported(C.byref(d)))
         if not ok:
             conv_wgrad(P, Q, dW, kh=3, kw=3, stride=1, pad=1, gather_i=True, Ci=Ci, Cj=Cj, grid_g=hw, grid_d=hw, mode=mode, P2=P2)
             return
-        self.items.append((d, P, P2, Q, dW))
+        self.items3.append((d, P, P2, Q, dW))
         self.pushed += 1
-        if len(self.items) >= self.group:
-            self.flush()
+        if len(self.items3) >= self.group:
+            self.flush(kinds=(3,))
 
-    def flush(self):
-        items = self.items
-        self.items = []
-        self.flushed += len(items)
-        if items:
+    def push1x1(self, P, Q, dW, *, Ci, Cj, hw, mode, P2=None, dbias=None):
+        """1x1; dbias (optional) += column sums of Q"""
+        d = self._desc(P, Q, 1, Ci, Cj, hw, mode, P2)
+        q32 = int(Q.dtype == torch.float32)
+        ok = (USE_WGRAD_TR and self.group > 1 and _b16(P) and (P2 is None or _b16(P2)) and (dbias is None or q32)
+              and load_library().mi_conv1x1_wgrad_tr_supported(C.byref(d), q32))
+        if not ok:
+            conv_wgrad(P, Q, dW, kh=1, kw=1, stride=1, pad=0, gather_i=True, Ci=Ci, Cj=Cj, grid_g=hw, grid_d=hw, mode=mode, P2=P2, dbias=dbias)
+            return
+        self.items1.append((d, P, P2, Q, dW, dbias, q32))
+        self.pushed += 1
+        if len(self.items1) >= self.group:
+            self.flush(kinds=(1,))
+
+    def flush(self, kinds=(3, 1)):
+        lib = load_library()
+        arr = lambda items, k: (C.c_void_p * len(items))(*[(it[k].data_ptr() if it[k] is not None else 0) for it in items])   # noqa: E731
+        if 3 in kinds and self.items3:
+            items, self.items3 = self.items3, []
+            self.flushed += len(items)
             _need_gpu(items[0][1])
             n = len(items)
-            lib = load_library()
             descs = (MiWgradDesc * n)(*[it[0] for it in items])
-            arr = lambda k: (C.c_void_p * n)(*[(it[k].data_ptr() if it[k] is not None else 0) for it in items])   # noqa: E731
             need = lib.mi_conv3x3_wgrad_tr_batch_workspace(n, descs)
             ws = _workspace(items[0][1].device, need)
 
             def go():
-                check(lib.mi_conv3x3_wgrad_tr_batch(n, descs, arr(1), arr(2), arr(3), arr(4), _p(ws), ws.numel() * 4, _stream()),
-                      "mi_conv3x3_wgrad_tr_batch")
-            if PROBE is None:
-                go()
-            else:
-                flops = sum(2.0 * it[0].N * it[0].DH * it[0].DW * it[0].Ci * it[0].Cj * 9 for it in items)
-                nb = sum(it[0].N * it[0].DH * it[0].DW * (it[0].Ci + it[0].Cj) * 2.0 for it in items)
-                try:
-                    lib.mi_debug_wgrad_tr_phase(1)
-                    e0 = _probe_open(); go(); _probe_close(e0, "wgrad_tr_kernel", flops, f"{n} layers", nb + need)
-                    lib.mi_debug_wgrad_tr_phase(2)
-                    e0 = _probe_open(); go(); _probe_close(e0, "wgrad_tr_reduce_kernel", 0.0, f"{n} layers", float(need))
-                finally:
-                    lib.mi_debug_wgrad_tr_phase(0)
+                check(lib.mi_conv3x3_wgrad_tr_batch(n, descs, arr(items, 1), arr(items, 2), arr(items, 3), arr(items, 4), _p(ws), ws.numel() * 4,
+                                                    _stream()), "mi_conv3x3_wgrad_tr_batch")
+            flops = sum(2.0 * it[0].N * it[0].DH * it[0].DW * it[0].Ci * it[0].Cj * 9 for it in items)
+            nb = sum(it[0].N * it[0].DH * it[0].DW * (it[0].Ci + it[0].Cj) * 2.0 for it in items)
+            self._run(go, lib.mi_debug_wgrad_tr_phase, "wgrad_tr", n, flops, nb, need)
+        if 1 in kinds and self.items1:
+            items, self.items1 = self.items1, []
+            self.flushed += len(items)
+            _need_gpu(items[0][1])
+            n = len(items)
+            descs = (MiWgradDesc * n)(*[it[0] for it in items])
+            q32 = (C.c_int * n)(*[it[6] for it in items])
+            need = lib.mi_conv1x1_wgrad_tr_batch_workspace(n, descs, q32)
+            ws = _workspace(items[0][1].device, need)
+
+            def go1():
+                check(lib.mi_conv1x1_wgrad_tr_batch(n, descs, q32, arr(items, 1), arr(items, 2), arr(items, 3), arr(items, 4), arr(items, 5),
+                                                    _p(ws), ws.numel() * 4, _stream()), "mi_conv1x1_wgrad_tr_batch")
+            flops = sum(2.0 * it[0].N * it[0].DH * it[0].DW * it[0].Ci * it[0].Cj for it in items)
+            nb = sum(it[0].N * it[0].DH * it[0].DW * (it[0].Ci * 2.0 + it[0].Cj * (4.0 if it[6] else 2.0)) for it in items)
+            self._run(go1, lib.mi_debug_wgrad1x1_tr_phase, "wgrad1x1_tr", n, flops, nb, need)
         if self.on_flush is not None:
             self.on_flush()
+
+    @staticmethod
+    def _run(go, phase, name, n, flops, nb, need):
+        if PROBE is None:
+            go()
+            return
+        try:                                   # contraction and partial-tile reduce under separate events
+            phase(1)
+            e0 = _probe_open(); go(); _probe_close(e0, name + "_kernel", flops, f"{n} layers", nb + need)
+            phase(2)
+            e0 = _probe_open(); go(); _probe_close(e0, name + "_reduce_kernel", 0.0, f"{n} layers", float(need))
+        finally:
+            phase(0)
 
 
 _WS = {}

@@ -50,6 +50,11 @@ SIGNATURES = {
     "mi_conv3x3_wgrad_tr": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P, _Z, _P],
     "mi_conv3x3_wgrad_tr_batch": [_I, C.POINTER(MiWgradDesc), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _Z, _P],
     "mi_debug_wgrad_tr_phase": [_I],
+    "mi_conv1x1_wgrad_tr_supported": [C.POINTER(MiWgradDesc), _I],
+    "mi_conv1x1_wgrad_tr_batch": [_I, C.POINTER(MiWgradDesc), C.POINTER(_I), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                                  C.POINTER(_P), _P, _Z, _P],
+    "mi_debug_wgrad1x1_tr_phase": [_I],
+    "mi_debug_wgrad1x1_tr_blocks": [_I],
     "mi_debug_wgrad_tr_blocks": [_I],
     "mi_conv3x3_bf16w_io": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
     "mi_conv3x3_wgrad_io": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _P, _P, _Z, _I, _P],
@@ -124,6 +129,7 @@ OTHER = {"mi_abi_version": ([], C.c_int), "mi_last_error": ([], C.c_char_p),
          "mi_conv3x3_wgrad_workspace": ([C.POINTER(MiWgradDesc)], C.c_size_t),
          "mi_conv3x3_wgrad_tr_workspace": ([C.POINTER(MiWgradDesc)], C.c_size_t),
          "mi_conv3x3_wgrad_tr_batch_workspace": ([_I, C.POINTER(MiWgradDesc)], C.c_size_t),
+         "mi_conv1x1_wgrad_tr_batch_workspace": ([_I, C.POINTER(MiWgradDesc), C.POINTER(_I)], C.c_size_t),
          "mi_conv_small_wgrad_workspace": ([_I], C.c_size_t)}
 ABI_VERSION = 1
 

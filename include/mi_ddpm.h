@@ -192,6 +192,18 @@ int mi_conv3x3_wgrad_tr(const MiWgradDesc* d, const void* P, const void* P2, con
 size_t mi_conv3x3_wgrad_tr_batch_workspace(int n, const MiWgradDesc* descs);
 int mi_conv3x3_wgrad_tr_batch(int n, const MiWgradDesc* descs, const void* const* P, const void* const* P2,
                               const void* const* Q, float* const* dW, void* workspace, size_t ws_bytes, void* stream);
+/* The 1x1 convolutions' weight gradients (to_qkv / to_out / res_conv, ddpm.py:134,151-152) the same way: dW[Ci][Cj] += X^T dY over
+ * all pixels, up to 8 layers per launch on shares of the workgroups proportional to the bytes they stream (these are HBM-bound).
+ * P / P2 are bf16 tensors; Q is bf16 (q_is_fp32[i] = 0) or the fp32 residual-stream gradient (1: rows are DMA'd raw and converted
+ * in LDS, and dbias[i] (optional) += column sums of Q -- the conv's bias gradient, replacing a separate mi_colsum pass).
+ * Needs N*H*W % 64 == 0, Ci % 64 == 0, I1 % 64 == 0, Cj % 32 == 0, ldp % 8 == 0, ldq % 8 (bf16) / % 4 (fp32) == 0. */
+int mi_conv1x1_wgrad_tr_supported(const MiWgradDesc* d, int q_is_fp32);
+size_t mi_conv1x1_wgrad_tr_batch_workspace(int n, const MiWgradDesc* descs, const int* q_is_fp32);
+int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const int* q_is_fp32, const void* const* P,
+                              const void* const* P2, const void* const* Q, float* const* dW, float* const* dbias,
+                              void* workspace, size_t ws_bytes, void* stream);
+int mi_debug_wgrad1x1_tr_phase(int phase);
+int mi_debug_wgrad1x1_tr_blocks(int blocks);
 /* measurement aid, as mi_debug_wgrad3x3_phase: 1 = contraction kernel only, 2 = reduce only, 0 = both */
 int mi_debug_wgrad_tr_phase(int phase);
 /* test aid: plan the k-slices for `blocks` workgroups instead of one per CU (0 = default) */

@@ -485,6 +485,43 @@ def test_conv3x3_wgrad_lds_dma(K, cfg):
         assert rel_err(dW2, dW / 2) < 2e-5
 
 
+def test_conv1x1_wgrad_queue(K):
+    """K.WgradQueue.push1x1: the 1x1 convs' weight gradients (to_qkv: bf16 dY; to_out / res_conv: fp32 stream gradient + fused bias
+    gradient; a two-source res_conv; a ragged co tile) batched into mi_conv1x1_wgrad_tr_batch launches, against fp64 on the same
+    bf16-rounded operands (fp32 dY is rounded to bf16 in LDS exactly like the register-staged kernel rounds it)."""
+    g = torch.Generator().manual_seed(47)
+    layers = [dict(N=8, H=32, Ci=128, Co=384, q32=False), dict(N=8, H=32, Ci=128, Co=128, q32=True, bias=True),
+              dict(N=8, H=16, Ci=256, Co=384, q32=False), dict(N=8, H=16, Ci=128, Co=256, q32=True, bias=True),
+              dict(N=8, H=8, Ci=1024, Co=256, q32=True, bias=True, split=512), dict(N=8, H=8, Ci=512, Co=384, q32=False),
+              dict(N=4, H=8, Ci=128, Co=96, q32=True, bias=True), dict(N=8, H=16, Ci=512, Co=128, q32=True, split=256),
+              dict(N=2, H=8, Ci=64, Co=32, q32=False), dict(N=8, H=8, Ci=128, Co=512, q32=True, bias=True)]
+    q = K.WgradQueue(group=8)
+    checks = []
+    for L in layers:
+        N, H, Ci, Co, split = L["N"], L["H"], L["Ci"], L["Co"], L.get("split")
+        x = torch.randn(N, Ci, H, H, generator=g).bfloat16()
+        dy = torch.randn(N, Co, H, H, generator=g)
+        dyq = dy.bfloat16()
+        wq = torch.zeros(Co, Ci, 1, 1, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x.double(), wq, None).backward(dyq.double())
+        nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+        P, P2 = (nh(x[:, :split]), nh(x[:, split:])) if split else (nh(x), None)
+        Q = nh(dy) if L["q32"] else nh(dyq)
+        dW = torch.zeros(Ci * Co, device=DEV)
+        db = torch.zeros(Co, device=DEV) if L.get("bias") else None
+        q.push1x1(P, Q, dW, Ci=Ci, Cj=Co, hw=(H, H), mode=1, P2=P2, dbias=db)
+        checks.append((dW, db, Ci, Co, wq.grad, dy.double().sum((0, 2, 3))))
+    assert q.flushed == 8 and q.pushed == 10
+    q.flush()
+    torch.cuda.synchronize()
+    assert q.flushed == 10
+    for dW, db, Ci, Co, ref, bref in checks:
+        got = dW.view(Ci, Co).t().cpu().double()
+        assert rel_err(got, ref.view(Co, Ci)) < 2e-5, (Ci, Co)
+        if db is not None:
+            assert rel_err(db, bref) < 1e-5, (Ci, Co)
+
+
 @pytest.mark.parametrize("group", [8, 3])
 def test_conv3x3_wgrad_queue_batches_layers(K, group):
     """K.WgradQueue: several Block convs' weight gradients in ONE launch (mi_conv3x3_wgrad_tr_batch), each on its share of the

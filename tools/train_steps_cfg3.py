@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""N training steps of cfg 3 (CelebA 64x64, hidden_dim 64, mults 1-2-4-8) at per-GPU batch B, timed (no profiler needed)."""
+"""N training steps of cfg 3 (CelebA 64x64, hidden_dim 64, mults 1-2-4-8) at per-GPU batch B, timed (no profiler needed).
+GRAPH=1: the step (training_step + backward + fused Adam with device-side step count) is captured once and replayed as one hipGraph
+(src/runtime/graphed.py) -- at B=32 (the per-GPU batch of BASELINE configs[2]: 256 images over 8 GPUs) the eager step is ~600
+launches of ~10 us kernels, i.e. bound by Python's enqueue rate."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "image-generation-models_amd")]
@@ -13,10 +16,24 @@ m = DDPM({"width": 64, "height": 64, "channels": 3, "transforms": {"normalize": 
 m.denoising_model.compute_mode = os.environ.get("MODE", "bf16"); m.train()
 opt = m.configure_optimizers()
 x = torch.rand(B, 3, 64, 64, device="cuda") * 2 - 1
+graph = os.environ.get("GRAPH", "0") == "1"
+if graph:
+    opt.device_state = True
 for i in range(3):
     loss = m.training_step((x, None), i); loss.backward(); opt.step()
+if graph:
+    from src.runtime.graphed import GraphedTrainStep
+    m.log = lambda *a, **k: None
+    gs = GraphedTrainStep(m, opt, (x, None), warmup=0)
+    step = lambda i: gs((x, None))
+else:
+    def step(i):
+        loss = m.training_step((x, None), i); loss.backward(); opt.step()
+        return loss
+for i in range(5):
+    step(i)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(n):
-    loss = m.training_step((x, None), i); loss.backward(); opt.step()
+    loss = step(i)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f"cfg3 B={B}: {dt / n * 1e3:.2f} ms/step, {B * n / dt:.0f} images/s, {B * n / dt * 26.278 / 1e3:.1f} TFLOP/s, loss {float(loss):.4f}")
+print(f"cfg3 B={B}{' hipGraph' if graph else ' eager'}: {dt / n * 1e3:.2f} ms/step, {B * n / dt:.0f} images/s, {B * n / dt * 26.278 / 1e3:.1f} TFLOP/s, loss {float(loss):.4f}")
