@@ -46,6 +46,7 @@ struct HaloArgs {
     int HP;              // halo pixels = TI*(TH+2)*(W+2)
     int tiles_per_img;   // H/TH when TI == 1
     int xmap;            // XCD-aware tile order (3x3, several row tiles per image, N % 8 == 0)
+    const float* coef;   // FUSE: [3][N][K] scale / shift / time bias of the GroupNorm + Mish applied to x while it is staged
 };
 
 // waves are arranged (WAVES/2) along M x 2 along N; a wave owns (MI*32) pixels x 64 channels
@@ -67,9 +68,15 @@ template <int BM, int WAVES = (BM == 256 ? 8 : 4)> struct HaloCfg {
 // load the compiler can count outstanding loads exactly (s_waitcnt vmcnt(N)); any conditional load makes
 // it drain the whole ring (vmcnt(0)) at every tap, which is what bounded the first version of this kernel.
 // IO bit 0: activations x / x2 are stored as bf16 (copied to LDS as they are); bit 1: y is written as bf16.
-template <int BM, int CK, int KS, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4)>
+// FUSE (north_star's named kernel): x is the RAW output of the previous conv; GroupNorm-apply + Mish (+ time bias),
+//     h = mish(x * scale[n][c] + shift[n][c]) + tb[n][c]      (reference ddpm.py:112-120,139-140),
+// is applied in registers between the global load and the LDS store of the halo tile, so the normalised tensor never exists in HBM.
+// The coefficients come from mi_gn_stats_coef; tiles must lie inside one image (TI == 1); zero padding stays zero (it is the
+// padding of h, not of x: the AND mask is applied after the transform).
+template <int BM, int CK, int KS, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4), bool FUSE = false>
 __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(const HaloArgs a) {
     constexpr bool IN16 = IO & 1, OUT16 = IO & 2;
+    static_assert(!FUSE || (KS == 3 && !SK), "fusion: 3x3 forward tiles only");
     static_assert(!(SK && OUT16), "split-K accumulates with fp32 atomics");
     static_assert(KS == 3 || CK == 32, "1x1: 32-channel stages");
     constexpr int BN = 128;
@@ -172,6 +179,15 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
 
     f32x4 ra[R][A_SL];
     u32x4 rb[R][B_IT];
+    // FUSE: coefficients of the chunk whose slices are being stored (this thread's channel quad), of image bx / tiles_per_img
+    f32x4 cf_s = {1.f, 1.f, 1.f, 1.f}, cf_b = {0.f, 0.f, 0.f, 0.f}, cf_t = {0.f, 0.f, 0.f, 0.f};
+    auto load_coef = [&](int ch) {
+        if constexpr (FUSE) {
+            const size_t NK = (size_t)a.N * a.K;
+            const float* c = a.coef + (size_t)(bx / a.tiles_per_img) * a.K + (size_t)(ch0 + ch) * CK + a_c4 * 4;
+            cf_s = *reinterpret_cast<const f32x4*>(c); cf_b = *reinterpret_cast<const f32x4*>(c + NK); cf_t = *reinterpret_cast<const f32x4*>(c + 2 * NK);
+        }
+    };
 
     // fetch slice `sl` of chunk `ch`'s halo tile (unconditional: padding slots read pixel 0 and are masked at the store)
     auto load_a = [&](f32x4 (&r)[A_SL], int ch, int sl) {
@@ -196,8 +212,21 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
         for (int j = 0; j < A_SL; ++j) {
             const int hp = min(a_hp0 + (sl * A_SL + j) * (NT / Q), MAXHP);   // MAXHP = dump row
             const uint32_t keep = ~(uint32_t)(pofs[sl][j] >> 31);
-            const u32x2 v = IN16 ? u32x2{__float_as_uint(r[j].x), __float_as_uint(r[j].y)}
-                                 : u32x2{pack_bf16(r[j].x, r[j].y), pack_bf16(r[j].z, r[j].w)};
+            u32x2 v;
+            if constexpr (FUSE) {
+                f32x4 x4;
+                if constexpr (IN16) {
+                    const uint32_t ux = __float_as_uint(r[j].x), uy = __float_as_uint(r[j].y);
+                    x4 = f32x4{__uint_as_float(ux << 16), __uint_as_float(ux & 0xffff0000u), __uint_as_float(uy << 16), __uint_as_float(uy & 0xffff0000u)};
+                } else {
+                    x4 = r[j];
+                }
+                const f32x4 z = x4 * cf_s + cf_b;
+                v = u32x2{pack_bf16(mish_fast_f(z.x) + cf_t.x, mish_fast_f(z.y) + cf_t.y), pack_bf16(mish_fast_f(z.z) + cf_t.z, mish_fast_f(z.w) + cf_t.w)};
+            } else {
+                v = IN16 ? u32x2{__float_as_uint(r[j].x), __float_as_uint(r[j].y)}
+                         : u32x2{pack_bf16(r[j].x, r[j].y), pack_bf16(r[j].z, r[j].w)};
+            }
             *reinterpret_cast<u32x2*>(&As[buf * ASZ + hp * PITCH + a_c4 * 4]) = u32x2{v.x & keep, v.y & keep};
         }
     };
@@ -249,6 +278,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     // and weights both ride R taps ahead.  LAST: nothing beyond this group is loaded or stored.
     auto group = [&](auto lastc, int gi) {
         constexpr bool LAST = decltype(lastc)::value;
+        if constexpr (FUSE && !LAST) load_coef(gi + 1);      // the slices stored during this group belong to chunk gi + 1
         static_for<0, TP>([&](auto tpc) {
             constexpr int tp = decltype(tpc)::value;
             if constexpr (KS == 3) {
@@ -299,6 +329,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
             load_b(rb[2], min(2, nchunks - 1), 0); load_a(ra[2], min(2, nchunks - 1), 0);
             load_b(rb[3], min(3, nchunks - 1), 0); load_a(ra[3], min(3, nchunks - 1), 0);
         }
+        load_coef(0);
 #pragma unroll
         for (int sl = 0; sl < NSL; ++sl) store_a(0, p0[sl], sl);
         store_b(0, b0);
@@ -409,18 +440,18 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     MI_TS(4);
 }
 
-template <int BM, int CK, int KS = 3, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4)>
+template <int BM, int CK, int KS = 3, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4), bool FUSE = false>
 void launch_halo(const HaloArgs& a, hipStream_t st) {
     constexpr int PITCH = CK + 8;
     constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
     size_t lds = (size_t)(2 * (MAXHP + 1) * PITCH + 2 * 128 * PITCH) * 2 + MAXHP * 4;
     dim3 grid((a.N * a.H * a.W + BM - 1) / BM, (a.Nc + 127) / 128, a.ksplit);
     static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES>), grid, dim3(HaloCfg<BM, WAVES>::NT), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE>), grid, dim3(HaloCfg<BM, WAVES>::NT), lds, st, a);
 }
 
 // fp32 [tap][k][n] master weights -> bf16 Wd[tap][k][n] (same layout) and Wf[tap][n][k] (transposed per tap)
@@ -654,6 +685,66 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
          else launch_halo<64, 32, 3, false, IOV>(a, st); } while (0)
     switch (io) { case 0: MI_HALO_GO(0); break; case 1: MI_HALO_GO(1); break; case 2: MI_HALO_GO(2); break; default: MI_HALO_GO(3); break; }
 #undef MI_HALO_GO
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- north_star's named kernel: GroupNorm-apply + Mish (+ time bias) fused into the 3x3 conv's input staging -------------------
+// Tile = the largest of 256 / 128 / 64 output pixels that lies inside ONE image and still fills the chip.
+static bool fused_plan(const MiConvDesc* d, int* bm, int* ck, int* th) {
+    if (d->KH != 3 || d->KW != 3 || d->pad != 1 || d->stride != 1 || d->mode != 1 || d->transposed) return false;
+    if (d->IH != d->OH || d->IW != d->OW || d->K1 != d->K || d->K % 32 || d->Nc % 4 || d->OW < 4 || d->OW > 64) return false;
+    const long M = (long)d->N * d->OH * d->OW, nt = (d->Nc + 127) / 128;
+    const int cand[3] = {256, 128, 64};
+    const long need[3] = {200, 400, 0};
+    int best = 0, bth = 0;
+    for (int c = 0; c < 3; ++c) {
+        int TH, TI;
+        if (!halo_geom(d, cand[c], &TH, &TI) || TI != 1) continue;
+        best = cand[c]; bth = TH;
+        if ((M + cand[c] - 1) / cand[c] * nt >= need[c]) break;
+    }
+    if (!best) return false;
+    *bm = best; *th = bth;
+    *ck = (d->K % 64 == 0 && (best == 256 || (best == 64 && (M + 63) / 64 * nt <= 256))) ? 64 : 32;
+    return true;
+}
+
+extern "C" int mi_conv3x3_gn_mish_supported(const MiConvDesc* d) {
+    int bm, ck, th;
+    return (d && fused_plan(d, &bm, &ck, &th)) ? 1 : 0;
+}
+
+// profiling attribution: conv3x3_halo_kernel<bm, ck, 3, false, io, waves, true>
+extern "C" int mi_conv3x3_gn_mish_tile(const MiConvDesc* d, int* bm, int* ck) {
+    int th;
+    MI_REQUIRE(d && bm && ck && fused_plan(d, bm, ck, &th), "descriptor not supported by the fused kernel");
+    return 0;
+}
+
+// y = conv3x3( mish(x * scale + shift) + tb ) + bias, with x the raw output of the previous conv (fp32 or bf16, io bit 0) and
+// coef = [3][N][K] from mi_gn_stats_coef.  io bit 1: y is written as bf16.  Only io 0 (fp32 -> fp32) and 3 (bf16 -> bf16) exist.
+extern "C" int mi_conv3x3_gn_mish(const MiConvDesc* d, const void* x, const float* coef, const void* w_nk_bf16, const float* bias,
+                                  void* y, int io, void* stream) {
+    MI_REQUIRE(d && x && coef && w_nk_bf16 && y && (io == 0 || io == 3), "bad argument (io 0 or 3)");
+    int BM, CK, TH;
+    MI_REQUIRE(fused_plan(d, &BM, &CK, &TH), "descriptor not supported by the fused GroupNorm+Mish+Conv3x3 kernel");
+    MI_REQUIRE(d->ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w_nk_bf16 | (uintptr_t)coef) & 15) == 0 && !d->accumulate, "alignment / accumulate");
+    HaloArgs a;
+    a.x = (const float*)x; a.x2 = a.x; a.w = (const uint16_t*)w_nk_bf16; a.bias = bias; a.res = nullptr; a.y = (float*)y;
+    a.N = d->N; a.H = d->OH; a.W = d->OW; a.K = d->K; a.Nc = d->Nc; a.K1 = d->K; a.ldx = d->ldx; a.ldx2 = d->ldx; a.ldy = d->ldy; a.ldr = 0;
+    a.accumulate = 0; a.flip = 0; a.ksplit = 1; a.coef = coef;
+    a.TH = TH; a.TI = 1; a.tiles_per_img = a.H / TH; a.HP = (TH + 2) * (a.W + 2);
+    a.xmap = a.tiles_per_img > 1 && a.N % 8 == 0;
+    hipStream_t st = (hipStream_t)stream;
+#define MI_FUSE_GO(IOV) \
+    do { if (BM == 256 && CK == 64) launch_halo<256, 64, 3, false, IOV, 8, true>(a, st); \
+         else if (BM == 256) launch_halo<256, 32, 3, false, IOV, 8, true>(a, st); \
+         else if (BM == 128) launch_halo<128, 32, 3, false, IOV, 4, true>(a, st); \
+         else if (CK == 64) launch_halo<64, 64, 3, false, IOV, 4, true>(a, st); \
+         else launch_halo<64, 32, 3, false, IOV, 4, true>(a, st); } while (0)
+    if (io == 0) MI_FUSE_GO(0); else MI_FUSE_GO(3);
+#undef MI_FUSE_GO
     MI_LAUNCH_CHECK();
     return 0;
 }

@@ -43,6 +43,7 @@ struct GnArgs {
     const float* x; const float* gamma; const float* beta; const float* temb; const float* res;
     float* y; float* stats;
     uint16_t* y16; int ldy16;      // optional second copy of y rounded to bf16 (the conv / weight-gradient operand of the next layer)
+    float* coef;                   // statistics-only mode: [3][N][C] = scale (rstd*gamma), shift (beta - mean*scale), time bias; no y
     int N, HW, C, G, Cg; float eps; int ldx, ldy, ldr, ldt;
     // backward
     const float* dout; float* dx; float* dgamma; float* dbeta; float* dtemb; float* dbias; int lddo, lddx;
@@ -114,6 +115,16 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
         ga[j] = a.gamma[c0 + j] * rstd;
         be[j] = a.beta[c0 + j] - mean * ga[j];
         tb[j] = a.temb ? a.temb[(size_t)n * a.ldt + c0 + j] : 0.f;
+    }
+    if (a.coef) {
+        // the apply step is folded into the consuming conv's staging (mi_conv3x3_gn_mish): hand it the per-(sample, channel)
+        // coefficients instead of writing y
+        if (pr == 0) {
+            const size_t NC = (size_t)a.N * a.C, o = (size_t)n * a.C + c0;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { a.coef[o + j] = ga[j]; a.coef[NC + o + j] = be[j]; a.coef[2 * NC + o + j] = tb[j]; }
+        }
+        return;
     }
     const size_t yoff = (size_t)n * a.HW * a.ldy + c0;
     const float* rb = a.res ? a.res + (size_t)n * a.HW * a.ldr + c0 : nullptr;
@@ -532,6 +543,22 @@ extern "C" int mi_gn_mish_fwd_dual(const MiGnDesc* d, const void* x, const float
         case 2: GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 2); break;
         default: GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 3); break;
     }
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+// Statistics only: stats[n][g] = {mean, rstd} as above, and coef[3][N][C] = {rstd*gamma, beta - mean*rstd*gamma, temb} -- what
+// mi_conv3x3_gn_mish needs to apply GroupNorm + Mish (+ time bias) while it stages its input.  One read of x, no y.
+extern "C" int mi_gn_stats_coef(const MiGnDesc* d, const void* x, const float* gamma, const float* beta, const float* temb, int ldt,
+                                float* stats, float* coef, int x_is_bf16, void* stream) {
+    MI_REQUIRE(x && gamma && beta && coef, "null argument");
+    GnArgs a{};
+    int vec, units;
+    int rc = gn_prepare(d, a, vec, units);
+    MI_REQUIRE(rc == 0 && vec == 4 && d->ldx % 4 == 0, "C/G must be a multiple of 4 (power of two <= 128), ldx % 4 == 0");
+    a.x = (const float*)x; a.gamma = gamma; a.beta = beta; a.temb = temb; a.ldt = ldt; a.stats = stats; a.coef = coef;
+    a.y = coef; a.ldy = d->C;      // unused
+    hipStream_t st = (hipStream_t)stream;
+    if (x_is_bf16) GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 1); else GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 0);
     MI_LAUNCH_CHECK();
     return 0;
 }

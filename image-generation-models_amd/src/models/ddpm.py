@@ -248,6 +248,11 @@ class Unet(nn.Module):
         # stream, attention path and every parameter/statistic stay fp32.  Measured on cfg 2 (B=128): bf16 12.8k,
         # auto 12.6k, fp32 12.5k images/s.
         self.block_storage = os.environ.get("MI_DDPM_STORAGE", "bf16")
+        # inference: fold GroupNorm-apply + Mish (+ time bias) into the following 3x3 conv's staging (mi_conv3x3_gn_mish, the
+        # fused kernel BASELINE.json names).  Off by default: with bf16 block storage the statistics pass it still needs
+        # (mi_gn_stats_coef) costs what the apply pass cost, and the sampler measured 671 vs 692 denoise steps/s at B=64
+        # (tools/sample_steps.py); with fp32 storage the fused unit is 65.6 us against 86.3 us in two passes (bench.py named_kernel).
+        self.fuse_gn_conv = os.environ.get("MI_DDPM_FUSE_GN", "0") == "1"
         self.accumulate_grads = False
         self.grad_ready_hook = None        # callable(lo, hi): flat_grads[lo:hi) is final (set by the DDP reducer)
 
@@ -445,7 +450,9 @@ class Unet(nn.Module):
         # can take their operands by LDS-DMA).  A ResnetBlock output is copied by the GroupNorm kernel that writes it
         # (want16), everything else by mi_f32_to_bf16 on first use.
         sh: Dict[int, tuple] = {}          # id(tensor) -> (tensor, copy): holding the tensor keeps its id from being reused
-        use_sh = mode == K.MODE_BF16 and self.block_storage in ("bf16", "auto") and os.environ.get("MI_DDPM_SHADOW", "1") == "1"
+        # (training only: in inference there is no weight gradient to feed and the copies cost 2.5 % of a denoise step)
+        use_sh = (record and mode == K.MODE_BF16 and self.block_storage in ("bf16", "auto")
+                  and os.environ.get("MI_DDPM_SHADOW", "1") == "1")
 
         def shadow(t):
             ent = sh.get(id(t))
@@ -495,9 +502,18 @@ class Unet(nn.Module):
                 inp_c, x2_c = shadow(inp), (shadow(x2) if x2 is not None else None)
             c1 = conv(inp_c, pre + "block1.block.0.", 3, 1, 1, x2=x2_c, out_dtype=BF if c1_16 else torch.float32)
             tb = tb_all[:, blk["tcol"]:blk["tcol"] + co]
-            h1, st1 = K.gn_mish_fwd(c1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], temb=tb,
-                                    out_dtype=BF if lo16 else torch.float32)
-            c2 = conv(h1, pre + "block2.block.0.", 3, 1, 1, out_dtype=BF if lo16 else torch.float32)
+            c2 = None
+            if (not record and mode == K.MODE_BF16 and self.fuse_gn_conv and c1.dtype == (BF if lo16 else torch.float32)
+                    and K.conv3x3_gn_mish_supported(B, inp.shape[1], inp.shape[2], co, co)):
+                # inference / sampling: GroupNorm-apply + Mish + time bias ride in block2's conv staging (the named fused kernel);
+                # h1 is never materialised.  Training keeps h1: the weight gradient of block2's conv reads it.
+                st1, coef = K.gn_stats_coef(c1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], temb=tb)
+                c2 = K.conv3x3_gn_mish(c1, coef, wf_sh[offs[pre + "block2.block.0.weight"]:], K=co, Nc=co, bias=sv[pre + "block2.block.0.bias"])
+                h1 = None
+            if c2 is None:
+                h1, st1 = K.gn_mish_fwd(c1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], temb=tb,
+                                        out_dtype=BF if lo16 else torch.float32)
+                c2 = conv(h1, pre + "block2.block.0.", 3, 1, 1, out_dtype=BF if lo16 else torch.float32)
             r = conv(inp, pre + "res_conv.", 1, x2=x2) if blk["res"] else inp
             if want_out16 and use_sh and co % 32 == 0:
                 out, st2, out16 = K.gn_mish_fwd(c2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], residual=r, want16=True)

@@ -158,6 +158,54 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
     return out
 
 
+def gn_stats_coef(x, gamma, beta, *, groups=8, eps=1e-5, temb=None):
+    """GroupNorm statistics of x only: -> (stats [N,G,2] = mean, rstd; coef [3,N,C] = scale, shift, time bias) for
+    conv3x3_gn_mish, which applies GroupNorm + Mish (+ time bias) while it stages its input (ddpm.py:112-120,139-140)."""
+    _need_gpu(x)
+    N, H, W, Cc = x.shape
+    stats = torch.empty((N, groups, 2), device=x.device, dtype=torch.float32)
+    coef = torch.empty((3, N, Cc), device=x.device, dtype=torch.float32)
+    d = MiGnDesc(N=N, HW=H * W, C=Cc, G=groups, eps=eps, ldx=ld_of(x), ldy=Cc, ldr=0)
+    e0 = _probe_open()
+    check(load_library().mi_gn_stats_coef(C.byref(d), _p(x), _p(gamma), _p(beta), _p(temb), ld_of(temb) if temb is not None else 0,
+                                          _p(stats), _p(coef), _b16(x), _stream()), "mi_gn_stats_coef")
+    if e0 is not None:
+        _probe_close(e0, f"gn_mish_fwd_kernel<io{_b16(x)}> (statistics only)", 0.0, f"N{N} HW{H * W} C{Cc}", N * H * W * Cc * _esz(x))
+    return stats, coef
+
+
+def conv3x3_gn_mish_supported(N, H, W, K, Nc):
+    d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=MODE_BF16, K1=K,
+                   ldx=K, ldx2=K, ldy=Nc, ldr=0, accumulate=0)
+    return bool(load_library().mi_conv3x3_gn_mish_supported(C.byref(d)))
+
+
+def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None):
+    """The fused kernel BASELINE.json names: y = conv3x3(mish(x * scale + shift) + tb) + bias with x the RAW previous conv output
+    (fp32 -> fp32 y, or bf16 -> bf16 y), coef from gn_stats_coef.  Returns None when the shape is not supported."""
+    _need_gpu(x)
+    N, H, W, _ = x.shape
+    d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=MODE_BF16, K1=K,
+                   ldx=ld_of(x), ldx2=ld_of(x), ldy=Nc, ldr=0, accumulate=0)
+    lib = load_library()
+    if not lib.mi_conv3x3_gn_mish_supported(C.byref(d)):
+        return None
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    if out_dtype != x.dtype:
+        raise RuntimeError("the fused kernel writes y in x's storage type (fp32 -> fp32 or bf16 -> bf16)")
+    y = new_act(N, H, W, Nc, x, out_dtype)
+    io = 3 if x.dtype == torch.bfloat16 else 0
+    e0 = _probe_open()
+    check(lib.mi_conv3x3_gn_mish(C.byref(d), _p(x), _p(coef), _p(wsh), _p(bias), _p(y), io, _stream()), "mi_conv3x3_gn_mish")
+    if e0 is not None:
+        bm, ck = C.c_int(), C.c_int()
+        lib.mi_conv3x3_gn_mish_tile(C.byref(d), C.byref(bm), C.byref(ck))
+        _probe_close(e0, f"conv3x3_halo_kernel<{bm.value}, {ck.value}, 3, false, {io}, {8 if bm.value == 256 else 4}, true>",
+                     2.0 * N * H * W * Nc * K * 9, f"N{N} {H}x{W} K{K}->{Nc} fused GN+Mish",
+                     N * H * W * (K * _esz(x) + Nc * _esz(y)) + 9 * K * Nc * 2)
+    return y
+
+
 def pack_weights_bf16(table_dev, nent, total_tiles, master, wd, wf):
     e0 = _probe_open()
     check(load_library().mi_pack_weights_bf16(nent, _p(table_dev), total_tiles, _p(master), _p(wd), _p(wf), _stream()),

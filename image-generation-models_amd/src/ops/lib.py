@@ -63,6 +63,10 @@ SIGNATURES = {
     "mi_f32_to_bf16": [_Z, _I, _P, _I, _P, _I, _P],
     "mi_gn_mish_bwd_io": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P],
     "mi_pack_weights_bf16": [_I, _P, _I, _P, _P, _P, _P],
+    "mi_gn_stats_coef": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    "mi_conv3x3_gn_mish_supported": [C.POINTER(MiConvDesc)],
+    "mi_conv3x3_gn_mish_tile": [C.POINTER(MiConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "mi_conv3x3_gn_mish": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _P],
     "mi_conv3x3_small_cin_fwd": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P],
     "mi_conv3x3_small_cin_wgrad": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P],
     "mi_conv1x1_small_cout": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],

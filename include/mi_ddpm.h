@@ -95,6 +95,18 @@ int mi_conv3x3_bf16w_tile(const MiConvDesc* d, int io, int* bm, int* ck, int* sk
  * elements.  3x3 and 1x1; with bit 1 the split-K variant (fp32 atomics) is not used. */
 int mi_conv3x3_bf16w_io(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16,
                         const float* bias, const float* residual, void* y, int io, void* stream);
+/* ---- the fused GroupNorm-apply + Mish (+ time bias) + Conv3x3 kernel (BASELINE.json's named kernel) -------------------------
+ * ResnetBlock: h = block1(x) = mish(GN(conv(x))); h += mlp(t); h = block2(h) (ddpm.py:112-120,136-143).  Here block2's conv
+ * reads the RAW output c1 of block1's conv and applies  mish(c1 * scale[n][c] + shift[n][c]) + tb[n][c]  in registers while it
+ * stages its halo tile, so the normalised tensor is never written to or read from HBM.  coef = [3][N][K] (scale = rstd*gamma,
+ * shift = beta - mean*scale, tb = the block's time bias) comes from mi_gn_stats_coef, a statistics-only pass over c1 that also
+ * writes stats[n][g] = {mean, rstd}.  Forward / sampling path; tiles lie inside one image.  io: 0 = fp32 c1 -> fp32 y, 3 = bf16 ->
+ * bf16 (the block-internal storage of bf16 mode). */
+/* (mi_gn_stats_coef is declared with the GroupNorm entry points below) */
+int mi_conv3x3_gn_mish_supported(const MiConvDesc* d);
+int mi_conv3x3_gn_mish_tile(const MiConvDesc* d, int* bm, int* ck);
+int mi_conv3x3_gn_mish(const MiConvDesc* d, const void* x, const float* coef, const void* w_nk_bf16, const float* bias,
+                       void* y, int io, void* stream);
 /* bf16 shadow copies of every conv weight of the flat fp32 parameter buffer (master layout
  * [tap][Cin][Cout] at float offset `off`): wd = same layout, wf = [tap][Cout][Cin].
  * entries_dev: device array of {int64 off; int32 taps, ci, co, tile0}, tile0 = first 32x32-tile
@@ -244,6 +256,9 @@ int mi_gn_mish_fwd_io(const MiGnDesc* d, const void* x, const float* gamma, cons
 int mi_gn_mish_fwd_dual(const MiGnDesc* d, const void* x, const float* gamma, const float* beta,
                         const float* temb, int ldt, const float* residual, void* y, void* y16, int ldy16,
                         float* stats, int io, void* stream);
+/* statistics-only pass for the fused conv above */
+int mi_gn_stats_coef(const MiGnDesc* d, const void* x, const float* gamma, const float* beta, const float* temb, int ldt,
+                     float* stats, float* coef, int x_is_bf16, void* stream);
 int mi_gn_mish_bwd_io(const MiGnDesc* d, const void* x, const float* stats, const float* gamma, const float* beta,
                       const void* dout, int lddo, void* dx, int lddx, float* dgamma, float* dbeta, float* dtemb,
                       int ldt, float* dbias, int io, void* stream);

@@ -165,6 +165,50 @@ def _mish64(x):
     return x * torch.tanh(F.softplus(x))
 
 
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+@pytest.mark.parametrize("cfg", [(16, 32, 32, 128, 128), (8, 16, 16, 256, 256), (16, 8, 8, 512, 512), (8, 16, 16, 128, 256),
+                                 (2, 64, 64, 64, 64), (3, 32, 32, 128, 96)])
+def test_fused_gn_mish_conv3x3(K, cfg, storage):
+    """BASELINE.json's named kernel: GroupNorm-apply + Mish (+ time bias) folded into the 3x3 conv's input staging
+    (mi_gn_stats_coef + mi_conv3x3_gn_mish; reference ddpm.py:112-120,139-140 Block -> time bias -> Block's conv) against
+    (a) an fp64 evaluation of GroupNorm -> Mish -> + temb -> Conv2d on the same stored c1 and bf16-rounded weights, and
+    (b) the two-pass path of this library (gn_mish_fwd, then the plain conv): the fused kernel must agree with it to bf16 rounding."""
+    N, H, W, Cc, Co = cfg
+    g = torch.Generator().manual_seed(61)
+    dt = torch.bfloat16 if storage == "bf16" else torch.float32
+    c1 = (torch.randn(N, Cc, H, W, generator=g) * 1.7 + 0.3).to(dt)
+    gamma, beta = torch.randn(Cc, generator=g) * 0.5 + 1, torch.randn(Cc, generator=g) * 0.2
+    temb = torch.randn(N, Cc, generator=g) * 0.3
+    w = torch.randn(Co, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc)
+    bias = torch.randn(Co, generator=g) * 0.1
+    wq = w.bfloat16()
+    x64 = c1.double()
+    hn = F.group_norm(x64, 8, gamma.double(), beta.double(), 1e-5)
+    h = _mish64(hn) + temb.double()[:, :, None, None]
+    ref = F.conv2d(h, wq.double(), bias.double(), padding=1)
+    xg = c1.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wsh = wq.permute(2, 3, 0, 1).contiguous().to(DEV).reshape(-1)            # [ky][kx][Co][Ci]
+    assert K.conv3x3_gn_mish_supported(N, H, W, Cc, Co)
+    stats, coef = K.gn_stats_coef(xg, gamma.to(DEV), beta.to(DEV), temb=temb.to(DEV))
+    y = K.conv3x3_gn_mish(xg, coef, wsh, K=Cc, Nc=Co, bias=bias.to(DEV))
+    assert y is not None and y.dtype == dt
+    h1, st2 = K.gn_mish_fwd(xg, gamma.to(DEV), beta.to(DEV), temb=temb.to(DEV), out_dtype=dt)
+    y2 = K.conv3x3_bf16w(h1, wsh, K=Cc, Nc=Co, flip=False, bias=bias.to(DEV), out_dtype=dt)
+    torch.cuda.synchronize()
+    assert torch.allclose(stats, st2, rtol=1e-6, atol=1e-7)                  # same statistics kernel
+    mean = x64.view(N, 8, -1).mean(-1)
+    assert torch.allclose(stats[..., 0].cpu().double(), mean, atol=2e-5)
+    got = y.float().cpu().permute(0, 3, 1, 2).double()
+    two = y2.float().cpu().permute(0, 3, 1, 2).double()
+    # h is rounded to bf16 before the MFMA in both paths (2^-9 relative per element, averaged over 9*C products)
+    assert rel_err(got, ref) < (4e-3 if storage == "fp32" else 6e-3)
+    assert rel_err(got, two) < (2e-3 if storage == "fp32" else 5e-3)
+    if storage == "fp32":
+        # the two paths round the same h values (the two-pass path stores h in fp32 and rounds it in the conv's staging; only the
+        # reciprocal-based Mish of the fused path differs): nearly identical
+        assert rel_err(got, two) < 1e-3
+
+
 @pytest.mark.parametrize("cfg", [(2, 8, 8, 8), (2, 8, 8, 16), (3, 16, 16, 32), (2, 32, 32, 128), (2, 8, 8, 512),
                                  (2, 7, 7, 64), (1, 64, 64, 64), (2, 16, 16, 1024)])
 def test_gn_mish_fwd_bwd(K, cfg):

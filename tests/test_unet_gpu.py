@@ -330,6 +330,25 @@ def test_sampler_T1000_golden(golden_dir, case, hw):
     assert errs["bf16_final_rel_l2"] < 1e-2, errs                                                # measured 4.0e-3 / 4.9e-3
 
 
+def test_fused_eval_path_matches_two_pass(golden_dir):
+    """Inference with GroupNorm-apply + Mish folded into block2's conv (the default in eval) against the two-pass path, cfg 2 at
+    B = 16, bf16 mode: same epsilon prediction up to bf16 rounding, and both within the bf16 bar of the reference's output."""
+    g = _load(golden_dir, "cfg2_unet.npz")
+    net = _seeded(128, (1, 2, 4), "bf16").eval()
+    x = _t(g["x"]).repeat(8, 1, 1, 1).to(DEV); t = _t(g["t"]).repeat(8).to(DEV)
+    from src.models.ddpm import GaussianDiffusion
+    gd = GaussianDiffusion(net, image_size=(32, 32), timesteps=1000).to(DEV)
+    xn = gd.q_sample(x, t, _t(g["noise"]).repeat(8, 1, 1, 1).to(DEV))
+    with torch.no_grad():
+        net.fuse_gn_conv = True
+        y1 = net(xn, t)
+        net.fuse_gn_conv = False
+        y2 = net(xn, t)
+    e12, e1, e2 = rel_err(y1, y2), rel_err(y1[:2], _t(g["eps_hat"])), rel_err(y2[:2], _t(g["eps_hat"]))
+    record("cfg2_fused_eval_vs_two_pass_bf16", fused_vs_two_pass_rel_l2=e12, fused_vs_reference_rel_l2=e1, two_pass_vs_reference_rel_l2=e2)
+    assert e12 < 2e-2 and e1 < 2e-2 and e2 < 2e-2
+
+
 def test_graph_sampler_matches_eager():
     """hipGraph-replayed denoise iterations == the eager loop on the same noise tape."""
     from src.models.ddpm import GaussianDiffusion

@@ -8,6 +8,7 @@ from src.ops import functional as K
 which, B, H, Ci, Co = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 DT = torch.bfloat16 if len(sys.argv) > 6 and sys.argv[6] == "bf16" else torch.float32     # activation storage
 DEV = "cuda"
+H, Ci, Co = max(H, 8), max(Ci, 64), max(Co, 64)
 x = torch.randn(B, H, H, Ci, device=DEV).to(DT); w = torch.randn(3, 3, Ci, Co, device=DEV) * 0.05
 dy = torch.randn(B, H, H, Co, device=DEV).to(DT)
 wd = w.to(torch.bfloat16).reshape(-1); wf = w.permute(0, 1, 3, 2).contiguous().to(torch.bfloat16).reshape(-1)
@@ -15,6 +16,22 @@ y = torch.empty(B, H, H, Co, device=DEV, dtype=DT); dW = torch.zeros(9 * Ci * Co
 for _ in range(5):
     if which == "wgrad":
         K.conv_wgrad(x, dy, dW, kh=3, kw=3, stride=1, pad=1, gather_i=True, Ci=Ci, Cj=Co, grid_g=(H, H), grid_d=(H, H), mode=1)
+    elif which == "wgradq":
+        # the eight Block-conv weight gradients of a backward pass's first group in ONE launch (K.WgradQueue), cfg-2 shapes
+        if "Q8" not in globals():
+            Q8 = []
+            for (h, ci, co) in [(32, 128, 128)] * 4 + [(16, 256, 256)] * 2 + [(16, 512, 128), (16, 256, 256)]:
+                Q8.append((torch.randn(B, h, h, ci, device=DEV).bfloat16(), torch.randn(B, h, h, co, device=DEV).bfloat16(),
+                           torch.zeros(9 * ci * co, device=DEV), h, ci, co))
+        q = K.WgradQueue(group=8)
+        for (xx, dd, ww, h, ci, co) in Q8:
+            q.push(xx, dd, ww, Ci=ci, Cj=co, hw=(h, h), mode=1)
+        q.flush()
+    elif which == "fused":
+        if "COEF" not in globals():
+            gam = torch.ones(Ci, device=DEV); bet = torch.zeros(Ci, device=DEV); tb = torch.randn(B, Ci, device=DEV) * 0.1
+            _, COEF = K.gn_stats_coef(x, gam, bet, temb=tb)
+        K.conv3x3_gn_mish(x, COEF, wf, K=Ci, Nc=Co, bias=None)
     elif which == "halo":
         K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, out=y)
     elif which == "igemm":

@@ -1,26 +1,31 @@
 #!/bin/bash
 # Everything profiles/ needs for one round, run on the GPU box:  tools/profile_round.sh <tag>
 #  1. rocprofv3 --kernel-trace --stats of the default bench.py command (+ its JSON line)
-#  2. the same over 10 bare training steps (per-kernel ms/step)
-#  3. PMC passes (separate runs, never combined with trace domains other than --kernel-trace) for the two dominant
-#     kernels on the level-0 shape: HBM traffic (FETCH_SIZE / WRITE_SIZE) and the SQ / TCC sets of tools/pmc.sh
-tag=${1:-r01}
+#  2. the same over 10 bare training steps (per-kernel ms/step), and over cfg 3 at B=32
+#  3. PMC passes (separate runs, never combined with trace domains other than --kernel-trace): HBM traffic (FETCH_SIZE /
+#     WRITE_SIZE) of the dominant kernels on their cfg-2 shapes and the SQ / TCC sets of tools/pmc.sh
+tag=${1:-r02}
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $OUT
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_b -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 > $OUT/bench_stdout.txt 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_b -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_stdout.txt 2>/dev/null
 cp /tmp/prof_b/*kernel_stats.csv $OUT/bench_kernel_stats.csv
-tail -1 $OUT/bench_stdout.txt > $OUT/bench.json
+tail -1 $OUT/bench_stdout.txt > $OUT/bench_under_rocprof.json
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_t -o t -- python $GRAFT_REPO_ROOT/tools/train_steps.py 10 > /dev/null 2>&1
 cp /tmp/prof_t/*kernel_stats.csv $OUT/train_step_kernel_stats.csv
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_c -o c -- python $GRAFT_REPO_ROOT/tools/train_steps_cfg3.py 10 32 > /dev/null 2>&1
+cp /tmp/prof_c/*kernel_stats.csv $OUT/cfg3_b32_kernel_stats.csv
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_s -o s -- python $GRAFT_REPO_ROOT/tools/sample_steps.py 40 > /dev/null 2>&1
+cp /tmp/prof_s/*kernel_stats.csv $OUT/denoise_kernel_stats.csv
 cd $GRAFT_REPO_ROOT
-for cfg in "halo 128 32 128 128 bf16" "halo 128 32 128 128 fp32" "wgrad 128 32 128 128 bf16" "wgrad 128 32 128 128 fp32" "halo 128 16 256 256 bf16" "halo 128 8 512 512 bf16" "halo 128 8 1024 256 bf16"; do
+for cfg in "halo 128 8 512 512 bf16" "halo 128 32 128 128 bf16" "halo 128 32 128 128 fp32" "wgrad 128 32 128 128 bf16" "wgrad 128 8 512 512 bf16" "wgradq 128 0 0 0 bf16" "fused 128 32 128 128 bf16" "fused 128 32 128 128 fp32"; do
   name=$(echo $cfg | tr ' ' '_')
   timeout 400 bash tools/pmc_traffic.sh ${tag}_$name $cfg > $OUT/pmc_traffic_$name.txt 2>&1
 done
-for cfg in "halo 128 32 128 128 bf16" "wgrad 128 32 128 128 bf16"; do
+for cfg in "halo 128 8 512 512 bf16" "wgrad 128 32 128 128 bf16" "wgradq 128 0 0 0 bf16"; do
   name=$(echo $cfg | tr ' ' '_')
   timeout 400 bash tools/pmc.sh ${tag}_$name $cfg > $OUT/pmc_sq_$name.txt 2>&1
 done
+python bench.py > $OUT/bench.json 2> /dev/null
 ls -la $OUT

@@ -12,7 +12,12 @@ torch.manual_seed(0)
 m = DDPM({"width": 32, "height": 32, "channels": 3, "transforms": {"normalize": True}}, hidden_dim=128, dim_mults=(1, 2, 4)).to("cuda")
 m.denoising_model.compute_mode = os.environ.get("MODE", "bf16"); m.eval()
 gs = GraphSampler(m.diffusion_model, (B, 3, 32, 32)); gs._capture()
+import time
 gs.x.normal_(); gs.t.fill_(999)
+for _ in range(5):
+    gs.z.normal_(); gs.graph.replay()
+torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(n):
     gs.z.normal_(); gs.graph.replay()
-torch.cuda.synchronize()
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f"B={B} fuse_gn={os.environ.get('MI_DDPM_FUSE_GN', '1')} shadow={os.environ.get('MI_DDPM_SHADOW', '1')}: {n / dt:.1f} denoise steps/s ({dt / n * 1e3:.3f} ms/step)")
