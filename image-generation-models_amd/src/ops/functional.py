@@ -20,6 +20,11 @@ PROBE = None      # bench.py sets this to a list: (kernel symbol, algorithmic FL
                   # HBM bytes) per launch, events recorded on the launch stream
 
 
+# The LDS-DMA 3x3 conv kernel (csrc/conv_dma.hip) is opt-in: measured against the register-staged halo kernel on the cfg-2 shapes
+# (tools/bench_dma_conv.py, B=128, bf16 in/out) it is 3-6 % faster on the 8x8 level (512->512: 41.5 vs 44.2 us) and 15 % slower on
+# the 32x32 / 16x16 levels (128->128: 62.5 vs 53.7 us): with one 64x64 tile per wave both kernels move 1 KB of LDS per MFMA and the
+# DMA writes share the LDS port with the fragment reads.
+USE_CONV_DMA = os.environ.get("MI_CONV_DMA", "0") == "1"
 USE_WGRAD_TR = os.environ.get("MI_W3_TR", "1") != "0"      # A/B switch for the LDS-DMA weight-gradient kernel (csrc/wgrad_tr.hip)
 
 
@@ -140,6 +145,15 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
     d.ldy = ld_of(out)
     io = _b16(x) | (_b16(out) << 1)
     assert x2 is None or x2.dtype == x.dtype
+    if USE_CONV_DMA and ksize == 3 and _b16(x) and lib.mi_conv3x3_dma_supported(C.byref(d)):
+        # bf16-stored activations: the LDS-DMA kernel (conv_dma.hip)
+        e0 = _probe_open()
+        check(lib.mi_conv3x3_dma(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv3x3_dma")
+        if e0 is not None:
+            nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 2)
+            _probe_close(e0, f"conv_dma_kernel<{'true' if _b16(out) else 'false'}>", 2.0 * N * H * W * Nc * K * 9,
+                         f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
+        return out
     e0 = _probe_open()
     if io:
         check(lib.mi_conv3x3_bf16w_io(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), io, _stream()),
