@@ -25,6 +25,7 @@ struct TrArgs {
     int gx, gy;         // ci tiles (64), co tiles (128)
     int wg0;            // first workgroup of this problem in the launch
     int tile0;          // first tile of this problem in the reduce launch
+    int xcd_map;        // workgroup -> (k-slice, tile) such that the tiles of a k-slice share an XCD
 };
 constexpr int MAXP = 8;
 // One launch = up to MAXP independent weight-gradient problems, each on its own share of the workgroups.  A layer's partial-tile

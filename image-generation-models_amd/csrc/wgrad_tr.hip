@@ -62,7 +62,14 @@ __device__ __forceinline__ void wgrad_tr_body(const TrArgs& a, const int wg, uin
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wi = wv >> 2, wj = wv & 3;             // 2 ci halves x 4 co quarters
     const int ntiles = a.gx * a.gy;
-    const int split = wg / ntiles, tile = wg - split * ntiles;
+    // k-slice and tile of this workgroup.  The tiles of one k-slice read the same X / dY rows; consecutive workgroup ids go to
+    // different XCDs (id % 8), each with its own L2 -- when the slices divide evenly, ids xcd + 8*slot with slot = tile + ntiles*m
+    // belong to slice xcd + 8*m, so that one L2 serves all tiles of a slice (the problem starts at a multiple of 8: host).
+    int split = wg / ntiles, tile = wg - split * ntiles;
+    if (a.xcd_map) {
+        const int xcd = wg & 7, slot = wg >> 3;
+        tile = slot % ntiles; split = xcd + 8 * (slot / ntiles);
+    }
     const int ci0 = (tile % a.gx) * 64, co0 = (tile / a.gx) * 128;
     const int sb = split * a.sps, se = min(a.total, sb + a.sps);
 
@@ -384,6 +391,8 @@ extern "C" int mi_conv3x3_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         a.ldp = descs[i].ldp; a.ldp2 = (P2 && P2[i]) ? descs[i].ldp2 : descs[i].ldp; a.ldq = descs[i].ldq;
         a.ws = (float*)workspace + off;
         off += tr_ws_floats(a);
+        static const int xcd_env = [] { const char* e = getenv("MI_WTR_XCD"); return e ? atoi(e) : 1; }();
+        a.xcd_map = xcd_env && a.splits % 8 == 0 && a.gx * a.gy > 1 && wg % 8 == 0;
         a.wg0 = wg; wg += a.gx * a.gy * a.splits;
         a.tile0 = tile; if (a.splits > 1) tile += a.gx * a.gy;
         if (a.splits > max_splits) max_splits = a.splits;

@@ -25,6 +25,7 @@ PROBE = None      # bench.py sets this to a list: (kernel symbol, algorithmic FL
 # the 32x32 / 16x16 levels (128->128: 62.5 vs 53.7 us): with one 64x64 tile per wave both kernels move 1 KB of LDS per MFMA and the
 # DMA writes share the LDS port with the fragment reads.
 USE_CONV_DMA = os.environ.get("MI_CONV_DMA", "0") == "1"
+USE_CONV_SHIFT = os.environ.get("MI_CONV_SHIFT", "1") != "0"   # the LDS-frugal 3x3 conv kernel (csrc/conv_shift.hip)
 USE_WGRAD_TR = os.environ.get("MI_W3_TR", "1") != "0"      # A/B switch for the LDS-DMA weight-gradient kernel (csrc/wgrad_tr.hip)
 
 
@@ -145,6 +146,17 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
     d.ldy = ld_of(out)
     io = _b16(x) | (_b16(out) << 1)
     assert x2 is None or x2.dtype == x.dtype
+    if USE_CONV_SHIFT and ksize == 3 and _b16(x) and lib.mi_conv3x3_shift_supported(C.byref(d)):
+        # bf16-stored activations: the LDS-frugal kernel (conv_shift.hip)
+        e0 = _probe_open()
+        check(lib.mi_conv3x3_shift(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv3x3_shift")
+        if e0 is not None:
+            ni = C.c_int()
+            lib.mi_conv3x3_shift_tile(C.byref(d), C.byref(ni))
+            nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 2)
+            _probe_close(e0, f"conv_shift_kernel<{ni.value}, {'true' if _b16(out) else 'false'}>", 2.0 * N * H * W * Nc * K * 9,
+                         f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
+        return out
     if USE_CONV_DMA and ksize == 3 and _b16(x) and lib.mi_conv3x3_dma_supported(C.byref(d)):
         # bf16-stored activations: the LDS-DMA kernel (conv_dma.hip)
         e0 = _probe_open()

@@ -64,6 +64,9 @@ SIGNATURES = {
     "mi_gn_mish_bwd_io": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P],
     "mi_pack_weights_bf16": [_I, _P, _I, _P, _P, _P, _P],
     "mi_conv3x3_dma_supported": [C.POINTER(MiConvDesc)],
+    "mi_conv3x3_shift_supported": [C.POINTER(MiConvDesc)],
+    "mi_conv3x3_shift_tile": [C.POINTER(MiConvDesc), C.POINTER(C.c_int)],
+    "mi_conv3x3_shift": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
     "mi_conv3x3_dma": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
     "mi_gn_stats_coef": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _I, _P, _P, _I, _P],
     "mi_conv3x3_gn_mish_supported": [C.POINTER(MiConvDesc)],

@@ -113,6 +113,13 @@ int mi_conv3x3_gn_mish(const MiConvDesc* d, const void* x, const float* coef, co
 int mi_conv3x3_dma_supported(const MiConvDesc* d);
 int mi_conv3x3_dma(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16, const float* bias,
                    const float* residual, void* y, int out_bf16, void* stream);
+/* ... and the LDS-frugal variant (conv_shift.hip): a wave owns 128 pixels x 64 channels and derives the left / right tap columns'
+ * activation fragments from the centre column's by one-lane DPP shifts, 0.4 KB of LDS per MFMA instead of 1 KB.  Same arguments.
+ * Needs W in {8, 16, 32} with 256-pixel row tiles (N*H*W % 256 == 0), K % 64 == 0, K1 % 64 == 0. */
+int mi_conv3x3_shift_supported(const MiConvDesc* d);
+int mi_conv3x3_shift_tile(const MiConvDesc* d, int* ni);
+int mi_conv3x3_shift(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16, const float* bias,
+                     const float* residual, void* y, int out_bf16, void* stream);
 /* bf16 shadow copies of every conv weight of the flat fp32 parameter buffer (master layout
  * [tap][Cin][Cout] at float offset `off`): wd = same layout, wf = [tap][Cout][Cin].
  * entries_dev: device array of {int64 off; int32 taps, ci, co, tile0}, tile0 = first 32x32-tile

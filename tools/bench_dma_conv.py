@@ -27,11 +27,10 @@ for H, Ci, Co in [(32, 128, 128), (16, 128, 256), (16, 256, 256), (16, 512, 128)
     fl = 2.0 * B * H * H * Ci * Co * 9
     line = f"{H}x{H} {Ci}->{Co}:"
     for name, out in (("bf16 out", y16), ("fp32 out", y32)):
-        res = {False: [], True: []}
+        res = {"halo": [], "dma": [], "shift": []}
         for rnd in range(3):
-            for dma in (False, True):
-                K.USE_CONV_DMA = dma
-                res[dma].append(timed(lambda: K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, out=out)))
-        a, b = sorted(res[False])[1], sorted(res[True])[1]
-        line += f"  [{name}] halo {a:.1f}us {fl / a / 1e6:.0f}TF | dma {b:.1f}us {fl / b / 1e6:.0f}TF"
+            for which in res:
+                K.USE_CONV_DMA, K.USE_CONV_SHIFT = which == "dma", which == "shift"
+                res[which].append(timed(lambda: K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, out=out)))
+        line += f"  [{name}]" + " |".join(f" {k} {sorted(v)[1]:.1f}us {fl / sorted(v)[1] / 1e6:.0f}TF" for k, v in res.items())
     print(line, flush=True)
