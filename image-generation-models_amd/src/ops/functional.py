@@ -25,7 +25,11 @@ PROBE = None      # bench.py sets this to a list: (kernel symbol, algorithmic FL
 # the 32x32 / 16x16 levels (128->128: 62.5 vs 53.7 us): with one 64x64 tile per wave both kernels move 1 KB of LDS per MFMA and the
 # DMA writes share the LDS port with the fragment reads.
 USE_CONV_DMA = os.environ.get("MI_CONV_DMA", "0") == "1"
-USE_CONV_SHIFT = os.environ.get("MI_CONV_SHIFT", "1") != "0"   # the LDS-frugal 3x3 conv kernel (csrc/conv_shift.hip)
+# ... and so is the LDS-frugal variant (csrc/conv_shift.hip: 128 x 64 wave tiles, left / right tap columns by DPP lane shifts, 0.4 KB
+# of LDS per MFMA): correct, and slower than the halo kernel on every cfg-2 shape (128->128 @32x32: 62.8 vs 52.6 us; 512->512 @8x8:
+# 50.1 vs 46.0 us).  Both experiments run ONE wave per SIMD; what they show is that the halo kernel's two waves per SIMD hide more
+# latency than the LDS-DMA staging or the halved LDS traffic buy back (the same lesson as round 1's 4-wave halo variant).
+USE_CONV_SHIFT = os.environ.get("MI_CONV_SHIFT", "0") == "1"
 USE_WGRAD_TR = os.environ.get("MI_W3_TR", "1") != "0"      # A/B switch for the LDS-DMA weight-gradient kernel (csrc/wgrad_tr.hip)
 
 
