@@ -50,17 +50,21 @@ template <int DIR> __device__ __forceinline__ bf16x8 shift_frag(const bf16x8& c,
     return __builtin_bit_cast(bf16x8, o);
 }
 
-template <int NI, bool OUT16>
-__global__ __launch_bounds__(256, 1) void conv_shift_kernel(const ShiftConvArgs a) {
+// WM waves along the pixel axis (2: one wave per SIMD, 128 pixels per wave; 4: two waves per SIMD, 64 pixels per wave) x 2 along channels
+template <int WM, int NI, bool OUT16>
+__global__ __launch_bounds__(128 * WM, 1) void conv_shift_kernel(const ShiftConvArgs a) {
+    constexpr int NW = 2 * WM, MI = 8 / WM;           // waves, 32-pixel blocks per wave
     constexpr int BN = 64 * NI;                       // output channels per workgroup (two waves of 32 * NI)
     constexpr int WTAP = BN * 128;                    // bytes of one tap's weight tile
-    constexpr int WPER = BN / 32;                     // weight DMA instructions per wave and tap
+    constexpr int WPER = BN / (8 * NW);               // weight DMA instructions per wave and tap
+    constexpr int XPW = 40 / NW, XPS = XPW / 5;       // X DMA instructions per wave and chunk / per stage (first five stages)
+    static_assert(WPER >= 1 && XPS >= 1, "every wave stages something");
     constexpr int XOFF = 0, WOFF = 2 * SXBUF;         // [X buffers][3 weight slots]
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
     const int t = threadIdx.x, l = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wv >> 1, wn = wv & 1;
+    const int wm = wv >> 1, wn = wv & 1;             // wm in [0, WM)
     int bx = blockIdx.x;
     if (a.xmap) {        // an image's row tiles share rows: keep them on one XCD (ids xcd + 8*slot -> image xcd + 8*m)
         const int xcd = bx & 7, slot = bx >> 3;
@@ -74,14 +78,14 @@ __global__ __launch_bounds__(256, 1) void conv_shift_kernel(const ShiftConvArgs 
     // ---- DMA pieces.  X: 40 instructions per chunk, 10 per wave, two per stage over a chunk's first five stages.  Instruction
     //      idx covers tile pixels 8*idx .. +7 (tile pixel hp = (image ti, row hy = y+1, column x)); lane -> pixel lane >> 3, stored
     //      chunk position lane & 7 holds channel chunk (lane & 7) ^ ((hp >> 1) & 7).
-    int xpix[10], xcol[10];
+    int xpix[XPW], xcol[XPW];
     {
         int img0, y0;
         if (a.TI > 1) { img0 = bx * a.TI; y0 = 0; }
         else { img0 = bx / a.tiles_per_img; y0 = (bx % a.tiles_per_img) * a.TH; }
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const int hp = 8 * (wv + 4 * i) + (l >> 3);
+        for (int i = 0; i < XPW; ++i) {
+            const int hp = 8 * (wv + NW * i) + (l >> 3);
             int v = -1;
             if (hp < a.XP) {
                 const int row = hp / a.W, x = hp - row * a.W;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256, 1) void conv_shift_kernel(const ShiftConvArgs 
     int wrow[WPER], wcol[WPER];
 #pragma unroll
     for (int i = 0; i < WPER; ++i) {
-        const int n = 8 * (wv + 4 * i) + (l >> 3);
+        const int n = 8 * (wv + NW * i) + (l >> 3);
         wrow[i] = min(n0 + n, a.Nc - 1);
         wcol[i] = ((l & 7) ^ ((n >> 1) & 7)) * 8;
     }
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256, 1) void conv_shift_kernel(const ShiftConvArgs 
         const uint16_t* src = second ? a.x2 : a.x;
         const int ld = second ? a.ldx2 : a.ldx, cc = second ? cc0 - a.K1 : cc0;
         const uint16_t* p = xpix[i] >= 0 ? src + (size_t)xpix[i] * ld + cc + xcol[i] : zero + (l & 7) * 8;
-        glds16(p, lds0 + XOFF + (ch & 1) * SXBUF + (wv + 4 * i) * 1024);
+        glds16(p, lds0 + XOFF + (ch & 1) * SXBUF + (wv + NW * i) * 1024);
     };
     // stage st = chunk st / 9, tap row (st % 9) / 3, tap column in the order centre, left, right
     auto stage_w = [&](int st) {
@@ -119,15 +123,15 @@ __global__ __launch_bounds__(256, 1) void conv_shift_kernel(const ShiftConvArgs 
         const uint16_t* base = a.w + (size_t)(a.flip ? 8 - tap : tap) * tap_stride + (size_t)ch * SCK;
 #pragma unroll
         for (int i = 0; i < WPER; ++i)
-            glds16(base + (size_t)wrow[i] * a.K + wcol[i], lds0 + WOFF + (st % 3) * WTAP + (wv + 4 * i) * 1024);
+            glds16(base + (size_t)wrow[i] * a.K + wcol[i], lds0 + WOFF + (st % 3) * WTAP + (wv + NW * i) * 1024);
     };
 
     // ---- fragment addressing.  Activations (MFMA "B" operand): lane -> pixel (l & 31) of the wave's i-th 32-pixel block (whole
     //      image rows), k-chunk 2*ks + (l >> 5); weights ("A"): lane -> output channel wn*32*NI + jn*32 + (l & 31).
-    int hp0[4];
+    int hp0[MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wm * 128 + i * 32 + (l & 31);
+    for (int i = 0; i < MI; ++i) {
+        const int r = wm * (32 * MI) + i * 32 + (l & 31);
         const int tx = r % a.W, q = r / a.W;
         const int ty = q % a.TH, ti = q / a.TH;
         hp0[i] = (ti * TH2 + ty) * a.W + tx;                 // tile pixel of tap row ky = 0 (one row up)
@@ -142,14 +146,14 @@ __global__ __launch_bounds__(256, 1) void conv_shift_kernel(const ShiftConvArgs 
         wb[jn] = n * 128; wsw[jn] = ((n >> 1) & 7) * 16;
     }
 
-    f32x16 acc[4][NI];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int jn = 0; jn < NI; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
-    bf16x8 XC[4][4];                                         // centre-column fragments of the current tap row: [k-step][pixel block]
+    bf16x8 XC[4][MI];                                        // centre-column fragments of the current tap row: [k-step][pixel block]
     bf16x8 FW[SPD + 1][NI];                                  // weight fragments, SPD units ahead
 #pragma unroll
     for (int q = 0; q <= SPD; ++q)
@@ -160,13 +164,13 @@ __global__ __launch_bounds__(256, 1) void conv_shift_kernel(const ShiftConvArgs 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int e = 0; e < 8; ++e) XC[ks][i][e] = (__bf16)0.f;
 
     // ---- prologue: the first chunk's rows and the first two taps
 #pragma unroll
-    for (int i = 0; i < 10; ++i) stage_x(0, i);
+    for (int i = 0; i < XPW; ++i) stage_x(0, i);
     stage_w(0);
     stage_w(1);
 
@@ -177,14 +181,14 @@ __global__ __launch_bounds__(256, 1) void conv_shift_kernel(const ShiftConvArgs 
             const int st = ch * 9 + sidx;
             // stage st's weights have landed (this wave's pieces: everything but what the previous stage's block requested), and
             // every LDS read this wave issued is complete ...
-            constexpr int newer = WPER + ((sidx + 8) % 9 < 5 ? 2 : 0);
-            if constexpr (newer == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-            else if constexpr (newer == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-            static_assert(newer == 2 || newer == 4 || newer == 6, "vmcnt immediates above");
+            constexpr int newer = WPER + ((sidx + 8) % 9 < 5 ? XPS : 0);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(newer) : "memory");
             __builtin_amdgcn_s_barrier();                     // ... for every wave: the slot of stage st-1 may be refilled
             asm volatile("" ::: "memory");
-            if constexpr (sidx < 5) { stage_x(ch + 1, 2 * sidx); stage_x(ch + 1, 2 * sidx + 1); }
+            if constexpr (sidx < 5) {
+#pragma unroll
+                for (int q = 0; q < XPS; ++q) stage_x(ch + 1, XPS * sidx + q);
+            }
             stage_w(st + 2);
             const uint32_t xb = lds0 + XOFF + (ch & 1) * SXBUF, wbase = lds0 + WOFF + (st % 3) * WTAP;
             static_for<0, 4>([&](auto kc) {
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void conv_shift_kernel(const ShiftConvArgs 
                 constexpr int um = (u + 36 - SPD) % 36;                       // the unit whose MFMAs run now (SPD behind)
                 constexpr int mj = (um / 4) % 3, mks = um % 4, mslot = um % (SPD + 1), lslot = u % (SPD + 1);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < MI; ++i) {
                     bf16x8 xf;
                     if constexpr (mj == 0) xf = XC[mks][i];
                     else if constexpr (mj == 1) xf = shift_frag<0>(XC[mks][i], mask_l);
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256, 1) void conv_shift_kernel(const ShiftConvArgs 
                 for (int jn = 0; jn < NI; ++jn) FW[lslot][jn] = lds_b128s(wbase + wb[jn] + ((ks * 32 + half16) ^ wsw[jn]));
                 if constexpr (j == 0) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < MI; ++i) {
                         const int hp = hp0[i] + ky * a.W;
                         XC[ks][i] = lds_b128s(xb + hp * 128 + ((ks * 32 + half16) ^ (((hp >> 1) & 7) * 16)));
                     }
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void conv_shift_kernel(const ShiftConvArgs 
     static_for<0, SPD>([&](auto qc) {                        // the last SPD units: right tap column of the last row, k-steps 2, 3
         constexpr int um = 36 - SPD + decltype(qc)::value, mks = um % 4, mslot = um % (SPD + 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
             const bf16x8 xf = shift_frag<1>(XC[mks][i], mask_r);
 #pragma unroll
             for (int jn = 0; jn < NI; ++jn)
@@ -237,8 +241,8 @@ __global__ __launch_bounds__(256, 1) void conv_shift_kernel(const ShiftConvArgs 
             bq[jn][rq] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + min(col, a.Nc - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const size_t m = (size_t)m0 + wm * 128 + i * 32 + (l & 31);
+    for (int i = 0; i < MI; ++i) {
+        const size_t m = (size_t)m0 + wm * (32 * MI) + i * 32 + (l & 31);
         const size_t mc = min(m, (size_t)Mtot - 1);
         f32x4 v[NI][4];
 #pragma unroll
@@ -344,22 +348,20 @@ extern "C" int mi_conv3x3_shift(const MiConvDesc* d, const void* x, const void* 
     const int BN = 64 * ni;
     const dim3 grid((unsigned)((long)d->N * d->OH * d->OW / SBM), (unsigned)((d->Nc + BN - 1) / BN));
     const size_t lds = (size_t)2 * SXBUF + (size_t)3 * BN * 128;
-    static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)conv_shift_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_shift_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_shift_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_shift_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return true;
-    }();
-    (void)once;
+    static const int wm_env = [] { const char* e = getenv("MI_SHIFT_WM"); return e ? atoi(e) : 4; }();
     hipStream_t st = (hipStream_t)stream;
-    if (ni == 2) {
-        if (out_bf16) hipLaunchKernelGGL((conv_shift_kernel<2, true>), grid, dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((conv_shift_kernel<2, false>), grid, dim3(256), lds, st, a);
+#define MI_SHIFT_GO(WMV, NIV, O16) do { \
+        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_shift_kernel<WMV, NIV, O16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
+        (void)once_; \
+        hipLaunchKernelGGL((conv_shift_kernel<WMV, NIV, O16>), grid, dim3(128 * WMV), lds, st, a); } while (0)
+    if (wm_env == 2) {
+        if (ni == 2) { if (out_bf16) MI_SHIFT_GO(2, 2, true); else MI_SHIFT_GO(2, 2, false); }
+        else { if (out_bf16) MI_SHIFT_GO(2, 1, true); else MI_SHIFT_GO(2, 1, false); }
     } else {
-        if (out_bf16) hipLaunchKernelGGL((conv_shift_kernel<1, true>), grid, dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((conv_shift_kernel<1, false>), grid, dim3(256), lds, st, a);
+        if (ni == 2) { if (out_bf16) MI_SHIFT_GO(4, 2, true); else MI_SHIFT_GO(4, 2, false); }
+        else { if (out_bf16) MI_SHIFT_GO(4, 1, true); else MI_SHIFT_GO(4, 1, false); }
     }
+#undef MI_SHIFT_GO
     MI_LAUNCH_CHECK();
     return 0;
 }
