@@ -384,13 +384,20 @@ class WgradQueue:
     """Deferred weight gradients of the Block convs (3x3) and of the 1x1 convs.  Backward pushes (X, dY, dW) here instead of
     launching one full-chip kernel per layer; every `group` layers of a kind go out as ONE launch (mi_conv3x3_wgrad_tr_batch /
     mi_conv1x1_wgrad_tr_batch), each layer on its share of the CUs (see include/mi_ddpm.h: an eighth of the partial-tile traffic,
-    an eighth of the launches).  Layers the LDS-DMA kernels cannot take run at once through conv_wgrad.  `pushed` / `flushed` count
-    the deferred layers and how many of them have been issued; `on_flush()` is called after every flush."""
+    an eighth of the launches).  Layers the LDS-DMA kernels cannot take run at once through conv_wgrad.  `pushed` numbers the deferred
+    layers (1, 2, ...); `flushed` = the largest n such that layers 1..n have ALL been issued (the two kinds flush independently, so a
+    count of issued layers would not say that); `on_flush()` is called after every flush."""
 
     def __init__(self, group: int = 8, on_flush=None):
         self.group, self.on_flush = max(1, min(8, int(group))), on_flush
         self.items3, self.items1 = [], []
-        self.pushed = self.flushed = 0
+        self.pushed = 0
+        self._seq3, self._seq1 = [], []        # sequence numbers of the queued layers, per kind
+
+    @property
+    def flushed(self) -> int:
+        pending = self._seq3[:1] + self._seq1[:1]
+        return min(pending) - 1 if pending else self.pushed
 
     def _desc(self, P, Q, k, Ci, Cj, hw, mode, P2):
         I1 = P.shape[3] if P2 is not None else Ci
@@ -407,6 +414,7 @@ class WgradQueue:
             return
         self.items3.append((d, P, P2, Q, dW))
         self.pushed += 1
+        self._seq3.append(self.pushed)
         if len(self.items3) >= self.group:
             self.flush(kinds=(3,))
 
@@ -421,6 +429,7 @@ class WgradQueue:
             return
         self.items1.append((d, P, P2, Q, dW, dbias, q32))
         self.pushed += 1
+        self._seq1.append(self.pushed)
         if len(self.items1) >= self.group:
             self.flush(kinds=(1,))
 
@@ -428,8 +437,7 @@ class WgradQueue:
         lib = load_library()
         arr = lambda items, k: (C.c_void_p * len(items))(*[(it[k].data_ptr() if it[k] is not None else 0) for it in items])   # noqa: E731
         if 3 in kinds and self.items3:
-            items, self.items3 = self.items3, []
-            self.flushed += len(items)
+            items, self.items3, self._seq3 = self.items3, [], []
             _need_gpu(items[0][1])
             n = len(items)
             descs = (MiWgradDesc * n)(*[it[0] for it in items])
@@ -443,8 +451,7 @@ class WgradQueue:
             nb = sum(it[0].N * it[0].DH * it[0].DW * (it[0].Ci + it[0].Cj) * 2.0 for it in items)
             self._run(go, lib.mi_debug_wgrad_tr_phase, "wgrad_tr", n, flops, nb, need)
         if 1 in kinds and self.items1:
-            items, self.items1 = self.items1, []
-            self.flushed += len(items)
+            items, self.items1, self._seq1 = self.items1, [], []
             _need_gpu(items[0][1])
             n = len(items)
             descs = (MiWgradDesc * n)(*[it[0] for it in items])

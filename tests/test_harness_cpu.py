@@ -262,3 +262,20 @@ def test_bench_self_launches_ranks_without_torchrun():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["self_launched"] and out["dry_run"] and out["steps"] == 3
     assert out["buckets_bytes"] and out["scaling"] == "weak"
+
+
+def test_wgrad_queue_flushed_is_a_prefix_not_a_count():
+    """WgradQueue.flushed releases gradient ranges to the all-reduce: it must be the longest issued PREFIX of the pushed layers
+    (the 3x3 and 1x1 kinds flush independently), not the number of issued layers."""
+    from src.ops.functional import WgradQueue
+    q = WgradQueue(group=8)
+    q.pushed, q._seq3, q._seq1 = 5, [1, 4], [2, 3, 5]
+    assert q.flushed == 0
+    q._seq1 = []                         # every 1x1 layer is out, layer 1 (3x3) is not
+    assert q.flushed == 0
+    q._seq3, q._seq1 = [4], [5]
+    assert q.flushed == 3
+    q._seq3 = []
+    assert q.flushed == 4
+    q._seq1 = []
+    assert q.flushed == 5

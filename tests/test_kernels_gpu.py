@@ -673,6 +673,25 @@ def test_conv1x1_wgrad_queue(K):
             assert rel_err(db, bref) < 1e-5, (Ci, Co)
 
 
+def test_wgrad_queue_flushed_means_every_earlier_layer_is_out(K):
+    """The gradient reducer releases a parameter range once `flushed` covers the layers pushed before it.  The two kinds flush
+    independently: a full group of 1x1 layers going out must NOT count a 3x3 layer pushed before them as issued."""
+    mk = lambda n, h, c: torch.randn(n, h, h, c, device=DEV).bfloat16()          # noqa: E731
+    q = K.WgradQueue(group=8)
+    x3, d3, w3 = mk(8, 16, 128), mk(8, 16, 128), torch.zeros(9 * 128 * 128, device=DEV)
+    q.push(x3, d3, w3, Ci=128, Cj=128, hw=(16, 16), mode=1)                       # layer 1 (3x3) stays queued
+    keep = []
+    for _ in range(8):                                                            # layers 2..9 (1x1): the eighth triggers their launch
+        x1, d1, w1 = mk(8, 16, 128), mk(8, 16, 128), torch.zeros(128 * 128, device=DEV)
+        keep.append((x1, d1, w1))
+        q.push1x1(x1, d1, w1, Ci=128, Cj=128, hw=(16, 16), mode=1)
+    assert q.pushed == 9 and q.flushed == 0 and float(w3.abs().sum()) == 0.0
+    assert all(float(w1.abs().sum()) > 0 for _, _, w1 in keep)
+    q.flush()
+    torch.cuda.synchronize()
+    assert q.flushed == 9 and float(w3.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("group", [8, 3])
 def test_conv3x3_wgrad_queue_batches_layers(K, group):
     """K.WgradQueue: several Block convs' weight gradients in ONE launch (mi_conv3x3_wgrad_tr_batch), each on its share of the

@@ -1,0 +1,51 @@
+"""profiles/<tag>_pmc_traffic.json from the <tag>_pmc_traffic_*.txt passes of tools/profile_round.sh (bench.py reads it for
+roofline.traffic).  FETCH_SIZE is doubled as MI355X_MICROARCH.md's HBM/rocprofv3 section prescribes for gfx950; both counters are
+in KB.  usage: python tools/make_traffic_json.py r02"""
+import glob, json, os, re, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+
+# bench_one.py case -> (symbol bench.py reports, shape text, algorithmic bytes per launch)
+def conv_bytes(N, H, Ci, Co, b_in, b_out): return N * H * H * (Ci * b_in + Co * b_out) + 9 * Ci * Co * 2
+CASES = {
+    "halo_128_8_512_512_bf16": ("conv3x3_halo_kernel<128, 64, 3, false, 3, 8>", "[128,8,8,512]->512 bf16 storage", conv_bytes(128, 8, 512, 512, 2, 2)),
+    "halo_128_32_128_128_bf16": ("conv3x3_halo_kernel<256, 64, 3, false, 3, 8>", "[128,32,32,128]->128 bf16 storage", conv_bytes(128, 32, 128, 128, 2, 2)),
+    "halo_128_32_128_128_fp32": ("conv3x3_halo_kernel<256, 64, 3, false, 0, 8>", "[128,32,32,128]->128 fp32 storage", conv_bytes(128, 32, 128, 128, 4, 4)),
+    "wgrad_128_32_128_128_bf16": ("wgrad_tr_kernel[single]", "[128,32,32,128]x[128,32,32,128] bf16 operands, one layer per launch",
+                                  2 * 128 * 32 * 32 * 128 * 2 + 9 * 128 * 128 * 4),
+    "wgrad_128_8_512_512_bf16": ("wgrad_tr_kernel[single 8x8]", "[128,8,8,512]x[128,8,8,512] bf16 operands, one layer per launch",
+                                 2 * 128 * 8 * 8 * 512 * 2 + 9 * 512 * 512 * 4),
+    "wgradq_128_0_0_0_bf16": ("wgrad_tr_kernel", "the eight layers of backward's first group in one launch (tools/bench_one.py wgradq: 4x 128->128 @32x32, 3x 256->256 + 512->128 @16x16), bf16 operands",
+                              sum(128 * h * h * (ci + co) * 2 + 9 * ci * co * 4
+                                  for h, ci, co in [(32, 128, 128)] * 4 + [(16, 256, 256)] * 2 + [(16, 512, 128), (16, 256, 256)])),
+    "fused_128_32_128_128_bf16": ("conv3x3_halo_kernel<256, 64, 3, false, 3, 8, true>", "fused GN+Mish+conv [128,32,32,128]->128 bf16 storage",
+                                  conv_bytes(128, 32, 128, 128, 2, 2) + 3 * 128 * 128 * 4),
+    "fused_128_32_128_128_fp32": ("conv3x3_halo_kernel<256, 64, 3, false, 0, 8, true>", "fused GN+Mish+conv [128,32,32,128]->128 fp32 storage",
+                                  conv_bytes(128, 32, 128, 128, 4, 4) + 3 * 128 * 128 * 4),
+}
+MAIN = {"halo": "conv3x3_halo_kernel", "fused": "conv3x3_halo_kernel", "wgrad": "wgrad_tr_kernel(", "wgradq": "wgrad_tr_kernel("}
+
+out = {}
+for path in sorted(glob.glob(os.path.join(root, f"{tag}_pmc_traffic_*.txt"))):
+    case = os.path.basename(path)[len(tag) + len("_pmc_traffic_"):-4]
+    if case not in CASES:
+        continue
+    want = MAIN[case.split("_")[0]]
+    vals = {}
+    for line in open(path):
+        m = re.match(r"(.*?)\s+(FETCH_SIZE|WRITE_SIZE) per-dispatch.*:\s*(\d+)\s*$", line)
+        if m and want in m.group(1) and "reduce" not in m.group(1):
+            vals[m.group(2)] = int(m.group(3))
+    if len(vals) != 2:
+        continue
+    sym, shape, alg = CASES[case]
+    hbm = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
+    out[sym] = {"shape": shape, "fetch_size_kb_raw": vals["FETCH_SIZE"], "write_size_kb_raw": vals["WRITE_SIZE"],
+                "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "ratio": round(hbm / alg, 2),
+                "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh) on {shape}; "
+                        "FETCH_SIZE doubled per MI355X_MICROARCH.md"}
+with open(os.path.join(root, f"{tag}_pmc_traffic.json"), "w") as f:
+    json.dump(out, f, indent=1)
+for k, v in out.items():
+    print(f"{k:60s} {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB  x{v['ratio']}")
