@@ -246,9 +246,99 @@ __global__ void f32_to_bf16_kernel(size_t M, int C4, const float* __restrict__ x
     }
 }
 
+// y = bf16(x) (CVT) and / or column sums of x (SUM) in ONE pass over x: a thread owns a channel quad and walks rows (256 / C4 rows
+// per sweep of the workgroup, four independent float4 loads in flight), then one LDS combine per workgroup.  The sums leave either
+// as 4 atomics per quad (ATOMIC: out[c] +=) or as this workgroup's row of a partial matrix (out[block][C], plain stores).
+// Device-scope fp32 atomics on ONE address from all eight XCDs serialise at ~40 ns each (measured: 512 workgroups -> 20 us,
+// 4096 -> 150 us, whatever the bytes), so a big tensor goes through partial rows and a second, small pass of the same kernel.
+template <bool CVT, bool SUM, bool ATOMIC>
+__global__ __launch_bounds__(256) void cvt_colsum_kernel(int M, int C4, const float* __restrict__ x, int ldx, uint16_t* __restrict__ y, int ldy,
+                                                         float* __restrict__ out, int rows_per_block) {
+    __shared__ float4 red[256];
+    const int nr = 256 / C4, tc = threadIdx.x % C4, tr = threadIdx.x / C4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tr < nr) {
+        const int mb = blockIdx.x * rows_per_block, me = min(M, mb + rows_per_block);
+        int m = mb + tr;
+        for (; m + 3 * nr < me; m += 4 * nr) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(x + (size_t)(m + k * nr) * ldx + tc * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (CVT) *reinterpret_cast<uint2*>(y + (size_t)(m + k * nr) * ldy + tc * 4) =
+                             make_uint2(pack_bf16(v[k].x, v[k].y), pack_bf16(v[k].z, v[k].w));
+                if (SUM) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+            }
+        }
+        for (; m < me; m += nr) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + tc * 4);
+            if (CVT) *reinterpret_cast<uint2*>(y + (size_t)m * ldy + tc * 4) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+            if (SUM) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        }
+    }
+    if (!SUM) return;
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (tr == 0) {
+        for (int r = 1; r < nr; ++r) { const float4 o = red[r * C4 + tc]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+        if (ATOMIC) {
+            atomicAdd(out + tc * 4, s.x); atomicAdd(out + tc * 4 + 1, s.y); atomicAdd(out + tc * 4 + 2, s.z); atomicAdd(out + tc * 4 + 3, s.w);
+        } else {
+            *reinterpret_cast<float4*>(out + (size_t)blockIdx.x * (C4 * 4) + tc * 4) = s;
+        }
+    }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+// One pass over an fp32 [M][C] tensor (row stride ldx): y_bf16 (optional) = bf16(x), colsum (optional)[c] += column sums.
+// Backward uses it on a residual-stream gradient that a weight-gradient kernel wants as bf16 and a bias gradient wants summed.
+// workspace (optional, mi_f32_to_bf16_colsum_workspace(M, C) bytes, 16-byte aligned): per-workgroup partial sums, so that the
+// pass runs on a full grid; without it the sums are added atomically from at most 64 workgroups (slow for large tensors).
+extern "C" size_t mi_f32_to_bf16_colsum_workspace(size_t M, int C) {
+    if (C < 4 || C > 1024 || C % 4) return 0;
+    const int nr = 256 / (C / 4);
+    size_t rows = 16 * (size_t)nr;
+    while ((M + rows - 1) / rows > 2048) rows *= 2;
+    return ((M + rows - 1) / rows) * (size_t)C * sizeof(float);
+}
+
+extern "C" int mi_f32_to_bf16_colsum(size_t M, int C, const float* x, int ldx, void* y_bf16, int ldy, float* colsum, void* workspace,
+                                     size_t ws_bytes, void* stream) {
+    MI_REQUIRE(M > 0 && M < (1u << 31) && C >= 4 && C <= 1024 && C % 4 == 0 && ldx % 4 == 0 && x && (y_bf16 || colsum) &&
+               (((uintptr_t)x) & 15) == 0, "bad argument (4 <= C <= 1024, C and ldx % 4 == 0, x 16-byte aligned)");
+    MI_REQUIRE(!y_bf16 || (ldy % 4 == 0 && (((uintptr_t)y_bf16) & 7) == 0), "bf16 output: ldy % 4 == 0, 8-byte aligned");
+    const int C4 = C / 4, nr = 256 / C4;
+    uint16_t* y = (uint16_t*)y_bf16;
+    auto plan = [&](size_t cap) { int rows = 16 * nr; while ((M + rows - 1) / rows > cap) rows *= 2; return rows; };
+    if (!colsum) {
+        const int rows = plan(4096);
+        hipLaunchKernelGGL((cvt_colsum_kernel<true, false, false>), dim3((unsigned)((M + rows - 1) / rows)), dim3(256), 0, ST, (int)M, C4, x, ldx, y, ldy,
+                           colsum, rows);
+        MI_LAUNCH_CHECK();
+        return 0;
+    }
+    const size_t need = mi_f32_to_bf16_colsum_workspace(M, C);
+    const bool two_pass = workspace && (((uintptr_t)workspace) & 15) == 0 && ws_bytes >= need && M >= 4096;
+    const int rows = plan(two_pass ? 2048 : 64);
+    const unsigned nb = (unsigned)((M + rows - 1) / rows);
+    float* part = two_pass ? (float*)workspace : colsum;
+    if (two_pass) {
+        if (y) hipLaunchKernelGGL((cvt_colsum_kernel<true, true, false>), dim3(nb), dim3(256), 0, ST, (int)M, C4, x, ldx, y, ldy, part, rows);
+        else   hipLaunchKernelGGL((cvt_colsum_kernel<false, true, false>), dim3(nb), dim3(256), 0, ST, (int)M, C4, x, ldx, y, ldy, part, rows);
+        int rows2 = nr; while ((nb + rows2 - 1) / rows2 > 16) rows2 *= 2;          // the partial rows: <= 16 workgroups add atomically
+        hipLaunchKernelGGL((cvt_colsum_kernel<false, true, true>), dim3((nb + rows2 - 1) / rows2), dim3(256), 0, ST, (int)nb, C4, part, C, nullptr, 0,
+                           colsum, rows2);
+    } else {
+        if (y) hipLaunchKernelGGL((cvt_colsum_kernel<true, true, true>), dim3(nb), dim3(256), 0, ST, (int)M, C4, x, ldx, y, ldy, part, rows);
+        else   hipLaunchKernelGGL((cvt_colsum_kernel<false, true, true>), dim3(nb), dim3(256), 0, ST, (int)M, C4, x, ldx, y, ldy, part, rows);
+    }
+    MI_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int mi_f32_to_bf16(size_t M, int C, const float* x, int ldx, void* y_bf16, int ldy, void* stream) {
     MI_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && x && y_bf16, "bad argument (C, ld % 4 == 0)");

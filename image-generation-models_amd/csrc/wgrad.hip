@@ -442,8 +442,13 @@ extern "C" int mi_conv_wgrad(const MiWgradDesc* d, const float* P, const float* 
     return 0;
 }
 
+extern "C" int mi_f32_to_bf16_colsum(size_t M, int C, const float* x, int ldx, void* y_bf16, int ldy, float* colsum, void* workspace,
+                                     size_t ws_bytes, void* stream);
+
 extern "C" int mi_colsum(int M, int C, const float* x, int ld, float* out, void* stream) {
     MI_REQUIRE(M > 0 && C > 0 && x && out, "bad argument");
+    if (C % 4 == 0 && C >= 4 && C <= 1024 && ld % 4 == 0 && (((uintptr_t)x) & 15) == 0)       // float4 rows, several loads in flight
+        return mi_f32_to_bf16_colsum((size_t)M, C, x, ld, nullptr, 0, out, nullptr, 0, stream);
     int rows = 256;
     dim3 grid((M + rows - 1) / rows, (C + 63) / 64);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, M, C, x, ld, out, rows);

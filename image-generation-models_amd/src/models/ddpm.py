@@ -253,6 +253,8 @@ class Unet(nn.Module):
         # (mi_gn_stats_coef) costs what the apply pass cost, and the sampler measured 671 vs 692 denoise steps/s at B=64
         # (tools/sample_steps.py); with fp32 storage the fused unit is 65.6 us against 86.3 us in two passes (bench.py named_kernel).
         self.fuse_gn_conv = os.environ.get("MI_DDPM_FUSE_GN", "0") == "1"
+        # Downsample / Upsample weight gradients through the LDS-DMA kernel (csrc/wgrad_s2_tr.hip); 0 = round 1's ring kernel
+        self.s2_wgrad_tr = os.environ.get("MI_DDPM_S2_TR", "1") != "0"
         self.accumulate_grads = False
         self.grad_ready_hook = None        # callable(lo, hi): flat_grads[lo:hi) is final (set by the DDP reducer)
 
@@ -551,8 +553,8 @@ class Unet(nn.Module):
             if lvl["down"] is not None:
                 inp = h
                 h = conv(inp, lvl["down"]["pre"], 3, 2, 1)
-                if record:
-                    tape.append(("down", lvl["down"], inp, h))
+                if record:    # the skip tensor's bf16 copy (its consumer in the up path wants it too) feeds Downsample's weight gradient
+                    tape.append(("down", lvl["down"], inp, h, shadow(inp) if use_sh and self.s2_wgrad_tr else None))
         h = resblock(A.mid1, h)
         h = attention(A.mid_attn, h)
         h = resblock(A.mid2, h, want_out16=True)                  # feeds the first up block's conv
@@ -563,7 +565,7 @@ class Unet(nn.Module):
             inp = h
             h = conv(inp, lvl["up"]["pre"], 4, 2, 1, transposed_conv=True)
             if record:
-                tape.append(("up", lvl["up"], inp, h))
+                tape.append(("up", lvl["up"], inp, h, None))
         cF = conv(h, "final_conv.0.block.0.", 3, 1, 1)
         hF, stF = K.gn_mish_fwd(cF, sv["final_conv.0.block.1.weight"], sv["final_conv.0.block.1.bias"])
         eps = conv(hF, "final_conv.1.", 1)
@@ -593,6 +595,20 @@ class Unet(nn.Module):
         B = x_in.shape[0]
         dtb_all = torch.zeros((B, A.mlp_rows), device=x_in.device, dtype=torch.float32)
 
+        def s2_push(dy, inp, pre, k, ci, co, transposed_conv, ihw, ohw, bias):
+            """Downsample / Upsample weight gradient through the LDS-DMA kernel: both operands as bf16 (the input's copy is the one
+            the skip connection's consumer reads when there is one; the output gradient is rounded by the pass that also sums
+            it into the bias gradient)."""
+            big, small = (ohw, ihw) if transposed_conv else (ihw, ohw)
+            if dy.dtype != torch.float32 or not K.s2_wgrad_supported(inp.shape[0], k, ci, co, transposed_conv, big, small, mode):
+                return False
+            x16 = inp if inp.dtype == torch.bfloat16 else K.to_bf16(inp)
+            dy16 = K.to_bf16(dy, colsum_out=gv[pre + "bias"] if bias == "colsum" else None)
+            ok = wq.push_s2(x16, dy16, gv[pre + "weight"], k=k, Ci=ci, Cj=co, gather_i=not transposed_conv, grid_g=big, grid_d=small,
+                            mode=mode)
+            assert ok
+            return True
+
         def conv_bwd(dy, inp, pre, k, stride=1, pad=0, x2=None, transposed_conv=False, bias="colsum", want_dx=True, winp=None, wx2=None):
             """Gradients of y = conv(inp [|x2]); dy may be a channel slice.  The gradient wrt inp has inp's dtype
             (bf16 for the block-internal h1, fp32 for everything on the residual stream).  winp / wx2: the tensors the forward
@@ -615,6 +631,9 @@ class Unet(nn.Module):
             small_cin = x2 is None and stride == 1 and not transposed_conv and K.small_cin_supported(k, ci, co, wgrad=True)
             if small_cin:
                 K.conv_small_cin_wgrad(inp, dy, gv[pre + "weight"], k)
+            elif stride == 2 and mode == K.MODE_BF16 and self.s2_wgrad_tr and s2_push(dy, winp, pre, kh, ci, co, transposed_conv,
+                                                                                      (ih, iw), (oh, ow), bias):
+                bias = None                                           # Downsample / Upsample: deferred, bias gradient rode along
             elif transposed_conv:   # dW[tap][ci][co] = sum over input pixels  x[j] * dy[gather(j, tap)]
                 K.conv_wgrad(inp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=False,
                              Ci=ci, Cj=co, grid_g=(oh, ow), grid_d=(ih, iw), mode=mode)
@@ -629,6 +648,8 @@ class Unet(nn.Module):
                 if fuse_b:
                     bias = None
             else:
+                if stride == 2:
+                    winp = inp                                        # round 1's ring kernel converts while it stages
                 K.conv_wgrad(winp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=True,
                              Ci=ci, Cj=co, grid_g=(ih, iw), grid_d=(oh, ow), mode=mode, P2=wx2,
                              dbias=gv[pre + "bias"] if bias == "colsum" else None)
@@ -732,11 +753,11 @@ class Unet(nn.Module):
             elif kind == "attn":
                 attn_bwd(rec)
             elif kind == "down":
-                _, dn, inp, out = rec
-                conv_bwd(G.take(out), inp, dn["pre"], 3, 2, 1)
+                _, dn, inp, out, inp_c = rec
+                conv_bwd(G.take(out), inp, dn["pre"], 3, 2, 1, winp=inp_c)
             elif kind == "up":
-                _, up, inp, out = rec
-                conv_bwd(G.take(out), inp, up["pre"], 4, 2, 1, transposed_conv=True)
+                _, up, inp, out, inp_c = rec
+                conv_bwd(G.take(out), inp, up["pre"], 4, 2, 1, transposed_conv=True, winp=inp_c)
             elif kind == "time":
                 _, te, t1, a1, temb, mt = rec
                 dim = A.dim

@@ -380,6 +380,14 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
             colsum(Q, dbias)
 
 
+def s2_wgrad_supported(N, k, Ci, Cj, transposed, big, small, mode):
+    """Can the stride-2 LDS-DMA weight-gradient kernel take this Downsample (3x3 conv) / Upsample (4x4 transposed conv) layer
+    (dense bf16 operands)?  big / small: the (H, W) of the 2x-resolution tensor and of the other one."""
+    d = MiWgradDesc(N=N, GH=big[0], GW=big[1], DH=small[0], DW=small[1], Ci=Ci, Cj=Cj, KH=k, KW=k, stride=2, pad=1,
+                    gather_i=int(not transposed), mode=mode, I1=Ci, ldp=Ci, ldp2=0, ldq=Cj)
+    return bool(USE_WGRAD_TR and load_library().mi_conv_s2_wgrad_tr_supported(C.byref(d)))
+
+
 class WgradQueue:
     """Deferred weight gradients of the Block convs (3x3) and of the 1x1 convs.  Backward pushes (X, dY, dW) here instead of
     launching one full-chip kernel per layer; every `group` layers of a kind go out as ONE launch (mi_conv3x3_wgrad_tr_batch /
@@ -390,13 +398,13 @@ class WgradQueue:
 
     def __init__(self, group: int = 8, on_flush=None):
         self.group, self.on_flush = max(1, min(8, int(group))), on_flush
-        self.items3, self.items1 = [], []
+        self.items3, self.items1, self.items2 = [], [], []
         self.pushed = 0
-        self._seq3, self._seq1 = [], []        # sequence numbers of the queued layers, per kind
+        self._seq3, self._seq1, self._seq2 = [], [], []        # sequence numbers of the queued layers, per kind
 
     @property
     def flushed(self) -> int:
-        pending = self._seq3[:1] + self._seq1[:1]
+        pending = self._seq3[:1] + self._seq1[:1] + self._seq2[:1]
         return min(pending) - 1 if pending else self.pushed
 
     def _desc(self, P, Q, k, Ci, Cj, hw, mode, P2):
@@ -433,7 +441,22 @@ class WgradQueue:
         if len(self.items1) >= self.group:
             self.flush(kinds=(1,))
 
-    def flush(self, kinds=(3, 1)):
+    def push_s2(self, P, Q, dW, *, k, Ci, Cj, gather_i, grid_g, grid_d, mode):
+        """Downsample (3x3 / stride 2 / pad 1 conv: gather_i, P = X on the 2x grid) and Upsample (4x4 / stride 2 / pad 1 transposed
+        conv: not gather_i, Q = dY on the 2x grid) weight gradients; both operands bf16.  Returns False when the LDS-DMA kernel
+        cannot take the layer (the caller then runs conv_wgrad)."""
+        d = MiWgradDesc(N=P.shape[0], GH=grid_g[0], GW=grid_g[1], DH=grid_d[0], DW=grid_d[1], Ci=Ci, Cj=Cj, KH=k, KW=k, stride=2, pad=1,
+                        gather_i=int(gather_i), mode=mode, I1=Ci, ldp=ld_of(P), ldp2=0, ldq=ld_of(Q))
+        if not (USE_WGRAD_TR and _b16(P) and _b16(Q) and load_library().mi_conv_s2_wgrad_tr_supported(C.byref(d))):
+            return False
+        self.items2.append((d, P, None, Q, dW))
+        self.pushed += 1
+        self._seq2.append(self.pushed)
+        if len(self.items2) >= self.group:
+            self.flush(kinds=(2,))
+        return True
+
+    def flush(self, kinds=(3, 1, 2)):
         lib = load_library()
         arr = lambda items, k: (C.c_void_p * len(items))(*[(it[k].data_ptr() if it[k] is not None else 0) for it in items])   # noqa: E731
         if 3 in kinds and self.items3:
@@ -465,6 +488,21 @@ class WgradQueue:
             flops = sum(2.0 * it[0].N * it[0].DH * it[0].DW * it[0].Ci * it[0].Cj for it in items)
             nb = sum(it[0].N * it[0].DH * it[0].DW * (it[0].Ci * 2.0 + it[0].Cj * (4.0 if it[6] else 2.0)) for it in items)
             self._run(go1, lib.mi_debug_wgrad1x1_tr_phase, "wgrad1x1_tr", n, flops, nb, need)
+        if 2 in kinds and self.items2:
+            items, self.items2, self._seq2 = self.items2, [], []
+            _need_gpu(items[0][1])
+            n = len(items)
+            descs = (MiWgradDesc * n)(*[it[0] for it in items])
+            need = lib.mi_conv_s2_wgrad_tr_batch_workspace(n, descs)
+            ws = _workspace(items[0][1].device, need)
+
+            def go2():
+                check(lib.mi_conv_s2_wgrad_tr_batch(n, descs, arr(items, 1), arr(items, 3), arr(items, 4), _p(ws), ws.numel() * 4, _stream()),
+                      "mi_conv_s2_wgrad_tr_batch")
+            flops = sum(2.0 * it[0].N * it[0].DH * it[0].DW * it[0].Ci * it[0].Cj * it[0].KH * it[0].KW for it in items)
+            nb = sum(it[0].N * it[0].DH * it[0].DW * 2.0 * ((4 if it[0].gather_i else 1) * it[0].Ci + (1 if it[0].gather_i else 4) * it[0].Cj)
+                     for it in items)
+            self._run(go2, lib.mi_debug_wgrad_s2_tr_phase, "wgrad_s2_tr", n, flops, nb, need)
         if self.on_flush is not None:
             self.on_flush()
 
@@ -507,22 +545,36 @@ def colsum(x, out):
     Cc = x.shape[-1]
     M = _rows(x)
     e0 = _probe_open()
-    check(load_library().mi_colsum(M, Cc, _p(x), ld_of(x), _p(out), _stream()), "mi_colsum")
+    vec = Cc % 4 == 0 and 4 <= Cc <= 1024 and ld_of(x) % 4 == 0 and x.data_ptr() % 16 == 0 and x.dtype == torch.float32
+    lib = load_library()
+    if vec:       # float4 rows on a full grid, per-workgroup partial sums through the scratch buffer
+        ws = _workspace(x.device, lib.mi_f32_to_bf16_colsum_workspace(M, Cc))
+        check(lib.mi_f32_to_bf16_colsum(M, Cc, _p(x), ld_of(x), None, 0, _p(out), _p(ws), ws.numel() * 4, _stream()), "mi_f32_to_bf16_colsum")
+    else:
+        check(lib.mi_colsum(M, Cc, _p(x), ld_of(x), _p(out), _stream()), "mi_colsum")
     if e0 is not None:
-        _probe_close(e0, "colsum_kernel", 0.0, f"M{M} C{Cc}", M * Cc * _esz(x))
+        _probe_close(e0, "cvt_colsum_kernel<false, true>" if vec else "colsum_kernel", 0.0, f"M{M} C{Cc}", M * Cc * _esz(x))
 
 
 # --------------------------------------------------------------------------- norms
-def to_bf16(x):
+def to_bf16(x, colsum_out=None):
     """bf16 copy (round-to-nearest-even) of an fp32 NHWC activation or channel slice: the MFMA operand of the next conv /
-    weight gradient, rounded once for all of its consumers."""
+    weight gradient, rounded once for all of its consumers.  colsum_out (optional)[c] += sum over pixels of x[..., c] from the
+    same pass (the bias gradient when x is a conv's output gradient)."""
     _need_gpu(x)
     N, H, W, Cc = x.shape
     y = new_act(N, H, W, Cc, x, torch.bfloat16)
     e0 = _probe_open()
-    check(load_library().mi_f32_to_bf16(N * H * W, Cc, _p(x), ld_of(x), _p(y), Cc, _stream()), "mi_f32_to_bf16")
+    if colsum_out is not None:
+        lib = load_library()
+        ws = _workspace(x.device, lib.mi_f32_to_bf16_colsum_workspace(N * H * W, Cc))
+        check(lib.mi_f32_to_bf16_colsum(N * H * W, Cc, _p(x), ld_of(x), _p(y), Cc, _p(colsum_out), _p(ws), ws.numel() * 4, _stream()),
+              "mi_f32_to_bf16_colsum")
+    else:
+        check(load_library().mi_f32_to_bf16(N * H * W, Cc, _p(x), ld_of(x), _p(y), Cc, _stream()), "mi_f32_to_bf16")
     if e0 is not None:
-        _probe_close(e0, "f32_to_bf16_kernel", 0.0, f"M{N * H * W} C{Cc}", N * H * W * Cc * 6.0)
+        _probe_close(e0, "cvt_colsum_kernel<true, true>" if colsum_out is not None else "f32_to_bf16_kernel", 0.0,
+                     f"M{N * H * W} C{Cc}", N * H * W * Cc * 6.0)
     return y
 
 

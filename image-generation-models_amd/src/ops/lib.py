@@ -54,6 +54,9 @@ SIGNATURES = {
     "mi_conv1x1_wgrad_tr_batch": [_I, C.POINTER(MiWgradDesc), C.POINTER(_I), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                                   C.POINTER(_P), _P, _Z, _P],
     "mi_debug_wgrad1x1_tr_phase": [_I],
+    "mi_conv_s2_wgrad_tr_supported": [C.POINTER(MiWgradDesc)],
+    "mi_conv_s2_wgrad_tr_batch": [_I, C.POINTER(MiWgradDesc), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _Z, _P],
+    "mi_debug_wgrad_s2_tr_phase": [_I],
     "mi_debug_wgrad1x1_tr_blocks": [_I],
     "mi_debug_wgrad_tr_blocks": [_I],
     "mi_conv3x3_bf16w_io": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
@@ -61,6 +64,7 @@ SIGNATURES = {
     "mi_gn_mish_fwd_io": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P],
     "mi_gn_mish_fwd_dual": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _P],
     "mi_f32_to_bf16": [_Z, _I, _P, _I, _P, _I, _P],
+    "mi_f32_to_bf16_colsum": [_Z, _I, _P, _I, _P, _I, _P, _P, _Z, _P],
     "mi_gn_mish_bwd_io": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P],
     "mi_pack_weights_bf16": [_I, _P, _I, _P, _P, _P, _P],
     "mi_conv3x3_dma_supported": [C.POINTER(MiConvDesc)],
@@ -139,6 +143,8 @@ OTHER = {"mi_abi_version": ([], C.c_int), "mi_last_error": ([], C.c_char_p),
          "mi_conv3x3_wgrad_tr_workspace": ([C.POINTER(MiWgradDesc)], C.c_size_t),
          "mi_conv3x3_wgrad_tr_batch_workspace": ([_I, C.POINTER(MiWgradDesc)], C.c_size_t),
          "mi_conv1x1_wgrad_tr_batch_workspace": ([_I, C.POINTER(MiWgradDesc), C.POINTER(_I)], C.c_size_t),
+         "mi_conv_s2_wgrad_tr_batch_workspace": ([_I, C.POINTER(MiWgradDesc)], C.c_size_t),
+         "mi_f32_to_bf16_colsum_workspace": ([_Z, _I], C.c_size_t),
          "mi_conv_small_wgrad_workspace": ([_I], C.c_size_t)}
 ABI_VERSION = 1
 

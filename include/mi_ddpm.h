@@ -234,6 +234,27 @@ int mi_debug_wgrad_tr_phase(int phase);
 /* test aid: plan the k-slices for `blocks` workgroups instead of one per CU (0 = default) */
 int mi_debug_wgrad_tr_blocks(int blocks);
 
+/* The stride-2 layers' weight gradients for bf16-stored operands on the same machinery (csrc/wgrad_s2_tr.hip):
+ *   Downsample Conv2d(C, C, 3, 2, 1), ddpm.py:70:           descriptor KH = KW = 3, stride 2, pad 1, gather_i = 1, (GH, GW) = X's grid =
+ *                                                            2 x (DH, DW) = dY's grid, P = X, Q = dY;
+ *   Upsample ConvTranspose2d(C, C, 4, 2, 1), ddpm.py:79:     KH = KW = 4, stride 2, pad 1, gather_i = 0, (GH, GW) = dY's grid =
+ *                                                            2 x (DH, DW) = X's grid, P = X, Q = dY.
+ * dW[KH][KW][Ci][Cj] += result.  The 2x-resolution tensor is staged as even / odd column planes (LDS-DMA places every 16-byte piece
+ * individually), so the stride costs nothing; up to 8 layers per launch.  Needs DW in {8,16,32}, DH % (64/DW) == 0,
+ * N*DH*DW % 64 == 0, channels of the 2x tensor % 64 == 0, of the other % 32 == 0, strides % 8 == 0 (query _supported). */
+int mi_conv_s2_wgrad_tr_supported(const MiWgradDesc* d);
+size_t mi_conv_s2_wgrad_tr_batch_workspace(int n, const MiWgradDesc* descs);
+int mi_conv_s2_wgrad_tr_batch(int n, const MiWgradDesc* descs, const void* const* P, const void* const* Q, float* const* dW,
+                              void* workspace, size_t ws_bytes, void* stream);
+int mi_debug_wgrad_s2_tr_phase(int phase);
+
+/* One pass over an fp32 [M][C] tensor: y_bf16 (optional) = bf16(x), colsum (optional)[c] += sum_m x[m][c].  Backward: a residual-
+ * stream gradient that the LDS-DMA weight-gradient kernels want bf16-stored and whose column sums are the conv's bias gradient.
+ * workspace (optional; mi_f32_to_bf16_colsum_workspace bytes, 16-byte aligned) holds per-workgroup partial sums so that the pass runs
+ * on a full grid and a second small pass adds them; without it the sums are added atomically from at most 64 workgroups. */
+size_t mi_f32_to_bf16_colsum_workspace(size_t M, int C);
+int mi_f32_to_bf16_colsum(size_t M, int C, const float* x, int ldx, void* y_bf16, int ldy, float* colsum, void* workspace,
+                          size_t ws_bytes, void* stream);
 /* out[c] += sum_m x[m*ld + c]  (bias gradients) */
 int mi_colsum(int M, int C, const float* x, int ld, float* out, void* stream);
 

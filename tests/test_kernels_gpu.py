@@ -673,6 +673,66 @@ def test_conv1x1_wgrad_queue(K):
             assert rel_err(db, bref) < 1e-5, (Ci, Co)
 
 
+@pytest.mark.parametrize("shape", [(128, 32, 32, 128), (16, 16, 16, 256), (3, 8, 8, 64), (2, 8, 8, 1024), (5, 7, 9, 36)])
+def test_to_bf16_with_column_sums(K, shape):
+    """mi_f32_to_bf16_colsum: the bf16 copy equals torch's round-to-nearest-even, the column sums (added onto what is there) equal an
+    fp64 sum -- full tensors (two-pass through the scratch buffer) and small ones (atomics), a channel slice as input, sums alone."""
+    g = torch.Generator().manual_seed(59)
+    N, H, W, Cc = shape
+    full = torch.randn(N, H, W, 2 * Cc, generator=g).to(DEV)
+    x = full[..., :Cc]                                                   # pixel stride 2C
+    out = torch.full((Cc,), 0.5, device=DEV)
+    y = K.to_bf16(x, colsum_out=out)
+    ref = x.double().sum((0, 1, 2)).cpu() + 0.5
+    assert torch.equal(y.cpu(), x.contiguous().bfloat16().cpu())
+    assert float((out.double().cpu() - ref).abs().max()) < 2e-5 * float(x.abs().double().sum((0, 1, 2)).max()), shape
+    out2 = torch.zeros(Cc, device=DEV)
+    K.colsum(x, out2)
+    assert float((out2.double().cpu() - (ref - 0.5)).abs().max()) < 2e-5 * float(x.abs().double().sum((0, 1, 2)).max()), shape
+
+
+def test_stride2_wgrad_lds_dma_queue(K):
+    """K.WgradQueue.push_s2: Downsample (3x3 / stride 2 conv) and Upsample (4x4 / stride 2 transposed conv) weight gradients through
+    mi_conv_s2_wgrad_tr_batch -- the cfg-2 and cfg-3 layer shapes at a small batch, a ragged small-side channel count, image
+    borders on every side -- against fp64 on the same bf16 operands; layers in one launch must not disturb each other."""
+    g = torch.Generator().manual_seed(53)
+    layers = [dict(kind="down", N=4, h=16, C=128), dict(kind="down", N=8, h=8, C=256), dict(kind="up", N=8, h=8, C=256),
+              dict(kind="up", N=4, h=16, C=128), dict(kind="down", N=2, h=32, C=64), dict(kind="up", N=2, h=32, C=64),
+              dict(kind="down", N=8, h=8, C=192, Co=96), dict(kind="up", N=8, h=8, C=96, Co=192), dict(kind="up", N=4, h=16, C=64),
+              dict(kind="down", N=16, h=8, C=64)]
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+    q = K.WgradQueue(group=8)
+    checks = []
+    for L in layers:
+        N, h, Ci, Co = L["N"], L["h"], L["C"], L.get("Co", L["C"])
+        if L["kind"] == "down":
+            x = torch.randn(N, Ci, 2 * h, 2 * h, generator=g).bfloat16()
+            dy = torch.randn(N, Co, h, h, generator=g).bfloat16()
+            w = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+            F.conv2d(x.double(), w, None, stride=2, padding=1).backward(dy.double())
+            dW = torch.zeros(9 * Ci * Co, device=DEV)
+            ok = q.push_s2(nh(x), nh(dy), dW, k=3, Ci=Ci, Cj=Co, gather_i=True, grid_g=(2 * h, 2 * h), grid_d=(h, h), mode=1)
+            checks.append((dW, 3, Ci, Co, w.grad, False))
+        else:
+            x = torch.randn(N, Ci, h, h, generator=g).bfloat16()
+            dy = torch.randn(N, Co, 2 * h, 2 * h, generator=g).bfloat16()
+            w = torch.zeros(Ci, Co, 4, 4, dtype=torch.float64, requires_grad=True)
+            F.conv_transpose2d(x.double(), w, None, stride=2, padding=1).backward(dy.double())
+            dW = torch.zeros(16 * Ci * Co, device=DEV)
+            ok = q.push_s2(nh(x), nh(dy), dW, k=4, Ci=Ci, Cj=Co, gather_i=False, grid_g=(2 * h, 2 * h), grid_d=(h, h), mode=1)
+            checks.append((dW, 4, Ci, Co, w.grad, True))
+        assert ok, L
+    assert q.pushed == 10 and q.flushed == 8
+    q.flush()
+    torch.cuda.synchronize()
+    assert q.flushed == 10
+    for dW, k, Ci, Co, ref, tr in checks:
+        assert rel_err(w_from_storage(dW.view(k, k, Ci, Co), transposed=tr), ref) < 2e-5, (k, Ci, Co)
+    # fp32 operands and other geometries are refused (the caller falls back to conv_wgrad)
+    assert not q.push_s2(torch.zeros(2, 16, 16, 64, device=DEV), torch.zeros(2, 8, 8, 64, device=DEV).bfloat16(), torch.zeros(9 * 64 * 64, device=DEV),
+                         k=3, Ci=64, Cj=64, gather_i=True, grid_g=(16, 16), grid_d=(8, 8), mode=1)
+
+
 def test_wgrad_queue_flushed_means_every_earlier_layer_is_out(K):
     """The gradient reducer releases a parameter range once `flushed` covers the layers pushed before it.  The two kinds flush
     independently: a full group of 1x1 layers going out must NOT count a 3x3 layer pushed before them as issued."""
