@@ -337,16 +337,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-template <int BM, int BN>
+// IN16: the activations are a bf16 tensor (a copy the caller already has: the skip connection's, the one the weight gradient reads).
+// A 16-byte load is then 8 channels, so the same loads per thread cover a 64-channel stage: half the barriers per MFMA, half the
+// bytes, no pack on the way into LDS.
+template <int BM, int BN, bool IN16>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_fast_kernel(const IgemmArgs a, const FastTaps tt) {
-    constexpr int PITCH = 40;
-    constexpr int A_IT = BM / 32;          // 16-byte activation loads per thread per stage (BM rows x 32 channels)
-    constexpr int B_IT = BN / 64;          // 16-byte weight loads per thread per stage (BN rows x 32 k, bf16)
+    constexpr int CK = IN16 ? 64 : 32;     // channels per stage
+    constexpr int KS = CK / 16;            // MFMA k-steps per stage
+    constexpr int PITCH = CK + 8;
+    constexpr int A_IT = BM / 32;          // 16-byte activation loads per thread per stage (BM rows x CK channels)
+    constexpr int BROWS = 256 / (CK / 8);  // weight rows covered by one 16-byte load per thread
+    constexpr int B_IT = BN / BROWS;       // 16-byte weight loads per thread per stage (BN rows x CK k, bf16)
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int ABUF = (BM + BN) * PITCH;
 
-    __shared__ __attribute__((aligned(16))) uint16_t lds[2 * ABUF];
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];         // 2 * ABUF
 
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int wm = wv >> 1, wn = wv & 1;
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_fas
     const int s = a.stride, cls = blockIdx.z;
     const int py = a.transposed ? cls / s : 0, px = a.transposed ? cls % s : 0;
     const int ntap = tt.ntap[cls];
-    const int nchunks = a.K / 32;
+    const int nchunks = a.K / CK;
     const int nsteps = ntap * nchunks;
 
     MI_TSI(0);
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_fas
         }
         amask[i] = mk;
     }
-    const int b_row = t >> 2, b_k8 = t & 3;
+    const int b_row = t / (CK / 8), b_k8 = t % (CK / 8);
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -388,13 +394,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_fas
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[3][A_IT]; u32x4 rb[3][B_IT]; uint32_t rk[3];
+    u32x4 ra[3][A_IT]; u32x4 rb[3][B_IT]; uint32_t rk[3];      // ra: 4 fp32 or (IN16) 8 bf16 channels
     int lti = 0, lkc = 0;                   // load cursor: (tap index in the class, channel offset) of the next stage
 
-    auto load_stage = [&](f32x4 (&A)[A_IT], u32x4 (&B)[B_IT], uint32_t& keep) {
+    auto load_stage = [&](u32x4 (&A)[A_IT], u32x4 (&B)[B_IT], uint32_t& keep) {
         const int dpix = tt.dpix[cls * 16 + lti];
         const bool second = lkc >= a.K1;
-        const float* src = (second ? a.x2 : a.x) + (second ? lkc - a.K1 : lkc) + ac4 * 4;
+        const int coff = (second ? lkc - a.K1 : lkc) + ac4 * (IN16 ? 8 : 4);
         const int ld = second ? a.ldx2 : a.ldx;
         uint32_t kp = 0;
 #pragma unroll
@@ -402,42 +408,47 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_fas
             const uint32_t ok = (amask[i] >> lti) & 1u;
             kp |= ok << i;
             const int pix = ok ? apix[i] + dpix : 0;
-            A[i] = *reinterpret_cast<const f32x4*>(src + (size_t)pix * ld);
+            if constexpr (IN16) A[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(second ? a.x2 : a.x) + (size_t)pix * ld + coff);
+            else A[i] = *reinterpret_cast<const u32x4*>((second ? a.x2 : a.x) + (size_t)pix * ld + coff);
         }
         keep = kp;
         const uint16_t* wsrc = a.wb + (size_t)tt.tap[cls * 16 + lti] * a.Nc * a.K + lkc + b_k8 * 8;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int n = min(n0 + b_row + 64 * i, a.Nc - 1);          // rows past Nc: their columns are never written
+            const int n = min(n0 + b_row + BROWS * i, a.Nc - 1);       // rows past Nc: their columns are never written
             B[i] = *reinterpret_cast<const u32x4*>(wsrc + (size_t)n * a.K);
         }
         // advance the cursor; past the end it stays on the last stage (a harmless re-read)
-        lkc += 32;
+        lkc += CK;
         if (lkc >= a.K) { lkc = 0; ++lti; }
-        if (lti >= ntap) { lti = ntap - 1; lkc = a.K - 32; }
+        if (lti >= ntap) { lti = ntap - 1; lkc = a.K - CK; }
     };
-    auto store_stage = [&](int buf, const f32x4 (&A)[A_IT], const u32x4 (&B)[B_IT], uint32_t keep, uint32_t live) {
+    auto store_stage = [&](int buf, const u32x4 (&A)[A_IT], const u32x4 (&B)[B_IT], uint32_t keep, uint32_t live) {
         uint16_t* As = lds + buf * ABUF;
         uint16_t* Bs = As + BM * PITCH;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const uint32_t m = 0u - ((keep >> i) & 1u);
-            *reinterpret_cast<u32x2*>(&As[((t >> 3) + 32 * i) * PITCH + ac4 * 4]) =
-                u32x2{pack_bf16(A[i].x, A[i].y) & m, pack_bf16(A[i].z, A[i].w) & m};
+            if constexpr (IN16) {
+                *reinterpret_cast<u32x4*>(&As[((t >> 3) + 32 * i) * PITCH + ac4 * 8]) = A[i] & m;
+            } else {
+                const f32x4 v = __builtin_bit_cast(f32x4, A[i]);
+                *reinterpret_cast<u32x2*>(&As[((t >> 3) + 32 * i) * PITCH + ac4 * 4]) = u32x2{pack_bf16(v.x, v.y) & m, pack_bf16(v.z, v.w) & m};
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            *reinterpret_cast<u32x4*>(&Bs[(b_row + 64 * i) * PITCH + b_k8 * 8]) = B[i] & live;
+            *reinterpret_cast<u32x4*>(&Bs[(b_row + BROWS * i) * PITCH + b_k8 * 8]) = B[i] & live;
     };
     const int arow = (wm * WM + (l & 31)) * PITCH + (l >> 5) * 8, brow = (wn * WN + (l & 31)) * PITCH + (l >> 5) * 8;
     // one step = fragment reads of the current buffer, then the LDS stores of the next stage (they drain under the
     // MFMAs), then the MFMAs
-    bf16x8 af[2][MI], bf[2][NI];
+    bf16x8 af[KS][MI], bf[KS][NI];
     auto read_frags = [&](int buf) {
         const uint16_t* As = lds + buf * ABUF;
         const uint16_t* Bs = As + BM * PITCH;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(&As[arow + 32 * i * PITCH + ks * 16]);
 #pragma unroll
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_fas
     };
     auto mma_frags = [&]() {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -535,17 +546,27 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_fas
     MI_TSI(3);
 }
 
-template <int BM, int BN>
-int launch_fast(const IgemmArgs& a, const FastTaps& tt, int classes, hipStream_t st) {
+template <int BM, int BN, bool IN16>
+int launch_fast_t(const IgemmArgs& a, const FastTaps& tt, int classes, hipStream_t st) {
     dim3 grid((a.Mc + BM - 1) / BM, (a.Nc + BN - 1) / BN, classes);
-    hipLaunchKernelGGL((igemm_fast_kernel<BM, BN>), grid, dim3(256), 0, st, a, tt);
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * ((IN16 ? 64 : 32) + 8) * sizeof(uint16_t);
+    static bool once = [] {
+        (void)hipFuncSetAttribute((const void*)igemm_fast_kernel<BM, BN, IN16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL((igemm_fast_kernel<BM, BN, IN16>), grid, dim3(256), lds, st, a, tt);
     return 0;
+}
+template <int BM, int BN>
+int launch_fast(const IgemmArgs& a, const FastTaps& tt, int classes, bool in16, hipStream_t st) {
+    return in16 ? launch_fast_t<BM, BN, true>(a, tt, classes, st) : launch_fast_t<BM, BN, false>(a, tt, classes, st);
 }
 
 }  // namespace
 
 static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, const float* w, const uint16_t* wb,
-                          const float* bias, const float* residual, float* y, void* stream);
+                          const float* bias, const float* residual, float* y, void* stream, bool in16 = false);
 
 extern "C" int mi_conv_igemm(const MiConvDesc* d, const float* x, const float* x2, const float* w,
                              const float* bias, const float* residual, float* y, void* stream) {
@@ -561,13 +582,31 @@ extern "C" int mi_conv_igemm_bf16w(const MiConvDesc* d, const float* x, const fl
     return igemm_dispatch(d, x, x2, (const float*)w_nk_bf16, (const uint16_t*)w_nk_bf16, bias, residual, y, stream);
 }
 
+// ... and bf16-stored activations (x_is_bf16: x / x2 are bf16 tensors, ldx / ldx2 in elements, % 8 == 0, K and K1 % 64 == 0): only
+// the shapes the ring kernel takes (the stride-2 conv, the transposed conv and their data gradients); query first.
+extern "C" int mi_conv_igemm_bf16w_io_supported(const MiConvDesc* d) {
+    if (!d || d->mode != 1 || d->K % 64 || d->K1 % 64 || d->ldx % 8 || (d->K1 != d->K && d->ldx2 % 8)) return 0;
+    if (d->KH * d->KW > 16 || d->KH * d->KW == 1) return 0;
+    if (d->transposed && d->stride > 1 && (d->OH % d->stride || d->OW % d->stride || d->stride != 2)) return 0;
+    return 1;
+}
+extern "C" int mi_conv_igemm_bf16w_io(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16,
+                                      const float* bias, const float* residual, float* y, int x_is_bf16, void* stream) {
+    if (!x_is_bf16) return mi_conv_igemm_bf16w(d, (const float*)x, (const float*)x2, w_nk_bf16, bias, residual, y, stream);
+    if (!mi_conv_igemm_bf16w_io_supported(d) || !w_nk_bf16 || (((uintptr_t)w_nk_bf16 | (uintptr_t)x | (uintptr_t)(x2 ? x2 : x)) & 15))
+        return mi_set_error(-1, "mi_conv_igemm_bf16w_io: bf16 activations need mode 1, K / K1 %% 64 == 0, ldx %% 8 == 0, 16-byte aligned "
+                                "operands and a stride-2 / multi-tap layer (mi_conv_igemm_bf16w_io_supported)");
+    return igemm_dispatch(d, (const float*)x, (const float*)x2, (const float*)w_nk_bf16, (const uint16_t*)w_nk_bf16, bias, residual, y, stream, true);
+}
+
 static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, const float* w, const uint16_t* wb,
-                          const float* bias, const float* residual, float* y, void* stream) {
+                          const float* bias, const float* residual, float* y, void* stream, bool in16) {
     MI_REQUIRE(d && x && w && y, "null argument");
     MI_REQUIRE(d->N > 0 && d->K > 0 && d->Nc > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0, "bad sizes");
     MI_REQUIRE(d->mode == 0 || d->mode == 1, "mode must be 0 (fp32) or 1 (bf16)");
     MI_REQUIRE(d->K1 == d->K || (x2 && d->K1 > 0 && d->K1 < d->K && d->K1 % 4 == 0), "bad two-source split");
     MI_REQUIRE(d->ldx % 4 == 0 && d->ldy >= d->Nc, "ldx must be a multiple of 4, ldy >= Nc");
+    MI_REQUIRE(!in16 || d->K1 == d->K || d->K1 % 64 == 0, "bf16 activations: K1 % 64 == 0");
     IgemmArgs a;
     a.x = x; a.x2 = x2 ? x2 : x; a.w = w; a.wb = wb; a.bias = bias; a.res = residual; a.y = y;
     a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW; a.K = d->K; a.Nc = d->Nc;
@@ -635,14 +674,15 @@ static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, 
         if (ok) {
             static const int force = [] { const char* e = getenv("MI_IGEMM_TILE"); return e ? atoi(e) : 0; }();   // 11 / 10 / 01 / 00 = bm64,bn64 (profiling)
             if (force) { bm64 = (force / 10) % 10 == 1; bn64 = force % 10 == 1; if (force == 100) { bm64 = false; bn64 = false; } }
-            if (!bm64 && !bn64) launch_fast<128, 128>(a, tt, classes, st);
-            else if (!bm64 && bn64) launch_fast<128, 64>(a, tt, classes, st);
-            else if (bm64 && !bn64) launch_fast<64, 128>(a, tt, classes, st);
-            else launch_fast<64, 64>(a, tt, classes, st);
+            if (!bm64 && !bn64) launch_fast<128, 128>(a, tt, classes, in16, st);
+            else if (!bm64 && bn64) launch_fast<128, 64>(a, tt, classes, in16, st);
+            else if (bm64 && !bn64) launch_fast<64, 128>(a, tt, classes, in16, st);
+            else launch_fast<64, 64>(a, tt, classes, in16, st);
             MI_LAUNCH_CHECK();
             return 0;
         }
     }
+    MI_REQUIRE(!in16, "bf16 activations: the layer does not fit the ring kernel (mi_conv_igemm_bf16w_io_supported)");
 #define MI_GO(MODE) \
     do { if (!bm64 && !bn64) launch<MODE, 128, 128>(a, classes, st); \
          else if (!bm64 && bn64) launch<MODE, 128, 64>(a, classes, st); \

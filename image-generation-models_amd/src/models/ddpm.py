@@ -456,6 +456,9 @@ class Unet(nn.Module):
         use_sh = (record and mode == K.MODE_BF16 and self.block_storage in ("bf16", "auto")
                   and os.environ.get("MI_DDPM_SHADOW", "1") == "1")
 
+        def s2_copy(c, k, transposed):      # Downsample / Upsample read (and their weight gradients want) a bf16 copy of their input
+            return (use_sh and self.s2_wgrad_tr and K.igemm_bf16_in_supported(c, c, k, 2, transposed, mode, (8, 8)))
+
         def shadow(t):
             ent = sh.get(id(t))
             if ent is None:
@@ -476,12 +479,14 @@ class Unet(nn.Module):
                                     bias=sv[pre + "bias"] if bias else None, residual=residual, out_dtype=out_dtype)
                 if y is not None:
                     return y
-            assert out_dtype == torch.float32 and inp.dtype == torch.float32, "bf16 block storage needs the tile kernel"
             ih, iw = inp.shape[1], inp.shape[2]
             if transposed_conv:
                 oh, ow = ih * stride, iw * stride
             else:
                 oh, ow = (ih + 2 * pad - kh) // stride + 1, (iw + 2 * pad - kw) // stride + 1
+            assert out_dtype == torch.float32 and (inp.dtype == torch.float32 or (
+                stride == 2 and K.igemm_bf16_in_supported(ci, co, k, stride, transposed_conv, mode, (oh, ow)))), \
+                "bf16 block storage needs the tile kernel"
             y = K.conv_igemm(inp, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=transposed_conv, w_kn=True,
                              K=ci, Nc=co, out_hw=(oh, ow), mode=mode, x2=x2,
                              bias=sv[pre + "bias"] if bias else None, residual=residual,
@@ -552,9 +557,11 @@ class Unet(nn.Module):
             skips.append(h)
             if lvl["down"] is not None:
                 inp = h
-                h = conv(inp, lvl["down"]["pre"], 3, 2, 1)
-                if record:    # the skip tensor's bf16 copy (its consumer in the up path wants it too) feeds Downsample's weight gradient
-                    tape.append(("down", lvl["down"], inp, h, shadow(inp) if use_sh and self.s2_wgrad_tr else None))
+                # training: the skip tensor's bf16 copy (its consumer in the up path wants it too) feeds Downsample and its weight gradient
+                inp_c = shadow(inp) if s2_copy(inp.shape[3], 3, False) else None
+                h = conv(inp if inp_c is None else inp_c, lvl["down"]["pre"], 3, 2, 1)
+                if record:
+                    tape.append(("down", lvl["down"], inp, h, inp_c))
         h = resblock(A.mid1, h)
         h = attention(A.mid_attn, h)
         h = resblock(A.mid2, h, want_out16=True)                  # feeds the first up block's conv
@@ -563,9 +570,10 @@ class Unet(nn.Module):
             h = resblock(lvl["res2"], h)
             h = attention(lvl["attn"], h)
             inp = h
-            h = conv(inp, lvl["up"]["pre"], 4, 2, 1, transposed_conv=True)
+            inp_c = shadow(inp) if s2_copy(inp.shape[3], 4, True) else None
+            h = conv(inp if inp_c is None else inp_c, lvl["up"]["pre"], 4, 2, 1, transposed_conv=True)
             if record:
-                tape.append(("up", lvl["up"], inp, h, None))
+                tape.append(("up", lvl["up"], inp, h, inp_c))
         cF = conv(h, "final_conv.0.block.0.", 3, 1, 1)
         hF, stF = K.gn_mish_fwd(cF, sv["final_conv.0.block.1.weight"], sv["final_conv.0.block.1.bias"])
         eps = conv(hF, "final_conv.1.", 1)
@@ -601,13 +609,13 @@ class Unet(nn.Module):
             it into the bias gradient)."""
             big, small = (ohw, ihw) if transposed_conv else (ihw, ohw)
             if dy.dtype != torch.float32 or not K.s2_wgrad_supported(inp.shape[0], k, ci, co, transposed_conv, big, small, mode):
-                return False
+                return None
             x16 = inp if inp.dtype == torch.bfloat16 else K.to_bf16(inp)
             dy16 = K.to_bf16(dy, colsum_out=gv[pre + "bias"] if bias == "colsum" else None)
             ok = wq.push_s2(x16, dy16, gv[pre + "weight"], k=k, Ci=ci, Cj=co, gather_i=not transposed_conv, grid_g=big, grid_d=small,
                             mode=mode)
             assert ok
-            return True
+            return dy16
 
         def conv_bwd(dy, inp, pre, k, stride=1, pad=0, x2=None, transposed_conv=False, bias="colsum", want_dx=True, winp=None, wx2=None):
             """Gradients of y = conv(inp [|x2]); dy may be a channel slice.  The gradient wrt inp has inp's dtype
@@ -619,6 +627,7 @@ class Unet(nn.Module):
             oh, ow = dy.shape[1], dy.shape[2]
             winp = inp if winp is None else winp
             wx2 = x2 if wx2 is None else wx2
+            dy16 = None
             if (x2 is None and stride == 1 and not transposed_conv and k == 1 and K.small_cout_supported(2, ci, co)
                     and K.small_cout_supported(1, ci, co)):
                 K.conv1x1_small_cout(2, inp, None, b=dy, out=gv[pre + "weight"])
@@ -631,8 +640,8 @@ class Unet(nn.Module):
             small_cin = x2 is None and stride == 1 and not transposed_conv and K.small_cin_supported(k, ci, co, wgrad=True)
             if small_cin:
                 K.conv_small_cin_wgrad(inp, dy, gv[pre + "weight"], k)
-            elif stride == 2 and mode == K.MODE_BF16 and self.s2_wgrad_tr and s2_push(dy, winp, pre, kh, ci, co, transposed_conv,
-                                                                                      (ih, iw), (oh, ow), bias):
+            elif (stride == 2 and mode == K.MODE_BF16 and self.s2_wgrad_tr and
+                  (dy16 := s2_push(dy, winp, pre, kh, ci, co, transposed_conv, (ih, iw), (oh, ow), bias)) is not None):
                 bias = None                                           # Downsample / Upsample: deferred, bias gradient rode along
             elif transposed_conv:   # dW[tap][ci][co] = sum over input pixels  x[j] * dy[gather(j, tap)]
                 K.conv_wgrad(inp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=False,
@@ -665,6 +674,8 @@ class Unet(nn.Module):
                                             accumulate=acc) is not None:
                     return
                 assert dy.dtype == torch.float32 and buf.dtype == torch.float32, "bf16 block storage needs the tile kernel"
+                if dy16 is not None and K.igemm_bf16_in_supported(co, ci, k, stride, not transposed_conv, mode, (ih, iw)):
+                    dy = dy16                                         # the copy the weight gradient reads: half the bytes, 64-channel stages
                 K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=not transposed_conv, w_kn=False,
                              K=co, Nc=ci, out_hw=(ih, iw), mode=mode, out=buf, accumulate=acc,
                              wb=wd_sh[offs[pre + "weight"]:] if mode == K.MODE_BF16 else None)

@@ -93,6 +93,13 @@ def _b16(t) -> int:
 
 
 # --------------------------------------------------------------------------- conv family
+def igemm_bf16_in_supported(K, Nc, k, stride, transposed, mode, out_hw):
+    """Can conv_igemm read bf16-stored activations for this layer (the stride-2 conv / transposed conv family, dense tensors)?"""
+    d = MiConvDesc(N=1, IH=1, IW=1, OH=out_hw[0], OW=out_hw[1], K=K, Nc=Nc, KH=k, KW=k, stride=stride, pad=1, transposed=int(transposed),
+                   w_kn=0, mode=mode, K1=K, ldx=K, ldx2=0, ldy=Nc, ldr=0, accumulate=0)
+    return bool(load_library().mi_conv_igemm_bf16w_io_supported(C.byref(d)))
+
+
 def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mode, x2=None,
                bias=None, residual=None, out=None, accumulate=False, wb=None):
     """y = conv(x [| x2]) per MiConvDesc.  x: [N,IH,IW,K1], x2: [N,IH,IW,K-K1] or None."""
@@ -116,7 +123,13 @@ def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mo
         load_library().mi_conv_igemm_tile(C.byref(d), C.byref(bm), C.byref(bn))
         flops = 2.0 * N * OH * OW * Nc * K * (kh * kw if not (transposed and stride > 1) else kh * kw / (stride * stride))
         e0 = _probe_open()
-    if wb is not None and mode == MODE_BF16 and K % 8 == 0:      # bf16 weight copy [tap][Nc][K]
+    in16 = _b16(x)
+    if in16:                                                     # bf16-stored activations: ring kernel with 64-channel stages
+        if wb is None or mode != MODE_BF16 or (x2 is not None and not _b16(x2)) or not load_library().mi_conv_igemm_bf16w_io_supported(C.byref(d)):
+            raise RuntimeError("bf16-stored activations: layer not supported (check igemm_bf16_in_supported first)")
+        check(load_library().mi_conv_igemm_bf16w_io(C.byref(d), _p(x), _p(x2), _p(wb), _p(bias), _p(residual), _p(out), 1, _stream()),
+              "mi_conv_igemm_bf16w_io")
+    elif wb is not None and mode == MODE_BF16 and K % 8 == 0:    # bf16 weight copy [tap][Nc][K]
         check(load_library().mi_conv_igemm_bf16w(C.byref(d), _p(x), _p(x2), _p(wb), _p(bias), _p(residual), _p(out), _stream()),
               "mi_conv_igemm_bf16w")
     else:
@@ -125,7 +138,7 @@ def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mo
     if PROBE is not None:
         fast = wb is not None and mode == MODE_BF16 and K % 8 == 0
         nb = N * IH * IW * K * _esz(x) + N * OH * OW * Nc * _esz(out) * (2 if accumulate else 1) + kh * kw * K * Nc * (2 if fast else 4)
-        _probe_close(e0, f"igemm{'_fast' if fast else ''}_kernel<{mode},{bm.value},{bn.value}>", flops,
+        _probe_close(e0, f"igemm{'_fast' if fast else ''}_kernel<{mode},{bm.value},{bn.value}{',in16' if in16 else ''}>", flops,
                      f"N{N} {IH}x{IW}->{OH}x{OW} K{K}->{Nc} k{kh} s{stride} T{int(transposed)} acc{int(accumulate)}", nb)
     return out
 

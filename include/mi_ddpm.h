@@ -72,6 +72,13 @@ int mi_conv_igemm(const MiConvDesc* d, const float* x, const float* x2, const fl
  * used for the stride-2 / transposed convolutions */
 int mi_conv_igemm_bf16w(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
                         const float* bias, const float* residual, float* y, void* stream);
+/* ... with bf16-STORED activations (x_is_bf16 != 0: x / x2 are bf16 tensors, strides in elements and % 8 == 0, K and K1 % 64 == 0):
+ * the Downsample conv, the Upsample transposed conv and their data gradients (ddpm.py:70,79) read the bf16 copies that the
+ * skip connection / the weight gradient already have -- a 16-byte load is 8 channels, so a ring stage covers 64 channels (half the
+ * barriers per MFMA, half the bytes, no pack).  Only layers the ring kernel takes; query _supported first.  y stays fp32. */
+int mi_conv_igemm_bf16w_io_supported(const MiConvDesc* d);
+int mi_conv_igemm_bf16w_io(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16,
+                           const float* bias, const float* residual, float* y, int x_is_bf16, void* stream);
 /* tile instantiation mi_conv_igemm will launch for d (BM x BN); used to attribute profiles */
 int mi_conv_igemm_tile(const MiConvDesc* d, int* bm, int* bn);
 

@@ -99,6 +99,53 @@ def test_conv_dgrad_and_wgrad(K, mode, cfg):
     assert rel_err(from_nhwc(dx2), 2 * x.grad) < TOL[mode]
 
 
+@pytest.mark.parametrize("cfg", [dict(N=4, h=16, C=128), dict(N=8, h=8, C=256), dict(N=2, h=32, C=64), dict(N=3, h=8, C=64, Co=192)])
+def test_stride2_family_reads_bf16_activations(K, cfg):
+    """mi_conv_igemm_bf16w_io: Downsample (3x3 / stride 2), Upsample (4x4 / stride 2 transposed) and both data gradients with
+    bf16-STORED activations (64-channel ring stages) against fp64 on the same bf16-rounded operands; accumulate and bias."""
+    g = torch.Generator().manual_seed(61)
+    N, h, Ci = cfg["N"], cfg["h"], cfg["C"]
+    Co = cfg.get("Co", Ci)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+    # Downsample forward + its data gradient
+    x = torch.randn(N, Ci, 2 * h, 2 * h, generator=g).bfloat16()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)).bfloat16()
+    b = torch.randn(Co, generator=g)
+    xd = x.double().requires_grad_(True)
+    y = F.conv2d(xd, w.double(), b.double(), stride=2, padding=1)
+    dy = torch.randn(y.shape, generator=g).bfloat16()
+    y.backward(dy.double())
+    ws = conv_w_storage(w.float())                                      # [kh][kw][ci][co]
+    wf, wd = ws.permute(0, 1, 3, 2).contiguous().bfloat16(), ws.bfloat16()
+    assert K.igemm_bf16_in_supported(Ci, Co, 3, 2, False, 1, (h, h))
+    yg = K.conv_igemm(nh(x), ws, kh=3, kw=3, stride=2, pad=1, transposed=False, w_kn=True, K=Ci, Nc=Co, out_hw=(h, h), mode=1,
+                      bias=b.to(DEV), wb=wf)
+    dxg = K.conv_igemm(nh(dy), ws, kh=3, kw=3, stride=2, pad=1, transposed=True, w_kn=False, K=Co, Nc=Ci, out_hw=(2 * h, 2 * h), mode=1, wb=wd)
+    dx2 = K.conv_igemm(nh(dy), ws, kh=3, kw=3, stride=2, pad=1, transposed=True, w_kn=False, K=Co, Nc=Ci, out_hw=(2 * h, 2 * h), mode=1, wb=wd,
+                       out=dxg.clone(), accumulate=True)
+    torch.cuda.synchronize()
+    assert yg.dtype == torch.float32 and rel_err(from_nhwc(yg), y) < 2e-5
+    assert rel_err(from_nhwc(dxg), xd.grad) < 2e-5 and rel_err(from_nhwc(dx2), 2 * xd.grad) < 2e-5
+    # Upsample forward + its data gradient
+    x = torch.randn(N, Ci, h, h, generator=g).bfloat16()
+    w = (torch.randn(Ci, Co, 4, 4, generator=g) / math.sqrt(Ci * 4)).bfloat16()
+    xd = x.double().requires_grad_(True)
+    y = F.conv_transpose2d(xd, w.double(), b.double(), stride=2, padding=1)
+    dy = torch.randn(y.shape, generator=g).bfloat16()
+    y.backward(dy.double())
+    ws = conv_w_storage(w.float(), transposed=True)
+    wf, wd = ws.permute(0, 1, 3, 2).contiguous().bfloat16(), ws.bfloat16()
+    yg = K.conv_igemm(nh(x), ws, kh=4, kw=4, stride=2, pad=1, transposed=True, w_kn=True, K=Ci, Nc=Co, out_hw=(2 * h, 2 * h), mode=1,
+                      bias=b.to(DEV), wb=wf)
+    dxg = K.conv_igemm(nh(dy), ws, kh=4, kw=4, stride=2, pad=1, transposed=False, w_kn=False, K=Co, Nc=Ci, out_hw=(h, h), mode=1, wb=wd)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(yg), y) < 2e-5 and rel_err(from_nhwc(dxg), xd.grad) < 2e-5
+    # a layer the ring kernel does not take is refused, not silently converted
+    with pytest.raises(RuntimeError):
+        K.conv_igemm(torch.zeros(2, 8, 8, 32, device=DEV).bfloat16(), torch.zeros(3, 3, 32, 32, device=DEV), kh=3, kw=3, stride=2, pad=1,
+                     transposed=False, w_kn=True, K=32, Nc=32, out_hw=(4, 4), mode=1, wb=torch.zeros(9 * 32 * 32, device=DEV).bfloat16())
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("C", [32, 128])
 def test_conv_transpose_all(K, mode, C):
