@@ -30,20 +30,34 @@ struct DmaConvArgs {
     int TH, TI, HP, tiles_per_img, xmap;
 };
 
-constexpr int BM = 128, BN = 128, CK = 64;
+constexpr int BM = 128, BN = 128;
 constexpr int MAXHP = 208;                       // halo pixels: 4 rows of 32 (6 x 34 = 204), 8 of 16 (180), two 8x8 images (200)
-constexpr int XBUF = MAXHP * 128;                // one halo buffer
-constexpr int WSTG = 3 * BN * 128;               // weights of one stage: three taps x 128 output channels x 64 input channels
-constexpr int XOFF = 0, WOFF = 2 * XBUF, PIXOFF = WOFF + 2 * WSTG;     // + int[MAXHP] source pixel of each halo pixel
 constexpr int PD = 2;                            // (tap, k-step) units fetched ahead
+// CK = channels per chunk.  64: one workgroup per CU (148 KB of LDS).  32: half the LDS (77 KB), so TWO independent workgroups
+// share a CU -- while one waits at its stage barrier, fetches its first tile or stores its outputs, the other one's waves keep the
+// matrix pipe busy (the 8-wave single-workgroup kernels stall both waves of a SIMD at every barrier).
+template <int CK> struct DmaShape {
+    static constexpr int ROWB = CK * 2;              // bytes of a pixel / an output channel of one tap in LDS
+    static constexpr int NCH = ROWB / 16;            // 16-byte chunks per row
+    static constexpr int PPI = 1024 / ROWB;          // rows one wave-wide DMA instruction covers
+    static constexpr int SH = CK == 64 ? 1 : 2;      // chunk position = chunk ^ ((row >> SH) & (NCH - 1)): 16 consecutive rows, one chunk -> all banks
+    static constexpr int XBUF = MAXHP * ROWB;        // one halo buffer
+    static constexpr int WSTG = 3 * BN * ROWB;       // weights of one stage: three taps x 128 output channels x CK input channels
+    static constexpr int XOFF = 0, WOFF = 2 * XBUF, PIXOFF = WOFF + 2 * WSTG;     // + int[MAXHP] source pixel of each halo pixel
+    static constexpr int KSN = CK / 16;              // MFMA k-steps per tap
+    static constexpr int NU = 3 * KSN;               // (tap, k-step) units per stage
+};
 
 __device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
     typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
     return *(lds_bf16x8*)(uintptr_t)addr;
 }
 
-template <bool OUT16>
-__global__ __launch_bounds__(256, 1) void conv_dma_kernel(const DmaConvArgs a) {
+template <int CK, bool OUT16>
+__global__ __launch_bounds__(256, (CK == 64 ? 1 : 2)) void conv_dma_kernel(const DmaConvArgs a) {
+    using Sh = DmaShape<CK>;
+    constexpr int ROWB = Sh::ROWB, NCH = Sh::NCH, PPI = Sh::PPI, SH = Sh::SH, XBUF = Sh::XBUF, WSTG = Sh::WSTG;
+    constexpr int XOFF = Sh::XOFF, WOFF = Sh::WOFF, PIXOFF = Sh::PIXOFF, KSN = Sh::KSN, NU = Sh::NU;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
     int* pix = reinterpret_cast<int*>(lds_raw + PIXOFF);
@@ -59,6 +73,7 @@ __global__ __launch_bounds__(256, 1) void conv_dma_kernel(const DmaConvArgs a) {
     const int W2 = a.W + 2, TH2 = a.TH + 2;
     const int Mtot = a.N * a.H * a.W;
     const int nchunks = a.K / CK;
+    static_assert(CK == 64 || CK == 32, "chunk width");
 
     // ---- halo pixel -> source pixel (or -1)
     {
@@ -77,23 +92,24 @@ __global__ __launch_bounds__(256, 1) void conv_dma_kernel(const DmaConvArgs a) {
         }
     }
     __syncthreads();
-    // DMA pieces of this lane.  X: instruction i of a wave covers halo pixels 8*(wv + 4*i) .. +7, lane -> pixel lane >> 3, stored
-    // chunk position lane & 7 holds channel chunk (lane & 7) ^ ((hp >> 1) & 7).
-    constexpr int NXI = (MAXHP / 8 + 3) / 4;             // 7 instructions per wave cover 224 >= MAXHP pixels
+    // DMA pieces of this lane.  X: instruction i of a wave covers halo pixels PPI*(wv + 4*i) .. +PPI-1, lane -> pixel lane / NCH,
+    // stored chunk position lane % NCH holds channel chunk (lane % NCH) ^ swizzle(hp).
+    constexpr int NXI = ((MAXHP + PPI - 1) / PPI + 3) / 4;
     int xpix[NXI], xcol[NXI];
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
-        const int hp = 8 * (wv + 4 * i) + (l >> 3);
+        const int hp = PPI * (wv + 4 * i) + l / NCH;
         xpix[i] = hp < MAXHP ? pix[hp] : -1;
-        xcol[i] = ((l & 7) ^ ((hp >> 1) & 7)) * 8;
+        xcol[i] = ((l % NCH) ^ ((hp >> SH) & (NCH - 1))) * 8;
     }
-    // W: instruction i of a wave covers output channels 8*(wv + 4*i) .. +7 of one tap (16 KB = 16 instructions, 4 per wave)
-    int wrow[4], wcol[4];
+    // W: instruction i of a wave covers output channels PPI*(wv + 4*i) .. of one tap (BN / PPI instructions per tap)
+    constexpr int NWI = BN / PPI / 4;
+    int wrow[NWI], wcol[NWI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = 8 * (wv + 4 * i) + (l >> 3);
+    for (int i = 0; i < NWI; ++i) {
+        const int n = PPI * (wv + 4 * i) + l / NCH;
         wrow[i] = min(n0 + n, a.Nc - 1);
-        wcol[i] = ((l & 7) ^ ((n >> 1) & 7)) * 8;
+        wcol[i] = ((l % NCH) ^ ((n >> SH) & (NCH - 1))) * 8;
     }
     const size_t tap_stride = (size_t)a.Nc * a.K;
     const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
@@ -105,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void conv_dma_kernel(const DmaConvArgs a) {
         const int ld = second ? a.ldx2 : a.ldx, cc = second ? kc - a.K1 : kc;
 #pragma unroll
         for (int i = 0; i < NXI; ++i) {
-            if (8 * (wv + 4 * i) < MAXHP) {              // wave-uniform: the last instruction slot of waves 2, 3 lies past the buffer
+            if (PPI * (wv + 4 * i) < MAXHP) {            // wave-uniform: the last instruction slots of some waves lie past the buffer
                 const uint16_t* p = xpix[i] >= 0 ? src + (size_t)xpix[i] * ld + cc + xcol[i] : zero + (l & 7) * 8;
                 glds16(p, lds0 + XOFF + (ch & 1) * XBUF + (wv + 4 * i) * 1024);
             }
@@ -118,8 +134,8 @@ __global__ __launch_bounds__(256, 1) void conv_dma_kernel(const DmaConvArgs a) {
             const int tap = ky * 3 + kx;
             const uint16_t* base = a.w + (size_t)(a.flip ? 8 - tap : tap) * tap_stride + (size_t)ch * CK;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                glds16(base + (size_t)wrow[i] * a.K + wcol[i], lds0 + WOFF + (st & 1) * WSTG + kx * (BN * 128) + (wv + 4 * i) * 1024);
+            for (int i = 0; i < NWI; ++i)
+                glds16(base + (size_t)wrow[i] * a.K + wcol[i], lds0 + WOFF + (st & 1) * WSTG + kx * (BN * ROWB) + (wv + 4 * i) * 1024);
         }
     };
 
@@ -138,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void conv_dma_kernel(const DmaConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = wn * 64 + j * 32 + (l & 31);
-        wb[j] = n * 128; wsw[j] = ((n >> 1) & 7) * 16;
+        wb[j] = n * ROWB; wsw[j] = ((n >> SH) & (NCH - 1)) * 16;
     }
 
     f32x16 acc[2][2];
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void conv_dma_kernel(const DmaConvArgs a) {
     stage_x(0);
     stage_w(0);
     const int nstages = nchunks * 3;
-    static_assert(12 % (PD + 1) == 0, "ring slots must line up across stages");
+    static_assert(NU % (PD + 1) == 0, "ring slots must line up across stages");
     for (int st = 0; st < nstages; ++st) {
         // stage st's weights (and halo tile) have landed: this wave's pieces; every LDS read this wave issued is complete ...
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -180,12 +196,12 @@ __global__ __launch_bounds__(256, 1) void conv_dma_kernel(const DmaConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int hp = hp0[i] + ky * W2 + kx;
-                xo[kx][i] = hp * 128; xs[kx][i] = ((hp >> 1) & 7) * 16;
+                xo[kx][i] = hp * ROWB; xs[kx][i] = ((hp >> SH) & (NCH - 1)) * 16;
             }
-        // 12 units = (tap column kx, k-step ks); a unit = 2 + 2 fragment reads and 4 MFMAs
-        static_for<0, 12>([&](auto uc) {
-            constexpr int u = decltype(uc)::value, kx = u / 4, ks = u % 4;
-            constexpr int ld_slot = u % (PD + 1), mm_slot = (u + 12 - PD) % (PD + 1);      // the unit PD behind (of stage st-1 for u < PD)
+        // NU units = (tap column kx, k-step ks); a unit = 2 + 2 fragment reads and 4 MFMAs
+        static_for<0, NU>([&](auto uc) {
+            constexpr int u = decltype(uc)::value, kx = u / KSN, ks = u % KSN;
+            constexpr int ld_slot = u % (PD + 1), mm_slot = (u + NU - PD) % (PD + 1);      // the unit PD behind (of stage st-1 for u < PD)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -194,12 +210,12 @@ __global__ __launch_bounds__(256, 1) void conv_dma_kernel(const DmaConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) FX[ld_slot][i] = lds_b128(xb + xo[kx][i] + ((ks * 32 + half16) ^ xs[kx][i]));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) FW[ld_slot][j] = lds_b128(wbase + kx * (BN * 128) + wb[j] + ((ks * 32 + half16) ^ wsw[j]));
+            for (int j = 0; j < 2; ++j) FW[ld_slot][j] = lds_b128(wbase + kx * (BN * ROWB) + wb[j] + ((ks * 32 + half16) ^ wsw[j]));
             __builtin_amdgcn_sched_barrier(0);
         });
     }
     static_for<0, PD>([&](auto qc) {                         // the last PD units
-        constexpr int mm_slot = (12 - PD + decltype(qc)::value) % (PD + 1);
+        constexpr int mm_slot = (NU - PD + decltype(qc)::value) % (PD + 1);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -266,6 +282,8 @@ __global__ __launch_bounds__(256, 1) void conv_dma_kernel(const DmaConvArgs a) {
     }
 }
 
+int g_dma_ck = [] { const char* e = getenv("MI_CONV_DMA_CK"); return (e && atoi(e) == 32) ? 32 : 64; }();
+
 bool dma_geom(const MiConvDesc* d, int* TH, int* TI) {
     const int W = d->OW, H = d->OH;
     if (BM % W) return false;
@@ -307,16 +325,31 @@ extern "C" int mi_conv3x3_dma(const MiConvDesc* d, const void* x, const void* x2
     a.HP = a.TI * (a.TH + 2) * (a.W + 2);
     a.xmap = a.TI == 1 && a.tiles_per_img > 1 && a.N % 8 == 0;
     const dim3 grid((unsigned)((long)d->N * d->OH * d->OW / BM), (unsigned)((d->Nc + BN - 1) / BN));
-    const size_t lds = (size_t)PIXOFF + MAXHP * 4;
     static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)conv_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_dma_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_dma_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_dma_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_dma_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         return true;
     }();
     (void)once;
     hipStream_t st = (hipStream_t)stream;
-    if (out_bf16) hipLaunchKernelGGL(conv_dma_kernel<true>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(conv_dma_kernel<false>, grid, dim3(256), lds, st, a);
+    if (g_dma_ck == 32) {
+        const size_t lds = (size_t)DmaShape<32>::PIXOFF + MAXHP * 4;
+        if (out_bf16) hipLaunchKernelGGL((conv_dma_kernel<32, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((conv_dma_kernel<32, false>), grid, dim3(256), lds, st, a);
+    } else {
+        const size_t lds = (size_t)DmaShape<64>::PIXOFF + MAXHP * 4;
+        if (out_bf16) hipLaunchKernelGGL((conv_dma_kernel<64, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((conv_dma_kernel<64, false>), grid, dim3(256), lds, st, a);
+    }
     MI_LAUNCH_CHECK();
+    return 0;
+}
+
+// 32: two workgroups per CU on 32-channel chunks; 64 (default): one workgroup per CU on 64-channel chunks
+extern "C" int mi_debug_conv_dma_chunk(int ck) {
+    if (ck != 32 && ck != 64) return mi_set_error(-1, "mi_debug_conv_dma_chunk: 32 or 64");
+    g_dma_ck = ck;
     return 0;
 }

@@ -17,7 +17,21 @@ struct AttnArgs {
     const float* qkv; float* out; float* ctx; float* kstat;
     const float* dout; float* dqkv;
     int B, n, heads, ldq;        // ldq = 3*heads*32
+    int S, per;                  // pixel slices per (batch, head) and pixels per slice (S == 1: the whole image in one workgroup)
+    float* part;                 // S > 1: per-slice partial results (see the PH template parameter of the kernels)
 };
+
+// workgroup -> (batch, head, slice).  The heads (and slices) of one batch element share cache lines (32 channels = 64..128 bytes of a
+// pixel row) and consecutive workgroup ids land on different XCDs, so ids xcd + 8*slot with slot = s + S*(h + heads*m) are
+// batch element xcd + 8*m: everything of one batch element stays on one XCD / one L2.
+__device__ __forceinline__ void attn_block(const AttnArgs& a, int& b, int& h, int& sl) {
+    const int id = blockIdx.x;
+    sl = id % a.S; h = (id / a.S) % a.heads; b = id / (a.S * a.heads);
+    if (a.B % 8 == 0) {
+        const int xcd = id & 7, slot = id >> 3;
+        sl = slot % a.S; h = (slot / a.S) % a.heads; b = xcd + 8 * (slot / (a.S * a.heads));
+    }
+}
 
 // element access for the activation tensors (qkv, out, dout, dqkv): fp32, or bf16 when T16 (offsets count elements)
 template <bool T16> __device__ __forceinline__ float ldx(const float* base, size_t i) {
@@ -42,7 +56,7 @@ __device__ __forceinline__ int tile_row(int r, int lane) { return (r & 3) + 8 * 
 
 // S[d][e] = sum_p f(A[p][d]) * Bm[p][e] over this block's pixels, waves split p, result in sm[32][33]
 template <bool EXP, bool T16>
-__device__ __forceinline__ void reduce_outer(const float* A, const float* Bm, int ldA, int ldB, int n,
+__device__ __forceinline__ void reduce_outer(const float* A, const float* Bm, int ldA, int ldB, int pb, int n,
                                              const float* kmax, float* sm, float* wsum, float* scratch) {
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int i = l & 31, kk = l >> 5;
@@ -54,7 +68,7 @@ __device__ __forceinline__ void reduce_outer(const float* A, const float* Bm, in
     // four pixel pairs per trip, all eight loads issued before the first use and none of them inside a branch (a
     // guarded load is followed by s_waitcnt vmcnt(0): one memory round trip per pair); rows past n are clamped + masked
     constexpr int UN = 4;
-    for (int p0 = 2 * w; p0 < n; p0 += 8 * UN) {
+    for (int p0 = pb + 2 * w; p0 < n; p0 += 8 * UN) {
         float av[UN], bv[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -132,34 +146,38 @@ __device__ __forceinline__ f32x16 tile_mm(const float* A, int ldA, int p0, int n
     return acc;
 }
 
-template <bool T16>     // T16: qkv and out are stored as bf16
+// PH = 0: the whole image of one (batch, head) in one workgroup (S == 1).  With S > 1 the pixel axis is cut into slices and the
+// three dependent steps become three launches over (batch, head, slice):  1: column max of k over the slice -> part_max;
+// 2: max over the slices, then exp / outer product over the slice -> part_ctx, part_sum;  3: slices summed in a fixed order
+// (deterministic), normalised, written to ctx / kstat by slice 0, then out for the slice's pixels.  One image per workgroup keeps
+// 4096 pixels behind 8 KB of loads in flight; sliced, every CU holds several workgroups and the loads of all of them.
+template <bool T16, int PH>     // T16: qkv and out are stored as bf16
 __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
     __shared__ float scratch[4 * 32 * 33];
     __shared__ float ctx_s[32 * 33];
     __shared__ float kmax_s[32], ksum_s[32], wsum[4 * 32], pmax[8 * 32];
-    // (batch, head) of this workgroup.  The heads of one batch element share cache lines (32 channels = 64..128 bytes of
-    // a pixel row) and consecutive workgroup ids land on different XCDs, so ids xcd + 8*slot with slot = h + heads*m
-    // are batch element xcd + 8*m: its heads stay on one XCD / one L2.
-    int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    if (a.B % 8 == 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        h = slot % a.heads; b = xcd + 8 * (slot / a.heads);
-    }
+    int b, h, sl;
+    attn_block(a, b, h, sl);
     const int bh = b * a.heads + h;
+    const int pb = sl * a.per, pe = min(a.n, pb + a.per);
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int hid = a.heads * DH;
     const float* q = offs<T16>(a.qkv, (size_t)b * a.n * a.ldq + h * DH);
     const float* k = offs<T16>(q, hid);
     const float* v = offs<T16>(q, 2 * hid);
+    const int BHS = a.B * a.heads * a.S;
+    float* part_max = a.part;                         // [BH][S][32]
+    float* part_sum = a.part + (size_t)BHS * 32;      // [BH][S][32]
+    float* part_ctx = a.part + (size_t)BHS * 64;      // [BH][S][32*32]
+    const size_t bhs = (size_t)bh * a.S + sl;
 
-    // column max of k over pixels
-    {
+    if constexpr (PH == 0 || PH == 1) {               // column max of k over the slice's pixels
         int d = t & 31, pr = t >> 5;
         float m = -INFINITY;
-        for (int p = pr; p < a.n; p += 32) {              // four rows in flight; rows past n repeat the last row (max-neutral)
+        for (int p = pb + pr; p < pe; p += 32) {          // four rows in flight; rows past the end repeat the last row (max-neutral)
             float v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = ldx<T16>(k, (size_t)min(p + 8 * u, a.n - 1) * a.ldq + d);
+            for (int u = 0; u < 4; ++u) v[u] = ldx<T16>(k, (size_t)min(p + 8 * u, pe - 1) * a.ldq + d);
             m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
         }
         pmax[pr * 32 + d] = m;
@@ -169,53 +187,78 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
             for (int r = 1; r < 8; ++r) mm = fmaxf(mm, pmax[r * 32 + t]);
             kmax_s[t] = mm;
+            if constexpr (PH == 1) part_max[bhs * 32 + t] = mm;
+        }
+        if constexpr (PH == 1) return;
+        __syncthreads();
+    } else {                                          // max over the slices
+        if (t < 32) {
+            float mm = part_max[(size_t)bh * a.S * 32 + t];
+            for (int s2 = 1; s2 < a.S; ++s2) mm = fmaxf(mm, part_max[((size_t)bh * a.S + s2) * 32 + t]);
+            kmax_s[t] = mm;
         }
         __syncthreads();
     }
-    reduce_outer<true, T16>(k, v, a.ldq, a.ldq, a.n, kmax_s, ctx_s, wsum, scratch);
-    if (t < 32) ksum_s[t] = wsum[t] + wsum[32 + t] + wsum[64 + t] + wsum[96 + t];
-    __syncthreads();
+    if constexpr (PH == 0 || PH == 2) {
+        reduce_outer<true, T16>(k, v, a.ldq, a.ldq, pb, pe, kmax_s, ctx_s, wsum, scratch);
+        if (t < 32) ksum_s[t] = wsum[t] + wsum[32 + t] + wsum[64 + t] + wsum[96 + t];
+        __syncthreads();
+        if constexpr (PH == 2) {
+            for (int idx = t; idx < 32 * 32; idx += 256) part_ctx[bhs * 1024 + idx] = ctx_s[(idx >> 5) * 33 + (idx & 31)];
+            if (t < 32) part_sum[bhs * 32 + t] = ksum_s[t];
+            return;
+        }
+    } else {                                          // PH == 3: slices in a fixed order
+        for (int idx = t; idx < 32 * 32; idx += 256) {
+            float c = 0.f;
+            for (int s2 = 0; s2 < a.S; ++s2) c += part_ctx[((size_t)bh * a.S + s2) * 1024 + idx];
+            ctx_s[(idx >> 5) * 33 + (idx & 31)] = c;
+        }
+        if (t < 32) {
+            float c = 0.f;
+            for (int s2 = 0; s2 < a.S; ++s2) c += part_sum[((size_t)bh * a.S + s2) * 32 + t];
+            ksum_s[t] = c;
+        }
+        __syncthreads();
+    }
     float* ctx_g = a.ctx + (size_t)bh * 32 * 32;
     for (int idx = t; idx < 32 * 32; idx += 256) {
         int d = idx >> 5, e = idx & 31;
         float c = ctx_s[d * 33 + e] / ksum_s[d];
         ctx_s[d * 33 + e] = c;
-        ctx_g[idx] = c;
+        if (sl == 0) ctx_g[idx] = c;
     }
-    if (t < 32) {
+    if (t < 32 && sl == 0) {
         float* ks = a.kstat + (size_t)bh * 64;
         ks[2 * t] = kmax_s[t]; ks[2 * t + 1] = ksum_s[t];
     }
     __syncthreads();
     // out[p][e] = sum_d q[p][d] ctx[d][e]
     float* o = offs<T16>(a.out, (size_t)b * a.n * hid + h * DH);
-    for (int p0 = 32 * w; p0 < a.n; p0 += 128) {
-        f32x16 acc = tile_mm<T16>(q, a.ldq, p0, a.n, ctx_s, 33, 1, scratch + w * (32 * 33));
+    for (int p0 = pb + 32 * w; p0 < pe; p0 += 128) {
+        f32x16 acc = tile_mm<T16>(q, a.ldq, p0, pe, ctx_s, 33, 1, scratch + w * (32 * 33));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int p = p0 + tile_row(r, l);
-            if (p < a.n) stx<T16>(o, (size_t)p * hid + (l & 31), acc[r]);
+            if (p < pe) stx<T16>(o, (size_t)p * hid + (l & 31), acc[r]);
         }
     }
 }
 
 // Backward.  With P = softmax_p(k), ctx = P^T v (saved), r[d] = sum_e ctx[d,e] dctx[d,e]:
 //   dctx = q^T dout ; dq = dout ctx^T ; dv = P dctx ; dP = v dctx^T ; dk = P * (dP - r)
-template <bool T16>     // T16: qkv, dout and dqkv are stored as bf16
+// PH = 0: one workgroup per (batch, head).  S > 1:  1: dctx over the slice -> part;  2: slices summed in a fixed order, then the
+// per-pixel gradients of the slice.
+template <bool T16, int PH>     // T16: qkv, dout and dqkv are stored as bf16
 __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
     __shared__ float scratch[4 * 32 * 33];
     __shared__ float ctx_s[32 * 33], dctx_s[32 * 33];
     __shared__ float stage_s[4 * 32 * 33];
     __shared__ float kmax_s[32], kinv_s[32], r_s[32];
-    // (batch, head) of this workgroup.  The heads of one batch element share cache lines (32 channels = 64..128 bytes of
-    // a pixel row) and consecutive workgroup ids land on different XCDs, so ids xcd + 8*slot with slot = h + heads*m
-    // are batch element xcd + 8*m: its heads stay on one XCD / one L2.
-    int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    if (a.B % 8 == 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        h = slot % a.heads; b = xcd + 8 * (slot / a.heads);
-    }
+    int b, h, sl;
+    attn_block(a, b, h, sl);
     const int bh = b * a.heads + h;
+    const int pb = sl * a.per, pe = min(a.n, pb + a.per);
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int hid = a.heads * DH;
     const float* q = offs<T16>(a.qkv, (size_t)b * a.n * a.ldq + h * DH);
@@ -225,14 +268,30 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
     float* dq = offs<T16>(a.dqkv, (size_t)b * a.n * a.ldq + h * DH);
     float* dk = offs<T16>(dq, hid);
     float* dv = offs<T16>(dq, 2 * hid);
+    const size_t bhs = (size_t)bh * a.S + sl;
 
-    const float* ctx_g = a.ctx + (size_t)bh * 32 * 32;
-    for (int idx = t; idx < 32 * 32; idx += 256) ctx_s[(idx >> 5) * 33 + (idx & 31)] = ctx_g[idx];
-    if (t < 32) {
-        const float* ks = a.kstat + (size_t)bh * 64;
-        kmax_s[t] = ks[2 * t]; kinv_s[t] = 1.0f / ks[2 * t + 1];
+    if constexpr (PH != 1) {
+        const float* ctx_g = a.ctx + (size_t)bh * 32 * 32;
+        for (int idx = t; idx < 32 * 32; idx += 256) ctx_s[(idx >> 5) * 33 + (idx & 31)] = ctx_g[idx];
+        if (t < 32) {
+            const float* ks = a.kstat + (size_t)bh * 64;
+            kmax_s[t] = ks[2 * t]; kinv_s[t] = 1.0f / ks[2 * t + 1];
+        }
     }
-    reduce_outer<false, T16>(q, dout, a.ldq, hid, a.n, nullptr, dctx_s, nullptr, scratch);   // syncs inside
+    if constexpr (PH == 0 || PH == 1) {
+        reduce_outer<false, T16>(q, dout, a.ldq, hid, pb, pe, nullptr, dctx_s, nullptr, scratch);   // syncs inside
+        if constexpr (PH == 1) {
+            for (int idx = t; idx < 32 * 32; idx += 256) a.part[bhs * 1024 + idx] = dctx_s[(idx >> 5) * 33 + (idx & 31)];
+            return;
+        }
+    } else {
+        for (int idx = t; idx < 32 * 32; idx += 256) {
+            float c = 0.f;
+            for (int s2 = 0; s2 < a.S; ++s2) c += a.part[((size_t)bh * a.S + s2) * 1024 + idx];
+            dctx_s[(idx >> 5) * 33 + (idx & 31)] = c;
+        }
+        __syncthreads();
+    }
     if (t < 32) {
         float s = 0.f;
 #pragma unroll
@@ -243,21 +302,21 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
 
     float* pt = scratch + w * (32 * 33);        // this wave's P tile [pixel][d]
     float* stg = stage_s + w * (32 * 33);       // this wave's operand staging tile
-    for (int p0 = 32 * w; p0 < a.n; p0 += 128) {
+    for (int p0 = pb + 32 * w; p0 < pe; p0 += 128) {
         const int col = l & 31;
         // dq[p][d] = sum_e dout[p][e] ctx[d][e]      (B(k=e, j=d) = ctx_s[d*33+e])
-        f32x16 acc = tile_mm<T16>(dout, hid, p0, a.n, ctx_s, 1, 33, stg);
+        f32x16 acc = tile_mm<T16>(dout, hid, p0, pe, ctx_s, 1, 33, stg);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < a.n) stx<T16>(dq, (size_t)p * a.ldq + col, acc[r]); }
+        for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < pe) stx<T16>(dq, (size_t)p * a.ldq + col, acc[r]); }
         // P tile into LDS (rows = pixels) so it can serve as the A operand of dv
         {
             float kv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) kv[r] = ldx<T16>(k, (size_t)min(p0 + tile_row(r, l), a.n - 1) * a.ldq + col);
+            for (int r = 0; r < 16; ++r) kv[r] = ldx<T16>(k, (size_t)min(p0 + tile_row(r, l), pe - 1) * a.ldq + col);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = tile_row(r, l);
-                pt[row * 33 + col] = p0 + row < a.n ? __expf(kv[r] - kmax_s[col]) * kinv_s[col] : 0.f;
+                pt[row * 33 + col] = p0 + row < pe ? __expf(kv[r] - kmax_s[col]) * kinv_s[col] : 0.f;
             }
         }
         // (wave-private LDS region: the wave's own ds_write -> ds_read ordering is enough)
@@ -273,56 +332,120 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
                 a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pt[i * 33 + kd], dctx_s[kd * 33 + i], a2, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < a.n) stx<T16>(dv, (size_t)p * a.ldq + col, a2[r]); }
+            for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < pe) stx<T16>(dv, (size_t)p * a.ldq + col, a2[r]); }
         }
         // dP[p][d] = sum_e v[p][e] dctx[d][e]        (B(k=e, j=d) = dctx_s[d*33+e]) ; dk = P*(dP - r)
-        acc = tile_mm<T16>(v, a.ldq, p0, a.n, dctx_s, 1, 33, stg);
+        acc = tile_mm<T16>(v, a.ldq, p0, pe, dctx_s, 1, 33, stg);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = tile_row(r, l), p = p0 + row;
-            if (p < a.n) stx<T16>(dk, (size_t)p * a.ldq + col, pt[row * 33 + col] * (acc[r] - r_s[col]));
+            if (p < pe) stx<T16>(dk, (size_t)p * a.ldq + col, pt[row * 33 + col] * (acc[r] - r_s[col]));
         }
     }
 }
 
+// slices per (batch, head): only as many as it takes to give every CU two workgroups (measured on MI355X: with 512 (batch, head)
+// pairs -- cfg 2 at B = 128 -- slicing further changes nothing, the kernels are bound by their VALU + fp32-MFMA issue, not by
+// loads in flight: forward 0.128 -> 0.153 ms per step with 8 slices), slices of at least 128 pixels (one 32-pixel tile per wave)
+int attn_slices(int B, int n, int heads) {
+    static const int force = [] { const char* e = getenv("MI_ATTN_SLICES"); return e ? atoi(e) : 0; }();
+    if (force > 0) return (n / force >= 32) ? force : 1;
+    int S = 1;
+    while (S < 32 && (long)B * heads * S < 512 && n / (2 * S) >= 128) S *= 2;
+    return S;
+}
+
 }  // namespace
 
-static int linattn_fwd_go(int B, int n, int heads, const void* qkv, void* out, float* ctx, float* kstat, int b16, void* stream) {
+static void attn_plan(AttnArgs& a, int S, void* workspace) {
+    a.S = S;
+    a.per = ((a.n + S - 1) / S + 31) / 32 * 32;
+    a.part = (float*)workspace;
+}
+
+// scratch bytes the sliced launches need (0: one workgroup per (batch, head), no scratch)
+extern "C" size_t mi_linattn_workspace(int B, int n, int heads) {
+    if (B <= 0 || n <= 0 || heads <= 0) return 0;
+    const int S = attn_slices(B, n, heads);
+    return S > 1 ? (size_t)B * heads * S * (1024 + 64) * sizeof(float) : 0;
+}
+
+static int linattn_fwd_go(int B, int n, int heads, const void* qkv, void* out, float* ctx, float* kstat, int b16, void* workspace,
+                          size_t ws_bytes, void* stream) {
     MI_REQUIRE(B > 0 && n > 0 && heads > 0 && qkv && out && ctx && kstat, "bad argument");
     AttnArgs a{};
     a.qkv = (const float*)qkv; a.out = (float*)out; a.ctx = ctx; a.kstat = kstat; a.B = B; a.n = n; a.heads = heads; a.ldq = 3 * heads * DH;
-    if (b16) hipLaunchKernelGGL(linattn_fwd_kernel<true>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
-    else     hipLaunchKernelGGL(linattn_fwd_kernel<false>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
+    int S = attn_slices(B, n, heads);
+    if (S > 1 && (!workspace || ws_bytes < mi_linattn_workspace(B, n, heads) || ((uintptr_t)workspace & 15))) S = 1;
+    attn_plan(a, S, workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(B * heads * S);
+    if (S == 1) {
+        if (b16) hipLaunchKernelGGL((linattn_fwd_kernel<true, 0>), grid, dim3(256), 0, st, a);
+        else     hipLaunchKernelGGL((linattn_fwd_kernel<false, 0>), grid, dim3(256), 0, st, a);
+    } else if (b16) {
+        hipLaunchKernelGGL((linattn_fwd_kernel<true, 1>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((linattn_fwd_kernel<true, 2>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((linattn_fwd_kernel<true, 3>), grid, dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((linattn_fwd_kernel<false, 1>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((linattn_fwd_kernel<false, 2>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((linattn_fwd_kernel<false, 3>), grid, dim3(256), 0, st, a);
+    }
     MI_LAUNCH_CHECK();
     return 0;
 }
 static int linattn_bwd_go(int B, int n, int heads, const void* qkv, const float* ctx, const float* kstat,
-                          const void* dout, void* dqkv, int b16, void* stream) {
+                          const void* dout, void* dqkv, int b16, void* workspace, size_t ws_bytes, void* stream) {
     MI_REQUIRE(B > 0 && n > 0 && heads > 0 && qkv && ctx && kstat && dout && dqkv, "bad argument");
     AttnArgs a{};
     a.qkv = (const float*)qkv; a.ctx = const_cast<float*>(ctx); a.kstat = const_cast<float*>(kstat); a.dout = (const float*)dout; a.dqkv = (float*)dqkv;
     a.B = B; a.n = n; a.heads = heads; a.ldq = 3 * heads * DH;
-    if (b16) hipLaunchKernelGGL(linattn_bwd_kernel<true>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
-    else     hipLaunchKernelGGL(linattn_bwd_kernel<false>, dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
+    int S = attn_slices(B, n, heads);
+    if (S > 1 && (!workspace || ws_bytes < mi_linattn_workspace(B, n, heads) || ((uintptr_t)workspace & 15))) S = 1;
+    attn_plan(a, S, workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(B * heads * S);
+    if (S == 1) {
+        if (b16) hipLaunchKernelGGL((linattn_bwd_kernel<true, 0>), grid, dim3(256), 0, st, a);
+        else     hipLaunchKernelGGL((linattn_bwd_kernel<false, 0>), grid, dim3(256), 0, st, a);
+    } else if (b16) {
+        hipLaunchKernelGGL((linattn_bwd_kernel<true, 1>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((linattn_bwd_kernel<true, 2>), grid, dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((linattn_bwd_kernel<false, 1>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((linattn_bwd_kernel<false, 2>), grid, dim3(256), 0, st, a);
+    }
     MI_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int mi_linattn_fwd(int B, int n, int heads, const float* qkv, float* out, float* ctx, float* kstat,
                               void* stream) {
-    return linattn_fwd_go(B, n, heads, qkv, out, ctx, kstat, 0, stream);
+    return linattn_fwd_go(B, n, heads, qkv, out, ctx, kstat, 0, nullptr, 0, stream);
 }
 extern "C" int mi_linattn_bwd(int B, int n, int heads, const float* qkv, const float* ctx, const float* kstat,
                               const float* dout, float* dqkv, void* stream) {
-    return linattn_bwd_go(B, n, heads, qkv, ctx, kstat, dout, dqkv, 0, stream);
+    return linattn_bwd_go(B, n, heads, qkv, ctx, kstat, dout, dqkv, 0, nullptr, 0, stream);
 }
 // bf16 storage of the attention-internal activations: b16 != 0 -> qkv, out (forward) and qkv, dout, dqkv (backward)
 // are bf16 tensors; ctx / kstat and all arithmetic stay fp32.
 extern "C" int mi_linattn_fwd_io(int B, int n, int heads, const void* qkv, void* out, float* ctx, float* kstat, int b16,
                                  void* stream) {
-    return linattn_fwd_go(B, n, heads, qkv, out, ctx, kstat, b16, stream);
+    return linattn_fwd_go(B, n, heads, qkv, out, ctx, kstat, b16, nullptr, 0, stream);
 }
 extern "C" int mi_linattn_bwd_io(int B, int n, int heads, const void* qkv, const float* ctx, const float* kstat,
                                  const void* dout, void* dqkv, int b16, void* stream) {
-    return linattn_bwd_go(B, n, heads, qkv, ctx, kstat, dout, dqkv, b16, stream);
+    return linattn_bwd_go(B, n, heads, qkv, ctx, kstat, dout, dqkv, b16, nullptr, 0, stream);
+}
+// ... with a scratch buffer (mi_linattn_workspace bytes, 16-byte aligned): large images are cut into pixel slices, one workgroup
+// each, so that every CU holds several workgroups' loads in flight; partial results are combined in a fixed order (deterministic).
+// A null / too small workspace runs one workgroup per (batch, head) as above.
+extern "C" int mi_linattn_fwd_ws(int B, int n, int heads, const void* qkv, void* out, float* ctx, float* kstat, int b16,
+                                 void* workspace, size_t ws_bytes, void* stream) {
+    return linattn_fwd_go(B, n, heads, qkv, out, ctx, kstat, b16, workspace, ws_bytes, stream);
+}
+extern "C" int mi_linattn_bwd_ws(int B, int n, int heads, const void* qkv, const float* ctx, const float* kstat,
+                                 const void* dout, void* dqkv, int b16, void* workspace, size_t ws_bytes, void* stream) {
+    return linattn_bwd_go(B, n, heads, qkv, ctx, kstat, dout, dqkv, b16, workspace, ws_bytes, stream);
 }

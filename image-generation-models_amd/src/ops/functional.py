@@ -730,7 +730,11 @@ def linattn_fwd(qkv, heads=4):
     ctx = torch.empty((N, heads, 32, 32), device=qkv.device, dtype=torch.float32)
     kstat = torch.empty((N, heads, 32, 2), device=qkv.device, dtype=torch.float32)
     e0 = _probe_open()
-    check(load_library().mi_linattn_fwd_io(N, H * W, heads, _p(qkv), _p(out), _p(ctx), _p(kstat), _b16(qkv), _stream()), "mi_linattn_fwd")
+    lib = load_library()
+    need = lib.mi_linattn_workspace(N, H * W, heads)         # > 0: the pixel axis is cut into slices (several workgroups per image)
+    ws = _workspace(qkv.device, need) if need else None
+    check(lib.mi_linattn_fwd_ws(N, H * W, heads, _p(qkv), _p(out), _p(ctx), _p(kstat), _b16(qkv), _p(ws), ws.numel() * 4 if need else 0,
+                                _stream()), "mi_linattn_fwd")
     if e0 is not None:
         _probe_close(e0, f"linattn_fwd_kernel<io{_b16(qkv)}>", 4.0 * N * heads * 32 * 32 * H * W, f"N{N} n{H * W}",
                      N * H * W * heads * 32 * 4 * _esz(qkv))
@@ -742,8 +746,11 @@ def linattn_bwd(qkv, ctx, kstat, dout, heads=4):
     assert dout.is_contiguous() and dout.dtype == qkv.dtype
     dqkv = torch.empty_like(qkv)
     e0 = _probe_open()
-    check(load_library().mi_linattn_bwd_io(N, H * W, heads, _p(qkv), _p(ctx), _p(kstat), _p(dout), _p(dqkv), _b16(qkv), _stream()),
-          "mi_linattn_bwd")
+    lib = load_library()
+    need = lib.mi_linattn_workspace(N, H * W, heads)
+    ws = _workspace(qkv.device, need) if need else None
+    check(lib.mi_linattn_bwd_ws(N, H * W, heads, _p(qkv), _p(ctx), _p(kstat), _p(dout), _p(dqkv), _b16(qkv), _p(ws),
+                                ws.numel() * 4 if need else 0, _stream()), "mi_linattn_bwd")
     if e0 is not None:
         _probe_close(e0, f"linattn_bwd_kernel<io{_b16(qkv)}>", 12.0 * N * heads * 32 * 32 * H * W, f"N{N} n{H * W}",
                      N * H * W * heads * 32 * 7 * _esz(qkv))

@@ -59,6 +59,7 @@ SIGNATURES = {
     "mi_conv_s2_wgrad_tr_supported": [C.POINTER(MiWgradDesc)],
     "mi_conv_s2_wgrad_tr_batch": [_I, C.POINTER(MiWgradDesc), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _Z, _P],
     "mi_debug_wgrad_s2_tr_phase": [_I],
+    "mi_debug_conv_dma_chunk": [_I],
     "mi_debug_wgrad1x1_tr_blocks": [_I],
     "mi_debug_wgrad_tr_blocks": [_I],
     "mi_conv3x3_bf16w_io": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
@@ -104,6 +105,8 @@ SIGNATURES = {
     "mi_small_gemm_supported": [_I, _I, _I, _I, _I, _I, _I],
     "mi_linattn_fwd_io": [_I, _I, _I, _P, _P, _P, _P, _I, _P],
     "mi_linattn_bwd_io": [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
+    "mi_linattn_fwd_ws": [_I, _I, _I, _P, _P, _P, _P, _I, _P, _Z, _P],
+    "mi_linattn_bwd_ws": [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _Z, _P],
     "mi_chan_layernorm_fwd_io": [_I, _I, _P, _I, _P, _P, _F, _P, _I, _I, _P],
     "mi_chan_layernorm_bwd_io": [_I, _I, _P, _I, _P, _F, _P, _I, _P, _I, _I, _P, _P, _I, _P],
     "mi_time_embed": [_I, _I, _P, _P, _P],
@@ -147,6 +150,7 @@ OTHER = {"mi_abi_version": ([], C.c_int), "mi_last_error": ([], C.c_char_p),
          "mi_conv1x1_wgrad_tr_batch_workspace": ([_I, C.POINTER(MiWgradDesc), C.POINTER(_I)], C.c_size_t),
          "mi_conv_s2_wgrad_tr_batch_workspace": ([_I, C.POINTER(MiWgradDesc)], C.c_size_t),
          "mi_f32_to_bf16_colsum_workspace": ([_Z, _I], C.c_size_t),
+         "mi_linattn_workspace": ([_I, _I, _I], C.c_size_t),
          "mi_conv_small_wgrad_workspace": ([_I], C.c_size_t)}
 ABI_VERSION = 1
 

@@ -118,6 +118,8 @@ int mi_conv3x3_gn_mish(const MiConvDesc* d, const void* x, const float* coef, co
  * x / x2 bf16 (pixel strides in elements, % 8 == 0), w as for mi_conv3x3_bf16w, d->transposed = 1 -> data gradient; y fp32 or
  * bf16 (out_bf16).  Needs K % 64 == 0, K1 % 64 == 0, W in 8..32 with 128-pixel row tiles, N*H*W % 128 == 0 (query _supported). */
 int mi_conv3x3_dma_supported(const MiConvDesc* d);
+/* experiment switch: 64 (default) = 64-channel chunks, one workgroup per CU; 32 = 32-channel chunks, two workgroups per CU */
+int mi_debug_conv_dma_chunk(int ck);
 int mi_conv3x3_dma(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16, const float* bias,
                    const float* residual, void* y, int out_bf16, void* stream);
 /* ... and the LDS-frugal variant (conv_shift.hip): a wave owns 128 pixels x 64 channels and derives the left / right tap columns'
@@ -330,6 +332,16 @@ int mi_linattn_fwd_io(int B, int n, int heads, const void* qkv, void* out, float
                       void* stream);
 int mi_linattn_bwd_io(int B, int n, int heads, const void* qkv, const float* ctx, const float* kstat,
                       const void* dout, void* dqkv, int b16, void* stream);
+/* ... with a scratch buffer (mi_linattn_workspace(B, n, heads) bytes, 16-byte aligned; 0 = not needed): images with many pixels per
+ * (batch, head) are cut into pixel slices, one workgroup each -- three launches forward (slice max, slice exp / outer product,
+ * combine + out), two backward (slice dctx, combine + per-pixel gradients) -- so that every CU holds several workgroups' loads in
+ * flight instead of one workgroup walking 1024-4096 pixels.  Partial results are combined in a fixed order (deterministic).  A
+ * null / too small workspace runs one workgroup per (batch, head). */
+size_t mi_linattn_workspace(int B, int n, int heads);
+int mi_linattn_fwd_ws(int B, int n, int heads, const void* qkv, void* out, float* ctx, float* kstat, int b16,
+                      void* workspace, size_t ws_bytes, void* stream);
+int mi_linattn_bwd_ws(int B, int n, int heads, const void* qkv, const float* ctx, const float* kstat,
+                      const void* dout, void* dqkv, int b16, void* workspace, size_t ws_bytes, void* stream);
 
 /* ---- small exact-fp32 GEMM: nn.Linear of the time-embedding MLP (ddpm.py:126-130,186-193), forward, input
  * gradient and weight gradient ---------------------------------------------------------------------

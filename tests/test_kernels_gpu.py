@@ -322,9 +322,11 @@ def test_chan_layernorm(K, cfg):
     assert rel_err(dg, gg.grad.reshape(-1)) < 5e-5 and rel_err(db, bb.grad.reshape(-1)) < 5e-5
 
 
-@pytest.mark.parametrize("cfg", [(2, 4, 4), (2, 8, 8), (3, 7, 7), (2, 32, 32), (1, 64, 64)])
+@pytest.mark.parametrize("cfg", [(2, 4, 4), (2, 8, 8), (3, 7, 7), (2, 32, 32), (1, 64, 64), (2, 24, 24), (16, 16, 16)])
 def test_linear_attention_core(K, cfg):
-    """softmax over pixels of k, ctx = k v^T, out = ctx^T q (ddpm.py:157-165)."""
+    """softmax over pixels of k, ctx = k v^T, out = ctx^T q (ddpm.py:157-165).  Images with >= 256 pixels per (batch, head) run as
+    pixel slices when there are fewer than two workgroups per CU otherwise (three launches forward, two backward, partial results
+    combined in a fixed order): 32x32 -> 8 slices, 64x64 -> 32, 24x24 -> 4 ragged ones, 16 x 16x16 -> 2; bitwise reproducible."""
     N, H, W = cfg
     n, heads = H * W, 4
     g = torch.Generator().manual_seed(17)
@@ -342,6 +344,10 @@ def test_linear_attention_core(K, cfg):
     assert rel_err(from_nhwc(og), out) < 1e-5
     assert rel_err(cg, ctx) < 1e-5
     assert rel_err(from_nhwc(dq), qkv.grad) < 5e-5
+    og2, cg2, sg2 = K.linattn_fwd(qg, heads)
+    dq2 = K.linattn_bwd(qg, cg2, sg2, to_nhwc_gpu(dout.float()).contiguous(), heads)
+    assert torch.equal(og, og2) and torch.equal(cg, cg2) and torch.equal(dq, dq2)
+    assert (K.load_library().mi_linattn_workspace(N, n, heads) > 0) == (n >= 256 and N * heads < 512)
 
 
 def test_time_embed_and_layouts(K, golden_dir):
@@ -495,9 +501,13 @@ def test_conv3x3_shift_fwd_and_dgrad(K, cfg, out16):
     dict(N=2, H=16, Ci=64, Co=96),               # ragged co tile
     dict(N=4, H=8, Ci=1024, Co=64, split=512),   # long K, half-empty co tile
 ])
-def test_conv3x3_lds_dma_fwd_and_dgrad(K, cfg, out16):
+@pytest.mark.parametrize("chunk", [64, 32])
+def test_conv3x3_lds_dma_fwd_and_dgrad(K, cfg, out16, chunk, request):
     """Block's 3x3 conv (ddpm.py:116) and its data gradient for bf16-stored activations through the LDS-DMA kernel
-    (mi_conv3x3_dma): bias, residual, fp32 and bf16 output, accumulate; against fp64 on the same bf16-rounded operands."""
+    (mi_conv3x3_dma): bias, residual, fp32 and bf16 output, accumulate; against fp64 on the same bf16-rounded operands.
+    chunk = 32: the variant with 32-channel chunks and two workgroups per CU."""
+    K.load_library().mi_debug_conv_dma_chunk(chunk)
+    request.addfinalizer(lambda: K.load_library().mi_debug_conv_dma_chunk(64))
     from src.ops.lib import MiConvDesc, load_library
     import ctypes
     N, H, Ci, Co = cfg["N"], cfg["H"], cfg["Ci"], cfg["Co"]

@@ -32,6 +32,29 @@ for _ in range(5):
             gam = torch.ones(Ci, device=DEV); bet = torch.zeros(Ci, device=DEV); tb = torch.randn(B, Ci, device=DEV) * 0.1
             _, COEF = K.gn_stats_coef(x, gam, bet, temb=tb)
         K.conv3x3_gn_mish(x, COEF, wf, K=Ci, Nc=Co, bias=None)
+    elif which == "gn":          # GroupNorm+Mish of a Block (bf16 in / out) forward + backward on [B,H,H,Ci]
+        if "GN" not in globals():
+            ga = torch.ones(Ci, device=DEV); be = torch.zeros(Ci, device=DEV); tb = torch.randn(B, Ci, device=DEV)
+            GN = (ga, be, tb, torch.zeros(Ci, device=DEV), torch.zeros(Ci, device=DEV), torch.zeros(Ci, device=DEV), torch.zeros(B, Ci, device=DEV))
+        ga, be, tb, dg, db, dbias, dtb = GN
+        yy, st = K.gn_mish_fwd(x, ga, be, temb=tb, out_dtype=DT)
+        K.gn_mish_bwd(x, st, ga, be, yy, dgamma=dg, dbeta=db, dtemb=dtb, dbias=dbias, out_dtype=DT)
+    elif which == "ln":          # channel LayerNorm of PreNorm (fp32 stream in, bf16 out) forward + backward
+        if "LN" not in globals():
+            LN = (torch.randn(B, H, H, Ci, device=DEV), torch.ones(Ci, device=DEV), torch.zeros(Ci, device=DEV),
+                  torch.zeros(B, H, H, Ci, device=DEV), torch.zeros(Ci, device=DEV), torch.zeros(Ci, device=DEV))
+        xs, g1, b1, dxs, dg1, db1 = LN
+        yy = K.chan_layernorm_fwd(xs, g1, b1, out_dtype=torch.bfloat16)
+        K.chan_layernorm_bwd(xs, g1, yy, dxs, True, dg1, db1)
+    elif which == "attn":        # LinearAttention core on bf16 qkv [B,H,H,384]
+        if "QKV" not in globals():
+            QKV = torch.randn(B, H, H, 384, device=DEV).bfloat16()
+        ao, ctx, kst = K.linattn_fwd(QKV, 4)
+        K.linattn_bwd(QKV, ctx, kst, ao, 4)
+    elif which == "c1x1":        # to_qkv (Ci -> Co, bf16 in / out) forward through the tile kernel
+        if "W1" not in globals():
+            W1 = (torch.randn(Co * Ci, device=DEV) * 0.05).bfloat16()
+        K.conv3x3_bf16w(x, W1, K=Ci, Nc=Co, flip=False, ksize=1, out_dtype=DT)
     elif which == "halo":
         K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, out=y)
     elif which == "igemm":

@@ -26,6 +26,18 @@ CASES = {
 }
 MAIN = {"halo": "conv3x3_halo_kernel", "fused": "conv3x3_halo_kernel", "wgrad": "wgrad_tr_kernel(", "wgradq": "wgrad_tr_kernel("}
 
+# HBM-bound kernels (tools/bench_one.py gn / ln / attn / c1x1 at level 0, B = 128, bf16 storage): every kernel of the pass gets a row
+E0 = 128 * 32 * 32 * 128
+HBM_CASES = {
+    "gn_128_32_128_128_bf16": {"gn_mish_fwd_kernel": ("GroupNorm+Mish fwd [128,32,32,128] bf16 -> bf16", E0 * 4),
+                               "gn_mish_bwd_kernel": ("GroupNorm+Mish bwd, same tensor (x, dout in, dx out, bf16)", E0 * 6)},
+    "ln_128_32_128_128_bf16": {"chan_ln_fwd_kernel": ("channel LayerNorm fwd [128,32,32,128] fp32 -> bf16", E0 * 6),
+                               "chan_ln_bwd_kernel": ("channel LayerNorm bwd (x fp32, dy bf16 in; dx fp32 read-modify-write)", E0 * 14)},
+    "attn_128_32_128_128_bf16": {"linattn_fwd_kernel": ("LinearAttention fwd, qkv [128,32,32,384] bf16 (k twice: max pass)", E0 * 2 * 5),
+                                 "linattn_bwd_kernel": ("LinearAttention bwd (q, dout, then dout, k, v in; dq, dk, dv out; bf16)", E0 * 2 * 8)},
+    "c1x1_128_32_128_384_bf16": {"conv3x3_halo_kernel": ("to_qkv 1x1 conv 128 -> 384 @32x32, bf16 in / out", E0 * 2 * 4 + 128 * 384 * 2)},
+}
+
 out = {}
 for path in sorted(glob.glob(os.path.join(root, f"{tag}_pmc_traffic_*.txt"))):
     case = os.path.basename(path)[len(tag) + len("_pmc_traffic_"):-4]
@@ -45,6 +57,35 @@ for path in sorted(glob.glob(os.path.join(root, f"{tag}_pmc_traffic_*.txt"))):
                 "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "ratio": round(hbm / alg, 2),
                 "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh) on {shape}; "
                         "FETCH_SIZE doubled per MI355X_MICROARCH.md"}
+for case, kernels in HBM_CASES.items():
+    path = os.path.join(root, f"{tag}_pmc_traffic_{case}.txt")
+    if not os.path.exists(path):
+        continue
+    vals = {}
+    for line in open(path):
+        m = re.match(r"(.*?)\s+(FETCH_SIZE|WRITE_SIZE) per-dispatch.*:\s*(\d+)\s*$", line)
+        if m:
+            for key in kernels:
+                if key in m.group(1):
+                    vals.setdefault(key, {})[m.group(2)] = int(m.group(3))
+        m = re.match(r"(.*?)\s+DURATION_US\s+([0-9.]+)\s*$", line)
+        if m:
+            for key in kernels:
+                if key in m.group(1):
+                    vals.setdefault(key, {})["us"] = float(m.group(2))
+    for key, (shape, alg) in kernels.items():
+        v = vals.get(key, {})
+        if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+            continue
+        hbm = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+        extra = {}
+        if "us" in v:
+            extra = {"duration_us_under_pmc": v["us"], "hbm_gbs_from_pmc": round(hbm / v["us"] / 1e3, 1),
+                     "algorithmic_gbs": round(alg / v["us"] / 1e3, 1), "hbm_frac_of_8tbs": round(hbm / v["us"] / 1e3 / 8000.0, 3)}
+        out[f"{key} [{case}]"] = {"shape": shape, "fetch_size_kb_raw": v["FETCH_SIZE"], "write_size_kb_raw": v["WRITE_SIZE"],
+                                  "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "ratio": round(hbm / alg, 2), **extra,
+                                  "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh) on {shape}; "
+                                          "FETCH_SIZE doubled per MI355X_MICROARCH.md"}
 with open(os.path.join(root, f"{tag}_pmc_traffic.json"), "w") as f:
     json.dump(out, f, indent=1)
 for k, v in out.items():

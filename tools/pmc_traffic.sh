@@ -15,4 +15,10 @@ for d in sorted(glob.glob('gpurun_out/traffic_$tag/*')):
         agg[(r['Kernel_Name'][:50], r['Counter_Name'])][r['Dispatch_Id']] += float(r['Counter_Value'])
     for (k,c),v in agg.items():
         print(k, c, 'per-dispatch (counter units, KB):', round(list(v.values())[-1]))
+    if d.endswith('FETCH_SIZE'):       # kernel durations of the same (counter) pass: last dispatch of each kernel
+        last={}
+        for r in csv.DictReader(open(d+'/p_kernel_trace.csv')):
+            if 'at::' in r['Kernel_Name'] or 'rocclr' in r['Kernel_Name']: continue
+            last[r['Kernel_Name'][:50]]=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
+        for k,v in last.items(): print(k, 'DURATION_US', v)
 PY
