@@ -47,6 +47,19 @@ struct HaloArgs {
     int tiles_per_img;   // H/TH when TI == 1
     int xmap;            // XCD-aware tile order (3x3, several row tiles per image, N % 8 == 0)
     const float* coef;   // FUSE: [3][N][K] scale / shift / time bias of the GroupNorm + Mish applied to x while it is staged
+    int skew;            // extra LDS elements per halo ROW (see HaloSkew); 0 = rows packed
+};
+
+// Bank conflicts of the 8-pixel-wide tiles.  A halo pixel is PITCH = CK + 8 elements = an odd number of 16-byte granules, so the
+// 16 pixels one ds_read_b128 pass serves land in 16 different granules (mod 16) when they are consecutive.  With W = 8 the 16
+// pixels are two image rows, W + 2 = 10 positions apart, and pixels x of one row / x + 6 of the next are exactly 16 positions
+// apart: the same granule, a 2-way conflict on a quarter of the reads (measured on the 8x8-level kernel: SQ_LDS_BANK_CONFLICT =
+// 32 % of SQ_LDS_IDX_ACTIVE).  Skewing every halo row by `skew` granules moves the row distance to the one residue no pixel pair
+// can hit: 9 d + 90 + skew = 8 (mod 16) has no solution for d in -7 .. 7 when skew = 14 granules (CK = 64), 6 (CK = 32).
+template <int BM, int CK> struct HaloSkew {
+    static constexpr int EL = CK == 64 ? 14 * 8 : 6 * 8;                            // elements per row
+    static constexpr int ROWS = BM <= 128 ? (BM / 64) * 10 + 2 : 0;                 // halo rows of the W = 8 tiles (+ dump row)
+    static constexpr int ALLOW = ROWS * EL;                                         // extra elements per halo buffer
 };
 
 // waves are arranged (WAVES/2) along M x 2 along N; a wave owns (MI*32) pixels x 64 channels
@@ -87,7 +100,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     constexpr int NT = HaloCfg<BM, WAVES>::NT, MI = HaloCfg<BM, WAVES>::MI, NI = 2;
     constexpr int PITCH = CK + 8;                  // bf16 elements; 16-B aligned rows, conflict-free b128 reads
     constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
-    constexpr int ASZ = (MAXHP + 1) * PITCH;       // one halo buffer (+1 dump row for the staging slots past the tile)
+    constexpr int ASZ = (MAXHP + 1) * PITCH + (KS == 3 ? HaloSkew<BM, CK>::ALLOW : 0);   // one halo buffer (+1 dump row for the staging slots past the tile)
     constexpr int Q = CK / 4;                      // float4 per halo pixel per chunk
     constexpr int A_IT = (MAXHP * Q + NT - 1) / NT;
     constexpr int A_SL = (A_IT + NSL - 1) / NSL;   // float4 per thread per slice
@@ -155,6 +168,16 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
         }
     }
 
+    // LDS element offset of each of this thread's staging slots (slots past the tile go to the dump row)
+    int aofs[NSL][A_SL];
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+        for (int j = 0; j < A_SL; ++j) {
+            const int hp = min(a_hp0 + (sl * A_SL + j) * (NT / Q), MAXHP);
+            aofs[sl][j] = hp * PITCH + (KS == 3 ? (min(hp, a.HP) / W2) * a.skew : 0) + a_c4 * 4;      // slots past the tile: one row further
+        }
+
     // ---- MFMA row -> halo pixel (before the tap shift)
     int a_row[MI];
 #pragma unroll
@@ -163,7 +186,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
         if (KS == 1) { a_row[i] = r * PITCH + (l >> 5) * 8; continue; }
         int tx = r % a.W, q = r / a.W;
         int ty = q % a.TH, ti = q / a.TH;
-        a_row[i] = ((ti * TH2 + ty) * W2 + tx) * PITCH + (l >> 5) * 8;
+        a_row[i] = ((ti * TH2 + ty) * W2 + tx) * PITCH + (ti * TH2 + ty) * a.skew + (l >> 5) * 8;
     }
     const int b_row0 = (wn * 64 + (l & 31)) * PITCH + (l >> 5) * 8;
     const int b_n = t / (CK / 8), b_k8 = t % (CK / 8);     // + NT/(CK/8) rows per i
@@ -210,7 +233,6 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     auto store_a = [&](int buf, const f32x4 (&r)[A_SL], int sl) {
 #pragma unroll
         for (int j = 0; j < A_SL; ++j) {
-            const int hp = min(a_hp0 + (sl * A_SL + j) * (NT / Q), MAXHP);   // MAXHP = dump row
             const uint32_t keep = ~(uint32_t)(pofs[sl][j] >> 31);
             u32x2 v;
             if constexpr (FUSE) {
@@ -227,7 +249,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
                 v = IN16 ? u32x2{__float_as_uint(r[j].x), __float_as_uint(r[j].y)}
                          : u32x2{pack_bf16(r[j].x, r[j].y), pack_bf16(r[j].z, r[j].w)};
             }
-            *reinterpret_cast<u32x2*>(&As[buf * ASZ + hp * PITCH + a_c4 * 4]) = u32x2{v.x & keep, v.y & keep};
+            *reinterpret_cast<u32x2*>(&As[buf * ASZ + aofs[sl][j]]) = u32x2{v.x & keep, v.y & keep};
         }
     };
     // weight tile of chunk `ch`, tap `tap`; rows past Nc are clamped (their output columns are never written)
@@ -248,7 +270,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     };
     auto mma_tap = [&](int abuf, int slot, int tap) {
         const int ky = tap / KS, kx = tap - ky * KS;
-        const uint16_t* At = As + abuf * ASZ + (ky * W2 + kx) * PITCH;
+        const uint16_t* At = As + abuf * ASZ + (ky * W2 + kx) * PITCH + ky * a.skew;
         const uint16_t* Bt = Bs + slot * (BN * PITCH);
         bf16x8 af[2][MI], bf[2][NI];
         auto frags = [&](int set, int ks) {
@@ -441,10 +463,14 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
 }
 
 template <int BM, int CK, int KS = 3, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4), bool FUSE = false>
-void launch_halo(const HaloArgs& a, hipStream_t st) {
+void launch_halo(const HaloArgs& a_in, hipStream_t st) {
     constexpr int PITCH = CK + 8;
     constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
-    size_t lds = (size_t)(2 * (MAXHP + 1) * PITCH + 2 * 128 * PITCH) * 2 + MAXHP * 4;
+    constexpr int ALLOW = KS == 3 ? HaloSkew<BM, CK>::ALLOW : 0;
+    size_t lds = (size_t)(2 * ((MAXHP + 1) * PITCH + ALLOW) + 2 * 128 * PITCH) * 2 + MAXHP * 4;
+    HaloArgs a = a_in;
+    static const int skew_env = [] { const char* e = getenv("MI_HALO_SKEW"); return e ? atoi(e) : 1; }();
+    a.skew = (skew_env && KS == 3 && ALLOW > 0 && a.W == 8 && a.TI * (a.TH + 2) + 1 <= HaloSkew<BM, CK>::ROWS) ? HaloSkew<BM, CK>::EL : 0;
     dim3 grid((a.N * a.H * a.W + BM - 1) / BM, (a.Nc + 127) / 128, a.ksplit);
     static bool once = [] {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
