@@ -50,17 +50,15 @@ struct HaloArgs {
     int skew;            // extra LDS elements per halo ROW (see HaloSkew); 0 = rows packed
 };
 
-// Bank conflicts of the 8-pixel-wide tiles.  A halo pixel is PITCH = CK + 8 elements = an odd number of 16-byte granules, so the
-// 16 pixels one ds_read_b128 pass serves land in 16 different granules (mod 16) when they are consecutive.  With W = 8 the 16
-// pixels are two image rows, W + 2 = 10 positions apart, and pixels x of one row / x + 6 of the next are exactly 16 positions
-// apart: the same granule, a 2-way conflict on a quarter of the reads (measured on the 8x8-level kernel: SQ_LDS_BANK_CONFLICT =
-// 32 % of SQ_LDS_IDX_ACTIVE).  Skewing every halo row by `skew` granules moves the row distance to the one residue no pixel pair
-// can hit: 9 d + 90 + skew = 8 (mod 16) has no solution for d in -7 .. 7 when skew = 14 granules (CK = 64), 6 (CK = 32).
-template <int BM, int CK> struct HaloSkew {
-    static constexpr int EL = CK == 64 ? 14 * 8 : 6 * 8;                            // elements per row
-    static constexpr int ROWS = BM <= 128 ? (BM / 64) * 10 + 2 : 0;                 // halo rows of the W = 8 tiles (+ dump row)
-    static constexpr int ALLOW = ROWS * EL;                                         // extra elements per halo buffer
-};
+// Bank conflicts of the 8- and 16-pixel-wide tiles.  A ds_read_b128 serves a half-wave (32 lanes) conflict-free when the 32
+// 16-byte granules it touches are distinct mod 32 (measured with SQ_LDS_BANK_CONFLICT on W = 8 / 16 / 32 tiles).  A halo pixel
+// is PITCH = CK + 8 elements = an odd number g of granules, so 32 consecutive pixels of one row are fine (W = 32); with W = 16 / 8
+// the half-wave spans 2 / 4 image rows (W + 2 positions apart) and granules collide (W = 8: 32 % of SQ_LDS_IDX_ACTIVE were
+// conflict cycles, W = 16: 27 %).  The rows' granule sets interleave exactly when consecutive rows are 16 (W = 16) resp. 8 (W = 8)
+// granules apart mod 32, which a skew of SK granules per halo row gives: SK = 14 for CK = 64 ((W + 2) * 9 + 14 = 176 / 104),
+// 22 for CK = 32 ((W + 2) * 5 + 22 = 112 / 72).  The skewed rows use the part of the halo buffer that these narrow tiles leave
+// empty (HP < MAXHP); staging slots past the tile all write their zeros to the dump row.
+template <int CK> struct HaloSkew { static constexpr int EL = (CK == 64 ? 14 : 22) * 8; };     // elements per halo row
 
 // waves are arranged (WAVES/2) along M x 2 along N; a wave owns (MI*32) pixels x 64 channels
 template <int BM, int WAVES = (BM == 256 ? 8 : 4)> struct HaloCfg {
@@ -100,7 +98,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     constexpr int NT = HaloCfg<BM, WAVES>::NT, MI = HaloCfg<BM, WAVES>::MI, NI = 2;
     constexpr int PITCH = CK + 8;                  // bf16 elements; 16-B aligned rows, conflict-free b128 reads
     constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
-    constexpr int ASZ = (MAXHP + 1) * PITCH + (KS == 3 ? HaloSkew<BM, CK>::ALLOW : 0);   // one halo buffer (+1 dump row for the staging slots past the tile)
+    constexpr int ASZ = (MAXHP + 1) * PITCH;       // one halo buffer (+1 dump row for the staging slots past the tile)
     constexpr int Q = CK / 4;                      // float4 per halo pixel per chunk
     constexpr int A_IT = (MAXHP * Q + NT - 1) / NT;
     constexpr int A_SL = (A_IT + NSL - 1) / NSL;   // float4 per thread per slice
@@ -174,8 +172,8 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     for (int sl = 0; sl < NSL; ++sl)
 #pragma unroll
         for (int j = 0; j < A_SL; ++j) {
-            const int hp = min(a_hp0 + (sl * A_SL + j) * (NT / Q), MAXHP);
-            aofs[sl][j] = hp * PITCH + (KS == 3 ? (min(hp, a.HP) / W2) * a.skew : 0) + a_c4 * 4;      // slots past the tile: one row further
+            const int hp = a_hp0 + (sl * A_SL + j) * (NT / Q);
+            aofs[sl][j] = (hp < (KS == 3 ? a.HP : MAXHP) ? hp * PITCH + (KS == 3 ? (hp / W2) * a.skew : 0) : MAXHP * PITCH) + a_c4 * 4;
         }
 
     // ---- MFMA row -> halo pixel (before the tap shift)
@@ -466,11 +464,14 @@ template <int BM, int CK, int KS = 3, bool SK = false, int IO = 0, int WAVES = (
 void launch_halo(const HaloArgs& a_in, hipStream_t st) {
     constexpr int PITCH = CK + 8;
     constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
-    constexpr int ALLOW = KS == 3 ? HaloSkew<BM, CK>::ALLOW : 0;
-    size_t lds = (size_t)(2 * ((MAXHP + 1) * PITCH + ALLOW) + 2 * 128 * PITCH) * 2 + MAXHP * 4;
+    size_t lds = (size_t)(2 * (MAXHP + 1) * PITCH + 2 * 128 * PITCH) * 2 + MAXHP * 4;
     HaloArgs a = a_in;
     static const int skew_env = [] { const char* e = getenv("MI_HALO_SKEW"); return e ? atoi(e) : 1; }();
-    a.skew = (skew_env && KS == 3 && ALLOW > 0 && a.W == 8 && a.TI * (a.TH + 2) + 1 <= HaloSkew<BM, CK>::ROWS) ? HaloSkew<BM, CK>::EL : 0;
+    a.skew = 0;
+    if (skew_env && KS == 3 && (a.W == 8 || a.W == 16)) {     // the skewed tile must end before the dump row
+        const int rows = a.TI * (a.TH + 2);
+        if (a.HP * PITCH + rows * HaloSkew<CK>::EL <= MAXHP * PITCH) a.skew = HaloSkew<CK>::EL;
+    }
     dim3 grid((a.N * a.H * a.W + BM - 1) / BM, (a.Nc + 127) / 128, a.ksplit);
     static bool once = [] {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
