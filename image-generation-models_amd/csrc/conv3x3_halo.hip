@@ -484,31 +484,60 @@ void launch_halo(const HaloArgs& a_in, hipStream_t st) {
 // fp32 [tap][k][n] master weights -> bf16 Wd[tap][k][n] (same layout) and Wf[tap][n][k] (transposed per tap)
 struct PackEntry { long long off; int taps, ci, co, tile0; };
 
+constexpr int PACK_TILE = 64;       // mi_pack_weights_tile(): entries count their tiles as taps * ceil(ci / 64) * ceil(co / 64)
+
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __restrict__ ents, int nent,
                                                            const float* __restrict__ master, uint16_t* __restrict__ wd,
                                                            uint16_t* __restrict__ wf) {
-    __shared__ float tile[32][33];
-    int e = 0;
-    while (e + 1 < nent && (int)blockIdx.x >= ents[e + 1].tile0) ++e;
+    __shared__ float tile[PACK_TILE][PACK_TILE + 1];
+    int e = 0;                      // last entry whose first tile is <= blockIdx.x: binary search (a linear walk is ~60 dependent
+    for (int hi = nent; hi - e > 1;) {      // scalar loads per workgroup and was most of this kernel's time)
+        const int mid = (e + hi) >> 1;
+        if ((int)blockIdx.x >= ents[mid].tile0) e = mid; else hi = mid;
+    }
     const PackEntry en = ents[e];
     int local = blockIdx.x - en.tile0;
-    const int tci = (en.ci + 31) / 32, tco = (en.co + 31) / 32;
+    const int tci = (en.ci + PACK_TILE - 1) / PACK_TILE, tco = (en.co + PACK_TILE - 1) / PACK_TILE;
     int tap = local / (tci * tco);
     int rem = local - tap * (tci * tco);
     int bi = rem / tco, bj = rem - bi * tco;
     const float* src = master + en.off + (size_t)tap * en.ci * en.co;
     uint16_t* d1 = wd + en.off + (size_t)tap * en.ci * en.co;
     uint16_t* d2 = wf + en.off + (size_t)tap * en.ci * en.co;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int r = ty; r < 32; r += 8) {
-        int i = bi * 32 + r, j = bj * 32 + tx;
+    if (((en.ci | en.co) & 3) == 0 && (en.off & 3) == 0) {
+        // 64 x 64 tile, 16 threads per row: float4 in, 4 bf16 (8 bytes) out, both copies in 128-byte row segments
+        const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = r0 + 16 * p, i = bi * PACK_TILE + r, j = bj * PACK_TILE + c4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < en.ci && j < en.co) {
+                v = *reinterpret_cast<const f32x4*>(src + (size_t)i * en.co + j);
+                *reinterpret_cast<u32x2*>(d1 + (size_t)i * en.co + j) = u32x2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};
+            }
+            tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = r0 + 16 * p, j = bj * PACK_TILE + r, i = bi * PACK_TILE + c4;      // output row = co, 4 consecutive ci
+            if (i < en.ci && j < en.co)
+                *reinterpret_cast<u32x2*>(d2 + (size_t)j * en.ci + i) =
+                    u32x2{pack_bf16(tile[c4][r], tile[c4 + 1][r]), pack_bf16(tile[c4 + 2][r], tile[c4 + 3][r])};
+        }
+        return;
+    }
+    // channel counts that are not multiples of 4 (the 3-channel ends): element by element
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < PACK_TILE; r += 4) {
+        int i = bi * PACK_TILE + r, j = bj * PACK_TILE + tx;
         float v = (i < en.ci && j < en.co) ? src[(size_t)i * en.co + j] : 0.f;
         tile[r][tx] = v;
         if (i < en.ci && j < en.co) d1[(size_t)i * en.co + j] = (uint16_t)(pack_bf16(v, 0.f) & 0xffff);
     }
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        int j = bj * 32 + r, i = bi * 32 + tx;
+    for (int r = ty; r < PACK_TILE; r += 4) {
+        int j = bj * PACK_TILE + r, i = bi * PACK_TILE + tx;
         if (i < en.ci && j < en.co) d2[(size_t)j * en.ci + i] = (uint16_t)(pack_bf16(tile[tx][r], 0.f) & 0xffff);
     }
 }
@@ -793,6 +822,9 @@ extern "C" int mi_conv3x3_bf16w_supported(const MiConvDesc* d) {
     int bm, ck;
     return (d && halo_ok(d, &bm, &ck)) ? 1 : 0;
 }
+
+// tile edge the entries' tile0 fields are counted in: taps * ceil(ci / T) * ceil(co / T) tiles per entry
+extern "C" int mi_pack_weights_tile(void) { return PACK_TILE; }
 
 extern "C" int mi_pack_weights_bf16(int nent, const void* entries_dev, int total_tiles, const float* master,
                                     void* wd_bf16, void* wf_bf16, void* stream) {

@@ -198,11 +198,11 @@ class FlatNet(nn.Module):
             if sh is None or sh[0].device != flat.device:
                 ents = [e for e in self._entries if e.layout in ("conv", "convT")]
                 rec = np.zeros(len(ents), dtype=np.dtype([("off", "<i8"), ("taps", "<i4"), ("ci", "<i4"), ("co", "<i4"), ("tile0", "<i4")]))
-                tile = 0
+                tile, T = 0, K.pack_weights_tile()
                 for i, e in enumerate(ents):
                     kh, kw, ci, co = e.storage_view(flat).shape
                     rec[i] = (e.offset, kh * kw, ci, co, tile)
-                    tile += kh * kw * ((ci + 31) // 32) * ((co + 31) // 32)
+                    tile += kh * kw * ((ci + T - 1) // T) * ((co + T - 1) // T)
                 table = torch.from_numpy(rec.view(np.uint8).copy()).to(flat.device)
                 sh = (torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16),
                       torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16), table, len(ents), tile)

@@ -249,6 +249,11 @@ def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None):
     return y
 
 
+def pack_weights_tile():
+    """Tile edge mi_pack_weights_bf16 counts an entry's tiles in (tile0 = running sum of taps * ceil(ci / T) * ceil(co / T))."""
+    return int(load_library().mi_pack_weights_tile())
+
+
 def pack_weights_bf16(table_dev, nent, total_tiles, master, wd, wf):
     e0 = _probe_open()
     check(load_library().mi_pack_weights_bf16(nent, _p(table_dev), total_tiles, _p(master), _p(wd), _p(wf), _stream()),

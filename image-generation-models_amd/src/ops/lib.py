@@ -60,6 +60,7 @@ SIGNATURES = {
     "mi_conv_s2_wgrad_tr_batch": [_I, C.POINTER(MiWgradDesc), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _Z, _P],
     "mi_debug_wgrad_s2_tr_phase": [_I],
     "mi_debug_conv_dma_chunk": [_I],
+    "mi_pack_weights_tile": [],
     "mi_debug_wgrad1x1_tr_blocks": [_I],
     "mi_debug_wgrad_tr_blocks": [_I],
     "mi_conv3x3_bf16w_io": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],

@@ -131,8 +131,10 @@ int mi_conv3x3_shift(const MiConvDesc* d, const void* x, const void* x2, const v
                      const float* residual, void* y, int out_bf16, void* stream);
 /* bf16 shadow copies of every conv weight of the flat fp32 parameter buffer (master layout
  * [tap][Cin][Cout] at float offset `off`): wd = same layout, wf = [tap][Cout][Cin].
- * entries_dev: device array of {int64 off; int32 taps, ci, co, tile0}, tile0 = first 32x32-tile
- * index of the entry (prefix sum of taps*ceil(ci/32)*ceil(co/32)); total_tiles = grid size. */
+ * entries_dev: device array of {int64 off; int32 taps, ci, co, tile0}, tile0 = first tile
+ * index of the entry (prefix sum of taps*ceil(ci/T)*ceil(co/T), T = mi_pack_weights_tile()); total_tiles = grid size. */
+/* tile edge T the entries' tile0 fields are counted in: an entry owns taps * ceil(ci / T) * ceil(co / T) consecutive tiles */
+int mi_pack_weights_tile(void);
 int mi_pack_weights_bf16(int nent, const void* entries_dev, int total_tiles, const float* master,
                          void* wd_bf16, void* wf_bf16, void* stream);
 

@@ -417,7 +417,8 @@ def _pack(K, w_storage_list):
         kh, kw, ci, co = w.shape
         flat[o:o + w.numel()] = w.reshape(-1)
         rec[i] = (o, kh * kw, ci, co, tile)
-        tile += kh * kw * ((ci + 31) // 32) * ((co + 31) // 32)
+        T = K.pack_weights_tile()
+        tile += kh * kw * ((ci + T - 1) // T) * ((co + T - 1) // T)
     table = torch.from_numpy(rec.view(np.uint8).copy()).to(DEV)
     wd = torch.zeros(off, device=DEV, dtype=torch.bfloat16)
     wf = torch.zeros(off, device=DEV, dtype=torch.bfloat16)
@@ -428,7 +429,8 @@ def _pack(K, w_storage_list):
 def test_pack_weights_bf16(K):
     g = torch.Generator().manual_seed(23)
     ws = [torch.randn(3, 3, 40, 24, generator=g).to(DEV), torch.randn(1, 1, 16, 3, generator=g).to(DEV),
-          torch.randn(4, 4, 32, 32, generator=g).to(DEV)]
+          torch.randn(4, 4, 32, 32, generator=g).to(DEV), torch.randn(3, 3, 3, 128, generator=g).to(DEV),
+          torch.randn(3, 3, 192, 100, generator=g).to(DEV), torch.randn(1, 1, 128, 384, generator=g).to(DEV)]
     flat, wd, wf, offs = _pack(K, ws)
     torch.cuda.synchronize()
     for w, o in zip(ws, offs):

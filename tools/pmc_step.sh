@@ -13,8 +13,13 @@ for r in csv.DictReader(open('gpurun_out/pmcstep_$tag/p_counter_collection.csv')
     k=re.sub(r'^void ','',k).split('(')[0][:60]
     agg[k][r['Counter_Name']] += float(r['Counter_Value'])
     if (r['Dispatch_Id'],) not in seen: seen.add((r['Dispatch_Id'],)); cnt[k]+=1
+dur=collections.defaultdict(float)
+for r in csv.DictReader(open('gpurun_out/pmcstep_$tag/p_kernel_trace.csv')):
+    k=re.sub(r'\(anonymous namespace\)::','',r['Kernel_Name'])
+    k=re.sub(r'^void ','',k).split('(')[0][:60]
+    dur[k]+=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
 names=sorted({c for v in agg.values() for c in v})
-print('kernel'.ljust(62), 'launches', *names)
-for k,v in sorted(agg.items(), key=lambda kv: -sum(kv[1].values())):
-    print(k.ljust(62), cnt[k], *[int(v.get(c,0)) for c in names])
+print('kernel'.ljust(62), 'launches', 'total_us', *names)
+for k,v in sorted(agg.items(), key=lambda kv: -dur[kv[0]]):
+    print(k.ljust(62), cnt[k], round(dur[k],1), *[int(v.get(c,0)) for c in names])
 PY
