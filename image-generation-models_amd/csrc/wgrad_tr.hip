@@ -25,6 +25,9 @@
 // contiguous per wave and store) and wgrad_tr_reduce_kernel sums them in a fixed order (deterministic) into dW.
 #include "tr_common.h"
 
+#ifndef MI_WTR_VMCNT2
+#define MI_WTR_VMCNT2 0   // 1: leave the newest dY pieces in flight across the step barrier (measured: 0.640 vs 0.635 ms per step, no gain)
+#endif
 #ifndef MI_WTR_ABL
 #define MI_WTR_ABL 0     // profiling only: 1 no partial-tile stores, 2 no main loop
 #endif
@@ -140,7 +143,13 @@ __device__ __forceinline__ void wgrad_tr_body(const TrArgs& a, const int wg, uin
 #endif
 
     for (int s = sb; s < ((MI_WTR_ABL & 2) ? sb + 1 : se); ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // everything requested so far (steps <= s+1) has landed ...
+        // everything this step reads has landed: X and dY of steps <= s, the X row of step s+1 (halo below).  (MI_WTR_VMCNT2: the two
+        // dY pieces of step s+1 are the newest requests and could stay in flight -- loads complete in order.)
+#if MI_WTR_VMCNT2
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_s_barrier();                         // ... for every wave, and every wave is done reading step s-1
         asm volatile("" ::: "memory");
         stage(s + 2);
