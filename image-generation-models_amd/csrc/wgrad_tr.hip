@@ -69,9 +69,14 @@ __device__ __forceinline__ void wgrad_tr_body(const TrArgs& a, const int wg, uin
     // different XCDs (id % 8), each with its own L2 -- when the slices divide evenly, ids xcd + 8*slot with slot = tile + ntiles*m
     // belong to slice xcd + 8*m, so that one L2 serves all tiles of a slice (the problem starts at a multiple of 8: host).
     int split = wg / ntiles, tile = wg - split * ntiles;
-    if (a.xcd_map) {
+    if (a.xcd_map == 1) {
         const int xcd = wg & 7, slot = wg >> 3;
         tile = slot % ntiles; split = xcd + 8 * (slot / ntiles);
+    } else if (a.xcd_map == 2) {
+        // fewer than 8 slices: g = 8 / splits XCDs per slice, each takes ntiles / g consecutive tiles (consecutive tiles share their
+        // co tile, i.e. their dY rows) -- ids xcd + 8*slot -> slice xcd / g, tile (xcd % g) * (ntiles / g) + slot
+        const int xcd = wg & 7, slot = wg >> 3, g = 8 / a.splits;
+        split = xcd / g; tile = (xcd % g) * (ntiles / g) + slot;
     }
     const int ci0 = (tile % a.gx) * 64, co0 = (tile / a.gx) * 128;
     const int sb = split * a.sps, se = min(a.total, sb + a.sps);
@@ -400,8 +405,12 @@ extern "C" int mi_conv3x3_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         a.ldp = descs[i].ldp; a.ldp2 = (P2 && P2[i]) ? descs[i].ldp2 : descs[i].ldp; a.ldq = descs[i].ldq;
         a.ws = (float*)workspace + off;
         off += tr_ws_floats(a);
-        static const int xcd_env = [] { const char* e = getenv("MI_WTR_XCD"); return e ? atoi(e) : 1; }();
-        a.xcd_map = xcd_env && a.splits % 8 == 0 && a.gx * a.gy > 1 && wg % 8 == 0;
+        static const int xcd_env = [] { const char* e = getenv("MI_WTR_XCD"); return e ? atoi(e) : 2; }();
+        a.xcd_map = 0;
+        if (xcd_env && a.gx * a.gy > 1 && wg % 8 == 0) {
+            if (a.splits % 8 == 0) a.xcd_map = 1;
+            else if (xcd_env > 1 && a.splits < 8 && 8 % a.splits == 0 && (a.gx * a.gy) % (8 / a.splits) == 0) a.xcd_map = 2;
+        }
         a.wg0 = wg; wg += a.gx * a.gy * a.splits;
         a.tile0 = tile; if (a.splits > 1) tile += a.gx * a.gy;
         if (a.splits > max_splits) max_splits = a.splits;
