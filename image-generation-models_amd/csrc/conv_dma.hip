@@ -32,20 +32,24 @@ struct DmaConvArgs {
 
 constexpr int BM = 128, BN = 128;
 constexpr int MAXHP = 208;                       // halo pixels: 4 rows of 32 (6 x 34 = 204), 8 of 16 (180), two 8x8 images (200)
-constexpr int PD = 2;                            // (tap, k-step) units fetched ahead
 // CK = channels per chunk.  64: one workgroup per CU (148 KB of LDS).  32: half the LDS (77 KB), so TWO independent workgroups
 // share a CU -- while one waits at its stage barrier, fetches its first tile or stores its outputs, the other one's waves keep the
 // matrix pipe busy (the 8-wave single-workgroup kernels stall both waves of a SIMD at every barrier).
-template <int CK> struct DmaShape {
+// TPS = taps per stage (between two barriers).  3: a tap row, weights double-buffered 2 x 3 taps.  1: one tap, weights 2 x 1 tap --
+// with CK = 32 that is 42 KB of LDS, THREE workgroups per CU (3 waves per SIMD), fragments fetched one unit ahead.
+template <int CK, int TPS = 3> struct DmaShape {
     static constexpr int ROWB = CK * 2;              // bytes of a pixel / an output channel of one tap in LDS
     static constexpr int NCH = ROWB / 16;            // 16-byte chunks per row
     static constexpr int PPI = 1024 / ROWB;          // rows one wave-wide DMA instruction covers
     static constexpr int SH = CK == 64 ? 1 : 2;      // chunk position = chunk ^ ((row >> SH) & (NCH - 1)): 16 consecutive rows, one chunk -> all banks
     static constexpr int XBUF = MAXHP * ROWB;        // one halo buffer
-    static constexpr int WSTG = 3 * BN * ROWB;       // weights of one stage: three taps x 128 output channels x CK input channels
+    static constexpr int WSTG = TPS * BN * ROWB;     // weights of one stage: TPS taps x 128 output channels x CK input channels
     static constexpr int XOFF = 0, WOFF = 2 * XBUF, PIXOFF = WOFF + 2 * WSTG;     // + int[MAXHP] source pixel of each halo pixel
     static constexpr int KSN = CK / 16;              // MFMA k-steps per tap
-    static constexpr int NU = 3 * KSN;               // (tap, k-step) units per stage
+    static constexpr int NU = TPS * KSN;             // (tap, k-step) units per stage
+    static constexpr int PD = TPS == 3 ? 2 : 1;      // (tap, k-step) units fetched ahead
+    static constexpr int NST = 9 / TPS;              // stages per chunk
+    static constexpr int WGS = CK == 64 ? 1 : (TPS == 3 ? 2 : 3);     // workgroups per CU
 };
 
 __device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
@@ -53,9 +57,10 @@ __device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
     return *(lds_bf16x8*)(uintptr_t)addr;
 }
 
-template <int CK, bool OUT16>
-__global__ __launch_bounds__(256, (CK == 64 ? 1 : 2)) void conv_dma_kernel(const DmaConvArgs a) {
-    using Sh = DmaShape<CK>;
+template <int CK, bool OUT16, int TPS = 3>
+__global__ __launch_bounds__(256, (DmaShape<CK, TPS>::WGS)) void conv_dma_kernel(const DmaConvArgs a) {
+    using Sh = DmaShape<CK, TPS>;
+    constexpr int PD = Sh::PD, NST = Sh::NST;
     constexpr int ROWB = Sh::ROWB, NCH = Sh::NCH, PPI = Sh::PPI, SH = Sh::SH, XBUF = Sh::XBUF, WSTG = Sh::WSTG;
     constexpr int XOFF = Sh::XOFF, WOFF = Sh::WOFF, PIXOFF = Sh::PIXOFF, KSN = Sh::KSN, NU = Sh::NU;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -127,11 +132,11 @@ __global__ __launch_bounds__(256, (CK == 64 ? 1 : 2)) void conv_dma_kernel(const
             }
         }
     };
-    auto stage_w = [&](int st) {                         // weights of stage st = (chunk st / 3, tap row st % 3) -> slot st & 1
-        const int ch = st / 3, ky = st - ch * 3;
+    auto stage_w = [&](int st) {                         // weights of stage st = (chunk st / NST, taps (st % NST) * TPS ..) -> slot st & 1
+        const int ch = st / NST, t0 = (st - ch * NST) * TPS;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int tap = ky * 3 + kx;
+        for (int kx = 0; kx < TPS; ++kx) {
+            const int tap = t0 + kx;
             const uint16_t* base = a.w + (size_t)(a.flip ? 8 - tap : tap) * tap_stride + (size_t)ch * CK;
 #pragma unroll
             for (int i = 0; i < NWI; ++i)
@@ -178,24 +183,25 @@ __global__ __launch_bounds__(256, (CK == 64 ? 1 : 2)) void conv_dma_kernel(const
         }
     stage_x(0);
     stage_w(0);
-    const int nstages = nchunks * 3;
+    const int nstages = nchunks * NST;
     static_assert(NU % (PD + 1) == 0, "ring slots must line up across stages");
     for (int st = 0; st < nstages; ++st) {
         // stage st's weights (and halo tile) have landed: this wave's pieces; every LDS read this wave issued is complete ...
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                         // ... for every wave: stage st-1's slot may be refilled
         asm volatile("" ::: "memory");
-        const int ch = st / 3, ky = st - ch * 3;
+        const int ch = st / NST, t0 = (st - ch * NST) * TPS;
         if (st + 1 < nstages) stage_w(st + 1);
-        if (ky == 0 && ch + 1 < nchunks) stage_x(ch + 1);
+        if (t0 == 0 && ch + 1 < nchunks) stage_x(ch + 1);
         const uint32_t xb = lds0 + XOFF + (ch & 1) * XBUF, wbase = lds0 + WOFF + (st & 1) * WSTG;
         // per tap column: the lane's two halo pixels, their byte offset and swizzle
-        int xo[3][2], xs[3][2];
+        int xo[TPS][2], xs[TPS][2];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+        for (int kx = 0; kx < TPS; ++kx)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int hp = hp0[i] + ky * W2 + kx;
+                const int tap = t0 + kx;
+                const int hp = hp0[i] + (tap / 3) * W2 + tap % 3;
                 xo[kx][i] = hp * ROWB; xs[kx][i] = ((hp >> SH) & (NCH - 1)) * 16;
             }
         // NU units = (tap column kx, k-step ks); a unit = 2 + 2 fragment reads and 4 MFMAs
@@ -267,6 +273,9 @@ __global__ __launch_bounds__(256, (CK == 64 ? 1 : 2)) void conv_dma_kernel(const
                 }
         }
         if (m >= (size_t)Mtot) continue;
+#ifdef MI_DMA_ABL       // profiling only: no output stores (one guarded store keeps the accumulators live)
+        if (v[0][0].x != 123.456f) continue;
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(256, (CK == 64 ? 1 : 2)) void conv_dma_kernel(const
     }
 }
 
-int g_dma_ck = [] { const char* e = getenv("MI_CONV_DMA_CK"); return (e && atoi(e) == 32) ? 32 : 64; }();
+int g_dma_ck = [] { const char* e = getenv("MI_CONV_DMA_CK"); const int v = e ? atoi(e) : 64; return (v == 32 || v == 33) ? v : 64; }();
 
 bool dma_geom(const MiConvDesc* d, int* TH, int* TI) {
     const int W = d->OW, H = d->OH;
@@ -330,11 +339,17 @@ extern "C" int mi_conv3x3_dma(const MiConvDesc* d, const void* x, const void* x2
         (void)hipFuncSetAttribute((const void*)conv_dma_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_dma_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_dma_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_dma_kernel<32, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 53 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_dma_kernel<32, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 53 * 1024);
         return true;
     }();
     (void)once;
     hipStream_t st = (hipStream_t)stream;
-    if (g_dma_ck == 32) {
+    if (g_dma_ck == 33) {        // 32-channel chunks, one tap per stage: three workgroups per CU
+        const size_t lds = (size_t)DmaShape<32, 1>::PIXOFF + MAXHP * 4;
+        if (out_bf16) hipLaunchKernelGGL((conv_dma_kernel<32, true, 1>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((conv_dma_kernel<32, false, 1>), grid, dim3(256), lds, st, a);
+    } else if (g_dma_ck == 32) {
         const size_t lds = (size_t)DmaShape<32>::PIXOFF + MAXHP * 4;
         if (out_bf16) hipLaunchKernelGGL((conv_dma_kernel<32, true>), grid, dim3(256), lds, st, a);
         else hipLaunchKernelGGL((conv_dma_kernel<32, false>), grid, dim3(256), lds, st, a);
@@ -349,7 +364,7 @@ extern "C" int mi_conv3x3_dma(const MiConvDesc* d, const void* x, const void* x2
 
 // 32: two workgroups per CU on 32-channel chunks; 64 (default): one workgroup per CU on 64-channel chunks
 extern "C" int mi_debug_conv_dma_chunk(int ck) {
-    if (ck != 32 && ck != 64) return mi_set_error(-1, "mi_debug_conv_dma_chunk: 32 or 64");
+    if (ck != 32 && ck != 33 && ck != 64) return mi_set_error(-1, "mi_debug_conv_dma_chunk: 32, 33 (= 32 with one tap per stage) or 64");
     g_dma_ck = ck;
     return 0;
 }

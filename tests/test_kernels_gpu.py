@@ -503,11 +503,11 @@ def test_conv3x3_shift_fwd_and_dgrad(K, cfg, out16):
     dict(N=2, H=16, Ci=64, Co=96),               # ragged co tile
     dict(N=4, H=8, Ci=1024, Co=64, split=512),   # long K, half-empty co tile
 ])
-@pytest.mark.parametrize("chunk", [64, 32])
+@pytest.mark.parametrize("chunk", [64, 32, 33])
 def test_conv3x3_lds_dma_fwd_and_dgrad(K, cfg, out16, chunk, request):
     """Block's 3x3 conv (ddpm.py:116) and its data gradient for bf16-stored activations through the LDS-DMA kernel
     (mi_conv3x3_dma): bias, residual, fp32 and bf16 output, accumulate; against fp64 on the same bf16-rounded operands.
-    chunk = 32: the variant with 32-channel chunks and two workgroups per CU."""
+    chunk = 32: the variant with 32-channel chunks and two workgroups per CU; 33: one tap per stage, three workgroups per CU."""
     K.load_library().mi_debug_conv_dma_chunk(chunk)
     request.addfinalizer(lambda: K.load_library().mi_debug_conv_dma_chunk(64))
     from src.ops.lib import MiConvDesc, load_library
