@@ -48,6 +48,7 @@ struct HaloArgs {
     int xmap;            // XCD-aware tile order (3x3, several row tiles per image, N % 8 == 0)
     const float* coef;   // FUSE: [3][N][K] scale / shift / time bias of the GroupNorm + Mish applied to x while it is staged
     int skew;            // extra LDS elements per halo ROW (see HaloSkew); 0 = rows packed
+    int ep_rows;         // epilogue through LDS: row-contiguous stores and residual / accumulate loads
 };
 
 // Bank conflicts of the 8- and 16-pixel-wide tiles.  A ds_read_b128 serves a half-wave (32 lanes) conflict-free when the 32
@@ -399,6 +400,62 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
                 bq[j][rq] = *reinterpret_cast<const f32x4*>(a.bias + min(col, a.Nc - 4));
             }
     }
+    if (a.ep_rows) {
+        // Row-contiguous epilogue.  In the accumulator layout a lane owns 4 consecutive channels of ONE pixel, so a store (and a
+        // residual / accumulate load) instruction touches 64 different rows with 8-16 bytes each: 13.1 us instead of 7.1 us for a
+        // [131072][128] bf16 tensor (tools/proto/store_probe.hip), and nothing overlaps it because all workgroups of a round finish
+        // together.  The wave's tile goes through a wave-private LDS area ([pixel][64 co] fp32, 272-byte pitch: an odd number of
+        // 16-byte granules, so the 32 rows a half-wave writes are conflict-free) and comes back as lane = (pixel, 4-channel chunk):
+        // an instruction then covers 4 whole 256-byte (fp32) / 128-byte (bf16) row segments.
+        constexpr int EPP = 68;                                  // floats per staged pixel row
+        __syncthreads();                                         // every wave is done with the halo / weight tiles
+        float* ep = reinterpret_cast<float*>(lds) + wv * (MI * 32 * EPP);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+                    *reinterpret_cast<f32x4*>(ep + (i * 32 + (l & 31)) * EPP + j * 32 + 8 * rq + 4 * (l >> 5)) =
+                        f32x4{acc[i][j][4 * rq], acc[i][j][4 * rq + 1], acc[i][j][4 * rq + 2], acc[i][j][4 * rq + 3]} + bq[j][rq];
+        const int c4 = (l & 15) * 4, col = n0 + wn * 64 + c4, colc = min(col, a.Nc - 4);
+        const bool use_res = a.res && first;
+#pragma unroll
+        for (int k0 = 0; k0 < MI * 8; k0 += 4) {                 // 4 pixels per pass, 4 passes per batch of loads
+            f32x4 v[4], rv[4], ov[4];
+            size_t mm[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = (k0 + q) * 4 + (l >> 4);
+                mm[q] = (size_t)m0 + wm * (MI * 32) + p;
+                const size_t mc = min(mm[q], (size_t)Mtot - 1);
+                v[q] = *reinterpret_cast<const f32x4*>(ep + p * EPP + c4);
+                rv[q] = use_res ? *reinterpret_cast<const f32x4*>(a.res + mc * a.ldr + colc) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.accumulate) {
+                    if constexpr (OUT16) {
+                        const u32x2 o = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(a.y) + mc * a.ldy + colc);
+                        ov[q] = f32x4{__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u),
+                                      __uint_as_float(o.y << 16), __uint_as_float(o.y & 0xffff0000u)};
+                    } else {
+                        ov[q] = *reinterpret_cast<const f32x4*>(a.y + mc * a.ldy + colc);
+                    }
+                } else {
+                    ov[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 o = (v[q] + rv[q]) + ov[q];
+                if (mm[q] >= (size_t)Mtot || col >= a.Nc) continue;
+                if constexpr (OUT16)
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.y) + mm[q] * a.ldy + col) = u32x2{pack_bf16(o.x, o.y), pack_bf16(o.z, o.w)};
+                else
+                    *reinterpret_cast<f32x4*>(a.y + mm[q] * a.ldy + col) = o;
+            }
+        }
+        MI_TS(4);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const size_t m = (size_t)m0 + wm * (MI * 32) + i * 32 + (l & 31);
@@ -466,6 +523,14 @@ void launch_halo(const HaloArgs& a_in, hipStream_t st) {
     constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
     size_t lds = (size_t)(2 * (MAXHP + 1) * PITCH + 2 * 128 * PITCH) * 2 + MAXHP * 4;
     HaloArgs a = a_in;
+    // off by default: measured neutral (level 0 56.7 -> 55.8 us, step 6.39 vs 6.41 ms) -- what the ablation charges to the stores is
+    // their burst at the end of a round of workgroups, not the rows per instruction
+    static const int ep_env = [] { const char* e = getenv("MI_HALO_EPI"); return e ? atoi(e) : 0; }();
+    a.ep_rows = (ep_env && !SK) ? 1 : 0;
+    if (a.ep_rows) {
+        const size_t need = (size_t)WAVES * HaloCfg<BM, WAVES>::MI * 32 * 68 * sizeof(float);
+        if (need > lds) lds = need;
+    }
     static const int skew_env = [] { const char* e = getenv("MI_HALO_SKEW"); return e ? atoi(e) : 1; }();
     a.skew = 0;
     if (skew_env && KS == 3 && (a.W == 8 || a.W == 16)) {     // the skewed tile must end before the dump row
