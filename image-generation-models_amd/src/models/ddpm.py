@@ -255,6 +255,8 @@ class Unet(nn.Module):
         self.fuse_gn_conv = os.environ.get("MI_DDPM_FUSE_GN", "0") == "1"
         # Downsample / Upsample weight gradients through the LDS-DMA kernel (csrc/wgrad_s2_tr.hip); 0 = round 1's ring kernel
         self.s2_wgrad_tr = os.environ.get("MI_DDPM_S2_TR", "1") != "0"
+        # final_conv.0's conv output stored like the other Blocks' (bf16 in bf16 mode); 0 = fp32 as in round 1
+        self.final_block16 = os.environ.get("MI_DDPM_FINAL16", "1") != "0"
         self.accumulate_grads = False
         self.grad_ready_hook = None        # callable(lo, hi): flat_grads[lo:hi) is final (set by the DDP reducer)
 
@@ -574,11 +576,19 @@ class Unet(nn.Module):
             h = conv(inp if inp_c is None else inp_c, lvl["up"]["pre"], 4, 2, 1, transposed_conv=True)
             if record:
                 tape.append(("up", lvl["up"], inp, h, inp_c))
-        cF = conv(h, "final_conv.0.block.0.", 3, 1, 1)
+        # final_conv.0 is a Block too (ddpm.py:232-234): its conv output is block-internal and stored like every other Block's
+        # (bf16 in bf16 mode); the GroupNorm output feeds the 128 -> 3 conv, an fp32 VALU kernel, and stays fp32
+        cdim = h.shape[3]
+        f16 = False
+        if mode == K.MODE_BF16 and self.block_storage in ("bf16", "auto") and cdim % 64 == 0 and B % 8 == 0 and self.final_block16:
+            okf = K.fast3x3_supported(B, h.shape[1], h.shape[2], cdim, cdim)
+            f16 = okf[0] and okf[1] and not K.conv3x3_uses_splitk(B, h.shape[1], h.shape[2], cdim, cdim)
+        h_c = shadow(h) if (f16 and use_sh) else h
+        cF = conv(h_c, "final_conv.0.block.0.", 3, 1, 1, out_dtype=BF if f16 else torch.float32)
         hF, stF = K.gn_mish_fwd(cF, sv["final_conv.0.block.1.weight"], sv["final_conv.0.block.1.bias"])
         eps = conv(hF, "final_conv.1.", 1)
         if record:
-            tape.append(("final", h, cF, stF, hF, eps))
+            tape.append(("final", h, cF, stF, hF, eps, h_c))
             tape.append(("input", x))
         return eps, tape
 
@@ -752,13 +762,13 @@ class Unet(nn.Module):
             if hook is not None:
                 rng = (A.final_range if kind == "final" else A.time_range if kind == "time" else rec[1]["range"])
             if kind == "final":
-                _, h, cF, stF, hF, eps = rec
+                _, h, cF, stF, hF, eps, h_c = rec
                 conv_bwd(d_eps, hF, "final_conv.1.", 1)
                 dhF = G.take(hF)
                 dcF = K.gn_mish_bwd(cF, stF, sv["final_conv.0.block.1.weight"], sv["final_conv.0.block.1.bias"], dhF,
                                     dgamma=gv["final_conv.0.block.1.weight"], dbeta=gv["final_conv.0.block.1.bias"],
-                                    dbias=gv["final_conv.0.block.0.bias"])
-                conv_bwd(dcF, h, "final_conv.0.block.0.", 3, 1, 1, bias=None)
+                                    dbias=gv["final_conv.0.block.0.bias"], out_dtype=cF.dtype)
+                conv_bwd(dcF, h, "final_conv.0.block.0.", 3, 1, 1, bias=None, winp=h_c)
             elif kind == "res":
                 res_bwd(rec)
             elif kind == "attn":

@@ -347,7 +347,7 @@ def test_linear_attention_core(K, cfg):
     og2, cg2, sg2 = K.linattn_fwd(qg, heads)
     dq2 = K.linattn_bwd(qg, cg2, sg2, to_nhwc_gpu(dout.float()).contiguous(), heads)
     assert torch.equal(og, og2) and torch.equal(cg, cg2) and torch.equal(dq, dq2)
-    assert (K.load_library().mi_linattn_workspace(N, n, heads) > 0) == (n >= 256 and N * heads < 512)
+    assert (K.load_library().mi_linattn_workspace(N, n, heads) > 0) == (n >= 256 and N * heads < 256)
 
 
 def test_time_embed_and_layouts(K, golden_dir):
