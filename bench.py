@@ -204,6 +204,28 @@ def named_kernel_line(K, dev):
         fused_us = [v for k, v in med.items() if k.startswith("conv3x3_halo_kernel")][0]
         ent["fused"] = dict(kernel=[k for k in med if k.startswith("conv3x3_halo_kernel")][0],
                             statistics_pass_us=[v for k, v in med.items() if "statistics" in k][0], **line(fused_us))
+        # ... and with the statistics taken from the PRODUCING conv's epilogue (mi_conv3x3_bf16w_io_gnsums) and resolved inside the
+        # fused kernel (mi_conv3x3_gn_mish_sums): no pass over the tensor at all.  The unit is the one fused launch; what the sums
+        # cost the producing conv is reported beside it (same shape: conv 128 -> 128 with and without the sums).
+        sums = torch.zeros(N * (Cc // 16) * 2, device=dev)
+        xin = torch.randn(N, H, W, Cc, device=dev, generator=g).to(dt)
+        gn = (sums, gamma, beta, temb, 8, 1e-5)
+        for _ in range(5):
+            K.conv3x3_bf16w(xin, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt, gn_sums=sums)
+            K.conv3x3_gn_mish(x, None, w, K=Cc, Nc=Cc, bias=bias, gn=gn)
+        t = {"plain": [], "sums": [], "fused": []}
+        for _ in range(20):
+            for key, fn in (("plain", lambda: K.conv3x3_bf16w(xin, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt)),
+                            ("sums", lambda: K.conv3x3_bf16w(xin, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt, gn_sums=sums)),
+                            ("fused", lambda: K.conv3x3_gn_mish(x, None, w, K=Cc, Nc=Cc, bias=bias, gn=gn))):
+                K.PROBE = []
+                fn()
+                torch.cuda.synchronize()
+                t[key].append(sum(e0.elapsed_time(e1) for _s, _f, e0, e1, _d, _n in K.PROBE) * 1e3)
+                K.PROBE = None
+        md = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
+        ent["fused_epilogue_stats"] = dict(kernel=ent["fused"]["kernel"], producer_conv_us=round(md["plain"], 2),
+                                           producer_conv_with_sums_us=round(md["sums"], 2), **line(md["fused"]))
         out[sto + "_storage"] = ent
     return out
 

@@ -49,6 +49,10 @@ struct HaloArgs {
     const float* coef;   // FUSE: [3][N][K] scale / shift / time bias of the GroupNorm + Mish applied to x while it is staged
     int skew;            // extra LDS elements per halo ROW (see HaloSkew); 0 = rows packed
     int ep_rows;         // epilogue through LDS: row-contiguous stores and residual / accumulate loads
+    const float* gn_sums; const float* gn_gamma; const float* gn_beta; const float* gn_temb;   // FUSE without a coef tensor: the
+    int gn_cg, gn_ldt; float gn_eps; double gn_icnt;   // producing conv's per-slab sums [N][K / 16][2] + the affine / time-bias vectors
+    float* gsum;         // optional [N][C / 16][2]: += (sum, sum of squares) of the STORED outputs per sample and 16-channel slab --
+                         // the GroupNorm statistics of the next layer, taken from this conv's epilogue instead of a pass over y
 };
 
 // Bank conflicts of the 8- and 16-pixel-wide tiles.  A ds_read_b128 serves a half-wave (32 lanes) conflict-free when the 32
@@ -205,9 +209,24 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     f32x4 cf_s = {1.f, 1.f, 1.f, 1.f}, cf_b = {0.f, 0.f, 0.f, 0.f}, cf_t = {0.f, 0.f, 0.f, 0.f};
     auto load_coef = [&](int ch) {
         if constexpr (FUSE) {
-            const size_t NK = (size_t)a.N * a.K;
-            const float* c = a.coef + (size_t)(bx / a.tiles_per_img) * a.K + (size_t)(ch0 + ch) * CK + a_c4 * 4;
-            cf_s = *reinterpret_cast<const f32x4*>(c); cf_b = *reinterpret_cast<const f32x4*>(c + NK); cf_t = *reinterpret_cast<const f32x4*>(c + 2 * NK);
+            const int n = bx / a.tiles_per_img, c0 = (ch0 + ch) * CK + a_c4 * 4;
+            if (a.gn_sums) {
+                // statistics straight from the sums the producing conv's epilogue left (no coefficient tensor, no extra launch):
+                // the group's 16-channel slabs are combined in double, var = E[x^2] - mean^2
+                const int g = c0 / a.gn_cg, nslab = a.gn_cg >> 4;
+                const float* p = a.gn_sums + ((size_t)n * (a.K >> 4) + (size_t)g * nslab) * 2;
+                double sm = 0.0, sq = 0.0;
+                for (int k = 0; k < nslab; ++k) { sm += p[2 * k]; sq += p[2 * k + 1]; }
+                const double mean = sm * a.gn_icnt;                                      // no fp64 division in the loop
+                const float var = (float)fmax(sq * a.gn_icnt - mean * mean, 0.0), rstd = __builtin_amdgcn_rsqf(var + a.gn_eps), mf = (float)mean;
+                cf_s = *reinterpret_cast<const f32x4*>(a.gn_gamma + c0) * rstd;
+                cf_b = *reinterpret_cast<const f32x4*>(a.gn_beta + c0) - cf_s * mf;
+                cf_t = a.gn_temb ? *reinterpret_cast<const f32x4*>(a.gn_temb + (size_t)n * a.gn_ldt + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const size_t NK = (size_t)a.N * a.K;
+                const float* c = a.coef + (size_t)n * a.K + c0;
+                cf_s = *reinterpret_cast<const f32x4*>(c); cf_b = *reinterpret_cast<const f32x4*>(c + NK); cf_t = *reinterpret_cast<const f32x4*>(c + 2 * NK);
+            }
         }
     };
 
@@ -456,6 +475,9 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
         MI_TS(4);
         return;
     }
+    float wps[NI * 2], wpq[NI * 2];             // a.gsum: this wave's sums over its MI pixel blocks
+#pragma unroll
+    for (int k = 0; k < NI * 2; ++k) wps[k] = wpq[k] = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const size_t m = (size_t)m0 + wm * (MI * 32) + i * 32 + (l & 31);
@@ -500,6 +522,50 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) v[j][rq] += ov[j][rq];
         }
+        if (a.gsum) {
+            // per-lane partial sums of this 32-pixel block (one image: H*W % 32 == 0), four 16-channel slabs per wave column
+            // block; the values are the ones the next kernel will read (rounded to bf16 when y is stored as bf16)
+            float ps[NI * 2], pq[NI * 2];
+#pragma unroll
+            for (int k = 0; k < NI * 2; ++k) ps[k] = pq[k] = 0.f;
+            const bool rowok = m < (size_t)Mtot;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int col = n0 + wn * 64 + j * 32 + 8 * rq + 4 * (l >> 5);
+                    f32x4 q = v[j][rq];
+                    if constexpr (OUT16) {
+                        const uint32_t p0 = pack_bf16(q.x, q.y), p1 = pack_bf16(q.z, q.w);
+                        q = f32x4{__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u), __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+                    }
+                    const float live = (rowok && col < a.Nc) ? 1.f : 0.f;
+                    ps[j * 2 + (rq >> 1)] += live * ((q.x + q.y) + (q.z + q.w));
+                    pq[j * 2 + (rq >> 1)] += live * ((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w));
+                }
+#pragma unroll
+            for (int k = 0; k < NI * 2; ++k) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) { ps[k] += __shfl_xor(ps[k], off, 64); pq[k] += __shfl_xor(pq[k], off, 64); }
+            }
+            if (a.TI == 1) {                       // the whole tile is one image: combined per workgroup after the loop
+#pragma unroll
+                for (int k = 0; k < NI * 2; ++k) { wps[k] += ps[k]; wpq[k] += pq[k]; }
+            } else if (l == 0) {
+                const size_t mblk = (size_t)m0 + wm * (MI * 32) + i * 32;
+                if (mblk < (size_t)Mtot) {
+                    const int n = (int)(mblk / ((size_t)a.H * a.W));
+#pragma unroll
+                    for (int k = 0; k < NI * 2; ++k) {
+                        const int col = n0 + wn * 64 + (k >> 1) * 32 + (k & 1) * 16;
+                        if (col < a.Nc) {
+                            float* g = a.gsum + ((size_t)n * (a.Nc / 16) + col / 16) * 2;
+                            atomicAdd(g, ps[k]); atomicAdd(g + 1, pq[k]);
+                        }
+                    }
+                }
+            }
+        }
         if (m >= (size_t)Mtot) continue;
 #pragma unroll
         for (int j = 0; j < NI; ++j)
@@ -514,6 +580,25 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
                     *reinterpret_cast<f32x4*>(a.y + m * a.ldy + col) = v[j][rq];
             }
     }
+    if (a.gsum && a.TI == 1) {
+        // one atomic pair per (sample, 16-channel slab) and workgroup instead of one per wave and pixel block: device-scope fp32
+        // atomics run at ~8 per ns chip-wide (131 k of them cost the level-0 conv 16 us), the combine through LDS costs nothing
+        float* red = reinterpret_cast<float*>(lds);                         // [wave][4 slabs][2]
+        __syncthreads();                                                    // every wave is done with the tiles
+        if (l == 0) {
+#pragma unroll
+            for (int k = 0; k < NI * 2; ++k) { red[(wv * 4 + k) * 2] = wps[k]; red[(wv * 4 + k) * 2 + 1] = wpq[k]; }
+        }
+        __syncthreads();
+        if (t < 16) {                                                       // thread = (wn, slab k, sum / square)
+            const int wn2 = t >> 3, k = (t >> 1) & 3, q = t & 1;
+            float tot = 0.f;
+            for (int w2 = 0; w2 < WAVES / 2; ++w2) tot += red[((w2 * 2 + wn2) * 4 + k) * 2 + q];
+            const int col = n0 + wn2 * 64 + (k >> 1) * 32 + (k & 1) * 16;
+            if (col < a.Nc && (size_t)m0 < (size_t)Mtot)
+                atomicAdd(a.gsum + ((size_t)(m0 / (a.H * a.W)) * (a.Nc / 16) + col / 16) * 2 + q, tot);
+        }
+    }
     MI_TS(4);
 }
 
@@ -526,7 +611,7 @@ void launch_halo(const HaloArgs& a_in, hipStream_t st) {
     // off by default: measured neutral (level 0 56.7 -> 55.8 us, step 6.39 vs 6.41 ms) -- what the ablation charges to the stores is
     // their burst at the end of a round of workgroups, not the rows per instruction
     static const int ep_env = [] { const char* e = getenv("MI_HALO_EPI"); return e ? atoi(e) : 0; }();
-    a.ep_rows = (ep_env && !SK) ? 1 : 0;
+    a.ep_rows = (ep_env && !SK && !a.gsum) ? 1 : 0;
     if (a.ep_rows) {
         const size_t need = (size_t)WAVES * HaloCfg<BM, WAVES>::MI * 32 * 68 * sizeof(float);
         if (need > lds) lds = need;
@@ -654,7 +739,7 @@ static bool halo_ok(const MiConvDesc* d, int* bm, int* ck) {
 }
 
 static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
-                         const float* bias, const float* residual, float* y, int io, void* stream);
+                         const float* bias, const float* residual, float* y, int io, void* stream, float* gsum = nullptr);
 
 // k-slices of the split-K plan for this layer (0 = none).  Small-M layers (8x8 levels): a 256-pixel x
 // 64-channel-chunk tile with the K loop split over 2-8 workgroups beats 64-pixel tiles (weights are re-read
@@ -712,8 +797,18 @@ extern "C" int mi_conv3x3_bf16w_io(const MiConvDesc* d, const void* x, const voi
     return halo_dispatch(d, (const float*)x, (const float*)x2, w_nk_bf16, bias, residual, (float*)y, io, stream);
 }
 
+// ... and the next layer's GroupNorm statistics from this conv's epilogue: gsum [N][Nc / 16][2] (zeroed by the caller) += (sum,
+// sum of squares) of the values as stored, per sample and 16-channel slab; mi_gn_coef_from_sums turns them into the coefficients
+// mi_conv3x3_gn_mish reads.  3x3, Nc % 16 == 0, H*W % 32 == 0, no split-K plan.
+extern "C" int mi_conv3x3_bf16w_io_gnsums(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16, const float* bias,
+                                          const float* residual, void* y, int io, float* gsum, void* stream) {
+    if (!d || d->KH != 3 || (io & ~3) || !gsum || d->Nc % 16 || (d->OH * d->OW) % 32)
+        return mi_set_error(-1, "mi_conv3x3_bf16w_io_gnsums: 3x3, io in 0..3, Nc %% 16 == 0, H*W %% 32 == 0");
+    return halo_dispatch(d, (const float*)x, (const float*)x2, w_nk_bf16, bias, residual, (float*)y, io, stream, gsum);
+}
+
 static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
-                         const float* bias, const float* residual, float* y, int io, void* stream) {
+                         const float* bias, const float* residual, float* y, int io, void* stream, float* gsum) {
     MI_REQUIRE(d && x && w_nk_bf16 && y, "null argument");
     int BM, CK;
     MI_REQUIRE(halo_ok(d, &BM, &CK), "descriptor not supported by the halo kernel (use mi_conv_igemm)");
@@ -725,11 +820,12 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
     a.N = d->N; a.H = d->OH; a.W = d->OW; a.K = d->K; a.Nc = d->Nc; a.K1 = d->K1; a.ldx = d->ldx;
     a.ldx2 = x2 ? d->ldx2 : d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.accumulate = d->accumulate;
     a.flip = d->transposed ? 1 : 0;
+    a.gsum = gsum; a.coef = nullptr; a.gn_sums = nullptr;
     hipStream_t st = (hipStream_t)stream;
     // Small-M layers (8x8 levels): a 256-pixel x 64-channel-chunk tile with the K loop split over
     // 2-4 workgroups beats 64-pixel tiles (weights are re-read per M tile); slices are summed with
     // row-coalesced fp32 atomics.
-    if (!(io & 2)) {
+    if (!(io & 2) && !gsum) {
         int th, ti;
         const int ks = halo_splitk(d, BM, &th, &ti);
         if (ks) {
@@ -845,16 +941,38 @@ extern "C" int mi_conv3x3_gn_mish_tile(const MiConvDesc* d, int* bm, int* ck) {
 
 // y = conv3x3( mish(x * scale + shift) + tb ) + bias, with x the raw output of the previous conv (fp32 or bf16, io bit 0) and
 // coef = [3][N][K] from mi_gn_stats_coef.  io bit 1: y is written as bf16.  Only io 0 (fp32 -> fp32) and 3 (bf16 -> bf16) exist.
+static int fused_go(const MiConvDesc* d, const void* x, const float* coef, const float* sums, const float* gamma, const float* beta,
+                    const float* temb, int ldt, int G, float eps, const void* w_nk_bf16, const float* bias, void* y, int io, void* stream);
+
 extern "C" int mi_conv3x3_gn_mish(const MiConvDesc* d, const void* x, const float* coef, const void* w_nk_bf16, const float* bias,
                                   void* y, int io, void* stream) {
-    MI_REQUIRE(d && x && coef && w_nk_bf16 && y && (io == 0 || io == 3), "bad argument (io 0 or 3)");
+    MI_REQUIRE(coef, "null coef");
+    return fused_go(d, x, coef, nullptr, nullptr, nullptr, nullptr, 0, 1, 0.f, w_nk_bf16, bias, y, io, stream);
+}
+// The same kernel fed by the producing conv's epilogue sums (mi_conv3x3_bf16w_io_gnsums) instead of a coefficient tensor: GroupNorm
+// (G groups, K / G % 16 == 0) statistics, affine and time bias (temb [N][ldt], optional) are resolved per channel chunk inside the
+// kernel -- Block -> Block costs two launches: conv1 (+ sums) and this one.
+extern "C" int mi_conv3x3_gn_mish_sums(const MiConvDesc* d, const void* x, const float* sums, const float* gamma, const float* beta,
+                                       const float* temb, int ldt, int G, float eps, const void* w_nk_bf16, const float* bias, void* y,
+                                       int io, void* stream) {
+    MI_REQUIRE(d && sums && gamma && beta && G > 0 && d->K % G == 0 && (d->K / G) % 16 == 0 && (!temb || ldt % 4 == 0) &&
+               (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)(temb ? temb : gamma)) & 15) == 0,
+               "bad argument (K / G must be a multiple of 16, 16-byte aligned vectors)");
+    return fused_go(d, x, nullptr, sums, gamma, beta, temb, ldt, G, eps, w_nk_bf16, bias, y, io, stream);
+}
+
+static int fused_go(const MiConvDesc* d, const void* x, const float* coef, const float* sums, const float* gamma, const float* beta,
+                    const float* temb, int ldt, int G, float eps, const void* w_nk_bf16, const float* bias, void* y, int io, void* stream) {
+    MI_REQUIRE(d && x && (coef || sums) && w_nk_bf16 && y && (io == 0 || io == 3), "bad argument (io 0 or 3)");
     int BM, CK, TH;
     MI_REQUIRE(fused_plan(d, &BM, &CK, &TH), "descriptor not supported by the fused GroupNorm+Mish+Conv3x3 kernel");
-    MI_REQUIRE(d->ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w_nk_bf16 | (uintptr_t)coef) & 15) == 0 && !d->accumulate, "alignment / accumulate");
+    MI_REQUIRE(d->ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w_nk_bf16 | (uintptr_t)(coef ? coef : sums)) & 7) == 0 && !d->accumulate, "alignment / accumulate");
     HaloArgs a;
     a.x = (const float*)x; a.x2 = a.x; a.w = (const uint16_t*)w_nk_bf16; a.bias = bias; a.res = nullptr; a.y = (float*)y;
     a.N = d->N; a.H = d->OH; a.W = d->OW; a.K = d->K; a.Nc = d->Nc; a.K1 = d->K; a.ldx = d->ldx; a.ldx2 = d->ldx; a.ldy = d->ldy; a.ldr = 0;
-    a.accumulate = 0; a.flip = 0; a.ksplit = 1; a.coef = coef;
+    a.accumulate = 0; a.flip = 0; a.ksplit = 1; a.coef = coef; a.gsum = nullptr;
+    a.gn_sums = sums; a.gn_gamma = gamma; a.gn_beta = beta; a.gn_temb = temb; a.gn_ldt = ldt; a.gn_eps = eps;
+    a.gn_cg = sums ? d->K / G : 16; a.gn_icnt = 1.0 / ((double)d->OH * (double)d->OW * (double)a.gn_cg);
     a.TH = TH; a.TI = 1; a.tiles_per_img = a.H / TH; a.HP = (TH + 2) * (a.W + 2);
     a.xmap = a.tiles_per_img > 1 && a.N % 8 == 0;
     hipStream_t st = (hipStream_t)stream;

@@ -562,6 +562,39 @@ extern "C" int mi_gn_stats_coef(const MiGnDesc* d, const void* x, const float* g
     MI_LAUNCH_CHECK();
     return 0;
 }
+// The same stats / coef from per-slab sums that the producing conv's epilogue accumulated (mi_conv3x3_bf16w_io_gnsums):
+// sums [N][C / 16][2] = (sum, sum of squares) per sample and 16-channel slab.  One thread per (n, c); the group's slabs are
+// combined in double (var = E[x^2] - mean^2).
+__global__ __launch_bounds__(256) void gn_coef_from_sums_kernel(int N, int C, int G, int HW, float eps, const float* __restrict__ sums,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ temb, int ldt, float* __restrict__ stats,
+                                                                float* __restrict__ coef) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C, Cg = C / G, g = c / Cg, nslab = Cg / 16;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nslab; ++k) {
+        const float* p = sums + ((size_t)n * (C / 16) + g * nslab + k) * 2;
+        s += p[0]; q += p[1];
+    }
+    const double cnt = (double)HW * Cg, mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = 1.0f / sqrtf((float)var + eps), mf = (float)mean;
+    if (stats && c == g * Cg) { stats[2 * (n * G + g)] = mf; stats[2 * (n * G + g) + 1] = rstd; }
+    const float sc = gamma[c] * rstd;
+    const size_t NC = (size_t)N * C;
+    coef[i] = sc; coef[NC + i] = beta[c] - mf * sc; coef[2 * NC + i] = temb ? temb[(size_t)n * ldt + c] : 0.f;
+}
+extern "C" int mi_gn_coef_from_sums(int N, int C, int G, int HW, float eps, const float* sums, const float* gamma, const float* beta,
+                                    const float* temb, int ldt, float* stats, float* coef, void* stream) {
+    MI_REQUIRE(N > 0 && C > 0 && G > 0 && HW > 0 && C % G == 0 && (C / G) % 16 == 0 && sums && gamma && beta && coef,
+               "bad argument (C / G must be a multiple of 16)");
+    hipLaunchKernelGGL(gn_coef_from_sums_kernel, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, C, G, HW, eps, sums, gamma,
+                       beta, temb, ldt, stats, coef);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
 // bwd io: bit 0 = x is bf16, bit 1 = dx is written as bf16, bit 2 = dout is bf16.
 extern "C" int mi_gn_mish_bwd_io(const MiGnDesc* d, const void* x, const float* stats, const float* gamma,
                                  const float* beta, const void* dout, int lddo, void* dx, int lddx,

@@ -252,7 +252,7 @@ class Unet(nn.Module):
         # fused kernel BASELINE.json names).  Off by default: with bf16 block storage the statistics pass it still needs
         # (mi_gn_stats_coef) costs what the apply pass cost, and the sampler measured 671 vs 692 denoise steps/s at B=64
         # (tools/sample_steps.py); with fp32 storage the fused unit is 65.6 us against 86.3 us in two passes (bench.py named_kernel).
-        self.fuse_gn_conv = os.environ.get("MI_DDPM_FUSE_GN", "0") == "1"
+        self.fuse_gn_conv = int(os.environ.get("MI_DDPM_FUSE_GN", "0"))     # 1: statistics pass + fused conv; 2: statistics from conv1's epilogue
         # Downsample / Upsample weight gradients through the LDS-DMA kernel (csrc/wgrad_s2_tr.hip); 0 = round 1's ring kernel
         self.s2_wgrad_tr = os.environ.get("MI_DDPM_S2_TR", "1") != "0"
         # final_conv.0's conv output stored like the other Blocks' (bf16 in bf16 mode); 0 = fp32 as in round 1
@@ -461,6 +461,8 @@ class Unet(nn.Module):
         def s2_copy(c, k, transposed):      # Downsample / Upsample read (and their weight gradients want) a bf16 copy of their input
             return (use_sh and self.s2_wgrad_tr and K.igemm_bf16_in_supported(c, c, k, 2, transposed, mode, (8, 8)))
 
+        zpool = [None, 0]                   # fused eval path: zeroed pool for the per-block GroupNorm sums, next free float
+
         def shadow(t):
             ent = sh.get(id(t))
             if ent is None:
@@ -468,7 +470,8 @@ class Unet(nn.Module):
                 sh[id(t)] = ent
             return ent[1]
 
-        def conv(inp, pre, k, stride=1, pad=0, x2=None, residual=None, transposed_conv=False, bias=True, out_dtype=torch.float32):
+        def conv(inp, pre, k, stride=1, pad=0, x2=None, residual=None, transposed_conv=False, bias=True, out_dtype=torch.float32,
+                 gn_sums=None):
             w = sv[pre + "weight"]
             kh, kw, ci, co = w.shape
             if x2 is None and residual is None and stride == 1 and not transposed_conv:
@@ -478,9 +481,10 @@ class Unet(nn.Module):
                     return K.conv1x1_small_cout(0, inp, w, bias=sv[pre + "bias"] if bias else None, Cs=co)
             if mode == K.MODE_BF16 and k in (1, 3) and stride == 1 and not transposed_conv:
                 y = K.conv3x3_bf16w(inp, wf_sh[offs[pre + "weight"]:], K=ci, Nc=co, flip=False, ksize=k, x2=x2,
-                                    bias=sv[pre + "bias"] if bias else None, residual=residual, out_dtype=out_dtype)
+                                    bias=sv[pre + "bias"] if bias else None, residual=residual, out_dtype=out_dtype, gn_sums=gn_sums)
                 if y is not None:
                     return y
+            assert gn_sums is None, "GroupNorm sums ride in the tile kernel's epilogue only"
             ih, iw = inp.shape[1], inp.shape[2]
             if transposed_conv:
                 oh, ow = ih * stride, iw * stride
@@ -509,15 +513,31 @@ class Unet(nn.Module):
             inp_c, x2_c = inp, x2
             if c1_16 and use_sh and inp.dtype == torch.float32 and inp.shape[3] % 8 == 0:
                 inp_c, x2_c = shadow(inp), (shadow(x2) if x2 is not None else None)
-            c1 = conv(inp_c, pre + "block1.block.0.", 3, 1, 1, x2=x2_c, out_dtype=BF if c1_16 else torch.float32)
             tb = tb_all[:, blk["tcol"]:blk["tcol"] + co]
+            hw = inp.shape[1] * inp.shape[2]
+            fuse = (not record and mode == K.MODE_BF16 and self.fuse_gn_conv and c1_16 == lo16
+                    and K.conv3x3_gn_mish_supported(B, inp.shape[1], inp.shape[2], co, co))
+            # ... with block1's GroupNorm statistics taken from conv1's epilogue when the tile kernel runs it (no pass over c1 at all)
+            sums = None
+            if fuse and self.fuse_gn_conv == 2 and (co // _GN_GROUPS) % 16 == 0 and hw % 32 == 0 and ci % 32 == 0 and \
+                    all(K.fast3x3_supported(B, inp.shape[1], inp.shape[2], ci, co, k1)):
+                nsum = B * (co // 16) * 2
+                if zpool[0] is None:      # one zero fill per forward for every block's sums
+                    zpool[0] = torch.zeros(2 * B * sum(rb["cout"] // 16 + 1 for rb in A.res_blocks), device=inp.device, dtype=torch.float32)
+                sums = zpool[0][zpool[1]:zpool[1] + nsum]
+                zpool[1] += (nsum + 3) // 4 * 4
+            c1 = conv(inp_c, pre + "block1.block.0.", 3, 1, 1, x2=x2_c, out_dtype=BF if c1_16 else torch.float32, gn_sums=sums)
             c2 = None
-            if (not record and mode == K.MODE_BF16 and self.fuse_gn_conv and c1.dtype == (BF if lo16 else torch.float32)
-                    and K.conv3x3_gn_mish_supported(B, inp.shape[1], inp.shape[2], co, co)):
+            if fuse:
                 # inference / sampling: GroupNorm-apply + Mish + time bias ride in block2's conv staging (the named fused kernel);
                 # h1 is never materialised.  Training keeps h1: the weight gradient of block2's conv reads it.
-                st1, coef = K.gn_stats_coef(c1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], temb=tb)
-                c2 = K.conv3x3_gn_mish(c1, coef, wf_sh[offs[pre + "block2.block.0.weight"]:], K=co, Nc=co, bias=sv[pre + "block2.block.0.bias"])
+                if sums is not None:
+                    st1 = None
+                    c2 = K.conv3x3_gn_mish(c1, None, wf_sh[offs[pre + "block2.block.0.weight"]:], K=co, Nc=co, bias=sv[pre + "block2.block.0.bias"],
+                                           gn=(sums, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], tb, _GN_GROUPS, 1e-5))
+                else:
+                    st1, coef = K.gn_stats_coef(c1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], temb=tb)
+                    c2 = K.conv3x3_gn_mish(c1, coef, wf_sh[offs[pre + "block2.block.0.weight"]:], K=co, Nc=co, bias=sv[pre + "block2.block.0.bias"])
                 h1 = None
             if c2 is None:
                 h1, st1 = K.gn_mish_fwd(c1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], temb=tb,

@@ -144,7 +144,7 @@ def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mo
 
 
 def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=None, out=None, accumulate=False,
-                  out_dtype=torch.float32):
+                  out_dtype=torch.float32, gn_sums=None):
     """3x3/s1/p1 (or 1x1) conv (flip=False) or its data gradient (flip=True) through the pipelined
     LDS-tile kernel.  wsh: bf16 weights [k][k][Nc][K].  Returns None when the shape is not supported."""
     _need_gpu(x)
@@ -163,7 +163,7 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
     d.ldy = ld_of(out)
     io = _b16(x) | (_b16(out) << 1)
     assert x2 is None or x2.dtype == x.dtype
-    if USE_CONV_SHIFT and ksize == 3 and _b16(x) and lib.mi_conv3x3_shift_supported(C.byref(d)):
+    if gn_sums is None and USE_CONV_SHIFT and ksize == 3 and _b16(x) and lib.mi_conv3x3_shift_supported(C.byref(d)):
         # bf16-stored activations: the LDS-frugal kernel (conv_shift.hip)
         e0 = _probe_open()
         check(lib.mi_conv3x3_shift(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv3x3_shift")
@@ -174,7 +174,7 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
             _probe_close(e0, f"conv_shift_kernel<{ni.value}, {'true' if _b16(out) else 'false'}>", 2.0 * N * H * W * Nc * K * 9,
                          f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
         return out
-    if USE_CONV_DMA and ksize == 3 and _b16(x) and lib.mi_conv3x3_dma_supported(C.byref(d)):
+    if gn_sums is None and USE_CONV_DMA and ksize == 3 and _b16(x) and lib.mi_conv3x3_dma_supported(C.byref(d)):
         # bf16-stored activations: the LDS-DMA kernel (conv_dma.hip)
         e0 = _probe_open()
         check(lib.mi_conv3x3_dma(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv3x3_dma")
@@ -184,7 +184,11 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
                          f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
         return out
     e0 = _probe_open()
-    if io:
+    if gn_sums is not None:       # the next layer's GroupNorm statistics ride in this conv's epilogue
+        assert ksize == 3 and gn_sums.dtype == torch.float32 and gn_sums.numel() == N * (Nc // 16) * 2
+        check(lib.mi_conv3x3_bf16w_io_gnsums(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), io, _p(gn_sums), _stream()),
+              "mi_conv3x3_bf16w_io_gnsums")
+    elif io:
         check(lib.mi_conv3x3_bf16w_io(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), io, _stream()),
               "mi_conv3x3_bf16w_io")
     else:
@@ -217,15 +221,31 @@ def gn_stats_coef(x, gamma, beta, *, groups=8, eps=1e-5, temb=None):
     return stats, coef
 
 
+def gn_coef_from_sums(sums, N, HW, gamma, beta, *, groups=8, eps=1e-5, temb=None):
+    """-> (stats [N][G][2], coef [3][N][C]) from the (sum, sum of squares) per sample and 16-channel slab that the producing conv's
+    epilogue accumulated (conv3x3_bf16w(..., gn_sums=sums)): what gn_stats_coef computes with a pass over the tensor."""
+    Cc = gamma.numel()
+    stats = torch.empty((N, groups, 2), device=sums.device, dtype=torch.float32)
+    coef = torch.empty((3, N, Cc), device=sums.device, dtype=torch.float32)
+    e0 = _probe_open()
+    check(load_library().mi_gn_coef_from_sums(N, Cc, groups, HW, eps, _p(sums), _p(gamma), _p(beta), _p(temb),
+                                              ld_of(temb) if temb is not None else 0, _p(stats), _p(coef), _stream()), "mi_gn_coef_from_sums")
+    if e0 is not None:
+        _probe_close(e0, "gn_coef_from_sums_kernel", 0.0, f"N{N} C{Cc}", N * Cc * 16.0)
+    return stats, coef
+
+
 def conv3x3_gn_mish_supported(N, H, W, K, Nc):
     d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=MODE_BF16, K1=K,
                    ldx=K, ldx2=K, ldy=Nc, ldr=0, accumulate=0)
     return bool(load_library().mi_conv3x3_gn_mish_supported(C.byref(d)))
 
 
-def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None):
+def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None, gn=None):
     """The fused kernel BASELINE.json names: y = conv3x3(mish(x * scale + shift) + tb) + bias with x the RAW previous conv output
-    (fp32 -> fp32 y, or bf16 -> bf16 y), coef from gn_stats_coef.  Returns None when the shape is not supported."""
+    (fp32 -> fp32 y, or bf16 -> bf16 y), coef from gn_stats_coef -- or coef = None and gn = (sums, gamma, beta, temb, groups, eps):
+    the statistics come from the sums the producing conv's epilogue left (conv3x3_bf16w(..., gn_sums=sums)) and are resolved inside
+    the kernel.  Returns None when the shape is not supported."""
     _need_gpu(x)
     N, H, W, _ = x.shape
     d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=MODE_BF16, K1=K,
@@ -239,7 +259,12 @@ def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None):
     y = new_act(N, H, W, Nc, x, out_dtype)
     io = 3 if x.dtype == torch.bfloat16 else 0
     e0 = _probe_open()
-    check(lib.mi_conv3x3_gn_mish(C.byref(d), _p(x), _p(coef), _p(wsh), _p(bias), _p(y), io, _stream()), "mi_conv3x3_gn_mish")
+    if gn is not None:
+        sums, gamma, beta, temb, groups, eps = gn
+        check(lib.mi_conv3x3_gn_mish_sums(C.byref(d), _p(x), _p(sums), _p(gamma), _p(beta), _p(temb), ld_of(temb) if temb is not None else 0,
+                                          groups, eps, _p(wsh), _p(bias), _p(y), io, _stream()), "mi_conv3x3_gn_mish_sums")
+    else:
+        check(lib.mi_conv3x3_gn_mish(C.byref(d), _p(x), _p(coef), _p(wsh), _p(bias), _p(y), io, _stream()), "mi_conv3x3_gn_mish")
     if e0 is not None:
         bm, ck = C.c_int(), C.c_int()
         lib.mi_conv3x3_gn_mish_tile(C.byref(d), C.byref(bm), C.byref(ck))

@@ -61,6 +61,9 @@ SIGNATURES = {
     "mi_debug_wgrad_s2_tr_phase": [_I],
     "mi_debug_conv_dma_chunk": [_I],
     "mi_pack_weights_tile": [],
+    "mi_conv3x3_bf16w_io_gnsums": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P],
+    "mi_gn_coef_from_sums": [_I, _I, _I, _I, _F, _P, _P, _P, _P, _I, _P, _P, _P],
+    "mi_conv3x3_gn_mish_sums": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _I, _P],
     "mi_debug_wgrad1x1_tr_blocks": [_I],
     "mi_debug_wgrad_tr_blocks": [_I],
     "mi_conv3x3_bf16w_io": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],

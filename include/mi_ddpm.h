@@ -110,6 +110,20 @@ int mi_conv3x3_bf16w_io(const MiConvDesc* d, const void* x, const void* x2, cons
  * writes stats[n][g] = {mean, rstd}.  Forward / sampling path; tiles lie inside one image.  io: 0 = fp32 c1 -> fp32 y, 3 = bf16 ->
  * bf16 (the block-internal storage of bf16 mode). */
 /* (mi_gn_stats_coef is declared with the GroupNorm entry points below) */
+/* GroupNorm statistics of the NEXT layer from this conv's epilogue (instead of mi_gn_stats_coef's pass over the tensor):
+ * mi_conv3x3_bf16w_io_gnsums is mi_conv3x3_bf16w_io that also adds, per sample and 16-channel slab, the sum and the sum of squares of
+ * the values it stores (rounded to bf16 when y is bf16) into gsum [N][Nc / 16][2] (zeroed by the caller; Nc % 16 == 0, H*W % 32 == 0);
+ * mi_gn_coef_from_sums combines the slabs of each group into stats [N][G][2] = {mean, rstd} (optional) and coef [3][N][C] as
+ * mi_gn_stats_coef would have written them (C / G % 16 == 0).  Block -> Block: conv1 + sums, coef, then mi_conv3x3_gn_mish. */
+int mi_conv3x3_bf16w_io_gnsums(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16, const float* bias,
+                               const float* residual, void* y, int io, float* gsum, void* stream);
+int mi_gn_coef_from_sums(int N, int C, int G, int HW, float eps, const float* sums, const float* gamma, const float* beta,
+                         const float* temb, int ldt, float* stats, float* coef, void* stream);
+/* ... or skip the coefficient tensor: the fused kernel resolves statistics, affine and time bias (temb [N][ldt], optional) per channel
+ * chunk from the sums themselves.  Block -> Block is then two launches: conv1 (+ sums) and this one. */
+int mi_conv3x3_gn_mish_sums(const MiConvDesc* d, const void* x, const float* sums, const float* gamma, const float* beta,
+                            const float* temb, int ldt, int G, float eps, const void* w_nk_bf16, const float* bias, void* y,
+                            int io, void* stream);
 int mi_conv3x3_gn_mish_supported(const MiConvDesc* d);
 int mi_conv3x3_gn_mish_tile(const MiConvDesc* d, int* bm, int* ck);
 int mi_conv3x3_gn_mish(const MiConvDesc* d, const void* x, const float* coef, const void* w_nk_bf16, const float* bias,

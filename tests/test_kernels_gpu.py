@@ -208,6 +208,36 @@ def test_linear_via_igemm(K):
     assert rel_err(yg, y) < 2e-5 and rel_err(dxg, x.grad) < 2e-5 and rel_err(dW.view(O, I), w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+@pytest.mark.parametrize("cfg", [(16, 32, 32, 128, 128), (8, 16, 16, 128, 256), (16, 8, 8, 256, 512), (3, 32, 32, 64, 160)])
+def test_conv_epilogue_groupnorm_sums(K, cfg, storage):
+    """mi_conv3x3_bf16w_io_gnsums + mi_gn_coef_from_sums: the next GroupNorm's statistics and coefficients from the conv's epilogue
+    equal what mi_gn_stats_coef computes with a pass over the stored tensor (fp32 summation order aside), and the conv's output is
+    unchanged (bitwise)."""
+    N, H, W, Ci, Co = cfg
+    g = torch.Generator().manual_seed(67)
+    dt = torch.float32 if storage == "fp32" else torch.bfloat16
+    x = torch.randn(N, H, W, Ci, generator=g).to(DEV).to(dt)
+    wsh = (torch.randn(9 * Co * Ci, generator=g) / math.sqrt(9 * Ci)).to(DEV).bfloat16()
+    bias = torch.randn(Co, generator=g).to(DEV)
+    gamma, beta = (torch.rand(Co, generator=g) + 0.5).to(DEV), torch.randn(Co, generator=g).to(DEV)
+    temb = torch.randn(N, Co, generator=g).to(DEV)
+    y0 = K.conv3x3_bf16w(x, wsh, K=Ci, Nc=Co, flip=False, bias=bias, out_dtype=dt)
+    sums = torch.zeros(N * (Co // 16) * 2, device=DEV)
+    y1 = K.conv3x3_bf16w(x, wsh, K=Ci, Nc=Co, flip=False, bias=bias, out_dtype=dt, gn_sums=sums)
+    assert torch.equal(y0, y1)
+    if (Co // 8) % 16:                              # 160 / 8 = 20 channels per group: slabs do not tile the groups -> refused
+        with pytest.raises(RuntimeError):
+            K.gn_coef_from_sums(sums, N, H * W, gamma, beta, temb=temb)
+        return
+    st1, cf1 = K.gn_coef_from_sums(sums, N, H * W, gamma, beta, temb=temb)
+    st0, cf0 = K.gn_stats_coef(y0, gamma, beta, temb=temb)
+    torch.cuda.synchronize()
+    assert float((st1[..., 0] - st0[..., 0]).abs().max()) < 2e-5
+    assert float(((st1[..., 1] - st0[..., 1]) / st0[..., 1]).abs().max()) < 2e-5
+    assert float((cf1 - cf0).abs().max()) < 1e-4 * float(cf0.abs().max())
+
+
 def _mish64(x):
     return x * torch.tanh(F.softplus(x))
 
