@@ -31,7 +31,7 @@ struct S2Args {
     int rows2;                              // big rows in the batch: N * 2h
     int total, sps, splits;                 // steps of 64 small pixels, steps per k-slice, k-slices
     int gx, gy, ntiles;                     // big-channel tiles (64), small-channel tiles (128), tiles incl. the plane factor
-    int wg0, tile0;
+    int wg0, tile0, xcd_map;
 };
 struct S2Batch { S2Args p[MAXP]; int n; };
 
@@ -83,7 +83,14 @@ __device__ __forceinline__ void wgrad_s2_body(const S2Args& a, const int wg, uin
     const int t = threadIdx.x, l = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wi = wv >> 2, wj = wv & 3;             // 2 big-channel halves x 4 small-channel quarters
-    const int split = wg / a.ntiles, tile = wg - split * a.ntiles;
+    // (k-slice, tile) in XCD rank order: a slice's tiles (they read the same rows) run on one XCD / one L2 -- see wgrad1x1_tr.hip
+    int rank = wg;
+    if (a.xcd_map) {
+        const int Wg = a.ntiles * a.splits, x = (a.wg0 + wg) & 7;
+        rank = (wg - ((x - a.wg0) & 7)) >> 3;
+        for (int xx = 0; xx < x; ++xx) rank += (Wg - ((xx - a.wg0) & 7) + 7) >> 3;
+    }
+    const int split = rank / a.ntiles, tile = rank - split * a.ntiles;
     const int tb = tile % a.gx, tsm = (tile / a.gx) % a.gy, q = tile / (a.gx * a.gy);      // q: column plane of a 4x4 tile (0 even, 1 odd)
     const int cb0 = tb * 64, cs0 = tsm * 128;
     const int sb = split * a.sps, se = min(a.total, sb + a.sps);
@@ -418,6 +425,8 @@ extern "C" int mi_conv_s2_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         a.dW = dW[i];
         a.ws = (float*)workspace + off;
         off += s2_ws_floats(a);
+        static const int xcd_env = [] { const char* e = getenv("MI_WS2_XCD"); return e ? atoi(e) : 1; }();
+        a.xcd_map = xcd_env && a.ntiles > 1 && a.splits > 1;
         a.wg0 = wg; wg += a.ntiles * a.splits;
         a.tile0 = tile; if (a.splits > 1) tile += a.ntiles;
         if (a.splits > max_splits) max_splits = a.splits;
