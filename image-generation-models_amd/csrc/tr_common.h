@@ -33,6 +33,28 @@ constexpr int MAXP = 8;
 // writes (75 MB) for the same MFMA work, and layers with >= 32 tiles need no k-slices at all (they add into dW directly).
 struct TrBatch { TrArgs p[MAXP]; int n; };
 
+// Workgroups per problem of a batched launch: every problem gets whole k-slices (a multiple of its tile count), at most `target`
+// workgroups in total (one round of the chip), and the launch lasts as long as its slowest workgroup -- so slices are handed out
+// greedily to the problem whose workgroups currently carry the most work each.  (Shares proportional to the work, rounded down to
+// whole slices, left a 24-tile layer with 48 of the 70 workgroups it was due: the whole launch ran 1.46x longer.)
+inline void balance_shares(int n, const double* work, const long* tiles, long target, long* wgs) {
+    long total = 0;
+    for (int i = 0; i < n; ++i) { wgs[i] = tiles[i]; total += tiles[i]; }
+    for (;;) {
+        int best = -1; double worst = 0;
+        for (int i = 0; i < n; ++i) {
+            const double per = work[i] / (double)wgs[i];
+            if (per > worst && total + tiles[i] <= target) { worst = per; best = i; }
+        }
+        if (best < 0) break;
+        // stop when the most loaded problem cannot be relieved: further slices for the others would not shorten the launch
+        double top = 0;
+        for (int i = 0; i < n; ++i) top = work[i] / (double)wgs[i] > top ? work[i] / (double)wgs[i] : top;
+        if (worst < top) break;
+        wgs[best] += tiles[best]; total += tiles[best];
+    }
+}
+
 // LDS-DMA: 16 bytes per lane from each lane's own global address to LDS byte address lds_dst (wave-uniform) + 16 * lane.
 // M0 carries the LDS base and is compiler-reserved: it is saved, set and restored inside the one statement.  The compiler does
 // not know this is a load: completion is waited for with explicit s_waitcnt vmcnt(N) below.

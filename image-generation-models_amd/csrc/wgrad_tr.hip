@@ -334,14 +334,20 @@ void tr_plan(const MiWgradDesc* d, TrArgs& a, long wgs) {
 
 // workgroups per problem in proportion to the MFMA work (N*H*W*Ci*Cj rounded up to whole tiles), every problem at least its tiles
 void tr_shares(int n, const MiWgradDesc* d, long* wgs) {
-    double tot = 0, fl[MAXP];
-    for (int i = 0; i < n; ++i) { fl[i] = (double)d[i].N * d[i].DH * d[i].DW * d[i].Ci * ((d[i].Cj + 127) / 128 * 128); tot += fl[i]; }
-    const long target = tr_target();
+    double fl[MAXP]; long tiles[MAXP];
     for (int i = 0; i < n; ++i) {
-        const long tiles = (long)(d[i].Ci / 64) * ((d[i].Cj + 127) / 128);
+        fl[i] = (double)d[i].N * d[i].DH * d[i].DW * d[i].Ci * ((d[i].Cj + 127) / 128 * 128);
+        tiles[i] = (long)(d[i].Ci / 64) * ((d[i].Cj + 127) / 128);
+    }
+    static const int greedy = [] { const char* e = getenv("MI_WTR_BALANCE"); return e ? atoi(e) : 1; }();
+    const long target = tr_target();
+    if (greedy) { balance_shares(n, fl, tiles, target, wgs); return; }
+    double tot = 0;
+    for (int i = 0; i < n; ++i) tot += fl[i];
+    for (int i = 0; i < n; ++i) {
         long w = (long)(target * fl[i] / tot + 0.5);
-        w = w / tiles * tiles;                                  // whole k-slices
-        wgs[i] = w < tiles ? tiles : w;
+        w = w / tiles[i] * tiles[i];                            // whole k-slices
+        wgs[i] = w < tiles[i] ? tiles[i] : w;
     }
 }
 
@@ -416,6 +422,15 @@ extern "C" int mi_conv3x3_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         if (a.splits > max_splits) max_splits = a.splits;
         const size_t l = tr_lds(a.W);
         if (l > lds) lds = l;
+    }
+    static const int dbg = [] { const char* e = getenv("MI_WTR_DEBUG"); return e ? atoi(e) : 0; }();
+    if (dbg) {
+        fprintf(stderr, "[wgrad_tr] %d layers, %d workgroups\n", n, wg);
+        for (int i = 0; i < n; ++i) {
+            const TrArgs& a = b.p[i];
+            fprintf(stderr, "   W%-2d Ci%-4d Cj%-4d tiles %2d x splits %3d (steps/slice %3d): %.2f GFLOP per workgroup\n", a.W, a.Ci, a.Cj, a.gx * a.gy,
+                    a.splits, a.sps, 2.0 * 64 * a.sps * 64 * 128 * 9 / 1e9);
+        }
     }
     MI_REQUIRE(off == 0 || (workspace && ((uintptr_t)workspace & 15) == 0 && ws_bytes >= off * sizeof(float)),
                "workspace too small (mi_conv3x3_wgrad_tr_batch_workspace)");
