@@ -232,6 +232,13 @@ void w1_shares(int n, const MiWgradDesc* d, const int* q32, long* wgs) {
         tot += by[i];
     }
     const long target = g_w1_blocks > 0 ? g_w1_blocks : 256;
+    static const int greedy = [] { const char* e = getenv("MI_W1_BALANCE"); return e ? atoi(e) : 1; }();
+    if (greedy) {               // whole k-slices to whoever carries the most bytes per workgroup (tr_common.h)
+        long tiles[MAXP];
+        for (int i = 0; i < n; ++i) tiles[i] = (long)(d[i].Ci / 64) * ((d[i].Cj + 127) / 128);
+        balance_shares(n, by, tiles, target, wgs);
+        return;
+    }
     for (int i = 0; i < n; ++i) {
         const long tiles = (long)(d[i].Ci / 64) * ((d[i].Cj + 127) / 128);
         long w = (long)(target * by[i] / tot + 0.5);

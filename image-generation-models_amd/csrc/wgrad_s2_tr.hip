@@ -367,6 +367,13 @@ void s2_shares(int n, const MiWgradDesc* d, long* wgs) {
     double tot = 0, fl[MAXP];
     for (int i = 0; i < n; ++i) { fl[i] = (double)d[i].N * d[i].DH * d[i].DW * d[i].Ci * d[i].Cj * d[i].KH * d[i].KW; tot += fl[i]; }
     const long target = s2_target();
+    static const int greedy = [] { const char* e = getenv("MI_WS2_BALANCE"); return e ? atoi(e) : 1; }();
+    if (greedy) {
+        long tiles[MAXP];
+        for (int i = 0; i < n; ++i) tiles[i] = s2_tiles(&d[i]);
+        balance_shares(n, fl, tiles, target, wgs);
+        return;
+    }
     for (int i = 0; i < n; ++i) {
         const long tiles = s2_tiles(&d[i]);
         long w = (long)(target * fl[i] / tot + 0.5);
