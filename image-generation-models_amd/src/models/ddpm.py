@@ -458,6 +458,12 @@ class Unet(nn.Module):
         use_sh = (record and mode == K.MODE_BF16 and self.block_storage in ("bf16", "auto")
                   and os.environ.get("MI_DDPM_SHADOW", "1") == "1")
 
+        # inference: the GroupNorm kernel of a ResnetBlock whose output goes straight into the next Block's conv can write the bf16 copy
+        # along (no conversion launch).  Off: measured 680 vs 720 denoise steps/s at B = 64 -- the dual-output GroupNorm costs
+        # +4 us per launch and the convs that switch to bf16 input were the cheap ones
+        eval16 = (not record and mode == K.MODE_BF16 and self.block_storage in ("bf16", "auto")
+                  and os.environ.get("MI_DDPM_EVAL16", "0") == "1")
+
         def s2_copy(c, k, transposed):      # Downsample / Upsample read (and their weight gradients want) a bf16 copy of their input
             return (use_sh and self.s2_wgrad_tr and K.igemm_bf16_in_supported(c, c, k, 2, transposed, mode, (8, 8)))
 
@@ -499,7 +505,7 @@ class Unet(nn.Module):
                              wb=wf_sh[offs[pre + "weight"]:] if mode == K.MODE_BF16 else None)
             return y
 
-        def resblock(blk, inp, x2=None, want_out16=False):
+        def resblock(blk, inp, x2=None, want_out16=False, out16_in_eval=True):
             pre, co, ci = blk["pre"], blk["cout"], blk["cin"]
             # bf16 storage of c1 / h1 / c2 when every kernel touching them has a bf16 path for this shape
             lo16 = False
@@ -513,6 +519,8 @@ class Unet(nn.Module):
             inp_c, x2_c = inp, x2
             if c1_16 and use_sh and inp.dtype == torch.float32 and inp.shape[3] % 8 == 0:
                 inp_c, x2_c = shadow(inp), (shadow(x2) if x2 is not None else None)
+            elif c1_16 and eval16 and x2 is None and id(inp) in sh:
+                inp_c = sh[id(inp)][1]            # inference: the copy the producing GroupNorm kernel wrote along (no conversion launches)
             tb = tb_all[:, blk["tcol"]:blk["tcol"] + co]
             hw = inp.shape[1] * inp.shape[2]
             fuse = (not record and mode == K.MODE_BF16 and self.fuse_gn_conv and c1_16 == lo16
@@ -544,7 +552,7 @@ class Unet(nn.Module):
                                         out_dtype=BF if lo16 else torch.float32)
                 c2 = conv(h1, pre + "block2.block.0.", 3, 1, 1, out_dtype=BF if lo16 else torch.float32)
             r = conv(inp, pre + "res_conv.", 1, x2=x2) if blk["res"] else inp
-            if want_out16 and use_sh and co % 32 == 0:
+            if want_out16 and (use_sh or (eval16 and out16_in_eval)) and co % 32 == 0:
                 out, st2, out16 = K.gn_mish_fwd(c2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], residual=r, want16=True)
                 sh[id(out)] = (out, out16)
             else:
@@ -586,7 +594,7 @@ class Unet(nn.Module):
                     tape.append(("down", lvl["down"], inp, h, inp_c))
         h = resblock(A.mid1, h)
         h = attention(A.mid_attn, h)
-        h = resblock(A.mid2, h, want_out16=True)                  # feeds the first up block's conv
+        h = resblock(A.mid2, h, want_out16=True, out16_in_eval=False)    # feeds the first up block's conv (with the skip: training only)
         for lvl in A.ups:
             h = resblock(lvl["res1"], h, x2=skips.pop(), want_out16=True)          # cat((x, skip)) read in place (ddpm.py:255)
             h = resblock(lvl["res2"], h)
