@@ -49,6 +49,7 @@ struct HaloArgs {
     const float* coef;   // FUSE: [3][N][K] scale / shift / time bias of the GroupNorm + Mish applied to x while it is staged
     int skew;            // extra LDS elements per halo ROW (see HaloSkew); 0 = rows packed
     int ep_rows;         // epilogue through LDS: row-contiguous stores and residual / accumulate loads
+    int qmap, gx, gy;    // 1-D launch of gx pixel tiles x gy channel tiles, each XCD takes gx / (8 / qmap) pixel tiles x gy / qmap channel tiles
     const float* gn_sums; const float* gn_gamma; const float* gn_beta; const float* gn_temb;   // FUSE without a coef tensor: the
     int gn_cg, gn_ldt; float gn_eps; double gn_icnt;   // producing conv's per-slab sums [N][K / 16][2] + the affine / time-bias vectors
     float* gsum;         // optional [N][C / 16][2]: += (sum, sum of squares) of the STORED outputs per sample and 16-channel slab --
@@ -125,7 +126,17 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
         const int xcd = bx & 7, slot = bx >> 3;
         bx = (xcd + 8 * (slot / a.tiles_per_img)) * a.tiles_per_img + slot % a.tiles_per_img;
     }
-    const int m0 = bx * BM, n0 = blockIdx.y * BN;
+    int by = blockIdx.y;
+    if (a.qmap) {
+        // Tiles of whole images (8x8 levels): ids go round-robin over the 8 XCDs, each with its own L2.  With the channel tiles in
+        // grid.y every XCD met ALL of them, i.e. pulled the whole weight tensor (8 x 4.7 MB of the 54.7 MB a 512 -> 512 launch
+        // moved).  Here XCD = (pixel group, channel group) of a P x Q = 8 split: traffic Q * in + P * w + out, 44 MB at (4, 2);
+        // within an XCD the channel tiles of one pixel tile are adjacent in time (its input tile is still in L2).
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3, Q = a.qmap, P = 8 / Q;
+        const int ppx = a.gx / P, cpq = a.gy / Q;
+        bx = (xcd / Q) * ppx + slot / cpq; by = (xcd % Q) * cpq + slot % cpq;
+    }
+    const int m0 = bx * BM, n0 = by * BN;
     const int W2 = a.W + (KS - 1), TH2 = a.TH + (KS - 1);
     const int Mtot = a.N * a.H * a.W;
 
@@ -623,6 +634,12 @@ void launch_halo(const HaloArgs& a_in, hipStream_t st) {
         if (a.HP * PITCH + rows * HaloSkew<CK>::EL <= MAXHP * PITCH) a.skew = HaloSkew<CK>::EL;
     }
     dim3 grid((a.N * a.H * a.W + BM - 1) / BM, (a.Nc + 127) / 128, a.ksplit);
+    a.qmap = 0; a.gx = (int)grid.x; a.gy = (int)grid.y;
+    static const int q_env = [] { const char* e = getenv("MI_HALO_PQ"); return e ? atoi(e) : 1; }();
+    if (q_env && KS == 3 && !SK && a.ksplit == 1 && !a.xmap && a.gy > 1 && a.TI * a.TH == a.H * a.TI && a.TH == a.H) {   // whole-image tiles
+        const int Q = (a.gy % 2 == 0) ? 2 : 1, P = 8 / Q;
+        if (Q > 1 && a.gx % P == 0) { a.qmap = Q; grid = dim3(grid.x * grid.y, 1, 1); }
+    }
     static bool once = [] {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
