@@ -69,8 +69,8 @@ s = s[:i] + f"""## Dominant kernel (`roofline` in `{tag}_bench.json`)
 `{tag}_train_step_kernel_stats.csv`), {r['avg_gflop_per_launch']} GFLOP/launch => {r['achieved']} TFLOP/s = {100 * r['frac']:.1f} % of the dense bf16 MFMA peak;
 HBM traffic {r['traffic'] / 1e6:.1f} MB per launch of its canonical shape (PMC, `{tag}_pmc_traffic.json`).
 The two kernels that share the top of the table: `{hk}` (3x3 conv / data gradient at the 8x8 level, 18 launches/step,
-{ak[hk]['ms_per_step']} ms, {ak[hk]['tflops']} TFLOP/s by events; 47.5 us = 814 TFLOP/s on the canonical 512->512 layer under the counters, 54.8 MB vs
-21.5 MB algorithmic: eight private L2s each pull the 4.7 MB weight tensor) and `{wt}` (eight Block-conv weight gradients per
+{ak[hk]['ms_per_step']} ms, {ak[hk]['tflops']} TFLOP/s by events; 47.2 us = 819 TFLOP/s on the canonical 512->512 layer under the counters, 44.3 MB vs
+21.5 MB algorithmic with the (4, 2) XCD grouping of pixel and channel tiles, 54.8 MB before it) and `{wt}` (eight Block-conv weight gradients per
 launch, LDS-DMA + transposing reads: {ak[wt]['launches_per_step']} launches/step, {ak[wt]['ms_per_step']} ms, {ak[wt]['tflops']} TFLOP/s by events; canonical 8-layer launch 1.26 PFLOP/s,
 `SQ_VALU_MFMA_BUSY_CYCLES` 60 %, `SQ_LDS_BANK_CONFLICT` 0, 554 MB vs 423 MB algorithmic = 1.31x).
 
