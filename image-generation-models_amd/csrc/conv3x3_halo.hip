@@ -734,6 +734,8 @@ static bool halo_ok(const MiConvDesc* d, int* bm, int* ck) {
     if (k1) {                                  // 1x1: plain GEMM over M = N*H*W pixels, any geometry; four 32-channel stages per group (K is padded with zero weights)
         const long M = (long)d->N * d->OH * d->OW, nt = (d->Nc + 127) / 128;
         *bm = (M + 255) / 256 * nt >= 200 ? 256 : ((M + 127) / 128 * nt >= 400 ? 128 : 64);
+        static const int force1 = [] { const char* e = getenv("MI_HALO_K1_BM"); return e ? atoi(e) : 0; }();     // experiment: 64 / 128 / 256
+        if (force1 == 64 || force1 == 128 || (force1 == 256 && M >= 256)) *bm = force1;
         *ck = 32;                              // 64 would spill: the whole A tile rides in the 4-deep register ring
         return true;
     }
