@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int DH = 32;           // dim_head, fixed by the reference (ddpm.py:147)
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 struct AttnArgs {
     const float* qkv; float* out; float* ctx; float* kstat;
@@ -54,44 +55,77 @@ template <bool T16> __device__ __forceinline__ float* offs(float* base, size_t i
 // acc[r] of a 32x32 MFMA tile <-> (row, col): row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
 __device__ __forceinline__ int tile_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// S[d][e] = sum_p f(A[p][d]) * Bm[p][e] over this block's pixels, waves split p, result in sm[32][33]
+// four consecutive channels of pixel p (clamped to the last valid row by the caller) as fp32
+template <bool T16> __device__ __forceinline__ f32x4v ld4(const float* base, size_t p, int ld, int c4) {
+    if constexpr (T16) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + p * ld + c4);
+        return f32x4v{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    } else {
+        const float4 u = *reinterpret_cast<const float4*>(base + p * ld + c4);
+        return f32x4v{u.x, u.y, u.z, u.w};
+    }
+}
+
+// S[d][e] = sum_p f(A[p][d]) * Bm[p][e] over this block's pixels, waves split p, result in sm[32][33].
+// A wave walks 32-pixel tiles: both operand tiles arrive with coalesced 8 / 16-byte loads (8 lanes per pixel row; the first version
+// fetched one 2-byte element per lane and MFMA operand, 850 k load instructions per launch), are transformed in registers, parked
+// in two wave-private LDS tiles ([32][33] floats) and read back as MFMA operands (one pixel row per lane, conflict-free).
 template <bool EXP, bool T16>
 __device__ __forceinline__ void reduce_outer(const float* A, const float* Bm, int ldA, int ldB, int pb, int n,
-                                             const float* kmax, float* sm, float* wsum, float* scratch) {
+                                             const float* kmax, float* sm, float* wsum, float* scratch, float* scratch2) {
     const int t = threadIdx.x, l = t & 63, w = t >> 6;
     const int i = l & 31, kk = l >> 5;
+    const int c4 = (l & 7) * 4, r0 = l >> 3;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float mx = EXP ? kmax[i] : 0.f;
-    float ssum = 0.f;
-    // four pixel pairs per trip, all eight loads issued before the first use and none of them inside a branch (a
-    // guarded load is followed by s_waitcnt vmcnt(0): one memory round trip per pair); rows past n are clamped + masked
-    constexpr int UN = 4;
-    for (int p0 = pb + 2 * w; p0 < n; p0 += 8 * UN) {
-        float av[UN], bv[UN];
+    f32x4v mx = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+    if (EXP) mx = f32x4v{kmax[c4], kmax[c4 + 1], kmax[c4 + 2], kmax[c4 + 3]};
+    float* tA = scratch + w * (32 * 33);
+    float* tB = scratch2 + w * (32 * 33);
+    for (int p0 = pb + 32 * w; p0 < n; p0 += 128) {
+        f32x4v av[4], bv[4];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const size_t p = (size_t)min(p0 + 8 * u + kk, n - 1);
-            av[u] = ldx<T16>(A, p * ldA + i);
-            bv[u] = ldx<T16>(Bm, p * ldB + i);
+        for (int j = 0; j < 4; ++j) {                     // eight unconditional loads in flight; rows past n re-read row n-1 and are zeroed
+            const size_t p = (size_t)min(p0 + r0 + 8 * j, n - 1);
+            av[j] = ld4<T16>(A, p, ldA, c4);
+            bv[j] = ld4<T16>(Bm, p, ldB, c4);
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const float live = p0 + 8 * u + kk < n ? 1.f : 0.f;
-            float x = av[u];
-            if (EXP) { x = __expf(x - mx) * live; ssum += x; } else x *= live;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bv[u], acc, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            const float live = p0 + r0 + 8 * j < n ? 1.f : 0.f;
+            f32x4v x = av[j];
+            if (EXP) {
+                x = f32x4v{__expf(x.x - mx.x), __expf(x.y - mx.y), __expf(x.z - mx.z), __expf(x.w - mx.w)} * live;
+                ss += x;
+            } else {
+                x *= live;
+            }
+            float* pa = tA + (r0 + 8 * j) * 33 + c4;
+            float* pb2 = tB + (r0 + 8 * j) * 33 + c4;
+            pa[0] = x.x; pa[1] = x.y; pa[2] = x.z; pa[3] = x.w;
+            pb2[0] = bv[j].x; pb2[1] = bv[j].y; pb2[2] = bv[j].z; pb2[3] = bv[j].w;
+        }
+        // (wave-private LDS tiles: the wave's own ds_write -> ds_read ordering is enough)
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int k = 2 * s2 + kk;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tA[k * 33 + i], tB[k * 33 + i], acc, 0, 0, 0);
+        }
+    }
+    float ssum = 0.f;
+    if (EXP) {                                            // per-channel sums: lanes with the same l & 7 hold the same channel quad
+#pragma unroll
+        for (int o = 8; o <= 32; o <<= 1) {
+            ss.x += __shfl_xor(ss.x, o, 64); ss.y += __shfl_xor(ss.y, o, 64); ss.z += __shfl_xor(ss.z, o, 64); ss.w += __shfl_xor(ss.w, o, 64);
         }
     }
     // combine the four waves through LDS
     float* mine = scratch + w * (32 * 33);
 #pragma unroll
     for (int r = 0; r < 16; ++r) mine[tile_row(r, l) * 33 + i] = acc[r];
-    if (EXP) {
-        ssum += __shfl_xor(ssum, 32, 64);
-        if (l < 32) wsum[w * 32 + l] = ssum;
-    }
+    (void)ssum;
+    if (EXP && l < 8) { wsum[w * 32 + c4] = ss.x; wsum[w * 32 + c4 + 1] = ss.y; wsum[w * 32 + c4 + 2] = ss.z; wsum[w * 32 + c4 + 3] = ss.w; }
     __syncthreads();
     for (int idx = t; idx < 32 * 32; idx += 256) {
         int d = idx >> 5, e = idx & 31;
@@ -153,9 +187,9 @@ __device__ __forceinline__ f32x16 tile_mm(const float* A, int ldA, int p0, int n
 // 4096 pixels behind 8 KB of loads in flight; sliced, every CU holds several workgroups and the loads of all of them.
 template <bool T16, int PH>     // T16: qkv and out are stored as bf16
 __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
-    __shared__ float scratch[4 * 32 * 33];
+    __shared__ float scratch[4 * 32 * 33], scratch2[PH == 1 ? 1 : 4 * 32 * 33];
     __shared__ float ctx_s[32 * 33];
-    __shared__ float kmax_s[32], ksum_s[32], wsum[4 * 32], pmax[8 * 32];
+    __shared__ float kmax_s[32], ksum_s[32], wsum[4 * 32], pmax[32 * 32];
     int b, h, sl;
     attn_block(a, b, h, sl);
     const int bh = b * a.heads + h;
@@ -172,20 +206,23 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
     const size_t bhs = (size_t)bh * a.S + sl;
 
     if constexpr (PH == 0 || PH == 1) {               // column max of k over the slice's pixels
-        int d = t & 31, pr = t >> 5;
-        float m = -INFINITY;
-        for (int p = pb + pr; p < pe; p += 32) {          // four rows in flight; rows past the end repeat the last row (max-neutral)
-            float v[4];
+        // thread = (row t >> 3 of a 32-row sweep, channel quad t & 7): 8 / 16-byte loads, four sweeps in flight; rows past the end
+        // repeat the last row (max-neutral)
+        const int c4 = (t & 7) * 4, pr = t >> 3;
+        f32x4v m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int p = pb + pr; p < pe; p += 128) {
+            f32x4v v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = ldx<T16>(k, (size_t)min(p + 8 * u, pe - 1) * a.ldq + d);
-            m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+            for (int u = 0; u < 4; ++u) v[u] = ld4<T16>(k, (size_t)min(p + 32 * u, pe - 1), a.ldq, c4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m = f32x4v{fmaxf(m.x, v[u].x), fmaxf(m.y, v[u].y), fmaxf(m.z, v[u].z), fmaxf(m.w, v[u].w)};
         }
-        pmax[pr * 32 + d] = m;
+        pmax[pr * 32 + c4] = m.x; pmax[pr * 32 + c4 + 1] = m.y; pmax[pr * 32 + c4 + 2] = m.z; pmax[pr * 32 + c4 + 3] = m.w;
         __syncthreads();
         if (t < 32) {
             float mm = pmax[t];
 #pragma unroll
-            for (int r = 1; r < 8; ++r) mm = fmaxf(mm, pmax[r * 32 + t]);
+            for (int r = 1; r < 32; ++r) mm = fmaxf(mm, pmax[r * 32 + t]);
             kmax_s[t] = mm;
             if constexpr (PH == 1) part_max[bhs * 32 + t] = mm;
         }
@@ -200,7 +237,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
         __syncthreads();
     }
     if constexpr (PH == 0 || PH == 2) {
-        reduce_outer<true, T16>(k, v, a.ldq, a.ldq, pb, pe, kmax_s, ctx_s, wsum, scratch);
+        reduce_outer<true, T16>(k, v, a.ldq, a.ldq, pb, pe, kmax_s, ctx_s, wsum, scratch, scratch2);
         if (t < 32) ksum_s[t] = wsum[t] + wsum[32 + t] + wsum[64 + t] + wsum[96 + t];
         __syncthreads();
         if constexpr (PH == 2) {
@@ -279,7 +316,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
         }
     }
     if constexpr (PH == 0 || PH == 1) {
-        reduce_outer<false, T16>(q, dout, a.ldq, hid, pb, pe, nullptr, dctx_s, nullptr, scratch);   // syncs inside
+        reduce_outer<false, T16>(q, dout, a.ldq, hid, pb, pe, nullptr, dctx_s, nullptr, scratch, stage_s);   // syncs inside
         if constexpr (PH == 1) {
             for (int idx = t; idx < 32 * 32; idx += 256) a.part[bhs * 1024 + idx] = dctx_s[(idx >> 5) * 33 + (idx & 31)];
             return;
