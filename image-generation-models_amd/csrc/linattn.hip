@@ -66,6 +66,26 @@ template <bool T16> __device__ __forceinline__ f32x4v ld4(const float* base, siz
     }
 }
 
+// A 32-pixel x 32-channel MFMA result (lane = channel column, 16 rows per lane) written as pixel rows: through a wave-private LDS
+// tile, then 8 lanes per pixel row with 8 / 16-byte stores (the accumulator layout would store one 2-byte element per lane).
+template <bool T16>
+__device__ __forceinline__ void store_tile(float* dst, int ld, int p0, int pe, const f32x16& acc, float* tile) {
+    const int l = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[tile_row(r, l) * 33 + (l & 31)] = acc[r];
+    const int c4 = (l & 7) * 4, r0 = l >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = r0 + 8 * j, p = p0 + row;
+        const float* q = tile + row * 33 + c4;
+        const float v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+        if (p < pe) {
+            if constexpr (T16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(dst) + (size_t)p * ld + c4) = make_uint2(pack_bf16(v0, v1), pack_bf16(v2, v3));
+            else *reinterpret_cast<float4*>(dst + (size_t)p * ld + c4) = make_float4(v0, v1, v2, v3);
+        }
+    }
+}
+
 // S[d][e] = sum_p f(A[p][d]) * Bm[p][e] over this block's pixels, waves split p, result in sm[32][33].
 // A wave walks 32-pixel tiles: both operand tiles arrive with coalesced 8 / 16-byte loads (8 lanes per pixel row; the first version
 // fetched one 2-byte element per lane and MFMA operand, 850 k load instructions per launch), are transformed in registers, parked
@@ -274,11 +294,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
     float* o = offs<T16>(a.out, (size_t)b * a.n * hid + h * DH);
     for (int p0 = pb + 32 * w; p0 < pe; p0 += 128) {
         f32x16 acc = tile_mm<T16>(q, a.ldq, p0, pe, ctx_s, 33, 1, scratch + w * (32 * 33));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int p = p0 + tile_row(r, l);
-            if (p < pe) stx<T16>(o, (size_t)p * hid + (l & 31), acc[r]);
-        }
+        store_tile<T16>(o, hid, p0, pe, acc, scratch + w * (32 * 33));
     }
 }
 
@@ -343,17 +359,19 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
         const int col = l & 31;
         // dq[p][d] = sum_e dout[p][e] ctx[d][e]      (B(k=e, j=d) = ctx_s[d*33+e])
         f32x16 acc = tile_mm<T16>(dout, hid, p0, pe, ctx_s, 1, 33, stg);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < pe) stx<T16>(dq, (size_t)p * a.ldq + col, acc[r]); }
+        store_tile<T16>(dq, a.ldq, p0, pe, acc, stg);
         // P tile into LDS (rows = pixels) so it can serve as the A operand of dv
         {
-            float kv[16];
+            const int c4 = (l & 7) * 4, r0 = l >> 3;
+            f32x4v kv[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) kv[r] = ldx<T16>(k, (size_t)min(p0 + tile_row(r, l), pe - 1) * a.ldq + col);
+            for (int j = 0; j < 4; ++j) kv[j] = ld4<T16>(k, (size_t)min(p0 + r0 + 8 * j, pe - 1), a.ldq, c4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = tile_row(r, l);
-                pt[row * 33 + col] = p0 + row < pe ? __expf(kv[r] - kmax_s[col]) * kinv_s[col] : 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const float live = p0 + r0 + 8 * j < pe ? 1.f : 0.f;
+                float* pp = pt + (r0 + 8 * j) * 33 + c4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pp[e] = __expf(kv[j][e] - kmax_s[c4 + e]) * kinv_s[c4 + e] * live;
             }
         }
         // (wave-private LDS region: the wave's own ds_write -> ds_read ordering is enough)
@@ -368,16 +386,13 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
                 int kd = 2 * s + kk;
                 a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pt[i * 33 + kd], dctx_s[kd * 33 + i], a2, 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { int p = p0 + tile_row(r, l); if (p < pe) stx<T16>(dv, (size_t)p * a.ldq + col, a2[r]); }
+            store_tile<T16>(dv, a.ldq, p0, pe, a2, stg);
         }
         // dP[p][d] = sum_e v[p][e] dctx[d][e]        (B(k=e, j=d) = dctx_s[d*33+e]) ; dk = P*(dP - r)
         acc = tile_mm<T16>(v, a.ldq, p0, pe, dctx_s, 1, 33, stg);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = tile_row(r, l), p = p0 + row;
-            if (p < pe) stx<T16>(dk, (size_t)p * a.ldq + col, pt[row * 33 + col] * (acc[r] - r_s[col]));
-        }
+        for (int r = 0; r < 16; ++r) acc[r] = pt[tile_row(r, l) * 33 + col] * (acc[r] - r_s[col]);
+        store_tile<T16>(dk, a.ldq, p0, pe, acc, stg);
     }
 }
 
