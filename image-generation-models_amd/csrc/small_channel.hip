@@ -74,6 +74,56 @@ __global__ __launch_bounds__(256) void small_cin_fwd_kernel(int N, int H, int W,
     }
 }
 
+// The same 3x3 conv with the input taps served from LDS.  In the kernel above every thread issues 9 global tap loads per pixel and
+// waits for them (200 registers of weights and taps, two waves per SIMD: a latency chain of ~1 M load instructions per launch at
+// B = 128).  Here a workgroup owns 64-pixel tiles (whole image rows), the tile's (rows + 2) x (W + 2) halo of padded pixels is
+// fetched by one load per thread -- the NEXT tile's while this one is computed -- and the taps are ds_read_b128.
+template <int CIN>
+__global__ __launch_bounds__(256) void small_cin3x3_fwd_tiled_kernel(int N, int H, int W, int Cout, const float* __restrict__ x, int ldx,
+                                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                                     float* __restrict__ y, int ldy, int w_sh, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float halo_s[];          // 2 x [(rows + 2) * (W + 2)] float4
+    const int nq = Cout / 4;
+    const int q = threadIdx.x % nq, psub = threadIdx.x / nq, pp = 256 / nq;
+    const int rows = 64 >> w_sh, W2 = W + 2, HP = (rows + 2) * W2, tiles_per_img = H / rows;
+    f32x4 wr[9 * CIN];
+#pragma unroll
+    for (int i = 0; i < 9 * CIN; ++i) wr[i] = *reinterpret_cast<const f32x4*>(w + (size_t)i * Cout + 4 * q);
+    const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // this thread's halo pixel (HP <= 256): position -> (row, column) of the tile's halo
+    const int hp = threadIdx.x, hy = hp / W2, hx = hp - hy * W2;
+    auto fetch = [&](int tile) -> f32x4 {
+        const int n = tile / tiles_per_img, y0 = (tile - n * tiles_per_img) * rows;
+        const int iy = y0 + hy - 1, ix = hx - 1;
+        const bool ok = hp < HP && tile < ntiles && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)((n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * (ok ? ldx : 0));
+        return v * (ok ? 1.f : 0.f);
+    };
+    int tile = blockIdx.x, buf = 0;
+    f32x4 nxt = fetch(tile);
+    if (hp < HP) *reinterpret_cast<f32x4*>(halo_s + (size_t)hp * 4) = nxt;
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        nxt = fetch(tile + gridDim.x);                                        // in flight under this tile's arithmetic
+        const float* hs = halo_s + (size_t)buf * HP * 4;
+        const size_t m0 = (size_t)tile * 64;
+        for (int px = psub; px < 64; px += pp) {
+            const int ty = px >> w_sh, tx = px & (W - 1);
+            f32x4 acc = b4;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(hs + (size_t)((ty + tp / 3) * W2 + tx + tp % 3) * 4);
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) acc += xv[ci] * wr[tp * CIN + ci];
+            }
+            *reinterpret_cast<f32x4*>(y + (m0 + px) * ldy + 4 * q) = acc;
+        }
+        buf ^= 1;
+        if (hp < HP) *reinterpret_cast<f32x4*>(halo_s + ((size_t)buf * HP + hp) * 4) = nxt;
+        __syncthreads();
+    }
+}
+
 // Sum of a per-thread array of NA float4 over the pixel lanes of a workgroup (threads with equal t % nq), result in
 // threads 0..nq-1.  nq is 16, 32 or 64: the pixel lanes inside a wave are combined by shuffles, the four waves via LDS.
 template <int NA>
@@ -285,6 +335,23 @@ extern "C" int mi_conv_small_cin_fwd(int ks, int N, int H, int W, int Cin, int C
     const bool pow2 = w_sh >= 0 && hw_sh >= 0;
     const bool vec = ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
+    {   // 3x3 on whole-row tiles of 64 pixels with the taps in LDS (see small_cin3x3_fwd_tiled_kernel)
+        static const int tiled = [] { const char* e = getenv("MI_SMALL_CIN_TILED"); return e ? atoi(e) : 1; }();
+        const int rows = w_sh >= 0 && W <= 64 ? 64 / W : 0;
+        if (tiled && ks == 3 && pow2 && vec && ldx == 4 && rows >= 1 && H % rows == 0 && (rows + 2) * (W + 2) <= 256 && Cout <= 256) {
+            const int ntiles = N * H * W / 64;
+            const int grid = ntiles < 1024 ? ntiles : 1024;
+            const size_t lds = (size_t)2 * (rows + 2) * (W + 2) * 16;
+            switch (Cin) {
+                case 1: hipLaunchKernelGGL(small_cin3x3_fwd_tiled_kernel<1>, dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, w_sh, ntiles); break;
+                case 2: hipLaunchKernelGGL(small_cin3x3_fwd_tiled_kernel<2>, dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, w_sh, ntiles); break;
+                case 3: hipLaunchKernelGGL(small_cin3x3_fwd_tiled_kernel<3>, dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, w_sh, ntiles); break;
+                default: hipLaunchKernelGGL(small_cin3x3_fwd_tiled_kernel<4>, dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, w_sh, ntiles); break;
+            }
+            MI_LAUNCH_CHECK();
+            return 0;
+        }
+    }
 #define MI_GO(CIN, KS) do { \
         if (pow2 && vec) hipLaunchKernelGGL((small_cin_fwd_kernel<CIN, KS, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, w_sh, hw_sh); \
         else if (vec) hipLaunchKernelGGL((small_cin_fwd_kernel<CIN, KS, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, 0, 0); \
