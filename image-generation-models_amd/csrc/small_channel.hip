@@ -193,6 +193,82 @@ __global__ __launch_bounds__(256) void small_cin_wgrad_kernel(int N, int H, int 
     }
 }
 
+// The 3x3 weight gradient with the input taps in LDS (same tiling as small_cin3x3_fwd_tiled_kernel): a workgroup walks 64-pixel
+// row tiles, a thread = (co quad, pixel lane) requests its tile's dy rows (64 / pp of them) up front, the taps are ds_read_b128.
+template <int CIN>
+__global__ __launch_bounds__(256) void small_cin3x3_wgrad_tiled_kernel(int N, int H, int W, int Cout, const float* __restrict__ x, int ldx,
+                                                                       const float* __restrict__ dy, int lddy, float* __restrict__ dW,
+                                                                       float* __restrict__ ws, int w_sh, int ntiles) {
+    constexpr int NA = 9 * CIN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];             // [reduce area 3 * NA * nq * 4][2 halo buffers]
+    const int nq = Cout / 4;
+    const int q = threadIdx.x % nq, psub = threadIdx.x / nq, pp = 256 / nq;
+    const int rows = 64 >> w_sh, W2 = W + 2, HP = (rows + 2) * W2, tiles_per_img = H / rows;
+    float* red = smem;
+    float* halo_s = smem + (size_t)3 * NA * nq * 4;
+    f32x4 acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int hp = threadIdx.x, hy = hp / W2, hx = hp - hy * W2;
+    auto fetch = [&](int tile) -> f32x4 {
+        const int n = tile / tiles_per_img, y0 = (tile - n * tiles_per_img) * rows;
+        const int iy = y0 + hy - 1, ix = hx - 1;
+        const bool ok = hp < HP && tile < ntiles && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)((n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * (ok ? ldx : 0));
+        return v * (ok ? 1.f : 0.f);
+    };
+    // contiguous range of tiles per workgroup (one partial tile per workgroup leaves at the end)
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int tb = blockIdx.x * per, te = min(ntiles, tb + per);
+    int buf = 0;
+    f32x4 nxt = fetch(tb < te ? tb : ntiles);
+    if (hp < HP) *reinterpret_cast<f32x4*>(halo_s + (size_t)hp * 4) = nxt;
+    __syncthreads();
+    constexpr int MAXPX = 8;                                                   // 64 / pp <= 8 for Cout >= 128; Cout = 64: two passes of 8... handled by the loop
+    for (int tile = tb; tile < te; ++tile) {
+        nxt = fetch(tile + 1 < te ? tile + 1 : ntiles);
+        const float* hs = halo_s + (size_t)buf * HP * 4;
+        const size_t m0 = (size_t)tile * 64;
+        for (int base = psub; base < 64; base += pp * MAXPX) {
+            f32x4 g[MAXPX];
+#pragma unroll
+            for (int k = 0; k < MAXPX; ++k) {
+                const int px = base + k * pp;
+                g[k] = *reinterpret_cast<const f32x4*>(dy + (m0 + (px < 64 ? px : 63)) * lddy + 4 * q);
+            }
+#pragma unroll
+            for (int k = 0; k < MAXPX; ++k) {
+                const int px = base + k * pp;
+                if (px < 64) {
+                    const int ty = px >> w_sh, tx = px & (W - 1);
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(hs + (size_t)((ty + tp / 3) * W2 + tx + tp % 3) * 4);
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci) acc[tp * CIN + ci] += xv[ci] * g[k];
+                    }
+                }
+            }
+        }
+        buf ^= 1;
+        if (hp < HP) *reinterpret_cast<f32x4*>(halo_s + ((size_t)buf * HP + hp) * 4) = nxt;
+        __syncthreads();
+    }
+    block_reduce_quads<NA>(acc, nq, red);
+    if (threadIdx.x < nq) {
+        if (ws) {
+            float* out = ws + (size_t)blockIdx.x * NA * Cout;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(out + (size_t)i * Cout + 4 * q) = acc[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(dW + (size_t)i * Cout + 4 * q + k, acc[i][k]);
+        }
+    }
+}
+
 // out[map(o)] += sum_p ws[p * nout + o]; rows4 > 0: the partial tiles are [rows][4] and out is [rows][rows4] (rows4 <= 4)
 __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ ws, int nparts, int nout, float* __restrict__ out, int rows4) {
     __shared__ float red[8][32];
@@ -375,6 +451,23 @@ extern "C" int mi_conv_small_cin_wgrad(int ks, int N, int H, int W, int Cin, int
     const bool vec = ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
     const size_t lds = (size_t)3 * na * (Cout / 4) * 4 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
+    {   // 3x3 on whole-row tiles of 64 pixels with the taps in LDS (small_cin3x3_wgrad_tiled_kernel); same partial-tile contract
+        static const int tiled = [] { const char* e = getenv("MI_SMALL_CIN_TILED"); return e ? atoi(e) : 1; }();
+        const int rows = w_sh >= 0 && W <= 64 ? 64 / W : 0;
+        if (tiled && ks == 3 && pow2 && vec && ldx == 4 && rows >= 1 && H % rows == 0 && (rows + 2) * (W + 2) <= 256 && Cout >= 128) {
+            const int ntiles = N * H * W / 64;
+            const size_t lds2 = lds + (size_t)2 * (rows + 2) * (W + 2) * 16;
+            switch (Cin) {
+                case 1: hipLaunchKernelGGL(small_cin3x3_wgrad_tiled_kernel<1>, dim3(WG_BLOCKS), dim3(256), lds2, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, w_sh, ntiles); break;
+                case 2: hipLaunchKernelGGL(small_cin3x3_wgrad_tiled_kernel<2>, dim3(WG_BLOCKS), dim3(256), lds2, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, w_sh, ntiles); break;
+                case 3: hipLaunchKernelGGL(small_cin3x3_wgrad_tiled_kernel<3>, dim3(WG_BLOCKS), dim3(256), lds2, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, w_sh, ntiles); break;
+                default: hipLaunchKernelGGL(small_cin3x3_wgrad_tiled_kernel<4>, dim3(WG_BLOCKS), dim3(256), lds2, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, w_sh, ntiles); break;
+            }
+            if (ws) hipLaunchKernelGGL(partial_sum_kernel, dim3((na * Cout + 31) / 32), dim3(256), 0, st, ws, WG_BLOCKS, na * Cout, dW, 0);
+            MI_LAUNCH_CHECK();
+            return 0;
+        }
+    }
 #define MI_GO(CIN, KS) do { \
         if (pow2 && vec) hipLaunchKernelGGL((small_cin_wgrad_kernel<CIN, KS, true, true>), dim3(WG_BLOCKS), dim3(256), lds, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, w_sh, hw_sh); \
         else if (vec) hipLaunchKernelGGL((small_cin_wgrad_kernel<CIN, KS, false, true>), dim3(WG_BLOCKS), dim3(256), lds, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, 0, 0); \
