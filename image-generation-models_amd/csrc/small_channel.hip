@@ -314,11 +314,24 @@ __global__ __launch_bounds__(256) void small_cout_fwd_kernel(int M, int Cs, cons
         }
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (bias) { b4.x = bias[0]; if (Cs > 1) b4.y = bias[1]; if (Cs > 2) b4.z = bias[2]; if (Cs > 3) b4.w = bias[3]; }
+    // the next 32 pixels' rows are requested before this iteration's arithmetic (a workgroup runs several iterations: the 48 scalar
+    // weight loads above used to be paid once per 32 pixels)
+    f32x4 xn[CK];
+    {
+        const int m = min((int)blockIdx.x * 32 + pl, M - 1);
+#pragma unroll
+        for (int k = 0; k < CK; ++k) xn[k] = *reinterpret_cast<const f32x4*>(x + (size_t)m * ldx + 4 * (sub + 8 * k));
+    }
     for (int m0 = blockIdx.x * 32; m0 < M; m0 += gridDim.x * 32) {
         const int m = min(m0 + pl, M - 1);
         f32x4 xv[CK];
 #pragma unroll
-        for (int k = 0; k < CK; ++k) xv[k] = *reinterpret_cast<const f32x4*>(x + (size_t)m * ldx + 4 * (sub + 8 * k));
+        for (int k = 0; k < CK; ++k) xv[k] = xn[k];
+        {
+            const int mn = min(m0 + (int)gridDim.x * 32 + pl, M - 1);
+#pragma unroll
+            for (int k = 0; k < CK; ++k) xn[k] = *reinterpret_cast<const f32x4*>(x + (size_t)mn * ldx + 4 * (sub + 8 * k));
+        }
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < CK; ++k)
@@ -500,7 +513,7 @@ extern "C" int mi_conv1x1_small_cout_ws(int op, int M, int C, int Cs, const floa
     hipStream_t st = (hipStream_t)stream;
     if (op == 0) {
         MI_REQUIRE(C <= 128 && lda % 4 == 0 && ((uintptr_t)a & 15) == 0, "forward: C <= 128, 16-byte aligned x rows");
-        int blocks = (M + 31) / 32; if (blocks > 4096) blocks = 4096;
+        int blocks = (M + 31) / 32; if (blocks > 1024) blocks = 1024;
         if (C == 128) hipLaunchKernelGGL(small_cout_fwd_kernel<4>, dim3(blocks), dim3(256), 0, st, M, Cs, a, lda, w, bias, out, ldo);
         else if (C == 64) hipLaunchKernelGGL(small_cout_fwd_kernel<2>, dim3(blocks), dim3(256), 0, st, M, Cs, a, lda, w, bias, out, ldo);
         else hipLaunchKernelGGL(small_cout_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, M, Cs, a, lda, w, bias, out, ldo);
