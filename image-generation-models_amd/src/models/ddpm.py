@@ -636,7 +636,10 @@ class Unet(nn.Module):
         if mode == K.MODE_BF16:
             wd_sh, wf_sh = self._shadows()
         G = _GradMap()
-        wq = K.WgradQueue(group=int(os.environ.get("MI_DDPM_WGRAD_GROUP", "8")))
+        # data parallel (a grad-ready hook is set): the two Upsample layers come early in backward, the two Downsample layers last; with
+        # all four in one launch at the very end their 8 MB of gradients would be all-reduced after backward, exposed -- two per launch
+        wq = K.WgradQueue(group=int(os.environ.get("MI_DDPM_WGRAD_GROUP", "8")),
+                          group_s2=2 if self.grad_ready_hook is not None else None)
         x_in = tape[-1][1]
         B = x_in.shape[0]
         dtb_all = torch.zeros((B, A.mlp_rows), device=x_in.device, dtype=torch.float32)

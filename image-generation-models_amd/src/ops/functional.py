@@ -439,8 +439,9 @@ class WgradQueue:
     layers (1, 2, ...); `flushed` = the largest n such that layers 1..n have ALL been issued (the two kinds flush independently, so a
     count of issued layers would not say that); `on_flush()` is called after every flush."""
 
-    def __init__(self, group: int = 8, on_flush=None):
+    def __init__(self, group: int = 8, on_flush=None, group_s2=None):
         self.group, self.on_flush = max(1, min(8, int(group))), on_flush
+        self.group_s2 = self.group if group_s2 is None else max(1, min(8, int(group_s2)))    # stride-2 layers per launch
         self.items3, self.items1, self.items2 = [], [], []
         self.pushed = 0
         self._seq3, self._seq1, self._seq2 = [], [], []        # sequence numbers of the queued layers, per kind
@@ -495,7 +496,7 @@ class WgradQueue:
         self.items2.append((d, P, None, Q, dW))
         self.pushed += 1
         self._seq2.append(self.pushed)
-        if len(self.items2) >= self.group:
+        if len(self.items2) >= self.group_s2:
             self.flush(kinds=(2,))
         return True
 
