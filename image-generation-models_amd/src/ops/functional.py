@@ -8,6 +8,7 @@ CPU path: a tensor that is not on a GPU raises.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 from typing import Optional, Tuple
 
@@ -31,6 +32,34 @@ USE_CONV_DMA = os.environ.get("MI_CONV_DMA", "0") == "1"
 # latency than the LDS-DMA staging or the halved LDS traffic buy back (the same lesson as round 1's 4-wave halo variant).
 USE_CONV_SHIFT = os.environ.get("MI_CONV_SHIFT", "0") == "1"
 USE_WGRAD_TR = os.environ.get("MI_W3_TR", "1") != "0"      # A/B switch for the LDS-DMA weight-gradient kernel (csrc/wgrad_tr.hip)
+
+
+_QUERY_CACHE = {}
+
+
+def _desc_key(d):
+    return tuple(getattr(d, f) for f, _ in d._fields_)
+
+
+def _query(name, d, *extra):
+    """Cached yes / no (or size) answer of a descriptor query of the library: the answers are pure functions of the descriptor, and
+    one FFI call per launch for them was ~15 % of the step's enqueue time."""
+    key = (name, _desc_key(d)) + extra
+    r = _QUERY_CACHE.get(key)
+    if r is None:
+        r = getattr(load_library(), name)(C.byref(d), *extra)
+        _QUERY_CACHE[key] = r
+    return r
+
+
+@functools.lru_cache(maxsize=None)
+def _linattn_ws(N, n, heads):
+    return load_library().mi_linattn_workspace(N, n, heads)
+
+
+@functools.lru_cache(maxsize=None)
+def _cvt_colsum_ws(M, Cc):
+    return load_library().mi_f32_to_bf16_colsum_workspace(M, Cc)
 
 
 def _probe_open():
@@ -93,6 +122,7 @@ def _b16(t) -> int:
 
 
 # --------------------------------------------------------------------------- conv family
+@functools.lru_cache(maxsize=None)      # pure function of the shape: one FFI query per distinct layer, not per step
 def igemm_bf16_in_supported(K, Nc, k, stride, transposed, mode, out_hw):
     """Can conv_igemm read bf16-stored activations for this layer (the stride-2 conv / transposed conv family, dense tensors)?"""
     d = MiConvDesc(N=1, IH=1, IW=1, OH=out_hw[0], OW=out_hw[1], K=K, Nc=Nc, KH=k, KW=k, stride=stride, pad=1, transposed=int(transposed),
@@ -155,7 +185,7 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
                    w_kn=0, mode=MODE_BF16, K1=K1, ldx=ld_of(x), ldx2=ld_of(x2) if x2 is not None else 0, ldy=0,
                    ldr=ld_of(residual) if residual is not None else 0, accumulate=int(accumulate))
     lib = load_library()
-    if not lib.mi_conv3x3_bf16w_supported(C.byref(d)):
+    if not _query("mi_conv3x3_bf16w_supported", d):
         return None
     if out is None:
         assert not accumulate
@@ -235,6 +265,7 @@ def gn_coef_from_sums(sums, N, HW, gamma, beta, *, groups=8, eps=1e-5, temb=None
     return stats, coef
 
 
+@functools.lru_cache(maxsize=None)      # pure function of the shape: one FFI query per distinct layer, not per step
 def conv3x3_gn_mish_supported(N, H, W, K, Nc):
     d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=MODE_BF16, K1=K,
                    ldx=K, ldx2=K, ldy=Nc, ldr=0, accumulate=0)
@@ -287,6 +318,7 @@ def pack_weights_bf16(table_dev, nent, total_tiles, master, wd, wf):
         _probe_close(e0, "pack_weights_kernel", 0.0, f"{master.numel()} params", master.numel() * 8.0)
 
 
+@functools.lru_cache(maxsize=None)      # pure function of the shape: one FFI query per distinct layer, not per step
 def small_cin_supported(ks, Cin, Cout, wgrad=False):
     """The 3-channel-input kernels (mi_conv_small_cin_*): which (kernel size, Cin, Cout) they take."""
     if ks not in (1, 3) or not 1 <= Cin <= 4:
@@ -315,6 +347,7 @@ def conv_small_cin_wgrad(x, dy, dW, ks):
           "mi_conv_small_cin_wgrad")
 
 
+@functools.lru_cache(maxsize=None)      # pure function of the shape: one FFI query per distinct layer, not per step
 def small_cout_supported(op, C, Cs):
     """Conv2d(C, Cs<=4, 1) kernels (mi_conv1x1_small_cout): op 0 forward, 1 dgrad, 2 wgrad."""
     if not 1 <= Cs <= 4 or C not in (32, 64, 128, 256):
@@ -357,7 +390,7 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
     lib = load_library()
     fast = bool(lib.mi_conv3x3_wgrad_supported(C.byref(d)))
     use_tr = bool(USE_WGRAD_TR and dbias is None and kh == 3 and _b16(P) and _b16(Q) and (P2 is None or _b16(P2))
-                  and lib.mi_conv3x3_wgrad_tr_supported(C.byref(d)))
+                  and _query("mi_conv3x3_wgrad_tr_supported", d))
     if not fast and not use_tr and (_b16(P) or _b16(Q)):
         raise RuntimeError("bf16-stored operands need the fast wgrad kernel (caller must check wgrad_supported)")
     flops = 2.0 * N * grid_d[0] * grid_d[1] * Ci * Cj * kh * kw
@@ -423,6 +456,7 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
             colsum(Q, dbias)
 
 
+@functools.lru_cache(maxsize=None)      # pure function of the shape: one FFI query per distinct layer, not per step
 def s2_wgrad_supported(N, k, Ci, Cj, transposed, big, small, mode):
     """Can the stride-2 LDS-DMA weight-gradient kernel take this Downsample (3x3 conv) / Upsample (4x4 transposed conv) layer
     (dense bf16 operands)?  big / small: the (H, W) of the 2x-resolution tensor and of the other one."""
@@ -460,7 +494,7 @@ class WgradQueue:
         """3x3 / stride 1 / pad 1"""
         d = self._desc(P, Q, 3, Ci, Cj, hw, mode, P2)
         ok = (USE_WGRAD_TR and self.group > 1 and _b16(P) and _b16(Q) and (P2 is None or _b16(P2))
-              and load_library().mi_conv3x3_wgrad_tr_supported(C.byref(d)))
+              and _query("mi_conv3x3_wgrad_tr_supported", d))
         if not ok:
             conv_wgrad(P, Q, dW, kh=3, kw=3, stride=1, pad=1, gather_i=True, Ci=Ci, Cj=Cj, grid_g=hw, grid_d=hw, mode=mode, P2=P2)
             return
@@ -475,7 +509,7 @@ class WgradQueue:
         d = self._desc(P, Q, 1, Ci, Cj, hw, mode, P2)
         q32 = int(Q.dtype == torch.float32)
         ok = (USE_WGRAD_TR and self.group > 1 and _b16(P) and (P2 is None or _b16(P2)) and (dbias is None or q32)
-              and load_library().mi_conv1x1_wgrad_tr_supported(C.byref(d), q32))
+              and _query("mi_conv1x1_wgrad_tr_supported", d, q32))
         if not ok:
             conv_wgrad(P, Q, dW, kh=1, kw=1, stride=1, pad=0, gather_i=True, Ci=Ci, Cj=Cj, grid_g=hw, grid_d=hw, mode=mode, P2=P2, dbias=dbias)
             return
@@ -491,7 +525,7 @@ class WgradQueue:
         cannot take the layer (the caller then runs conv_wgrad)."""
         d = MiWgradDesc(N=P.shape[0], GH=grid_g[0], GW=grid_g[1], DH=grid_d[0], DW=grid_d[1], Ci=Ci, Cj=Cj, KH=k, KW=k, stride=2, pad=1,
                         gather_i=int(gather_i), mode=mode, I1=Ci, ldp=ld_of(P), ldp2=0, ldq=ld_of(Q))
-        if not (USE_WGRAD_TR and _b16(P) and _b16(Q) and load_library().mi_conv_s2_wgrad_tr_supported(C.byref(d))):
+        if not (USE_WGRAD_TR and _b16(P) and _b16(Q) and _query("mi_conv_s2_wgrad_tr_supported", d)):
             return False
         self.items2.append((d, P, None, Q, dW))
         self.pushed += 1
@@ -592,7 +626,7 @@ def colsum(x, out):
     vec = Cc % 4 == 0 and 4 <= Cc <= 1024 and ld_of(x) % 4 == 0 and x.data_ptr() % 16 == 0 and x.dtype == torch.float32
     lib = load_library()
     if vec:       # float4 rows on a full grid, per-workgroup partial sums through the scratch buffer
-        ws = _workspace(x.device, lib.mi_f32_to_bf16_colsum_workspace(M, Cc))
+        ws = _workspace(x.device, _cvt_colsum_ws(M, Cc))
         check(lib.mi_f32_to_bf16_colsum(M, Cc, _p(x), ld_of(x), None, 0, _p(out), _p(ws), ws.numel() * 4, _stream()), "mi_f32_to_bf16_colsum")
     else:
         check(lib.mi_colsum(M, Cc, _p(x), ld_of(x), _p(out), _stream()), "mi_colsum")
@@ -611,7 +645,7 @@ def to_bf16(x, colsum_out=None):
     e0 = _probe_open()
     if colsum_out is not None:
         lib = load_library()
-        ws = _workspace(x.device, lib.mi_f32_to_bf16_colsum_workspace(N * H * W, Cc))
+        ws = _workspace(x.device, _cvt_colsum_ws(N * H * W, Cc))
         check(lib.mi_f32_to_bf16_colsum(N * H * W, Cc, _p(x), ld_of(x), _p(y), Cc, _p(colsum_out), _p(ws), ws.numel() * 4, _stream()),
               "mi_f32_to_bf16_colsum")
     else:
@@ -762,7 +796,7 @@ def linattn_fwd(qkv, heads=4):
     kstat = torch.empty((N, heads, 32, 2), device=qkv.device, dtype=torch.float32)
     e0 = _probe_open()
     lib = load_library()
-    need = lib.mi_linattn_workspace(N, H * W, heads)         # > 0: the pixel axis is cut into slices (several workgroups per image)
+    need = _linattn_ws(N, H * W, heads)                      # > 0: the pixel axis is cut into slices (several workgroups per image)
     ws = _workspace(qkv.device, need) if need else None
     check(lib.mi_linattn_fwd_ws(N, H * W, heads, _p(qkv), _p(out), _p(ctx), _p(kstat), _b16(qkv), _p(ws), ws.numel() * 4 if need else 0,
                                 _stream()), "mi_linattn_fwd")
@@ -778,7 +812,7 @@ def linattn_bwd(qkv, ctx, kstat, dout, heads=4):
     dqkv = torch.empty_like(qkv)
     e0 = _probe_open()
     lib = load_library()
-    need = lib.mi_linattn_workspace(N, H * W, heads)
+    need = _linattn_ws(N, H * W, heads)
     ws = _workspace(qkv.device, need) if need else None
     check(lib.mi_linattn_bwd_ws(N, H * W, heads, _p(qkv), _p(ctx), _p(kstat), _p(dout), _p(dqkv), _b16(qkv), _p(ws),
                                 ws.numel() * 4 if need else 0, _stream()), "mi_linattn_bwd")
@@ -1075,6 +1109,7 @@ def u8_gather_normalize(data_u8, idx, flip=None, normalize=True):
     return out
 
 
+@functools.lru_cache(maxsize=None)      # pure function of the shape: one FFI query per distinct layer, not per step
 def fast3x3_supported(N, H, W, K, Nc, K1=None):
     """(conv via the LDS-tile kernel?, wgrad via the image-major kernel?) for a 3x3/s1/p1 layer in bf16 mode."""
     lib = load_library()
@@ -1085,6 +1120,7 @@ def fast3x3_supported(N, H, W, K, Nc, K1=None):
     return bool(lib.mi_conv3x3_bf16w_supported(C.byref(dc))), bool(lib.mi_conv3x3_wgrad_supported(C.byref(dw)))
 
 
+@functools.lru_cache(maxsize=None)      # pure function of the shape: one FFI query per distinct layer, not per step
 def fast1x1_supported(N, H, W, K, Nc):
     """(conv + dgrad via the LDS-tile kernel?, wgrad via the image-major kernel?) for a 1x1 layer in bf16 mode."""
     lib = load_library()
@@ -1098,6 +1134,7 @@ def fast1x1_supported(N, H, W, K, Nc):
     return ok, bool(lib.mi_conv3x3_wgrad_supported(C.byref(dw)))
 
 
+@functools.lru_cache(maxsize=None)      # pure function of the shape: one FFI query per distinct layer, not per step
 def conv3x3_uses_splitk(N, H, W, K, Nc, K1=None):
     """Would the 3x3 LDS-tile kernel run this layer with the split-K plan (fp32 output only)?"""
     dc = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0,
