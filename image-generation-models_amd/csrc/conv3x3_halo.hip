@@ -49,6 +49,8 @@ struct HaloArgs {
     const float* coef;   // FUSE: [3][N][K] scale / shift / time bias of the GroupNorm + Mish applied to x while it is staged
     int skew;            // extra LDS elements per halo ROW (see HaloSkew); 0 = rows packed
     int ep_rows;         // epilogue through LDS: row-contiguous stores and residual / accumulate loads
+    uint16_t* y16; int ldy16;   // optional second output: the same values rounded to bf16 (the copy the next Block's conv / the skip
+                         // connection's consumer reads), written by this epilogue instead of a separate conversion pass over y
     int qmap, gx, gy;    // 1-D launch of gx pixel tiles x gy channel tiles, each XCD takes gx / (8 / qmap) pixel tiles x gy / qmap channel tiles
     const float* gn_sums; const float* gn_gamma; const float* gn_beta; const float* gn_temb;   // FUSE without a coef tensor: the
     int gn_cg, gn_ldt; float gn_eps; double gn_icnt;   // producing conv's per-slab sums [N][K / 16][2] + the affine / time-bias vectors
@@ -589,6 +591,8 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
                         u32x2{pack_bf16(v[j][rq].x, v[j][rq].y), pack_bf16(v[j][rq].z, v[j][rq].w)};
                 else
                     *reinterpret_cast<f32x4*>(a.y + m * a.ldy + col) = v[j][rq];
+                if (!OUT16 && a.y16)
+                    *reinterpret_cast<u32x2*>(a.y16 + m * a.ldy16 + col) = u32x2{pack_bf16(v[j][rq].x, v[j][rq].y), pack_bf16(v[j][rq].z, v[j][rq].w)};
             }
     }
     if (a.gsum && a.TI == 1) {
@@ -622,7 +626,7 @@ void launch_halo(const HaloArgs& a_in, hipStream_t st) {
     // off by default: measured neutral (level 0 56.7 -> 55.8 us, step 6.39 vs 6.41 ms) -- what the ablation charges to the stores is
     // their burst at the end of a round of workgroups, not the rows per instruction
     static const int ep_env = [] { const char* e = getenv("MI_HALO_EPI"); return e ? atoi(e) : 0; }();
-    a.ep_rows = (ep_env && !SK && !a.gsum) ? 1 : 0;
+    a.ep_rows = (ep_env && !SK && !a.gsum && !a.y16) ? 1 : 0;
     if (a.ep_rows) {
         const size_t need = (size_t)WAVES * HaloCfg<BM, WAVES>::MI * 32 * 68 * sizeof(float);
         if (need > lds) lds = need;
@@ -761,7 +765,8 @@ static bool halo_ok(const MiConvDesc* d, int* bm, int* ck) {
 }
 
 static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
-                         const float* bias, const float* residual, float* y, int io, void* stream, float* gsum = nullptr);
+                         const float* bias, const float* residual, float* y, int io, void* stream, float* gsum = nullptr,
+                         void* y16 = nullptr, int ldy16 = 0);
 
 // k-slices of the split-K plan for this layer (0 = none).  Small-M layers (8x8 levels): a 256-pixel x
 // 64-channel-chunk tile with the K loop split over 2-8 workgroups beats 64-pixel tiles (weights are re-read
@@ -829,8 +834,17 @@ extern "C" int mi_conv3x3_bf16w_io_gnsums(const MiConvDesc* d, const void* x, co
     return halo_dispatch(d, (const float*)x, (const float*)x2, w_nk_bf16, bias, residual, (float*)y, io, stream, gsum);
 }
 
+// ... with a second, bf16 copy of an fp32 output written by the same epilogue (io bit 1 must be 0; 3x3 or 1x1; no split-K plan):
+// the residual-stream tensors that the next Block's conv and its weight gradient read as bf16.
+extern "C" int mi_conv3x3_bf16w_io_dual(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16, const float* bias,
+                                        const float* residual, float* y, void* y_bf16, int ldy16, int io, void* stream) {
+    if (!d || (d->KH != 3 && d->KH != 1) || (io & ~1) || !y_bf16 || ldy16 % 4 || ((uintptr_t)y_bf16 & 7))
+        return mi_set_error(-1, "mi_conv3x3_bf16w_io_dual: 3x3 or 1x1, fp32 y (io 0 or 1), 8-byte aligned bf16 copy with ldy16 %% 4 == 0");
+    return halo_dispatch(d, (const float*)x, (const float*)x2, w_nk_bf16, bias, residual, y, io, stream, nullptr, y_bf16, ldy16);
+}
+
 static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, const void* w_nk_bf16,
-                         const float* bias, const float* residual, float* y, int io, void* stream, float* gsum) {
+                         const float* bias, const float* residual, float* y, int io, void* stream, float* gsum, void* y16, int ldy16) {
     MI_REQUIRE(d && x && w_nk_bf16 && y, "null argument");
     int BM, CK;
     MI_REQUIRE(halo_ok(d, &BM, &CK), "descriptor not supported by the halo kernel (use mi_conv_igemm)");
@@ -842,12 +856,12 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
     a.N = d->N; a.H = d->OH; a.W = d->OW; a.K = d->K; a.Nc = d->Nc; a.K1 = d->K1; a.ldx = d->ldx;
     a.ldx2 = x2 ? d->ldx2 : d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.accumulate = d->accumulate;
     a.flip = d->transposed ? 1 : 0;
-    a.gsum = gsum; a.coef = nullptr; a.gn_sums = nullptr;
+    a.gsum = gsum; a.coef = nullptr; a.gn_sums = nullptr; a.y16 = (uint16_t*)y16; a.ldy16 = ldy16;
     hipStream_t st = (hipStream_t)stream;
     // Small-M layers (8x8 levels): a 256-pixel x 64-channel-chunk tile with the K loop split over
     // 2-4 workgroups beats 64-pixel tiles (weights are re-read per M tile); slices are summed with
     // row-coalesced fp32 atomics.
-    if (!(io & 2) && !gsum) {
+    if (!(io & 2) && !gsum && !y16) {
         int th, ti;
         const int ks = halo_splitk(d, BM, &th, &ti);
         if (ks) {
@@ -992,7 +1006,7 @@ static int fused_go(const MiConvDesc* d, const void* x, const float* coef, const
     HaloArgs a;
     a.x = (const float*)x; a.x2 = a.x; a.w = (const uint16_t*)w_nk_bf16; a.bias = bias; a.res = nullptr; a.y = (float*)y;
     a.N = d->N; a.H = d->OH; a.W = d->OW; a.K = d->K; a.Nc = d->Nc; a.K1 = d->K; a.ldx = d->ldx; a.ldx2 = d->ldx; a.ldy = d->ldy; a.ldr = 0;
-    a.accumulate = 0; a.flip = 0; a.ksplit = 1; a.coef = coef; a.gsum = nullptr;
+    a.accumulate = 0; a.flip = 0; a.ksplit = 1; a.coef = coef; a.gsum = nullptr; a.y16 = nullptr; a.ldy16 = 0;
     a.gn_sums = sums; a.gn_gamma = gamma; a.gn_beta = beta; a.gn_temb = temb; a.gn_ldt = ldt; a.gn_eps = eps;
     a.gn_cg = sums ? d->K / G : 16; a.gn_icnt = 1.0 / ((double)d->OH * (double)d->OW * (double)a.gn_cg);
     a.TH = TH; a.TI = 1; a.tiles_per_img = a.H / TH; a.HP = (TH + 2) * (a.W + 2);

@@ -257,6 +257,8 @@ class Unet(nn.Module):
         self.s2_wgrad_tr = os.environ.get("MI_DDPM_S2_TR", "1") != "0"
         # final_conv.0's conv output stored like the other Blocks' (bf16 in bf16 mode); 0 = fp32 as in round 1
         self.final_block16 = os.environ.get("MI_DDPM_FINAL16", "1") != "0"
+        # LinearAttention's to_out conv writes the bf16 copy of its (residual-stream) output along; 0 = separate conversion launches
+        self.dual_out = os.environ.get("MI_DDPM_DUAL_OUT", "1") != "0"
         self.accumulate_grads = False
         self.grad_ready_hook = None        # callable(lo, hi): flat_grads[lo:hi) is final (set by the DDP reducer)
 
@@ -477,7 +479,7 @@ class Unet(nn.Module):
             return ent[1]
 
         def conv(inp, pre, k, stride=1, pad=0, x2=None, residual=None, transposed_conv=False, bias=True, out_dtype=torch.float32,
-                 gn_sums=None):
+                 gn_sums=None, want16=False):
             w = sv[pre + "weight"]
             kh, kw, ci, co = w.shape
             if x2 is None and residual is None and stride == 1 and not transposed_conv:
@@ -487,9 +489,14 @@ class Unet(nn.Module):
                     return K.conv1x1_small_cout(0, inp, w, bias=sv[pre + "bias"] if bias else None, Cs=co)
             if mode == K.MODE_BF16 and k in (1, 3) and stride == 1 and not transposed_conv:
                 y = K.conv3x3_bf16w(inp, wf_sh[offs[pre + "weight"]:], K=ci, Nc=co, flip=False, ksize=k, x2=x2,
-                                    bias=sv[pre + "bias"] if bias else None, residual=residual, out_dtype=out_dtype, gn_sums=gn_sums)
+                                    bias=sv[pre + "bias"] if bias else None, residual=residual, out_dtype=out_dtype, gn_sums=gn_sums,
+                                    want16=want16)
                 if y is not None:
+                    if want16:                      # the epilogue wrote the bf16 copy along: register it for the consumers
+                        sh[id(y[0])] = y
+                        return y[0]
                     return y
+            assert not want16, "the bf16 copy rides in the tile kernel's epilogue only"
             assert gn_sums is None, "GroupNorm sums ride in the tile kernel's epilogue only"
             ih, iw = inp.shape[1], inp.shape[2]
             if transposed_conv:
@@ -573,7 +580,10 @@ class Unet(nn.Module):
             ln = K.chan_layernorm_fwd(inp, sv[pre + "fn.norm.g"], sv[pre + "fn.norm.b"], out_dtype=dt)
             qkv = conv(ln, pre + "fn.fn.to_qkv.", 1, bias=False, out_dtype=dt)
             ao, ctx, kstat = K.linattn_fwd(qkv, _HEADS)
-            out = conv(ao, pre + "fn.fn.to_out.", 1, residual=inp)
+            # training: the block's output is a residual-stream tensor whose bf16 copy is wanted by the skip connection's consumer,
+            # Downsample / Upsample and the next Block's conv: written by to_out's epilogue instead of a conversion pass
+            out = conv(ao, pre + "fn.fn.to_out.", 1, residual=inp,
+                       want16=bool(use_sh and a16 and self.dual_out and inp.shape[3] % 32 == 0))
             if record:
                 tape.append(("attn", at, inp, ln, qkv, ctx, kstat, ao, out))
             return out

@@ -180,9 +180,10 @@ def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mo
 
 
 def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=None, out=None, accumulate=False,
-                  out_dtype=torch.float32, gn_sums=None):
+                  out_dtype=torch.float32, gn_sums=None, want16=False):
     """3x3/s1/p1 (or 1x1) conv (flip=False) or its data gradient (flip=True) through the pipelined
-    LDS-tile kernel.  wsh: bf16 weights [k][k][Nc][K].  Returns None when the shape is not supported."""
+    LDS-tile kernel.  wsh: bf16 weights [k][k][Nc][K].  Returns None when the shape is not supported.
+    want16: -> (y, y16), the fp32 output and its bf16 copy written by the same epilogue."""
     _need_gpu(x)
     N, H, W, K1 = x.shape
     if x2 is None:
@@ -220,7 +221,12 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
                          f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
         return out
     e0 = _probe_open()
-    if gn_sums is not None:       # the next layer's GroupNorm statistics ride in this conv's epilogue
+    if want16:                    # fp32 output + its bf16 copy from one epilogue
+        assert out.dtype == torch.float32 and gn_sums is None and not accumulate
+        y16 = new_act(N, H, W, Nc, x, torch.bfloat16)
+        check(lib.mi_conv3x3_bf16w_io_dual(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _p(y16), ld_of(y16), io, _stream()),
+              "mi_conv3x3_bf16w_io_dual")
+    elif gn_sums is not None:     # the next layer's GroupNorm statistics ride in this conv's epilogue
         assert ksize == 3 and gn_sums.dtype == torch.float32 and gn_sums.numel() == N * (Nc // 16) * 2
         check(lib.mi_conv3x3_bf16w_io_gnsums(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), io, _p(gn_sums), _stream()),
               "mi_conv3x3_bf16w_io_gnsums")
@@ -238,7 +244,7 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
         _probe_close(e0, f"conv3x3_halo_kernel<{bm.value}, {ck.value}, {ksize}, {'true' if sk.value else 'false'}, {io}, {8 if bm.value == 256 or (bm.value == 128 and ck.value == 64) else 4}>",
                      2.0 * N * H * W * Nc * K * ksize * ksize,
                      f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)} io{io}", nb)
-    return out
+    return (out, y16) if want16 else out
 
 
 def gn_stats_coef(x, gamma, beta, *, groups=8, eps=1e-5, temb=None):

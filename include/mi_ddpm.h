@@ -115,6 +115,11 @@ int mi_conv3x3_bf16w_io(const MiConvDesc* d, const void* x, const void* x2, cons
  * the values it stores (rounded to bf16 when y is bf16) into gsum [N][Nc / 16][2] (zeroed by the caller; Nc % 16 == 0, H*W % 32 == 0);
  * mi_gn_coef_from_sums combines the slabs of each group into stats [N][G][2] = {mean, rstd} (optional) and coef [3][N][C] as
  * mi_gn_stats_coef would have written them (C / G % 16 == 0).  Block -> Block: conv1 + sums, coef, then mi_conv3x3_gn_mish. */
+/* mi_conv3x3_bf16w_io that also writes the bf16 copy of its fp32 output (y_bf16, pixel stride ldy16 elements): LinearAttention's
+ * to_out conv + residual (ddpm.py:45,152) produces a residual-stream tensor whose bf16 copy the skip connection's consumer, the
+ * Downsample conv and the weight gradients read -- one epilogue instead of a conversion pass over y. */
+int mi_conv3x3_bf16w_io_dual(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16, const float* bias,
+                             const float* residual, float* y, void* y_bf16, int ldy16, int io, void* stream);
 int mi_conv3x3_bf16w_io_gnsums(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16, const float* bias,
                                const float* residual, void* y, int io, float* gsum, void* stream);
 int mi_gn_coef_from_sums(int N, int C, int G, int HW, float eps, const float* sums, const float* gamma, const float* beta,
