@@ -23,8 +23,23 @@ extern "C" int mi_debug_halo_ts(unsigned long long* host_out) {
 #else
 #define MI_TS(k) do {} while (0)
 #endif
+#ifdef MI_HALO_TAPTIME
+// profiling build only (make EXTRA=-DMI_HALO_TAPTIME): per wave, shader-clock cycles spent between barriers (work) and from the
+// arrival at a tap's barrier (own LDS operations drained + the other waves) to leaving it, summed over the main loop
+__device__ unsigned long long g_halo_tap[4096 * 8 * 5];
+extern "C" int mi_debug_halo_tap(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_halo_tap), sizeof(g_halo_tap));
+}
+#define MI_TAP_BARRIER() do { const unsigned long long b0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); \
+        const unsigned long long b1_ = __builtin_amdgcn_s_memtime(); tt_work += b0_ - tt_prev; tt_bar += b1_ - b0_; tt_prev = b1_; ++tt_n; } while (0)
+#else
+#define MI_TAP_BARRIER() __syncthreads()
+#endif
+#ifndef MI_HALO_STORE_FIRST
+#define MI_HALO_STORE_FIRST 1
+#endif
 #ifndef MI_ABL
-#define MI_ABL 0      // profiling only: 1 no tap barrier, 2 no global loads, 4 no LDS stores, 8 no MFMA in the main loop
+#define MI_ABL 0      // profiling only: 1 no tap barrier, 2 no global loads, 4 no LDS stores, 8 no MFMA in the main loop, 16 (PIPE) half the weight-fragment reads
 #endif
 
 namespace {
@@ -73,6 +88,7 @@ template <int BM, int WAVES = (BM == 256 ? 8 : 4)> struct HaloCfg {
     static constexpr int NT = 64 * WAVES;                        // threads
     static constexpr int MI = BM / (16 * WAVES);                 // 32-row MFMA tiles per wave: 256/8 -> 2, 256/4 -> 4, 128/4 -> 2, 64/4 -> 1
     static constexpr int MAXHP = (BM == 256) ? 400 : (BM == 128 ? 288 : 160);
+    static constexpr int MAXHP3 = (BM == 256) ? 355 : MAXHP;      // with a third weight slot (PIPE) 400 halo pixels no longer fit 160 KB
 };
 
 // Software pipeline, per workgroup.  "Stage" g = chunk*9 + tap (3x3) or the 32-channel chunk index (1x1).
@@ -92,9 +108,15 @@ template <int BM, int WAVES = (BM == 256 ? 8 : 4)> struct HaloCfg {
 // is applied in registers between the global load and the LDS store of the halo tile, so the normalised tensor never exists in HBM.
 // The coefficients come from mi_gn_stats_coef; tiles must lie inside one image (TI == 1); zero padding stays zero (it is the
 // padding of h, not of x: the AND mask is applied after the transform).
-template <int BM, int CK, int KS, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4), bool FUSE = false>
+// PIPE: three weight slots instead of two -- the weights of stage g+2 are written during tap g, so everything tap g+1 reads was
+// published by the barrier BEFORE tap g and the first MFMA operands of tap g+1 are fetched from LDS while tap g's last MFMAs
+// run.  After the barrier the matrix pipe starts at once instead of waiting for an LDS round trip that all 8 waves of the
+// workgroup (one workgroup per CU: nobody else to fill the gap) begin at the same moment.
+template <int BM, int CK, int KS, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4), bool FUSE = false, bool PIPE = false>
 __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(const HaloArgs a) {
     constexpr bool IN16 = IO & 1, OUT16 = IO & 2;
+    static_assert(!PIPE || (KS == 3 && !SK && CK == 64), "PIPE: 3x3, 64-channel chunks");
+    constexpr int WS = PIPE ? 3 : 2;               // weight slots
     static_assert(!FUSE || (KS == 3 && !SK), "fusion: 3x3 forward tiles only");
     static_assert(!(SK && OUT16), "split-K accumulates with fp32 atomics");
     static_assert(KS == 3 || CK == 32, "1x1: 32-channel stages");
@@ -105,7 +127,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     constexpr int NSL = KS == 3 ? 9 : 1;           // slices a halo tile is fetched in
     constexpr int NT = HaloCfg<BM, WAVES>::NT, MI = HaloCfg<BM, WAVES>::MI, NI = 2;
     constexpr int PITCH = CK + 8;                  // bf16 elements; 16-B aligned rows, conflict-free b128 reads
-    constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
+    constexpr int MAXHP = KS == 3 ? (PIPE ? HaloCfg<BM>::MAXHP3 : HaloCfg<BM>::MAXHP) : BM;
     constexpr int ASZ = (MAXHP + 1) * PITCH;       // one halo buffer (+1 dump row for the staging slots past the tile)
     constexpr int Q = CK / 4;                      // float4 per halo pixel per chunk
     constexpr int A_IT = (MAXHP * Q + NT - 1) / NT;
@@ -115,8 +137,8 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
 
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t* As = lds;                                    // 2 x [MAXHP + 1][PITCH]
-    uint16_t* Bs = lds + 2 * ASZ;                          // 2 x [BN][PITCH]
-    int* pix = reinterpret_cast<int*>(Bs + 2 * BN * PITCH); // [MAXHP] source pixel index of each halo pixel, -1 = zero
+    uint16_t* Bs = lds + 2 * ASZ;                          // WS x [BN][PITCH]
+    int* pix = reinterpret_cast<int*>(Bs + WS * BN * PITCH); // [MAXHP] source pixel index of each halo pixel, -1 = zero
 
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
     const int wm = wv >> 1, wn = wv & 1;
@@ -299,6 +321,33 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
             *reinterpret_cast<u32x4*>(&Bs[slot * (BN * PITCH) + (b_n + i * (NT / (CK / 8))) * PITCH + b_k8 * 8]) =
                 KS == 1 ? r[i] & keep : r[i];
     };
+    bf16x8 pa[2][MI], pb[2][NI];                           // PIPE: operand sets that live across taps
+    // tap `tp` of a chunk with the operands of its first k-step already in set 0 (tp > 0: fetched during tap tp - 1; tp == 0: the
+    // chunk's halo buffer was completed by the slice stored during the previous tap, so it is read here, after the barrier)
+    auto mma_tap_pipe = [&](auto tpc, auto lastc, int abuf) {
+        constexpr int tp = decltype(tpc)::value;
+        auto opnd = [&](int set, int tap, int ks) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const uint16_t* At = As + abuf * ASZ + (ky * W2 + kx) * PITCH + ky * a.skew;
+            const uint16_t* Bt = Bs + (tap % WS) * (BN * PITCH);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) pa[set][i] = *reinterpret_cast<const bf16x8*>(&At[a_row[i] + ks * 16]);
+#pragma unroll
+            for (int j = 0; j < ((MI_ABL & 16) ? 1 : NI); ++j) pb[set][j] = *reinterpret_cast<const bf16x8*>(&Bt[b_row0 + j * 32 * PITCH + ks * 16]);
+            if constexpr ((MI_ABL & 16) != 0) pb[set][1] = pb[set][0];        // profiling only: one of the two weight fragments is not read
+        };
+        if constexpr (tp == 0) opnd(0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < CK / 16; ++ks) {
+            if (ks + 1 < CK / 16) opnd((ks + 1) & 1, tp, ks + 1);
+            else if constexpr (tp + 1 < TP) opnd(0, tp + 1, 0);       // next tap: slot (tp + 1) % 3 and the halo buffer are already published
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pb[ks & 1][j], pa[ks & 1][i], acc[i][j], 0, 0, 0);
+        }
+    };
     auto mma_tap = [&](int abuf, int slot, int tap) {
         const int ky = tap / KS, kx = tap - ky * KS;
         const uint16_t* At = As + abuf * ASZ + (ky * W2 + kx) * PITCH + ky * a.skew;
@@ -329,12 +378,41 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     // g+1 stored at the end of tap g; halo slice (tp+R-1) % 9 of the next chunk(s) is loaded into ra[(tp+R-1) % R]
     // and slice tp of chunk gi+1 stored at the end of tap tp.  1x1: stage = 32-channel chunk gi*4 + tp, activations
     // and weights both ride R taps ahead.  LAST: nothing beyond this group is loaded or stored.
+#ifdef MI_HALO_TAPTIME
+    unsigned long long tt_prev = 0, tt_work = 0, tt_bar = 0, tt_n = 0, tt_st = 0;
+#endif
     auto group = [&](auto lastc, int gi) {
         constexpr bool LAST = decltype(lastc)::value;
         if constexpr (FUSE && !LAST) load_coef(gi + 1);      // the slices stored during this group belong to chunk gi + 1
         static_for<0, TP>([&](auto tpc) {
             constexpr int tp = decltype(tpc)::value;
-            if constexpr (KS == 3) {
+            if constexpr (PIPE) {
+                // weights: stage g+4 is requested, stage g+2 goes to slot (tp + 2) % 3 (9 % 3 == 0: slot = tap % 3 in every chunk).
+                // The LDS stores come FIRST: nothing reads their targets before the next barrier, their sources were requested two
+                // taps ago, and issued here they complete under this tap's MFMAs -- at the end of the tap every wave would sit
+                // through vmcnt -> ds_write -> lgkmcnt(0) in front of the barrier with the matrix pipe idle (ablation: 23 % of the
+                // 8x8-level kernel, 14 % at level 0).
+                if constexpr (MI_HALO_STORE_FIRST && !(MI_ABL & 4)) {
+                    if constexpr (tp + 2 < TP || !LAST) store_b((tp + 2) % WS, rb[(tp + 2) % R]);
+                    if constexpr (!LAST) store_a((gi & 1) ^ 1, ra[tp % R], tp);
+#ifdef MI_HALO_TAPTIME
+                    __builtin_amdgcn_sched_barrier(0);
+                    tt_st += __builtin_amdgcn_s_memtime() - tt_prev;      // from leaving the barrier to the last LDS store issued
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+                if constexpr (tp + 4 < TP) load_b(rb[(tp + 1) % R], gi, tp + 4);
+                else if constexpr (!LAST) load_b(rb[(tp + 1) % R], gi + 1, tp + 4 - TP);
+                if constexpr (!LAST) {
+                    constexpr int sl = (tp + R - 1) % TP;
+                    load_a(ra[(tp + R - 1) % R], tp + R - 1 < TP ? gi + 1 : min(gi + 2, nchunks - 1), sl);
+                }
+                mma_tap_pipe(tpc, lastc, gi & 1);
+                if constexpr (!MI_HALO_STORE_FIRST && !(MI_ABL & 4)) {
+                if constexpr (tp + 2 < TP || !LAST) store_b((tp + 2) % WS, rb[(tp + 2) % R]);
+                if constexpr (!LAST) store_a((gi & 1) ^ 1, ra[tp % R], tp);
+                }
+            } else if constexpr (KS == 3) {
                 if constexpr (!(MI_ABL & 2)) {
                 if constexpr (tp + R < TP) load_b(rb[tp % R], gi, tp + R);
                 else if constexpr (!LAST) load_b(rb[tp % R], gi + 1, tp + R - TP);
@@ -360,7 +438,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
                     store_a((tp + 1) & 1, ra[(tp + 1) % R], 0);
                 }
             }
-            if constexpr (!(MI_ABL & 1)) __syncthreads();
+            if constexpr (!(MI_ABL & 1)) MI_TAP_BARRIER();
         });
     };
 
@@ -373,7 +451,14 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
 #pragma unroll
         for (int sl = 0; sl < NSL; ++sl) load_a(p0[sl], 0, sl);
         load_b(b0, 0, 0);
-        if constexpr (KS == 3) {
+        if constexpr (PIPE) {
+            const int c1 = min(1, nchunks - 1);
+            u32x4 b1[B_IT];
+            load_b(b1, 0, 1);
+            load_b(rb[2], 0, 2); load_a(ra[0], c1, 0);
+            load_b(rb[0], 0, 3); load_a(ra[1], c1, 1);
+            store_b(1, b1);
+        } else if constexpr (KS == 3) {
             const int c1 = min(1, nchunks - 1);
             load_b(rb[1], 0, 1); load_a(ra[0], c1, 0);
             load_b(rb[2], 0, 2); load_a(ra[1], c1, 1);
@@ -389,8 +474,18 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     }
     __syncthreads();
     MI_TS(2);
+#ifdef MI_HALO_TAPTIME
+    tt_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tt_w0 = wall_clock64();
+#endif
     for (int gi = 0; gi + 1 < ngroups; ++gi) group(std::false_type{}, gi);
     group(std::true_type{}, ngroups - 1);
+#ifdef MI_HALO_TAPTIME
+    if (l == 0 && blockIdx.x < 4096 && blockIdx.y == 0 && blockIdx.z == 0) {
+        unsigned long long* g = g_halo_tap + ((size_t)blockIdx.x * 8 + wv) * 5;
+        g[0] = tt_work; g[1] = tt_bar; g[2] = tt_n; g[3] = wall_clock64() - tt_w0; g[4] = tt_st;       // 100 MHz ticks over the same span
+    }
+#endif
 
     MI_TS(3);
     // ---- epilogue: lane = pixel (l & 31), register quad rq = channels 8*rq + 4*(l >> 5) .. +3
@@ -617,11 +712,11 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     MI_TS(4);
 }
 
-template <int BM, int CK, int KS = 3, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4), bool FUSE = false>
+template <int BM, int CK, int KS = 3, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4), bool FUSE = false, bool PIPE = false>
 void launch_halo(const HaloArgs& a_in, hipStream_t st) {
     constexpr int PITCH = CK + 8;
-    constexpr int MAXHP = KS == 3 ? HaloCfg<BM>::MAXHP : BM;
-    size_t lds = (size_t)(2 * (MAXHP + 1) * PITCH + 2 * 128 * PITCH) * 2 + MAXHP * 4;
+    constexpr int MAXHP = KS == 3 ? (PIPE ? HaloCfg<BM>::MAXHP3 : HaloCfg<BM>::MAXHP) : BM;
+    size_t lds = (size_t)(2 * (MAXHP + 1) * PITCH + (PIPE ? 3 : 2) * 128 * PITCH) * 2 + MAXHP * 4;
     HaloArgs a = a_in;
     // off by default: measured neutral (level 0 56.7 -> 55.8 us, step 6.39 vs 6.41 ms) -- what the ablation charges to the stores is
     // their burst at the end of a round of workgroups, not the rows per instruction
@@ -648,11 +743,11 @@ void launch_halo(const HaloArgs& a_in, hipStream_t st) {
     // pixel tile adjacent, so the input tile is read from HBM once instead of once per channel tile (level 0: 203 -> 137 MB)
     if (q_env && KS == 1 && !SK && a.ksplit == 1 && a.gy > 1 && a.gx % 8 == 0) { a.qmap = 1; grid = dim3(grid.x * grid.y, 1, 1); }
     static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE>), grid, dim3(HaloCfg<BM, WAVES>::NT), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE, PIPE>), grid, dim3(HaloCfg<BM, WAVES>::NT), lds, st, a);
 }
 
 // fp32 [tap][k][n] master weights -> bf16 Wd[tap][k][n] (same layout) and Wf[tap][n][k] (transposed per tap)
@@ -796,6 +891,11 @@ static bool halo_w8(const MiConvDesc* d, int BM, int* th, int* ti) {
 }
 // 64-pixel tiles that cannot fill the chip twice anyway (<= 256 workgroups): 64-channel chunks, i.e. twice the MFMAs per
 // barrier; the larger LDS footprint (one workgroup per CU) costs nothing then
+// three weight slots + operands of the next tap fetched before the barrier (PIPE); MI_HALO_PIPE=0 restores the two-slot kernels
+static bool halo_pipe() {
+    static const int on = [] { const char* e = getenv("MI_HALO_PIPE"); return e ? atoi(e) : 0; }();
+    return on != 0;
+}
 static bool halo_wide64(const MiConvDesc* d, int BM) {
     static const int ck64 = [] { const char* e = getenv("MI_HALO_CK64"); return e ? atoi(e) : 1; }();
     return ck64 && d->KH == 3 && BM == 64 && d->K % 64 == 0 && d->K1 % 64 == 0 &&
@@ -920,6 +1020,14 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
         if (halo_w8(d, BM, &th8, &ti8)) {
             a.TH = th8; a.TI = ti8; a.tiles_per_img = ti8 > 1 ? 1 : a.H / th8; a.HP = ti8 * (th8 + 2) * (a.W + 2);
             a.xmap = a.xmap && a.TI == 1 && a.tiles_per_img > 1;
+            if (halo_pipe())
+                switch (io) {
+                    case 0: launch_halo<128, 64, 3, false, 0, 8, false, true>(a, st); break;
+                    case 1: launch_halo<128, 64, 3, false, 1, 8, false, true>(a, st); break;
+                    case 2: launch_halo<128, 64, 3, false, 2, 8, false, true>(a, st); break;
+                    default: launch_halo<128, 64, 3, false, 3, 8, false, true>(a, st); break;
+                }
+            else
             switch (io) {
                 case 0: launch_halo<128, 64, 3, false, 0, 8>(a, st); break;
                 case 1: launch_halo<128, 64, 3, false, 1, 8>(a, st); break;
@@ -932,7 +1040,8 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
     }
     const bool wide64 = halo_wide64(d, BM);
 #define MI_HALO_GO(IOV) \
-    do { if (BM == 256) { if (CK == 64) launch_halo<256, 64, 3, false, IOV>(a, st); else launch_halo<256, 32, 3, false, IOV>(a, st); } \
+    do { if (BM == 256) { if (CK == 64 && halo_pipe() && a.HP <= HaloCfg<256>::MAXHP3) launch_halo<256, 64, 3, false, IOV, 8, false, true>(a, st); \
+                          else if (CK == 64) launch_halo<256, 64, 3, false, IOV>(a, st); else launch_halo<256, 32, 3, false, IOV>(a, st); } \
          else if (BM == 128) launch_halo<128, 32, 3, false, IOV>(a, st); \
          else if (wide64) launch_halo<64, 64, 3, false, IOV>(a, st); \
          else launch_halo<64, 32, 3, false, IOV>(a, st); } while (0)

@@ -238,6 +238,24 @@ def test_conv_epilogue_groupnorm_sums(K, cfg, storage):
     assert float((cf1 - cf0).abs().max()) < 1e-4 * float(cf0.abs().max())
 
 
+@pytest.mark.parametrize("cfg", [(16, 32, 32, 128, 128, 1), (8, 16, 16, 256, 256, 1), (4, 8, 8, 512, 512, 1), (4, 32, 32, 128, 128, 3),
+                                 (3, 32, 32, 64, 160, 1)])
+def test_conv_dual_output(K, cfg):
+    """mi_conv3x3_bf16w_io_dual (to_out + Residual, reference ddpm.py:45,152): the fp32 output is the one the plain entry point
+    writes (bitwise) and the second output is that tensor rounded to bf16 (bitwise)."""
+    N, H, W, Ci, Co, ks = cfg
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(N, H, W, Ci, generator=g).to(DEV).bfloat16()
+    wsh = (torch.randn(ks * ks * Co * Ci, generator=g) / math.sqrt(ks * ks * Ci)).to(DEV).bfloat16()
+    bias = torch.randn(Co, generator=g).to(DEV)
+    res = torch.randn(N, H, W, Co, generator=g).to(DEV)
+    y0 = K.conv3x3_bf16w(x, wsh, K=Ci, Nc=Co, flip=False, ksize=ks, bias=bias, residual=res)
+    y1, y16 = K.conv3x3_bf16w(x, wsh, K=Ci, Nc=Co, flip=False, ksize=ks, bias=bias, residual=res, want16=True)
+    torch.cuda.synchronize()
+    assert y16.dtype == torch.bfloat16 and y16.shape == y0.shape
+    assert torch.equal(y0, y1) and torch.equal(y16, y0.bfloat16())
+
+
 def _mish64(x):
     return x * torch.tanh(F.softplus(x))
 
@@ -1142,3 +1160,17 @@ def test_small_gemm_linear(K, M, N, Kc):
     else:
         assert rel_err(dW - 0.25, dy.t() @ x) < 2e-6
     assert K.small_gemm(False, True, xg[:, :Kc - 1], wg[:, :Kc - 1]) is None          # K % 32 != 0 -> caller falls back
+
+
+def test_conv3x3_three_slot_variant_in_a_subprocess():
+    """MI_HALO_PIPE=1 (read once per process): the 3x3 conv kernels with three weight slots, the next tap's first MFMA operands fetched
+    before the barrier and the LDS stores at the top of the tap pass the same forward / data-gradient / dual-output / epilogue-sum
+    parity tests as the default two-slot kernels."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MI_HALO_PIPE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "test_conv3x3_halo_fwd_and_dgrad or test_conv_dual_output or test_conv_epilogue_groupnorm_sums or test_conv_forward"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

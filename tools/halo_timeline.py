@@ -13,10 +13,11 @@ lib = load_library()
 fn = lib.mi_debug_halo_ts
 fn.argtypes = [ctypes.c_void_p]; fn.restype = ctypes.c_int
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+DT = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32
 for H, Ci, Co in [(32, 128, 128), (32, 256, 128), (16, 256, 256), (16, 512, 128), (8, 512, 512)]:
-    x = torch.randn(B, H, H, Ci, device="cuda")
+    x = torch.randn(B, H, H, Ci, device="cuda").to(DT)
     w = (torch.randn(3, 3, Co, Ci, device="cuda") * 0.05).to(torch.bfloat16).reshape(-1)
-    y = torch.empty(B, H, H, Co, device="cuda")
+    y = torch.empty(B, H, H, Co, device="cuda", dtype=DT)
     for _ in range(3):
         K.conv3x3_bf16w(x, w, K=Ci, Nc=Co, flip=False, out=y)
     torch.cuda.synchronize()

@@ -8,11 +8,13 @@ from src.models.ddpm import DDPM
 from src.ops import functional as K
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 torch.manual_seed(0)
-m = DDPM({"width": 32, "height": 32, "channels": 3, "transforms": {"normalize": True}}, hidden_dim=128, dim_mults=(1, 2, 4),
-         lr=1e-4, b1=0.9, b2=0.999).to("cuda")
+CFG3 = len(sys.argv) > 2 and sys.argv[2] == "cfg3"        # python tools/probe_step.py 32 cfg3
+S = 64 if CFG3 else 32
+m = DDPM({"width": S, "height": S, "channels": 3, "transforms": {"normalize": True}}, hidden_dim=64 if CFG3 else 128,
+         dim_mults=(1, 2, 4, 8) if CFG3 else (1, 2, 4), lr=1e-4, b1=0.9, b2=0.999).to("cuda")
 m.denoising_model.compute_mode = "bf16"; m.train()
 opt = m.configure_optimizers()
-x = torch.rand(B, 3, 32, 32, device="cuda") * 2 - 1
+x = torch.rand(B, 3, S, S, device="cuda") * 2 - 1
 for i in range(3):
     loss = m.training_step((x, None), i); loss.backward(); opt.step()
 torch.cuda.synchronize()
