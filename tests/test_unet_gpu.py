@@ -106,6 +106,46 @@ def test_tiny_sampler_T8_golden(golden_dir):
     assert abs(float(s.sum()) + 43.85355830) < 5e-3            # SURVEY.md KAT-C
 
 
+def test_offpath_posterior_helpers(golden_dir):
+    """predict_start_from_noise / q_posterior / p_mean_variance / q_mean_variance (reference ddpm.py:359-388; the sampler itself
+    runs the fused mi_p_sample_update kernel): (a) each equals its closed form evaluated in float64 from the schedule buffers
+    (which test_host_cpu pins bit-equal to the reference's); (b) p_sample == mean + [t > 0] * exp(0.5 * log_variance) * z with the
+    same z (ddpm.py:390-397), i.e. the helpers and the fused kernel describe the same posterior."""
+    from src.models.ddpm import GaussianDiffusion
+    g, net = _tiny(golden_dir)
+    net.eval()
+    gd = GaussianDiffusion(net, image_size=(8, 8), timesteps=8).to(DEV)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 8, 8, generator=gen).to(DEV)
+    x0 = (torch.rand(4, 3, 8, 8, generator=gen) * 2 - 1).to(DEV)
+    nz = torch.randn(4, 3, 8, 8, generator=gen).to(DEV)
+    t = torch.tensor([5, 0, 7, 1], device=DEV)
+    buf = {k: getattr(gd, k).double().cpu().numpy() for k in ("sqrt_alphas_cumprod", "alphas_cumprod", "log_one_minus_alphas_cumprod",
+           "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2",
+           "posterior_variance", "posterior_log_variance_clipped")}
+    tc = t.cpu().numpy()
+    col = lambda k: buf[k][tc].reshape(-1, 1, 1, 1)                                        # noqa: E731
+    xd, x0d, nzd = (v.double().cpu().numpy() for v in (x, x0, nz))
+    with torch.no_grad():
+        m, v, lv = gd.q_mean_variance(x0, t)
+        assert np.abs(m.cpu().numpy() - col("sqrt_alphas_cumprod") * x0d).max() < 1e-6
+        assert np.abs(v.cpu().numpy() - (1.0 - col("alphas_cumprod"))).max() < 1e-6
+        assert np.abs(lv.cpu().numpy() - col("log_one_minus_alphas_cumprod")).max() < 1e-5
+        xs = gd.predict_start_from_noise(x, t, nz)
+        want_xs = col("sqrt_recip_alphas_cumprod") * xd - col("sqrt_recipm1_alphas_cumprod") * nzd     # coefficients reach 163 at t = T - 1
+        assert np.abs(xs.cpu().numpy() - want_xs).max() < 2e-6 * np.abs(col("sqrt_recip_alphas_cumprod") * xd).max()
+        pm, pv, plv = gd.q_posterior(x0, x, t)
+        assert np.abs(pm.cpu().numpy() - (col("posterior_mean_coef1") * x0d + col("posterior_mean_coef2") * xd)).max() < 1e-5
+        assert np.abs(pv.cpu().numpy() - col("posterior_variance")).max() < 1e-7
+        assert np.abs(plv.cpu().numpy() - col("posterior_log_variance_clipped")).max() < 1e-5
+        mean, _, logvar = gd.p_mean_variance(x, t, clip_denoised=True)
+        gd.noise_source = lambda shape, device: nz.to(device)
+        xp = gd.p_sample(x, t, clip_denoised=True)
+    keep = (t > 0).float().view(-1, 1, 1, 1)
+    want = mean + keep * torch.exp(0.5 * logvar) * nz
+    assert float((xp - want).abs().max()) < 2e-5
+
+
 def test_tiny_adam5_golden(golden_dir):
     """Five optimisation steps (Adam lr 1e-4, betas .9/.999) track the reference's loss curve."""
     from src.models.ddpm import GaussianDiffusion
