@@ -16,6 +16,16 @@ template <> struct V<4> {
     __device__ static V load(const float* p) { float4 t = *reinterpret_cast<const float4*>(p); return V{{t.x, t.y, t.z, t.w}}; }
     __device__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
+template <> struct V<8> {
+    float v[8];
+    __device__ static V load(const float* p) {
+        float4 t = *reinterpret_cast<const float4*>(p), u = *reinterpret_cast<const float4*>(p + 4);
+        return V{{t.x, t.y, t.z, t.w, u.x, u.y, u.z, u.w}};
+    }
+    __device__ void store(float* p) const {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
 template <> struct V<1> {
     float v[1];
     __device__ static V load(const float* p) { return V{{*p}}; }
@@ -25,7 +35,11 @@ template <> struct V<1> {
 // element-type-generic access: T16 = tensor stored as bf16 (offsets count elements)
 template <int VEC, bool T16> __device__ __forceinline__ V<VEC> vload(const void* base, size_t off) {
     if constexpr (!T16) return V<VEC>::load(reinterpret_cast<const float*>(base) + off);
-    else if constexpr (VEC == 4) {
+    else if constexpr (VEC == 8) {          // 8 bf16 = one 16-byte load
+        const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + off);
+        return V<8>{{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u),
+                     __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)}};
+    } else if constexpr (VEC == 4) {
         const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + off);
         return V<4>{{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)}};
     } else {
@@ -34,6 +48,9 @@ template <int VEC, bool T16> __device__ __forceinline__ V<VEC> vload(const void*
 }
 template <int VEC, bool T16> __device__ __forceinline__ void vstore(void* base, size_t off, const V<VEC>& v) {
     if constexpr (!T16) v.store(reinterpret_cast<float*>(base) + off);
+    else if constexpr (VEC == 8)
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + off) =
+            make_uint4(pack_bf16(v.v[0], v.v[1]), pack_bf16(v.v[2], v.v[3]), pack_bf16(v.v[4], v.v[5]), pack_bf16(v.v[6], v.v[7]));
     else if constexpr (VEC == 4)
         *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + off) = make_uint2(pack_bf16(v.v[0], v.v[1]), pack_bf16(v.v[2], v.v[3]));
     else reinterpret_cast<uint16_t*>(base)[off] = (uint16_t)(pack_bf16(v.v[0], 0.f) & 0xffff);
@@ -48,6 +65,7 @@ struct GnArgs {
     // backward
     const float* dout; float* dx; float* dgamma; float* dbeta; float* dtemb; float* dbias; int lddo, lddx;
     int xcd_map;
+    int vec8_units;                // > 0: units per thread if a lane took 8 channels (see gn_vec8)
 };
 
 // thread layout inside a (n,g) slice: W = Cg/VEC channel units per pixel; unit u = t % W handles
@@ -293,6 +311,9 @@ int gn_prepare(const MiGnDesc* d, GnArgs& a, int& vec, int& units) {
     if (vec == 1 && cg > 2) return -2;
     int W = cg / vec, PP = 256 / W;
     units = (d->HW + PP - 1) / PP;                // V<VEC> units per thread
+    // 8 channels (16 bytes of bf16) per lane: half the load / store instructions for the same bytes, 64-byte instead of 32-byte
+    // pieces of a pixel row per pair of lanes.  Callers switch it on with gn_vec8() when every bf16 pointer / stride allows it.
+    a.vec8_units = (cg % 8 == 0) ? (d->HW + 256 / (cg / 8) - 1) / (256 / (cg / 8)) : 0;
     return 0;
 }
 
@@ -450,10 +471,22 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
 
 }  // namespace
 
+// 8-channel lanes: bf16 tensors only (a lane's 8 channels are one 16-byte access), every stride a multiple of 8 elements, slices
+// of 5..8 units per thread (the level-0 layers)
+static bool gn_vec8(const GnArgs& a, int io_all16, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+    static const int on = [] { const char* e = getenv("MI_GN_VEC8"); return e ? atoi(e) : 1; }();
+    if (!on || !io_all16 || a.vec8_units <= 4 || a.vec8_units > 8) return false;      // measured: a gain on the 1024-pixel slices (backward 36.1 -> 33.0 us at level 0), none on the small ones
+    for (int l : lds) if (l % 8) return false;
+    for (const void* p : ptrs) if ((uintptr_t)p & 15) return false;
+    return true;
+}
 #define GN_DISPATCH_IO_(KERNEL, IOV, FWD)                                                                 \
     do {                                                                                            \
         dim3 grid(a.N * a.G), blk(256);                                                             \
-        if (vec == 4) {                                                                             \
+        if (vec == 8) {                                                                             \
+            if (a.vec8_units <= 4) hipLaunchKernelGGL((KERNEL<8, 4, IOV>), grid, blk, 0, st, a);    \
+            else hipLaunchKernelGGL((KERNEL<8, 8, IOV>), grid, blk, 0, st, a);                      \
+        } else if (vec == 4) {                                                                             \
             if (units <= 4) hipLaunchKernelGGL((KERNEL<4, 4, IOV>), grid, blk, 0, st, a);           \
             else if (units <= 16) hipLaunchKernelGGL((KERNEL<4, 16, IOV>), grid, blk, 0, st, a);    \
             else if (units <= 32 && FWD) hipLaunchKernelGGL((KERNEL<4, 32, IOV>), grid, blk, 0, st, a); \
@@ -509,9 +542,10 @@ extern "C" int mi_gn_mish_fwd_io(const MiGnDesc* d, const void* x, const float* 
     GnArgs a{};
     int vec, units;
     int rc = gn_prepare(d, a, vec, units);
-    MI_REQUIRE(rc == 0 && vec == 4, "bf16 storage needs C/G to be a multiple of 4 (power of two <= 128)");
+    MI_REQUIRE(rc == 0 && vec >= 4, "bf16 storage needs C/G to be a multiple of 4 (power of two <= 128)");
     MI_REQUIRE(d->ldx % 4 == 0 && d->ldy % 4 == 0 && (!residual || d->ldr % 4 == 0), "ld must be a multiple of 4");
     a.x = (const float*)x; a.gamma = gamma; a.beta = beta; a.temb = temb; a.ldt = ldt; a.res = residual; a.y = (float*)y; a.stats = stats;
+    if (gn_vec8(a, io & 1, {d->ldx, d->ldy, residual ? d->ldr : 0, temb ? ldt : 0}, {x, y, residual, temb, gamma, beta})) vec = 8;
     hipStream_t st = (hipStream_t)stream;
     switch (io) {
         case 0: GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 0); break;
@@ -532,10 +566,11 @@ extern "C" int mi_gn_mish_fwd_dual(const MiGnDesc* d, const void* x, const float
     GnArgs a{};
     int vec, units;
     int rc = gn_prepare(d, a, vec, units);
-    MI_REQUIRE(rc == 0 && vec == 4, "the bf16 copy needs C/G to be a multiple of 4 (power of two <= 128)");
+    MI_REQUIRE(rc == 0 && vec >= 4, "the bf16 copy needs C/G to be a multiple of 4 (power of two <= 128)");
     MI_REQUIRE(d->ldx % 4 == 0 && d->ldy % 4 == 0 && ldy16 % 4 == 0 && (!residual || d->ldr % 4 == 0), "ld must be a multiple of 4");
     a.x = (const float*)x; a.gamma = gamma; a.beta = beta; a.temb = temb; a.ldt = ldt; a.res = residual; a.y = (float*)y; a.stats = stats;
     a.y16 = (uint16_t*)y16; a.ldy16 = ldy16;
+    if (gn_vec8(a, io & 1, {d->ldx, d->ldy, ldy16, residual ? d->ldr : 0, temb ? ldt : 0}, {x, y, y16, residual, temb, gamma, beta})) vec = 8;
     hipStream_t st = (hipStream_t)stream;
     switch (io) {
         case 0: GN_DISPATCH_FWD_IO(gn_mish_fwd_kernel, 0); break;
@@ -603,10 +638,11 @@ extern "C" int mi_gn_mish_bwd_io(const MiGnDesc* d, const void* x, const float* 
     GnArgs a{};
     int vec, units;
     int rc = gn_prepare(d, a, vec, units);
-    MI_REQUIRE(rc == 0 && vec == 4, "bf16 storage needs C/G to be a multiple of 4 (power of two <= 128)");
+    MI_REQUIRE(rc == 0 && vec >= 4, "bf16 storage needs C/G to be a multiple of 4 (power of two <= 128)");
     MI_REQUIRE(d->ldx % 4 == 0 && lddo % 4 == 0 && lddx % 4 == 0, "ld must be a multiple of 4");
     a.x = (const float*)x; a.stats = const_cast<float*>(stats); a.gamma = gamma; a.beta = beta; a.dout = (const float*)dout; a.lddo = lddo;
     a.dx = (float*)dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta; a.dtemb = dtemb; a.ldt = ldt; a.dbias = dbias;
+    if (gn_vec8(a, io & 1, {d->ldx, lddo, lddx}, {x, dout, dx, gamma, beta})) vec = 8;
     hipStream_t st = (hipStream_t)stream;
     switch (io) {
         case 0: GN_DISPATCH_IO(gn_mish_bwd_kernel, 0); break;
