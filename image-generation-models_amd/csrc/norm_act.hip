@@ -8,6 +8,10 @@
 #include <stdlib.h>
 #include "common.h"
 
+#ifndef MI_GN_WAVES
+#define MI_GN_WAVES 4     // waves per SIMD the packed-cache GroupNorm backward is compiled for
+#endif
+
 namespace {
 
 template <int VEC> struct V;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
 
 // Backward of y = mish(xhat*gamma+beta) + temb + res wrt x (the conv output), gamma, beta, temb.
 template <int VEC, int MAXU, int IO = 0>     // IO bit 0: x is bf16, bit 1: dx is written as bf16, bit 2: dout is bf16
-__global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
+__global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? MI_GN_WAVES : 1)) void gn_mish_bwd_kernel(const GnArgs a) {
     constexpr bool X16 = IO & 1, DX16 = IO & 2, DO16 = IO & 4;
     __shared__ float part[4][256 * VEC];
     __shared__ float chs[4][128];
@@ -192,7 +196,19 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { ga[j] = a.gamma[c0 + j]; be[j] = a.beta[c0 + j]; }
 
-    V<VEC> cx[MAXU > 0 ? MAXU : 1], cd[MAXU > 0 ? MAXU : 1];   // cached xhat and dz
+    // Cached slice between the two passes.  fp32 x: xhat and dz as fp32.  bf16 x (PKC): x as loaded (packed pairs, exact) and dz
+    // rounded to bf16 -- a quarter of the registers, i.e. 4 instead of 2 waves per SIMD for this HBM-bound kernel; xhat is one
+    // FMA to recompute, and dx leaves as bf16 (or feeds a bf16-mode consumer) anyway.
+    constexpr bool PKC = X16 && MAXU > 4 && VEC >= 4;
+    const int cu = u * VEC;                                                                                  // this lane's first channel inside the group
+    const uint16_t* xg = reinterpret_cast<const uint16_t*>(a.x) + (size_t)n * a.HW * a.ldx + g * a.Cg;     // (sample, group) slice bases: wave-uniform
+    const void* dg = DO16 ? (const void*)(reinterpret_cast<const uint16_t*>(a.dout) + (size_t)n * a.HW * a.lddo + g * a.Cg)
+                          : (const void*)(a.dout + (size_t)n * a.HW * a.lddo + g * a.Cg);
+    void* dxg = DX16 ? (void*)(reinterpret_cast<uint16_t*>(a.dx) + (size_t)n * a.HW * a.lddx + g * a.Cg)
+                     : (void*)(a.dx + (size_t)n * a.HW * a.lddx + g * a.Cg);          // the small slices (MAXU <= 4) hold 32 registers of cache either way
+    V<VEC> cx[(MAXU > 0 && !PKC) ? MAXU : 1], cd[(MAXU > 0 && !PKC) ? MAXU : 1];   // cached xhat and dz
+    uint32_t px[PKC ? MAXU : 1][VEC >= 2 ? VEC / 2 : 1], pd[PKC ? MAXU : 1][VEC >= 2 ? VEC / 2 : 1];
+    const float icnt = 1.0f / cnt;
     float sA[VEC], sD[VEC], sT[VEC], sB[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) sA[j] = sD[j] = sT[j] = sB[j] = 0.f;
@@ -229,6 +245,41 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
                 const float dzz = dd * (X16 ? mish_grad_fast_f(z) : mish_grad_f(z));
                 cx[k].v[j] = h; cd[k].v[j] = dzz;
                 sA[j] += dzz; sD[j] += dzz * h; sT[j] += dd; sB[j] += h;
+            }
+        }
+    } else if constexpr (PKC) {
+        // (Issuing every load of the slice -- or batches of 2..8 units -- before the first use, as the small-slice path above does,
+        //  was tried here: one basic block of 16 units makes the scheduler interleave their exp / rcp chains and the register
+        //  allocator spills 500-800 bytes per lane at 3 or 4 waves per SIMD.  The guarded form keeps one unit per block; its load
+        //  round trips are covered by the 16 waves per CU that the packed cache makes room for.)
+#pragma unroll
+        for (int k = 0; k < MAXU; ++k) {
+            const int p = pr + k * PP;
+            if (p < a.HW) {
+                // uniform slice base + one 32-bit offset per access
+                const uint16_t* xp = xg + (uint32_t)(p * a.ldx + cu);
+                if constexpr (VEC == 8) {
+                    const uint4 w = *reinterpret_cast<const uint4*>(xp);
+                    px[k][0] = w.x; px[k][1] = w.y; px[k][2] = w.z; px[k][3] = w.w;
+                } else {
+                    const uint2 w = *reinterpret_cast<const uint2*>(xp);
+                    px[k][0] = w.x; px[k][1] = w.y;
+                }
+                const V<VEC> d = vload<VEC, DO16>(dg, (size_t)(uint32_t)(p * a.lddo + cu));
+#pragma unroll
+                for (int j2 = 0; j2 < VEC / 2; ++j2) {
+                    float dzp[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * j2 + e;
+                        const float q = __uint_as_float(e ? (px[k][j2] & 0xffff0000u) : (px[k][j2] << 16));
+                        const float h = (q - mean) * rstd, z = h * ga[j] + be[j];
+                        const float dzz = d.v[j] * mish_grad_fast_f(z);
+                        dzp[e] = dzz;
+                        sA[j] += dzz; sD[j] += dzz * h; sT[j] += d.v[j]; sB[j] += h;
+                    }
+                    pd[k][j2] = pack_bf16(dzp[0], dzp[1]);
+                }
             }
         }
     } else if constexpr (MAXU > 0) {
@@ -277,10 +328,29 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const GnArgs a) {
     auto pass2 = [&](int p, const V<VEC>& xh, const V<VEC>& dz) {
         V<VEC> o;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o.v[j] = rstd * (dz.v[j] * ga[j] - (s1 + xh.v[j] * s2) / cnt);
+        for (int j = 0; j < VEC; ++j) o.v[j] = rstd * (dz.v[j] * ga[j] - (s1 + xh.v[j] * s2) * icnt);
         vstore<VEC, DX16>(a.dx, dxoff + (size_t)p * a.lddx, o);
     };
-    if constexpr (MAXU > 0) {
+    if constexpr (PKC) {
+#pragma unroll
+        for (int k = 0; k < MAXU; ++k) {
+            const int p = pr + k * PP;
+            if (p < a.HW) {
+                V<VEC> xh, dz;
+#pragma unroll
+                for (int j2 = 0; j2 < VEC / 2; ++j2) {
+                    xh.v[2 * j2] = (__uint_as_float(px[k][j2] << 16) - mean) * rstd;
+                    xh.v[2 * j2 + 1] = (__uint_as_float(px[k][j2] & 0xffff0000u) - mean) * rstd;
+                    dz.v[2 * j2] = __uint_as_float(pd[k][j2] << 16);
+                    dz.v[2 * j2 + 1] = __uint_as_float(pd[k][j2] & 0xffff0000u);
+                }
+                V<VEC> o;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o.v[j] = rstd * (dz.v[j] * ga[j] - (s1 + xh.v[j] * s2) * icnt);
+                vstore<VEC, DX16>(dxg, (size_t)(uint32_t)(p * a.lddx + cu), o);
+            }
+        }
+    } else if constexpr (MAXU > 0) {
 #pragma unroll
         for (int k = 0; k < MAXU; ++k) { int p = pr + k * PP; if (p < a.HW) pass2(p, cx[k], cd[k]); }
     } else {
@@ -474,8 +544,8 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
 // 8-channel lanes: bf16 tensors only (a lane's 8 channels are one 16-byte access), every stride a multiple of 8 elements, slices
 // of 5..8 units per thread (the level-0 layers)
 static bool gn_vec8(const GnArgs& a, int io_all16, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
-    static const int on = [] { const char* e = getenv("MI_GN_VEC8"); return e ? atoi(e) : 1; }();
-    if (!on || !io_all16 || a.vec8_units <= 4 || a.vec8_units > 8) return false;      // measured: a gain on the 1024-pixel slices (backward 36.1 -> 33.0 us at level 0), none on the small ones
+    static const int on = [] { const char* e = getenv("MI_GN_VEC8"); return e ? atoi(e) : 0; }();
+    if (!on || !io_all16 || a.vec8_units <= 4 || a.vec8_units > 8) return false;      // measured on the 1024-pixel slices: backward 36.1 -> 33.0 us with fp32 caches, but no better than 4-channel lanes once the caches are packed (4 waves per SIMD): off by default
     for (int l : lds) if (l % 8) return false;
     for (const void* p : ptrs) if ((uintptr_t)p & 15) return false;
     return true;
