@@ -196,7 +196,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
 #pragma unroll
             for (int j = 0; j < A_SL; ++j) {
                 const int hp = a_hp0 + (sl * A_SL + j) * (NT / Q);
-                pofs[sl][j] = hp < MAXHP ? pix[hp] : -1;
+                pofs[sl][j] = (sl * A_SL + j < A_IT && hp < MAXHP) ? pix[hp] : -1;
             }
     } else {
 #pragma unroll
@@ -274,6 +274,8 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
         const int cc = second ? kc - a.K1 : kc;
 #pragma unroll
         for (int j = 0; j < A_SL; ++j) {
+            if (KS == 3 && sl * A_SL + j >= A_IT) continue;      // slots past the largest tile (NSL * A_SL rounds A_IT up): no thread has one -- no
+                                                                 // dummy load, no dump-row store, no registers (BM = 256: 5 of 18)
             const size_t e = (size_t)max(pofs[sl][j], 0) * ld + cc + a_c4 * 4;
             if constexpr (IN16) {     // 4 bf16 = 8 bytes, carried in .x/.y
                 const u32x2 u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(src) + e);
@@ -286,6 +288,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     auto store_a = [&](int buf, const f32x4 (&r)[A_SL], int sl) {
 #pragma unroll
         for (int j = 0; j < A_SL; ++j) {
+            if (KS == 3 && sl * A_SL + j >= A_IT) continue;
             const uint32_t keep = ~(uint32_t)(pofs[sl][j] >> 31);
             u32x2 v;
             if constexpr (FUSE) {
