@@ -26,11 +26,23 @@ PROBE = None      # bench.py sets this to a list: (kernel symbol, algorithmic FL
 # the 32x32 / 16x16 levels (128->128: 62.5 vs 53.7 us): with one 64x64 tile per wave both kernels move 1 KB of LDS per MFMA and the
 # DMA writes share the LDS port with the fragment reads.
 USE_CONV_DMA = os.environ.get("MI_CONV_DMA", "0") == "1"
-# ... and so is the LDS-frugal variant (csrc/conv_shift.hip: 128 x 64 wave tiles, left / right tap columns by DPP lane shifts, 0.4 KB
-# of LDS per MFMA): correct, and slower than the halo kernel on every cfg-2 shape (128->128 @32x32: 62.8 vs 52.6 us; 512->512 @8x8:
-# 50.1 vs 46.0 us).  Both experiments run ONE wave per SIMD; what they show is that the halo kernel's two waves per SIMD hide more
-# latency than the LDS-DMA staging or the halved LDS traffic buy back (the same lesson as round 1's 4-wave halo variant).
+# MI_CONV_SHIFT=1 forces the LDS-frugal variant (csrc/conv_shift.hip: left / right tap columns by DPP lane shifts, half the LDS operand
+# reads) wherever it applies.  Its first, 4-wave form lost to the halo kernel on every shape (128->128 @32x32: 62.8 vs 52.6 us); with 8
+# waves (two per SIMD, like the halo tiles) it is the faster kernel of the two -- see _pick3x3 below.
 USE_CONV_SHIFT = os.environ.get("MI_CONV_SHIFT", "0") == "1"
+# Which 3x3 kernel takes a bf16-stored layer when none is forced: the LDS-frugal conv_shift (centre-column fragments + DPP shifts: half
+# the LDS operand reads) for the layers with >= 128 channels on both sides, the register-staged halo kernel for the rest.  Per shape
+# (tools/bench_dma_conv.py, B = 128) conv_shift wins 4-7 % on the 32- and 16-pixel-wide levels (level 0: 50.1 vs 54.0 us) and ties on
+# 8x8; in the training step (one box, two runs each): halo only 5.723 ms, conv_shift everywhere 5.657 ms (+1.2 %), conv_shift on
+# the wide levels + the LDS-DMA kernel on 8x8 (where IT wins per shape, 40.6 vs 42.3 us) 5.69 ms -- so no LDS-DMA pick.
+# MI_CONV_AUTO=0: always the halo kernel.
+CONV_AUTO = os.environ.get("MI_CONV_AUTO", "1") == "1"
+
+
+def _pick3x3(W, K, Nc):
+    return "shift" if (CONV_AUTO and K >= 128 and Nc >= 128) else "halo"
+
+
 USE_WGRAD_TR = os.environ.get("MI_W3_TR", "1") != "0"      # A/B switch for the LDS-DMA weight-gradient kernel (csrc/wgrad_tr.hip)
 
 
@@ -200,7 +212,10 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
     d.ldy = ld_of(out)
     io = _b16(x) | (_b16(out) << 1)
     assert x2 is None or x2.dtype == x.dtype
-    if gn_sums is None and USE_CONV_SHIFT and ksize == 3 and _b16(x) and lib.mi_conv3x3_shift_supported(C.byref(d)):
+    pick = "halo"
+    if gn_sums is None and not want16 and ksize == 3 and _b16(x):
+        pick = "shift" if USE_CONV_SHIFT else "dma" if USE_CONV_DMA else _pick3x3(W, K, Nc)
+    if pick == "shift" and _query("mi_conv3x3_shift_supported", d):
         # bf16-stored activations: the LDS-frugal kernel (conv_shift.hip)
         e0 = _probe_open()
         check(lib.mi_conv3x3_shift(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv3x3_shift")
@@ -211,7 +226,7 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
             _probe_close(e0, f"conv_shift_kernel<{ni.value}, {'true' if _b16(out) else 'false'}>", 2.0 * N * H * W * Nc * K * 9,
                          f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
         return out
-    if gn_sums is None and USE_CONV_DMA and ksize == 3 and _b16(x) and lib.mi_conv3x3_dma_supported(C.byref(d)):
+    if pick == "dma" and _query("mi_conv3x3_dma_supported", d):
         # bf16-stored activations: the LDS-DMA kernel (conv_dma.hip)
         e0 = _probe_open()
         check(lib.mi_conv3x3_dma(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv3x3_dma")

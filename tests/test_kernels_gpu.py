@@ -222,7 +222,11 @@ def test_conv_epilogue_groupnorm_sums(K, cfg, storage):
     bias = torch.randn(Co, generator=g).to(DEV)
     gamma, beta = (torch.rand(Co, generator=g) + 0.5).to(DEV), torch.randn(Co, generator=g).to(DEV)
     temb = torch.randn(N, Co, generator=g).to(DEV)
-    y0 = K.conv3x3_bf16w(x, wsh, K=Ci, Nc=Co, flip=False, bias=bias, out_dtype=dt)
+    auto, K.CONV_AUTO = K.CONV_AUTO, False          # the same (halo) kernel with and without the sums: bitwise comparison below
+    try:
+        y0 = K.conv3x3_bf16w(x, wsh, K=Ci, Nc=Co, flip=False, bias=bias, out_dtype=dt)
+    finally:
+        K.CONV_AUTO = auto
     sums = torch.zeros(N * (Co // 16) * 2, device=DEV)
     y1 = K.conv3x3_bf16w(x, wsh, K=Ci, Nc=Co, flip=False, bias=bias, out_dtype=dt, gn_sums=sums)
     assert torch.equal(y0, y1)
@@ -249,7 +253,11 @@ def test_conv_dual_output(K, cfg):
     wsh = (torch.randn(ks * ks * Co * Ci, generator=g) / math.sqrt(ks * ks * Ci)).to(DEV).bfloat16()
     bias = torch.randn(Co, generator=g).to(DEV)
     res = torch.randn(N, H, W, Co, generator=g).to(DEV)
-    y0 = K.conv3x3_bf16w(x, wsh, K=Ci, Nc=Co, flip=False, ksize=ks, bias=bias, residual=res)
+    auto, K.CONV_AUTO = K.CONV_AUTO, False          # the dual-output entry point belongs to the halo kernel: compare with that kernel
+    try:
+        y0 = K.conv3x3_bf16w(x, wsh, K=Ci, Nc=Co, flip=False, ksize=ks, bias=bias, residual=res)
+    finally:
+        K.CONV_AUTO = auto
     y1, y16 = K.conv3x3_bf16w(x, wsh, K=Ci, Nc=Co, flip=False, ksize=ks, bias=bias, residual=res, want16=True)
     torch.cuda.synchronize()
     assert y16.dtype == torch.bfloat16 and y16.shape == y0.shape
@@ -1165,12 +1173,27 @@ def test_small_gemm_linear(K, M, N, Kc):
 def test_conv3x3_three_slot_variant_in_a_subprocess():
     """MI_HALO_PIPE=1 (read once per process): the 3x3 conv kernels with three weight slots, the next tap's first MFMA operands fetched
     before the barrier and the LDS stores at the top of the tap pass the same forward / data-gradient / dual-output / epilogue-sum
-    parity tests as the default two-slot kernels."""
+    parity tests as the default two-slot kernels (MI_CONV_AUTO=0: every bf16 layer goes to the halo kernel, not to conv_shift)."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, MI_HALO_PIPE="1")
+    env = dict(os.environ, MI_HALO_PIPE="1", MI_CONV_AUTO="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
                         "test_conv3x3_halo_fwd_and_dgrad or test_conv_dual_output or test_conv_epilogue_groupnorm_sums or test_conv_forward"],
                        capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_halo_kernel_takes_every_bf16_layer_in_a_subprocess():
+    """MI_CONV_AUTO=0: the register-staged halo kernel (the fallback of the per-shape pick, and the only kernel behind the dual-output,
+    epilogue-sum and fused entry points) on the bf16-stored layers that conv_shift takes by default -- every conv kernel test and the
+    end-to-end bf16 block test."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MI_CONV_AUTO="0")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), os.path.join(here, "test_unet_gpu.py"), "-q", "-x",
+                        "-p", "no:cacheprovider", "-k", "(conv and not subprocess) or bf16_block or cfg2_eps or mid_unet"],
+                       capture_output=True, text=True, timeout=1200, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

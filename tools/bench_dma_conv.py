@@ -7,6 +7,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "image-generation-models_amd")]
 import torch
 from src.ops import functional as K
 B = int(os.environ.get("B", 128))
+K.CONV_AUTO = False            # "halo" below means the halo kernel, not the per-shape pick
 
 
 def timed(run, n=20):
