@@ -28,6 +28,7 @@ struct ShiftConvArgs {
     const uint16_t* x; const uint16_t* x2; const uint16_t* w; const float* bias; const float* res; void* y;
     int N, H, W, K, Nc, K1, ldx, ldx2, ldy, ldr, accumulate, flip;
     int TH, TI, XP, tiles_per_img, xmap;
+    int qmap, gx, gy;    // 1-D launch of gx pixel tiles x gy channel tiles: XCD = (pixel group, channel group) of a (8 / qmap) x qmap split
 };
 
 constexpr int SBM = 256, SCK = 64;
@@ -70,7 +71,17 @@ __global__ __launch_bounds__(128 * WM, 1) void conv_shift_kernel(const ShiftConv
         const int xcd = bx & 7, slot = bx >> 3;
         bx = (xcd + 8 * (slot / a.tiles_per_img)) * a.tiles_per_img + slot % a.tiles_per_img;
     }
-    const int m0 = bx * SBM, n0 = blockIdx.y * BN;
+    int by = blockIdx.y;
+    if (a.qmap) {
+        // Whole-image tiles (8x8 level): workgroup ids go round-robin over the 8 XCDs, each with its own L2.  With the channel tiles
+        // in grid.y every XCD meets all of them and pulls the whole weight tensor: 54.8 MB for the 512 -> 512 layer (PMC) against
+        // 21.5 MB algorithmic.  Here an XCD owns gx / P pixel tiles x gy / Q channel tiles: traffic Q * in + P * w + out, 44 MB at
+        // (P, Q) = (4, 2); the channel tiles of one pixel tile are adjacent in time (same mapping as conv3x3_halo.hip).
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3, Q = a.qmap, P = 8 / Q;
+        const int ppx = a.gx / P, cpq = a.gy / Q;
+        bx = (xcd / Q) * ppx + slot / cpq; by = (xcd % Q) * cpq + slot % cpq;
+    }
+    const int m0 = bx * SBM, n0 = by * BN;
     const int TH2 = a.TH + 2;
     const int Mtot = a.N * a.H * a.W;
     const int nchunks = a.K / SCK;
@@ -346,7 +357,10 @@ extern "C" int mi_conv3x3_shift(const MiConvDesc* d, const void* x, const void* 
     a.xmap = a.TI == 1 && a.tiles_per_img > 1 && a.N % 8 == 0;
     const int ni = shift_ni(d);
     const int BN = 64 * ni;
-    const dim3 grid((unsigned)((long)d->N * d->OH * d->OW / SBM), (unsigned)((d->Nc + BN - 1) / BN));
+    dim3 grid((unsigned)((long)d->N * d->OH * d->OW / SBM), (unsigned)((d->Nc + BN - 1) / BN));
+    a.qmap = 0; a.gx = (int)grid.x; a.gy = (int)grid.y;
+    static const int q_env = [] { const char* e = getenv("MI_SHIFT_PQ"); return e ? atoi(e) : 1; }();
+    if (q_env && !a.xmap && a.gy > 1 && a.gy % 2 == 0 && a.gx % 4 == 0) { a.qmap = 2; grid = dim3(grid.x * grid.y, 1, 1); }
     const size_t lds = (size_t)2 * SXBUF + (size_t)3 * BN * 128;
     static const int wm_env = [] { const char* e = getenv("MI_SHIFT_WM"); return e ? atoi(e) : 4; }();
     hipStream_t st = (hipStream_t)stream;

@@ -40,7 +40,13 @@ CONV_AUTO = os.environ.get("MI_CONV_AUTO", "1") == "1"
 
 
 def _pick3x3(W, K, Nc):
-    return "shift" if (CONV_AUTO and K >= 128 and Nc >= 128) else "halo"
+    if not CONV_AUTO or K < 128 or Nc < 128:
+        return "halo"
+    if W <= 8 and os.environ.get("MI_CONV_PICK8", "1") == "1":
+        # 8x8 level, per shape (shift vs halo): 512 -> 512 41.7 vs 42.3 us, 256 -> 512 a tie, but 1024 -> 256 64.4 vs 57.3 and
+        # 256 -> 256 21.8 vs 19.5: the narrow / very deep layers stay with the halo kernel
+        return "shift" if (256 <= K <= 512 and Nc >= 512) else "halo"
+    return "shift"
 
 
 USE_WGRAD_TR = os.environ.get("MI_W3_TR", "1") != "0"      # A/B switch for the LDS-DMA weight-gradient kernel (csrc/wgrad_tr.hip)
@@ -223,7 +229,8 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
             ni = C.c_int()
             lib.mi_conv3x3_shift_tile(C.byref(d), C.byref(ni))
             nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 2)
-            _probe_close(e0, f"conv_shift_kernel<{ni.value}, {'true' if _b16(out) else 'false'}>", 2.0 * N * H * W * Nc * K * 9,
+            wm = 2 if os.environ.get("MI_SHIFT_WM", "4") == "2" else 4
+            _probe_close(e0, f"conv_shift_kernel<{wm}, {ni.value}, {'true' if _b16(out) else 'false'}>", 2.0 * N * H * W * Nc * K * 9,
                          f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
         return out
     if pick == "dma" and _query("mi_conv3x3_dma_supported", d):

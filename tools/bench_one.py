@@ -55,7 +55,11 @@ for _ in range(5):
         if "W1" not in globals():
             W1 = (torch.randn(Co * Ci, device=DEV) * 0.05).bfloat16()
         K.conv3x3_bf16w(x, W1, K=Ci, Nc=Co, flip=False, ksize=1, out_dtype=DT)
-    elif which == "halo":
+    elif which == "halo":        # the register-staged halo kernel (not the per-shape pick)
+        K.CONV_AUTO = False
+        K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, out=y)
+    elif which == "shift":       # conv_shift, the default kernel of the bf16-stored >= 128-channel layers
+        K.USE_CONV_SHIFT = True
         K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, out=y)
     elif which == "igemm":
         K.conv_igemm(x, w, kh=3, kw=3, stride=1, pad=1, transposed=False, w_kn=True, K=Ci, Nc=Co, out_hw=(H, H), mode=1, out=y)

@@ -12,6 +12,8 @@ CASES = {
     "halo_128_8_512_512_bf16": ("conv3x3_halo_kernel<128, 64, 3, false, 3, 8>", "[128,8,8,512]->512 bf16 storage", conv_bytes(128, 8, 512, 512, 2, 2)),
     "halo_128_32_128_128_bf16": ("conv3x3_halo_kernel<256, 64, 3, false, 3, 8>", "[128,32,32,128]->128 bf16 storage", conv_bytes(128, 32, 128, 128, 2, 2)),
     "halo_128_32_128_128_fp32": ("conv3x3_halo_kernel<256, 64, 3, false, 0, 8>", "[128,32,32,128]->128 fp32 storage", conv_bytes(128, 32, 128, 128, 4, 4)),
+    "shift_128_8_512_512_bf16": ("conv_shift_kernel<4, 1, true>", "[128,8,8,512]->512 bf16 storage", conv_bytes(128, 8, 512, 512, 2, 2)),
+    "shift_128_32_128_128_bf16": ("conv_shift_kernel<4, 2, true>", "[128,32,32,128]->128 bf16 storage", conv_bytes(128, 32, 128, 128, 2, 2)),
     "wgrad_128_32_128_128_bf16": ("wgrad_tr_kernel[single]", "[128,32,32,128]x[128,32,32,128] bf16 operands, one layer per launch",
                                   2 * 128 * 32 * 32 * 128 * 2 + 9 * 128 * 128 * 4),
     "wgrad_128_8_512_512_bf16": ("wgrad_tr_kernel[single 8x8]", "[128,8,8,512]x[128,8,8,512] bf16 operands, one layer per launch",
@@ -24,7 +26,7 @@ CASES = {
     "fused_128_32_128_128_fp32": ("conv3x3_halo_kernel<256, 64, 3, false, 0, 8, true>", "fused GN+Mish+conv [128,32,32,128]->128 fp32 storage",
                                   conv_bytes(128, 32, 128, 128, 4, 4) + 3 * 128 * 128 * 4),
 }
-MAIN = {"halo": "conv3x3_halo_kernel", "fused": "conv3x3_halo_kernel", "wgrad": "wgrad_tr_kernel(", "wgradq": "wgrad_tr_kernel("}
+MAIN = {"shift": "conv_shift_kernel", "halo": "conv3x3_halo_kernel", "fused": "conv3x3_halo_kernel", "wgrad": "wgrad_tr_kernel(", "wgradq": "wgrad_tr_kernel("}
 
 # HBM-bound kernels (tools/bench_one.py gn / ln / attn / c1x1 at level 0, B = 128, bf16 storage): every kernel of the pass gets a row
 E0 = 128 * 32 * 32 * 128

@@ -13,6 +13,7 @@ for x in rows:
     avg[n] = float(x["AverageNs"]) / 1e3
     m = re.search(r"conv3x3_halo_kernel<(\d+), (\d+), (\d)", n)
     if m: add("halo" + m.group(3), ms)
+    elif "conv_shift_kernel" in n or "conv_dma_kernel" in n: add("halo3", ms)
     elif "wgrad_tr_reduce" in n: add("wtr_red", ms)
     elif "wgrad_tr_kernel" in n: add("wtr", ms)
     elif "wgrad1x1_tr_reduce" in n: add("w1_red", ms)
@@ -61,18 +62,28 @@ def prof_avg(sym):
     for n, v in avg.items():
         if key in n and (not targs or targs[1:] in n): return v
     return float("nan")
-wt, hk = "wgrad_tr_kernel", "conv3x3_halo_kernel<128, 64, 3, false, 3, 8>"
+traf = json.load(open(f"{root}/profiles/{tag}_pmc_traffic.json"))
+top = sorted(ak.items(), key=lambda kv: -kv[1]["ms_per_step"])[:3]
+def trow(sym, e):
+    t = traf.get(sym)
+    tr = (f"; canonical shape under the counters ({t['shape']}): {t['hbm_bytes_per_launch'] / 1e6:.1f} MB of HBM traffic vs "
+          f"{t['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic = {t['ratio']}x") if t else ""
+    return (f"* `{sym}`: {e['launches_per_step']} launches/step, {e['ms_per_step']} ms, {e['tflops']} TFLOP/s by events "
+            f"({prof_avg(sym):.1f} us AverageNs in the rocprof summary){tr}")
 i = s.index("## Dominant kernel (`roofline` in"); j = s.index("## The named kernel")
+tline = f"HBM traffic {r['traffic'] / 1e6:.1f} MB per launch of its canonical shape (PMC, `{tag}_pmc_traffic.json`)." if r.get("traffic") else "No PMC pass for this symbol."
 s = s[:i] + f"""## Dominant kernel (`roofline` in `{tag}_bench.json`)
 
 `{r['kernel']}`: {r['launches_per_step']} launches/step, {r['avg_launch_us']} us/launch by HIP events ({prof_avg(r['kernel']):.1f} us AverageNs in
 `{tag}_train_step_kernel_stats.csv`), {r['avg_gflop_per_launch']} GFLOP/launch => {r['achieved']} TFLOP/s = {100 * r['frac']:.1f} % of the dense bf16 MFMA peak;
-HBM traffic {r['traffic'] / 1e6:.1f} MB per launch of its canonical shape (PMC, `{tag}_pmc_traffic.json`).
-The two kernels that share the top of the table: `{hk}` (3x3 conv / data gradient at the 8x8 level, 18 launches/step,
-{ak[hk]['ms_per_step']} ms, {ak[hk]['tflops']} TFLOP/s by events; 47.2 us = 819 TFLOP/s on the canonical 512->512 layer under the counters, 44.3 MB vs
-21.5 MB algorithmic with the (4, 2) XCD grouping of pixel and channel tiles, 54.8 MB before it) and `{wt}` (eight Block-conv weight gradients per
-launch, LDS-DMA + transposing reads: {ak[wt]['launches_per_step']} launches/step, {ak[wt]['ms_per_step']} ms, {ak[wt]['tflops']} TFLOP/s by events; canonical 8-layer launch 1.26 PFLOP/s,
-`SQ_VALU_MFMA_BUSY_CYCLES` 60 %, `SQ_LDS_BANK_CONFLICT` 0, 554 MB vs 423 MB algorithmic = 1.31x).
+{tline}
+The top of the per-symbol table (`roofline.all_kernels`, HIP events around every launch of one instrumented step):
+""" + "\n".join(trow(k, e) for k, e in top) + """
+
+(`conv_shift_kernel<4, NI, out16>` = the 3x3 conv / data gradient of the bf16-stored layers, 8 waves, 256 pixels x 64*NI channels per workgroup;
+`wgrad_tr_kernel` = eight Block-conv weight gradients per launch, LDS-DMA + transposing reads: canonical 8-layer launch 1.26 PFLOP/s,
+`SQ_VALU_MFMA_BUSY_CYCLES` 60 %, `SQ_LDS_BANK_CONFLICT` 0; the register-staged `conv3x3_halo_kernel` now runs the 1x1 convs, the < 128-channel
+layers and the dual-output / fused entry points.)
 
 """ + s[j:]
 f = nk["fp32_storage"]; b = nk["bf16_storage"]
