@@ -286,7 +286,29 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? MI_GN_WA
 #pragma unroll
         for (int k = 0; k < MAXU; ++k) { int p = pr + k * PP; if (p < a.HW) pass1(p, cx[k], cd[k]); }
     } else {
-        for (int p = pr; p < a.HW; p += PP) { V<VEC> xh, dz; pass1(p, xh, dz); }
+        // slices too large for the register cache (64x64 images): four rows' loads are issued before the first use -- one guarded
+        // load per iteration is one serialized HBM round trip per row (rows past the slice re-read its last row and are masked)
+        constexpr int UB = 4;
+        for (int p0 = pr; p0 < a.HW; p0 += UB * PP) {
+            V<VEC> q[UB], d[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const size_t p = (size_t)min(p0 + u * PP, a.HW - 1);
+                q[u] = vload<VEC, X16>(a.x, xoff + p * a.ldx);
+                d[u] = vload<VEC, DO16>(a.dout, dooff + p * a.lddo);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const float live = p0 + u * PP < a.HW ? 1.f : 0.f;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float h = (q[u].v[j] - mean) * rstd * live, dd = d[u].v[j] * live;
+                    const float z = h * ga[j] + be[j];
+                    const float dzz = dd * (X16 ? mish_grad_fast_f(z) : mish_grad_f(z));
+                    sA[j] += dzz; sD[j] += dzz * h; sT[j] += dd; sB[j] += h;
+                }
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -354,16 +376,27 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? MI_GN_WA
 #pragma unroll
         for (int k = 0; k < MAXU; ++k) { int p = pr + k * PP; if (p < a.HW) pass2(p, cx[k], cd[k]); }
     } else {
-        for (int p = pr; p < a.HW; p += PP) {
-            V<VEC> q = vload<VEC, X16>(a.x, xoff + (size_t)p * a.ldx);
-            V<VEC> d = vload<VEC, DO16>(a.dout, dooff + (size_t)p * a.lddo);
-            V<VEC> xh, dz;
+        constexpr int UB = 4;
+        for (int p0 = pr; p0 < a.HW; p0 += UB * PP) {
+            V<VEC> q[UB], d[UB];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                xh.v[j] = (q.v[j] - mean) * rstd;
-                dz.v[j] = d.v[j] * (X16 ? mish_grad_fast_f(xh.v[j] * ga[j] + be[j]) : mish_grad_f(xh.v[j] * ga[j] + be[j]));
+            for (int u = 0; u < UB; ++u) {
+                const size_t p = (size_t)min(p0 + u * PP, a.HW - 1);
+                q[u] = vload<VEC, X16>(a.x, xoff + p * a.ldx);
+                d[u] = vload<VEC, DO16>(a.dout, dooff + p * a.lddo);
             }
-            pass2(p, xh, dz);
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int p = p0 + u * PP;
+                if (p >= a.HW) continue;
+                V<VEC> xh, dz;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    xh.v[j] = (q[u].v[j] - mean) * rstd;
+                    dz.v[j] = d[u].v[j] * (X16 ? mish_grad_fast_f(xh.v[j] * ga[j] + be[j]) : mish_grad_f(xh.v[j] * ga[j] + be[j]));
+                }
+                pass2(p, xh, dz);
+            }
         }
     }
 }
