@@ -8,6 +8,9 @@
 #include <stdlib.h>
 #include "common.h"
 
+#ifndef MI_GN_UB0
+#define MI_GN_UB0 4      // rows per load batch of the uncached GroupNorm backward loops
+#endif
 #ifndef MI_GN_WAVES
 #define MI_GN_WAVES 4     // waves per SIMD the packed-cache GroupNorm backward is compiled for
 #endif
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? MI_GN_WA
     } else {
         // slices too large for the register cache (64x64 images): four rows' loads are issued before the first use -- one guarded
         // load per iteration is one serialized HBM round trip per row (rows past the slice re-read its last row and are masked)
-        constexpr int UB = 4;
+        constexpr int UB = MI_GN_UB0;
         for (int p0 = pr; p0 < a.HW; p0 += UB * PP) {
             V<VEC> q[UB], d[UB];
 #pragma unroll
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? MI_GN_WA
 #pragma unroll
         for (int k = 0; k < MAXU; ++k) { int p = pr + k * PP; if (p < a.HW) pass2(p, cx[k], cd[k]); }
     } else {
-        constexpr int UB = 4;
+        constexpr int UB = MI_GN_UB0;
         for (int p0 = pr; p0 < a.HW; p0 += UB * PP) {
             V<VEC> q[UB], d[UB];
 #pragma unroll
