@@ -753,14 +753,18 @@ void launch_halo(const HaloArgs& a_in, hipStream_t st) {
     hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE, PIPE>), grid, dim3(HaloCfg<BM, WAVES>::NT), lds, st, a);
 }
 
-// fp32 [tap][k][n] master weights -> bf16 Wd[tap][k][n] (same layout) and Wf[tap][n][k] (transposed per tap)
-struct PackEntry { long long off; int taps, ci, co, tile0; };
+// fp32 [tap][k][n] master weights -> bf16 Wd[tap][k][n] (same layout) and Wf[tap][n][k] (transposed per tap); entries with frag != 0
+// (3x3 layers, ci % 64 == 0 and co % 64 == 0) also get both copies in MFMA-fragment order for conv_pw.hip:
+//   Wfq[tap][co / 32][ci / 16][lane][8] = W[tap][ci = 16 kq + 8 (lane >> 5) + e][co = 32 nb + (lane & 31)]   (forward operand)
+//   Wdq[tap][ci / 32][co / 16][lane][8] = W[tap][ci = 32 nb + (lane & 31)][co = 16 kq + 8 (lane >> 5) + e]   (data-gradient operand)
+struct PackEntry { long long off; int taps, ci, co, tile0, frag, pad_; };
 
 constexpr int PACK_TILE = 64;       // mi_pack_weights_tile(): entries count their tiles as taps * ceil(ci / 64) * ceil(co / 64)
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __restrict__ ents, int nent,
                                                            const float* __restrict__ master, uint16_t* __restrict__ wd,
-                                                           uint16_t* __restrict__ wf) {
+                                                           uint16_t* __restrict__ wf, uint16_t* __restrict__ wdq,
+                                                           uint16_t* __restrict__ wfq) {
     __shared__ float tile[PACK_TILE][PACK_TILE + 1];
     int e = 0;                      // last entry whose first tile is <= blockIdx.x: binary search (a linear walk is ~60 dependent
     for (int hi = nent; hi - e > 1;) {      // scalar loads per workgroup and was most of this kernel's time)
@@ -796,6 +800,29 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackEntry* __re
             if (i < en.ci && j < en.co)
                 *reinterpret_cast<u32x2*>(d2 + (size_t)j * en.ci + i) =
                     u32x2{pack_bf16(tile[c4][r], tile[c4 + 1][r]), pack_bf16(tile[c4 + 2][r], tile[c4 + 3][r])};
+        }
+        if (en.frag && wdq) {
+            // the tile = 2 x 4 fragments of each order; thread = (fragments f and f + 4, lane l): 8 values out of LDS and one 16-byte
+            // store per fragment, 1 KB per wave and store
+            const int l = threadIdx.x & 63;
+            const size_t tapo = (size_t)en.off + (size_t)tap * en.ci * en.co;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int f = (threadIdx.x >> 6) + 4 * h;
+                const int r32 = (f >> 2) * 32 + (l & 31), c8 = (f & 3) * 16 + 8 * (l >> 5);
+                {   // data-gradient operand: rows = ci (n), columns = co (k)
+                    const size_t fo = ((size_t)(bi * 2 + (f >> 2)) * (en.co / 16) + bj * 4 + (f & 3)) * 512 + l * 8;
+                    *reinterpret_cast<u32x4*>(wdq + tapo + fo) =
+                        u32x4{pack_bf16(tile[r32][c8], tile[r32][c8 + 1]), pack_bf16(tile[r32][c8 + 2], tile[r32][c8 + 3]),
+                              pack_bf16(tile[r32][c8 + 4], tile[r32][c8 + 5]), pack_bf16(tile[r32][c8 + 6], tile[r32][c8 + 7])};
+                }
+                {   // forward operand: rows = co (n), columns = ci (k)
+                    const size_t fo = ((size_t)(bj * 2 + (f >> 2)) * (en.ci / 16) + bi * 4 + (f & 3)) * 512 + l * 8;
+                    *reinterpret_cast<u32x4*>(wfq + tapo + fo) =
+                        u32x4{pack_bf16(tile[c8][r32], tile[c8 + 1][r32]), pack_bf16(tile[c8 + 2][r32], tile[c8 + 3][r32]),
+                              pack_bf16(tile[c8 + 4][r32], tile[c8 + 5][r32]), pack_bf16(tile[c8 + 6][r32], tile[c8 + 7][r32])};
+                }
+            }
         }
         return;
     }
@@ -1158,10 +1185,13 @@ extern "C" int mi_conv3x3_bf16w_supported(const MiConvDesc* d) {
 extern "C" int mi_pack_weights_tile(void) { return PACK_TILE; }
 
 extern "C" int mi_pack_weights_bf16(int nent, const void* entries_dev, int total_tiles, const float* master,
-                                    void* wd_bf16, void* wf_bf16, void* stream) {
+                                    void* wd_bf16, void* wf_bf16, void* wdq_bf16, void* wfq_bf16, void* stream) {
     MI_REQUIRE(nent > 0 && entries_dev && total_tiles > 0 && master && wd_bf16 && wf_bf16, "bad argument");
+    MI_REQUIRE((wdq_bf16 == nullptr) == (wfq_bf16 == nullptr), "fragment-order copies: both or neither");
+    MI_REQUIRE((((uintptr_t)wdq_bf16 | (uintptr_t)wfq_bf16) & 15) == 0, "fragment-order copies must be 16-byte aligned");
     hipLaunchKernelGGL(pack_weights_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
-                       (const PackEntry*)entries_dev, nent, master, (uint16_t*)wd_bf16, (uint16_t*)wf_bf16);
+                       (const PackEntry*)entries_dev, nent, master, (uint16_t*)wd_bf16, (uint16_t*)wf_bf16,
+                       (uint16_t*)wdq_bf16, (uint16_t*)wfq_bf16);
     MI_LAUNCH_CHECK();
     return 0;
 }

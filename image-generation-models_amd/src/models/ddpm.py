@@ -329,26 +329,24 @@ class Unet(nn.Module):
     def _shadows(self):
         """bf16 copies of every conv weight for the bf16-MFMA kernels: wd = master layout
         [tap][Cin][Cout] (dgrad operand), wf = [tap][Cout][Cin] (forward operand).  Rebuilt by one
-        kernel launch whenever the fp32 master buffer changed."""
+        kernel launch whenever the fp32 master buffer changed.  wdq / wfq: the same two operands of the 3x3 layers in
+        MFMA-fragment order (mi_conv3x3_pw streams them 1 KB per instruction)."""
         flat = self._flat
         key = (flat.data_ptr(), flat._version, self._dirty)
         if self._shadow_key != key:
             if self._shadow is None or self._shadow[0].device != flat.device:
-                ents = [e for e in self._arch.entries if e.layout in ("conv", "convT")]
-                rec = np.zeros(len(ents), dtype=np.dtype([("off", "<i8"), ("taps", "<i4"), ("ci", "<i4"), ("co", "<i4"), ("tile0", "<i4")]))
-                tile, T = 0, K.pack_weights_tile()
-                for i, e in enumerate(ents):
-                    kh, kw, ci, co = e.storage_view(flat).shape
-                    rec[i] = (e.offset, kh * kw, ci, co, tile)
-                    tile += kh * kw * ((ci + T - 1) // T) * ((co + T - 1) // T)
-                table = torch.from_numpy(rec.view(np.uint8).copy()).to(flat.device)
-                wd = torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16)
-                wf = torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16)
-                object.__setattr__(self, "_shadow", (wd, wf, table, len(ents), tile))
-            wd, wf, table, nent, tiles = self._shadow
-            K.pack_weights_bf16(table, nent, tiles, flat, wd, wf)
+                ents = []
+                for e in self._arch.entries:
+                    if e.layout in ("conv", "convT"):
+                        kh, kw, ci, co = e.storage_view(flat).shape
+                        ents.append((e.offset, kh * kw, ci, co))
+                table, nent, tiles = K.pack_table(ents, flat.device)
+                bufs = [torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16) for _ in range(4)]
+                object.__setattr__(self, "_shadow", (*bufs, table, nent, tiles))
+            wd, wf, wdq, wfq, table, nent, tiles = self._shadow
+            K.pack_weights_bf16(table, nent, tiles, flat, wd, wf, wdq, wfq)
             object.__setattr__(self, "_shadow_key", key)
-        return self._shadow[0], self._shadow[1]
+        return self._shadow[:4]
 
     @property
     def flat_grads(self) -> torch.Tensor:
@@ -447,7 +445,7 @@ class Unet(nn.Module):
                 tape.append(("time", te, t1, a1, temb, mt))
 
         if mode == K.MODE_BF16:
-            wd_sh, wf_sh = self._shadows()
+            wd_sh, wf_sh, wdq_sh, wfq_sh = self._shadows()
         offs = self._offs
 
         BF = torch.bfloat16
@@ -490,7 +488,7 @@ class Unet(nn.Module):
             if mode == K.MODE_BF16 and k in (1, 3) and stride == 1 and not transposed_conv:
                 y = K.conv3x3_bf16w(inp, wf_sh[offs[pre + "weight"]:], K=ci, Nc=co, flip=False, ksize=k, x2=x2,
                                     bias=sv[pre + "bias"] if bias else None, residual=residual, out_dtype=out_dtype, gn_sums=gn_sums,
-                                    want16=want16)
+                                    want16=want16, wq=wfq_sh[offs[pre + "weight"]:] if k == 3 else None)
                 if y is not None:
                     if want16:                      # the epilogue wrote the bf16 copy along: register it for the consumers
                         sh[id(y[0])] = y
@@ -644,7 +642,7 @@ class Unet(nn.Module):
         gv = self._gv
         offs = self._offs
         if mode == K.MODE_BF16:
-            wd_sh, wf_sh = self._shadows()
+            wd_sh, wf_sh, wdq_sh, wfq_sh = self._shadows()
         G = _GradMap()
         # data parallel (a grad-ready hook is set): the two Upsample layers come early in backward, the two Downsample layers last; with
         # all four in one launch at the very end their 8 MB of gradients would be all-reduced after backward, exposed -- two per launch
@@ -722,7 +720,7 @@ class Unet(nn.Module):
             if x2 is None:
                 buf, acc = G.target(inp)
                 if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, ksize=k, out=buf,
-                                            accumulate=acc) is not None:
+                                            accumulate=acc, wq=wdq_sh[offs[pre + "weight"]:] if k == 3 else None) is not None:
                     return
                 assert dy.dtype == torch.float32 and buf.dtype == torch.float32, "bf16 block storage needs the tile kernel"
                 if dy16 is not None and K.igemm_bf16_in_supported(co, ci, k, stride, not transposed_conv, mode, (ih, iw)):
@@ -738,7 +736,7 @@ class Unet(nn.Module):
                     cat = torch.empty((B, ih, iw, ci), device=dy.device, dtype=torch.float32)
                     G._g[("cat", id(inp))] = cat
                 if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, ksize=k, out=cat,
-                                            accumulate=acc) is not None:
+                                            accumulate=acc, wq=wdq_sh[offs[pre + "weight"]:] if k == 3 else None) is not None:
                     return
                 K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=True, w_kn=False,
                              K=co, Nc=ci, out_hw=(ih, iw), mode=mode, out=cat, accumulate=acc)

@@ -196,16 +196,14 @@ class FlatNet(nn.Module):
         if getattr(self, "_shadow_key", None) != key:
             sh = getattr(self, "_shadow", None)
             if sh is None or sh[0].device != flat.device:
-                ents = [e for e in self._entries if e.layout in ("conv", "convT")]
-                rec = np.zeros(len(ents), dtype=np.dtype([("off", "<i8"), ("taps", "<i4"), ("ci", "<i4"), ("co", "<i4"), ("tile0", "<i4")]))
-                tile, T = 0, K.pack_weights_tile()
-                for i, e in enumerate(ents):
-                    kh, kw, ci, co = e.storage_view(flat).shape
-                    rec[i] = (e.offset, kh * kw, ci, co, tile)
-                    tile += kh * kw * ((ci + T - 1) // T) * ((co + T - 1) // T)
-                table = torch.from_numpy(rec.view(np.uint8).copy()).to(flat.device)
+                ents = []
+                for e in self._entries:
+                    if e.layout in ("conv", "convT"):
+                        kh, kw, ci, co = e.storage_view(flat).shape
+                        ents.append((e.offset, kh * kw, ci, co))
+                table, nent, tile = K.pack_table(ents, flat.device)
                 sh = (torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16),
-                      torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16), table, len(ents), tile)
+                      torch.zeros(flat.numel(), device=flat.device, dtype=torch.bfloat16), table, nent, tile)
                 object.__setattr__(self, "_shadow", sh)
             wd, wf, table, nent, tiles = sh
             K.pack_weights_bf16(table, nent, tiles, flat, wd, wf)

@@ -49,6 +49,20 @@ def _pick3x3(W, K, Nc):
     return "shift"
 
 
+# The private-weight-stream kernel (csrc/conv_pw.hip): 128-pixel tiles, one barrier per 64-channel chunk, two workgroups per CU.
+USE_CONV_PW = os.environ.get("MI_CONV_PW", "1") == "1"
+
+
+def _pick_pw(N, H, W, K, Nc):
+    """128-pixel x 128-channel tiles, two workgroups per CU: taken when the layer has at least about one tile per CU (fewer: round 2's
+    kernels with their 64-channel / 64-pixel tiles fill the chip better -- 8x8 level at B = 128, 256 -> 256: 20.1 vs 19.4 us,
+    1024 -> 256: 61.9 vs 58.5 us, tools/bench_pw.py)."""
+    return (N * H * W // 128) * ((Nc + 127) // 128) >= PW_MIN_TILES
+
+
+PW_MIN_TILES = int(os.environ.get("MI_CONV_PW_MIN_TILES", "200"))
+
+
 USE_WGRAD_TR = os.environ.get("MI_W3_TR", "1") != "0"      # A/B switch for the LDS-DMA weight-gradient kernel (csrc/wgrad_tr.hip)
 
 
@@ -198,10 +212,12 @@ def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mo
 
 
 def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=None, out=None, accumulate=False,
-                  out_dtype=torch.float32, gn_sums=None, want16=False):
+                  out_dtype=torch.float32, gn_sums=None, want16=False, wq=None):
     """3x3/s1/p1 (or 1x1) conv (flip=False) or its data gradient (flip=True) through the pipelined
     LDS-tile kernel.  wsh: bf16 weights [k][k][Nc][K].  Returns None when the shape is not supported.
-    want16: -> (y, y16), the fp32 output and its bf16 copy written by the same epilogue."""
+    want16: -> (y, y16), the fp32 output and its bf16 copy written by the same epilogue.
+    wq: the same weights in MFMA-fragment order (pack_weights_bf16's wfq / wdq slice) -- lets the private-weight-stream kernel
+    (mi_conv3x3_pw) take the layer."""
     _need_gpu(x)
     N, H, W, K1 = x.shape
     if x2 is None:
@@ -221,6 +237,16 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
     pick = "halo"
     if gn_sums is None and not want16 and ksize == 3 and _b16(x):
         pick = "shift" if USE_CONV_SHIFT else "dma" if USE_CONV_DMA else _pick3x3(W, K, Nc)
+        if USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc) and _query("mi_conv3x3_pw_supported", d):
+            pick = "pw"
+    if pick == "pw":
+        e0 = _probe_open()
+        check(lib.mi_conv3x3_pw(C.byref(d), _p(x), _p(x2), _p(wq), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv3x3_pw")
+        if e0 is not None:
+            nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 2)
+            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(out) else 'false'}>", 2.0 * N * H * W * Nc * K * 9,
+                         f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
+        return out
     if pick == "shift" and _query("mi_conv3x3_shift_supported", d):
         # bf16-stored activations: the LDS-frugal kernel (conv_shift.hip)
         e0 = _probe_open()
@@ -344,15 +370,30 @@ def pack_weights_tile():
     return int(load_library().mi_pack_weights_tile())
 
 
-def pack_weights_bf16(table_dev, nent, total_tiles, master, wd, wf):
+PACK_ENTRY = [("off", "<i8"), ("taps", "<i4"), ("ci", "<i4"), ("co", "<i4"), ("tile0", "<i4"), ("frag", "<i4"), ("pad", "<i4")]
+
+
+def pack_table(entries, device):
+    """Device table for mi_pack_weights_bf16 from (float offset, taps, ci, co) per conv weight -> (table, nent, total tiles).
+    3x3 layers with ci % 64 == 0 and co % 64 == 0 are flagged for the MFMA-fragment-order copies (mi_conv3x3_pw's operands)."""
+    import numpy as np
+    rec = np.zeros(len(entries), dtype=np.dtype(PACK_ENTRY))
+    tile, T = 0, pack_weights_tile()
+    for i, (off, taps, ci, co) in enumerate(entries):
+        rec[i] = (off, taps, ci, co, tile, int(taps == 9 and ci % 64 == 0 and co % 64 == 0), 0)
+        tile += taps * ((ci + T - 1) // T) * ((co + T - 1) // T)
+    return torch.from_numpy(rec.view(np.uint8).copy()).to(device), len(entries), tile
+
+
+def pack_weights_bf16(table_dev, nent, total_tiles, master, wd, wf, wdq=None, wfq=None):
+    """wdq / wfq: the fragment-order copies (same offsets as the master buffer) of the entries the table flags."""
     e0 = _probe_open()
-    check(load_library().mi_pack_weights_bf16(nent, _p(table_dev), total_tiles, _p(master), _p(wd), _p(wf), _stream()),
+    check(load_library().mi_pack_weights_bf16(nent, _p(table_dev), total_tiles, _p(master), _p(wd), _p(wf), _p(wdq), _p(wfq), _stream()),
           "mi_pack_weights_bf16")
     if e0 is not None:
-        _probe_close(e0, "pack_weights_kernel", 0.0, f"{master.numel()} params", master.numel() * 8.0)
+        _probe_close(e0, "pack_weights_kernel", 0.0, f"{master.numel()} params", master.numel() * (8.0 if wdq is None else 12.0))
 
 
-@functools.lru_cache(maxsize=None)      # pure function of the shape: one FFI query per distinct layer, not per step
 def small_cin_supported(ks, Cin, Cout, wgrad=False):
     """The 3-channel-input kernels (mi_conv_small_cin_*): which (kernel size, Cin, Cout) they take."""
     if ks not in (1, 3) or not 1 <= Cin <= 4:

@@ -74,7 +74,9 @@ SIGNATURES = {
     "mi_f32_to_bf16": [_Z, _I, _P, _I, _P, _I, _P],
     "mi_f32_to_bf16_colsum": [_Z, _I, _P, _I, _P, _I, _P, _P, _Z, _P],
     "mi_gn_mish_bwd_io": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P],
-    "mi_pack_weights_bf16": [_I, _P, _I, _P, _P, _P, _P],
+    "mi_pack_weights_bf16": [_I, _P, _I, _P, _P, _P, _P, _P, _P],
+    "mi_conv3x3_pw_supported": [C.POINTER(MiConvDesc)],
+    "mi_conv3x3_pw": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
     "mi_conv3x3_dma_supported": [C.POINTER(MiConvDesc)],
     "mi_conv3x3_shift_supported": [C.POINTER(MiConvDesc)],
     "mi_conv3x3_shift_tile": [C.POINTER(MiConvDesc), C.POINTER(C.c_int)],
@@ -157,7 +159,7 @@ OTHER = {"mi_abi_version": ([], C.c_int), "mi_last_error": ([], C.c_char_p),
          "mi_f32_to_bf16_colsum_workspace": ([_Z, _I], C.c_size_t),
          "mi_linattn_workspace": ([_I, _I, _I], C.c_size_t),
          "mi_conv_small_wgrad_workspace": ([_I], C.c_size_t)}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 def load_library():

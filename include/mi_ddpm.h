@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 1
+#define MI_ABI_VERSION 2   /* 2: mi_pack_weights_bf16 takes the fragment-order copies; mi_adam_step_dev betas are double */
 #define MI_MODE_FP32 0
 #define MI_MODE_BF16 1
 
@@ -154,8 +154,19 @@ int mi_conv3x3_shift(const MiConvDesc* d, const void* x, const void* x2, const v
  * index of the entry (prefix sum of taps*ceil(ci/T)*ceil(co/T), T = mi_pack_weights_tile()); total_tiles = grid size. */
 /* tile edge T the entries' tile0 fields are counted in: an entry owns taps * ceil(ci / T) * ceil(co / T) consecutive tiles */
 int mi_pack_weights_tile(void);
+/* entries_dev (ABI 2): {int64 off; int32 taps, ci, co, tile0, frag, pad}.  Entries with frag != 0 (ci % 64 == 0 and co % 64 == 0)
+ * are also written in MFMA-fragment order for mi_conv3x3_pw (wdq / wfq may both be NULL: no such copies):
+ *   wfq[tap][co/32][ci/16][lane][8] = W[tap][ci = 16 kq + 8 (lane >> 5) + e][co = 32 nb + (lane & 31)]   (forward operand)
+ *   wdq[tap][ci/32][co/16][lane][8] = W[tap][ci = 32 nb + (lane & 31)][co = 16 kq + 8 (lane >> 5) + e]   (data-gradient operand) */
 int mi_pack_weights_bf16(int nent, const void* entries_dev, int total_tiles, const float* master,
-                         void* wd_bf16, void* wf_bf16, void* stream);
+                         void* wd_bf16, void* wf_bf16, void* wdq_bf16, void* wfq_bf16, void* stream);
+/* ---- 3x3 conv / data gradient for bf16-stored activations with wave-private weight streams (conv_pw.hip; replaces the per-tap
+ * workgroup barrier of the kernels above: reference op src/models/ddpm.py:116).  w_frag_bf16 = the layer's slice of wfq (forward) or
+ * wdq (d->transposed = 1: data gradient, flipped taps).  Needs W in {8, 16, 32} with 128-pixel row tiles (N*H*W % 128 == 0),
+ * K % 64 == 0, K1 % 64 == 0, Nc % 32 == 0, ldy % 4 == 0. */
+int mi_conv3x3_pw_supported(const MiConvDesc* d);
+int mi_conv3x3_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,
+                  const float* residual, void* y, int out_bf16, void* stream);
 
 /* ---- the 3-channel ends of the UNet (fp32 VALU, bound by the wide tensor they stream) ------------
  * Conv2d(Cin<=4, Cout, ks, padding=ks/2), ks = 3 (downs.0.0.block1, ddpm.py:116,208) or 1 (its res_conv,

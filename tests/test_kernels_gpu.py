@@ -461,25 +461,27 @@ def test_diffusion_elementwise(K, golden_dir):
     assert torch.allclose(pg[:1003].cpu(), pr.detach(), atol=1e-6)
 
 
-def _pack(K, w_storage_list):
-    """fp32 tap-major weights -> (flat master, bf16 wd, bf16 wf, offsets) through mi_pack_weights_bf16."""
+def _pack(K, w_storage_list, frag=False):
+    """fp32 tap-major weights -> (flat master, bf16 wd, bf16 wf, offsets) through mi_pack_weights_bf16; frag: -> (..., wdq, wfq), the
+    MFMA-fragment-order copies as well."""
     offs, off = [], 0
     for w in w_storage_list:
         offs.append(off); off += (w.numel() + 63) // 64 * 64
     flat = torch.zeros(off, device=DEV)
-    rec = np.zeros(len(w_storage_list), dtype=np.dtype([("off", "<i8"), ("taps", "<i4"), ("ci", "<i4"), ("co", "<i4"), ("tile0", "<i4")]))
-    tile = 0
-    for i, (w, o) in enumerate(zip(w_storage_list, offs)):
+    ents = []
+    for w, o in zip(w_storage_list, offs):
         kh, kw, ci, co = w.shape
         flat[o:o + w.numel()] = w.reshape(-1)
-        rec[i] = (o, kh * kw, ci, co, tile)
-        T = K.pack_weights_tile()
-        tile += kh * kw * ((ci + T - 1) // T) * ((co + T - 1) // T)
-    table = torch.from_numpy(rec.view(np.uint8).copy()).to(DEV)
+        ents.append((o, kh * kw, ci, co))
+    table, nent, tile = K.pack_table(ents, DEV)
     wd = torch.zeros(off, device=DEV, dtype=torch.bfloat16)
     wf = torch.zeros(off, device=DEV, dtype=torch.bfloat16)
-    K.pack_weights_bf16(table, len(w_storage_list), tile, flat, wd, wf)
-    return flat, wd, wf, offs
+    if not frag:
+        K.pack_weights_bf16(table, nent, tile, flat, wd, wf)
+        return flat, wd, wf, offs
+    wdq, wfq = torch.zeros_like(wd), torch.zeros_like(wf)
+    K.pack_weights_bf16(table, nent, tile, flat, wd, wf, wdq, wfq)
+    return flat, wd, wf, offs, wdq, wfq
 
 
 def test_pack_weights_bf16(K):
@@ -547,6 +549,89 @@ def test_conv3x3_shift_fwd_and_dgrad(K, cfg, out16):
         y2 = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Co, flip=False, x2=xb, bias=b.to(DEV), residual=to_nhwc_gpu(r), out_dtype=odt)
     finally:
         K.USE_CONV_SHIFT = was
+    assert rel_err(yg.float(), y2.float()) < tol
+
+
+def test_pack_weights_fragment_order(K):
+    """The MFMA-fragment-order copies mi_conv3x3_pw streams (include/mi_ddpm.h): wfq[tap][co/32][ci/16][lane][8] and
+    wdq[tap][ci/32][co/16][lane][8]; layers that are not 3x3 with 64-multiples on both sides get none (their slice stays zero)."""
+    g = torch.Generator().manual_seed(29)
+    ws = [torch.randn(3, 3, 128, 64, generator=g).to(DEV), torch.randn(1, 1, 128, 384, generator=g).to(DEV),
+          torch.randn(3, 3, 192, 256, generator=g).to(DEV), torch.randn(3, 3, 40, 64, generator=g).to(DEV)]
+    flat, wd, wf, offs, wdq, wfq = _pack(K, ws, frag=True)
+    torch.cuda.synchronize()
+    for w, o in zip(ws, offs):
+        kh, kw, ci, co = w.shape
+        n = w.numel()
+        assert torch.equal(wd[o:o + n].view(w.shape), w.to(torch.bfloat16))            # the plain copies are unchanged
+        if kh * kw != 9 or ci % 64 or co % 64:
+            assert not wdq[o:o + n].any() and not wfq[o:o + n].any()
+            continue
+        wb = w.to(torch.bfloat16).view(9, ci, co)
+        # lane l, element e of fragment (nb, kq): row 32 nb + (l & 31), column 16 kq + 8 (l >> 5) + e
+        fq = wfq[o:o + n].view(9, co // 32, ci // 16, 2, 32, 8)          # [tap][nb][kq][l >> 5][l & 31][e]
+        ref_f = wb.permute(0, 2, 1).reshape(9, co // 32, 32, ci // 16, 2, 8).permute(0, 1, 3, 4, 2, 5)
+        assert torch.equal(fq, ref_f.contiguous())
+        dq = wdq[o:o + n].view(9, ci // 32, co // 16, 2, 32, 8)
+        ref_d = wb.reshape(9, ci // 32, 32, co // 16, 2, 8).permute(0, 1, 3, 4, 2, 5)
+        assert torch.equal(dq, ref_d.contiguous())
+
+
+@pytest.mark.parametrize("out16", [False, True])
+@pytest.mark.parametrize("cfg", [
+    dict(N=2, H=32, Ci=128, Co=128),             # level 0: 4 rows of 32 per tile, 2 chunks
+    dict(N=8, H=32, Ci=64, Co=256),              # XCD-grouped tile order, one chunk, 2 channel tiles
+    dict(N=4, H=16, Ci=256, Co=128, split=128),  # skip concat (two sources), 8 rows of 16
+    dict(N=16, H=8, Ci=512, Co=512),             # two 8x8 images per tile, 8 chunks, (pixel, channel) XCD groups
+    dict(N=2, H=16, Ci=64, Co=96),               # ragged channel tile: one idle wave
+    dict(N=4, H=8, Ci=1024, Co=64, split=512),   # long K, half-empty channel tile
+    dict(N=6, H=8, Ci=192, Co=320),              # odd chunk count, ragged channel tile
+])
+def test_conv3x3_pw_fwd_and_dgrad(K, cfg, out16):
+    """Block's 3x3 conv (ddpm.py:116) and its data gradient for bf16-stored activations through the private-weight-stream kernel
+    (mi_conv3x3_pw: fragment-order weights by LDS-DMA per wave, one barrier per 64-channel chunk): bias, residual, fp32 and bf16
+    output, accumulate; against fp64 on the same bf16-rounded operands and against the halo kernel."""
+    from src.ops.lib import MiConvDesc, load_library
+    import ctypes
+    N, H, Ci, Co = cfg["N"], cfg["H"], cfg["Ci"], cfg["Co"]
+    split = cfg.get("split")
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(N, Ci, H, H, generator=g).bfloat16()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9))
+    b = torch.randn(Co, generator=g)
+    r = torch.randn(N, Co, H, H, generator=g)
+    dy = torch.randn(N, Co, H, H, generator=g).bfloat16()
+    xq = x.double().requires_grad_(True)
+    wq = w.bfloat16().double()
+    yq = F.conv2d(xq, wq, b.double(), padding=1) + r.double()
+    yq.backward(dy.double())
+    # weights padded to 64-multiples on both sides (the fragment copies need them; the extra rows / columns are zero)
+    Cip, Cop = (Ci + 63) // 64 * 64, (Co + 63) // 64 * 64
+    wp = torch.zeros(Cop, Cip, 3, 3, dtype=torch.float64)
+    wp[:Co, :Ci] = w.double()
+    flat, wd, wf, offs, wdq, wfq = _pack(K, [conv_w_storage(wp)], frag=True)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+    xa, xb = (nh(x[:, :split]), nh(x[:, split:])) if split else (nh(x), None)
+    d = MiConvDesc(N=N, IH=H, IW=H, OH=H, OW=H, K=Ci, Nc=Cop, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=1, K1=split or Ci,
+                   ldx=xa.shape[3], ldx2=xb.shape[3] if xb is not None else 0, ldy=Cop, ldr=Cop, accumulate=0)
+    assert load_library().mi_conv3x3_pw_supported(ctypes.byref(d)) == 1
+    assert K.USE_CONV_PW
+    odt = torch.bfloat16 if out16 else torch.float32
+    tol = 6e-3 if out16 else 1e-5                                        # bf16 output: one more rounding
+    bp = torch.zeros(Cop); bp[:Co] = b
+    rp = torch.zeros(N, Cop, H, H); rp[:, :Co] = r
+    dyp = torch.zeros(N, Cop, H, H); dyp[:, :Co] = dy.float()
+    yg = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Cop, flip=False, x2=xb, bias=bp.to(DEV), residual=to_nhwc_gpu(rp), out_dtype=odt, wq=wfq)
+    assert yg is not None and yg.dtype == odt
+    dxg = K.conv3x3_bf16w(nh(dyp.bfloat16()), wd, K=Cop, Nc=Cip, flip=True, out_dtype=odt, wq=wdq)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(yg.float())[:, :Co], yq) < tol
+    assert not yg[..., Co:].any()
+    assert rel_err(from_nhwc(dxg.float())[:, :Ci], xq.grad) < tol
+    dx2 = K.conv3x3_bf16w(nh(dyp.bfloat16()), wd, K=Cop, Nc=Cip, flip=True, out=dxg.clone(), accumulate=True, wq=wdq)
+    assert rel_err(from_nhwc(dx2.float())[:, :Ci], 2 * xq.grad) < 2 * tol
+    # the halo / shift kernels on the same operands (no fragment-order weights passed: the default pick of round 2)
+    y2 = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Cop, flip=False, x2=xb, bias=bp.to(DEV), residual=to_nhwc_gpu(rp), out_dtype=odt)
     assert rel_err(yg.float(), y2.float()) < tol
 
 
