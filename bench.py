@@ -149,35 +149,61 @@ def dry_run_cpu(args, world, rank):
 
 def named_kernel_line(K, dev):
     """north_star's named unit at its canonical shape: GroupNorm-apply + Mish (+ time bias) + Conv3x3 on
-    X = [128,32,32,128] NHWC -> 128 channels, level 0 of cfg 2.  Timed standalone with HIP events on the launch stream, for both
-    activation storages of the bf16-MFMA mode; `unit_us` is the whole unit (every launch it takes: today the GN pass and the conv),
-    hbm_frac = algorithmic bytes / unit time / 8 TB/s, mfma_frac = 38.65 GFLOP / unit time / 2.5 PFLOP/s."""
-    from src.ops.lib import load_library
+    X = [128,32,32,128] NHWC -> 128 channels, level 0 of cfg 2, for both activation storages of the bf16-MFMA mode.  Every entry's
+    `unit_us` is EVERYTHING the unit needs, timed with HIP events on the launch stream (median of 20): the two-pass unit = GroupNorm
+    kernel + conv; a fused unit = the fused conv + whatever produces its statistics (a statistics pass over the tensor, or what the
+    sums cost the PRODUCING conv's epilogue: that conv timed with and without them); the single fused launch is reported beside it as
+    `fused_launch_us`.  hbm_frac = algorithmic bytes / unit time / 8 TB/s, mfma_frac = 38.65 GFLOP / unit time / 2.5 PFLOP/s."""
     out = {"shape": "[128,32,32,128] NHWC -> 128, 3x3/s1/p1", "gflop": NAMED_GFLOP}
     N, H, W, Cc = 128, 32, 32, 128
     g = torch.Generator(device=dev).manual_seed(7)
     gamma = torch.ones(Cc, device=dev); beta = torch.zeros(Cc, device=dev)
     temb = torch.randn(N, Cc, device=dev, generator=g) * 0.1
-    w = (torch.randn(9 * Cc * Cc, device=dev, generator=g) * 0.03).to(torch.bfloat16)
+    w32 = torch.randn(9 * Cc * Cc, device=dev, generator=g) * 0.03                 # master layout [tap][ci][co]
+    table, nent, tiles = K.pack_table([(0, 9, Cc, Cc)], dev)
+    wd, w, wdq, wq = (torch.zeros(w32.numel(), device=dev, dtype=torch.bfloat16) for _ in range(4))
+    K.pack_weights_bf16(table, nent, tiles, w32, wd, w, wdq, wq)
     bias = torch.zeros(Cc, device=dev)
-    for sto, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
-        x = torch.randn(N, H, W, Cc, device=dev, generator=g).to(dt)
 
-        def unit():
-            h, _ = K.gn_mish_fwd(x, gamma, beta, temb=temb, out_dtype=dt)
-            return K.conv3x3_bf16w(h, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt)
-        for _ in range(5):
-            unit()
-        K.PROBE = []
+    def timed(fns):
+        """{name: callable} -> median us of each callable's launches (sum over the launches it makes), interleaved rounds"""
+        for fn in fns.values():
+            for _ in range(3):
+                fn()
+        t = {k: [] for k in fns}
+        syms = {k: [] for k in fns}
         for _ in range(20):
-            unit()
-        torch.cuda.synchronize()
-        per = {}
-        for sym, fl, e0, e1, desc, nb in K.PROBE:
-            per.setdefault(sym, []).append(e0.elapsed_time(e1) * 1e3)
-        K.PROBE = None
-        launches = {k: round(sorted(v)[len(v) // 2], 2) for k, v in per.items()}         # median us per launch
-        unit_us = sum(launches.values())
+            for k, fn in fns.items():
+                K.PROBE = []
+                fn()
+                torch.cuda.synchronize()
+                t[k].append(sum(e0.elapsed_time(e1) for _s, _f, e0, e1, _d, _n in K.PROBE) * 1e3)
+                syms[k] = [q[0] for q in K.PROBE]
+                K.PROBE = None
+        return {k: sorted(v)[len(v) // 2] for k, v in t.items()}, syms
+
+    for sto, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        x = torch.randn(N, H, W, Cc, device=dev, generator=g).to(dt)           # c1: the raw output of block1's conv
+        xin = torch.randn(N, H, W, Cc, device=dev, generator=g).to(dt)         # block1's input (producer timing)
+        xs = x.float().view(N, H * W, Cc // 16, 16)
+        sums = torch.stack([xs.sum((1, 3)), (xs * xs).sum((1, 3))], dim=-1).contiguous().view(-1)     # what c1's producer would have left
+        scratch = torch.zeros_like(sums)                                       # the timed producer adds into this one
+        gn = (sums, gamma, beta, temb, 8, 1e-5)
+        stats, coef = K.gn_stats_coef(x, gamma, beta, temb=temb)
+        hbuf = [None]
+
+        def gn_pass():
+            hbuf[0], _ = K.gn_mish_fwd(x, gamma, beta, temb=temb, out_dtype=dt)
+        gn_pass()
+        md, syms = timed({
+            "gn": gn_pass,
+            "conv": lambda: K.conv3x3_bf16w(hbuf[0], w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt, wq=wq),
+            "stats": lambda: K.gn_stats_coef(x, gamma, beta, temb=temb),
+            "fused_coef": lambda: K.conv3x3_gn_mish(x, coef, w, K=Cc, Nc=Cc, bias=bias, wq=wq),
+            "fused_sums": lambda: K.conv3x3_gn_mish(x, None, w, K=Cc, Nc=Cc, bias=bias, gn=gn, wq=wq),
+            "producer": lambda: K.conv3x3_bf16w(xin, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt, wq=wq),
+            "producer_sums": lambda: K.conv3x3_bf16w(xin, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt, gn_sums=scratch, wq=wq),
+        })
 
         def line(us):
             return {"unit_us": round(us, 2), "algorithmic_mb": NAMED_MB[sto],
@@ -185,48 +211,21 @@ def named_kernel_line(K, dev):
                     "hbm_frac": round(NAMED_MB[sto] * 1e6 / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
                     "tflops": round(NAMED_GFLOP * 1e9 / (us * 1e-6) / 1e12, 1),
                     "mfma_frac": round(NAMED_GFLOP * 1e9 / (us * 1e-6) / 1e12 / PEAK_TFLOPS["bf16"], 4)}
-        ent = {"two_pass": dict(launches_us=launches, **line(unit_us))}
-        # the fused kernel itself (mi_conv3x3_gn_mish): GroupNorm statistics come from the producer side (mi_gn_stats_coef, timed
-        # beside it), the apply + Mish + time bias ride in the conv's staging -- the unit is the ONE conv launch
-        stats, coef = K.gn_stats_coef(x, gamma, beta, temb=temb)
-        for _ in range(5):
-            K.conv3x3_gn_mish(x, coef, w, K=Cc, Nc=Cc, bias=bias)
-        K.PROBE = []
-        for _ in range(20):
-            K.gn_stats_coef(x, gamma, beta, temb=temb)
-            K.conv3x3_gn_mish(x, coef, w, K=Cc, Nc=Cc, bias=bias)
-        torch.cuda.synchronize()
-        per = {}
-        for sym, fl, e0, e1, desc, nb in K.PROBE:
-            per.setdefault(sym, []).append(e0.elapsed_time(e1) * 1e3)
-        K.PROBE = None
-        med = {k: round(sorted(v)[len(v) // 2], 2) for k, v in per.items()}
-        fused_us = [v for k, v in med.items() if k.startswith("conv3x3_halo_kernel")][0]
-        ent["fused"] = dict(kernel=[k for k in med if k.startswith("conv3x3_halo_kernel")][0],
-                            statistics_pass_us=[v for k, v in med.items() if "statistics" in k][0], **line(fused_us))
-        # ... and with the statistics taken from the PRODUCING conv's epilogue (mi_conv3x3_bf16w_io_gnsums) and resolved inside the
-        # fused kernel (mi_conv3x3_gn_mish_sums): no pass over the tensor at all.  The unit is the one fused launch; what the sums
-        # cost the producing conv is reported beside it (same shape: conv 128 -> 128 with and without the sums).
-        sums = torch.zeros(N * (Cc // 16) * 2, device=dev)
-        xin = torch.randn(N, H, W, Cc, device=dev, generator=g).to(dt)
-        gn = (sums, gamma, beta, temb, 8, 1e-5)
-        for _ in range(5):
-            K.conv3x3_bf16w(xin, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt, gn_sums=sums)
-            K.conv3x3_gn_mish(x, None, w, K=Cc, Nc=Cc, bias=bias, gn=gn)
-        t = {"plain": [], "sums": [], "fused": []}
-        for _ in range(20):
-            for key, fn in (("plain", lambda: K.conv3x3_bf16w(xin, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt)),
-                            ("sums", lambda: K.conv3x3_bf16w(xin, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt, gn_sums=sums)),
-                            ("fused", lambda: K.conv3x3_gn_mish(x, None, w, K=Cc, Nc=Cc, bias=bias, gn=gn))):
-                K.PROBE = []
-                fn()
-                torch.cuda.synchronize()
-                t[key].append(sum(e0.elapsed_time(e1) for _s, _f, e0, e1, _d, _n in K.PROBE) * 1e3)
-                K.PROBE = None
-        md = {k: sorted(v)[len(v) // 2] for k, v in t.items()}
-        ent["fused_epilogue_stats"] = dict(kernel=ent["fused"]["kernel"], producer_conv_us=round(md["plain"], 2),
-                                           producer_conv_with_sums_us=round(md["sums"], 2), **line(md["fused"]))
+        sums_cost = max(md["producer_sums"] - md["producer"], 0.0)
+        ent = {"two_pass": dict(launches_us={syms["gn"][0]: round(md["gn"], 2), syms["conv"][0]: round(md["conv"], 2)},
+                                **line(md["gn"] + md["conv"])),
+               # statistics by a pass over c1 (mi_gn_stats_coef), then the fused conv fed by the coefficient tensor
+               "fused": dict(kernel=syms["fused_coef"][-1], fused_launch_us=round(md["fused_coef"], 2),
+                             statistics_pass_us=round(md["stats"], 2), **line(md["fused_coef"] + md["stats"])),
+               # statistics from the producing conv's epilogue, coefficients resolved inside the fused kernel: Block -> Block is two
+               # launches; the unit = the fused launch + what the sums add to the producer
+               "fused_epilogue_stats": dict(kernel=syms["fused_sums"][-1], fused_launch_us=round(md["fused_sums"], 2),
+                                            producer_conv=syms["producer_sums"][-1], producer_conv_us=round(md["producer"], 2),
+                                            producer_conv_with_sums_us=round(md["producer_sums"], 2),
+                                            statistics_cost_us=round(sums_cost, 2), **line(md["fused_sums"] + sums_cost))}
         out[sto + "_storage"] = ent
+    out["default_path"] = ("bf16 storage; inference: fused_epilogue_stats wherever the private-weight-stream kernel takes block2's conv "
+                           "(Unet.fuse_gn_conv = 'auto'), training: two_pass (block2's weight gradient reads the normalised tensor)")
     return out
 
 

@@ -31,6 +31,12 @@ struct PwArgs {
     int N, H, W, K, Nc, K1, ldx, ldx2, ldy, ldr, accumulate, flip;
     int TH, TI, XP, tiles_per_img, xmap;
     int qmap, gx, gy;    // 1-D launch of gx pixel tiles x gy channel tiles: XCD = (pixel group, channel group) of a (8 / qmap) x qmap split
+    float* gsum;         // VAR 1: [N][Nc / 16][2] sum / sum of squares of the stored values per sample and 16-channel slab (+=)
+    const float* coef;   // VAR 2: [3][N][K] scale, shift, time bias of the GroupNorm + Mish applied to x while it is staged
+    // VAR 3: the same coefficients resolved in the kernel from the sums the producing conv's epilogue left (gsum layout), the affine
+    // parameters and the time bias rows temb [N][ldt] (may be null)
+    const float* sums; const float* gamma; const float* beta; const float* temb;
+    int ldt, cpg, hw; float eps;
 };
 
 constexpr int PBM = 128;                        // output pixels per workgroup
@@ -86,17 +92,35 @@ template <int DIR> __device__ __forceinline__ bf16x8 pw_shift(const bf16x8& c, u
 // Unit s (0..35) of a chunk body = (tap row ky, 16-channel step ks, tap column j in the order centre, left, right).
 // Activation piece i of the NEXT chunk is requested in unit 3i + 1.
 constexpr bool pw_is_x(int s) { return s >= 0 && s % 3 == 1 && s / 3 < PXPW; }
+// vector-memory instructions a unit issues after its fragment request: its activation piece, and (fused variants, unit 0) the
+// coefficient loads of the next chunk
+constexpr int pw_ncoef(int var) { return var == 2 ? 6 : var == 3 ? 10 : 0; }
+constexpr int pw_extra(int q, int var) { return (pw_is_x(q) ? 1 : 0) + (q == 0 ? pw_ncoef(var) : 0); }
 // DMA instructions issued after the request of the fragment that unit s reads (unit s + PRD's fragment), up to the start of unit s
-// (a unit requests its fragment first, then its activation piece)
-constexpr int pw_newer(int s) {
-    int n = pw_is_x(s - (PDD - PRD)) ? 1 : 0;
-    for (int q = s - (PDD - PRD - 1); q < s; ++q) n += 1 + (pw_is_x(q) ? 1 : 0);
+constexpr int pw_newer(int s, int var) {
+    int n = pw_extra(s - (PDD - PRD), var);
+    for (int q = s - (PDD - PRD - 1); q < s; ++q) n += 1 + pw_extra(q, var);
     return n;
 }
+// fused variants: piece i of the next chunk (requested in unit 3i + 1) is read back in unit 3i + 7 (its request is older than
+// anything that unit's counted wait leaves in flight), transformed one packed register (two elements) per unit in units 3i + 8 ..
+// 3i + 11 -- right behind the unit's first MFMA, so that the exp / rcp chain runs under the other three -- and written back in 3i + 11
+constexpr int PTU = 8;
+constexpr int pw_part(int s, int i) { return s - PTU - 3 * i; }          // part of piece i that unit s transforms (valid: 0..3; -1: read)
+constexpr bool pw_has_part(int s) {
+    for (int i = 0; i < PXPW; ++i) if (pw_part(s, i) >= -1 && pw_part(s, i) <= 3) return true;
+    return false;
+}
 
+// VAR 0: the plain conv.  VAR 1: the epilogue also accumulates the GroupNorm sums of the NEXT layer (a.gsum).  VAR 2 / 3: the named
+// fused kernel (2: coefficients given, 3: resolved here from the producer's sums) -- x is the RAW output of the previous conv and mish(x * scale[n][c] + shift[n][c]) + tb[n][c] (a.coef; GroupNorm-apply
+// + Mish + time bias, reference src/models/ddpm.py:112-120,139-141) is applied ONCE per staged element: every wave transforms the
+// pieces it requested itself, in place in LDS, after its own counted wait and before the chunk barrier publishes them; rows outside
+// the image stay zero.  One image per tile (TI == 1).
 // ABL (profiling builds only, -DMI_PW_ABL_BUILD): 1 no fragment DMA in the main loop, 2 no activation DMA in the main loop, 4 no stores
-template <bool OUT16, int ABL = 0>
+template <bool OUT16, int VAR = 0, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
+    constexpr bool FUSE = VAR >= 2, GNS = VAR == 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
     const int t = threadIdx.x, l = t & 63;
@@ -122,9 +146,12 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
 
     // ---- activation DMA pieces: piece p = wv + 4i covers tile pixels 8p .. 8p+7 (tile pixel hp = (image ti, row hy = y+1, column x));
     //      lane -> pixel lane >> 3, stored 16-byte position lane & 7 holds channel chunk (lane & 7) ^ ((hp >> 1) & 7)
-    int xpix[PXPW], xcol[PXPW];
+    // ((hp >> 1) & 7 = (4 wv + (l >> 4)) & 7 for every piece of a wave: a lane always holds the same channel chunk)
+    int xpix[PXPW];
+    const int xcol = ((l & 7) ^ ((4 * wv + (l >> 4)) & 7)) * 8;
+    int img0;
     {
-        int img0, y0;
+        int y0;
         if (a.TI > 1) { img0 = bx * a.TI; y0 = 0; }
         else { img0 = bx / a.tiles_per_img; y0 = (bx % a.tiles_per_img) * a.TH; }
 #pragma unroll
@@ -138,7 +165,6 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                 if (iy >= 0 && iy < a.H && img < a.N) v = (img * a.H + iy) * a.W + x;
             }
             xpix[i] = v;
-            xcol[i] = ((l & 7) ^ ((hp >> 1) & 7)) * 8;
         }
     }
     const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page3);
@@ -147,9 +173,104 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         const bool second = cc0 >= a.K1;
         const uint16_t* src = second ? a.x2 : a.x;
         const int ld = second ? a.ldx2 : a.ldx, cc = second ? cc0 - a.K1 : cc0;
-        const uint16_t* p = xpix[i] >= 0 ? src + (size_t)xpix[i] * ld + cc + xcol[i] : zero + (l & 7) * 8;
+        // (both addresses are formed, then one is selected: a select with a multiply in one arm becomes a branch around it)
+        int xp = xpix[i];
+        asm volatile("" : "+v"(xp));                         // (opaque: the 64-bit row offsets are recomputed per chunk, not hoisted into six
+        size_t off = (size_t)max(xp, 0) * ld + cc + xcol;    //  register pairs that end up in scratch)
+        asm volatile("" : "+v"(off));
+        const uint16_t* p = xp >= 0 ? src + off : zero + (l & 7) * 8;
         glds16(p, lds0 + (ch & 1) * PXBUF + (wv + 4 * i) * 1024);
     };
+
+    // ---- fused variants: the 3 x 8 coefficients of this lane's channel chunk of chunk ch.  Plain loads would make hipcc drain the DMA
+    //      queue (vmcnt(0)) at their first use, so they are issued from one asm statement and counted by hand (pw_newer); their
+    //      destination registers are touched again only behind coef_landed(), which sits after the counted wait that covers them.
+    f32x4 cq[6];                                             // scale[8], shift[8], time bias[8] of the chunk being transformed
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 sq[4];                                             // VAR 3: (sum, sum of squares) of the group's slabs
+    const int nslab = FUSE ? a.cpg >> 4 : 1;
+    auto load_coef = [&](int ch) {
+        const int c = min(ch, nchunks - 1) * PCK + xcol;
+        if constexpr (VAR == 2) {
+            const float* p0 = a.coef + (size_t)img0 * a.K + c;
+            const size_t pl = (size_t)a.N * a.K;
+            asm volatile("global_load_dwordx4 %0, %6, off\n\tglobal_load_dwordx4 %1, %6, off offset:16\n\t"
+                         "global_load_dwordx4 %2, %7, off\n\tglobal_load_dwordx4 %3, %7, off offset:16\n\t"
+                         "global_load_dwordx4 %4, %8, off\n\tglobal_load_dwordx4 %5, %8, off offset:16"
+                         : "=&v"(cq[0]), "=&v"(cq[1]), "=&v"(cq[2]), "=&v"(cq[3]), "=&v"(cq[4]), "=&v"(cq[5])
+                         : "v"(p0), "v"(p0 + pl), "v"(p0 + 2 * pl) : "memory");
+        } else {
+            // gamma, beta, the time-bias row (the zero page when there is none) and up to four slabs of the group's sums (a group
+            // with fewer slabs reads its first one again: the number of loads is what the counted waits assume)
+            const float* tb = a.temb ? a.temb + (size_t)img0 * a.ldt + c : reinterpret_cast<const float*>(g_zero_page3);
+            const float* sp = a.sums + ((size_t)img0 * (a.K >> 4) + (c / a.cpg) * nslab) * 2;
+            const float* s1 = sp + (nslab > 1 ? 2 : 0); const float* s2 = sp + (nslab > 2 ? 4 : 0); const float* s3 = sp + (nslab > 2 ? 6 : 0);
+            asm volatile("global_load_dwordx4 %0, %10, off\n\tglobal_load_dwordx4 %1, %10, off offset:16\n\t"
+                         "global_load_dwordx4 %2, %11, off\n\tglobal_load_dwordx4 %3, %11, off offset:16\n\t"
+                         "global_load_dwordx4 %4, %12, off\n\tglobal_load_dwordx4 %5, %12, off offset:16\n\t"
+                         "global_load_dwordx2 %6, %13, off\n\tglobal_load_dwordx2 %7, %14, off\n\t"
+                         "global_load_dwordx2 %8, %15, off\n\tglobal_load_dwordx2 %9, %16, off"
+                         : "=&v"(cq[0]), "=&v"(cq[1]), "=&v"(cq[2]), "=&v"(cq[3]), "=&v"(cq[4]), "=&v"(cq[5]),
+                           "=&v"(sq[0]), "=&v"(sq[1]), "=&v"(sq[2]), "=&v"(sq[3])
+                         : "v"(a.gamma + c), "v"(a.beta + c), "v"(tb), "v"(sp), "v"(s1), "v"(s2), "v"(s3) : "memory");
+        }
+    };
+    auto coef_landed = [&]() {
+        asm volatile("" : "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+v"(cq[3]), "+v"(cq[4]), "+v"(cq[5]) :: "memory");
+        if constexpr (VAR == 3) {
+            // mi_gn_coef_from_sums' arithmetic (norm_act.hip): the group's slabs combined in double, var = E[x^2] - mean^2
+            asm volatile("" : "+v"(sq[0]), "+v"(sq[1]), "+v"(sq[2]), "+v"(sq[3]) :: "memory");
+            double sm = 0.0, qm = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < nslab) { sm += sq[k].x; qm += sq[k].y; }
+            const double cnt = (double)a.hw * a.cpg, mean = sm / cnt;
+            double var = qm / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = 1.0f / sqrtf((float)var + a.eps), mf = (float)mean;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sc = cq[h][e] * rstd;
+                    cq[2 + h][e] = cq[2 + h][e] - mf * sc;
+                    cq[h][e] = sc;
+                }
+        }
+#ifndef MI_PW_NOFOLD
+#pragma unroll
+        for (int h = 0; h < 4; ++h) cq[h] *= 1.44269504f;    // scale, shift -> scale log2(e), shift log2(e): see mish_tb
+#endif
+    };
+    // two elements (one packed register) of a piece: channels 2q, 2q + 1 of the lane's chunk
+    // mish(u) + tb with u = x * scale + shift, as mish_fast_f (common.h) computes it -- e = exp(min(u, 20)), w = e (e + 2),
+    // u w / (w + 2) -- with the constants moved to where they are free: scale and shift carry log2(e) (coef_landed), so that
+    // t = u log2(e) feeds v_exp_f32 directly, and ln(2) / (w + 2) = 1 / fma(w, 1 / ln 2, 2 / ln 2) restores u = t ln(2)
+    auto mish_tb = [&](float x, float sc, float sh, float tb) -> float {
+#ifdef MI_PW_NOFOLD
+        return mish_fast_f(fmaf(x, sc, sh)) + tb;
+#endif
+        const float t = fmaf(x, sc, sh);
+        const float e = __builtin_amdgcn_exp2f(fminf(t, 20.f * 1.44269504f));
+        const float w = e * (e + 2.f);
+        const float r = __builtin_amdgcn_rcpf(fmaf(w, 1.44269504f, 2.88539008f));
+        return fmaf(t * w, r, tb);
+    };
+    auto tpart = [&](uint32_t v, auto qc, uint32_t vmask) -> uint32_t {
+        constexpr int q = decltype(qc)::value, e0 = 2 * q, e1 = 2 * q + 1;
+        const float x0 = __uint_as_float(v << 16), x1 = __uint_as_float(v & 0xffff0000u);
+        const float m0_ = mish_tb(x0, cq[e0 >> 2][e0 & 3], cq[2 + (e0 >> 2)][e0 & 3], cq[4 + (e0 >> 2)][e0 & 3]);
+        const float m1_ = mish_tb(x1, cq[e1 >> 2][e1 & 3], cq[2 + (e1 >> 2)][e1 & 3], cq[4 + (e1 >> 2)][e1 & 3]);
+        return pack_bf16(m0_, m1_) & vmask;                  // rows above / below the image stay zero padding
+    };
+    auto piece_addr = [&](int buf, int i) -> uint32_t { return lds0 + buf * PXBUF + (wv + 4 * i) * 1024 + l * 16; };
+    auto piece_mask = [&](int i) -> uint32_t {
+        uint32_t m = xpix[i] >= 0 ? ~0u : 0u;
+        asm volatile("" : "+v"(m));                          // a mask, not a branch around the arithmetic
+        return m;
+    };
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+    u32x4 tv[2];                                             // main loop: the (at most two) pieces in transformation, rewritten in place
 
     // ---- weight stream of this wave: fragment (tap, nb, kq) = 1 KB at ((tap * NB + nb) * KQ + kq) * 1024 bytes
     const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(a.w) + (size_t)nb * KQ * 1024;
@@ -193,10 +314,29 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     bf16x8 FW[PRD + 1];                                      // weight fragments, PRD units ahead
 
     // ---- prologue: the first chunk's rows, the first PDD fragments
+    if constexpr (FUSE) load_coef(0);
 #pragma unroll
     for (int i = 0; i < PXPW; ++i) stage_x(0, i);
     static_for<0, PDD>([&](auto sc) { stage_w(0, sc); });
-    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PDD - PRD) : "memory");     // the rows and fragments 0 .. PRD-1 have landed (this wave's)
+    if constexpr (FUSE) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PDD) : "memory");       // coefficients and rows of chunk 0
+        coef_landed();
+        static_for<0, 2>([&](auto hc) {                      // three pieces in flight at a time, three independent transforms
+            constexpr int h = decltype(hc)::value;
+            u32x4 pv[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pv[i] = __builtin_bit_cast(u32x4, lds_b128p(piece_addr(0, 3 * h + i)));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const uint32_t vm = piece_mask(3 * h + i);
+                u32x4 o;
+                static_for<0, 4>([&](auto qc) { o[decltype(qc)::value] = tpart(pv[i][decltype(qc)::value], qc, vm); });
+                *(lds_u32x4*)(uintptr_t)piece_addr(0, 3 * h + i) = o;
+            }
+        });
+    }
+    // the rows and fragments 0 .. PRD-1 have landed (this wave's; the fused variant's rewritten pieces are in LDS) ...
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(PDD - PRD) : "memory");
     __builtin_amdgcn_s_barrier();                                          // ... every wave's
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -204,46 +344,70 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     static_for<0, PRD>([&](auto sc) { FW[decltype(sc)::value] = lds_b128p(wrd0 + decltype(sc)::value * 1024); });
 
     static_assert(36 % (PRD + 1) == 0, "fragment register slots line up across chunks");
+    // one chunk: 36 units.  Fused variants: EVERY chunk runs the transform parts -- in the last one they rewrite the clamped re-fetch of
+    // its own rows, wasted VALU work.  Both ways of skipping them measured worse: a branch around a part fences it off from the MFMAs
+    // it is meant to run under (and a per-unit branch between two copies of the unit: 99-114 spilled registers); a second copy of the
+    // whole body for the last chunk has its 36 fragment addresses formed ahead of the loop, live across it, and spills.
     for (int ch = 0; ch < nchunks; ++ch) {
         // ring slot of unit s of this chunk: (36 ch + s) % 8 = (s & 7) with bit 2 toggled in odd chunks
         const uint32_t wsame = wrd0 + (ch & 1) * 4096, wflip = wrd0 + 4096 - (ch & 1) * 4096;
         const uint32_t xcur = (ch & 1) * PXBUF, xnxt = PXBUF - xcur;
         static_for<0, 36>([&](auto sc) {
             constexpr int s = decltype(sc)::value, g = s / 3, ky = g / 4, ks = g % 4, j = s % 3;
-            // the fragment of unit s + PRD has landed ...
-            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(pw_newer(s)) : "memory");
-            {
-                constexpr int sr = s + PRD, over = sr >= 36 ? 1 : 0, srr = sr - 36 * over;
-                FW[sr % (PRD + 1)] = lds_b128p((((srr & 4) != 0) != (over != 0) ? wflip : wsame) + (srr & 3) * 1024);
-            }
-            if constexpr (j == 0) {                          // the next group's centre-column fragments
-                if constexpr (g == 11) {
-                    // chunk boundary: every wave has read all it needs of this chunk's rows and has its pieces of the next chunk's
-                    // (their requests are older than the fragment just waited for)
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) XC[0][i] = lds_b128p(xa[i][0] + xnxt);
-                } else {
-                    constexpr int gn = g + 1, kyn = gn / 4, ksn = gn % 4;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) XC[gn & 1][i] = lds_b128p((xa[i][kyn] ^ (ksn * 32)) + xcur);
+            auto unit = [&](auto more_c) {
+                constexpr bool MORE = decltype(more_c)::value;
+                // the fragment of unit s + PRD has landed ...
+                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(pw_newer(s, VAR)) : "memory");
+                {
+                    constexpr int sr = s + PRD, over = sr >= 36 ? 1 : 0, srr = sr - 36 * over;
+                    FW[sr % (PRD + 1)] = lds_b128p((((srr & 4) != 0) != (over != 0) ? wflip : wsame) + (srr & 3) * 1024);
                 }
-            }
-            // ring slot of unit s - 1 is free (its fragment is in registers since the previous unit's MFMAs)
-            if constexpr (!(ABL & 1)) stage_w(ch, std::integral_constant<int, s + PDD>{});
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if constexpr (pw_is_x(s) && !(ABL & 2)) stage_x(ch + 1, s / 3);
+                if constexpr (j == 0) {                      // the next group's centre-column fragments
+                    if constexpr (g == 11) {
+                        // chunk boundary: every wave has read all it needs of this chunk's rows and has its pieces of the next
+                        // chunk's (their requests are older than the fragment just waited for)
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                bf16x8 xf;
-                if constexpr (j == 0) xf = XC[g & 1][i];
-                else if constexpr (j == 1) xf = pw_shift<0>(XC[g & 1][i], mask_l);
-                else xf = pw_shift<1>(XC[g & 1][i], mask_r);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FW[s % (PRD + 1)], xf, acc[i], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                        for (int i = 0; i < 4; ++i) XC[0][i] = lds_b128p(xa[i][0] + xnxt);
+                    } else {
+                        constexpr int gn = g + 1, kyn = gn / 4, ksn = gn % 4;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) XC[gn & 1][i] = lds_b128p((xa[i][kyn] ^ (ksn * 32)) + xcur);
+                    }
+                }
+                // ring slot of unit s - 1 is free (its fragment is in registers since the previous unit's MFMAs)
+                if constexpr (!(ABL & 1)) stage_w(ch, std::integral_constant<int, s + PDD>{});
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (pw_is_x(s) && !(ABL & 2)) stage_x(ch + 1, s / 3);
+                if constexpr (FUSE && s == 0) load_coef(ch + 1);
+                if constexpr (FUSE && s == PTU - 2) coef_landed();
+                if constexpr (FUSE && MORE) {
+                    static_for<0, PXPW>([&](auto pc) {
+                        constexpr int i = decltype(pc)::value, q = pw_part(s, i);
+                        if constexpr (q == -1) tv[i & 1] = __builtin_bit_cast(u32x4, lds_b128p(piece_addr((ch + 1) & 1, i)));
+                        if constexpr (q >= 0 && q < 4)
+                            tv[i & 1][q] = tpart(tv[i & 1][q], std::integral_constant<int, (q >= 0 && q < 4) ? q : 0>{}, piece_mask(i));
+                    });
+                }
+                static_for<0, 4>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    bf16x8 xf;
+                    if constexpr (j == 0) xf = XC[g & 1][i];
+                    else if constexpr (j == 1) xf = pw_shift<0>(XC[g & 1][i], mask_l);
+                    else xf = pw_shift<1>(XC[g & 1][i], mask_r);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FW[s % (PRD + 1)], xf, acc[i], 0, 0, 0);
+                });
+                if constexpr (FUSE && MORE) {
+                    static_for<0, PXPW>([&](auto pc) {
+                        constexpr int i = decltype(pc)::value;
+                        if constexpr (pw_part(s, i) == 3) *(lds_u32x4*)(uintptr_t)piece_addr((ch + 1) & 1, i) = tv[i & 1];
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            unit(std::bool_constant<FUSE>{});
         });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped re-fetches must not outlive the workgroup's LDS
@@ -279,10 +443,10 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         }
     }
     __syncthreads();
-    {
-        typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-        const int j = t & 15, col = n0 + 8 * j;              // this thread's 8 channels
-        if (col >= a.Nc) return;
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+    const int j = t & 15, col = n0 + 8 * j;                  // this thread's 8 channels
+    float gs[2][2] = {{0.f, 0.f}, {0.f, 0.f}};               // VAR 1: [image of the tile][sum, sum of squares]
+    if (col < a.Nc) {
         f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
         if (a.bias) { b0 = *reinterpret_cast<const f32x4*>(a.bias + col); b1 = *reinterpret_cast<const f32x4*>(a.bias + col + 4); }
 #pragma unroll
@@ -304,12 +468,49 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                     v1 += f32x4{__uint_as_float(o.z << 16), __uint_as_float(o.z & 0xffff0000u),
                                 __uint_as_float(o.w << 16), __uint_as_float(o.w & 0xffff0000u)};
                 }
-                *reinterpret_cast<u32x4*>(yp) = u32x4{pack_bf16(v0.x, v0.y), pack_bf16(v0.z, v0.w), pack_bf16(v1.x, v1.y), pack_bf16(v1.z, v1.w)};
+                const u32x4 o = u32x4{pack_bf16(v0.x, v0.y), pack_bf16(v0.z, v0.w), pack_bf16(v1.x, v1.y), pack_bf16(v1.z, v1.w)};
+                *reinterpret_cast<u32x4*>(yp) = o;
+                if constexpr (GNS) {                         // statistics of what the next layer will read: the rounded values
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float e0 = __uint_as_float(o[q] << 16), e1 = __uint_as_float(o[q] & 0xffff0000u);
+                        gs[it >> 2][0] += e0 + e1; gs[it >> 2][1] += e0 * e0 + e1 * e1;
+                    }
+                }
             } else {
                 float* yp = reinterpret_cast<float*>(a.y) + m * a.ldy + col;
                 if (a.accumulate) { v0 += *reinterpret_cast<const f32x4*>(yp); v1 += *reinterpret_cast<const f32x4*>(yp + 4); }
                 *reinterpret_cast<f32x4*>(yp) = v0;
                 *reinterpret_cast<f32x4*>(yp + 4) = v1;
+                if constexpr (GNS) {
+                    gs[it >> 2][0] += (v0.x + v0.y) + (v0.z + v0.w) + (v1.x + v1.y) + (v1.z + v1.w);
+                    gs[it >> 2][1] += (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w) + (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w);
+                }
+            }
+        }
+    }
+    if constexpr (GNS) {
+        // a 16-channel slab = two neighbouring lanes (j = 2q, 2q + 1) x the 16 row groups t >> 4 (4 per wave): lanes, then waves
+        // through the LDS behind the tile, then ONE atomic pair per slab, image and workgroup (rows 0-63 / 64-127 are the two images
+        // of a TI == 2 tile; with TI == 1 both halves belong to image img0)
+        float r[4] = {gs[0][0], gs[0][1], gs[1][0], gs[1][1]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r[k] += __shfl_xor(r[k], 1, 64); r[k] += __shfl_xor(r[k], 16, 64); r[k] += __shfl_xor(r[k], 32, 64);
+        }
+        float* red = reinterpret_cast<float*>(lds_raw + 65536);          // [4 waves][8 slabs][4]
+        if ((l & 0x31) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[(wv * 8 + (l >> 1)) * 4 + k] = r[k];
+        }
+        __syncthreads();
+        if (t < 32) {
+            const int q = t >> 2, k = t & 3;                 // slab, (image half, sum / sum of squares)
+            const float v = red[(0 * 8 + q) * 4 + k] + red[(1 * 8 + q) * 4 + k] + red[(2 * 8 + q) * 4 + k] + red[(3 * 8 + q) * 4 + k];
+            const int slab = (n0 >> 4) + q;
+            if (slab * 16 < a.Nc) {
+                const int img = a.TI > 1 ? img0 + (k >> 1) : img0;
+                atomicAdd(a.gsum + ((size_t)img * (a.Nc >> 4) + slab) * 2 + (k & 1), v);
             }
         }
     }
@@ -334,27 +535,34 @@ bool pw_ok(const MiConvDesc* d, int* TH, int* TI) {
     return pw_geom(d, TH, TI);
 }
 
-}  // namespace
+struct PwGn { const float* sums; const float* gamma; const float* beta; const float* temb; int ldt, G; float eps; };
 
-extern "C" int mi_conv3x3_pw_supported(const MiConvDesc* d) {
-    int th, ti;
-    return (d && pw_ok(d, &th, &ti)) ? 1 : 0;
-}
-
-// x / x2: bf16 tensors (pixel strides in elements, % 8 == 0); w: bf16 weights in MFMA-fragment order [tap][Nc / 32][K / 16][64][8]
-// (mi_pack_weights_bf16's wfq for the forward conv, wdq with d->transposed = 1 -> flipped taps for the data gradient);
-// out_bf16: y is written as bf16 (else fp32).  bias / residual fp32, d->accumulate: y += result.
-extern "C" int mi_conv3x3_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,
-                             const float* residual, void* y, int out_bf16, void* stream) {
-    MI_REQUIRE(d && x && w_frag_bf16 && y, "null argument");
-    PwArgs a;
-    MI_REQUIRE(pw_ok(d, &a.TH, &a.TI), "descriptor not supported by the private-weight-stream conv kernel (use mi_conv3x3_bf16w_io)");
-    MI_REQUIRE(d->K1 == d->K || x2, "two-source split without x2");
-    MI_REQUIRE((((uintptr_t)x | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)w_frag_bf16) & 15) == 0, "operands must be 16-byte aligned");
-    MI_REQUIRE(d->ldy % 4 == 0 && (!residual || d->ldr % 4 == 0), "output / residual pixel strides must be multiples of 4");
+static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,
+                     const float* residual, void* y, int out_bf16, int var, float* gsum, const float* coef, void* stream,
+                     const PwGn* gn = nullptr) {
+    PwArgs a{};
+    if (!d || !x || !w_frag_bf16 || !y) return mi_set_error(-1, "%s: null argument", who);
+    if (!pw_ok(d, &a.TH, &a.TI)) return mi_set_error(-1, "%s: descriptor not supported by the private-weight-stream conv kernel", who);
+    if (d->K1 != d->K && !x2) return mi_set_error(-1, "%s: two-source split without x2", who);
+    if ((((uintptr_t)x | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)w_frag_bf16) & 15) != 0) return mi_set_error(-1, "%s: operands must be 16-byte aligned", who);
+    if (d->ldy % 8 || (residual && d->ldr % 4)) return mi_set_error(-1, "%s: output pixel stride must be a multiple of 8, the residual's of 4", who);
+    if (var >= 2 && (a.TI != 1 || d->K1 != d->K))
+        return mi_set_error(-1, "%s: the fused variants need one image per tile and one source", who);
+    if (var == 2 && (!coef || ((uintptr_t)coef & 15)))
+        return mi_set_error(-1, "%s: the fused variant needs a 16-byte aligned coefficient tensor", who);
+    if (var == 3) {
+        if (!gn || !gn->sums || !gn->gamma || !gn->beta || gn->G <= 0 || d->K % gn->G || (d->K / gn->G) % 16 || d->K / gn->G > 64)
+            return mi_set_error(-1, "%s: sums, gamma, beta; K / G in {16, 32, 64}", who);
+        if ((((uintptr_t)gn->gamma | (uintptr_t)gn->beta | (uintptr_t)gn->sums) & 7) || (gn->temb && (((uintptr_t)gn->temb & 15) || gn->ldt % 4)))
+            return mi_set_error(-1, "%s: misaligned GroupNorm operands", who);
+        a.sums = gn->sums; a.gamma = gn->gamma; a.beta = gn->beta; a.temb = gn->temb; a.ldt = gn->ldt; a.cpg = d->K / gn->G;
+        a.hw = d->OH * d->OW; a.eps = gn->eps;
+    }
+    if (var == 1 && (!gsum || d->Nc % 16)) return mi_set_error(-1, "%s: GroupNorm sums need Nc %% 16 == 0 and a sum buffer", who);
     a.x = (const uint16_t*)x; a.x2 = (const uint16_t*)(x2 ? x2 : x); a.w = (const uint16_t*)w_frag_bf16; a.bias = bias; a.res = residual; a.y = y;
     a.N = d->N; a.H = d->OH; a.W = d->OW; a.K = d->K; a.Nc = d->Nc; a.K1 = d->K1; a.ldx = d->ldx; a.ldx2 = x2 ? d->ldx2 : d->ldx;
     a.ldy = d->ldy; a.ldr = d->ldr; a.accumulate = d->accumulate; a.flip = d->transposed ? 1 : 0;
+    a.gsum = gsum; a.coef = coef;
     a.tiles_per_img = a.TI > 1 ? 1 : a.H / a.TH;
     a.XP = a.TI * (a.TH + 2) * a.W;
     a.xmap = a.TI == 1 && a.tiles_per_img > 1 && a.N % 8 == 0;
@@ -363,32 +571,73 @@ extern "C" int mi_conv3x3_pw(const MiConvDesc* d, const void* x, const void* x2,
     if (!a.xmap && a.gy > 1 && a.gy % 2 == 0 && a.gx % 4 == 0) { a.qmap = 2; grid = dim3(grid.x * grid.y, 1, 1); }
     hipStream_t st = (hipStream_t)stream;
     size_t lds = PLDS;
+#define MI_PW_GO(O16, V, A) do { \
+        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, A>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
+        (void)once_; \
+        hipLaunchKernelGGL((conv_pw_kernel<O16, V, A>), grid, dim3(256), lds, st, a); } while (0)
 #ifdef MI_PW_ABL_BUILD
     static const int abl = [] { const char* e = getenv("MI_PW_ABL"); return e ? atoi(e) : 0; }();
     if (abl & 8) lds = 100 * 1024;            // one workgroup per CU
-#define MI_PW_GO(O16, A) do { \
-        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, A>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
-        (void)once_; \
-        hipLaunchKernelGGL((conv_pw_kernel<O16, A>), grid, dim3(256), lds, st, a); } while (0)
-    switch (abl & 7) {
-        case 1: if (out_bf16) MI_PW_GO(true, 1); else MI_PW_GO(false, 1); break;
-        case 2: if (out_bf16) MI_PW_GO(true, 2); else MI_PW_GO(false, 2); break;
-        case 3: if (out_bf16) MI_PW_GO(true, 3); else MI_PW_GO(false, 3); break;
-        case 4: if (out_bf16) MI_PW_GO(true, 4); else MI_PW_GO(false, 4); break;
-        case 7: if (out_bf16) MI_PW_GO(true, 7); else MI_PW_GO(false, 7); break;
-        default: if (out_bf16) MI_PW_GO(true, 0); else MI_PW_GO(false, 0); break;
+    if (var == 0 && (abl & 7)) {
+        switch (abl & 7) {
+            case 1: if (out_bf16) MI_PW_GO(true, 0, 1); else MI_PW_GO(false, 0, 1); break;
+            case 2: if (out_bf16) MI_PW_GO(true, 0, 2); else MI_PW_GO(false, 0, 2); break;
+            case 3: if (out_bf16) MI_PW_GO(true, 0, 3); else MI_PW_GO(false, 0, 3); break;
+            case 4: if (out_bf16) MI_PW_GO(true, 0, 4); else MI_PW_GO(false, 0, 4); break;
+            default: if (out_bf16) MI_PW_GO(true, 0, 7); else MI_PW_GO(false, 0, 7); break;
+        }
+        hipError_t e_ = hipGetLastError();
+        return e_ == hipSuccess ? 0 : mi_set_error((int)e_, "%s: %s", who, hipGetErrorString(e_));
+    }
+#endif
+    switch (var) {
+        case 1: if (out_bf16) MI_PW_GO(true, 1, 0); else MI_PW_GO(false, 1, 0); break;
+        case 2: if (out_bf16) MI_PW_GO(true, 2, 0); else MI_PW_GO(false, 2, 0); break;
+        case 3: if (out_bf16) MI_PW_GO(true, 3, 0); else MI_PW_GO(false, 3, 0); break;
+        default: if (out_bf16) MI_PW_GO(true, 0, 0); else MI_PW_GO(false, 0, 0); break;
     }
 #undef MI_PW_GO
-#else
-    static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)conv_pw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
-        (void)hipFuncSetAttribute((const void*)conv_pw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
-        return true;
-    }();
-    (void)once;
-    if (out_bf16) hipLaunchKernelGGL((conv_pw_kernel<true>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((conv_pw_kernel<false>), grid, dim3(256), lds, st, a);
-#endif
-    MI_LAUNCH_CHECK();
-    return 0;
+    hipError_t e_ = hipGetLastError();
+    return e_ == hipSuccess ? 0 : mi_set_error((int)e_, "%s: %s", who, hipGetErrorString(e_));
+}
+
+}  // namespace
+
+extern "C" int mi_conv3x3_pw_supported(const MiConvDesc* d) {
+    int th, ti;
+    return (d && pw_ok(d, &th, &ti)) ? 1 : 0;
+}
+// the fused GroupNorm-apply + Mish + conv variant: tiles inside one image, one source
+extern "C" int mi_conv3x3_pw_gn_mish_supported(const MiConvDesc* d) {
+    int th, ti;
+    return (d && pw_ok(d, &th, &ti) && ti == 1 && d->K1 == d->K) ? 1 : 0;
+}
+
+// x / x2: bf16 tensors (pixel strides in elements, % 8 == 0); w: bf16 weights in MFMA-fragment order [tap][Nc / 32][K / 16][64][8]
+// (mi_pack_weights_bf16's wfq for the forward conv, wdq with d->transposed = 1 -> flipped taps for the data gradient);
+// out_bf16: y is written as bf16 (else fp32).  bias / residual fp32, d->accumulate: y += result.
+extern "C" int mi_conv3x3_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,
+                             const float* residual, void* y, int out_bf16, void* stream) {
+    return pw_launch(__func__, d, x, x2, w_frag_bf16, bias, residual, y, out_bf16, 0, nullptr, nullptr, stream);
+}
+// ... that also adds the sum and the sum of squares of the values it stores, per sample and 16-channel slab, into gsum [N][Nc/16][2]
+// (zeroed by the caller): the statistics of the GroupNorm that follows (mi_gn_coef_from_sums), without a pass over y
+extern "C" int mi_conv3x3_pw_gnsums(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,
+                                    const float* residual, void* y, int out_bf16, float* gsum, void* stream) {
+    return pw_launch(__func__, d, x, x2, w_frag_bf16, bias, residual, y, out_bf16, 1, gsum, nullptr, stream);
+}
+// BASELINE.json's named kernel on this structure: y = conv3x3(mish(x * scale + shift) + tb) + bias, x the RAW bf16 output of the
+// previous conv, coef [3][N][K] = scale, shift, tb (mi_gn_coef_from_sums / mi_gn_stats_coef)
+extern "C" int mi_conv3x3_pw_gn_mish(const MiConvDesc* d, const void* x, const float* coef, const void* w_frag_bf16, const float* bias,
+                                     void* y, int out_bf16, void* stream) {
+    return pw_launch(__func__, d, x, nullptr, w_frag_bf16, bias, nullptr, y, out_bf16, 2, nullptr, coef, stream);
+}
+// ... with the coefficients resolved in the kernel from the sums the producing conv's epilogue left (mi_conv3x3_pw_gnsums or
+// mi_conv3x3_bf16w_io_gnsums: sums [N][K / 16][2]), gamma / beta [K] and the block's time-bias rows temb [N][ldt] (optional): Block ->
+// Block is two launches, no statistics pass and no coefficient tensor.  K / G in {16, 32, 64}.
+extern "C" int mi_conv3x3_pw_gn_mish_sums(const MiConvDesc* d, const void* x, const float* sums, const float* gamma, const float* beta,
+                                          const float* temb, int ldt, int G, float eps, const void* w_frag_bf16, const float* bias,
+                                          void* y, int out_bf16, void* stream) {
+    const PwGn gn{sums, gamma, beta, temb, ldt, G, eps};
+    return pw_launch(__func__, d, x, nullptr, w_frag_bf16, bias, nullptr, y, out_bf16, 3, nullptr, nullptr, stream, &gn);
 }

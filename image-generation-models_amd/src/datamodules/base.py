@@ -61,19 +61,28 @@ class ArrayImageDataset(Dataset):
         return x, int(self.labels[i])
 
 
+def _resized_item(dataset, i):
+    """Module-level so that multiprocessing can pickle `functools.partial(_resized_item, dataset)` (a local lambda cannot be)."""
+    return dataset.resized(dataset.images[i])
+
+
 def materialize_uint8(dataset, num_workers: int = 0) -> "ArrayImageDataset":
     """Apply the deterministic part of the transform chain (decode, resize) ONCE and return an ArrayImageDataset over a uint8
     array without a resize step; flip / normalize stay per-access.  Accepts ArrayImageDataset (with or without resize) and
-    datasets exposing `load_uint8(i)` (the jpg folder)."""
+    datasets exposing `load_uint8(i)` + `_tf` (the jpg folder); anything else raises TypeError."""
     if isinstance(dataset, ArrayImageDataset) and dataset.resize is None:
         return dataset
     n = len(dataset)
     if isinstance(dataset, ArrayImageDataset):
+        import functools
         tf, labels = dataset, np.asarray(dataset.labels)
-        get = lambda i: tf.resized(tf.images[i])                                   # noqa: E731
-    else:
+        get = functools.partial(_resized_item, dataset)
+    elif hasattr(dataset, "load_uint8") and hasattr(dataset, "_tf"):
         tf, labels = dataset._tf, np.zeros(n, dtype=np.int64)
         get = dataset.load_uint8
+    else:
+        raise TypeError(f"materialize_uint8: {type(dataset).__name__} is neither an ArrayImageDataset nor a dataset with "
+                        "load_uint8(i) / _tf; use device_resident=False (DataLoader + DevicePrefetcher) for it")
     if num_workers > 0 and n >= 4 * num_workers:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(num_workers) as pool:
@@ -88,9 +97,11 @@ def materialize_uint8(dataset, num_workers: int = 0) -> "ArrayImageDataset":
 
 class DeviceBatchLoader:
     """Serves (images fp32 NCHW, labels int64) batches from a uint8 dataset resident in HBM.  Epoch order: a fresh random
-    permutation per epoch seeded from torch's global CPU generator exactly the way torch's RandomSampler seeds its own
+    permutation per epoch seeded from torch's global CPU generator with the draw torch's RandomSampler makes
     (`int(torch.empty((), dtype=torch.int64).random_())`), or the ShardSampler order under data-parallel training; the last
-    batch is ragged (no drop_last), as with the reference's DataLoader."""
+    batch is ragged (no drop_last), as with the reference's DataLoader.  NOT the reference's sample order for the same global seed:
+    a torch DataLoader iterator also draws its `_base_seed` from the global generator before the sampler's seed each epoch, and the
+    flips here come from the device generator.  Under world > 1 every rank decodes and uploads the whole dataset in setup."""
 
     def __init__(self, dataset: ArrayImageDataset, batch_size: int, device, shuffle: bool, sampler=None):
         if dataset.resize is not None:

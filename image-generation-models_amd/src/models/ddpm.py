@@ -248,11 +248,13 @@ class Unet(nn.Module):
         # stream, attention path and every parameter/statistic stay fp32.  Measured on cfg 2 (B=128): bf16 12.8k,
         # auto 12.6k, fp32 12.5k images/s.
         self.block_storage = os.environ.get("MI_DDPM_STORAGE", "bf16")
-        # inference: fold GroupNorm-apply + Mish (+ time bias) into the following 3x3 conv's staging (mi_conv3x3_gn_mish, the
-        # fused kernel BASELINE.json names).  Off by default: with bf16 block storage the statistics pass it still needs
-        # (mi_gn_stats_coef) costs what the apply pass cost, and the sampler measured 671 vs 692 denoise steps/s at B=64
-        # (tools/sample_steps.py); with fp32 storage the fused unit is 65.6 us against 86.3 us in two passes (bench.py named_kernel).
-        self.fuse_gn_conv = int(os.environ.get("MI_DDPM_FUSE_GN", "0"))     # 1: statistics pass + fused conv; 2: statistics from conv1's epilogue
+        # inference: GroupNorm-apply + Mish (+ time bias) folded into the staging of block2's 3x3 conv (BASELINE.json's named fused
+        # kernel; h1 is never materialised).  "auto" (default): wherever the private-weight-stream kernel takes the layer
+        # (mi_conv3x3_pw_gn_mish_sums: the transform runs once per staged element between the MFMAs, statistics from conv1's
+        # epilogue -- two launches per Block -> Block; sampler at B = 64: 722 vs 722 denoise steps/s with the 8x8 level included through
+        # round 2's halo kernel, which loses there and is therefore not taken).  "0": never; "1": everywhere a fused kernel exists,
+        # statistics by a pass over c1 (mi_gn_stats_coef); "2": everywhere, statistics from conv1's epilogue.
+        self.fuse_gn_conv = os.environ.get("MI_DDPM_FUSE_GN", "auto")
         # Downsample / Upsample weight gradients through the LDS-DMA kernel (csrc/wgrad_s2_tr.hip); 0 = round 1's ring kernel
         self.s2_wgrad_tr = os.environ.get("MI_DDPM_S2_TR", "1") != "0"
         # final_conv.0's conv output stored like the other Blocks' (bf16 in bf16 mode); 0 = fp32 as in round 1
@@ -528,12 +530,16 @@ class Unet(nn.Module):
                 inp_c = sh[id(inp)][1]            # inference: the copy the producing GroupNorm kernel wrote along (no conversion launches)
             tb = tb_all[:, blk["tcol"]:blk["tcol"] + co]
             hw = inp.shape[1] * inp.shape[2]
-            fuse = (not record and mode == K.MODE_BF16 and self.fuse_gn_conv and c1_16 == lo16
+            fmode = str(self.fuse_gn_conv)
+            sums_ok = ((co // _GN_GROUPS) % 16 == 0 and hw % 32 == 0 and ci % 32 == 0
+                       and all(K.fast3x3_supported(B, inp.shape[1], inp.shape[2], ci, co, k1)))
+            fuse = (not record and mode == K.MODE_BF16 and fmode != "0" and c1_16 == lo16
                     and K.conv3x3_gn_mish_supported(B, inp.shape[1], inp.shape[2], co, co))
+            if fuse and fmode == "auto":
+                fuse = lo16 and sums_ok and K.conv3x3_pw_gn_mish_picked(B, inp.shape[1], inp.shape[2], co, co)
             # ... with block1's GroupNorm statistics taken from conv1's epilogue when the tile kernel runs it (no pass over c1 at all)
             sums = None
-            if fuse and self.fuse_gn_conv == 2 and (co // _GN_GROUPS) % 16 == 0 and hw % 32 == 0 and ci % 32 == 0 and \
-                    all(K.fast3x3_supported(B, inp.shape[1], inp.shape[2], ci, co, k1)):
+            if fuse and fmode in ("2", "auto") and sums_ok:
                 nsum = B * (co // 16) * 2
                 if zpool[0] is None:      # one zero fill per forward for every block's sums
                     zpool[0] = torch.zeros(2 * B * sum(rb["cout"] // 16 + 1 for rb in A.res_blocks), device=inp.device, dtype=torch.float32)
@@ -547,10 +553,12 @@ class Unet(nn.Module):
                 if sums is not None:
                     st1 = None
                     c2 = K.conv3x3_gn_mish(c1, None, wf_sh[offs[pre + "block2.block.0.weight"]:], K=co, Nc=co, bias=sv[pre + "block2.block.0.bias"],
-                                           gn=(sums, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], tb, _GN_GROUPS, 1e-5))
+                                           gn=(sums, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], tb, _GN_GROUPS, 1e-5),
+                                           wq=wfq_sh[offs[pre + "block2.block.0.weight"]:])
                 else:
                     st1, coef = K.gn_stats_coef(c1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], temb=tb)
-                    c2 = K.conv3x3_gn_mish(c1, coef, wf_sh[offs[pre + "block2.block.0.weight"]:], K=co, Nc=co, bias=sv[pre + "block2.block.0.bias"])
+                    c2 = K.conv3x3_gn_mish(c1, coef, wf_sh[offs[pre + "block2.block.0.weight"]:], K=co, Nc=co, bias=sv[pre + "block2.block.0.bias"],
+                                           wq=wfq_sh[offs[pre + "block2.block.0.weight"]:])
                 h1 = None
             if c2 is None:
                 h1, st1 = K.gn_mish_fwd(c1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], temb=tb,

@@ -235,6 +235,18 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
     io = _b16(x) | (_b16(out) << 1)
     assert x2 is None or x2.dtype == x.dtype
     pick = "halo"
+    if (gn_sums is not None and ksize == 3 and _b16(x) and USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc)
+            and _query("mi_conv3x3_pw_supported", d)):
+        # the next layer's GroupNorm sums from the private-weight-stream kernel's epilogue
+        assert gn_sums.dtype == torch.float32 and gn_sums.numel() == N * (Nc // 16) * 2
+        e0 = _probe_open()
+        check(lib.mi_conv3x3_pw_gnsums(C.byref(d), _p(x), _p(x2), _p(wq), _p(bias), _p(residual), _p(out), _b16(out), _p(gn_sums), _stream()),
+              "mi_conv3x3_pw_gnsums")
+        if e0 is not None:
+            nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 2)
+            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(out) else 'false'}, 1>", 2.0 * N * H * W * Nc * K * 9,
+                         f"N{N} {H}x{W} K{K}->{Nc} + GroupNorm sums", nb)
+        return out
     if gn_sums is None and not want16 and ksize == 3 and _b16(x):
         pick = "shift" if USE_CONV_SHIFT else "dma" if USE_CONV_DMA else _pick3x3(W, K, Nc)
         if USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc) and _query("mi_conv3x3_pw_supported", d):
@@ -332,7 +344,15 @@ def conv3x3_gn_mish_supported(N, H, W, K, Nc):
     return bool(load_library().mi_conv3x3_gn_mish_supported(C.byref(d)))
 
 
-def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None, gn=None):
+@functools.lru_cache(maxsize=None)
+def conv3x3_pw_gn_mish_picked(N, H, W, K, Nc):
+    """Does conv3x3_gn_mish route a bf16-stored layer of this shape to the private-weight-stream fused kernel (given wq)?"""
+    d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=MODE_BF16, K1=K,
+                   ldx=K, ldx2=K, ldy=Nc, ldr=0, accumulate=0)
+    return bool(USE_CONV_PW and _pick_pw(N, H, W, K, Nc) and load_library().mi_conv3x3_pw_gn_mish_supported(C.byref(d)))
+
+
+def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None, gn=None, wq=None):
     """The fused kernel BASELINE.json names: y = conv3x3(mish(x * scale + shift) + tb) + bias with x the RAW previous conv output
     (fp32 -> fp32 y, or bf16 -> bf16 y), coef from gn_stats_coef -- or coef = None and gn = (sums, gamma, beta, temb, groups, eps):
     the statistics come from the sums the producing conv's epilogue left (conv3x3_bf16w(..., gn_sums=sums)) and are resolved inside
@@ -342,6 +362,25 @@ def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None, gn=None):
     d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=MODE_BF16, K1=K,
                    ldx=ld_of(x), ldx2=ld_of(x), ldy=Nc, ldr=0, accumulate=0)
     lib = load_library()
+    if (wq is not None and USE_CONV_PW and x.dtype == torch.bfloat16 and _pick_pw(N, H, W, K, Nc)
+            and _query("mi_conv3x3_pw_gn_mish_supported", d)):
+        # the private-weight-stream kernel: the transform runs once per staged element, in place in LDS
+        y = new_act(N, H, W, Nc, x, x.dtype if out_dtype is None else out_dtype)
+        d.ldy = Nc
+        e0 = _probe_open()
+        if coef is None and (K // gn[4]) not in (16, 32, 64):
+            _, coef = gn_coef_from_sums(gn[0], N, H * W, gn[1], gn[2], groups=gn[4], eps=gn[5], temb=gn[3])
+        if coef is None:          # statistics, affine and time bias resolved inside the kernel from the producer's sums
+            sums, gamma, beta, temb, groups, eps = gn
+            check(lib.mi_conv3x3_pw_gn_mish_sums(C.byref(d), _p(x), _p(sums), _p(gamma), _p(beta), _p(temb),
+                                                 ld_of(temb) if temb is not None else 0, groups, eps, _p(wq), _p(bias), _p(y), _b16(y),
+                                                 _stream()), "mi_conv3x3_pw_gn_mish_sums")
+        else:
+            check(lib.mi_conv3x3_pw_gn_mish(C.byref(d), _p(x), _p(coef), _p(wq), _p(bias), _p(y), _b16(y), _stream()), "mi_conv3x3_pw_gn_mish")
+        if e0 is not None:
+            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(y) else 'false'}, {3 if coef is None else 2}>", 2.0 * N * H * W * Nc * K * 9,
+                         f"N{N} {H}x{W} K{K}->{Nc} fused GN+Mish", N * H * W * (K * 2 + Nc * _esz(y)) + 9 * K * Nc * 2)
+        return y
     if not lib.mi_conv3x3_gn_mish_supported(C.byref(d)):
         return None
     out_dtype = x.dtype if out_dtype is None else out_dtype

@@ -167,6 +167,26 @@ int mi_pack_weights_bf16(int nent, const void* entries_dev, int total_tiles, con
 int mi_conv3x3_pw_supported(const MiConvDesc* d);
 int mi_conv3x3_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,
                   const float* residual, void* y, int out_bf16, void* stream);
+/* ... whose epilogue also adds the sum and the sum of squares of the values it stores (rounded to bf16 when y is bf16), per sample and
+ * 16-channel slab, into gsum [N][Nc/16][2] (zeroed by the caller, Nc % 16 == 0): the statistics of the GroupNorm that follows
+ * (mi_gn_coef_from_sums) without a pass over y -- one atomic pair per slab, image and workgroup. */
+int mi_conv3x3_pw_gnsums(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,
+                         const float* residual, void* y, int out_bf16, float* gsum, void* stream);
+/* BASELINE.json's named kernel on this structure (reference src/models/ddpm.py:112-120,136-143):
+ *   y = conv3x3(mish(x * scale[n][c] + shift[n][c]) + tb[n][c]) + bias,
+ * x = the RAW bf16 output of block1's conv, coef [3][N][K] fp32 = scale, shift, tb (mi_gn_coef_from_sums or mi_gn_stats_coef).  The
+ * transform is applied ONCE per staged element: a wave rewrites, in place in LDS, the activation pieces it requested itself (after its
+ * own counted wait, before the chunk barrier publishes them); rows outside the image stay zero.  Tiles lie inside one image
+ * (W in {16, 32}); the normalised tensor never exists in HBM. */
+int mi_conv3x3_pw_gn_mish_supported(const MiConvDesc* d);
+int mi_conv3x3_pw_gn_mish(const MiConvDesc* d, const void* x, const float* coef, const void* w_frag_bf16, const float* bias,
+                          void* y, int out_bf16, void* stream);
+/* ... or without the coefficient tensor: scale / shift are resolved per channel chunk inside the kernel from the sums the producing
+ * conv's epilogue left (sums [N][K/16][2], mi_conv3x3_pw_gnsums / mi_conv3x3_bf16w_io_gnsums), gamma, beta and the time-bias rows
+ * temb [N][ldt] (optional) with mi_gn_coef_from_sums' arithmetic.  K / G in {16, 32, 64}.  Block -> Block = two launches. */
+int mi_conv3x3_pw_gn_mish_sums(const MiConvDesc* d, const void* x, const float* sums, const float* gamma, const float* beta,
+                               const float* temb, int ldt, int G, float eps, const void* w_frag_bf16, const float* bias,
+                               void* y, int out_bf16, void* stream);
 
 /* ---- the 3-channel ends of the UNet (fp32 VALU, bound by the wide tensor they stream) ------------
  * Conv2d(Cin<=4, Cout, ks, padding=ks/2), ks = 3 (downs.0.0.block1, ddpm.py:116,208) or 1 (its res_conv,

@@ -1,13 +1,13 @@
 """Measured parity errors of the bf16-MFMA mode, recorded while the GPU tests run.
 
 Every bf16-mode test calls `record(case, metric=value, ...)` with what it measured before asserting its tolerance; the values
-are merged into gpurun_out/r02_parity.json on the GPU box (committed as profiles/r02_parity.json), so a tolerance in a test can be
+are merged into gpurun_out/r03_parity.json on the GPU box (committed as profiles/r03_parity.json), so a tolerance in a test can be
 read next to the error it bounds (the rule: tolerance <= 2x the recorded worst case)."""
 import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.path.join(ROOT, "gpurun_out", "r02_parity.json")
+PATH = os.path.join(ROOT, "gpurun_out", "r03_parity.json")
 
 
 def record(case: str, **metrics):

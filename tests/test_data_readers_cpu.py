@@ -132,3 +132,12 @@ def test_materialize_uint8_equals_per_access_chain(tmp_path):
     mat = materialize_uint8(ds)
     assert mat.images.shape == (5, 32, 32, 1) and all(torch.equal(mat[i][0], ds[i][0]) and mat[i][1] == ds[i][1] for i in range(5))
     assert materialize_uint8(mat) is mat
+    # a resized ARRAY dataset through the worker pool (cifar10 / mnist with a transforms.resize override and num_workers > 0): the
+    # per-item callable has to be picklable
+    ds9 = ArrayImageDataset(rng.integers(0, 256, (9, 28, 28, 1), dtype=np.uint8), np.arange(9), {"normalize": True, "resize": {"height": 32, "width": 32}})
+    mat9 = materialize_uint8(ds9, num_workers=2)
+    assert mat9.images.shape == (9, 32, 32, 1) and all(torch.equal(mat9[i][0], ds9[i][0]) for i in range(9))
+    # anything else is refused with a message, not an AttributeError
+    import pytest
+    with pytest.raises(TypeError, match="device_resident=False"):
+        materialize_uint8([1, 2, 3])

@@ -552,6 +552,115 @@ def test_conv3x3_shift_fwd_and_dgrad(K, cfg, out16):
     assert rel_err(yg.float(), y2.float()) < tol
 
 
+@pytest.fixture
+def pw_always(K):
+    """Route every supported layer to the private-weight-stream kernel (the default takes it only from ~one tile per CU up) and
+    record the launches (functional.PROBE) so that a test can assert which kernel it exercised."""
+    was, K.PW_MIN_TILES, K.PROBE = K.PW_MIN_TILES, 0, []
+    yield K.PROBE
+    K.PW_MIN_TILES, K.PROBE = was, None
+
+
+def _conv_launches(probe):
+    return [q[0] for q in probe if q[0].startswith("conv")]
+
+
+def _frag_weights(K, w):
+    """[Co][Ci][3][3] fp32 -> (plain bf16 [ky][kx][Co][Ci] flat, fragment-order forward operand) via the pack kernel."""
+    flat, wd, wf, offs, wdq, wfq = _pack(K, [conv_w_storage(w.double())], frag=True)
+    return wf, wfq
+
+
+@pytest.mark.parametrize("out16", [True, False])
+@pytest.mark.parametrize("cfg", [(16, 32, 32, 128, 128), (8, 16, 16, 256, 256), (4, 8, 8, 512, 512), (16, 16, 16, 128, 384)])
+def test_conv_pw_epilogue_groupnorm_sums(K, cfg, out16, pw_always):
+    """mi_conv3x3_pw_gnsums + mi_gn_coef_from_sums: the next GroupNorm's statistics and coefficients out of the conv's row-contiguous
+    epilogue (one image per tile at 32 / 16 pixels width, TWO at 8x8) equal what mi_gn_stats_coef computes with a pass over the
+    stored tensor, and the conv's output is the plain entry point's (bitwise)."""
+    N, H, W, Ci, Co = cfg
+    g = torch.Generator().manual_seed(73)
+    x = torch.randn(N, H, W, Ci, generator=g).to(DEV).bfloat16()
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)
+    wf, wfq = _frag_weights(K, w)
+    bias = torch.randn(Co, generator=g).to(DEV)
+    gamma, beta = (torch.rand(Co, generator=g) + 0.5).to(DEV), torch.randn(Co, generator=g).to(DEV)
+    temb = torch.randn(N, Co, generator=g).to(DEV)
+    dt = torch.bfloat16 if out16 else torch.float32
+    y0 = K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, bias=bias, out_dtype=dt, wq=wfq)
+    sums = torch.zeros(N * (Co // 16) * 2, device=DEV)
+    y1 = K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, bias=bias, out_dtype=dt, gn_sums=sums, wq=wfq)
+    assert torch.equal(y0, y1)
+    ls = _conv_launches(pw_always)
+    assert len(ls) == 2 and ls[0].startswith("conv_pw_kernel") and ls[1].startswith("conv_pw_kernel") and ls[1].endswith(", 1>"), ls
+    # the raw sums: per sample and 16-channel slab, of the STORED values
+    yd = y0.double().view(N, H * W, Co // 16, 16)
+    want = torch.stack([yd.sum((1, 3)), (yd * yd).sum((1, 3))], dim=-1)             # [N][Co/16][2]
+    got = sums.view(N, Co // 16, 2).double()
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+    if (Co // 8) % 16 or (Co // 8) & (Co // 8 - 1):
+        return                                      # (384 channels: 48 per group -- the GroupNorm kernels do not take it)
+    st1, cf1 = K.gn_coef_from_sums(sums, N, H * W, gamma, beta, temb=temb)
+    st0, cf0 = K.gn_stats_coef(y0, gamma, beta, temb=temb)
+    torch.cuda.synchronize()
+    assert float((st1[..., 0] - st0[..., 0]).abs().max()) < 2e-5
+    assert float(((st1[..., 1] - st0[..., 1]) / st0[..., 1]).abs().max()) < 2e-5
+    assert float((cf1 - cf0).abs().max()) < 1e-4 * float(cf0.abs().max())
+
+
+@pytest.mark.parametrize("out16", [True, False])
+@pytest.mark.parametrize("cfg", [(16, 32, 32, 128, 128), (8, 16, 16, 256, 256), (8, 16, 16, 128, 256), (3, 32, 32, 128, 96), (2, 32, 32, 64, 64),
+                                 (2, 16, 16, 512, 128)])
+def test_fused_gn_mish_conv3x3_pw(K, cfg, out16, pw_always):
+    """BASELINE.json's named kernel on the private-weight-stream structure (mi_conv3x3_pw_gn_mish; reference ddpm.py:112-120,139-140
+    Block -> time bias -> Block's conv): the transform is applied once per staged element, in place in LDS.  Against (a) an fp64
+    evaluation of GroupNorm -> Mish -> + temb -> Conv2d on the same stored bf16 c1 and bf16-rounded weights and (b) the two-pass path
+    (gn_mish_fwd writing h1 as bf16, then the plain conv): same rounding points, so the two agree to a bf16 ulp of h1 here and there.
+    Image borders (zero padding must stay zero after the transform), one to eight chunks, a ragged channel tile."""
+    N, H, W, Cc, Co = cfg
+    g = torch.Generator().manual_seed(79)
+    c1 = (torch.randn(N, Cc, H, W, generator=g) * 1.7 + 0.3).bfloat16()
+    gamma, beta = torch.randn(Cc, generator=g) * 0.5 + 1, torch.randn(Cc, generator=g) * 0.2
+    temb = torch.randn(N, Cc, generator=g) * 0.3 + 0.5          # a non-zero time bias: padding must NOT become mish(shift) + tb
+    w = torch.randn(Co, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc)
+    bias = torch.randn(Co, generator=g) * 0.1
+    Cop = (Co + 63) // 64 * 64
+    wp = torch.zeros(Cop, Cc, 3, 3); wp[:Co] = w
+    bp = torch.zeros(Cop); bp[:Co] = bias
+    x64 = c1.double()
+    hn = F.group_norm(x64, 8, gamma.double(), beta.double(), 1e-5)
+    h = _mish64(hn) + temb.double()[:, :, None, None]
+    ref = F.conv2d(h, w.bfloat16().double(), bias.double(), padding=1)
+    xg = c1.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wf, wfq = _frag_weights(K, wp)
+    dt = torch.bfloat16 if out16 else torch.float32
+    stats, coef = K.gn_stats_coef(xg, gamma.to(DEV), beta.to(DEV), temb=temb.to(DEV))
+    y = K.conv3x3_gn_mish(xg, coef, wf, K=Cc, Nc=Cop, bias=bp.to(DEV), out_dtype=dt, wq=wfq)
+    assert y is not None and y.dtype == dt
+    ls = _conv_launches(pw_always)
+    assert ls[-1].startswith("conv_pw_kernel") and ls[-1].endswith(", 2>"), ls
+    h1, _ = K.gn_mish_fwd(xg, gamma.to(DEV), beta.to(DEV), temb=temb.to(DEV), out_dtype=torch.bfloat16)
+    y2 = K.conv3x3_bf16w(h1, wf, K=Cc, Nc=Cop, flip=False, bias=bp.to(DEV), out_dtype=dt, wq=wfq)
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2).double()[:, :Co]
+    two = y2.float().cpu().permute(0, 3, 1, 2).double()[:, :Co]
+    assert rel_err(got, ref) < 6e-3
+    assert rel_err(got, two) < (5e-3 if out16 else 1.5e-3)
+    assert not y[..., Co:].any()
+    if (Cc // 8) % 16 == 0:
+        # the variant that resolves the coefficients itself from the producer's sums (mi_conv3x3_pw_gn_mish_sums) does
+        # mi_gn_coef_from_sums' arithmetic: bitwise the output of the coefficient-tensor variant fed by that kernel
+        xd = xg.double().view(N, H * W, Cc // 16, 16)
+        sums = torch.stack([xd.sum((1, 3)), (xd * xd).sum((1, 3))], dim=-1).float().contiguous()
+        _, coef2 = K.gn_coef_from_sums(sums, N, H * W, gamma.to(DEV), beta.to(DEV), temb=temb.to(DEV))
+        ya = K.conv3x3_gn_mish(xg, coef2, wf, K=Cc, Nc=Cop, bias=bp.to(DEV), out_dtype=dt, wq=wfq)
+        yb = K.conv3x3_gn_mish(xg, None, wf, K=Cc, Nc=Cop, bias=bp.to(DEV), out_dtype=dt, wq=wfq,
+                               gn=(sums, gamma.to(DEV), beta.to(DEV), temb.to(DEV), 8, 1e-5))
+        ls = _conv_launches(pw_always)
+        assert ls[-1].endswith(", 3>") and ls[-2].endswith(", 2>"), ls
+        assert torch.equal(ya, yb)
+        assert rel_err(yb.float().cpu().permute(0, 3, 1, 2).double()[:, :Co], ref) < 6e-3
+
+
 def test_pack_weights_fragment_order(K):
     """The MFMA-fragment-order copies mi_conv3x3_pw streams (include/mi_ddpm.h): wfq[tap][co/32][ci/16][lane][8] and
     wdq[tap][ci/32][co/16][lane][8]; layers that are not 3x3 with 64-multiples on both sides get none (their slice stays zero)."""
@@ -587,7 +696,7 @@ def test_pack_weights_fragment_order(K):
     dict(N=4, H=8, Ci=1024, Co=64, split=512),   # long K, half-empty channel tile
     dict(N=6, H=8, Ci=192, Co=320),              # odd chunk count, ragged channel tile
 ])
-def test_conv3x3_pw_fwd_and_dgrad(K, cfg, out16):
+def test_conv3x3_pw_fwd_and_dgrad(K, cfg, out16, pw_always):
     """Block's 3x3 conv (ddpm.py:116) and its data gradient for bf16-stored activations through the private-weight-stream kernel
     (mi_conv3x3_pw: fragment-order weights by LDS-DMA per wave, one barrier per 64-channel chunk): bias, residual, fp32 and bf16
     output, accumulate; against fp64 on the same bf16-rounded operands and against the halo kernel."""
@@ -624,6 +733,8 @@ def test_conv3x3_pw_fwd_and_dgrad(K, cfg, out16):
     yg = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Cop, flip=False, x2=xb, bias=bp.to(DEV), residual=to_nhwc_gpu(rp), out_dtype=odt, wq=wfq)
     assert yg is not None and yg.dtype == odt
     dxg = K.conv3x3_bf16w(nh(dyp.bfloat16()), wd, K=Cop, Nc=Cip, flip=True, out_dtype=odt, wq=wdq)
+    ls = _conv_launches(pw_always)
+    assert len(ls) == 2 and all(q.startswith("conv_pw_kernel") for q in ls), ls
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(yg.float())[:, :Co], yq) < tol
     assert not yg[..., Co:].any()

@@ -370,28 +370,43 @@ def test_sampler_T1000_golden(golden_dir, case, hw):
     assert errs["bf16_final_rel_l2"] < 1e-2, errs                                                # measured 4.0e-3 / 4.9e-3
 
 
-def test_fused_eval_path_matches_two_pass(golden_dir):
-    """Inference with GroupNorm-apply + Mish folded into block2's conv (the default in eval) against the two-pass path, cfg 2 at
-    B = 16, bf16 mode: same epsilon prediction up to bf16 rounding, and both within the bf16 bar of the reference's output."""
+def test_fused_eval_path_matches_two_pass(golden_dir, monkeypatch):
+    from src.ops import functional as _K
+    monkeypatch.setattr(_K, "PW_MIN_TILES", 50)       # B = 16 here (the sampler runs B = 64): 128 tiles at 32x32, 64 at 16x16 / 256 channels
+    _K.conv3x3_pw_gn_mish_picked.cache_clear()
+    """Inference with GroupNorm-apply + Mish folded into block2's conv against the two-pass path, cfg 2 at B = 16, bf16 mode: the
+    DEFAULT ("auto": mi_conv3x3_pw_gn_mish_sums wherever the private-weight-stream kernel takes the layer, asserted through the
+    launch probe) and the two forced modes (round 2's halo kernel where the new one does not apply) give the same epsilon prediction
+    up to bf16 rounding, all within the bf16 bar of the reference's output."""
     g = _load(golden_dir, "cfg2_unet.npz")
     net = _seeded(128, (1, 2, 4), "bf16").eval()
     x = _t(g["x"]).repeat(8, 1, 1, 1).to(DEV); t = _t(g["t"]).repeat(8).to(DEV)
     from src.models.ddpm import GaussianDiffusion
     gd = GaussianDiffusion(net, image_size=(32, 32), timesteps=1000).to(DEV)
     xn = gd.q_sample(x, t, _t(g["noise"]).repeat(8, 1, 1, 1).to(DEV))
+    from src.ops import functional as K
+    assert net.fuse_gn_conv == "auto"
     with torch.no_grad():
+        K.PROBE = []
+        y4 = net(xn, t)                           # the default: fused where the private-weight-stream kernel takes block2's conv
+        fused_default = [q[0] for q in K.PROBE if q[0].startswith("conv_pw_kernel") and q[0].endswith(", 3>")]
+        K.PROBE = None
         net.fuse_gn_conv = 1
         y1 = net(xn, t)
         net.fuse_gn_conv = 2                      # ... with the GroupNorm statistics from conv1's epilogue instead of a pass over c1
         y3 = net(xn, t)
         net.fuse_gn_conv = 0
         y2 = net(xn, t)
+    assert len(fused_default) == 3, fused_default       # downs.0 block 2 (32x32, 128 ch) and downs.1's two blocks (16x16, 256 ch)
     e12, e1, e2 = rel_err(y1, y2), rel_err(y1[:2], _t(g["eps_hat"])), rel_err(y2[:2], _t(g["eps_hat"]))
     e13, e3 = rel_err(y3, y1), rel_err(y3[:2], _t(g["eps_hat"]))
     record("cfg2_fused_eval_vs_two_pass_bf16", fused_vs_two_pass_rel_l2=e12, fused_vs_reference_rel_l2=e1, two_pass_vs_reference_rel_l2=e2,
            epilogue_stats_vs_pass_stats_rel_l2=e13, epilogue_stats_vs_reference_rel_l2=e3)
     assert e12 < 2e-2 and e1 < 2e-2 and e2 < 2e-2
     assert e13 < 2e-2 and e3 < 2e-2                # same statistics up to fp32 summation order: bf16 rounding flips only
+    e42, e4 = rel_err(y4, y2), rel_err(y4[:2], _t(g["eps_hat"]))
+    record("cfg2_default_fused_eval_bf16", default_vs_two_pass_rel_l2=e42, default_vs_reference_rel_l2=e4, fused_launches=len(fused_default))
+    assert e42 < 2e-2 and e4 < 2e-2
 
 
 def test_graph_sampler_matches_eager():
