@@ -289,9 +289,10 @@ def main():
 
     model, net, opt = build(args.mode)
     reducer = None
+    bucket_mb = int(os.environ.get("MI_DDP_BUCKET_MB", "32"))
     if use_dist:
         broadcast_parameters(net.flat_params)
-        reducer = FlatGradReducer(net.flat_grads)
+        reducer = FlatGradReducer(net.flat_grads, bucket_bytes=bucket_mb << 20)
         net.grad_ready_hook = reducer.range_ready
         opt.grad_scale = reducer.grad_scale
 
@@ -311,15 +312,16 @@ def main():
         o.step()                                   # fused Adam over the flat buffer
         return loss
 
-    # hipGraph replay of the whole step (single process): same kernels, same order, one graph launch per step
-    use_graph = args.graph == 1 and not use_dist
+    # hipGraph replay of the step: same kernels, same order.  One graph launch per step in a single process; under data parallelism
+    # a chain of graphs cut at the gradient buckets with the all-reduces issued between them (src/runtime/graphed.py)
+    use_graph = args.graph == 1
     train_step = eager_step
     if use_graph:
-        from src.runtime.graphed import GraphedTrainStep
+        from src.runtime.graphed import GraphedTrainStep, SegmentedGraphedTrainStep
         opt.device_state = True
         for i in range(3):
             eager_step(i)
-        gstep = GraphedTrainStep(model, opt, batch, warmup=0)
+        gstep = SegmentedGraphedTrainStep(model, opt, reducer, batch) if reducer is not None else GraphedTrainStep(model, opt, batch, warmup=0)
         train_step = lambda i: gstep(batch)        # noqa: E731
 
     def sync():
@@ -356,7 +358,11 @@ def main():
             waits.append((e0, e1))
         torch.cuda.synchronize()
         ms = sorted(a.elapsed_time(b) for a, b in waits)
-        comm = {"allreduce_ms_exposed": round(ms[len(ms) // 2], 3), "buckets_bytes": [4 * (hi - lo) for lo, hi in reducer.launched]}
+        comm = {"allreduce_ms_exposed": round(ms[len(ms) // 2], 3), "buckets_bytes": [4 * (hi - lo) for lo, hi in reducer.launched],
+                # the knobs that decide how much of the chip the collectives take from backward
+                "bucket_mb": bucket_mb, "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
+                "NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"),
+                "graph_segments": len(gstep.segments) + 1 if (use_graph and reducer is not None) else None}
         if use_dist:
             t = torch.tensor([comm["allreduce_ms_exposed"]], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -1051,6 +1051,23 @@ class GaussianDiffusion(nn.Module):
         t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long()     # t first, then eps (RNG order)
         return self.p_losses(x, t, *args, **kwargs)
 
+    @torch.no_grad()
+    def loss_and_backward(self, x):
+        """forward(x) followed by loss.backward(), without autograd: the same draws (t, then eps), the same kernels in the same
+        order, the flat gradient buffer written by the UNet's tape replay -- all on the CALLING thread (autograd runs a CUDA node's
+        backward on its device worker thread), which is what lets the data-parallel graph step cut its stream capture into segments
+        from inside the gradient-ready hook (src/runtime/graphed.py).  -> the loss as a device scalar."""
+        net = self.denoise_fn
+        b = x.shape[0]
+        t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long()
+        x0 = x.float().contiguous()
+        noise = torch.randn_like(x0)
+        xt, _ = K.q_sample(x0, noise, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
+        eps, tape = net.forward_nhwc(xt, t, record=True)
+        loss, dpred = K.eps_loss(eps, noise, 0 if self.loss_type == "l1" else 1, want_grad=True)
+        net.backward_nhwc(tape, dpred, need_dx=False)
+        return loss
+
 
 # --------------------------------------------------------------------------------------------
 # LightningModule-shaped wrapper
@@ -1073,6 +1090,13 @@ class DDPM(BaseModel):
         imgs, _ = batch
         loss = self.diffusion_model(imgs)
         self.log("train_loss/loss", loss)          # logged as a device scalar: no per-step host sync
+        return loss
+
+    def training_step_and_backward(self, batch, batch_idx):
+        """training_step + loss.backward() in one autograd-free call (GaussianDiffusion.loss_and_backward)."""
+        imgs, _ = batch
+        loss = self.diffusion_model.loss_and_backward(imgs)
+        self.log("train_loss/loss", loss)
         return loss
 
     def configure_optimizers(self):

@@ -116,7 +116,13 @@ def _stream() -> C.c_void_p:
     """torch's current stream on the CURRENT device: kernels launch on the current HIP device, so every wrapper first checks
     (`_need_gpu`) that its tensors live there -- a rank that forgot `torch.cuda.set_device(LOCAL_RANK)` raises instead of
     launching on GPU 0 against another GPU's memory."""
+    global LAUNCHES
+    LAUNCHES += 1
     return C.c_void_p(_raw_stream(_cur_dev()))
+
+
+LAUNCHES = 0      # library launches so far (every wrapper fetches the stream once per launch): lets a stream capture know whether a
+                  # segment it is about to close recorded anything (src/runtime/graphed.py)
 
 
 # the raw forms of torch.cuda.current_device() / current_stream(): same answers (they follow torch.cuda.stream(...) contexts and

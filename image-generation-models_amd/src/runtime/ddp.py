@@ -32,7 +32,11 @@ class FlatGradReducer:
         self._lo: Optional[int] = None
         self._hi: Optional[int] = None
         self._covered = 0
+        self._tail_sent = False
         self.launched: List[tuple] = []          # (lo, hi) of every all-reduce of the current step
+        # stream capture of a step (src/runtime/graphed.py): a bucket that is ready is handed to this callable instead of being
+        # all-reduced -- the capture is cut there and the collective is issued between the replays of the two segments
+        self.capture_sink = None
 
     @property
     def grad_scale(self) -> float:
@@ -42,6 +46,7 @@ class FlatGradReducer:
         self._works.clear(); self.launched.clear()
         self._lo = self._hi = None
         self._covered = 0
+        self._tail_sent = False
 
     def _launch(self):
         lo, hi = self._lo, self._hi
@@ -51,8 +56,20 @@ class FlatGradReducer:
         if self.launched and hi < self.launched[-1][0]:
             hi = self.launched[-1][0]             # alignment padding between two ranges: keep the launches gap-free
         self.launched.append((lo, hi))
+        if self.capture_sink is not None:
+            self.capture_sink(lo, hi)
+        elif self.world > 1:
+            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def all_reduce_async(self, lo: int, hi: int):
+        """The collective of one recorded bucket (replay of a segmented graph step)."""
         if self.world > 1:
             self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait_all(self):
+        for w in self._works:
+            w.wait()
+        self._works.clear()
 
     def range_ready(self, lo: int, hi: int):
         """Gradients in flat[lo:hi) are final.  Called in descending address order by backward."""
@@ -63,7 +80,10 @@ class FlatGradReducer:
                 pass
             self._lo = min(self._lo, lo)
             self._hi = max(self._hi, hi)
-        if self._hi - self._lo >= self.bucket_elems or self._lo <= self.tail_elems:
+        if self._hi - self._lo >= self.bucket_elems:
+            self._launch()
+        elif self._lo <= self.tail_elems and not self._tail_sent:
+            self._tail_sent = True                    # ... once: what follows (< tail_bytes) goes out with finish(), not piece by piece
             self._launch()
 
     def finish(self):

@@ -60,7 +60,8 @@ class Trainer:
                  num_sanity_val_steps: int = 2, log_every_n_steps: int = 50, enable_checkpointing: bool = True,
                  default_root_dir: str = ".", fast_dev_run: bool = False, strategy: str = "auto", graph_step: bool = False, **unused):
         # graph_step (not a Lightning argument; `+trainer.graph_step=true`): replay training_step + backward + optimizer step as one
-        # hipGraph for the launch-bound models (src/runtime/graphed.py).  Single process, automatic optimization, fused Adam only.
+        # hipGraph (src/runtime/graphed.py); under data parallelism (DDPM) as a chain of graphs cut at the gradient buckets with the
+        # all-reduces issued between them.  Automatic optimization, fused Adam only.
         self.graph_step = bool(graph_step)
         self.devices = devices
         self.max_epochs, self.max_steps = max_epochs, max_steps
@@ -96,7 +97,11 @@ class Trainer:
         want_cpu = self.accelerator == "cpu" or self.devices in (0, "0")
         if want_cpu or not torch.cuda.is_available():
             return torch.device("cpu")
-        return torch.device("cuda", self.local_rank)       # replaces the nvidia-smi picker of train.py:44-45
+        # one process per GPU: rank r of the node drives device r (replaces the nvidia-smi picker of train.py:44-45).
+        # MI_DDPM_ONE_GPU_RANKS=1 (with MI_DIST_BACKEND=gloo): every rank on device 0 -- the data-parallel path on a 1-GPU box
+        if os.environ.get("MI_DDPM_ONE_GPU_RANKS") == "1":
+            return torch.device("cuda", 0)
+        return torch.device("cuda", self.local_rank)
 
     def _log_metric(self, name, value):
         self._pending[name] = value
@@ -122,8 +127,10 @@ class Trainer:
             return
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            backend = "nccl" if device.type == "cuda" else "gloo"       # nccl == RCCL on ROCm
-            dist.init_process_group(backend, device_id=device if device.type == "cuda" else None)
+            # nccl == RCCL on ROCm.  MI_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses that) -- how the data-parallel
+            # Trainer path is exercised on a single-GPU box (tests/test_ddp_gpu.py)
+            backend = os.environ.get("MI_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
+            dist.init_process_group(backend, device_id=device if (device.type == "cuda" and backend == "nccl") else None)
         from .ddp import FlatGradReducer, broadcast_parameters
         net = getattr(model, "denoising_model", None)
         if net is not None and hasattr(net, "flat_grads"):
@@ -178,8 +185,12 @@ class Trainer:
             optimizer.grad_scale = self._reducer.grad_scale
         self.optimizer = optimizer
         from .optim import FlatAdam
+        from .ddp import FlatGradReducer
+        # one graph per step without a reducer; under data parallelism the capture is cut at the gradient buckets (graphed.py), which
+        # needs the autograd-free step of the DDPM module and the overlapping single-buffer reducer
+        seg_graph = (isinstance(self._reducer, FlatGradReducer) and hasattr(model, "training_step_and_backward"))
         use_graph = (self.graph_step and not manual and isinstance(optimizer, FlatAdam) and device.type == "cuda"
-                     and self._reducer is None and self.world_size == 1)
+                     and (self._reducer is None or seg_graph))
         gstep = None
         if use_graph:
             optimizer.device_state = True
@@ -209,9 +220,10 @@ class Trainer:
                         self._log_metric(k_, v_)
                 elif use_graph and self.global_step >= 1 and gstep is None:
                     # step 0 ran eagerly (lazy module loads, workspaces, Adam state); capture on this batch and replay it once
-                    from .graphed import GraphedTrainStep
+                    from .graphed import GraphedTrainStep, SegmentedGraphedTrainStep
                     model._logged.clear()
-                    gstep = GraphedTrainStep(model, optimizer, batch, warmup=0)
+                    gstep = (SegmentedGraphedTrainStep(model, optimizer, self._reducer, batch) if self._reducer is not None
+                             else GraphedTrainStep(model, optimizer, batch, warmup=0))
                     gstep.logged = dict(model._logged)
                     gstep(batch)
                     for k_, v_ in gstep.logged.items():
