@@ -490,7 +490,7 @@ class Unet(nn.Module):
             if mode == K.MODE_BF16 and k in (1, 3) and stride == 1 and not transposed_conv:
                 y = K.conv3x3_bf16w(inp, wf_sh[offs[pre + "weight"]:], K=ci, Nc=co, flip=False, ksize=k, x2=x2,
                                     bias=sv[pre + "bias"] if bias else None, residual=residual, out_dtype=out_dtype, gn_sums=gn_sums,
-                                    want16=want16, wq=wfq_sh[offs[pre + "weight"]:] if k == 3 else None)
+                                    want16=want16, wq=wfq_sh[offs[pre + "weight"]:])
                 if y is not None:
                     if want16:                      # the epilogue wrote the bf16 copy along: register it for the consumers
                         sh[id(y[0])] = y
@@ -728,7 +728,7 @@ class Unet(nn.Module):
             if x2 is None:
                 buf, acc = G.target(inp)
                 if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, ksize=k, out=buf,
-                                            accumulate=acc, wq=wdq_sh[offs[pre + "weight"]:] if k == 3 else None) is not None:
+                                            accumulate=acc, wq=wdq_sh[offs[pre + "weight"]:]) is not None:
                     return
                 assert dy.dtype == torch.float32 and buf.dtype == torch.float32, "bf16 block storage needs the tile kernel"
                 if dy16 is not None and K.igemm_bf16_in_supported(co, ci, k, stride, not transposed_conv, mode, (ih, iw)):
@@ -744,7 +744,7 @@ class Unet(nn.Module):
                     cat = torch.empty((B, ih, iw, ci), device=dy.device, dtype=torch.float32)
                     G._g[("cat", id(inp))] = cat
                 if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, ksize=k, out=cat,
-                                            accumulate=acc, wq=wdq_sh[offs[pre + "weight"]:] if k == 3 else None) is not None:
+                                            accumulate=acc, wq=wdq_sh[offs[pre + "weight"]:]) is not None:
                     return
                 K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=True, w_kn=False,
                              K=co, Nc=ci, out_hw=(ih, iw), mode=mode, out=cat, accumulate=acc)

@@ -241,6 +241,19 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
     io = _b16(x) | (_b16(out) << 1)
     assert x2 is None or x2.dtype == x.dtype
     pick = "halo"
+    if (ksize == 1 and wq is not None and USE_CONV_PW and _b16(x) and x2 is None and gn_sums is None and K == 128
+            and _query("mi_conv1x1_pw_supported", d)):
+        # K = 128: the whole tile staged once, per-wave weight streams, whole-row stores (conv1x1_pw_kernel)
+        y16 = new_act(N, H, W, Nc, x, torch.bfloat16) if want16 else None
+        assert not (want16 and (accumulate or _b16(out)))
+        e0 = _probe_open()
+        check(lib.mi_conv1x1_pw(C.byref(d), _p(x), _p(wq), _p(bias), _p(residual), _p(out), _b16(out), _p(y16),
+                                ld_of(y16) if y16 is not None else 0, _stream()), "mi_conv1x1_pw")
+        if e0 is not None:
+            nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual) + (2 if want16 else 0)) + K * Nc * 2)
+            _probe_close(e0, f"conv1x1_pw_kernel<{'true' if _b16(out) else 'false'}, {'true' if want16 else 'false'}>", 2.0 * N * H * W * Nc * K,
+                         f"N{N} {H}x{W} K{K}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
+        return (out, y16) if want16 else out
     if (gn_sums is not None and ksize == 3 and _b16(x) and USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc)
             and _query("mi_conv3x3_pw_supported", d)):
         # the next layer's GroupNorm sums from the private-weight-stream kernel's epilogue
@@ -420,12 +433,13 @@ PACK_ENTRY = [("off", "<i8"), ("taps", "<i4"), ("ci", "<i4"), ("co", "<i4"), ("t
 
 def pack_table(entries, device):
     """Device table for mi_pack_weights_bf16 from (float offset, taps, ci, co) per conv weight -> (table, nent, total tiles).
-    3x3 layers with ci % 64 == 0 and co % 64 == 0 are flagged for the MFMA-fragment-order copies (mi_conv3x3_pw's operands)."""
+    3x3 and 1x1 layers with ci % 64 == 0 and co % 64 == 0 are flagged for the MFMA-fragment-order copies (the operands of
+    mi_conv3x3_pw / mi_conv1x1_pw)."""
     import numpy as np
     rec = np.zeros(len(entries), dtype=np.dtype(PACK_ENTRY))
     tile, T = 0, pack_weights_tile()
     for i, (off, taps, ci, co) in enumerate(entries):
-        rec[i] = (off, taps, ci, co, tile, int(taps == 9 and ci % 64 == 0 and co % 64 == 0), 0)
+        rec[i] = (off, taps, ci, co, tile, int(taps in (1, 9) and ci % 64 == 0 and co % 64 == 0), 0)
         tile += taps * ((ci + T - 1) // T) * ((co + T - 1) // T)
     return torch.from_numpy(rec.view(np.uint8).copy()).to(device), len(entries), tile
 

@@ -78,6 +78,8 @@ SIGNATURES = {
     "mi_conv3x3_pw_supported": [C.POINTER(MiConvDesc)],
     "mi_conv3x3_pw": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
     "mi_conv3x3_pw_gn_mish_supported": [C.POINTER(MiConvDesc)],
+    "mi_conv1x1_pw_supported": [C.POINTER(MiConvDesc)],
+    "mi_conv1x1_pw": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P],
     "mi_conv3x3_pw_gnsums": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "mi_conv3x3_pw_gn_mish": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _P],
     "mi_conv3x3_pw_gn_mish_sums": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _I, _P],

@@ -184,6 +184,13 @@ int mi_conv3x3_pw_gn_mish(const MiConvDesc* d, const void* x, const float* coef,
 /* ... or without the coefficient tensor: scale / shift are resolved per channel chunk inside the kernel from the sums the producing
  * conv's epilogue left (sums [N][K/16][2], mi_conv3x3_pw_gnsums / mi_conv3x3_bf16w_io_gnsums), gamma, beta and the time-bias rows
  * temb [N][ldt] (optional) with mi_gn_coef_from_sums' arithmetic.  K / G in {16, 32, 64}.  Block -> Block = two launches. */
+/* ---- 1x1 convs with K = 128 input channels on the same machinery (to_qkv, to_out + residual, res_conv 128 -> 256, the data gradient of
+ * to_out at 128 channels; reference src/models/ddpm.py:134,151-152): the whole 128-pixel x 128-channel tile is staged once, the weights
+ * stream per wave, whole rows leave through LDS.  w_frag_bf16 = the layer's slice of wfq (forward) / wdq (data gradient); y fp32 or
+ * bf16 (out_bf16); y_bf16 (optional, fp32 y, no accumulate): the bf16 copy of y from the same epilogue (pixel stride ldy16). */
+int mi_conv1x1_pw_supported(const MiConvDesc* d);
+int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* w_frag_bf16, const float* bias, const float* residual,
+                  void* y, int out_bf16, void* y_bf16, int ldy16, void* stream);
 int mi_conv3x3_pw_gn_mish_sums(const MiConvDesc* d, const void* x, const float* sums, const float* gamma, const float* beta,
                                const float* temb, int ldt, int G, float eps, const void* w_frag_bf16, const float* bias,
                                void* y, int out_bf16, void* stream);

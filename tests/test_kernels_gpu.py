@@ -661,28 +661,78 @@ def test_fused_gn_mish_conv3x3_pw(K, cfg, out16, pw_always):
         assert rel_err(yb.float().cpu().permute(0, 3, 1, 2).double()[:, :Co], ref) < 6e-3
 
 
+@pytest.mark.parametrize("cfg", [dict(N=8, H=32, Co=384, kind="qkv"), dict(N=4, H=16, Co=128, kind="out"), dict(N=16, H=8, Co=256, kind="res"),
+                                 dict(N=2, H=16, Co=96, kind="res"), dict(N=8, H=16, Co=128, kind="dgrad")])
+def test_conv1x1_pw(K, cfg, pw_always):
+    """The 1x1 convs with 128 input channels through mi_conv1x1_pw (reference ddpm.py:134,151-152): to_qkv (no bias, bf16 out),
+    to_out (bias + fp32 residual, fp32 out AND its bf16 copy from the same epilogue), res_conv (bias, fp32 out, a ragged channel tile),
+    and the data gradient of to_out (transposed weights, accumulate into an fp32 buffer); against fp64 on the bf16-rounded operands."""
+    N, H, Co, kind = cfg["N"], cfg["H"], cfg["Co"], cfg["kind"]
+    Ci = 128
+    g = torch.Generator().manual_seed(83)
+    x = torch.randn(N, Ci, H, H, generator=g).bfloat16()
+    Cop = (Co + 63) // 64 * 64
+    w = torch.zeros(Cop, Ci, 1, 1)
+    w[:Co] = torch.randn(Co, Ci, 1, 1, generator=g) / math.sqrt(Ci)
+    b = torch.zeros(Cop); b[:Co] = torch.randn(Co, generator=g)
+    r = torch.randn(N, Cop, H, H, generator=g)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+    wq64 = w.bfloat16().double()
+    if kind == "dgrad":
+        # data gradient of a Cop -> 128 conv... here: dX[p][ci] = sum_co dY[p][co] W[co][ci] with co = the 128 "input" channels
+        wt = torch.randn(Ci, Cop, 1, 1, generator=g) / math.sqrt(Ci)          # forward weight [co = 128][ci = Cop]
+        flat, wd, wf, offs, wdq, wfq = _pack(K, [conv_w_storage(wt.double())], frag=True)
+        dy = x                                                                 # [N][128][H][H] bf16
+        prev = torch.randn(N, H, H, Cop, generator=g).to(DEV)
+        ref = F.conv_transpose2d(dy.double(), wt.bfloat16().double()) + prev.cpu().permute(0, 3, 1, 2).double()
+        out = K.conv3x3_bf16w(nh(dy), wd, K=Ci, Nc=Cop, flip=True, ksize=1, out=prev.clone(), accumulate=True, wq=wdq)
+        torch.cuda.synchronize()
+        assert _conv_launches(pw_always)[-1].startswith("conv1x1_pw_kernel")
+        assert rel_err(from_nhwc(out), ref) < 1e-5
+        return
+    flat, wd, wf, offs, wdq, wfq = _pack(K, [conv_w_storage(w.double())], frag=True)
+    y64 = F.conv2d(x.double(), wq64)
+    if kind == "qkv":
+        y = K.conv3x3_bf16w(nh(x), wf, K=Ci, Nc=Cop, flip=False, ksize=1, out_dtype=torch.bfloat16, wq=wfq)
+        torch.cuda.synchronize()
+        assert y.dtype == torch.bfloat16 and rel_err(from_nhwc(y.float()), y64) < 6e-3
+    elif kind == "out":
+        ref = y64 + b.double()[None, :, None, None] + r.double()
+        y, y16 = K.conv3x3_bf16w(nh(x), wf, K=Ci, Nc=Cop, flip=False, ksize=1, bias=b.to(DEV), residual=to_nhwc_gpu(r), want16=True, wq=wfq)
+        torch.cuda.synchronize()
+        assert rel_err(from_nhwc(y), ref) < 1e-5 and torch.equal(y16, y.bfloat16())
+    else:
+        ref = y64 + b.double()[None, :, None, None]
+        y = K.conv3x3_bf16w(nh(x), wf, K=Ci, Nc=Cop, flip=False, ksize=1, bias=b.to(DEV), wq=wfq)
+        torch.cuda.synchronize()
+        assert rel_err(from_nhwc(y)[:, :Co], ref[:, :Co]) < 1e-5 and not y[..., Co:].any()
+    assert _conv_launches(pw_always)[-1].startswith("conv1x1_pw_kernel"), _conv_launches(pw_always)
+
+
 def test_pack_weights_fragment_order(K):
     """The MFMA-fragment-order copies mi_conv3x3_pw streams (include/mi_ddpm.h): wfq[tap][co/32][ci/16][lane][8] and
-    wdq[tap][ci/32][co/16][lane][8]; layers that are not 3x3 with 64-multiples on both sides get none (their slice stays zero)."""
+    wdq[tap][ci/32][co/16][lane][8] for the 3x3 and 1x1 layers with 64-multiples on both sides; the others get none (zero slice)."""
     g = torch.Generator().manual_seed(29)
     ws = [torch.randn(3, 3, 128, 64, generator=g).to(DEV), torch.randn(1, 1, 128, 384, generator=g).to(DEV),
-          torch.randn(3, 3, 192, 256, generator=g).to(DEV), torch.randn(3, 3, 40, 64, generator=g).to(DEV)]
+          torch.randn(3, 3, 192, 256, generator=g).to(DEV), torch.randn(3, 3, 40, 64, generator=g).to(DEV),
+          torch.randn(4, 4, 64, 64, generator=g).to(DEV)]
     flat, wd, wf, offs, wdq, wfq = _pack(K, ws, frag=True)
     torch.cuda.synchronize()
     for w, o in zip(ws, offs):
         kh, kw, ci, co = w.shape
         n = w.numel()
         assert torch.equal(wd[o:o + n].view(w.shape), w.to(torch.bfloat16))            # the plain copies are unchanged
-        if kh * kw != 9 or ci % 64 or co % 64:
+        if kh * kw not in (1, 9) or ci % 64 or co % 64:
             assert not wdq[o:o + n].any() and not wfq[o:o + n].any()
             continue
-        wb = w.to(torch.bfloat16).view(9, ci, co)
+        T = kh * kw
+        wb = w.to(torch.bfloat16).view(T, ci, co)
         # lane l, element e of fragment (nb, kq): row 32 nb + (l & 31), column 16 kq + 8 (l >> 5) + e
-        fq = wfq[o:o + n].view(9, co // 32, ci // 16, 2, 32, 8)          # [tap][nb][kq][l >> 5][l & 31][e]
-        ref_f = wb.permute(0, 2, 1).reshape(9, co // 32, 32, ci // 16, 2, 8).permute(0, 1, 3, 4, 2, 5)
+        fq = wfq[o:o + n].view(T, co // 32, ci // 16, 2, 32, 8)          # [tap][nb][kq][l >> 5][l & 31][e]
+        ref_f = wb.permute(0, 2, 1).reshape(T, co // 32, 32, ci // 16, 2, 8).permute(0, 1, 3, 4, 2, 5)
         assert torch.equal(fq, ref_f.contiguous())
-        dq = wdq[o:o + n].view(9, ci // 32, co // 16, 2, 32, 8)
-        ref_d = wb.reshape(9, ci // 32, 32, co // 16, 2, 8).permute(0, 1, 3, 4, 2, 5)
+        dq = wdq[o:o + n].view(T, ci // 32, co // 16, 2, 32, 8)
+        ref_d = wb.reshape(T, ci // 32, 32, co // 16, 2, 8).permute(0, 1, 3, 4, 2, 5)
         assert torch.equal(dq, ref_d.contiguous())
 
 
