@@ -63,6 +63,13 @@ __device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32
                  : "=&s"(keep) : "v"(voff), "s"(q), "s"(dst) : "memory");
 }
 
+// 16 bytes per lane from sbase + voff + IMM straight into registers; asynchronous: the caller counts it (s_waitcnt vmcnt) and touches
+// dst again only behind that wait
+template <int IMM> __device__ __forceinline__ void gload16s(u32x4& dst, uint64_t sbase, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ void landed16(u32x4& r) { asm volatile("" : "+v"(r)); }
+
 __device__ __forceinline__ bf16x8 lds_b128p(uint32_t addr) {
     typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
     return *(lds_bf16x8*)(uintptr_t)addr;
@@ -75,17 +82,20 @@ __device__ __forceinline__ bf16x8 lds_b128p(uint32_t addr) {
 template <int DIR> __device__ __forceinline__ bf16x8 pw_shift(const bf16x8& c, uint32_t mask) {
     const u32x4 v = __builtin_bit_cast(u32x4, c);
     u32x4 o;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        uint32_t r;
-        if constexpr (DIR == 0)
-            asm("v_and_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v[q]), "v"(mask));
-        else
-            asm("v_and_b32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v[q]), "v"(mask));
-        o[q] = r;
-    }
-    // VALU write -> MFMA operand read needs two wait states; hipcc does not see the VALU instruction inside the statements above
-    asm("s_nop 1" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+    // (one statement: hipcc pads every asm statement that precedes an MFMA with an s_nop of its own.  The trailing s_nop 1: a VALU
+    //  write -> MFMA operand read needs two wait states and hipcc does not see the VALU instructions in here)
+    if constexpr (DIR == 0)
+        asm("v_and_b32_dpp %0, %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_and_b32_dpp %1, %5, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_and_b32_dpp %2, %6, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_and_b32_dpp %3, %7, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1"
+            : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(mask));
+    else
+        asm("v_and_b32_dpp %0, %4, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_and_b32_dpp %1, %5, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_and_b32_dpp %2, %6, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_and_b32_dpp %3, %7, %8 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1"
+            : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(mask));
     return __builtin_bit_cast(bf16x8, o);
 }
 
@@ -97,11 +107,19 @@ constexpr bool pw_is_x(int s) { return s >= 0 && s % 3 == 1 && s / 3 < PXPW; }
 constexpr int pw_ncoef(int var) { return var == 2 ? 6 : var == 3 ? 10 : 0; }
 constexpr int pw_extra(int q, int var) { return (pw_is_x(q) ? 1 : 0) + (q == 0 ? pw_ncoef(var) : 0); }
 // DMA instructions issued after the request of the fragment that unit s reads (unit s + PRD's fragment), up to the start of unit s
-constexpr int pw_newer(int s, int var) {
-    int n = pw_extra(s - (PDD - PRD), var);
-    for (int q = s - (PDD - PRD - 1); q < s; ++q) n += 1 + pw_extra(q, var);
+constexpr int pw_newer(int s, int var, int dd = PDD, int rd = PRD) {
+    int n = pw_extra(s - (dd - rd), var);
+    for (int q = s - (dd - rd - 1); q < s; ++q) n += 1 + pw_extra(q, var);
     return n;
 }
+// Plain variants (VAR < 2): the fragments do not pass through LDS at all -- they are wave-private, so each lane loads ITS 16 bytes of a
+// fragment straight into the registers the MFMA reads (global_load_dwordx4, counted by hand like the DMA), PWR fragments in a
+// register ring, the load of unit s + PWD issued in unit s.  No ring in LDS (two 24 KB activation buffers + the epilogue's 64 KB
+// tile), no ds_read per unit, no M0 juggling.  Measured with the ablation build: the fragment DMA cost 5-14 % and the LDS reads
+// 14-20 % of the kernel, 43 % of them the fragments'.
+constexpr int PWR = 9;                          // 36 % PWR == 0: a unit's ring slot is s % PWR in every chunk
+constexpr int PWD = PWR - 1;
+constexpr int PLDS_WD = 66 * 1024;
 // fused variants: piece i of the next chunk (requested in unit 3i + 1) is read back in unit 3i + 7 (its request is older than
 // anything that unit's counted wait leaves in flight), transformed one packed register (two elements) per unit in units 3i + 8 ..
 // 3i + 11 -- right behind the unit's first MFMA, so that the exp / rcp chain runs under the other three -- and written back in 3i + 11
@@ -117,10 +135,12 @@ constexpr bool pw_has_part(int s) {
 // + Mish + time bias, reference src/models/ddpm.py:112-120,139-141) is applied ONCE per staged element: every wave transforms the
 // pieces it requested itself, in place in LDS, after its own counted wait and before the chunk barrier publishes them; rows outside
 // the image stay zero.  One image per tile (TI == 1).
-// ABL (profiling builds only, -DMI_PW_ABL_BUILD): 1 no fragment DMA in the main loop, 2 no activation DMA in the main loop, 4 no stores
+// ABL (profiling builds only, -DMI_PW_ABL_BUILD): 1 no fragment DMA in the main loop, 2 no activation DMA in the main loop, 4 no stores,
+// 16 no DPP shifts (every tap column multiplies the centre fragments), 32 no LDS fragment reads in the main loop
 template <bool OUT16, int VAR = 0, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
-    constexpr bool FUSE = VAR >= 2, GNS = VAR == 1;
+    constexpr bool FUSE = VAR >= 2, GNS = VAR == 1, WD = VAR < 2;
+    constexpr int DD = WD ? PWD : PDD, RD = WD ? 1 : PRD;          // request distance, wait-ahead distance (units)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
     const int t = threadIdx.x, l = t & 63;
@@ -287,6 +307,20 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         glds16s(wsrc + off, wl16, wring + (((s & 7) * 1024) ^ ph));
     };
 
+    // direct variant: tap t's fragments of the current chunk start at wtap[t] (scalar), step ks at +1024 (the instruction's offset)
+    u32x4 WR[WD ? PWR : 1];
+    auto wbase = [&](int ch, int tap) -> uint64_t {
+        const uint64_t p = (uint64_t)(uintptr_t)(wsrc + (size_t)(a.flip ? 8 - tap : tap) * tap_bytes + (size_t)min(ch, nchunks - 1) * 4096);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    auto load_w = [&](int ch, auto sc) {
+        constexpr int s0 = decltype(sc)::value, over = s0 >= 36 ? 1 : 0, s = s0 - 36 * over;
+        constexpr int ky = s / 12, ks = (s / 3) % 4, j = s % 3, tap = ky * 3 + (j == 0 ? 1 : (j == 1 ? 0 : 2));
+        const uint64_t b = wbase(ch + over, tap);
+        gload16s<ks * 1024>(WR[s % PWR], b, wl16);
+    };
+
     // ---- fragment addressing.  Activations (MFMA "B" operand): lane -> pixel (l & 31) of the wave's i-th 32-pixel block (whole
     //      image rows), 8-channel piece 2*ks + (l >> 5); weights ("A"): lane -> its own 16 bytes of the fragment.
     uint32_t xa[4][3];                                       // byte offset of (block i, tap row ky), 16-channel step 0
@@ -317,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     if constexpr (FUSE) load_coef(0);
 #pragma unroll
     for (int i = 0; i < PXPW; ++i) stage_x(0, i);
-    static_for<0, PDD>([&](auto sc) { stage_w(0, sc); });
+    static_for<0, DD>([&](auto sc) { if constexpr (WD) load_w(0, sc); else stage_w(0, sc); });
     if constexpr (FUSE) {
         asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PDD) : "memory");       // coefficients and rows of chunk 0
         coef_landed();
@@ -336,12 +370,13 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         });
     }
     // the rows and fragments 0 .. PRD-1 have landed (this wave's; the fused variant's rewritten pieces are in LDS) ...
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(PDD - PRD) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(DD - RD) : "memory");
     __builtin_amdgcn_s_barrier();                                          // ... every wave's
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 4; ++i) XC[0][i] = lds_b128p(xa[i][0]);
-    static_for<0, PRD>([&](auto sc) { FW[decltype(sc)::value] = lds_b128p(wrd0 + decltype(sc)::value * 1024); });
+    if constexpr (WD) landed16(WR[0]);
+    else static_for<0, PRD>([&](auto sc) { FW[decltype(sc)::value] = lds_b128p(wrd0 + decltype(sc)::value * 1024); });
 
     static_assert(36 % (PRD + 1) == 0, "fragment register slots line up across chunks");
     // one chunk: 36 units.  Fused variants: EVERY chunk runs the transform parts -- in the last one they rewrite the clamped re-fetch of
@@ -357,12 +392,19 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             auto unit = [&](auto more_c) {
                 constexpr bool MORE = decltype(more_c)::value;
                 // the fragment of unit s + PRD has landed ...
-                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(pw_newer(s, VAR)) : "memory");
-                {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(pw_newer(s, VAR, DD, RD)) : "memory");
+                if constexpr (WD) landed16(WR[(s + 1) % PWR]);    // (its value exists from here on)
+                else {
                     constexpr int sr = s + PRD, over = sr >= 36 ? 1 : 0, srr = sr - 36 * over;
+                    if constexpr (!(ABL & 32))
                     FW[sr % (PRD + 1)] = lds_b128p((((srr & 4) != 0) != (over != 0) ? wflip : wsame) + (srr & 3) * 1024);
                 }
-                if constexpr (j == 0) {                      // the next group's centre-column fragments
+                if constexpr (j == 0 && (ABL & 32)) {
+                    if constexpr (g == 11) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(XC[(g + 1) & 1][i]));
+                }
+                if constexpr (j == 0 && !(ABL & 32)) {       // the next group's centre-column fragments
                     if constexpr (g == 11) {
                         // chunk boundary: every wave has read all it needs of this chunk's rows and has its pieces of the next
                         // chunk's (their requests are older than the fragment just waited for)
@@ -378,8 +420,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                     }
                 }
                 // ring slot of unit s - 1 is free (its fragment is in registers since the previous unit's MFMAs)
-                if constexpr (!(ABL & 1)) stage_w(ch, std::integral_constant<int, s + PDD>{});
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if constexpr (WD) load_w(ch, std::integral_constant<int, s + PWD>{});
+                else stage_w(ch, std::integral_constant<int, s + PDD>{});
                 if constexpr (pw_is_x(s) && !(ABL & 2)) stage_x(ch + 1, s / 3);
                 if constexpr (FUSE && s == 0) load_coef(ch + 1);
                 if constexpr (FUSE && s == PTU - 2) coef_landed();
@@ -394,10 +437,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                 static_for<0, 4>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     bf16x8 xf;
-                    if constexpr (j == 0) xf = XC[g & 1][i];
+                    if constexpr (j == 0 || (ABL & 16)) xf = XC[g & 1][i];
                     else if constexpr (j == 1) xf = pw_shift<0>(XC[g & 1][i], mask_l);
                     else xf = pw_shift<1>(XC[g & 1][i], mask_r);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FW[s % (PRD + 1)], xf, acc[i], 0, 0, 0);
+                    if constexpr (WD) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WR[s % PWR]), xf, acc[i], 0, 0, 0);
+                    else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FW[s % (PRD + 1)], xf, acc[i], 0, 0, 0);
                 });
                 if constexpr (FUSE && MORE) {
                     static_for<0, PXPW>([&](auto pc) {
@@ -706,7 +750,7 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     a.qmap = 0; a.gx = (int)grid.x; a.gy = (int)grid.y;
     if (!a.xmap && a.gy > 1 && a.gy % 2 == 0 && a.gx % 4 == 0) { a.qmap = 2; grid = dim3(grid.x * grid.y, 1, 1); }
     hipStream_t st = (hipStream_t)stream;
-    size_t lds = PLDS;
+    size_t lds = var < 2 ? PLDS_WD : PLDS;
 #define MI_PW_GO(O16, V, A) do { \
         static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, A>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
         (void)once_; \
@@ -714,14 +758,14 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
 #ifdef MI_PW_ABL_BUILD
     static const int abl = [] { const char* e = getenv("MI_PW_ABL"); return e ? atoi(e) : 0; }();
     if (abl & 8) lds = 100 * 1024;            // one workgroup per CU
-    if (var == 0 && (abl & 7)) {
-        switch (abl & 7) {
-            case 1: if (out_bf16) MI_PW_GO(true, 0, 1); else MI_PW_GO(false, 0, 1); break;
-            case 2: if (out_bf16) MI_PW_GO(true, 0, 2); else MI_PW_GO(false, 0, 2); break;
-            case 3: if (out_bf16) MI_PW_GO(true, 0, 3); else MI_PW_GO(false, 0, 3); break;
-            case 4: if (out_bf16) MI_PW_GO(true, 0, 4); else MI_PW_GO(false, 0, 4); break;
-            default: if (out_bf16) MI_PW_GO(true, 0, 7); else MI_PW_GO(false, 0, 7); break;
+    if (var == 0 && (abl & 0x37)) {
+#define MI_PW_ABL_CASE(V) case V: if (out_bf16) MI_PW_GO(true, 0, V); else MI_PW_GO(false, 0, V); break;
+        switch (abl & 0x37) {
+            MI_PW_ABL_CASE(1) MI_PW_ABL_CASE(2) MI_PW_ABL_CASE(3) MI_PW_ABL_CASE(4) MI_PW_ABL_CASE(7)
+            MI_PW_ABL_CASE(16) MI_PW_ABL_CASE(23) MI_PW_ABL_CASE(32) MI_PW_ABL_CASE(48) MI_PW_ABL_CASE(55)
+            default: return mi_set_error(-1, "MI_PW_ABL: combination not built");
         }
+#undef MI_PW_ABL_CASE
         hipError_t e_ = hipGetLastError();
         return e_ == hipSuccess ? 0 : mi_set_error((int)e_, "%s: %s", who, hipGetErrorString(e_));
     }

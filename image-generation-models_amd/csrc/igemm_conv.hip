@@ -648,7 +648,9 @@ static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, 
     if (bn64 == false && bm64 && (long)((a.Mc + 63) / 64) * ((d->Nc + 127) / 128) * classes < 384) bn64 = true;
     // aligned bf16 layers with few taps per class: the straight-line ring kernel
     static const int allow_fast = [] { const char* e = getenv("MI_IGEMM_FAST"); return e ? atoi(e) : 1; }();
-    if (allow_fast && !ragged && d->mode == 1 && wb && a.ksplit == 1 && d->K % 32 == 0 && d->K1 % 32 == 0 && a.vecA && classes <= 4 &&
+    // (bf16-stored activations exist only on the ring kernel: the profiling switch does not apply to them, so that
+    //  mi_conv_igemm_bf16w_io_supported() and this dispatch agree)
+    if ((allow_fast || in16) && !ragged && d->mode == 1 && wb && a.ksplit == 1 && d->K % 32 == 0 && d->K1 % 32 == 0 && a.vecA && classes <= 4 &&
         d->KH * d->KW <= 16) {
         FastTaps tt;
         bool ok = true;

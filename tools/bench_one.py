@@ -61,6 +61,12 @@ for _ in range(5):
     elif which == "shift":       # conv_shift, the default kernel of the bf16-stored >= 128-channel layers
         K.USE_CONV_SHIFT = True
         K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, out=y)
+    elif which == "pw":          # the private-weight-stream kernel (conv_pw.hip), the default of the bf16-stored layers with >= 200 tiles
+        if "WQ" not in globals():
+            table, nent, tiles = K.pack_table([(0, 9, Ci, Co)], DEV)
+            WQ = [torch.zeros(w.numel(), device=DEV, dtype=torch.bfloat16) for _ in range(4)]
+            K.pack_weights_bf16(table, nent, tiles, w.reshape(-1), *WQ)
+        K.conv3x3_bf16w(x, WQ[1], K=Ci, Nc=Co, flip=False, out=y, wq=WQ[3])
     elif which == "igemm":
         K.conv_igemm(x, w, kh=3, kw=3, stride=1, pad=1, transposed=False, w_kn=True, K=Ci, Nc=Co, out_hw=(H, H), mode=1, out=y)
 torch.cuda.synchronize()
