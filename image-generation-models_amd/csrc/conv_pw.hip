@@ -7,17 +7,23 @@
 // activation rows arriving from HBM) and epilogue (its output stores) overlapped nothing: one workgroup per CU.  Here
 //   * a workgroup = 4 waves = 128 output pixels (whole image rows) x 128 output channels; wave w owns ALL 128 pixels of the
 //     channels [32w, 32w + 32): four 32x32 MFMA tiles, 64 accumulator registers;
-//   * the weights a wave needs are needed by no other wave of the workgroup, so each wave streams its own: the bf16 copy is kept in
+//   * the weights a wave needs are needed by no other wave of the workgroup, so they never touch LDS: the bf16 copy is kept in
 //     MFMA-FRAGMENT order ([tap][co / 32][ci / 16][lane][8], written by mi_pack_weights_bf16), a fragment is 1 KB contiguous in
-//     memory, goes to the wave's private 8 KB ring in LDS with ONE global_load_lds_dwordx4 (lane-linear source and destination) and
-//     is read back with one conflict-free ds_read_b128; the wave waits for its own DMA with a counted s_waitcnt vmcnt(N) -- no
-//     barrier.  Seven fragments (28 MFMAs) are in flight per wave;
+//     memory and each lane loads ITS 16 bytes of it straight into the registers the MFMA reads (global_load_dwordx4 with a scalar
+//     base per tap, issued from asm and counted by hand).  The nine fragments of a 16-channel step arrive during the step before;
 //   * the activation tile (TH + 2 rows x 64 channels, XOR-swizzled through the DMA source address) is shared and double-buffered per
-//     64-channel chunk: ONE barrier per chunk (144 MFMAs per wave) instead of nine;
-//   * only the centre tap column's activation fragments are read from LDS (once per tap row and 16-channel step, 4 reads); the left /
-//     right columns are one-lane DPP shifts of them (conv_shift.hip): 7 LDS fragment reads per 12 MFMAs;
-//   * 80 KB of LDS and <= 128 registers per lane... two workgroups per CU: one computes while the other waits for its first rows or
-//     drains its stores, and every SIMD has two independent instruction streams.
+//     64-channel chunk (LDS-DMA): ONE barrier per chunk (144 MFMAs per wave) instead of nine;
+//   * a 32-pixel MFMA block is output row i of every 4-row band of the tile, so "tap row ky of output row i" is "halo row i + ky":
+//     ONE activation fragment per halo row serves the three tap rows, and only the centre tap column is read from LDS -- the left /
+//     right columns are one-lane DPP shifts of it (conv_shift.hip), made once per halo row: per 16-channel step 6 LDS fragment
+//     reads and 12 shifts feed 36 MFMAs;
+//   * 66 KB of LDS and <= 256 registers per lane: two workgroups per CU -- one computes while the other waits for its first rows or
+//     drains its stores.
+// What it measures (B = 128, bf16 in / out, tools/bench_pw.py; round 2's per-shape pick beside it): 128 -> 128 @32x32 38-39 us (52-54),
+// 256 -> 256 @16x16 34 us (41-43), 512 -> 512 @8x8 33.5-34.7 us (43-45) = 1.11-1.15 PFLOP/s.  Ablations of this structure (profiling
+// build, tools/abl_pw.sh): the DPP shifts are free (<= 4 %), waiting for loads is free (a build that never waits: +-1 %), what
+// costs is ISSUING vector-memory instructions next to the MFMA stream -- without the fragment loads -19 % on the deep layers,
+// without the activation DMA -16 %, without the output stores -7..12 %; the same time with one and with two waves per SIMD.
 #include "tr_common.h"
 
 namespace {
@@ -99,36 +105,8 @@ template <int DIR> __device__ __forceinline__ bf16x8 pw_shift(const bf16x8& c, u
     return __builtin_bit_cast(bf16x8, o);
 }
 
-// Unit s (0..35) of a chunk body = (tap row ky, 16-channel step ks, tap column j in the order centre, left, right).
-// Activation piece i of the NEXT chunk is requested in unit 3i + 1.
-constexpr bool pw_is_x(int s) { return s >= 0 && s % 3 == 1 && s / 3 < PXPW; }
-// vector-memory instructions a unit issues after its fragment request: its activation piece, and (fused variants, unit 0) the
-// coefficient loads of the next chunk
 constexpr int pw_ncoef(int var) { return var == 2 ? 6 : var == 3 ? 10 : 0; }
-constexpr int pw_extra(int q, int var) { return (pw_is_x(q) ? 1 : 0) + (q == 0 ? pw_ncoef(var) : 0); }
-// DMA instructions issued after the request of the fragment that unit s reads (unit s + PRD's fragment), up to the start of unit s
-constexpr int pw_newer(int s, int var, int dd = PDD, int rd = PRD) {
-    int n = pw_extra(s - (dd - rd), var);
-    for (int q = s - (dd - rd - 1); q < s; ++q) n += 1 + pw_extra(q, var);
-    return n;
-}
-// Plain variants (VAR < 2): the fragments do not pass through LDS at all -- they are wave-private, so each lane loads ITS 16 bytes of a
-// fragment straight into the registers the MFMA reads (global_load_dwordx4, counted by hand like the DMA), PWR fragments in a
-// register ring, the load of unit s + PWD issued in unit s.  No ring in LDS (two 24 KB activation buffers + the epilogue's 64 KB
-// tile), no ds_read per unit, no M0 juggling.  Measured with the ablation build: the fragment DMA cost 5-14 % and the LDS reads
-// 14-20 % of the kernel, 43 % of them the fragments'.
-constexpr int PWR = 9;                          // 36 % PWR == 0: a unit's ring slot is s % PWR in every chunk
-constexpr int PWD = PWR - 1;
-constexpr int PLDS_WD = 66 * 1024;
-// fused variants: piece i of the next chunk (requested in unit 3i + 1) is read back in unit 3i + 7 (its request is older than
-// anything that unit's counted wait leaves in flight), transformed one packed register (two elements) per unit in units 3i + 8 ..
-// 3i + 11 -- right behind the unit's first MFMA, so that the exp / rcp chain runs under the other three -- and written back in 3i + 11
-constexpr int PTU = 8;
-constexpr int pw_part(int s, int i) { return s - PTU - 3 * i; }          // part of piece i that unit s transforms (valid: 0..3; -1: read)
-constexpr bool pw_has_part(int s) {
-    for (int i = 0; i < PXPW; ++i) if (pw_part(s, i) >= -1 && pw_part(s, i) <= 3) return true;
-    return false;
-}
+constexpr int PLDS_WD = 66 * 1024;              // two 24 KB activation buffers; the epilogue's 64 KB tile (+ the GroupNorm sums' 512 bytes)
 
 // VAR 0: the plain conv.  VAR 1: the epilogue also accumulates the GroupNorm sums of the NEXT layer (a.gsum).  VAR 2 / 3: the named
 // fused kernel (2: coefficients given, 3: resolved here from the producer's sums) -- x is the RAW output of the previous conv and mish(x * scale[n][c] + shift[n][c]) + tb[n][c] (a.coef; GroupNorm-apply
@@ -136,11 +114,10 @@ constexpr bool pw_has_part(int s) {
 // pieces it requested itself, in place in LDS, after its own counted wait and before the chunk barrier publishes them; rows outside
 // the image stay zero.  One image per tile (TI == 1).
 // ABL (profiling builds only, -DMI_PW_ABL_BUILD): 1 no fragment DMA in the main loop, 2 no activation DMA in the main loop, 4 no stores,
-// 16 no DPP shifts (every tap column multiplies the centre fragments), 32 no LDS fragment reads in the main loop
+// 16 no DPP shifts (every tap column multiplies the centre fragments), 32 loads issued but never waited for in the main loop
 template <bool OUT16, int VAR = 0, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
-    constexpr bool FUSE = VAR >= 2, GNS = VAR == 1, WD = VAR < 2;
-    constexpr int DD = WD ? PWD : PDD, RD = WD ? 1 : PRD;          // request distance, wait-ahead distance (units)
+    constexpr bool FUSE = VAR >= 2, GNS = VAR == 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
     const int t = threadIdx.x, l = t & 63;
@@ -292,68 +269,66 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
     u32x4 tv[2];                                             // main loop: the (at most two) pieces in transformation, rewritten in place
 
-    // ---- weight stream of this wave: fragment (tap, nb, kq) = 1 KB at ((tap * NB + nb) * KQ + kq) * 1024 bytes
+    // ---- weight stream of this wave: fragment (tap, nb, kq) = 1 KB at ((tap * NB + nb) * KQ + kq) * 1024 bytes.  The fragments are
+    //      wave-private, so they never touch LDS: each lane loads ITS 16 bytes of a fragment straight into the registers the MFMA
+    //      reads (global_load_dwordx4 with a scalar base per tap, issued from asm and counted by hand like the DMA).  The nine
+    //      fragments of a 16-channel step are loaded during the step before (two register sets).
     const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(a.w) + (size_t)nb * KQ * 1024;
     const uint32_t tap_bytes = (uint32_t)a.Nc * a.K * 2;
     const uint32_t wl16 = l * 16;
-    const uint32_t wring = lds0 + PWOFF + wv * (PR * 1024);
-    // unit s of chunk ch (s may run past 35 into the next chunk): request its fragment into ring slot (36 ch + s) % 8
-    auto stage_w = [&](int ch, auto sc) {
-        constexpr int s0 = decltype(sc)::value, over = s0 >= 36 ? 1 : 0, s = s0 - 36 * over;
-        constexpr int ky = s / 12, ks = (s / 3) % 4, j = s % 3, tap = ky * 3 + (j == 0 ? 1 : (j == 1 ? 0 : 2));
-        const int chc = min(ch + over, nchunks - 1);         // past the end: re-fetch (keeps the DMA counts static)
-        const uint32_t ph = ((ch + over) & 1) * 4096;
-        const uint32_t off = (uint32_t)(a.flip ? 8 - tap : tap) * tap_bytes + (uint32_t)(chc * 4 + ks) * 1024;
-        glds16s(wsrc + off, wl16, wring + (((s & 7) * 1024) ^ ph));
+    uint64_t wtap[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        const uint64_t q = (uint64_t)(uintptr_t)(wsrc + (size_t)(a.flip ? 8 - tp : tp) * tap_bytes);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
+        wtap[tp] = ((uint64_t)hi << 32) | lo;
+    }
+    u32x4 WB[2][9];
+    // taps 3 part .. 3 part + 2 of step (ch, ks) (ks == 4: step 0 of chunk ch + 1; past the end: a re-fetch) -> set ks & 1
+    auto load_w3 = [&](int ch, auto ksc, auto partc) {
+        constexpr int ks0 = decltype(ksc)::value, over = ks0 >= 4 ? 1 : 0, ks = ks0 - 4 * over, part = decltype(partc)::value;
+        const uint32_t voff = wl16 + (uint32_t)min(ch + over, nchunks - 1) * 4096;
+        static_for<0, 3>([&](auto tc) {
+            constexpr int tp = 3 * part + decltype(tc)::value;
+            gload16s<ks * 1024>(WB[ks & 1][tp], wtap[tp], voff);
+        });
     };
 
-    // direct variant: tap t's fragments of the current chunk start at wtap[t] (scalar), step ks at +1024 (the instruction's offset)
-    u32x4 WR[WD ? PWR : 1];
-    auto wbase = [&](int ch, int tap) -> uint64_t {
-        const uint64_t p = (uint64_t)(uintptr_t)(wsrc + (size_t)(a.flip ? 8 - tap : tap) * tap_bytes + (size_t)min(ch, nchunks - 1) * 4096);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
-        return ((uint64_t)hi << 32) | lo;
-    };
-    auto load_w = [&](int ch, auto sc) {
-        constexpr int s0 = decltype(sc)::value, over = s0 >= 36 ? 1 : 0, s = s0 - 36 * over;
-        constexpr int ky = s / 12, ks = (s / 3) % 4, j = s % 3, tap = ky * 3 + (j == 0 ? 1 : (j == 1 ? 0 : 2));
-        const uint64_t b = wbase(ch + over, tap);
-        gload16s<ks * 1024>(WR[s % PWR], b, wl16);
-    };
-
-    // ---- fragment addressing.  Activations (MFMA "B" operand): lane -> pixel (l & 31) of the wave's i-th 32-pixel block (whole
-    //      image rows), 8-channel piece 2*ks + (l >> 5); weights ("A"): lane -> its own 16 bytes of the fragment.
-    uint32_t xa[4][3];                                       // byte offset of (block i, tap row ky), 16-channel step 0
+    // ---- fragment addressing.  A 32-pixel MFMA block = output row i (0..3) of every 4-row band of the tile: lane q = l & 31 ->
+    //      column x = q % W of band (q / W) % (TH / 4) of image q / W / (TH / 4) (W = 32: one row of one image; 16: rows i, i + 4;
+    //      8: rows i, i + 4 of two images).  With that, the block of tap row ky of output row i is "halo row r = i + ky of every
+    //      band" -- ONE activation fragment X_r serves the three tap rows (output rows r, r - 1, r - 2), and its two column shifts
+    //      are made once: per 16-channel step 6 LDS fragment reads and 12 DPP shifts feed 36 MFMAs (before: 12 reads, 24 shifts).
+    //      Lane -> 8-channel piece 2 ks + (l >> 5) of its pixel; weights: lane -> its own 16 bytes of the fragment.
+    uint32_t xr[6];                                          // byte address of X_r, 16-channel step 0, buffer 0
+    int ep_p0;                                               // epilogue: tile pixel of (output row 0, this lane)
+    {
+        const int q = l & 31, x = q & (a.W - 1), rest = q >> lw, nsub = a.TH >> 2;
+        const int sub = rest & (nsub - 1), ti = rest / nsub;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = i * 32 + (l & 31);
-        const int tx = r & (a.W - 1), q = r >> lw;
-        const int ty = q & (a.TH - 1), ti = q >> lth;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int hp = (ti * TH2 + ty + ky) * a.W + tx;
-            xa[i][ky] = lds0 + hp * 128 + (((l >> 5) * 16) ^ (((hp >> 1) & 7) * 16));
+        for (int r = 0; r < 6; ++r) {
+            const int hp = (ti * TH2 + r + 4 * sub) * a.W + x;
+            xr[r] = lds0 + hp * 128 + (((l >> 5) * 16) ^ (((hp >> 1) & 7) * 16));
         }
+        ep_p0 = (ti * a.TH + 4 * sub) * a.W + x;
     }
     const int xin = l & 31 & (a.W - 1);
     const uint32_t mask_l = xin == 0 ? 0u : ~0u, mask_r = xin == a.W - 1 ? 0u : ~0u;     // zero padding left / right of the row
-    const uint32_t wrd0 = wring + wl16;
 
     f32x16 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    bf16x8 XC[2][4];                                         // centre-column fragments of (tap row, 16-channel step): this group's, the next one's
-    bf16x8 FW[PRD + 1];                                      // weight fragments, PRD units ahead
+    bf16x8 XA, XB, XP, XQ;                                   // centre fragments: rows 0 and 5 of a step; rows 1 / 3 and 2 / 4
 
-    // ---- prologue: the first chunk's rows, the first PDD fragments
+    // ---- prologue: the first chunk's rows, the first step's fragments
     if constexpr (FUSE) load_coef(0);
 #pragma unroll
     for (int i = 0; i < PXPW; ++i) stage_x(0, i);
-    static_for<0, DD>([&](auto sc) { if constexpr (WD) load_w(0, sc); else stage_w(0, sc); });
+    static_for<0, 3>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
     if constexpr (FUSE) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PDD) : "memory");       // coefficients and rows of chunk 0
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // coefficients and rows of chunk 0
         coef_landed();
         static_for<0, 2>([&](auto hc) {                      // three pieces in flight at a time, three independent transforms
             constexpr int h = decltype(hc)::value;
@@ -369,89 +344,124 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             }
         });
     }
-    // the rows and fragments 0 .. PRD-1 have landed (this wave's; the fused variant's rewritten pieces are in LDS) ...
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(DD - RD) : "memory");
+    // the rows and the fragments have landed (this wave's; the fused variant's rewritten pieces are in LDS) ...
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                          // ... every wave's
     asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) XC[0][i] = lds_b128p(xa[i][0]);
-    if constexpr (WD) landed16(WR[0]);
-    else static_for<0, PRD>([&](auto sc) { FW[decltype(sc)::value] = lds_b128p(wrd0 + decltype(sc)::value * 1024); });
+    XA = lds_b128p(xr[0]); XB = lds_b128p(xr[5]);
 
-    static_assert(36 % (PRD + 1) == 0, "fragment register slots line up across chunks");
-    // one chunk: 36 units.  Fused variants: EVERY chunk runs the transform parts -- in the last one they rewrite the clamped re-fetch of
-    // its own rows, wasted VALU work.  Both ways of skipping them measured worse: a branch around a part fences it off from the MFMAs
-    // it is meant to run under (and a per-unit branch between two copies of the unit: 99-114 spilled registers); a second copy of the
-    // whole body for the last chunk has its 36 fragment addresses formed ahead of the loop, live across it, and spills.
+    // One chunk = four 16-channel steps of five row units (rows {0, 5}, 1, 2, 3, 4: 6, 6, 9, 9, 6 MFMAs; consecutive MFMAs go to
+    // different accumulators).  A unit reads the next unit's centre fragment(s); units 0-2 request the next step's fragments (three
+    // taps each), unit 3 of steps 0-2 two activation pieces of the next chunk; a step starts once everything the previous one
+    // requested before those pieces has landed.  Chunk boundary (before unit 4 of step 3, whose MFMAs then cover the first reads
+    // from the other buffer): every wave has read all it needs of this chunk's rows and has its pieces of the next chunk's.
+    // Fused variants: the coefficients of the next chunk are requested in step 0, the pieces requested in step k are transformed
+    // in place during units 0-3 of step k + 1 (two parts per unit) -- in the last chunk they rewrite the clamped re-fetch of its own
+    // rows, wasted VALU work (both ways of skipping them measured worse on the 36-unit body: a branch fences the parts off from the
+    // MFMAs they are meant to run under, a second copy of the body spills).
     for (int ch = 0; ch < nchunks; ++ch) {
-        // ring slot of unit s of this chunk: (36 ch + s) % 8 = (s & 7) with bit 2 toggled in odd chunks
-        const uint32_t wsame = wrd0 + (ch & 1) * 4096, wflip = wrd0 + 4096 - (ch & 1) * 4096;
         const uint32_t xcur = (ch & 1) * PXBUF, xnxt = PXBUF - xcur;
-        static_for<0, 36>([&](auto sc) {
-            constexpr int s = decltype(sc)::value, g = s / 3, ky = g / 4, ks = g % 4, j = s % 3;
-            auto unit = [&](auto more_c) {
-                constexpr bool MORE = decltype(more_c)::value;
-                // the fragment of unit s + PRD has landed ...
-                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(pw_newer(s, VAR, DD, RD)) : "memory");
-                if constexpr (WD) landed16(WR[(s + 1) % PWR]);    // (its value exists from here on)
-                else {
-                    constexpr int sr = s + PRD, over = sr >= 36 ? 1 : 0, srr = sr - 36 * over;
-                    if constexpr (!(ABL & 32))
-                    FW[sr % (PRD + 1)] = lds_b128p((((srr & 4) != 0) != (over != 0) ? wflip : wsame) + (srr & 3) * 1024);
-                }
-                if constexpr (j == 0 && (ABL & 32)) {
-                    if constexpr (g == 11) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(XC[(g + 1) & 1][i]));
-                }
-                if constexpr (j == 0 && !(ABL & 32)) {       // the next group's centre-column fragments
-                    if constexpr (g == 11) {
-                        // chunk boundary: every wave has read all it needs of this chunk's rows and has its pieces of the next
-                        // chunk's (their requests are older than the fragment just waited for)
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-                        asm volatile("" ::: "memory");
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) XC[0][i] = lds_b128p(xa[i][0] + xnxt);
-                    } else {
-                        constexpr int gn = g + 1, kyn = gn / 4, ksn = gn % 4;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) XC[gn & 1][i] = lds_b128p((xa[i][kyn] ^ (ksn * 32)) + xcur);
+        static_for<0, 4>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value, cur = ks & 1, kx32 = ks * 32;
+            if constexpr (ks > 0 && !(ABL & 32)) asm volatile("s_waitcnt vmcnt(%0)" :: "i"((FUSE || (ABL & 2)) ? 0 : 2) : "memory");
+            static_for<0, 9>([&](auto tc) { landed16(WB[cur][decltype(tc)::value]); });
+            if constexpr (FUSE && ks == 1) coef_landed();
+            auto mm = [&](auto ic, auto tapc, const bf16x8& xf) {
+                constexpr int i = decltype(ic)::value, tp = decltype(tapc)::value;
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WB[cur][tp]), xf, acc[i], 0, 0, 0);
+            };
+#define MI_MM(I, KY, KX, XF) mm(std::integral_constant<int, I>{}, std::integral_constant<int, (KY) * 3 + (KX)>{}, XF)
+            auto sh_l = [&](const bf16x8& c) { if constexpr (ABL & 16) return c; else return pw_shift<0>(c, mask_l); };
+            auto sh_r = [&](const bf16x8& c) { if constexpr (ABL & 16) return c; else return pw_shift<1>(c, mask_r); };
+            // what a unit issues besides its MFMAs
+            auto issue = [&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if constexpr (u < 3 && !(ABL & 1)) load_w3(ch, std::integral_constant<int, ks + 1>{}, uc);
+                if constexpr (u == 3 && ks < 3 && !(ABL & 2)) { stage_x(ch + 1, 2 * ks); stage_x(ch + 1, 2 * ks + 1); }
+                if constexpr (u == 3 && ks == 0 && FUSE) load_coef(ch + 1);
+            };
+            // fused variants: pieces 2 (ks - 1), 2 (ks - 1) + 1 of the next chunk, two parts per unit
+            auto fuse_pre = [&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if constexpr (FUSE && ks >= 1) {
+                    if constexpr (u == 0) {
+                        tv[0] = __builtin_bit_cast(u32x4, lds_b128p(piece_addr((ch + 1) & 1, 2 * (ks - 1))));
+                        tv[1] = __builtin_bit_cast(u32x4, lds_b128p(piece_addr((ch + 1) & 1, 2 * (ks - 1) + 1)));
                     }
                 }
-                // ring slot of unit s - 1 is free (its fragment is in registers since the previous unit's MFMAs)
-                if constexpr (ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if constexpr (WD) load_w(ch, std::integral_constant<int, s + PWD>{});
-                else stage_w(ch, std::integral_constant<int, s + PDD>{});
-                if constexpr (pw_is_x(s) && !(ABL & 2)) stage_x(ch + 1, s / 3);
-                if constexpr (FUSE && s == 0) load_coef(ch + 1);
-                if constexpr (FUSE && s == PTU - 2) coef_landed();
-                if constexpr (FUSE && MORE) {
-                    static_for<0, PXPW>([&](auto pc) {
-                        constexpr int i = decltype(pc)::value, q = pw_part(s, i);
-                        if constexpr (q == -1) tv[i & 1] = __builtin_bit_cast(u32x4, lds_b128p(piece_addr((ch + 1) & 1, i)));
-                        if constexpr (q >= 0 && q < 4)
-                            tv[i & 1][q] = tpart(tv[i & 1][q], std::integral_constant<int, (q >= 0 && q < 4) ? q : 0>{}, piece_mask(i));
-                    });
-                }
-                static_for<0, 4>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    bf16x8 xf;
-                    if constexpr (j == 0 || (ABL & 16)) xf = XC[g & 1][i];
-                    else if constexpr (j == 1) xf = pw_shift<0>(XC[g & 1][i], mask_l);
-                    else xf = pw_shift<1>(XC[g & 1][i], mask_r);
-                    if constexpr (WD) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WR[s % PWR]), xf, acc[i], 0, 0, 0);
-                    else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FW[s % (PRD + 1)], xf, acc[i], 0, 0, 0);
-                });
-                if constexpr (FUSE && MORE) {
-                    static_for<0, PXPW>([&](auto pc) {
-                        constexpr int i = decltype(pc)::value;
-                        if constexpr (pw_part(s, i) == 3) *(lds_u32x4*)(uintptr_t)piece_addr((ch + 1) & 1, i) = tv[i & 1];
-                    });
-                }
-                __builtin_amdgcn_sched_barrier(0);
             };
-            unit(std::bool_constant<FUSE>{});
+            auto fuse_mid = [&](auto uc) {                   // behind the unit's first MFMAs: the exp / rcp chains run under the others
+                constexpr int u = decltype(uc)::value;
+                if constexpr (FUSE && ks >= 1 && u < 4) {
+                    constexpr int pc = u >> 1, q0 = 2 * (u & 1);
+                    const uint32_t vm = piece_mask(2 * (ks - 1) + pc);
+                    tv[pc][q0] = tpart(tv[pc][q0], std::integral_constant<int, q0>{}, vm);
+                    tv[pc][q0 + 1] = tpart(tv[pc][q0 + 1], std::integral_constant<int, q0 + 1>{}, vm);
+                    if constexpr ((u & 1) == 1) *(lds_u32x4*)(uintptr_t)piece_addr((ch + 1) & 1, 2 * (ks - 1) + pc) = tv[pc];
+                }
+            };
+            // ---- unit 0: rows 0 (output row 0, tap row 0) and 5 (output row 3, tap row 2)
+            {
+                constexpr std::integral_constant<int, 0> U{};
+                fuse_pre(U);
+                XP = lds_b128p((xr[1] ^ kx32) + xcur);
+                issue(U);
+                MI_MM(0, 0, 1, XA); MI_MM(3, 2, 1, XB);
+                fuse_mid(U);
+                { const bf16x8 la = sh_l(XA), lb = sh_l(XB); MI_MM(0, 0, 0, la); MI_MM(3, 2, 0, lb); }
+                { const bf16x8 ra = sh_r(XA), rb = sh_r(XB); MI_MM(0, 0, 2, ra); MI_MM(3, 2, 2, rb); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- unit 1: row 1 (output rows 1, 0)
+            {
+                constexpr std::integral_constant<int, 1> U{};
+                XQ = lds_b128p((xr[2] ^ kx32) + xcur);
+                issue(U);
+                MI_MM(1, 0, 1, XP); MI_MM(0, 1, 1, XP);
+                fuse_mid(U);
+                { const bf16x8 lf = sh_l(XP); MI_MM(1, 0, 0, lf); MI_MM(0, 1, 0, lf); }
+                { const bf16x8 rf = sh_r(XP); MI_MM(1, 0, 2, rf); MI_MM(0, 1, 2, rf); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- unit 2: row 2 (output rows 2, 1, 0)
+            {
+                constexpr std::integral_constant<int, 2> U{};
+                XP = lds_b128p((xr[3] ^ kx32) + xcur);
+                issue(U);
+                MI_MM(2, 0, 1, XQ); MI_MM(1, 1, 1, XQ); MI_MM(0, 2, 1, XQ);
+                fuse_mid(U);
+                { const bf16x8 lf = sh_l(XQ); MI_MM(2, 0, 0, lf); MI_MM(1, 1, 0, lf); MI_MM(0, 2, 0, lf); }
+                { const bf16x8 rf = sh_r(XQ); MI_MM(2, 0, 2, rf); MI_MM(1, 1, 2, rf); MI_MM(0, 2, 2, rf); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- unit 3: row 3 (output rows 3, 2, 1)
+            {
+                constexpr std::integral_constant<int, 3> U{};
+                XQ = lds_b128p((xr[4] ^ kx32) + xcur);
+                issue(U);
+                MI_MM(3, 0, 1, XP); MI_MM(2, 1, 1, XP); MI_MM(1, 2, 1, XP);
+                fuse_mid(U);
+                { const bf16x8 lf = sh_l(XP); MI_MM(3, 0, 0, lf); MI_MM(2, 1, 0, lf); MI_MM(1, 2, 0, lf); }
+                { const bf16x8 rf = sh_r(XP); MI_MM(3, 0, 2, rf); MI_MM(2, 1, 2, rf); MI_MM(1, 2, 2, rf); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- unit 4: row 4 (output rows 3, 2); reads rows 0 and 5 of the next step
+            {
+                if constexpr (ks == 3) {
+                    if constexpr (ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    XA = lds_b128p(xr[0] + xnxt); XB = lds_b128p(xr[5] + xnxt);
+                } else {
+                    XA = lds_b128p((xr[0] ^ (kx32 + 32)) + xcur); XB = lds_b128p((xr[5] ^ (kx32 + 32)) + xcur);
+                }
+                MI_MM(3, 1, 1, XQ); MI_MM(2, 2, 1, XQ);
+                { const bf16x8 lf = sh_l(XQ); MI_MM(3, 1, 0, lf); MI_MM(2, 2, 0, lf); }
+                { const bf16x8 rf = sh_r(XQ); MI_MM(3, 1, 2, rf); MI_MM(2, 2, 2, rf); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef MI_MM
         });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped re-fetches must not outlive the workgroup's LDS
@@ -477,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int p = i * 32 + (l & 31);
+            const int p = ep_p0 + i * a.W;               // output row i of this lane's band
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 const int ck = 8 * wv + 2 * rq + (l >> 5);
@@ -566,7 +576,7 @@ bool pw_geom(const MiConvDesc* d, int* TH, int* TI) {
     const int rows = PBM / W;
     if (rows <= H) { if (H % rows) return false; *TH = rows; *TI = 1; }
     else { if (rows % H) return false; *TH = H; *TI = rows / H; if ((long)d->N % *TI) return false; }
-    if ((*TH & (*TH - 1)) || *TI > 2) return false;            // the kernel's index arithmetic: shifts, at most two images per tile
+    if ((*TH & (*TH - 1)) || *TH % 4 || *TI > 2) return false; // the kernel's index arithmetic: shifts, 4-row bands, at most two images per tile
     return *TI * (*TH + 2) * W <= PXP;
 }
 
@@ -750,7 +760,7 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     a.qmap = 0; a.gx = (int)grid.x; a.gy = (int)grid.y;
     if (!a.xmap && a.gy > 1 && a.gy % 2 == 0 && a.gx % 4 == 0) { a.qmap = 2; grid = dim3(grid.x * grid.y, 1, 1); }
     hipStream_t st = (hipStream_t)stream;
-    size_t lds = var < 2 ? PLDS_WD : PLDS;
+    size_t lds = PLDS_WD;
 #define MI_PW_GO(O16, V, A) do { \
         static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, A>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
         (void)once_; \
@@ -762,7 +772,7 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
 #define MI_PW_ABL_CASE(V) case V: if (out_bf16) MI_PW_GO(true, 0, V); else MI_PW_GO(false, 0, V); break;
         switch (abl & 0x37) {
             MI_PW_ABL_CASE(1) MI_PW_ABL_CASE(2) MI_PW_ABL_CASE(3) MI_PW_ABL_CASE(4) MI_PW_ABL_CASE(7)
-            MI_PW_ABL_CASE(16) MI_PW_ABL_CASE(23) MI_PW_ABL_CASE(32) MI_PW_ABL_CASE(48) MI_PW_ABL_CASE(55)
+            MI_PW_ABL_CASE(16) MI_PW_ABL_CASE(17) MI_PW_ABL_CASE(19) MI_PW_ABL_CASE(23) MI_PW_ABL_CASE(32) MI_PW_ABL_CASE(36)
             default: return mi_set_error(-1, "MI_PW_ABL: combination not built");
         }
 #undef MI_PW_ABL_CASE
