@@ -18,6 +18,14 @@ int mi_set_error(int code, const char* fmt, ...);
          if (e_ != hipSuccess) return mi_set_error((int)e_, "%s: %s", __func__, hipGetErrorString(e_)); } while (0)
 
 // two fp32 -> packed bf16x2 (round-to-nearest-even, one v_cvt_pk_bf16_f32)
+// Profiling / experiment switches (tile forcing, XCD maps off, alternative plans): read from the environment only in builds with
+// -DMI_EXPERIMENT (tools/), constants in the product library -- every one of them would otherwise be an untested configuration.
+#ifdef MI_EXPERIMENT
+inline long mi_knob(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
+#else
+inline constexpr long mi_knob(const char*, long dflt) { return dflt; }
+#endif
+
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     bf16x2 p = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(uint32_t, p);

@@ -723,13 +723,13 @@ void launch_halo(const HaloArgs& a_in, hipStream_t st) {
     HaloArgs a = a_in;
     // off by default: measured neutral (level 0 56.7 -> 55.8 us, step 6.39 vs 6.41 ms) -- what the ablation charges to the stores is
     // their burst at the end of a round of workgroups, not the rows per instruction
-    static const int ep_env = [] { const char* e = getenv("MI_HALO_EPI"); return e ? atoi(e) : 0; }();
+    static const int ep_env = (int)mi_knob("MI_HALO_EPI", 0);
     a.ep_rows = (ep_env && !SK && !a.gsum && !a.y16) ? 1 : 0;
     if (a.ep_rows) {
         const size_t need = (size_t)WAVES * HaloCfg<BM, WAVES>::MI * 32 * 68 * sizeof(float);
         if (need > lds) lds = need;
     }
-    static const int skew_env = [] { const char* e = getenv("MI_HALO_SKEW"); return e ? atoi(e) : 1; }();
+    static const int skew_env = (int)mi_knob("MI_HALO_SKEW", 1);
     a.skew = 0;
     if (skew_env && KS == 3 && (a.W == 8 || a.W == 16)) {     // the skewed tile must end before the dump row
         const int rows = a.TI * (a.TH + 2);
@@ -737,7 +737,7 @@ void launch_halo(const HaloArgs& a_in, hipStream_t st) {
     }
     dim3 grid((a.N * a.H * a.W + BM - 1) / BM, (a.Nc + 127) / 128, a.ksplit);
     a.qmap = 0; a.gx = (int)grid.x; a.gy = (int)grid.y;
-    static const int q_env = [] { const char* e = getenv("MI_HALO_PQ"); return e ? atoi(e) : 1; }();
+    static const int q_env = (int)mi_knob("MI_HALO_PQ", 1);
     if (q_env && KS == 3 && !SK && a.ksplit == 1 && !a.xmap && a.gy > 1 && a.TH == a.H) {   // whole-image tiles
         const int Q = (a.gy % 2 == 0) ? 2 : 1, P = 8 / Q;
         if (Q > 1 && a.gx % P == 0) { a.qmap = Q; grid = dim3(grid.x * grid.y, 1, 1); }
@@ -863,13 +863,13 @@ static bool halo_ok(const MiConvDesc* d, int* bm, int* ck) {
     if (k1) {                                  // 1x1: plain GEMM over M = N*H*W pixels, any geometry; four 32-channel stages per group (K is padded with zero weights)
         const long M = (long)d->N * d->OH * d->OW, nt = (d->Nc + 127) / 128;
         *bm = (M + 255) / 256 * nt >= 200 ? 256 : ((M + 127) / 128 * nt >= 400 ? 128 : 64);
-        static const int force1 = [] { const char* e = getenv("MI_HALO_K1_BM"); return e ? atoi(e) : 0; }();     // experiment: 64 / 128 / 256
+        static const int force1 = (int)mi_knob("MI_HALO_K1_BM", 0);     // experiment: 64 / 128 / 256
         if (force1 == 64 || force1 == 128 || (force1 == 256 && M >= 256)) *bm = force1;
         *ck = 32;                              // 64 would spill: the whole A tile rides in the 4-deep register ring
         return true;
     }
     if (d->OW < 4 || d->OW > 64) return false;
-    static const int force = [] { const char* e = getenv("MI_HALO_BM"); return e ? atoi(e) : 0; }();
+    static const int force = (int)mi_knob("MI_HALO_BM", 0);
     const long M = (long)d->N * d->OH * d->OW, nt = (d->Nc + 127) / 128;
     int TH, TI, best = 0;
     const int cand[3] = {256, 128, 64};
@@ -883,7 +883,7 @@ static bool halo_ok(const MiConvDesc* d, int* bm, int* ck) {
     }
     if (!best) return false;
     *bm = best;
-    static const int force_ck = [] { const char* e = getenv("MI_HALO_CK"); return e ? atoi(e) : 0; }();
+    static const int force_ck = (int)mi_knob("MI_HALO_CK", 0);
     *ck = (best == 256 && d->K % 64 == 0 && d->K1 % 64 == 0) ? 64 : 32;   // CK=64 only where one workgroup/CU is the plan anyway
     if (force_ck == 32 || (force_ck == 64 && d->K % 64 == 0 && d->K1 % 64 == 0)) *ck = force_ck;
     return true;
@@ -900,7 +900,7 @@ static int halo_splitk(const MiConvDesc* d, int BM, int* th, int* ti) {
     if (d->KH != 3 || BM >= 256 || d->K % 64 || d->K1 % 64 || !(d->accumulate || d->ldy == d->Nc)) return 0;
     // off by default: since the staging ring runs with exact waits the 64-pixel tiles (2-3 workgroups per CU) are
     // faster than split-K for every cfg-2 / cfg-3 layer (measured 14.17k vs 13.95k images/s); MI_HALO_SPLITK=1 enables it
-    static const int allow = [] { const char* e = getenv("MI_HALO_SPLITK"); return e ? atoi(e) : 0; }();
+    static const int allow = (int)mi_knob("MI_HALO_SPLITK", 0);
     const long b256 = ((long)d->N * d->OH * d->OW + 255) / 256 * ((d->Nc + 127) / 128);
     const long b128 = ((long)d->N * d->OH * d->OW + 127) / 128 * ((d->Nc + 127) / 128);
     const int chunks = d->K / 64;
@@ -915,7 +915,7 @@ static int halo_splitk(const MiConvDesc* d, int BM, int* th, int* ti) {
 // tile is shared by 8 waves and read once per 128 pixels, 8 MFMAs per wave between barriers -- when that still gives
 // (almost) every CU a workgroup.  MI_HALO_W8 = minimum number of workgroups (0 = never).
 static bool halo_w8(const MiConvDesc* d, int BM, int* th, int* ti) {
-    static const int w8 = [] { const char* e = getenv("MI_HALO_W8"); return e ? atoi(e) : 200; }();
+    static const int w8 = (int)mi_knob("MI_HALO_W8", 200);
     const long b128 = ((long)d->N * d->OH * d->OW + 127) / 128 * ((d->Nc + 127) / 128);
     return w8 && d->KH == 3 && BM == 64 && d->K % 64 == 0 && d->K1 % 64 == 0 && b128 >= w8 && halo_geom(d, 128, th, ti);
 }
@@ -923,11 +923,11 @@ static bool halo_w8(const MiConvDesc* d, int BM, int* th, int* ti) {
 // barrier; the larger LDS footprint (one workgroup per CU) costs nothing then
 // three weight slots + operands of the next tap fetched before the barrier (PIPE); MI_HALO_PIPE=0 restores the two-slot kernels
 static bool halo_pipe() {
-    static const int on = [] { const char* e = getenv("MI_HALO_PIPE"); return e ? atoi(e) : 0; }();
+    static const int on = (int)mi_knob("MI_HALO_PIPE", 0);
     return on != 0;
 }
 static bool halo_wide64(const MiConvDesc* d, int BM) {
-    static const int ck64 = [] { const char* e = getenv("MI_HALO_CK64"); return e ? atoi(e) : 1; }();
+    static const int ck64 = (int)mi_knob("MI_HALO_CK64", 1);
     return ck64 && d->KH == 3 && BM == 64 && d->K % 64 == 0 && d->K1 % 64 == 0 &&
            ((long)d->N * d->OH * d->OW + 63) / 64 * ((d->Nc + 127) / 128) <= 256;
 }
@@ -1012,7 +1012,7 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
     // combined with fp32 atomics into a zeroed (or, for accumulate, the existing) output
     a.ksplit = 1;
     {
-        static const int force_ks = [] { const char* e = getenv("MI_HALO_KSPLIT"); return e ? atoi(e) : 0; }();
+        static const int force_ks = (int)mi_knob("MI_HALO_KSPLIT", 0);
         const long blocks = ((long)d->N * d->OH * d->OW + BM - 1) / BM * ((d->Nc + 127) / 128);
         const int chunks = d->K / CK;
         int ks = 1;
@@ -1040,7 +1040,7 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
     }
     MI_REQUIRE(halo_geom(d, BM, &a.TH, &a.TI), "halo tile geometry");
     a.tiles_per_img = a.TI > 1 ? 1 : a.H / a.TH;
-    static const int xmap_env = [] { const char* e = getenv("MI_HALO_XCD"); return e ? atoi(e) : 1; }();
+    static const int xmap_env = (int)mi_knob("MI_HALO_XCD", 1);
     a.xmap = xmap_env && a.TI == 1 && a.tiles_per_img > 1 && a.N % 8 == 0;
     a.HP = a.TI * (a.TH + 2) * (a.W + 2);
     // (a 4-wave variant with 128x64 wave tiles was measured 15 % slower than 8 waves of 64x64: thread-level

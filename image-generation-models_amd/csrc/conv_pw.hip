@@ -590,24 +590,27 @@ bool pw_ok(const MiConvDesc* d, int* TH, int* TI) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// 1x1 convolution with K = 128 input channels on the same machinery (to_qkv, to_out + residual, res_conv and the data gradient of
-// to_out: reference src/models/ddpm.py:134,151-152).  These are streaming kernels (64-250 FLOP per byte): a workgroup = 128 pixels x
-// 128 output channels, the WHOLE 128 x 128-channel activation tile (32 KB, two swizzled 64-channel halves) is requested in the
-// prologue -- no chunk barrier, no activation DMA in the loop -- and each wave streams the 8 weight fragments of its 32 channels
-// through its private ring exactly as above (two 16-channel steps ahead in registers).  Eight units of four MFMAs per wave, then the
-// row-contiguous epilogue through LDS (bias, fp32 residual, accumulate; optional bf16 copy of an fp32 output: to_out's epilogue
-// writes the residual-stream tensor AND the copy its consumers read).  64 KB of LDS: two workgroups per CU.
+// 1x1 convolution on the same machinery (to_qkv, to_out + residual, res_conv -- also over the skip concat's two sources -- and their
+// data gradients: reference src/models/ddpm.py:134,151-152).  These are streaming kernels (64-250 FLOP per byte): a workgroup =
+// PXT (128 or 64) pixels x 128 output channels, wave w owns all pixels of channels [32w, 32w + 32).  Per 128-channel chunk the
+// PXT x 128-channel activation tile (two swizzled 64-channel halves) arrives by LDS-DMA into one of two buffers while the previous
+// chunk is multiplied, and each wave loads the 8 weight fragments of its 32 channels straight into registers (two sets); one
+// barrier per chunk (8 x PXT / 32 MFMAs per wave).  Then the row-contiguous epilogue through LDS (bias, fp32 residual, accumulate;
+// optional bf16 copy of an fp32 output: to_out's epilogue writes the residual-stream tensor AND the copy its consumers read).
+// 64 KB of LDS: two workgroups per CU.
 struct Pw1Args {
-    const uint16_t* x; const uint16_t* w; const float* bias; const float* res; void* y; uint16_t* y16;
-    int M, Nc, ldx, ldy, ldr, ldy16, accumulate, gx, gy;
+    const uint16_t* x; const uint16_t* x2; const uint16_t* w; const float* bias; const float* res; void* y; uint16_t* y16;
+    int M, K, K1, Nc, ldx, ldx2, ldy, ldr, ldy16, accumulate, gx, gy;
 };
 
-template <bool OUT16, bool DUAL>
+template <bool OUT16, bool DUAL, int PXT>
 __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
-    constexpr int XB = 128 * 128;                    // one 64-channel half of the tile
-    constexpr int WOFF = 2 * XB;
+    constexpr int NBLK = PXT / 32;                   // 32-pixel MFMA blocks per wave
+    constexpr int XH = PXT * 128;                    // one 64-channel half of a chunk's tile (bytes)
+    constexpr int XB = 2 * XH;                       // one chunk's tile
+    constexpr int NPC = 2 * PXT / 8 / 4;             // activation pieces (8 pixels x 64 channels = 1 KB) per wave and chunk
     const int t = threadIdx.x, l = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     // the channel tiles of one pixel tile are adjacent in time on one XCD (ids xcd + 8*slot): the tile is read from HBM once
@@ -616,64 +619,90 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
         const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
         bx = xcd * (a.gx >> 3) + slot / a.gy; by = slot % a.gy;
     }
-    const int m0 = bx * 128, n0 = by * 128;
-    const int NB = a.Nc >> 5;
+    const int m0 = bx * PXT, n0 = by * 128;
+    const int NB = a.Nc >> 5, KQ = a.K >> 4, nchunks = a.K >> 7;
     const bool live = n0 + 32 * wv < a.Nc;
     const int nb = min((n0 >> 5) + wv, NB - 1);
 
-    // activation pieces: piece p = wv + 4i (i < 8) = pixels 8 (p & 15) .. +7 of half p >> 4; lane -> pixel l >> 3, stored 16-byte
-    // position l & 7 holds channel chunk (l & 7) ^ ((pixel >> 1) & 7)
+    // activation pieces of chunk ch -> buffer ch & 1: piece p = wv + 4i = pixels 8 (p % (PXT / 8)) .. +7 of half p / (PXT / 8); lane ->
+    // pixel l >> 3, stored 16-byte position l & 7 holds channel chunk (l & 7) ^ ((pixel >> 1) & 7)
+    auto stage_x = [&](int ch) {
+        const int c0 = min(ch, nchunks - 1) * 128;
+        const bool second = c0 >= a.K1;
+        const uint16_t* src = second ? a.x2 : a.x;
+        const int ld = second ? a.ldx2 : a.ldx, cc = second ? c0 - a.K1 : c0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int p = wv + 4 * i, half = p >> 4, px = 8 * (p & 15) + (l >> 3);
-        const int col = half * 64 + ((l & 7) ^ ((px >> 1) & 7)) * 8;
-        glds16(a.x + (size_t)(m0 + px) * a.ldx + col, lds0 + half * XB + (p & 15) * 1024);
+        for (int i = 0; i < NPC; ++i) {
+            const int p = wv + 4 * i, half = p / (PXT / 8), px = 8 * (p % (PXT / 8)) + (l >> 3);
+            const int col = cc + half * 64 + ((l & 7) ^ ((px >> 1) & 7)) * 8;
+            glds16(src + (size_t)(m0 + px) * ld + col, lds0 + (ch & 1) * XB + half * XH + (p % (PXT / 8)) * 1024);
+        }
+    };
+    // weight fragments (nb, kq = 8 ch .. 8 ch + 7): 8 KB contiguous
+    uint64_t wsrc;
+    {
+        const uint64_t q = (uint64_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(a.w) + (size_t)nb * KQ * 1024);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
+        wsrc = ((uint64_t)hi << 32) | lo;
     }
-    const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(a.w) + (size_t)nb * 8 * 1024;     // fragments (nb, kq = 0..7): 8 KB contiguous
-    const uint32_t wring = lds0 + WOFF + wv * 8192, wl16 = l * 16;
+    const uint32_t wl16 = l * 16;
+    u32x4 WB[2][8];
+    auto load_w = [&](int ch, auto setc) {
+        constexpr int set = decltype(setc)::value;
+        const uint32_t voff = wl16 + (uint32_t)min(ch, nchunks - 1) * 8192;
+        static_for<0, 4>([&](auto uc) { gload16s<decltype(uc)::value * 1024>(WB[set][decltype(uc)::value], wsrc, voff); });
+        static_for<0, 4>([&](auto uc) { gload16s<decltype(uc)::value * 1024>(WB[set][4 + decltype(uc)::value], wsrc, voff + 4096); });
+    };
+    uint32_t xa[NBLK];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) glds16s(wsrc + u * 1024, wl16, wring + u * 1024);
-    uint32_t xa[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NBLK; ++i) {
         const int px = i * 32 + (l & 31);
         xa[i] = lds0 + px * 128 + (((l >> 5) * 16) ^ (((px >> 1) & 7) * 16));
     }
-    f32x16 acc[4];
+    f32x16 acc[NBLK];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NBLK; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    // everything is in flight; the tile (8 pieces) and fragments 0, 1 first
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    bf16x8 XC[2][4], FW[3];
+
+    stage_x(0);
+    load_w(0, std::integral_constant<int, 0>{});
+    auto chunk = [&](int ch, auto setc) {
+        constexpr int set = decltype(setc)::value;
+        // this chunk's tile and fragments have landed (every wave's pieces); the other buffer and register set are free
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        static_for<0, 8>([&](auto uc) { landed16(WB[set][decltype(uc)::value]); });
+        if (ch + 1 < nchunks) { stage_x(ch + 1); load_w(ch + 1, std::integral_constant<int, set ^ 1>{}); }
+        const uint32_t xb = (ch & 1) * XB;
+        bf16x8 XC[2][NBLK];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) XC[0][i] = lds_b128p(xa[i]);
-    FW[0] = lds_b128p(wring + wl16); FW[1] = lds_b128p(wring + wl16 + 1024);
-    static_for<0, 8>([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        if constexpr (u + 2 < 8) {
-            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(5 - u) : "memory");            // fragment u + 2 has landed (8 - (u + 3) newer)
-            FW[(u + 2) % 3] = lds_b128p(wring + wl16 + (u + 2) * 1024);
-        }
-        if constexpr (u + 1 < 8) {
-            constexpr int un = u + 1;
+        for (int i = 0; i < NBLK; ++i) XC[0][i] = lds_b128p(xa[i] + xb);
+        static_for<0, 8>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if constexpr (u + 1 < 8) {
+                constexpr int un = u + 1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) XC[un & 1][i] = lds_b128p((xa[i] ^ ((un & 3) * 32)) + (un >> 2) * XB);
-        }
+                for (int i = 0; i < NBLK; ++i) XC[un & 1][i] = lds_b128p((xa[i] ^ ((un & 3) * 32)) + (un >> 2) * XH + xb);
+            }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FW[u % 3], XC[u & 1][i], acc[i], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    });
+            for (int i = 0; i < NBLK; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WB[set][u]), XC[u & 1][i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        chunk(ch, std::integral_constant<int, 0>{});
+        if (ch + 1 < nchunks) chunk(ch + 1, std::integral_constant<int, 1>{});
+    }
 
     // ---- epilogue: as conv_pw_kernel's (fp32 tile through LDS, whole rows out)
     __syncthreads();
     typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
     if (live) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NBLK; ++i) {
             const int p = i * 32 + (l & 31);
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
@@ -689,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
     if (a.bias) { b0 = *reinterpret_cast<const f32x4*>(a.bias + col); b1 = *reinterpret_cast<const f32x4*>(a.bias + col + 4); }
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < PXT / 16; ++it) {
         const int p = it * 16 + (t >> 4);
         const size_t m = (size_t)m0 + p;
         f32x4 v0 = *(lds_f32x4*)(uintptr_t)(lds0 + p * 512 + (((2 * j) ^ (p & 31)) << 4)) + b0;
@@ -721,7 +750,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
 bool pw1_ok(const MiConvDesc* d) {
     if (d->KH != 1 || d->KW != 1 || d->pad != 0 || d->stride != 1 || d->mode != 1) return false;
     if (d->IH != d->OH || d->IW != d->OW) return false;
-    if (d->K != 128 || d->K1 != 128 || d->Nc % 32 || d->ldx % 8) return false;
+    if (d->K % 128 || d->K1 % 128 || d->K1 <= 0 || d->K1 > d->K || d->Nc % 32 || d->ldx % 8 || (d->K1 != d->K && d->ldx2 % 8)) return false;
     return ((long)d->N * d->OH * d->OW) % 128 == 0;
 }
 
@@ -832,31 +861,40 @@ extern "C" int mi_conv3x3_pw_gn_mish_sums(const MiConvDesc* d, const void* x, co
     return pw_launch(__func__, d, x, nullptr, w_frag_bf16, bias, nullptr, y, out_bf16, 3, nullptr, nullptr, stream, &gn);
 }
 
-// ---- 1x1 convs with K = 128 (see conv1x1_pw_kernel): w_frag_bf16 = the layer's slice of wfq (d->transposed = 0) or wdq (data gradient)
+// ---- 1x1 convs with K % 128 == 0 (see conv1x1_pw_kernel): w_frag_bf16 = the layer's slice of wfq (d->transposed = 0) or wdq (data
+//      gradient); x2: second source of a two-source layer (channels K1 .. K - 1, d->K1 % 128 == 0), else null
 extern "C" int mi_conv1x1_pw_supported(const MiConvDesc* d) { return (d && pw1_ok(d)) ? 1 : 0; }
 // y fp32 or bf16 (out_bf16); y_bf16 (optional, fp32 y only): the bf16 copy of y written by the same epilogue, pixel stride ldy16
-extern "C" int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* w_frag_bf16, const float* bias, const float* residual,
+extern "C" int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias, const float* residual,
                              void* y, int out_bf16, void* y_bf16, int ldy16, void* stream) {
     MI_REQUIRE(d && x && w_frag_bf16 && y, "null argument");
-    MI_REQUIRE(pw1_ok(d), "descriptor not supported (1x1, K = 128, Nc % 32 == 0, N*H*W % 128 == 0)");
-    MI_REQUIRE((((uintptr_t)x | (uintptr_t)w_frag_bf16) & 15) == 0, "operands must be 16-byte aligned");
+    MI_REQUIRE(pw1_ok(d), "descriptor not supported (1x1, K and K1 % 128 == 0, Nc % 32 == 0, N*H*W % 128 == 0)");
+    MI_REQUIRE(d->K1 == d->K || x2, "two-source split without x2");
+    MI_REQUIRE((((uintptr_t)x | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)w_frag_bf16) & 15) == 0, "operands must be 16-byte aligned");
     MI_REQUIRE(d->ldy % 8 == 0 && (!residual || d->ldr % 4 == 0) && (!y_bf16 || (ldy16 % 8 == 0 && !out_bf16 && !d->accumulate)),
                "pixel strides: y % 8, residual % 4, bf16 copy % 8 (fp32 y, no accumulate)");
     Pw1Args a{};
-    a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_frag_bf16; a.bias = bias; a.res = residual; a.y = y; a.y16 = (uint16_t*)y_bf16;
-    a.M = d->N * d->OH * d->OW; a.Nc = d->Nc; a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.ldy16 = ldy16; a.accumulate = d->accumulate;
-    a.gx = a.M / 128; a.gy = (d->Nc + 127) / 128;
+    a.x = (const uint16_t*)x; a.x2 = (const uint16_t*)(x2 ? x2 : x); a.w = (const uint16_t*)w_frag_bf16; a.bias = bias; a.res = residual;
+    a.y = y; a.y16 = (uint16_t*)y_bf16;
+    a.M = d->N * d->OH * d->OW; a.K = d->K; a.K1 = d->K1; a.Nc = d->Nc; a.ldx = d->ldx; a.ldx2 = x2 ? d->ldx2 : d->ldx;
+    a.ldy = d->ldy; a.ldr = d->ldr; a.ldy16 = ldy16; a.accumulate = d->accumulate;
+    a.gy = (d->Nc + 127) / 128;
+    // 64-pixel tiles when 128-pixel ones would leave CUs without a workgroup
+    const bool small = (long)(a.M / 128) * a.gy < 256;
+    a.gx = a.M / (small ? 64 : 128);
     dim3 grid((unsigned)a.gx, (unsigned)a.gy);
     if (a.gy > 1 && a.gx % 8 == 0) grid = dim3((unsigned)(a.gx * a.gy), 1, 1);
     constexpr size_t lds = 64 * 1024;
     hipStream_t st = (hipStream_t)stream;
-#define MI_PW1_GO(O16, DU) do { \
-        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<O16, DU>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); return true; }(); \
+#define MI_PW1_GO(O16, DU, PX) do { \
+        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<O16, DU, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); return true; }(); \
         (void)once_; \
-        hipLaunchKernelGGL((conv1x1_pw_kernel<O16, DU>), grid, dim3(256), lds, st, a); } while (0)
-    if (out_bf16) MI_PW1_GO(true, false);
-    else if (y_bf16) MI_PW1_GO(false, true);
-    else MI_PW1_GO(false, false);
+        hipLaunchKernelGGL((conv1x1_pw_kernel<O16, DU, PX>), grid, dim3(256), lds, st, a); } while (0)
+#define MI_PW1_PICK(O16, DU) do { if (small) MI_PW1_GO(O16, DU, 64); else MI_PW1_GO(O16, DU, 128); } while (0)
+    if (out_bf16) MI_PW1_PICK(true, false);
+    else if (y_bf16) MI_PW1_PICK(false, true);
+    else MI_PW1_PICK(false, false);
+#undef MI_PW1_PICK
 #undef MI_PW1_GO
     MI_LAUNCH_CHECK();
     return 0;

@@ -320,7 +320,7 @@ bool shift_ok(const MiConvDesc* d, int* TH, int* TI) {
 
 // 128-channel workgroups unless that leaves CUs idle (the 8x8 level at batch 128: 32 pixel tiles)
 int shift_ni(const MiConvDesc* d) {
-    static const int force = [] { const char* e = getenv("MI_SHIFT_NI"); return e ? atoi(e) : 0; }();
+    static const int force = (int)mi_knob("MI_SHIFT_NI", 0);
     if (force == 1 || force == 2) return force;
     const long mt = (long)d->N * d->OH * d->OW / SBM;
     return mt * ((d->Nc + 127) / 128) >= 200 ? 2 : 1;
@@ -359,10 +359,10 @@ extern "C" int mi_conv3x3_shift(const MiConvDesc* d, const void* x, const void* 
     const int BN = 64 * ni;
     dim3 grid((unsigned)((long)d->N * d->OH * d->OW / SBM), (unsigned)((d->Nc + BN - 1) / BN));
     a.qmap = 0; a.gx = (int)grid.x; a.gy = (int)grid.y;
-    static const int q_env = [] { const char* e = getenv("MI_SHIFT_PQ"); return e ? atoi(e) : 1; }();
+    static const int q_env = (int)mi_knob("MI_SHIFT_PQ", 1);
     if (q_env && !a.xmap && a.gy > 1 && a.gy % 2 == 0 && a.gx % 4 == 0) { a.qmap = 2; grid = dim3(grid.x * grid.y, 1, 1); }
     const size_t lds = (size_t)2 * SXBUF + (size_t)3 * BN * 128;
-    static const int wm_env = [] { const char* e = getenv("MI_SHIFT_WM"); return e ? atoi(e) : 4; }();
+    static const int wm_env = (int)mi_knob("MI_SHIFT_WM", 4);
     hipStream_t st = (hipStream_t)stream;
 #define MI_SHIFT_GO(WMV, NIV, O16) do { \
         static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_shift_kernel<WMV, NIV, O16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \

@@ -647,7 +647,7 @@ static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, 
     bool bm64 = tiles128 < 384 || a.Mc <= 64;
     if (bn64 == false && bm64 && (long)((a.Mc + 63) / 64) * ((d->Nc + 127) / 128) * classes < 384) bn64 = true;
     // aligned bf16 layers with few taps per class: the straight-line ring kernel
-    static const int allow_fast = [] { const char* e = getenv("MI_IGEMM_FAST"); return e ? atoi(e) : 1; }();
+    static const int allow_fast = (int)mi_knob("MI_IGEMM_FAST", 1);
     // (bf16-stored activations exist only on the ring kernel: the profiling switch does not apply to them, so that
     //  mi_conv_igemm_bf16w_io_supported() and this dispatch agree)
     if ((allow_fast || in16) && !ragged && d->mode == 1 && wb && a.ksplit == 1 && d->K % 32 == 0 && d->K1 % 32 == 0 && a.vecA && classes <= 4 &&
@@ -674,7 +674,7 @@ static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, 
             if (nt == 0) ok = false;
         }
         if (ok) {
-            static const int force = [] { const char* e = getenv("MI_IGEMM_TILE"); return e ? atoi(e) : 0; }();   // 11 / 10 / 01 / 00 = bm64,bn64 (profiling)
+            static const int force = (int)mi_knob("MI_IGEMM_TILE", 0);   // 11 / 10 / 01 / 00 = bm64,bn64 (profiling)
             if (force) { bm64 = (force / 10) % 10 == 1; bn64 = force % 10 == 1; if (force == 100) { bm64 = false; bn64 = false; } }
             if (!bm64 && !bn64) launch_fast<128, 128>(a, tt, classes, in16, st);
             else if (!bm64 && bn64) launch_fast<128, 64>(a, tt, classes, in16, st);

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
 // loads in flight: forward 0.128 -> 0.153 ms per step with 8 slices; with 256 pairs -- the sampler at B = 64 -- two slices cost 2 %
 // of a denoise step), slices of at least 128 pixels (one 32-pixel tile per wave)
 int attn_slices(int B, int n, int heads) {
-    static const int force = [] { const char* e = getenv("MI_ATTN_SLICES"); return e ? atoi(e) : 0; }();
+    static const int force = (int)mi_knob("MI_ATTN_SLICES", 0);
     if (force > 0) return (n / force >= 32) ? force : 1;
     int S = 1;
     while (S < 32 && (long)B * heads * S < 256 && n / (2 * S) >= 128) S *= 2;

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? MI_GN_WA
 int gn_prepare(const MiGnDesc* d, GnArgs& a, int& vec, int& units) {
     if (!d || d->N <= 0 || d->HW <= 0 || d->C <= 0 || d->G <= 0 || d->C % d->G) return -1;
     a.N = d->N; a.HW = d->HW; a.C = d->C; a.G = d->G; a.Cg = d->C / d->G; a.eps = d->eps;
-    static const int xcd_env = [] { const char* e = getenv("MI_GN_XCD"); return e ? atoi(e) : 1; }();
+    static const int xcd_env = (int)mi_knob("MI_GN_XCD", 1);
     a.xcd_map = xcd_env;
     a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr;
     int cg = a.Cg;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
 // 8-channel lanes: bf16 tensors only (a lane's 8 channels are one 16-byte access), every stride a multiple of 8 elements, slices
 // of 5..8 units per thread (the level-0 layers)
 static bool gn_vec8(const GnArgs& a, int io_all16, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
-    static const int on = [] { const char* e = getenv("MI_GN_VEC8"); return e ? atoi(e) : 0; }();
+    static const int on = (int)mi_knob("MI_GN_VEC8", 0);
     if (!on || !io_all16 || a.vec8_units <= 4 || a.vec8_units > 8) return false;      // measured on the 1024-pixel slices: backward 36.1 -> 33.0 us with fp32 caches, but no better than 4-channel lanes once the caches are packed (4 waves per SIMD): off by default
     for (int l : lds) if (l % 8) return false;
     for (const void* p : ptrs) if ((uintptr_t)p & 15) return false;
@@ -814,7 +814,7 @@ static int ln_bwd_go(int M, int C, const float* x, int ldx, const float* g, floa
     a.lddx = lddx; a.accumulate = accumulate_dx; a.eps = eps;
     const bool half = C <= 128;                       // two pixels per wave
     // every workgroup ends with 2*C atomics on the same C addresses: fewer, longer-running workgroups for wide layers
-    static const int capenv = [] { const char* e = getenv("MI_LN_BLOCKS"); return e ? atoi(e) : 0; }();
+    static const int capenv = (int)mi_knob("MI_LN_BLOCKS", 0);
     int cap = capenv ? capenv : 512;            // measured best of 256..2048 on the cfg-2 shapes
     int blocks = (M + (half ? 7 : 3)) / (half ? 8 : 4); if (blocks > cap) blocks = cap;
     hipStream_t st = (hipStream_t)stream;

@@ -425,7 +425,7 @@ extern "C" int mi_conv_small_cin_fwd(int ks, int N, int H, int W, int Cin, int C
     const bool vec = ldx % 4 == 0 && ((uintptr_t)x & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
     {   // 3x3 on whole-row tiles of 64 pixels with the taps in LDS (see small_cin3x3_fwd_tiled_kernel)
-        static const int tiled = [] { const char* e = getenv("MI_SMALL_CIN_TILED"); return e ? atoi(e) : 1; }();
+        static const int tiled = (int)mi_knob("MI_SMALL_CIN_TILED", 1);
         const int rows = w_sh >= 0 && W <= 64 ? 64 / W : 0;
         if (tiled && ks == 3 && pow2 && vec && ldx == 4 && rows >= 1 && H % rows == 0 && (rows + 2) * (W + 2) <= 256 && Cout <= 256) {
             const int ntiles = N * H * W / 64;
@@ -465,7 +465,7 @@ extern "C" int mi_conv_small_cin_wgrad(int ks, int N, int H, int W, int Cin, int
     const size_t lds = (size_t)3 * na * (Cout / 4) * 4 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     {   // 3x3 on whole-row tiles of 64 pixels with the taps in LDS (small_cin3x3_wgrad_tiled_kernel); same partial-tile contract
-        static const int tiled = [] { const char* e = getenv("MI_SMALL_CIN_TILED"); return e ? atoi(e) : 1; }();
+        static const int tiled = (int)mi_knob("MI_SMALL_CIN_TILED", 1);
         const int rows = w_sh >= 0 && W <= 64 ? 64 / W : 0;
         if (tiled && ks == 3 && pow2 && vec && ldx == 4 && rows >= 1 && H % rows == 0 && (rows + 2) * (W + 2) <= 256 && Cout >= 128) {
             const int ntiles = N * H * W / 64;

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void vq_scatter_kernel(int M, int D, const flo
 }  // namespace
 
 static bool vq_split(int M) {                                 // 32-row workgroups while 128-row ones would leave CUs idle
-    static const int thr = [] { const char* e = getenv("MI_VQ_SPLIT_BELOW"); return e ? atoi(e) : 384; }();
+    static const int thr = (int)mi_knob("MI_VQ_SPLIT_BELOW", 384);
     return (M + 127) / 128 < thr;
 }
 

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WgradArgs a, i
 
 template <int BI, int BJ>
 void launch_fast(WgradArgs a, int dw_sh, int dhw_sh, hipStream_t st) {
-    static const int xcd_env = [] { const char* e = getenv("MI_WGRAD_XCD"); return e ? atoi(e) : 1; }();
+    static const int xcd_env = (int)mi_knob("MI_WGRAD_XCD", 1);
     a.gx = (a.Ci + BI - 1) / BI; a.gy = (a.Cj + BJ - 1) / BJ;
     a.xcd_map = xcd_env && a.splits >= 8;
     dim3 grid(a.gx, a.gy, a.KH * a.KW * a.splits);
@@ -426,7 +426,7 @@ extern "C" int mi_conv_wgrad(const MiWgradDesc* d, const float* P, const float* 
     a.splits = (a.Mtot + a.chunk - 1) / a.chunk;
     hipStream_t st = (hipStream_t)stream;
     {   // aligned bf16 layers on a power-of-two dense grid: the straight-line ring kernel
-        static const int allow_fast = [] { const char* e = getenv("MI_WGRAD_FAST"); return e ? atoi(e) : 1; }();
+        static const int allow_fast = (int)mi_knob("MI_WGRAD_FAST", 1);
         auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
         const int dw_sh = lg(d->DW), dhw_sh = lg(d->DH * d->DW);
         if (allow_fast && d->mode == 1 && a.vec && dw_sh >= 0 && dhw_sh >= 0 && d->Ci % 4 == 0 && d->Cj % 4 == 0 && d->I1 % 4 == 0 &&

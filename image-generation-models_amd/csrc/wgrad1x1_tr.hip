@@ -232,7 +232,7 @@ void w1_shares(int n, const MiWgradDesc* d, const int* q32, long* wgs) {
         tot += by[i];
     }
     const long target = g_w1_blocks > 0 ? g_w1_blocks : 256;
-    static const int greedy = [] { const char* e = getenv("MI_W1_BALANCE"); return e ? atoi(e) : 1; }();
+    static const int greedy = (int)mi_knob("MI_W1_BALANCE", 1);
     if (greedy) {               // whole k-slices to whoever carries the most bytes per workgroup (tr_common.h)
         long tiles[MAXP];
         for (int i = 0; i < n; ++i) tiles[i] = (long)(d[i].Ci / 64) * ((d[i].Cj + 127) / 128);
@@ -297,7 +297,7 @@ extern "C" int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         a.ldp = descs[i].ldp; a.ldp2 = (P2 && P2[i]) ? descs[i].ldp2 : descs[i].ldp; a.ldq = descs[i].ldq;
         a.ws = (float*)workspace + off;
         off += w1_ws_floats(a);
-        static const int xcd_env = [] { const char* e = getenv("MI_W1_XCD"); return e ? atoi(e) : 1; }();
+        static const int xcd_env = (int)mi_knob("MI_W1_XCD", 1);
         a.xcd_map = xcd_env && a.gx * a.gy > 1 && a.splits > 1;
         a.wg0 = wg; wg += a.gx * a.gy * a.splits;
         a.tile0 = tile; if (a.splits > 1) tile += a.gx * a.gy;

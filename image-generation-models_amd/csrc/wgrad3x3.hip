@@ -495,7 +495,7 @@ static int w3_plan(const MiWgradDesc* d, W3Args& a, int& BJ, bool& wide) {
     a.tw_sh = a.TW == 16 ? 4 : (a.TW == 8 ? 3 : 2);
     a.tiles_x = a.W / a.TW; a.tiles = a.tiles_x * (a.H / a.TH);
     a.total = (a.N / 8) * a.tiles;
-    static const int force_nj = [] { const char* e = getenv("MI_W3_NJ"); return e ? atoi(e) : 0; }();
+    static const int force_nj = (int)mi_knob("MI_W3_NJ", 0);
     wide = force_nj ? force_nj == 2 : (d->Cj % 128 == 0 || d->Cj > 256);
     {   // the double-buffered LDS image must fit 160 KB: 4x4 images (25 X slots per channel) only fit with 64-wide co tiles
         const int xp = ((a.TH * (a.TW + d->KH - 1)) | 1) * 8;
@@ -505,10 +505,10 @@ static int w3_plan(const MiWgradDesc* d, W3Args& a, int& BJ, bool& wide) {
     const int KS = d->KH;
     long base = (long)((d->Ci + 127) / 128) * ((d->Cj + BJ - 1) / BJ) * KS;
     // exactly one round of workgroups: the kernel holds ~480 registers per lane, i.e. one workgroup per CU
-    static const long target = [] { const char* e = getenv("MI_W3_BLOCKS"); return e ? atol(e) : 256L; }();
+    static const long target = mi_knob("MI_W3_BLOCKS", 256);
     long splits = target / base;
     // a k-slice costs a prologue, a partial-tile store and a share of the reduce: keep >= MINC chunks per slice
-    static const long minc = [] { const char* e = getenv("MI_W3_MINC"); return e ? atol(e) : 1L; }();
+    static const long minc = mi_knob("MI_W3_MINC", 1);
     if (splits > a.total / minc) splits = a.total / minc;
     if (splits < 1) splits = 1;
     a.cps = (int)((a.total + splits - 1) / splits);
@@ -516,7 +516,7 @@ static int w3_plan(const MiWgradDesc* d, W3Args& a, int& BJ, bool& wide) {
     a.gx = (d->Ci + 127) / 128; a.gy = (d->Cj + BJ - 1) / BJ;
     // measured: helps the HBM-bound 1x1 gradients with many k-slices (77 -> 64 us for 128->384 at 32x32), neutral or
     // harmful for the 3x3 ones (not traffic-bound; rounding the k-slices up to a multiple of 8 idles workgroups)
-    static const int xcd_env = [] { const char* e = getenv("MI_W3_XCD"); return e ? atoi(e) : 1; }();
+    static const int xcd_env = (int)mi_knob("MI_W3_XCD", 1);
     a.xcd_map = xcd_env == 2 || (xcd_env == 1 && KS == 1 && a.splits >= 32);
     return 0;
 }

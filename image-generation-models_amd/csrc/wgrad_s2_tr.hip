@@ -339,7 +339,7 @@ bool s2_ok(const MiWgradDesc* d) {
 }
 
 long s2_target() {
-    static const long env_target = [] { const char* e = getenv("MI_WS2_BLOCKS"); return e ? atol(e) : 256L; }();
+    static const long env_target = mi_knob("MI_WS2_BLOCKS", 256);
     return env_target;
 }
 
@@ -367,7 +367,7 @@ void s2_shares(int n, const MiWgradDesc* d, long* wgs) {
     double tot = 0, fl[MAXP];
     for (int i = 0; i < n; ++i) { fl[i] = (double)d[i].N * d[i].DH * d[i].DW * d[i].Ci * d[i].Cj * d[i].KH * d[i].KW; tot += fl[i]; }
     const long target = s2_target();
-    static const int greedy = [] { const char* e = getenv("MI_WS2_BALANCE"); return e ? atoi(e) : 1; }();
+    static const int greedy = (int)mi_knob("MI_WS2_BALANCE", 1);
     if (greedy) {
         long tiles[MAXP];
         for (int i = 0; i < n; ++i) tiles[i] = s2_tiles(&d[i]);
@@ -432,7 +432,7 @@ extern "C" int mi_conv_s2_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         a.dW = dW[i];
         a.ws = (float*)workspace + off;
         off += s2_ws_floats(a);
-        static const int xcd_env = [] { const char* e = getenv("MI_WS2_XCD"); return e ? atoi(e) : 1; }();
+        static const int xcd_env = (int)mi_knob("MI_WS2_XCD", 1);
         a.xcd_map = xcd_env && a.ntiles > 1 && a.splits > 1;
         a.wg0 = wg; wg += a.ntiles * a.splits;
         a.tile0 = tile; if (a.splits > 1) tile += a.ntiles;

@@ -315,7 +315,7 @@ bool tr_ok(const MiWgradDesc* d) {
 int g_wtr_blocks = 0;       // mi_debug_wgrad_tr_blocks: workgroups wanted per launch (0 = one per CU)
 
 long tr_target() {
-    static const long env_target = [] { const char* e = getenv("MI_WTR_BLOCKS"); return e ? atol(e) : 256L; }();
+    static const long env_target = mi_knob("MI_WTR_BLOCKS", 256);
     return g_wtr_blocks > 0 ? g_wtr_blocks : env_target;
 }
 
@@ -339,7 +339,7 @@ void tr_shares(int n, const MiWgradDesc* d, long* wgs) {
         fl[i] = (double)d[i].N * d[i].DH * d[i].DW * d[i].Ci * ((d[i].Cj + 127) / 128 * 128);
         tiles[i] = (long)(d[i].Ci / 64) * ((d[i].Cj + 127) / 128);
     }
-    static const int greedy = [] { const char* e = getenv("MI_WTR_BALANCE"); return e ? atoi(e) : 1; }();
+    static const int greedy = (int)mi_knob("MI_WTR_BALANCE", 1);
     const long target = tr_target();
     if (greedy) { balance_shares(n, fl, tiles, target, wgs); return; }
     double tot = 0;
@@ -411,7 +411,7 @@ extern "C" int mi_conv3x3_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         a.ldp = descs[i].ldp; a.ldp2 = (P2 && P2[i]) ? descs[i].ldp2 : descs[i].ldp; a.ldq = descs[i].ldq;
         a.ws = (float*)workspace + off;
         off += tr_ws_floats(a);
-        static const int xcd_env = [] { const char* e = getenv("MI_WTR_XCD"); return e ? atoi(e) : 2; }();
+        static const int xcd_env = (int)mi_knob("MI_WTR_XCD", 2);
         a.xcd_map = 0;
         if (xcd_env && a.gx * a.gy > 1 && wg % 8 == 0) {
             if (a.splits % 8 == 0) a.xcd_map = 1;
@@ -423,7 +423,7 @@ extern "C" int mi_conv3x3_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         const size_t l = tr_lds(a.W);
         if (l > lds) lds = l;
     }
-    static const int dbg = [] { const char* e = getenv("MI_WTR_DEBUG"); return e ? atoi(e) : 0; }();
+    static const int dbg = (int)mi_knob("MI_WTR_DEBUG", 0);
     if (dbg) {
         fprintf(stderr, "[wgrad_tr] %d layers, %d workgroups\n", n, wg);
         for (int i = 0; i < n; ++i) {

@@ -256,11 +256,11 @@ class Unet(nn.Module):
         # statistics by a pass over c1 (mi_gn_stats_coef); "2": everywhere, statistics from conv1's epilogue.
         self.fuse_gn_conv = os.environ.get("MI_DDPM_FUSE_GN", "auto")
         # Downsample / Upsample weight gradients through the LDS-DMA kernel (csrc/wgrad_s2_tr.hip); 0 = round 1's ring kernel
-        self.s2_wgrad_tr = os.environ.get("MI_DDPM_S2_TR", "1") != "0"
+        self.s2_wgrad_tr = K.debug_knob("MI_DDPM_S2_TR", "1") != "0"
         # final_conv.0's conv output stored like the other Blocks' (bf16 in bf16 mode); 0 = fp32 as in round 1
-        self.final_block16 = os.environ.get("MI_DDPM_FINAL16", "1") != "0"
+        self.final_block16 = K.debug_knob("MI_DDPM_FINAL16", "1") != "0"
         # LinearAttention's to_out conv writes the bf16 copy of its (residual-stream) output along; 0 = separate conversion launches
-        self.dual_out = os.environ.get("MI_DDPM_DUAL_OUT", "1") != "0"
+        self.dual_out = K.debug_knob("MI_DDPM_DUAL_OUT", "1") != "0"
         self.accumulate_grads = False
         self.grad_ready_hook = None        # callable(lo, hi): flat_grads[lo:hi) is final (set by the DDP reducer)
 
@@ -458,13 +458,13 @@ class Unet(nn.Module):
         sh: Dict[int, tuple] = {}          # id(tensor) -> (tensor, copy): holding the tensor keeps its id from being reused
         # (training only: in inference there is no weight gradient to feed and the copies cost 2.5 % of a denoise step)
         use_sh = (record and mode == K.MODE_BF16 and self.block_storage in ("bf16", "auto")
-                  and os.environ.get("MI_DDPM_SHADOW", "1") == "1")
+                  and K.debug_knob("MI_DDPM_SHADOW", "1") == "1")
 
         # inference: the GroupNorm kernel of a ResnetBlock whose output goes straight into the next Block's conv can write the bf16 copy
         # along (no conversion launch).  Off: measured 680 vs 720 denoise steps/s at B = 64 -- the dual-output GroupNorm costs
         # +4 us per launch and the convs that switch to bf16 input were the cheap ones
         eval16 = (not record and mode == K.MODE_BF16 and self.block_storage in ("bf16", "auto")
-                  and os.environ.get("MI_DDPM_EVAL16", "0") == "1")
+                  and K.debug_knob("MI_DDPM_EVAL16", "0") == "1")
 
         def s2_copy(c, k, transposed):      # Downsample / Upsample read (and their weight gradients want) a bf16 copy of their input
             return (use_sh and self.s2_wgrad_tr and K.igemm_bf16_in_supported(c, c, k, 2, transposed, mode, (8, 8)))
@@ -564,7 +564,10 @@ class Unet(nn.Module):
                 h1, st1 = K.gn_mish_fwd(c1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], temb=tb,
                                         out_dtype=BF if lo16 else torch.float32)
                 c2 = conv(h1, pre + "block2.block.0.", 3, 1, 1, out_dtype=BF if lo16 else torch.float32)
-            r = conv(inp, pre + "res_conv.", 1, x2=x2) if blk["res"] else inp
+            # res_conv reads the bf16 copies where block1's conv does (the tile kernels round an fp32 input to bf16 while staging it: the
+            # same numbers, half the bytes, and the streaming 1x1 kernel takes bf16 operands only)
+            rc_in, rc_x2 = (inp_c, x2_c) if (inp_c is not inp and inp_c.dtype == BF and (x2 is None or x2_c is not None)) else (inp, x2)
+            r = conv(rc_in, pre + "res_conv.", 1, x2=rc_x2) if blk["res"] else inp
             if want_out16 and (use_sh or (eval16 and out16_in_eval)) and co % 32 == 0:
                 out, st2, out16 = K.gn_mish_fwd(c2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], residual=r, want16=True)
                 sh[id(out)] = (out, out16)
@@ -654,7 +657,7 @@ class Unet(nn.Module):
         G = _GradMap()
         # data parallel (a grad-ready hook is set): the two Upsample layers come early in backward, the two Downsample layers last; with
         # all four in one launch at the very end their 8 MB of gradients would be all-reduced after backward, exposed -- two per launch
-        wq = K.WgradQueue(group=int(os.environ.get("MI_DDPM_WGRAD_GROUP", "8")),
+        wq = K.WgradQueue(group=int(K.debug_knob("MI_DDPM_WGRAD_GROUP", "8")),
                           group_s2=2 if self.grad_ready_hook is not None else None)
         x_in = tape[-1][1]
         B = x_in.shape[0]

@@ -17,19 +17,24 @@ import torch
 from .lib import MiConvDesc, MiGnDesc, MiWgradDesc, check, load_library
 
 MODE_FP32, MODE_BF16 = 0, 1
+
+
+def debug_knob(name: str, default: str) -> str:
+    """Experiment / A-B switches (kernel picks, copies on or off): honoured only when MI_DEBUG_KNOBS=1 is set as well (tools/ do
+    that), so that a stray variable cannot put a production run on a path the test suite does not cover.  The mode selectors a
+    user is meant to set are read directly: MI_DDPM_MODE, MI_DDPM_STORAGE, MI_DDPM_FUSE_GN, MI_DDPM_GRAPH, MI_DDPM_LIB,
+    MI_CONV_AUTO (halo-only fallback, covered by a subprocess test), MI_DDP_BUCKET_MB, MI_DIST_BACKEND."""
+    if os.environ.get("MI_DEBUG_KNOBS") == "1":
+        return os.environ.get(name, default)
+    return default
 PROBE = None      # bench.py sets this to a list: (kernel symbol, algorithmic FLOPs, start event, end event, shape note, algorithmic
                   # HBM bytes) per launch, events recorded on the launch stream
 
 
-# The LDS-DMA 3x3 conv kernel (csrc/conv_dma.hip) is opt-in: measured against the register-staged halo kernel on the cfg-2 shapes
-# (tools/bench_dma_conv.py, B=128, bf16 in/out) it is 3-6 % faster on the 8x8 level (512->512: 41.5 vs 44.2 us) and 15 % slower on
-# the 32x32 / 16x16 levels (128->128: 62.5 vs 53.7 us): with one 64x64 tile per wave both kernels move 1 KB of LDS per MFMA and the
-# DMA writes share the LDS port with the fragment reads.
-USE_CONV_DMA = os.environ.get("MI_CONV_DMA", "0") == "1"
 # MI_CONV_SHIFT=1 forces the LDS-frugal variant (csrc/conv_shift.hip: left / right tap columns by DPP lane shifts, half the LDS operand
 # reads) wherever it applies.  Its first, 4-wave form lost to the halo kernel on every shape (128->128 @32x32: 62.8 vs 52.6 us); with 8
 # waves (two per SIMD, like the halo tiles) it is the faster kernel of the two -- see _pick3x3 below.
-USE_CONV_SHIFT = os.environ.get("MI_CONV_SHIFT", "0") == "1"
+USE_CONV_SHIFT = debug_knob("MI_CONV_SHIFT", "0") == "1"
 # Which 3x3 kernel takes a bf16-stored layer when none is forced: the LDS-frugal conv_shift (centre-column fragments + DPP shifts: half
 # the LDS operand reads) for the layers with >= 128 channels on both sides, the register-staged halo kernel for the rest.  Per shape
 # (tools/bench_dma_conv.py, B = 128) conv_shift wins 4-7 % on the 32- and 16-pixel-wide levels (level 0: 50.1 vs 54.0 us) and ties on
@@ -42,7 +47,7 @@ CONV_AUTO = os.environ.get("MI_CONV_AUTO", "1") == "1"
 def _pick3x3(W, K, Nc):
     if not CONV_AUTO or K < 128 or Nc < 128:
         return "halo"
-    if W <= 8 and os.environ.get("MI_CONV_PICK8", "1") == "1":
+    if W <= 8 and debug_knob("MI_CONV_PICK8", "1") == "1":
         # 8x8 level, per shape (shift vs halo): 512 -> 512 41.7 vs 42.3 us, 256 -> 512 a tie, but 1024 -> 256 64.4 vs 57.3 and
         # 256 -> 256 21.8 vs 19.5: the narrow / very deep layers stay with the halo kernel
         return "shift" if (256 <= K <= 512 and Nc >= 512) else "halo"
@@ -50,7 +55,7 @@ def _pick3x3(W, K, Nc):
 
 
 # The private-weight-stream kernel (csrc/conv_pw.hip): 128-pixel tiles, one barrier per 64-channel chunk, two workgroups per CU.
-USE_CONV_PW = os.environ.get("MI_CONV_PW", "1") == "1"
+USE_CONV_PW = CONV_AUTO and debug_knob("MI_CONV_PW", "1") == "1"     # MI_CONV_AUTO=0: the halo kernel everywhere
 
 
 def _pick_pw(N, H, W, K, Nc):
@@ -60,10 +65,10 @@ def _pick_pw(N, H, W, K, Nc):
     return (N * H * W // 128) * ((Nc + 127) // 128) >= PW_MIN_TILES
 
 
-PW_MIN_TILES = int(os.environ.get("MI_CONV_PW_MIN_TILES", "200"))
+PW_MIN_TILES = int(debug_knob("MI_CONV_PW_MIN_TILES", "200"))
 
 
-USE_WGRAD_TR = os.environ.get("MI_W3_TR", "1") != "0"      # A/B switch for the LDS-DMA weight-gradient kernel (csrc/wgrad_tr.hip)
+USE_WGRAD_TR = debug_knob("MI_W3_TR", "1") != "0"      # A/B switch for the LDS-DMA weight-gradient kernel (csrc/wgrad_tr.hip)
 
 
 _QUERY_CACHE = {}
@@ -241,18 +246,19 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
     io = _b16(x) | (_b16(out) << 1)
     assert x2 is None or x2.dtype == x.dtype
     pick = "halo"
-    if (ksize == 1 and wq is not None and USE_CONV_PW and _b16(x) and x2 is None and gn_sums is None and K == 128
+    if (ksize == 1 and wq is not None and USE_CONV_PW and _b16(x) and gn_sums is None and K % 128 == 0
             and _query("mi_conv1x1_pw_supported", d)):
-        # K = 128: the whole tile staged once, per-wave weight streams, whole-row stores (conv1x1_pw_kernel)
+        # the streaming 1x1 kernel: tile by LDS-DMA per 128-channel chunk, per-wave weight fragments, whole-row stores (conv1x1_pw_kernel)
         y16 = new_act(N, H, W, Nc, x, torch.bfloat16) if want16 else None
         assert not (want16 and (accumulate or _b16(out)))
         e0 = _probe_open()
-        check(lib.mi_conv1x1_pw(C.byref(d), _p(x), _p(wq), _p(bias), _p(residual), _p(out), _b16(out), _p(y16),
+        check(lib.mi_conv1x1_pw(C.byref(d), _p(x), _p(x2), _p(wq), _p(bias), _p(residual), _p(out), _b16(out), _p(y16),
                                 ld_of(y16) if y16 is not None else 0, _stream()), "mi_conv1x1_pw")
         if e0 is not None:
             nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual) + (2 if want16 else 0)) + K * Nc * 2)
-            _probe_close(e0, f"conv1x1_pw_kernel<{'true' if _b16(out) else 'false'}, {'true' if want16 else 'false'}>", 2.0 * N * H * W * Nc * K,
-                         f"N{N} {H}x{W} K{K}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
+            px = 64 if (N * H * W // 128) * ((Nc + 127) // 128) < 256 else 128
+            _probe_close(e0, f"conv1x1_pw_kernel<{'true' if _b16(out) else 'false'}, {'true' if want16 else 'false'}, {px}>", 2.0 * N * H * W * Nc * K,
+                         f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
         return (out, y16) if want16 else out
     if (gn_sums is not None and ksize == 3 and _b16(x) and USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc)
             and _query("mi_conv3x3_pw_supported", d)):
@@ -267,7 +273,7 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
                          f"N{N} {H}x{W} K{K}->{Nc} + GroupNorm sums", nb)
         return out
     if gn_sums is None and not want16 and ksize == 3 and _b16(x):
-        pick = "shift" if USE_CONV_SHIFT else "dma" if USE_CONV_DMA else _pick3x3(W, K, Nc)
+        pick = "shift" if USE_CONV_SHIFT else _pick3x3(W, K, Nc)
         if USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc) and _query("mi_conv3x3_pw_supported", d):
             pick = "pw"
     if pick == "pw":
@@ -286,17 +292,8 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
             ni = C.c_int()
             lib.mi_conv3x3_shift_tile(C.byref(d), C.byref(ni))
             nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 2)
-            wm = 2 if os.environ.get("MI_SHIFT_WM", "4") == "2" else 4
+            wm = 2 if debug_knob("MI_SHIFT_WM", "4") == "2" else 4
             _probe_close(e0, f"conv_shift_kernel<{wm}, {ni.value}, {'true' if _b16(out) else 'false'}>", 2.0 * N * H * W * Nc * K * 9,
-                         f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
-        return out
-    if pick == "dma" and _query("mi_conv3x3_dma_supported", d):
-        # bf16-stored activations: the LDS-DMA kernel (conv_dma.hip)
-        e0 = _probe_open()
-        check(lib.mi_conv3x3_dma(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv3x3_dma")
-        if e0 is not None:
-            nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 2)
-            _probe_close(e0, f"conv_dma_kernel<{'true' if _b16(out) else 'false'}>", 2.0 * N * H * W * Nc * K * 9,
                          f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
         return out
     e0 = _probe_open()

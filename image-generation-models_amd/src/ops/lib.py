@@ -59,7 +59,6 @@ SIGNATURES = {
     "mi_conv_s2_wgrad_tr_supported": [C.POINTER(MiWgradDesc)],
     "mi_conv_s2_wgrad_tr_batch": [_I, C.POINTER(MiWgradDesc), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _Z, _P],
     "mi_debug_wgrad_s2_tr_phase": [_I],
-    "mi_debug_conv_dma_chunk": [_I],
     "mi_pack_weights_tile": [],
     "mi_conv3x3_bf16w_io_gnsums": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "mi_gn_coef_from_sums": [_I, _I, _I, _I, _F, _P, _P, _P, _P, _I, _P, _P, _P],
@@ -79,15 +78,13 @@ SIGNATURES = {
     "mi_conv3x3_pw": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
     "mi_conv3x3_pw_gn_mish_supported": [C.POINTER(MiConvDesc)],
     "mi_conv1x1_pw_supported": [C.POINTER(MiConvDesc)],
-    "mi_conv1x1_pw": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P],
+    "mi_conv1x1_pw": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _I, _P],
     "mi_conv3x3_pw_gnsums": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "mi_conv3x3_pw_gn_mish": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _P],
     "mi_conv3x3_pw_gn_mish_sums": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _I, _P],
-    "mi_conv3x3_dma_supported": [C.POINTER(MiConvDesc)],
     "mi_conv3x3_shift_supported": [C.POINTER(MiConvDesc)],
     "mi_conv3x3_shift_tile": [C.POINTER(MiConvDesc), C.POINTER(C.c_int)],
     "mi_conv3x3_shift": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
-    "mi_conv3x3_dma": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
     "mi_gn_stats_coef": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _I, _P, _P, _I, _P],
     "mi_conv3x3_gn_mish_supported": [C.POINTER(MiConvDesc)],
     "mi_conv3x3_gn_mish_tile": [C.POINTER(MiConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)],
@@ -165,7 +162,7 @@ OTHER = {"mi_abi_version": ([], C.c_int), "mi_last_error": ([], C.c_char_p),
          "mi_f32_to_bf16_colsum_workspace": ([_Z, _I], C.c_size_t),
          "mi_linattn_workspace": ([_I, _I, _I], C.c_size_t),
          "mi_conv_small_wgrad_workspace": ([_I], C.c_size_t)}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def load_library():

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 2   /* 2: mi_pack_weights_bf16 takes the fragment-order copies; mi_adam_step_dev betas are double */
+#define MI_ABI_VERSION 3   /* 2: mi_pack_weights_bf16 takes the fragment-order copies; mi_adam_step_dev betas are double.  3: mi_conv1x1_pw takes x2 */
 #define MI_MODE_FP32 0
 #define MI_MODE_BF16 1
 
@@ -133,17 +133,11 @@ int mi_conv3x3_gn_mish_supported(const MiConvDesc* d);
 int mi_conv3x3_gn_mish_tile(const MiConvDesc* d, int* bm, int* ck);
 int mi_conv3x3_gn_mish(const MiConvDesc* d, const void* x, const float* coef, const void* w_nk_bf16, const float* bias,
                        void* y, int io, void* stream);
-/* ---- the same convolution for bf16-STORED activations, staged entirely by LDS-DMA (conv_dma.hip) ---------------------------
- * x / x2 bf16 (pixel strides in elements, % 8 == 0), w as for mi_conv3x3_bf16w, d->transposed = 1 -> data gradient; y fp32 or
- * bf16 (out_bf16).  Needs K % 64 == 0, K1 % 64 == 0, W in 8..32 with 128-pixel row tiles, N*H*W % 128 == 0 (query _supported). */
-int mi_conv3x3_dma_supported(const MiConvDesc* d);
-/* experiment switch: 64 (default) = 64-channel chunks, one workgroup per CU; 32 = 32-channel chunks, two workgroups per CU */
-int mi_debug_conv_dma_chunk(int ck);
-int mi_conv3x3_dma(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16, const float* bias,
-                   const float* residual, void* y, int out_bf16, void* stream);
-/* ... and the LDS-frugal variant (conv_shift.hip): a wave owns 128 pixels x 64 channels and derives the left / right tap columns'
- * activation fragments from the centre column's by one-lane DPP shifts, 0.4 KB of LDS per MFMA instead of 1 KB.  Same arguments.
- * Needs W in {8, 16, 32} with 256-pixel row tiles (N*H*W % 256 == 0), K % 64 == 0, K1 % 64 == 0. */
+/* ---- the same convolution for bf16-STORED activations, staged entirely by LDS-DMA (conv_shift.hip): a wave owns 128 pixels x 64
+ * channels and derives the left / right tap columns' activation fragments from the centre column's by one-lane DPP shifts.
+ * x / x2 bf16 (pixel strides in elements, % 8 == 0), w as for mi_conv3x3_bf16w, d->transposed = 1 -> data gradient; y fp32 or bf16
+ * (out_bf16).  Needs W in {8, 16, 32} with 256-pixel row tiles (N*H*W % 256 == 0), K % 64 == 0, K1 % 64 == 0 (query _supported).
+ * The host layer takes it for the layers too small for mi_conv3x3_pw's 128 x 128 tiles to fill the chip. */
 int mi_conv3x3_shift_supported(const MiConvDesc* d);
 int mi_conv3x3_shift_tile(const MiConvDesc* d, int* ni);
 int mi_conv3x3_shift(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16, const float* bias,
@@ -184,16 +178,18 @@ int mi_conv3x3_pw_gn_mish(const MiConvDesc* d, const void* x, const float* coef,
 /* ... or without the coefficient tensor: scale / shift are resolved per channel chunk inside the kernel from the sums the producing
  * conv's epilogue left (sums [N][K/16][2], mi_conv3x3_pw_gnsums / mi_conv3x3_bf16w_io_gnsums), gamma, beta and the time-bias rows
  * temb [N][ldt] (optional) with mi_gn_coef_from_sums' arithmetic.  K / G in {16, 32, 64}.  Block -> Block = two launches. */
-/* ---- 1x1 convs with K = 128 input channels on the same machinery (to_qkv, to_out + residual, res_conv 128 -> 256, the data gradient of
- * to_out at 128 channels; reference src/models/ddpm.py:134,151-152): the whole 128-pixel x 128-channel tile is staged once, the weights
- * stream per wave, whole rows leave through LDS.  w_frag_bf16 = the layer's slice of wfq (forward) / wdq (data gradient); y fp32 or
- * bf16 (out_bf16); y_bf16 (optional, fp32 y, no accumulate): the bf16 copy of y from the same epilogue (pixel stride ldy16). */
-int mi_conv1x1_pw_supported(const MiConvDesc* d);
-int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* w_frag_bf16, const float* bias, const float* residual,
-                  void* y, int out_bf16, void* y_bf16, int ldy16, void* stream);
 int mi_conv3x3_pw_gn_mish_sums(const MiConvDesc* d, const void* x, const float* sums, const float* gamma, const float* beta,
                                const float* temb, int ldt, int G, float eps, const void* w_frag_bf16, const float* bias,
                                void* y, int out_bf16, void* stream);
+/* ---- 1x1 convs with K % 128 == 0 input channels on the same machinery (to_qkv, to_out + residual, res_conv -- also over the skip
+ * concat's two sources, x2 = channels K1 .. K - 1 with K1 % 128 == 0 -- and their data gradients; reference src/models/ddpm.py:134,151-152):
+ * 128 (or 64) pixels x 128 output channels per workgroup, the activation tile double-buffered per 128-channel chunk by LDS-DMA, weight
+ * fragments straight into registers per wave, whole rows leave through LDS.  w_frag_bf16 = the layer's slice of wfq (forward) / wdq
+ * (data gradient); y fp32 or bf16 (out_bf16); y_bf16 (optional, fp32 y, no accumulate): the bf16 copy of y from the same epilogue
+ * (pixel stride ldy16). */
+int mi_conv1x1_pw_supported(const MiConvDesc* d);
+int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias, const float* residual,
+                  void* y, int out_bf16, void* y_bf16, int ldy16, void* stream);
 
 /* ---- the 3-channel ends of the UNet (fp32 VALU, bound by the wide tensor they stream) ------------
  * Conv2d(Cin<=4, Cout, ks, padding=ks/2), ks = 3 (downs.0.0.block1, ddpm.py:116,208) or 1 (its res_conv,

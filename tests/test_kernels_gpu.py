@@ -556,9 +556,9 @@ def test_conv3x3_shift_fwd_and_dgrad(K, cfg, out16):
 def pw_always(K):
     """Route every supported layer to the private-weight-stream kernel (the default takes it only from ~one tile per CU up) and
     record the launches (functional.PROBE) so that a test can assert which kernel it exercised."""
-    was, K.PW_MIN_TILES, K.PROBE = K.PW_MIN_TILES, 0, []
+    was, was_on, K.PW_MIN_TILES, K.USE_CONV_PW, K.PROBE = K.PW_MIN_TILES, K.USE_CONV_PW, 0, True, []
     yield K.PROBE
-    K.PW_MIN_TILES, K.PROBE = was, None
+    K.PW_MIN_TILES, K.USE_CONV_PW, K.PROBE = was, was_on, None
 
 
 def _conv_launches(probe):
@@ -662,13 +662,19 @@ def test_fused_gn_mish_conv3x3_pw(K, cfg, out16, pw_always):
 
 
 @pytest.mark.parametrize("cfg", [dict(N=8, H=32, Co=384, kind="qkv"), dict(N=4, H=16, Co=128, kind="out"), dict(N=16, H=8, Co=256, kind="res"),
-                                 dict(N=2, H=16, Co=96, kind="res"), dict(N=8, H=16, Co=128, kind="dgrad")])
+                                 dict(N=2, H=16, Co=96, kind="res"), dict(N=8, H=16, Co=128, kind="dgrad"),
+                                 dict(N=32, H=16, Co=384, kind="qkv", Ci=256),                 # two chunks, 128-pixel tiles
+                                 dict(N=16, H=8, Co=384, kind="qkv", Ci=512),                  # four chunks, 64-pixel tiles
+                                 dict(N=8, H=8, Co=256, kind="res", Ci=1024, split=512),       # res_conv over the skip concat
+                                 dict(N=8, H=16, Co=128, kind="res", Ci=512, split=256),
+                                 dict(N=64, H=16, Co=128, kind="out", Ci=384),                 # odd chunk count
+                                 dict(N=8, H=16, Co=256, kind="dgrad", Ci=384)])               # to_qkv's data gradient (K = 384)
 def test_conv1x1_pw(K, cfg, pw_always):
-    """The 1x1 convs with 128 input channels through mi_conv1x1_pw (reference ddpm.py:134,151-152): to_qkv (no bias, bf16 out),
+    """The 1x1 convs with K % 128 == 0 input channels through mi_conv1x1_pw (reference ddpm.py:134,151-152): to_qkv (no bias, bf16 out),
     to_out (bias + fp32 residual, fp32 out AND its bf16 copy from the same epilogue), res_conv (bias, fp32 out, a ragged channel tile),
     and the data gradient of to_out (transposed weights, accumulate into an fp32 buffer); against fp64 on the bf16-rounded operands."""
     N, H, Co, kind = cfg["N"], cfg["H"], cfg["Co"], cfg["kind"]
-    Ci = 128
+    Ci, split = cfg.get("Ci", 128), cfg.get("split")
     g = torch.Generator().manual_seed(83)
     x = torch.randn(N, Ci, H, H, generator=g).bfloat16()
     Cop = (Co + 63) // 64 * 64
@@ -703,7 +709,8 @@ def test_conv1x1_pw(K, cfg, pw_always):
         assert rel_err(from_nhwc(y), ref) < 1e-5 and torch.equal(y16, y.bfloat16())
     else:
         ref = y64 + b.double()[None, :, None, None]
-        y = K.conv3x3_bf16w(nh(x), wf, K=Ci, Nc=Cop, flip=False, ksize=1, bias=b.to(DEV), wq=wfq)
+        xa, xb = (nh(x[:, :split]), nh(x[:, split:])) if split else (nh(x), None)
+        y = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Cop, flip=False, ksize=1, bias=b.to(DEV), wq=wfq, x2=xb)
         torch.cuda.synchronize()
         assert rel_err(from_nhwc(y)[:, :Co], ref[:, :Co]) < 1e-5 and not y[..., Co:].any()
     assert _conv_launches(pw_always)[-1].startswith("conv1x1_pw_kernel"), _conv_launches(pw_always)
@@ -796,61 +803,6 @@ def test_conv3x3_pw_fwd_and_dgrad(K, cfg, out16, pw_always):
     assert rel_err(yg.float(), y2.float()) < tol
 
 
-@pytest.mark.parametrize("out16", [False, True])
-@pytest.mark.parametrize("cfg", [
-    dict(N=2, H=32, Ci=128, Co=128),             # level 0: 4 rows of 32 per tile, XCD-grouped order needs N % 8 (off here)
-    dict(N=8, H=32, Ci=64, Co=256),              # XCD-grouped tile order, 2 co tiles
-    dict(N=4, H=16, Ci=256, Co=128, split=128),  # skip concat (two sources), 8 rows of 16
-    dict(N=16, H=8, Ci=512, Co=512),             # two 8x8 images per tile, 8 chunks
-    dict(N=2, H=16, Ci=64, Co=96),               # ragged co tile
-    dict(N=4, H=8, Ci=1024, Co=64, split=512),   # long K, half-empty co tile
-])
-@pytest.mark.parametrize("chunk", [64, 32, 33])
-def test_conv3x3_lds_dma_fwd_and_dgrad(K, cfg, out16, chunk, request):
-    """Block's 3x3 conv (ddpm.py:116) and its data gradient for bf16-stored activations through the LDS-DMA kernel
-    (mi_conv3x3_dma): bias, residual, fp32 and bf16 output, accumulate; against fp64 on the same bf16-rounded operands.
-    chunk = 32: the variant with 32-channel chunks and two workgroups per CU; 33: one tap per stage, three workgroups per CU."""
-    K.load_library().mi_debug_conv_dma_chunk(chunk)
-    request.addfinalizer(lambda: K.load_library().mi_debug_conv_dma_chunk(64))
-    from src.ops.lib import MiConvDesc, load_library
-    import ctypes
-    N, H, Ci, Co = cfg["N"], cfg["H"], cfg["Ci"], cfg["Co"]
-    split = cfg.get("split")
-    g = torch.Generator().manual_seed(53)
-    x = torch.randn(N, Ci, H, H, generator=g).bfloat16()
-    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9))
-    b = torch.randn(Co, generator=g)
-    r = torch.randn(N, Co, H, H, generator=g)
-    dy = torch.randn(N, Co, H, H, generator=g).bfloat16()
-    xq = x.double().requires_grad_(True)
-    wq = w.bfloat16().double()
-    yq = F.conv2d(xq, wq, b.double(), padding=1) + r.double()
-    yq.backward(dy.double())
-    flat, wd, wf, offs = _pack(K, [conv_w_storage(w.double())])
-    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
-    xa, xb = (nh(x[:, :split]), nh(x[:, split:])) if split else (nh(x), None)
-    d = MiConvDesc(N=N, IH=H, IW=H, OH=H, OW=H, K=Ci, Nc=Co, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=1, K1=split or Ci,
-                   ldx=xa.shape[3], ldx2=xb.shape[3] if xb is not None else 0, ldy=Co, ldr=Co, accumulate=0)
-    assert load_library().mi_conv3x3_dma_supported(ctypes.byref(d)) == 1
-    was = K.USE_CONV_DMA
-    K.USE_CONV_DMA = True                        # opt-in kernel (functional.py explains why)
-    odt = torch.bfloat16 if out16 else torch.float32
-    tol = 6e-3 if out16 else 1e-5                                        # bf16 output: one more rounding
-    yg = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Co, flip=False, x2=xb, bias=b.to(DEV), residual=to_nhwc_gpu(r), out_dtype=odt)
-    assert yg is not None and yg.dtype == odt
-    dxg = K.conv3x3_bf16w(nh(dy), wd, K=Co, Nc=Ci, flip=True, out_dtype=odt)
-    torch.cuda.synchronize()
-    assert rel_err(from_nhwc(yg.float()), yq) < tol
-    assert rel_err(from_nhwc(dxg.float()), xq.grad) < tol
-    dx2 = K.conv3x3_bf16w(nh(dy), wd, K=Co, Nc=Ci, flip=True, out=dxg.clone(), accumulate=True)
-    assert rel_err(from_nhwc(dx2.float()), 2 * xq.grad) < 2 * tol
-    # and the register-staged halo kernel on the same operands
-    K.USE_CONV_DMA = False
-    try:
-        y2 = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Co, flip=False, x2=xb, bias=b.to(DEV), residual=to_nhwc_gpu(r), out_dtype=odt)
-    finally:
-        K.USE_CONV_DMA = was
-    assert rel_err(yg.float(), y2.float()) < tol
 
 
 @pytest.mark.parametrize("cfg", [
@@ -1416,23 +1368,9 @@ def test_small_gemm_linear(K, M, N, Kc):
     assert K.small_gemm(False, True, xg[:, :Kc - 1], wg[:, :Kc - 1]) is None          # K % 32 != 0 -> caller falls back
 
 
-def test_conv3x3_three_slot_variant_in_a_subprocess():
-    """MI_HALO_PIPE=1 (read once per process): the 3x3 conv kernels with three weight slots, the next tap's first MFMA operands fetched
-    before the barrier and the LDS stores at the top of the tap pass the same forward / data-gradient / dual-output / epilogue-sum
-    parity tests as the default two-slot kernels (MI_CONV_AUTO=0: every bf16 layer goes to the halo kernel, not to conv_shift)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, MI_HALO_PIPE="1", MI_CONV_AUTO="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
-                        "test_conv3x3_halo_fwd_and_dgrad or test_conv_dual_output or test_conv_epilogue_groupnorm_sums or test_conv_forward"],
-                       capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-
-
 def test_halo_kernel_takes_every_bf16_layer_in_a_subprocess():
     """MI_CONV_AUTO=0: the register-staged halo kernel (the fallback of the per-shape pick, and the only kernel behind the dual-output,
-    epilogue-sum and fused entry points) on the bf16-stored layers that conv_shift takes by default -- every conv kernel test and the
+    epilogue-sum and fused entry points) on the bf16-stored layers that conv_pw / conv1x1_pw / conv_shift take by default -- every conv kernel test and the
     end-to-end bf16 block test."""
     import os
     import subprocess

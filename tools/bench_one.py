@@ -32,6 +32,14 @@ for _ in range(5):
             gam = torch.ones(Ci, device=DEV); bet = torch.zeros(Ci, device=DEV); tb = torch.randn(B, Ci, device=DEV) * 0.1
             _, COEF = K.gn_stats_coef(x, gam, bet, temb=tb)
         K.conv3x3_gn_mish(x, COEF, wf, K=Ci, Nc=Co, bias=None)
+    elif which == "fusedpw":     # the named fused kernel on the private-weight-stream structure (coefficient tensor given)
+        if "COEF" not in globals():
+            gam = torch.ones(Ci, device=DEV); bet = torch.zeros(Ci, device=DEV); tb = torch.randn(B, Ci, device=DEV) * 0.1
+            _, COEF = K.gn_stats_coef(x, gam, bet, temb=tb)
+            table, nent, tiles = K.pack_table([(0, 9, Ci, Co)], DEV)
+            WQ = [torch.zeros(w.numel(), device=DEV, dtype=torch.bfloat16) for _ in range(4)]
+            K.pack_weights_bf16(table, nent, tiles, w.reshape(-1), *WQ)
+        K.conv3x3_gn_mish(x, COEF, WQ[1], K=Ci, Nc=Co, bias=None, wq=WQ[3])
     elif which == "gn":          # GroupNorm+Mish of a Block (bf16 in / out) forward + backward on [B,H,H,Ci]
         if "GN" not in globals():
             ga = torch.ones(Ci, device=DEV); be = torch.zeros(Ci, device=DEV); tb = torch.randn(B, Ci, device=DEV)

@@ -3,7 +3,7 @@ roofline.traffic).  FETCH_SIZE is doubled as MI355X_MICROARCH.md's HBM/rocprofv3
 in KB.  usage: python tools/make_traffic_json.py r02"""
 import glob, json, os, re, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 
 # bench_one.py case -> (symbol bench.py reports, shape text, algorithmic bytes per launch)
@@ -14,6 +14,11 @@ CASES = {
     "halo_128_32_128_128_fp32": ("conv3x3_halo_kernel<256, 64, 3, false, 0, 8>", "[128,32,32,128]->128 fp32 storage", conv_bytes(128, 32, 128, 128, 4, 4)),
     "shift_128_8_512_512_bf16": ("conv_shift_kernel<4, 1, true>", "[128,8,8,512]->512 bf16 storage", conv_bytes(128, 8, 512, 512, 2, 2)),
     "shift_128_32_128_128_bf16": ("conv_shift_kernel<4, 2, true>", "[128,32,32,128]->128 bf16 storage", conv_bytes(128, 32, 128, 128, 2, 2)),
+    "pw_128_8_512_512_bf16": ("conv_pw_kernel<true>", "[128,8,8,512]->512 bf16 storage", conv_bytes(128, 8, 512, 512, 2, 2)),
+    "pw_128_32_128_128_bf16": ("conv_pw_kernel<true> [level 0]", "[128,32,32,128]->128 bf16 storage", conv_bytes(128, 32, 128, 128, 2, 2)),
+    "pw_128_16_256_256_bf16": ("conv_pw_kernel<true> [16x16]", "[128,16,16,256]->256 bf16 storage", conv_bytes(128, 16, 256, 256, 2, 2)),
+    "fusedpw_128_32_128_128_bf16": ("conv_pw_kernel<true, 2>", "fused GN+Mish+conv [128,32,32,128]->128 bf16 storage (private-weight-stream kernel)",
+                                    conv_bytes(128, 32, 128, 128, 2, 2) + 3 * 128 * 128 * 4),
     "wgrad_128_32_128_128_bf16": ("wgrad_tr_kernel[single]", "[128,32,32,128]x[128,32,32,128] bf16 operands, one layer per launch",
                                   2 * 128 * 32 * 32 * 128 * 2 + 9 * 128 * 128 * 4),
     "wgrad_128_8_512_512_bf16": ("wgrad_tr_kernel[single 8x8]", "[128,8,8,512]x[128,8,8,512] bf16 operands, one layer per launch",
@@ -26,7 +31,7 @@ CASES = {
     "fused_128_32_128_128_fp32": ("conv3x3_halo_kernel<256, 64, 3, false, 0, 8, true>", "fused GN+Mish+conv [128,32,32,128]->128 fp32 storage",
                                   conv_bytes(128, 32, 128, 128, 4, 4) + 3 * 128 * 128 * 4),
 }
-MAIN = {"shift": "conv_shift_kernel", "halo": "conv3x3_halo_kernel", "fused": "conv3x3_halo_kernel", "wgrad": "wgrad_tr_kernel(", "wgradq": "wgrad_tr_kernel("}
+MAIN = {"pw": "conv_pw_kernel", "fusedpw": "conv_pw_kernel", "shift": "conv_shift_kernel", "halo": "conv3x3_halo_kernel", "fused": "conv3x3_halo_kernel", "wgrad": "wgrad_tr_kernel(", "wgradq": "wgrad_tr_kernel("}
 
 # HBM-bound kernels (tools/bench_one.py gn / ln / attn / c1x1 at level 0, B = 128, bf16 storage): every kernel of the pass gets a row
 E0 = 128 * 32 * 32 * 128
@@ -37,7 +42,7 @@ HBM_CASES = {
                                "chan_ln_bwd_kernel": ("channel LayerNorm bwd (x fp32, dy bf16 in; dx fp32 read-modify-write)", E0 * 14)},
     "attn_128_32_128_128_bf16": {"linattn_fwd_kernel": ("LinearAttention fwd, qkv [128,32,32,384] bf16 (k twice: max pass)", E0 * 2 * 5),
                                  "linattn_bwd_kernel": ("LinearAttention bwd (q, dout, then dout, k, v in; dq, dk, dv out; bf16)", E0 * 2 * 8)},
-    "c1x1_128_32_128_384_bf16": {"conv3x3_halo_kernel": ("to_qkv 1x1 conv 128 -> 384 @32x32, bf16 in / out", E0 * 2 * 4 + 128 * 384 * 2)},
+    "c1x1_128_32_128_384_bf16": {"conv1x1_pw_kernel": ("to_qkv 1x1 conv 128 -> 384 @32x32, bf16 in / out", E0 * 2 * 4 + 128 * 384 * 2)},
 }
 
 out = {}
