@@ -45,17 +45,10 @@ struct PwArgs {
     int ldt, cpg, hw; float eps;
 };
 
-constexpr int PBM = 128;                        // output pixels per workgroup
 constexpr int PCK = 64;                         // channels per chunk
-constexpr int PXP = 192;                        // tile pixels incl. the row above and below: 6 x 32, 10 x 16, 2 images x 10 x 8
-constexpr int PXBUF = PXP * 128;                // one chunk of the activation tile
-constexpr int PXPW = PXP / 8 / 4;               // activation DMA instructions per wave and chunk
-constexpr int PR = 8;                           // weight ring of a wave: fragments of 1 KB
-constexpr int PWOFF = 2 * PXBUF;                // LDS: [2 activation buffers][4 waves x PR KB]
-constexpr int PLDS = PWOFF + 4 * PR * 1024;     // 80 KB: two workgroups per CU
-constexpr int PDD = 7;                          // a fragment's DMA is issued PDD units before the unit that multiplies it
-constexpr int PRD = 2;                          // ... and read into registers PRD units before
-static_assert(PWOFF % 8192 == 0 && PR == 8, "ring slots are addressed by toggling bit 12");
+// PT = output pixels per workgroup: 128 (four 32-pixel MFMA blocks per wave) or, for the layers whose 128-pixel tiles would leave
+// CUs without a workgroup, 64 (two blocks: a fragment feeds two MFMAs instead of four, but the grid is twice as large)
+constexpr int pw_xp(int pt) { return pt == 128 ? 192 : 128; }      // tile pixels incl. the rows above and below: 6 x 32, 10 x 16, 2 images x 10 x 8 | 4 x 32, 6 x 16, 10 x 8
 
 // LDS-DMA with a scalar base: 16 bytes per lane from sbase + voff to LDS byte address lds_dst (wave-uniform) + 16 * lane
 __device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
@@ -106,7 +99,7 @@ template <int DIR> __device__ __forceinline__ bf16x8 pw_shift(const bf16x8& c, u
 }
 
 constexpr int pw_ncoef(int var) { return var == 2 ? 6 : var == 3 ? 10 : 0; }
-constexpr int PLDS_WD = 66 * 1024;              // two 24 KB activation buffers; the epilogue's 64 KB tile (+ the GroupNorm sums' 512 bytes)
+constexpr int pw_lds(int pt) { return (pt == 128 ? 64 : 32) * 1024 + 2048; }   // two activation buffers (24 / 16 KB); the epilogue's fp32 tile (+ the GroupNorm sums' 512 bytes)
 
 // VAR 0: the plain conv.  VAR 1: the epilogue also accumulates the GroupNorm sums of the NEXT layer (a.gsum).  VAR 2 / 3: the named
 // fused kernel (2: coefficients given, 3: resolved here from the producer's sums) -- x is the RAW output of the previous conv and mish(x * scale[n][c] + shift[n][c]) + tb[n][c] (a.coef; GroupNorm-apply
@@ -115,9 +108,13 @@ constexpr int PLDS_WD = 66 * 1024;              // two 24 KB activation buffers;
 // the image stay zero.  One image per tile (TI == 1).
 // ABL (profiling builds only, -DMI_PW_ABL_BUILD): 1 no fragment DMA in the main loop, 2 no activation DMA in the main loop, 4 no stores,
 // 16 no DPP shifts (every tap column multiplies the centre fragments), 32 loads issued but never waited for in the main loop
-template <bool OUT16, int VAR = 0, int ABL = 0>
+template <bool OUT16, int VAR = 0, int ABL = 0, int PT = 128>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     constexpr bool FUSE = VAR >= 2, GNS = VAR == 1;
+    constexpr int BH = PT / 32;                              // rows per band = 32-pixel blocks per wave
+    constexpr int PXBUF = pw_xp(PT) * 128;                   // one chunk of the activation tile
+    constexpr int PXPW = pw_xp(PT) / 8 / 4;                  // activation DMA instructions per wave and chunk
+    static_assert(!FUSE || PT == 128, "the fused variants are built for 128-pixel tiles");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
     const int t = threadIdx.x, l = t & 63;
@@ -133,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         const int ppx = a.gx / P, cpq = a.gy / Q;
         bx = (xcd / Q) * ppx + slot / cpq; by = (xcd % Q) * cpq + slot % cpq;
     }
-    const int m0 = bx * PBM, n0 = by * 128;
+    const int m0 = bx * PT, n0 = by * 128;
     const int TH2 = a.TH + 2;
     const int lw = 31 - __builtin_clz(a.W), lth = 31 - __builtin_clz(a.TH);      // W and TH are powers of two
     const int nchunks = a.K / PCK;
@@ -284,12 +281,16 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         wtap[tp] = ((uint64_t)hi << 32) | lo;
     }
     u32x4 WB[2][9];
-    // taps 3 part .. 3 part + 2 of step (ch, ks) (ks == 4: step 0 of chunk ch + 1; past the end: a re-fetch) -> set ks & 1
+    // part `part` of NPART of the nine taps of step (ch, ks) (ks == 4: step 0 of chunk ch + 1; past the end: a re-fetch) -> set ks & 1.
+    // Every part is requested BEFORE the chunk boundary's wait (the last row unit requests none): no register-destination load is
+    // ever in flight across the loop's back edge or its exit, where hipcc may copy or reuse the destination registers.
+    constexpr int NPART = BH >= 3 ? 3 : 2;
     auto load_w3 = [&](int ch, auto ksc, auto partc) {
         constexpr int ks0 = decltype(ksc)::value, over = ks0 >= 4 ? 1 : 0, ks = ks0 - 4 * over, part = decltype(partc)::value;
+        constexpr int t0 = (9 * part + NPART - 1) / NPART, t1 = (9 * (part + 1) + NPART - 1) / NPART;
         const uint32_t voff = wl16 + (uint32_t)min(ch + over, nchunks - 1) * 4096;
-        static_for<0, 3>([&](auto tc) {
-            constexpr int tp = 3 * part + decltype(tc)::value;
+        static_for<t0, t1>([&](auto tc) {
+            constexpr int tp = decltype(tc)::value;
             gload16s<ks * 1024>(WB[ks & 1][tp], wtap[tp], voff);
         });
     };
@@ -300,33 +301,33 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     //      band" -- ONE activation fragment X_r serves the three tap rows (output rows r, r - 1, r - 2), and its two column shifts
     //      are made once: per 16-channel step 6 LDS fragment reads and 12 DPP shifts feed 36 MFMAs (before: 12 reads, 24 shifts).
     //      Lane -> 8-channel piece 2 ks + (l >> 5) of its pixel; weights: lane -> its own 16 bytes of the fragment.
-    uint32_t xr[6];                                          // byte address of X_r, 16-channel step 0, buffer 0
+    uint32_t xr[BH + 2];                                     // byte address of X_r, 16-channel step 0, buffer 0
     int ep_p0;                                               // epilogue: tile pixel of (output row 0, this lane)
     {
-        const int q = l & 31, x = q & (a.W - 1), rest = q >> lw, nsub = a.TH >> 2;
+        const int q = l & 31, x = q & (a.W - 1), rest = q >> lw, nsub = a.TH / BH;
         const int sub = rest & (nsub - 1), ti = rest / nsub;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const int hp = (ti * TH2 + r + 4 * sub) * a.W + x;
+        for (int r = 0; r < BH + 2; ++r) {
+            const int hp = (ti * TH2 + r + BH * sub) * a.W + x;
             xr[r] = lds0 + hp * 128 + (((l >> 5) * 16) ^ (((hp >> 1) & 7) * 16));
         }
-        ep_p0 = (ti * a.TH + 4 * sub) * a.W + x;
+        ep_p0 = (ti * a.TH + BH * sub) * a.W + x;
     }
     const int xin = l & 31 & (a.W - 1);
     const uint32_t mask_l = xin == 0 ? 0u : ~0u, mask_r = xin == a.W - 1 ? 0u : ~0u;     // zero padding left / right of the row
 
-    f32x16 acc[4];
+    f32x16 acc[BH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < BH; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    bf16x8 XA, XB, XP, XQ;                                   // centre fragments: rows 0 and 5 of a step; rows 1 / 3 and 2 / 4
+    bf16x8 XA, XB, XP, XQ;                                   // centre fragments: rows 0 and BH + 1 of a step; odd / even rows 1 .. BH
 
     // ---- prologue: the first chunk's rows, the first step's fragments
     if constexpr (FUSE) load_coef(0);
 #pragma unroll
     for (int i = 0; i < PXPW; ++i) stage_x(0, i);
-    static_for<0, 3>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
+    static_for<0, NPART>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
     if constexpr (FUSE) {
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // coefficients and rows of chunk 0
         coef_landed();
@@ -348,22 +349,26 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                          // ... every wave's
     asm volatile("" ::: "memory");
-    XA = lds_b128p(xr[0]); XB = lds_b128p(xr[5]);
+    XA = lds_b128p(xr[0]); XB = lds_b128p(xr[BH + 1]);
 
-    // One chunk = four 16-channel steps of five row units (rows {0, 5}, 1, 2, 3, 4: 6, 6, 9, 9, 6 MFMAs; consecutive MFMAs go to
-    // different accumulators).  A unit reads the next unit's centre fragment(s); units 0-2 request the next step's fragments (three
-    // taps each), unit 3 of steps 0-2 two activation pieces of the next chunk; a step starts once everything the previous one
-    // requested before those pieces has landed.  Chunk boundary (before unit 4 of step 3, whose MFMAs then cover the first reads
-    // from the other buffer): every wave has read all it needs of this chunk's rows and has its pieces of the next chunk's.
+    // One chunk = four 16-channel steps of BH + 1 row units (rows {0, BH + 1}, then 1 .. BH: 6, 6, 9, 9, 6 MFMAs at BH = 4, 6, 6, 6 at
+    // BH = 2; consecutive MFMAs go to different accumulators).  A unit reads the next unit's centre fragment(s); units 0-2 request the
+    // next step's fragments (three taps each; units 0-1 at BH = 2), unit min(3, BH) of the first steps two activation pieces of the next chunk; a step
+    // starts once everything the previous one requested before those pieces has landed.  Chunk boundary (before the last unit of
+    // step 3, whose MFMAs then cover the first reads from the other buffer): every wave has read all it needs of this chunk's rows
+    // and has its pieces of the next chunk's.
     // Fused variants: the coefficients of the next chunk are requested in step 0, the pieces requested in step k are transformed
     // in place during units 0-3 of step k + 1 (two parts per unit) -- in the last chunk they rewrite the clamped re-fetch of its own
     // rows, wasted VALU work (both ways of skipping them measured worse on the 36-unit body: a branch fences the parts off from the
     // MFMAs they are meant to run under, a second copy of the body spills).
+    constexpr int XU = BH < 3 ? BH : 3;                      // the unit that requests activation pieces
     for (int ch = 0; ch < nchunks; ++ch) {
         const uint32_t xcur = (ch & 1) * PXBUF, xnxt = PXBUF - xcur;
         static_for<0, 4>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value, cur = ks & 1, kx32 = ks * 32;
-            if constexpr (ks > 0 && !(ABL & 32)) asm volatile("s_waitcnt vmcnt(%0)" :: "i"((FUSE || (ABL & 2)) ? 0 : 2) : "memory");
+            // pieces the previous step requested behind its fragments
+            constexpr int prevp = (ks > 0 && 2 * (ks - 1) < PXPW) ? 2 : 0;
+            if constexpr (ks > 0 && !(ABL & 32)) asm volatile("s_waitcnt vmcnt(%0)" :: "i"((FUSE || (ABL & 2)) ? 0 : prevp) : "memory");
             static_for<0, 9>([&](auto tc) { landed16(WB[cur][decltype(tc)::value]); });
             if constexpr (FUSE && ks == 1) coef_landed();
             auto mm = [&](auto ic, auto tapc, const bf16x8& xf) {
@@ -376,9 +381,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             // what a unit issues besides its MFMAs
             auto issue = [&](auto uc) {
                 constexpr int u = decltype(uc)::value;
-                if constexpr (u < 3 && !(ABL & 1)) load_w3(ch, std::integral_constant<int, ks + 1>{}, uc);
-                if constexpr (u == 3 && ks < 3 && !(ABL & 2)) { stage_x(ch + 1, 2 * ks); stage_x(ch + 1, 2 * ks + 1); }
-                if constexpr (u == 3 && ks == 0 && FUSE) load_coef(ch + 1);
+                if constexpr (u < NPART && !(ABL & 1)) load_w3(ch, std::integral_constant<int, ks + 1>{}, uc);
+                if constexpr (u == XU && 2 * ks < PXPW && !(ABL & 2)) { stage_x(ch + 1, 2 * ks); stage_x(ch + 1, 2 * ks + 1); }
+                if constexpr (u == XU && ks == 0 && FUSE) load_coef(ch + 1);
             };
             // fused variants: pieces 2 (ks - 1), 2 (ks - 1) + 1 of the next chunk, two parts per unit
             auto fuse_pre = [&](auto uc) {
@@ -400,71 +405,54 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                     if constexpr ((u & 1) == 1) *(lds_u32x4*)(uintptr_t)piece_addr((ch + 1) & 1, 2 * (ks - 1) + pc) = tv[pc];
                 }
             };
-            // ---- unit 0: rows 0 (output row 0, tap row 0) and 5 (output row 3, tap row 2)
+            // ---- unit 0: rows 0 (output row 0, tap row 0) and BH + 1 (output row BH - 1, tap row 2)
             {
                 constexpr std::integral_constant<int, 0> U{};
                 fuse_pre(U);
                 XP = lds_b128p((xr[1] ^ kx32) + xcur);
                 issue(U);
-                MI_MM(0, 0, 1, XA); MI_MM(3, 2, 1, XB);
+                MI_MM(0, 0, 1, XA); MI_MM(BH - 1, 2, 1, XB);
                 fuse_mid(U);
-                { const bf16x8 la = sh_l(XA), lb = sh_l(XB); MI_MM(0, 0, 0, la); MI_MM(3, 2, 0, lb); }
-                { const bf16x8 ra = sh_r(XA), rb = sh_r(XB); MI_MM(0, 0, 2, ra); MI_MM(3, 2, 2, rb); }
+                { const bf16x8 la = sh_l(XA), lb = sh_l(XB); MI_MM(0, 0, 0, la); MI_MM(BH - 1, 2, 0, lb); }
+                { const bf16x8 ra = sh_r(XA), rb = sh_r(XB); MI_MM(0, 0, 2, ra); MI_MM(BH - 1, 2, 2, rb); }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // ---- unit 1: row 1 (output rows 1, 0)
-            {
-                constexpr std::integral_constant<int, 1> U{};
-                XQ = lds_b128p((xr[2] ^ kx32) + xcur);
-                issue(U);
-                MI_MM(1, 0, 1, XP); MI_MM(0, 1, 1, XP);
-                fuse_mid(U);
-                { const bf16x8 lf = sh_l(XP); MI_MM(1, 0, 0, lf); MI_MM(0, 1, 0, lf); }
-                { const bf16x8 rf = sh_r(XP); MI_MM(1, 0, 2, rf); MI_MM(0, 1, 2, rf); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- unit 2: row 2 (output rows 2, 1, 0)
-            {
-                constexpr std::integral_constant<int, 2> U{};
-                XP = lds_b128p((xr[3] ^ kx32) + xcur);
-                issue(U);
-                MI_MM(2, 0, 1, XQ); MI_MM(1, 1, 1, XQ); MI_MM(0, 2, 1, XQ);
-                fuse_mid(U);
-                { const bf16x8 lf = sh_l(XQ); MI_MM(2, 0, 0, lf); MI_MM(1, 1, 0, lf); MI_MM(0, 2, 0, lf); }
-                { const bf16x8 rf = sh_r(XQ); MI_MM(2, 0, 2, rf); MI_MM(1, 1, 2, rf); MI_MM(0, 2, 2, rf); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- unit 3: row 3 (output rows 3, 2, 1)
-            {
-                constexpr std::integral_constant<int, 3> U{};
-                XQ = lds_b128p((xr[4] ^ kx32) + xcur);
-                issue(U);
-                MI_MM(3, 0, 1, XP); MI_MM(2, 1, 1, XP); MI_MM(1, 2, 1, XP);
-                fuse_mid(U);
-                { const bf16x8 lf = sh_l(XP); MI_MM(3, 0, 0, lf); MI_MM(2, 1, 0, lf); MI_MM(1, 2, 0, lf); }
-                { const bf16x8 rf = sh_r(XP); MI_MM(3, 0, 2, rf); MI_MM(2, 1, 2, rf); MI_MM(1, 2, 2, rf); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- unit 4: row 4 (output rows 3, 2); reads rows 0 and 5 of the next step
-            {
-                if constexpr (ks == 3) {
+            // ---- units 1 .. BH: row r feeds output rows r - ky (tap row ky); the last one reads rows 0 and BH + 1 of the next step
+            static_for<1, BH + 1>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                auto& xc = [&]() -> bf16x8& { if constexpr (r & 1) return XP; else return XQ; }();
+                if constexpr (r < BH) {
+                    auto& xn = [&]() -> bf16x8& { if constexpr (r & 1) return XQ; else return XP; }();
+                    xn = lds_b128p((xr[r + 1] ^ kx32) + xcur);
+                } else if constexpr (ks == 3) {
                     if constexpr (ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
-                    XA = lds_b128p(xr[0] + xnxt); XB = lds_b128p(xr[5] + xnxt);
+                    XA = lds_b128p(xr[0] + xnxt); XB = lds_b128p(xr[BH + 1] + xnxt);
                 } else {
-                    XA = lds_b128p((xr[0] ^ (kx32 + 32)) + xcur); XB = lds_b128p((xr[5] ^ (kx32 + 32)) + xcur);
+                    XA = lds_b128p((xr[0] ^ (kx32 + 32)) + xcur); XB = lds_b128p((xr[BH + 1] ^ (kx32 + 32)) + xcur);
                 }
-                MI_MM(3, 1, 1, XQ); MI_MM(2, 2, 1, XQ);
-                { const bf16x8 lf = sh_l(XQ); MI_MM(3, 1, 0, lf); MI_MM(2, 2, 0, lf); }
-                { const bf16x8 rf = sh_r(XQ); MI_MM(3, 1, 2, rf); MI_MM(2, 2, 2, rf); }
+                issue(rc);
+                // (ky, i = r - ky) with 0 <= i < BH, centre column first
+                auto taps = [&](auto kxc, const bf16x8& xf) {
+                    constexpr int kx = decltype(kxc)::value;
+                    static_for<0, 3>([&](auto kyc) {
+                        constexpr int ky = decltype(kyc)::value, i = r - ky;
+                        if constexpr (i >= 0 && i < BH) MI_MM(i, ky, kx, xf);
+                    });
+                };
+                taps(std::integral_constant<int, 1>{}, xc);
+                fuse_mid(rc);
+                { const bf16x8 lf = sh_l(xc); taps(std::integral_constant<int, 0>{}, lf); }
+                { const bf16x8 rf = sh_r(xc); taps(std::integral_constant<int, 2>{}, rf); }
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
 #undef MI_MM
         });
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped re-fetches must not outlive the workgroup's LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped re-fetches must not outlive the workgroup's LDS ...
+    static_for<0, 9>([&](auto tc) { landed16(WB[0][decltype(tc)::value]); landed16(WB[1][decltype(tc)::value]); });   // ... nor their registers
     if constexpr ((ABL & 4) != 0) {
         float v = 0.f;
 #pragma unroll
@@ -486,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     if (live) {
         typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < BH; ++i) {
             const int p = ep_p0 + i * a.W;               // output row i of this lane's band
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
@@ -504,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
         if (a.bias) { b0 = *reinterpret_cast<const f32x4*>(a.bias + col); b1 = *reinterpret_cast<const f32x4*>(a.bias + col + 4); }
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < PT / 16; ++it) {
             const int p = it * 16 + (t >> 4);
             const size_t m = (size_t)m0 + p;
             f32x4 v0 = *(lds_f32x4*)(uintptr_t)(lds0 + p * 512 + (((2 * j) ^ (p & 31)) << 4)) + b0;
@@ -552,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         for (int k = 0; k < 4; ++k) {
             r[k] += __shfl_xor(r[k], 1, 64); r[k] += __shfl_xor(r[k], 16, 64); r[k] += __shfl_xor(r[k], 32, 64);
         }
-        float* red = reinterpret_cast<float*>(lds_raw + 65536);          // [4 waves][8 slabs][4]
+        float* red = reinterpret_cast<float*>(lds_raw + PT * 512);        // behind the tile: [4 waves][8 slabs][4]
         if ((l & 0x31) == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) red[(wv * 8 + (l >> 1)) * 4 + k] = r[k];
@@ -570,23 +558,32 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     }
 }
 
-bool pw_geom(const MiConvDesc* d, int* TH, int* TI) {
+bool pw_geom(const MiConvDesc* d, int pt, int* TH, int* TI) {
     const int W = d->OW, H = d->OH;
     if (W != 8 && W != 16 && W != 32) return false;          // 32-pixel MFMA blocks must be whole image rows
-    const int rows = PBM / W;
+    const int rows = pt / W, bh = pt / 32;
     if (rows <= H) { if (H % rows) return false; *TH = rows; *TI = 1; }
     else { if (rows % H) return false; *TH = H; *TI = rows / H; if ((long)d->N % *TI) return false; }
-    if ((*TH & (*TH - 1)) || *TH % 4 || *TI > 2) return false; // the kernel's index arithmetic: shifts, 4-row bands, at most two images per tile
-    return *TI * (*TH + 2) * W <= PXP;
+    if ((*TH & (*TH - 1)) || *TH % bh || *TI > 2) return false; // the kernel's index arithmetic: shifts, bands of bh rows, at most two images per tile
+    return *TI * (*TH + 2) * W <= pw_xp(pt);
 }
 
-bool pw_ok(const MiConvDesc* d, int* TH, int* TI) {
+bool pw_ok(const MiConvDesc* d, int pt, int* TH, int* TI) {
     if (d->KH != 3 || d->KW != 3 || d->pad != 1 || d->stride != 1 || d->mode != 1) return false;
     if (d->IH != d->OH || d->IW != d->OW) return false;
     if (d->K % 64 || d->K1 % 64 || d->Nc % 32 || d->ldx % 8 || (d->K1 != d->K && d->ldx2 % 8)) return false;
-    if (((long)d->N * d->OH * d->OW) % PBM) return false;
+    if (((long)d->N * d->OH * d->OW) % pt) return false;
     if ((long)d->Nc * d->K * 2 * 9 >= (1L << 31)) return false;      // 32-bit fragment offsets
-    return pw_geom(d, TH, TI);
+    return pw_geom(d, pt, TH, TI);
+}
+// 64-pixel tiles where 128-pixel ones would leave CUs without a workgroup (and the geometry allows them)
+int g_pw_force_tile = 0;                 // tests: 0 = the rule below, 64 / 128 = that tile (or unsupported)
+int pw_pick_tile(const MiConvDesc* d, int var, int* TH, int* TI) {
+    if (g_pw_force_tile == 64) return (var < 2 && pw_ok(d, 64, TH, TI)) ? 64 : 0;
+    if (g_pw_force_tile == 128) return pw_ok(d, 128, TH, TI) ? 128 : 0;
+    const long t128 = ((long)d->N * d->OH * d->OW / 128) * ((d->Nc + 127) / 128);
+    if (var < 2 && t128 < 200 && pw_ok(d, 64, TH, TI)) return 64;
+    return pw_ok(d, 128, TH, TI) ? 128 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -761,7 +758,8 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
                      const PwGn* gn = nullptr) {
     PwArgs a{};
     if (!d || !x || !w_frag_bf16 || !y) return mi_set_error(-1, "%s: null argument", who);
-    if (!pw_ok(d, &a.TH, &a.TI)) return mi_set_error(-1, "%s: descriptor not supported by the private-weight-stream conv kernel", who);
+    const int pt = pw_pick_tile(d, var, &a.TH, &a.TI);
+    if (!pt) return mi_set_error(-1, "%s: descriptor not supported by the private-weight-stream conv kernel", who);
     if (d->K1 != d->K && !x2) return mi_set_error(-1, "%s: two-source split without x2", who);
     if ((((uintptr_t)x | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)w_frag_bf16) & 15) != 0) return mi_set_error(-1, "%s: operands must be 16-byte aligned", who);
     if (d->ldy % 8 || (residual && d->ldr % 4)) return mi_set_error(-1, "%s: output pixel stride must be a multiple of 8, the residual's of 4", who);
@@ -785,19 +783,31 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     a.tiles_per_img = a.TI > 1 ? 1 : a.H / a.TH;
     a.XP = a.TI * (a.TH + 2) * a.W;
     a.xmap = a.TI == 1 && a.tiles_per_img > 1 && a.N % 8 == 0;
-    dim3 grid((unsigned)((long)d->N * d->OH * d->OW / PBM), (unsigned)((d->Nc + 127) / 128));
+    dim3 grid((unsigned)((long)d->N * d->OH * d->OW / pt), (unsigned)((d->Nc + 127) / 128));
     a.qmap = 0; a.gx = (int)grid.x; a.gy = (int)grid.y;
     if (!a.xmap && a.gy > 1 && a.gy % 2 == 0 && a.gx % 4 == 0) { a.qmap = 2; grid = dim3(grid.x * grid.y, 1, 1); }
     hipStream_t st = (hipStream_t)stream;
-    size_t lds = PLDS_WD;
-#define MI_PW_GO(O16, V, A) do { \
-        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, A>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
+    size_t lds = pw_lds(pt);
+#define MI_PW_GO_T(O16, V, A, T) do { \
+        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, A, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
         (void)once_; \
-        hipLaunchKernelGGL((conv_pw_kernel<O16, V, A>), grid, dim3(256), lds, st, a); } while (0)
+        hipLaunchKernelGGL((conv_pw_kernel<O16, V, A, T>), grid, dim3(256), lds, st, a); } while (0)
+#define MI_PW_GO(O16, V, A) MI_PW_GO_T(O16, V, A, 128)
 #ifdef MI_PW_ABL_BUILD
     static const int abl = [] { const char* e = getenv("MI_PW_ABL"); return e ? atoi(e) : 0; }();
     if (abl & 8) lds = 100 * 1024;            // one workgroup per CU
-    if (var == 0 && (abl & 0x37)) {
+    if (var == 0 && pt == 64 && (abl & 0x37)) {       // debugging the 64-pixel tiles
+        switch (abl & 0x37) {
+            case 1: MI_PW_GO_T(false, 0, 1, 64); break;
+            case 2: MI_PW_GO_T(false, 0, 2, 64); break;
+            case 3: MI_PW_GO_T(false, 0, 3, 64); break;
+            case 4: MI_PW_GO_T(false, 0, 4, 64); break;
+            default: MI_PW_GO_T(false, 0, 7, 64); break;
+        }
+        hipError_t e_ = hipGetLastError();
+        return e_ == hipSuccess ? 0 : mi_set_error((int)e_, "%s: %s", who, hipGetErrorString(e_));
+    }
+    if (var == 0 && pt == 128 && (abl & 0x37)) {
 #define MI_PW_ABL_CASE(V) case V: if (out_bf16) MI_PW_GO(true, 0, V); else MI_PW_GO(false, 0, V); break;
         switch (abl & 0x37) {
             MI_PW_ABL_CASE(1) MI_PW_ABL_CASE(2) MI_PW_ABL_CASE(3) MI_PW_ABL_CASE(4) MI_PW_ABL_CASE(7)
@@ -809,13 +819,17 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
         return e_ == hipSuccess ? 0 : mi_set_error((int)e_, "%s: %s", who, hipGetErrorString(e_));
     }
 #endif
-    switch (var) {
+    if (pt == 64) {
+        if (var == 1) { if (out_bf16) MI_PW_GO_T(true, 1, 0, 64); else MI_PW_GO_T(false, 1, 0, 64); }
+        else { if (out_bf16) MI_PW_GO_T(true, 0, 0, 64); else MI_PW_GO_T(false, 0, 0, 64); }
+    } else switch (var) {
         case 1: if (out_bf16) MI_PW_GO(true, 1, 0); else MI_PW_GO(false, 1, 0); break;
         case 2: if (out_bf16) MI_PW_GO(true, 2, 0); else MI_PW_GO(false, 2, 0); break;
         case 3: if (out_bf16) MI_PW_GO(true, 3, 0); else MI_PW_GO(false, 3, 0); break;
         default: if (out_bf16) MI_PW_GO(true, 0, 0); else MI_PW_GO(false, 0, 0); break;
     }
 #undef MI_PW_GO
+#undef MI_PW_GO_T
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : mi_set_error((int)e_, "%s: %s", who, hipGetErrorString(e_));
 }
@@ -824,12 +838,23 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
 
 extern "C" int mi_conv3x3_pw_supported(const MiConvDesc* d) {
     int th, ti;
-    return (d && pw_ok(d, &th, &ti)) ? 1 : 0;
+    return (d && pw_pick_tile(d, 0, &th, &ti)) ? 1 : 0;
+}
+// test switch: force the pixel tile (64 / 128), 0 = automatic
+extern "C" int mi_debug_conv_pw_tile(int pt) {
+    if (pt != 0 && pt != 64 && pt != 128) return mi_set_error(-1, "mi_debug_conv_pw_tile: 0, 64 or 128");
+    g_pw_force_tile = pt;
+    return 0;
+}
+// pixels per workgroup the launch would use (128 or 64; 0: not supported) -- profiling attribution and the host layer's pick
+extern "C" int mi_conv3x3_pw_tile(const MiConvDesc* d) {
+    int th, ti;
+    return d ? pw_pick_tile(d, 0, &th, &ti) : 0;
 }
 // the fused GroupNorm-apply + Mish + conv variant: tiles inside one image, one source
 extern "C" int mi_conv3x3_pw_gn_mish_supported(const MiConvDesc* d) {
     int th, ti;
-    return (d && pw_ok(d, &th, &ti) && ti == 1 && d->K1 == d->K) ? 1 : 0;
+    return (d && pw_ok(d, 128, &th, &ti) && ti == 1 && d->K1 == d->K) ? 1 : 0;
 }
 
 // x / x2: bf16 tensors (pixel strides in elements, % 8 == 0); w: bf16 weights in MFMA-fragment order [tap][Nc / 32][K / 16][64][8]

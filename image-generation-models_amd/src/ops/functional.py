@@ -58,14 +58,27 @@ def _pick3x3(W, K, Nc):
 USE_CONV_PW = CONV_AUTO and debug_knob("MI_CONV_PW", "1") == "1"     # MI_CONV_AUTO=0: the halo kernel everywhere
 
 
-def _pick_pw(N, H, W, K, Nc):
-    """128-pixel x 128-channel tiles, two workgroups per CU: taken when the layer has at least about one tile per CU (fewer: round 2's
-    kernels with their 64-channel / 64-pixel tiles fill the chip better -- 8x8 level at B = 128, 256 -> 256: 20.1 vs 19.4 us,
-    1024 -> 256: 61.9 vs 58.5 us, tools/bench_pw.py)."""
-    return (N * H * W // 128) * ((Nc + 127) // 128) >= PW_MIN_TILES
+def _pw_sym(d, out16, var=0):
+    """conv_pw_kernel's symbol as rocprofv3 prints it (default template arguments dropped)."""
+    o = "true" if out16 else "false"
+    if _query("mi_conv3x3_pw_tile", d) == 64:
+        return f"conv_pw_kernel<{o}, {var}, 0, 64>"
+    return f"conv_pw_kernel<{o}, {var}>" if var else f"conv_pw_kernel<{o}>"
 
 
-PW_MIN_TILES = int(debug_knob("MI_CONV_PW_MIN_TILES", "200"))
+def _pick_pw(N, H, W, K, Nc, d=None):
+    """The private-weight-stream kernel takes a layer that offers it at least about one tile per CU: 128-pixel x 128-channel tiles,
+    or (d given: the plain conv and the variant with GroupNorm sums; the library decides, mi_conv3x3_pw_tile) 64-pixel tiles when
+    the 128-pixel ones would be too few.  Smaller layers stay with round 2's kernels."""
+    pt = 128
+    if d is not None:
+        pt = _query("mi_conv3x3_pw_tile", d)
+        if not pt:
+            return False
+    return (N * H * W // pt) * ((Nc + 127) // 128) >= PW_MIN_TILES
+
+
+PW_MIN_TILES = int(debug_knob("MI_CONV_PW_MIN_TILES", "64"))
 
 
 USE_WGRAD_TR = debug_knob("MI_W3_TR", "1") != "0"      # A/B switch for the LDS-DMA weight-gradient kernel (csrc/wgrad_tr.hip)
@@ -260,7 +273,7 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
             _probe_close(e0, f"conv1x1_pw_kernel<{'true' if _b16(out) else 'false'}, {'true' if want16 else 'false'}, {px}>", 2.0 * N * H * W * Nc * K,
                          f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
         return (out, y16) if want16 else out
-    if (gn_sums is not None and ksize == 3 and _b16(x) and USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc)
+    if (gn_sums is not None and ksize == 3 and _b16(x) and USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc, d)
             and _query("mi_conv3x3_pw_supported", d)):
         # the next layer's GroupNorm sums from the private-weight-stream kernel's epilogue
         assert gn_sums.dtype == torch.float32 and gn_sums.numel() == N * (Nc // 16) * 2
@@ -269,19 +282,19 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
               "mi_conv3x3_pw_gnsums")
         if e0 is not None:
             nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 2)
-            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(out) else 'false'}, 1>", 2.0 * N * H * W * Nc * K * 9,
+            _probe_close(e0, _pw_sym(d, _b16(out), 1), 2.0 * N * H * W * Nc * K * 9,
                          f"N{N} {H}x{W} K{K}->{Nc} + GroupNorm sums", nb)
         return out
     if gn_sums is None and not want16 and ksize == 3 and _b16(x):
         pick = "shift" if USE_CONV_SHIFT else _pick3x3(W, K, Nc)
-        if USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc) and _query("mi_conv3x3_pw_supported", d):
+        if USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc, d):
             pick = "pw"
     if pick == "pw":
         e0 = _probe_open()
         check(lib.mi_conv3x3_pw(C.byref(d), _p(x), _p(x2), _p(wq), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv3x3_pw")
         if e0 is not None:
             nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 2)
-            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(out) else 'false'}>", 2.0 * N * H * W * Nc * K * 9,
+            _probe_close(e0, _pw_sym(d, _b16(out)), 2.0 * N * H * W * Nc * K * 9,
                          f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
         return out
     if pick == "shift" and _query("mi_conv3x3_shift_supported", d):

@@ -75,6 +75,8 @@ SIGNATURES = {
     "mi_gn_mish_bwd_io": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _P],
     "mi_pack_weights_bf16": [_I, _P, _I, _P, _P, _P, _P, _P, _P],
     "mi_conv3x3_pw_supported": [C.POINTER(MiConvDesc)],
+    "mi_conv3x3_pw_tile": [C.POINTER(MiConvDesc)],
+    "mi_debug_conv_pw_tile": [_I],
     "mi_conv3x3_pw": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
     "mi_conv3x3_pw_gn_mish_supported": [C.POINTER(MiConvDesc)],
     "mi_conv1x1_pw_supported": [C.POINTER(MiConvDesc)],

@@ -561,6 +561,15 @@ def pw_always(K):
     K.PW_MIN_TILES, K.USE_CONV_PW, K.PROBE = was, was_on, None
 
 
+@pytest.fixture(params=[128, 64])
+def pw_tile(K, request):
+    """Force conv_pw's pixel tile (mi_debug_conv_pw_tile): 128 = four MFMA blocks per wave, 64 = two (what small grids get)."""
+    lib = K.load_library()
+    lib.mi_debug_conv_pw_tile(request.param); K._QUERY_CACHE.clear()
+    yield request.param
+    lib.mi_debug_conv_pw_tile(0); K._QUERY_CACHE.clear()
+
+
 def _conv_launches(probe):
     return [q[0] for q in probe if q[0].startswith("conv")]
 
@@ -573,7 +582,7 @@ def _frag_weights(K, w):
 
 @pytest.mark.parametrize("out16", [True, False])
 @pytest.mark.parametrize("cfg", [(16, 32, 32, 128, 128), (8, 16, 16, 256, 256), (4, 8, 8, 512, 512), (16, 16, 16, 128, 384)])
-def test_conv_pw_epilogue_groupnorm_sums(K, cfg, out16, pw_always):
+def test_conv_pw_epilogue_groupnorm_sums(K, cfg, out16, pw_always, pw_tile):
     """mi_conv3x3_pw_gnsums + mi_gn_coef_from_sums: the next GroupNorm's statistics and coefficients out of the conv's row-contiguous
     epilogue (one image per tile at 32 / 16 pixels width, TWO at 8x8) equal what mi_gn_stats_coef computes with a pass over the
     stored tensor, and the conv's output is the plain entry point's (bitwise)."""
@@ -591,7 +600,9 @@ def test_conv_pw_epilogue_groupnorm_sums(K, cfg, out16, pw_always):
     y1 = K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, bias=bias, out_dtype=dt, gn_sums=sums, wq=wfq)
     assert torch.equal(y0, y1)
     ls = _conv_launches(pw_always)
-    assert len(ls) == 2 and ls[0].startswith("conv_pw_kernel") and ls[1].startswith("conv_pw_kernel") and ls[1].endswith(", 1>"), ls
+    t64 = ", 0, 64>" if pw_tile == 64 else ">"
+    o16 = "true" if out16 else "false"
+    assert ls == [f"conv_pw_kernel<{o16}, 0, 0, 64>" if pw_tile == 64 else f"conv_pw_kernel<{o16}>", f"conv_pw_kernel<{o16}, 1{t64}"], ls
     # the raw sums: per sample and 16-channel slab, of the STORED values
     yd = y0.double().view(N, H * W, Co // 16, 16)
     want = torch.stack([yd.sum((1, 3)), (yd * yd).sum((1, 3))], dim=-1)             # [N][Co/16][2]
@@ -753,7 +764,7 @@ def test_pack_weights_fragment_order(K):
     dict(N=4, H=8, Ci=1024, Co=64, split=512),   # long K, half-empty channel tile
     dict(N=6, H=8, Ci=192, Co=320),              # odd chunk count, ragged channel tile
 ])
-def test_conv3x3_pw_fwd_and_dgrad(K, cfg, out16, pw_always):
+def test_conv3x3_pw_fwd_and_dgrad(K, cfg, out16, pw_always, pw_tile):
     """Block's 3x3 conv (ddpm.py:116) and its data gradient for bf16-stored activations through the private-weight-stream kernel
     (mi_conv3x3_pw: fragment-order weights by LDS-DMA per wave, one barrier per 64-channel chunk): bias, residual, fp32 and bf16
     output, accumulate; against fp64 on the same bf16-rounded operands and against the halo kernel."""
@@ -791,7 +802,7 @@ def test_conv3x3_pw_fwd_and_dgrad(K, cfg, out16, pw_always):
     assert yg is not None and yg.dtype == odt
     dxg = K.conv3x3_bf16w(nh(dyp.bfloat16()), wd, K=Cop, Nc=Cip, flip=True, out_dtype=odt, wq=wdq)
     ls = _conv_launches(pw_always)
-    assert len(ls) == 2 and all(q.startswith("conv_pw_kernel") for q in ls), ls
+    assert len(ls) == 2 and all(q.startswith("conv_pw_kernel") and q.endswith(", 64>") == (pw_tile == 64) for q in ls), ls
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(yg.float())[:, :Co], yq) < tol
     assert not yg[..., Co:].any()
