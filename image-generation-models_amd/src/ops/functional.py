@@ -59,11 +59,9 @@ USE_CONV_PW = CONV_AUTO and debug_knob("MI_CONV_PW", "1") == "1"     # MI_CONV_A
 
 
 def _pw_sym(d, out16, var=0):
-    """conv_pw_kernel's symbol as rocprofv3 prints it (default template arguments dropped)."""
-    o = "true" if out16 else "false"
-    if _query("mi_conv3x3_pw_tile", d) == 64:
-        return f"conv_pw_kernel<{o}, {var}, 0, 64>"
-    return f"conv_pw_kernel<{o}, {var}>" if var else f"conv_pw_kernel<{o}>"
+    """conv_pw_kernel's symbol as rocprofv3 prints it."""
+    pt = _query("mi_conv3x3_pw_tile", d) if var < 2 else 128
+    return f"conv_pw_kernel<{'true' if out16 else 'false'}, {var}, 0, {pt or 128}>"
 
 
 def _pick_pw(N, H, W, K, Nc, d=None):
@@ -407,7 +405,7 @@ def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None, gn=None, 
         else:
             check(lib.mi_conv3x3_pw_gn_mish(C.byref(d), _p(x), _p(coef), _p(wq), _p(bias), _p(y), _b16(y), _stream()), "mi_conv3x3_pw_gn_mish")
         if e0 is not None:
-            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(y) else 'false'}, {3 if coef is None else 2}>", 2.0 * N * H * W * Nc * K * 9,
+            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(y) else 'false'}, {3 if coef is None else 2}, 0, 128>", 2.0 * N * H * W * Nc * K * 9,
                          f"N{N} {H}x{W} K{K}->{Nc} fused GN+Mish", N * H * W * (K * 2 + Nc * _esz(y)) + 9 * K * Nc * 2)
         return y
     if not lib.mi_conv3x3_gn_mish_supported(C.byref(d)):

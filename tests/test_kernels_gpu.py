@@ -600,9 +600,8 @@ def test_conv_pw_epilogue_groupnorm_sums(K, cfg, out16, pw_always, pw_tile):
     y1 = K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, bias=bias, out_dtype=dt, gn_sums=sums, wq=wfq)
     assert torch.equal(y0, y1)
     ls = _conv_launches(pw_always)
-    t64 = ", 0, 64>" if pw_tile == 64 else ">"
     o16 = "true" if out16 else "false"
-    assert ls == [f"conv_pw_kernel<{o16}, 0, 0, 64>" if pw_tile == 64 else f"conv_pw_kernel<{o16}>", f"conv_pw_kernel<{o16}, 1{t64}"], ls
+    assert ls == [f"conv_pw_kernel<{o16}, 0, 0, {pw_tile}>", f"conv_pw_kernel<{o16}, 1, 0, {pw_tile}>"], ls
     # the raw sums: per sample and 16-channel slab, of the STORED values
     yd = y0.double().view(N, H * W, Co // 16, 16)
     want = torch.stack([yd.sum((1, 3)), (yd * yd).sum((1, 3))], dim=-1)             # [N][Co/16][2]
@@ -648,7 +647,7 @@ def test_fused_gn_mish_conv3x3_pw(K, cfg, out16, pw_always):
     y = K.conv3x3_gn_mish(xg, coef, wf, K=Cc, Nc=Cop, bias=bp.to(DEV), out_dtype=dt, wq=wfq)
     assert y is not None and y.dtype == dt
     ls = _conv_launches(pw_always)
-    assert ls[-1].startswith("conv_pw_kernel") and ls[-1].endswith(", 2>"), ls
+    assert ls[-1].startswith("conv_pw_kernel") and ls[-1].endswith(", 2, 0, 128>"), ls
     h1, _ = K.gn_mish_fwd(xg, gamma.to(DEV), beta.to(DEV), temb=temb.to(DEV), out_dtype=torch.bfloat16)
     y2 = K.conv3x3_bf16w(h1, wf, K=Cc, Nc=Cop, flip=False, bias=bp.to(DEV), out_dtype=dt, wq=wfq)
     torch.cuda.synchronize()
@@ -667,7 +666,7 @@ def test_fused_gn_mish_conv3x3_pw(K, cfg, out16, pw_always):
         yb = K.conv3x3_gn_mish(xg, None, wf, K=Cc, Nc=Cop, bias=bp.to(DEV), out_dtype=dt, wq=wfq,
                                gn=(sums, gamma.to(DEV), beta.to(DEV), temb.to(DEV), 8, 1e-5))
         ls = _conv_launches(pw_always)
-        assert ls[-1].endswith(", 3>") and ls[-2].endswith(", 2>"), ls
+        assert ls[-1].endswith(", 3, 0, 128>") and ls[-2].endswith(", 2, 0, 128>"), ls
         assert torch.equal(ya, yb)
         assert rel_err(yb.float().cpu().permute(0, 3, 1, 2).double()[:, :Co], ref) < 6e-3
 
@@ -802,7 +801,7 @@ def test_conv3x3_pw_fwd_and_dgrad(K, cfg, out16, pw_always, pw_tile):
     assert yg is not None and yg.dtype == odt
     dxg = K.conv3x3_bf16w(nh(dyp.bfloat16()), wd, K=Cop, Nc=Cip, flip=True, out_dtype=odt, wq=wdq)
     ls = _conv_launches(pw_always)
-    assert len(ls) == 2 and all(q.startswith("conv_pw_kernel") and q.endswith(", 64>") == (pw_tile == 64) for q in ls), ls
+    assert len(ls) == 2 and all(q.startswith("conv_pw_kernel") and q.endswith(f", {pw_tile}>") for q in ls), ls
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(yg.float())[:, :Co], yq) < tol
     assert not yg[..., Co:].any()

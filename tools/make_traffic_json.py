@@ -14,10 +14,10 @@ CASES = {
     "halo_128_32_128_128_fp32": ("conv3x3_halo_kernel<256, 64, 3, false, 0, 8>", "[128,32,32,128]->128 fp32 storage", conv_bytes(128, 32, 128, 128, 4, 4)),
     "shift_128_8_512_512_bf16": ("conv_shift_kernel<4, 1, true>", "[128,8,8,512]->512 bf16 storage", conv_bytes(128, 8, 512, 512, 2, 2)),
     "shift_128_32_128_128_bf16": ("conv_shift_kernel<4, 2, true>", "[128,32,32,128]->128 bf16 storage", conv_bytes(128, 32, 128, 128, 2, 2)),
-    "pw_128_8_512_512_bf16": ("conv_pw_kernel<true>", "[128,8,8,512]->512 bf16 storage", conv_bytes(128, 8, 512, 512, 2, 2)),
-    "pw_128_32_128_128_bf16": ("conv_pw_kernel<true> [level 0]", "[128,32,32,128]->128 bf16 storage", conv_bytes(128, 32, 128, 128, 2, 2)),
-    "pw_128_16_256_256_bf16": ("conv_pw_kernel<true> [16x16]", "[128,16,16,256]->256 bf16 storage", conv_bytes(128, 16, 256, 256, 2, 2)),
-    "fusedpw_128_32_128_128_bf16": ("conv_pw_kernel<true, 2>", "fused GN+Mish+conv [128,32,32,128]->128 bf16 storage (private-weight-stream kernel)",
+    "pw_128_8_512_512_bf16": ("conv_pw_kernel<true, 0, 0, 128>", "[128,8,8,512]->512 bf16 storage", conv_bytes(128, 8, 512, 512, 2, 2)),
+    "pw_128_32_128_128_bf16": ("conv_pw_kernel<true, 0, 0, 128> [level 0]", "[128,32,32,128]->128 bf16 storage", conv_bytes(128, 32, 128, 128, 2, 2)),
+    "pw_128_16_256_256_bf16": ("conv_pw_kernel<true, 0, 0, 128> [16x16]", "[128,16,16,256]->256 bf16 storage", conv_bytes(128, 16, 256, 256, 2, 2)),
+    "fusedpw_128_32_128_128_bf16": ("conv_pw_kernel<true, 2, 0, 128>", "fused GN+Mish+conv [128,32,32,128]->128 bf16 storage (private-weight-stream kernel)",
                                     conv_bytes(128, 32, 128, 128, 2, 2) + 3 * 128 * 128 * 4),
     "wgrad_128_32_128_128_bf16": ("wgrad_tr_kernel[single]", "[128,32,32,128]x[128,32,32,128] bf16 operands, one layer per launch",
                                   2 * 128 * 32 * 32 * 128 * 2 + 9 * 128 * 128 * 4),
