@@ -108,9 +108,13 @@ constexpr int pw_lds(int pt) { return (pt == 128 ? 64 : 32) * 1024 + 2048; }   /
 // the image stay zero.  One image per tile (TI == 1).
 // ABL (profiling builds only, -DMI_PW_ABL_BUILD): 1 no fragment DMA in the main loop, 2 no activation DMA in the main loop, 4 no stores,
 // 16 no DPP shifts (every tap column multiplies the centre fragments), 32 loads issued but never waited for in the main loop
-template <bool OUT16, int VAR = 0, int ABL = 0, int PT = 128>
+// IN32: x / x2 are fp32 tensors (the residual stream: the sampler's block1 convs, fp32 block storage).  Their pieces are loaded into
+// registers (two global_load_dwordx4 per lane and piece, counted like the fragments), rounded to bf16 once and written to the lane's
+// slot of the tile -- the lane loads the channel chunk that belongs in ITS slot, as the DMA's source addresses do for bf16 input.
+template <bool OUT16, int VAR = 0, int ABL = 0, int PT = 128, bool IN32 = false>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     constexpr bool FUSE = VAR >= 2, GNS = VAR == 1;
+    static_assert(!IN32 || (!FUSE && ABL == 0), "fp32 input: the plain conv and the variant with GroupNorm sums");
     constexpr int BH = PT / 32;                              // rows per band = 32-pixel blocks per wave
     constexpr int PXBUF = pw_xp(PT) * 128;                   // one chunk of the activation tile
     constexpr int PXPW = pw_xp(PT) / 8 / 4;                  // activation DMA instructions per wave and chunk
@@ -175,6 +179,29 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         const uint16_t* p = xp >= 0 ? src + off : zero + (l & 7) * 8;
         glds16(p, lds0 + (ch & 1) * PXBUF + (wv + 4 * i) * 1024);
     };
+    // fp32 input: piece i of chunk ch -> the two registers of `dst` (8 channels of this lane's pixel), asynchronous
+    auto load_x32 = [&](int ch, int i, u32x4* dst) {
+        const int cc0 = min(ch, nchunks - 1) * PCK;
+        const bool second = cc0 >= a.K1;
+        const float* src = reinterpret_cast<const float*>(second ? a.x2 : a.x);
+        const int ld = second ? a.ldx2 : a.ldx, cc = second ? cc0 - a.K1 : cc0;
+        int xp = xpix[i];
+        asm volatile("" : "+v"(xp));
+        size_t off = (size_t)max(xp, 0) * ld + cc + xcol;
+        asm volatile("" : "+v"(off));
+        const float* pf = xp >= 0 ? src + off : reinterpret_cast<const float*>(g_zero_page3) + (l & 7) * 8;
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                     : "=&v"(dst[0]), "=&v"(dst[1]) : "v"(pf) : "memory");
+    };
+    // ... rounded and written to the tile (buffer buf) once the wait that covers its loads has passed
+    auto store_x32 = [&](int buf, int i, u32x4* r) {
+        typedef __attribute__((address_space(3))) u32x4 lds_u32x4_;
+        landed16(r[0]); landed16(r[1]);
+        const u32x4 o = {pack_bf16(__uint_as_float(r[0].x), __uint_as_float(r[0].y)), pack_bf16(__uint_as_float(r[0].z), __uint_as_float(r[0].w)),
+                         pack_bf16(__uint_as_float(r[1].x), __uint_as_float(r[1].y)), pack_bf16(__uint_as_float(r[1].z), __uint_as_float(r[1].w))};
+        *(lds_u32x4_*)(uintptr_t)(lds0 + buf * PXBUF + (wv + 4 * i) * 1024 + l * 16) = o;
+    };
+    u32x4 XR32[IN32 ? 2 : 1][2];                             // main loop: the two pieces a step requests
 
     // ---- fused variants: the 3 x 8 coefficients of this lane's channel chunk of chunk ch.  Plain loads would make hipcc drain the DMA
     //      queue (vmcnt(0)) at their first use, so they are issued from one asm statement and counted by hand (pw_newer); their
@@ -325,9 +352,19 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
 
     // ---- prologue: the first chunk's rows, the first step's fragments
     if constexpr (FUSE) load_coef(0);
+    if constexpr (IN32) {
+        u32x4 pr[PXPW][2];
 #pragma unroll
-    for (int i = 0; i < PXPW; ++i) stage_x(0, i);
-    static_for<0, NPART>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
+        for (int i = 0; i < PXPW; ++i) load_x32(0, i, pr[i]);
+        static_for<0, NPART>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // the rows of chunk 0
+#pragma unroll
+        for (int i = 0; i < PXPW; ++i) store_x32(0, i, pr[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < PXPW; ++i) stage_x(0, i);
+        static_for<0, NPART>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
+    }
     if constexpr (FUSE) {
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // coefficients and rows of chunk 0
         coef_landed();
@@ -367,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         static_for<0, 4>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value, cur = ks & 1, kx32 = ks * 32;
             // pieces the previous step requested behind its fragments
-            constexpr int prevp = (ks > 0 && 2 * (ks - 1) < PXPW) ? 2 : 0;
+            constexpr int prevp = (ks > 0 && 2 * (ks - 1) < PXPW) ? (IN32 ? 4 : 2) : 0;
             if constexpr (ks > 0 && !(ABL & 32)) asm volatile("s_waitcnt vmcnt(%0)" :: "i"((FUSE || (ABL & 2)) ? 0 : prevp) : "memory");
             static_for<0, 9>([&](auto tc) { landed16(WB[cur][decltype(tc)::value]); });
             if constexpr (FUSE && ks == 1) coef_landed();
@@ -382,7 +419,15 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             auto issue = [&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 if constexpr (u < NPART && !(ABL & 1)) load_w3(ch, std::integral_constant<int, ks + 1>{}, uc);
-                if constexpr (u == XU && 2 * ks < PXPW && !(ABL & 2)) { stage_x(ch + 1, 2 * ks); stage_x(ch + 1, 2 * ks + 1); }
+                if constexpr (u == XU && IN32) {
+                    // the two pieces the previous step requested: older than this step's nine fragment requests
+                    if constexpr (prevp != 0) {
+                        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                        store_x32((ch + 1) & 1, 2 * (ks - 1), XR32[0]); store_x32((ch + 1) & 1, 2 * (ks - 1) + 1, XR32[1]);
+                    }
+                    if constexpr (2 * ks < PXPW) { load_x32(ch + 1, 2 * ks, XR32[0]); load_x32(ch + 1, 2 * ks + 1, XR32[1]); }
+                }
+                if constexpr (u == XU && !IN32 && 2 * ks < PXPW && !(ABL & 2)) { stage_x(ch + 1, 2 * ks); stage_x(ch + 1, 2 * ks + 1); }
                 if constexpr (u == XU && ks == 0 && FUSE) load_coef(ch + 1);
             };
             // fused variants: pieces 2 (ks - 1), 2 (ks - 1) + 1 of the next chunk, two parts per unit
@@ -568,22 +613,24 @@ bool pw_geom(const MiConvDesc* d, int pt, int* TH, int* TI) {
     return *TI * (*TH + 2) * W <= pw_xp(pt);
 }
 
-bool pw_ok(const MiConvDesc* d, int pt, int* TH, int* TI) {
+bool pw_ok(const MiConvDesc* d, int pt, int* TH, int* TI, bool in32 = false) {
     if (d->KH != 3 || d->KW != 3 || d->pad != 1 || d->stride != 1 || d->mode != 1) return false;
     if (d->IH != d->OH || d->IW != d->OW) return false;
-    if (d->K % 64 || d->K1 % 64 || d->Nc % 32 || d->ldx % 8 || (d->K1 != d->K && d->ldx2 % 8)) return false;
+    const int lda = in32 ? 4 : 8;                            // 16-byte pieces of a pixel row
+    if (d->K % 64 || d->K1 % 64 || d->Nc % 32 || d->ldx % lda || (d->K1 != d->K && d->ldx2 % lda)) return false;
     if (((long)d->N * d->OH * d->OW) % pt) return false;
     if ((long)d->Nc * d->K * 2 * 9 >= (1L << 31)) return false;      // 32-bit fragment offsets
     return pw_geom(d, pt, TH, TI);
 }
 // 64-pixel tiles where 128-pixel ones would leave CUs without a workgroup (and the geometry allows them)
 int g_pw_force_tile = 0;                 // tests: 0 = the rule below, 64 / 128 = that tile (or unsupported)
-int pw_pick_tile(const MiConvDesc* d, int var, int* TH, int* TI) {
-    if (g_pw_force_tile == 64) return (var < 2 && pw_ok(d, 64, TH, TI)) ? 64 : 0;
-    if (g_pw_force_tile == 128) return pw_ok(d, 128, TH, TI) ? 128 : 0;
+int pw_pick_tile(const MiConvDesc* d, int var, int* TH, int* TI, bool in32 = false) {
+    if (in32 && var >= 2) return 0;
+    if (g_pw_force_tile == 64) return (var < 2 && pw_ok(d, 64, TH, TI, in32)) ? 64 : 0;
+    if (g_pw_force_tile == 128) return pw_ok(d, 128, TH, TI, in32) ? 128 : 0;
     const long t128 = ((long)d->N * d->OH * d->OW / 128) * ((d->Nc + 127) / 128);
-    if (var < 2 && t128 < 200 && pw_ok(d, 64, TH, TI)) return 64;
-    return pw_ok(d, 128, TH, TI) ? 128 : 0;
+    if (var < 2 && t128 < 200 && pw_ok(d, 64, TH, TI, in32)) return 64;
+    return pw_ok(d, 128, TH, TI, in32) ? 128 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -755,10 +802,10 @@ struct PwGn { const float* sums; const float* gamma; const float* beta; const fl
 
 static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,
                      const float* residual, void* y, int out_bf16, int var, float* gsum, const float* coef, void* stream,
-                     const PwGn* gn = nullptr) {
+                     const PwGn* gn = nullptr, bool in32 = false) {
     PwArgs a{};
     if (!d || !x || !w_frag_bf16 || !y) return mi_set_error(-1, "%s: null argument", who);
-    const int pt = pw_pick_tile(d, var, &a.TH, &a.TI);
+    const int pt = pw_pick_tile(d, var, &a.TH, &a.TI, in32);
     if (!pt) return mi_set_error(-1, "%s: descriptor not supported by the private-weight-stream conv kernel", who);
     if (d->K1 != d->K && !x2) return mi_set_error(-1, "%s: two-source split without x2", who);
     if ((((uintptr_t)x | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)w_frag_bf16) & 15) != 0) return mi_set_error(-1, "%s: operands must be 16-byte aligned", who);
@@ -819,7 +866,19 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
         return e_ == hipSuccess ? 0 : mi_set_error((int)e_, "%s: %s", who, hipGetErrorString(e_));
     }
 #endif
-    if (pt == 64) {
+#define MI_PW_GO_X(O16, V, T) do { \
+        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, 0, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
+        (void)once_; \
+        hipLaunchKernelGGL((conv_pw_kernel<O16, V, 0, T, true>), grid, dim3(256), lds, st, a); } while (0)
+    if (in32) {
+        if (pt == 64) {
+            if (var == 1) { if (out_bf16) MI_PW_GO_X(true, 1, 64); else MI_PW_GO_X(false, 1, 64); }
+            else { if (out_bf16) MI_PW_GO_X(true, 0, 64); else MI_PW_GO_X(false, 0, 64); }
+        } else {
+            if (var == 1) { if (out_bf16) MI_PW_GO_X(true, 1, 128); else MI_PW_GO_X(false, 1, 128); }
+            else { if (out_bf16) MI_PW_GO_X(true, 0, 128); else MI_PW_GO_X(false, 0, 128); }
+        }
+    } else if (pt == 64) {
         if (var == 1) { if (out_bf16) MI_PW_GO_T(true, 1, 0, 64); else MI_PW_GO_T(false, 1, 0, 64); }
         else { if (out_bf16) MI_PW_GO_T(true, 0, 0, 64); else MI_PW_GO_T(false, 0, 0, 64); }
     } else switch (var) {
@@ -830,6 +889,7 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     }
 #undef MI_PW_GO
 #undef MI_PW_GO_T
+#undef MI_PW_GO_X
     hipError_t e_ = hipGetLastError();
     return e_ == hipSuccess ? 0 : mi_set_error((int)e_, "%s: %s", who, hipGetErrorString(e_));
 }
@@ -869,6 +929,20 @@ extern "C" int mi_conv3x3_pw(const MiConvDesc* d, const void* x, const void* x2,
 extern "C" int mi_conv3x3_pw_gnsums(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,
                                     const float* residual, void* y, int out_bf16, float* gsum, void* stream) {
     return pw_launch(__func__, d, x, x2, w_frag_bf16, bias, residual, y, out_bf16, 1, gsum, nullptr, stream);
+}
+// The same two entry points for fp32 x / x2 (pixel strides in floats, % 4 == 0): the residual-stream tensors as they are, rounded to
+// bf16 once while they are staged (the numbers mi_f32_to_bf16 + mi_conv3x3_pw give).  gsum may be null (no sums).
+extern "C" int mi_conv3x3_pw_x32_supported(const MiConvDesc* d) {
+    int th, ti;
+    return (d && pw_pick_tile(d, 0, &th, &ti, true)) ? 1 : 0;
+}
+extern "C" int mi_conv3x3_pw_x32_tile(const MiConvDesc* d) {
+    int th, ti;
+    return d ? pw_pick_tile(d, 0, &th, &ti, true) : 0;
+}
+extern "C" int mi_conv3x3_pw_x32(const MiConvDesc* d, const float* x, const float* x2, const void* w_frag_bf16, const float* bias,
+                                 const float* residual, void* y, int out_bf16, float* gsum, void* stream) {
+    return pw_launch(__func__, d, x, x2, w_frag_bf16, bias, residual, y, out_bf16, gsum ? 1 : 0, gsum, nullptr, stream, nullptr, true);
 }
 // BASELINE.json's named kernel on this structure: y = conv3x3(mish(x * scale + shift) + tb) + bias, x the RAW bf16 output of the
 // previous conv, coef [3][N][K] = scale, shift, tb (mi_gn_coef_from_sums / mi_gn_stats_coef)

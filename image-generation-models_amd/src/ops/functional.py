@@ -271,6 +271,19 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
             _probe_close(e0, f"conv1x1_pw_kernel<{'true' if _b16(out) else 'false'}, {'true' if want16 else 'false'}, {px}>", 2.0 * N * H * W * Nc * K,
                          f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
         return (out, y16) if want16 else out
+    if (ksize == 3 and not _b16(x) and USE_CONV_PW and wq is not None and not want16 and d.ldx % 4 == 0 and (x2 is None or d.ldx2 % 4 == 0)):
+        # fp32-stored input (the residual stream: the sampler's block1 convs): the same kernel, pieces rounded to bf16 while staged
+        pt = _query("mi_conv3x3_pw_x32_tile", d)
+        if pt and (N * H * W // pt) * ((Nc + 127) // 128) >= PW_MIN_TILES:
+            assert gn_sums is None or (gn_sums.dtype == torch.float32 and gn_sums.numel() == N * (Nc // 16) * 2)
+            e0 = _probe_open()
+            check(lib.mi_conv3x3_pw_x32(C.byref(d), _p(x), _p(x2), _p(wq), _p(bias), _p(residual), _p(out), _b16(out), _p(gn_sums), _stream()),
+                  "mi_conv3x3_pw_x32")
+            if e0 is not None:
+                nb = (N * H * W * K * 4 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 2)
+                _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(out) else 'false'}, {0 if gn_sums is None else 1}, 0, {pt}, true>",
+                             2.0 * N * H * W * Nc * K * 9, f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} fp32 in flip{int(flip)} acc{int(accumulate)}", nb)
+            return out
     if (gn_sums is not None and ksize == 3 and _b16(x) and USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc, d)
             and _query("mi_conv3x3_pw_supported", d)):
         # the next layer's GroupNorm sums from the private-weight-stream kernel's epilogue

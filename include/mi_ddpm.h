@@ -159,6 +159,12 @@ int mi_pack_weights_bf16(int nent, const void* entries_dev, int total_tiles, con
  * wdq (d->transposed = 1: data gradient, flipped taps).  Needs W in {8, 16, 32} with 128-pixel row tiles (N*H*W % 128 == 0),
  * K % 64 == 0, K1 % 64 == 0, Nc % 32 == 0, ldy % 4 == 0. */
 int mi_conv3x3_pw_supported(const MiConvDesc* d);
+/* ... for fp32 x / x2 (the residual stream as it is; pixel strides in floats, % 4 == 0): rounded to bf16 once while staged; gsum
+ * (optional): the GroupNorm sums of mi_conv3x3_pw_gnsums */
+int mi_conv3x3_pw_x32_supported(const MiConvDesc* d);
+int mi_conv3x3_pw_x32_tile(const MiConvDesc* d);
+int mi_conv3x3_pw_x32(const MiConvDesc* d, const float* x, const float* x2, const void* w_frag_bf16, const float* bias,
+                      const float* residual, void* y, int out_bf16, float* gsum, void* stream);
 int mi_debug_conv_pw_tile(int pt);               /* tests: force the pixel tile (64 / 128), 0 = automatic */
 int mi_conv3x3_pw_tile(const MiConvDesc* d);      /* pixels per workgroup the launch would use: 128, or 64 for small grids; 0 = unsupported */
 int mi_conv3x3_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,

@@ -726,6 +726,44 @@ def test_conv1x1_pw(K, cfg, pw_always):
     assert _conv_launches(pw_always)[-1].startswith("conv1x1_pw_kernel"), _conv_launches(pw_always)
 
 
+@pytest.mark.parametrize("out16", [False, True])
+@pytest.mark.parametrize("cfg", [dict(N=2, H=32, Ci=128, Co=128), dict(N=4, H=16, Ci=256, Co=128, split=128), dict(N=16, H=8, Ci=512, Co=256),
+                                 dict(N=6, H=8, Ci=192, Co=96)])
+def test_conv3x3_pw_fp32_input(K, cfg, out16, pw_always, pw_tile):
+    """mi_conv3x3_pw_x32: the private-weight-stream conv reading the fp32 residual stream directly (the sampler's block1 convs; pieces
+    loaded into registers, rounded to bf16 once, written to the tile): bitwise the result of mi_f32_to_bf16 + mi_conv3x3_pw on both
+    tile sizes, with two sources, bias, residual, accumulate, and with the GroupNorm sums in the epilogue."""
+    N, H, Ci, Co = cfg["N"], cfg["H"], cfg["Ci"], cfg["Co"]
+    split = cfg.get("split")
+    g = torch.Generator().manual_seed(97)
+    x = torch.randn(N, H, H, Ci, generator=g).to(DEV)
+    Cop = (Co + 63) // 64 * 64
+    w = torch.zeros(Cop, Ci, 3, 3); w[:Co] = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)
+    wf, wfq = _frag_weights(K, w)
+    bias = torch.randn(Cop, generator=g).to(DEV)
+    res = torch.randn(N, H, H, Cop, generator=g).to(DEV)
+    dt = torch.bfloat16 if out16 else torch.float32
+    xa, xb = (x[..., :split].contiguous(), x[..., split:].contiguous()) if split else (x, None)
+    y32 = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Cop, flip=False, x2=xb, bias=bias, residual=res, out_dtype=dt, wq=wfq)
+    y16 = K.conv3x3_bf16w(xa.bfloat16(), wf, K=Ci, Nc=Cop, flip=False, x2=xb.bfloat16() if split else None, bias=bias, residual=res,
+                          out_dtype=dt, wq=wfq)
+    ls = _conv_launches(pw_always)
+    o16 = "true" if out16 else "false"
+    assert ls[-2:] == [f"conv_pw_kernel<{o16}, 0, 0, {pw_tile}, true>", f"conv_pw_kernel<{o16}, 0, 0, {pw_tile}>"], ls
+    assert torch.equal(y32, y16)
+    y2 = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Cop, flip=False, x2=xb, out=y32.clone(), accumulate=True, wq=wfq)
+    y3 = K.conv3x3_bf16w(xa.bfloat16(), wf, K=Ci, Nc=Cop, flip=False, x2=xb.bfloat16() if split else None, out=y16.clone(), accumulate=True, wq=wfq)
+    assert torch.equal(y2, y3)
+    if Cop % 16 == 0:
+        s32, s16 = torch.zeros(N * (Cop // 16) * 2, device=DEV), torch.zeros(N * (Cop // 16) * 2, device=DEV)
+        ya = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Cop, flip=False, x2=xb, bias=bias, out_dtype=dt, gn_sums=s32, wq=wfq)
+        yb = K.conv3x3_bf16w(xa.bfloat16(), wf, K=Ci, Nc=Cop, flip=False, x2=xb.bfloat16() if split else None, bias=bias, out_dtype=dt,
+                             gn_sums=s16, wq=wfq)
+        torch.cuda.synchronize()
+        assert _conv_launches(pw_always)[-2] == f"conv_pw_kernel<{o16}, 1, 0, {pw_tile}, true>"
+        assert torch.equal(ya, yb) and float((s32 - s16).abs().max()) <= 2e-5 * float(s16.abs().max())     # (atomics order)
+
+
 def test_pack_weights_fragment_order(K):
     """The MFMA-fragment-order copies mi_conv3x3_pw streams (include/mi_ddpm.h): wfq[tap][co/32][ci/16][lane][8] and
     wdq[tap][ci/32][co/16][lane][8] for the 3x3 and 1x1 layers with 64-multiples on both sides; the others get none (zero slice)."""

@@ -311,6 +311,52 @@ def test_full_batch_backward_properties():
     assert out["bf16_vs_fp32_flat_grad_rel_l2"] < 1.8e-2                               # measured 8.8e-3
 
 
+def test_cfg3_per_gpu_batch_properties():
+    """BASELINE cfg 3 at its per-GPU batch (CelebA 64x64, dim 64, mults 1-2-4-8, B = 256 / 8 = 32) in the benchmarked bf16 mode and
+    in fp32 mode -- the size the data-parallel run executes per rank, where the small-grid kernel plans (64-pixel conv tiles, pixel-sliced
+    LinearAttention, the uncached GroupNorm backward of the 4096-pixel slices) are the ones that run: forward determinism and batch
+    independence, gradient determinism up to the order of the fp32 atomics, gradients of the four 8-sample slices summing to the
+    32-batch gradient, bf16 mode within the recorded distance of fp32 mode."""
+    from src.models.ddpm import GaussianDiffusion
+    out = {}
+    g = torch.Generator().manual_seed(16)
+    x = (torch.rand(32, 3, 64, 64, generator=g) * 2 - 1).to(DEV)
+    t = torch.randint(0, 1000, (32,), generator=g).to(DEV)
+    noise = torch.randn(32, 3, 64, 64, generator=g).to(DEV)
+    grads, eps = {}, {}
+    for mode in ("fp32", "bf16"):
+        net = _seeded(64, (1, 2, 4, 8), mode)
+        net.eval()
+        with torch.no_grad():
+            y = net(x, t)
+            out[f"{mode}_forward_rerun_rel_l2"] = rel_err(net(x, t), y)      # (pixel-sliced LinearAttention combines its slices with atomics)
+            ys = net(x[8:16].contiguous(), t[8:16].contiguous())
+        out[f"{mode}_forward_slice_vs_full_rel_l2"] = rel_err(ys, y[8:16])
+        eps[mode] = y
+        net.train()
+        gd = GaussianDiffusion(net, image_size=(64, 64), timesteps=1000).to(DEV)
+        loss = gd.p_losses(x, t, noise); loss.backward()
+        full = net.flat_grads.clone()
+        loss = gd.p_losses(x, t, noise); loss.backward()
+        out[f"{mode}_rerun_rel_l2"] = rel_err(net.flat_grads, full)
+        acc = torch.zeros_like(full)
+        for i in range(0, 32, 8):
+            l = gd.p_losses(x[i:i + 8].contiguous(), t[i:i + 8].contiguous(), noise[i:i + 8].contiguous()); l.backward()
+            acc += net.flat_grads
+        out[f"{mode}_slices_vs_full_rel_l2"] = rel_err(acc / 4, full)
+        grads[mode] = full
+        assert torch.isfinite(full).all() and torch.isfinite(y).all()
+    out["bf16_vs_fp32_eps_rel_l2"] = rel_err(eps["bf16"], eps["fp32"])
+    out["bf16_vs_fp32_flat_grad_rel_l2"] = rel_err(grads["bf16"], grads["fp32"])
+    record("cfg3_B32_properties", **out)
+    assert out["fp32_forward_rerun_rel_l2"] == 0.0 and out["bf16_forward_rerun_rel_l2"] == 0.0
+    assert out["fp32_forward_slice_vs_full_rel_l2"] < 1e-5 and out["fp32_rerun_rel_l2"] < 1e-6 and out["bf16_rerun_rel_l2"] < 1e-6
+    assert out["fp32_slices_vs_full_rel_l2"] < 1e-6
+    assert out["bf16_forward_slice_vs_full_rel_l2"] < 1e-2       # slices pick other kernel plans (tile sizes) than the full batch
+    assert out["bf16_slices_vs_full_rel_l2"] < 2e-2
+    assert out["bf16_vs_fp32_eps_rel_l2"] < 2e-2 and out["bf16_vs_fp32_flat_grad_rel_l2"] < 3e-2
+
+
 def _host_tape(shape, seed, n, sha):
     """The reference's host noise tape (torch CPU generator: x_T, then one draw per reverse step); refuses any other tape."""
     import hashlib

@@ -61,8 +61,11 @@ for _ in range(5):
         K.linattn_bwd(QKV, ctx, kst, ao, 4)
     elif which == "c1x1":        # to_qkv (Ci -> Co, bf16 in / out) forward through the tile kernel
         if "W1" not in globals():
-            W1 = (torch.randn(Co * Ci, device=DEV) * 0.05).bfloat16()
-        K.conv3x3_bf16w(x, W1, K=Ci, Nc=Co, flip=False, ksize=1, out_dtype=DT)
+            w1 = torch.randn(1, 1, Ci, Co, device=DEV) * 0.05
+            table, nent, tiles = K.pack_table([(0, 1, Ci, Co)], DEV)
+            W1 = [torch.zeros(w1.numel(), device=DEV, dtype=torch.bfloat16) for _ in range(4)]
+            K.pack_weights_bf16(table, nent, tiles, w1.reshape(-1), *W1)
+        K.conv3x3_bf16w(x, W1[1], K=Ci, Nc=Co, flip=False, ksize=1, out_dtype=DT, wq=W1[3])
     elif which == "halo":        # the register-staged halo kernel (not the per-shape pick)
         K.CONV_AUTO = False
         K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, out=y)

@@ -28,4 +28,6 @@ for cfg in "pw 128 8 512 512 bf16" "pw 128 32 128 128 bf16" "wgradq 128 0 0 0 bf
   timeout 400 bash tools/pmc.sh ${tag}_$name $cfg > $OUT/pmc_sq_$name.txt 2>&1
 done
 python bench.py > $OUT/bench.json 2> /dev/null
+python bench.py --cfg 3 --batch 32 --graph 1 --no-extras > $OUT/bench_cfg3_b32_graph.json 2> /dev/null
+python bench.py --cfg 3 --batch 32 --graph 0 --no-extras > $OUT/bench_cfg3_b32_eager.json 2> /dev/null
 ls -la $OUT
