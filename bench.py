@@ -186,7 +186,7 @@ def named_kernel_line(K, dev):
         x = torch.randn(N, H, W, Cc, device=dev, generator=g).to(dt)           # c1: the raw output of block1's conv
         xin = torch.randn(N, H, W, Cc, device=dev, generator=g).to(dt)         # block1's input (producer timing)
         xs = x.float().view(N, H * W, Cc // 16, 16)
-        sums = torch.stack([xs.sum((1, 3)), (xs * xs).sum((1, 3))], dim=-1).contiguous().view(-1)     # what c1's producer would have left
+        sums = K.gn_sums_encode(torch.stack([xs.sum((1, 3)), (xs * xs).sum((1, 3))], dim=-1))       # what c1's producer would have left
         scratch = torch.zeros_like(sums)                                       # the timed producer adds into this one
         gn = (sums, gamma, beta, temb, 8, 1e-5)
         stats, coef = K.gn_stats_coef(x, gamma, beta, temb=temb)

@@ -26,6 +26,18 @@ inline long mi_knob(const char* name, long dflt) { const char* e = getenv(name);
 inline constexpr long mi_knob(const char*, long dflt) { return dflt; }
 #endif
 
+// GroupNorm sums left by a conv's epilogue (sum, sum of squares per sample and 16-channel slab): 64-bit fixed point with 20 fraction
+// bits, added with INTEGER atomics -- the totals do not depend on the order in which the workgroups arrive.  (fp32 atomics made the
+// fused inference path differ from run to run: 1e-7 in the sums, a few bf16 rounding flips per layer, 7e-3 in the UNet's output.)
+// A workgroup's partial sums are formed in a fixed order before they are converted.
+constexpr double MI_GSUM_SCALE = 1048576.0;
+__device__ __forceinline__ void gsum_add(void* base, size_t idx, float v) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(base) + idx, (unsigned long long)__double2ll_rn((double)v * MI_GSUM_SCALE));
+}
+__device__ __forceinline__ double gsum_get(const void* base, size_t idx) {
+    return (double)reinterpret_cast<const long long*>(base)[idx] * (1.0 / MI_GSUM_SCALE);
+}
+
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     bf16x2 p = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(uint32_t, p);

@@ -249,9 +249,9 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
                 // statistics straight from the sums the producing conv's epilogue left (no coefficient tensor, no extra launch):
                 // the group's 16-channel slabs are combined in double, var = E[x^2] - mean^2
                 const int g = c0 / a.gn_cg, nslab = a.gn_cg >> 4;
-                const float* p = a.gn_sums + ((size_t)n * (a.K >> 4) + (size_t)g * nslab) * 2;
+                const size_t p = ((size_t)n * (a.K >> 4) + (size_t)g * nslab) * 2;
                 double sm = 0.0, sq = 0.0;
-                for (int k = 0; k < nslab; ++k) { sm += p[2 * k]; sq += p[2 * k + 1]; }
+                for (int k = 0; k < nslab; ++k) { sm += gsum_get(a.gn_sums, p + 2 * k); sq += gsum_get(a.gn_sums, p + 2 * k + 1); }
                 const double mean = sm * a.gn_icnt;                                      // no fp64 division in the loop
                 const float var = (float)fmax(sq * a.gn_icnt - mean * mean, 0.0), rstd = __builtin_amdgcn_rsqf(var + a.gn_eps), mf = (float)mean;
                 cf_s = *reinterpret_cast<const f32x4*>(a.gn_gamma + c0) * rstd;
@@ -670,8 +670,8 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
                     for (int k = 0; k < NI * 2; ++k) {
                         const int col = n0 + wn * 64 + (k >> 1) * 32 + (k & 1) * 16;
                         if (col < a.Nc) {
-                            float* g = a.gsum + ((size_t)n * (a.Nc / 16) + col / 16) * 2;
-                            atomicAdd(g, ps[k]); atomicAdd(g + 1, pq[k]);
+                            const size_t g = ((size_t)n * (a.Nc / 16) + col / 16) * 2;
+                            gsum_add(a.gsum, g, ps[k]); gsum_add(a.gsum, g + 1, pq[k]);
                         }
                     }
                 }
@@ -709,7 +709,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
             for (int w2 = 0; w2 < WAVES / 2; ++w2) tot += red[((w2 * 2 + wn2) * 4 + k) * 2 + q];
             const int col = n0 + wn2 * 64 + (k >> 1) * 32 + (k & 1) * 16;
             if (col < a.Nc && (size_t)m0 < (size_t)Mtot)
-                atomicAdd(a.gsum + ((size_t)(m0 / (a.H * a.W)) * (a.Nc / 16) + col / 16) * 2 + q, tot);
+                gsum_add(a.gsum, ((size_t)(m0 / (a.H * a.W)) * (a.Nc / 16) + col / 16) * 2 + q, tot);
         }
     }
     MI_TS(4);

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     //      destination registers are touched again only behind coef_landed(), which sits after the counted wait that covers them.
     f32x4 cq[6];                                             // scale[8], shift[8], time bias[8] of the chunk being transformed
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 sq[4];                                             // VAR 3: (sum, sum of squares) of the group's slabs
+    u32x4 sq[4];                                             // VAR 3: (sum, sum of squares) of the group's slabs, two 64-bit fixed-point values each
     const int nslab = FUSE ? a.cpg >> 4 : 1;
     auto load_coef = [&](int ch) {
         const int c = min(ch, nchunks - 1) * PCK + xcol;
@@ -224,13 +224,13 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             // gamma, beta, the time-bias row (the zero page when there is none) and up to four slabs of the group's sums (a group
             // with fewer slabs reads its first one again: the number of loads is what the counted waits assume)
             const float* tb = a.temb ? a.temb + (size_t)img0 * a.ldt + c : reinterpret_cast<const float*>(g_zero_page3);
-            const float* sp = a.sums + ((size_t)img0 * (a.K >> 4) + (c / a.cpg) * nslab) * 2;
-            const float* s1 = sp + (nslab > 1 ? 2 : 0); const float* s2 = sp + (nslab > 2 ? 4 : 0); const float* s3 = sp + (nslab > 2 ? 6 : 0);
+            const float* sp = a.sums + ((size_t)img0 * (a.K >> 4) + (c / a.cpg) * nslab) * 4;       // 16 bytes per slab
+            const float* s1 = sp + (nslab > 1 ? 4 : 0); const float* s2 = sp + (nslab > 2 ? 8 : 0); const float* s3 = sp + (nslab > 2 ? 12 : 0);
             asm volatile("global_load_dwordx4 %0, %10, off\n\tglobal_load_dwordx4 %1, %10, off offset:16\n\t"
                          "global_load_dwordx4 %2, %11, off\n\tglobal_load_dwordx4 %3, %11, off offset:16\n\t"
                          "global_load_dwordx4 %4, %12, off\n\tglobal_load_dwordx4 %5, %12, off offset:16\n\t"
-                         "global_load_dwordx2 %6, %13, off\n\tglobal_load_dwordx2 %7, %14, off\n\t"
-                         "global_load_dwordx2 %8, %15, off\n\tglobal_load_dwordx2 %9, %16, off"
+                         "global_load_dwordx4 %6, %13, off\n\tglobal_load_dwordx4 %7, %14, off\n\t"
+                         "global_load_dwordx4 %8, %15, off\n\tglobal_load_dwordx4 %9, %16, off"
                          : "=&v"(cq[0]), "=&v"(cq[1]), "=&v"(cq[2]), "=&v"(cq[3]), "=&v"(cq[4]), "=&v"(cq[5]),
                            "=&v"(sq[0]), "=&v"(sq[1]), "=&v"(sq[2]), "=&v"(sq[3])
                          : "v"(a.gamma + c), "v"(a.beta + c), "v"(tb), "v"(sp), "v"(s1), "v"(s2), "v"(s3) : "memory");
@@ -244,7 +244,10 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             double sm = 0.0, qm = 0.0;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (k < nslab) { sm += sq[k].x; qm += sq[k].y; }
+                if (k < nslab) {
+                    sm += (double)(long long)(((unsigned long long)sq[k].y << 32) | sq[k].x) * (1.0 / MI_GSUM_SCALE);
+                    qm += (double)(long long)(((unsigned long long)sq[k].w << 32) | sq[k].z) * (1.0 / MI_GSUM_SCALE);
+                }
             const double cnt = (double)a.hw * a.cpg, mean = sm / cnt;
             double var = qm / cnt - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             const int slab = (n0 >> 4) + q;
             if (slab * 16 < a.Nc) {
                 const int img = a.TI > 1 ? img0 + (k >> 1) : img0;
-                atomicAdd(a.gsum + ((size_t)img * (a.Nc >> 4) + slab) * 2 + (k & 1), v);
+                gsum_add(a.gsum, ((size_t)img * (a.Nc >> 4) + slab) * 2 + (k & 1), v);
             }
         }
     }
@@ -817,7 +820,7 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     if (var == 3) {
         if (!gn || !gn->sums || !gn->gamma || !gn->beta || gn->G <= 0 || d->K % gn->G || (d->K / gn->G) % 16 || d->K / gn->G > 64)
             return mi_set_error(-1, "%s: sums, gamma, beta; K / G in {16, 32, 64}", who);
-        if ((((uintptr_t)gn->gamma | (uintptr_t)gn->beta | (uintptr_t)gn->sums) & 7) || (gn->temb && (((uintptr_t)gn->temb & 15) || gn->ldt % 4)))
+        if ((((uintptr_t)gn->gamma | (uintptr_t)gn->beta | (uintptr_t)gn->sums) & 7) || ((uintptr_t)gn->sums & 15) || (gn->temb && (((uintptr_t)gn->temb & 15) || gn->ldt % 4)))
             return mi_set_error(-1, "%s: misaligned GroupNorm operands", who);
         a.sums = gn->sums; a.gamma = gn->gamma; a.beta = gn->beta; a.temb = gn->temb; a.ldt = gn->ldt; a.cpg = d->K / gn->G;
         a.hw = d->OH * d->OW; a.eps = gn->eps;

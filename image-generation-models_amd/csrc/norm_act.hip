@@ -715,8 +715,8 @@ __global__ __launch_bounds__(256) void gn_coef_from_sums_kernel(int N, int C, in
     const int n = i / C, c = i - n * C, Cg = C / G, g = c / Cg, nslab = Cg / 16;
     double s = 0.0, q = 0.0;
     for (int k = 0; k < nslab; ++k) {
-        const float* p = sums + ((size_t)n * (C / 16) + g * nslab + k) * 2;
-        s += p[0]; q += p[1];
+        const size_t p = ((size_t)n * (C / 16) + g * nslab + k) * 2;
+        s += gsum_get(sums, p); q += gsum_get(sums, p + 1);
     }
     const double cnt = (double)HW * Cg, mean = s / cnt;
     double var = q / cnt - mean * mean;

@@ -542,7 +542,7 @@ class Unet(nn.Module):
             if fuse and fmode in ("2", "auto") and sums_ok:
                 nsum = B * (co // 16) * 2
                 if zpool[0] is None:      # one zero fill per forward for every block's sums
-                    zpool[0] = torch.zeros(2 * B * sum(rb["cout"] // 16 + 1 for rb in A.res_blocks), device=inp.device, dtype=torch.float32)
+                    zpool[0] = torch.zeros(2 * B * sum(rb["cout"] // 16 + 1 for rb in A.res_blocks), device=inp.device, dtype=torch.int64)
                 sums = zpool[0][zpool[1]:zpool[1] + nsum]
                 zpool[1] += (nsum + 3) // 4 * 4
             c1 = conv(inp_c, pre + "block1.block.0.", 3, 1, 1, x2=x2_c, out_dtype=BF if c1_16 else torch.float32, gn_sums=sums)

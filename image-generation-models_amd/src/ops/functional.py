@@ -275,7 +275,7 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
         # fp32-stored input (the residual stream: the sampler's block1 convs): the same kernel, pieces rounded to bf16 while staged
         pt = _query("mi_conv3x3_pw_x32_tile", d)
         if pt and (N * H * W // pt) * ((Nc + 127) // 128) >= PW_MIN_TILES:
-            assert gn_sums is None or (gn_sums.dtype == torch.float32 and gn_sums.numel() == N * (Nc // 16) * 2)
+            assert gn_sums is None or (gn_sums.dtype == torch.int64 and gn_sums.numel() == N * (Nc // 16) * 2)
             e0 = _probe_open()
             check(lib.mi_conv3x3_pw_x32(C.byref(d), _p(x), _p(x2), _p(wq), _p(bias), _p(residual), _p(out), _b16(out), _p(gn_sums), _stream()),
                   "mi_conv3x3_pw_x32")
@@ -287,7 +287,7 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
     if (gn_sums is not None and ksize == 3 and _b16(x) and USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc, d)
             and _query("mi_conv3x3_pw_supported", d)):
         # the next layer's GroupNorm sums from the private-weight-stream kernel's epilogue
-        assert gn_sums.dtype == torch.float32 and gn_sums.numel() == N * (Nc // 16) * 2
+        assert gn_sums.dtype == torch.int64 and gn_sums.numel() == N * (Nc // 16) * 2
         e0 = _probe_open()
         check(lib.mi_conv3x3_pw_gnsums(C.byref(d), _p(x), _p(x2), _p(wq), _p(bias), _p(residual), _p(out), _b16(out), _p(gn_sums), _stream()),
               "mi_conv3x3_pw_gnsums")
@@ -327,7 +327,7 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
         check(lib.mi_conv3x3_bf16w_io_dual(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _p(y16), ld_of(y16), io, _stream()),
               "mi_conv3x3_bf16w_io_dual")
     elif gn_sums is not None:     # the next layer's GroupNorm statistics ride in this conv's epilogue
-        assert ksize == 3 and gn_sums.dtype == torch.float32 and gn_sums.numel() == N * (Nc // 16) * 2
+        assert ksize == 3 and gn_sums.dtype == torch.int64 and gn_sums.numel() == N * (Nc // 16) * 2
         check(lib.mi_conv3x3_bf16w_io_gnsums(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), io, _p(gn_sums), _stream()),
               "mi_conv3x3_bf16w_io_gnsums")
     elif io:
@@ -361,6 +361,23 @@ def gn_stats_coef(x, gamma, beta, *, groups=8, eps=1e-5, temb=None):
     if e0 is not None:
         _probe_close(e0, f"gn_mish_fwd_kernel<io{_b16(x)}> (statistics only)", 0.0, f"N{N} HW{H * W} C{Cc}", N * H * W * Cc * _esz(x))
     return stats, coef
+
+
+GSUM_SCALE = float(1 << 20)      # csrc/common.h MI_GSUM_SCALE: the epilogue sums are 64-bit fixed point (integer atomics: order-independent)
+
+
+def gn_sums_buffer(N, Nc, device):
+    """Zeroed [N][Nc / 16][2] buffer for the (sum, sum of squares) a conv's epilogue accumulates (gn_sums=...)."""
+    return torch.zeros(N * (Nc // 16) * 2, device=device, dtype=torch.int64)
+
+
+def gn_sums_encode(sums_f64):
+    """float sums [N][Nc / 16][2] -> the fixed-point buffer the kernels read (tests, benchmarks)."""
+    return torch.round(sums_f64.double() * GSUM_SCALE).to(torch.int64).contiguous().view(-1)
+
+
+def gn_sums_decode(buf):
+    return buf.double() / GSUM_SCALE
 
 
 def gn_coef_from_sums(sums, N, HW, gamma, beta, *, groups=8, eps=1e-5, temb=None):

@@ -167,7 +167,7 @@ OTHER = {"mi_abi_version": ([], C.c_int), "mi_last_error": ([], C.c_char_p),
          "mi_f32_to_bf16_colsum_workspace": ([_Z, _I], C.c_size_t),
          "mi_linattn_workspace": ([_I, _I, _I], C.c_size_t),
          "mi_conv_small_wgrad_workspace": ([_I], C.c_size_t)}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def load_library():

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 3   /* 2: mi_pack_weights_bf16 takes the fragment-order copies; mi_adam_step_dev betas are double.  3: mi_conv1x1_pw takes x2 */
+#define MI_ABI_VERSION 4   /* 2: mi_pack_weights_bf16 takes the fragment-order copies; mi_adam_step_dev betas are double.  3: mi_conv1x1_pw takes x2.  4: GroupNorm epilogue sums are 64-bit fixed point */
 #define MI_MODE_FP32 0
 #define MI_MODE_BF16 1
 
@@ -112,7 +112,10 @@ int mi_conv3x3_bf16w_io(const MiConvDesc* d, const void* x, const void* x2, cons
 /* (mi_gn_stats_coef is declared with the GroupNorm entry points below) */
 /* GroupNorm statistics of the NEXT layer from this conv's epilogue (instead of mi_gn_stats_coef's pass over the tensor):
  * mi_conv3x3_bf16w_io_gnsums is mi_conv3x3_bf16w_io that also adds, per sample and 16-channel slab, the sum and the sum of squares of
- * the values it stores (rounded to bf16 when y is bf16) into gsum [N][Nc / 16][2] (zeroed by the caller; Nc % 16 == 0, H*W % 32 == 0);
+ * the values it stores (rounded to bf16 when y is bf16) into gsum [N][Nc / 16][2] (zeroed by the caller; Nc % 16 == 0, H*W % 32 == 0).
+ * ABI 4: the elements of gsum / sums are 64-bit fixed-point integers with 20 fraction bits (16 bytes per slab; the float* in the
+ * signatures is an opaque, 16-byte aligned pointer): they are added with integer atomics, so the totals -- and everything computed
+ * from them -- do not depend on the order in which the workgroups arrive;
  * mi_gn_coef_from_sums combines the slabs of each group into stats [N][G][2] = {mean, rstd} (optional) and coef [3][N][C] as
  * mi_gn_stats_coef would have written them (C / G % 16 == 0).  Block -> Block: conv1 + sums, coef, then mi_conv3x3_gn_mish. */
 /* mi_conv3x3_bf16w_io that also writes the bf16 copy of its fp32 output (y_bf16, pixel stride ldy16 elements): LinearAttention's

@@ -105,7 +105,7 @@ def _worker_graph(rank, world, port, mode, q):
     try:
         out = {}
         x = _data(16)[0][rank * 8:rank * 8 + 8].cuda()
-        for which in ("eager", "graph"):
+        for which in ("eager", "eager2", "graph"):
             m = _build(mode)
             m.log = lambda *a, **k: None
             net = m.denoising_model
@@ -124,7 +124,7 @@ def _worker_graph(rank, world, port, mode, q):
                 red.finish()
                 opt.step()
             eager(); eager()
-            if which == "eager":
+            if which != "graph":
                 eager(); eager()
                 nseg = 0
             else:
@@ -141,11 +141,14 @@ def _worker_graph(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
-def test_segmented_graph_step_under_data_parallel(mode, tol):
+@pytest.mark.parametrize("mode,floor", [("fp32", 2e-5), ("bf16", 2e-3)])
+def test_segmented_graph_step_under_data_parallel(mode, floor):
     """trainer.graph_step under data parallelism (src/runtime/graphed.py::SegmentedGraphedTrainStep): two gloo ranks on the box's one
     GPU; the replayed chain of graphs + the all-reduces between them must leave the same averaged gradients and weights as the
-    eager data-parallel step from the same state and draws, on both ranks."""
+    eager data-parallel steps from the same state and draws, on both ranks -- within twice the distance TWO EAGER RUNS of the same
+    four steps end up from each other (fp32 atomics of the norm / bias gradients land in a different order from run to run, Adam and
+    the bf16 roundings amplify that over the steps: measured in the same worker, not assumed; a replay with stale weight copies, a
+    stale step count or other draws is off by orders of magnitude more)."""
     import torch.multiprocessing as mp
     sys.path[:0] = [ROOT, PKG]
     ctx = mp.get_context("spawn")
@@ -160,13 +163,15 @@ def test_segmented_graph_step_under_data_parallel(mode, tol):
     from _parity import record
     for rank in (0, 1):
         pe, ge, se, _ = res[rank]["eager"]
+        p2, g2, s2, _ = res[rank]["eager2"]
         pg, gg, sg, nseg = res[rank]["graph"]
-        assert se == sg == 4 and nseg >= 3                      # several buckets -> several graphs
-        pe, ge, pg, gg = (torch.from_numpy(a) for a in (pe, ge, pg, gg))
-        eg = float((gg - ge).abs().max()) / float(ge.abs().max())
-        ew = float((pg - pe).abs().max()) / float(pe.abs().max())
-        record(f"ddp_segmented_graph_vs_eager_{mode}_rank{rank}", grad_max_abs_over_max=eg, weight_max_abs_over_max=ew, graphs=nseg + 1)
-        assert eg <= tol and ew <= max(tol, 2.1e-3 if mode == "bf16" else 0), (eg, ew)
+        assert se == s2 == sg == 4 and nseg >= 3                # several buckets -> several graphs
+        pe, ge, p2, g2, pg, gg = (torch.from_numpy(a) for a in (pe, ge, p2, g2, pg, gg))
+        dist_ = lambda a, b: float((a - b).abs().max()) / float(b.abs().max())       # noqa: E731
+        eg, ew, ng, nw = dist_(gg, ge), dist_(pg, pe), dist_(g2, ge), dist_(p2, pe)
+        record(f"ddp_segmented_graph_vs_eager_{mode}_rank{rank}", grad_max_abs_over_max=eg, weight_max_abs_over_max=ew,
+               eager_noise_grad=ng, eager_noise_weights=nw, graphs=nseg + 1)
+        assert eg <= 2 * ng + floor and ew <= 2 * nw + floor, (eg, ng, ew, nw)
     assert (res[0]["graph"][0] == res[1]["graph"][0]).all()     # both ranks hold the same weights
 
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(library_path())
     for name in declared:
         assert getattr(raw, name) is not None
-    assert lib.mi_abi_version() == 3
+    assert lib.mi_abi_version() == 4
 
 
 def test_argument_errors_do_not_need_a_gpu():

@@ -17,7 +17,7 @@ K.pack_weights_bf16(table, nent, tiles, w32, wd, w, wdq, wq)
 bias = torch.zeros(Cc, device=dev)
 x = torch.randn(N, H, W, Cc, device=dev, generator=g).bfloat16()
 xs = x.float().view(N, H * W, Cc // 16, 16)
-sums = torch.stack([xs.sum((1, 3)), (xs * xs).sum((1, 3))], dim=-1).contiguous().view(-1)
+sums = K.gn_sums_encode(torch.stack([xs.sum((1, 3)), (xs * xs).sum((1, 3))], dim=-1))
 stats, coef = K.gn_stats_coef(x, gamma, beta, temb=temb)
 gn = (sums, gamma, beta, temb, 8, 1e-5)
 fns = {"plain": lambda: K.conv3x3_bf16w(x, w, K=Cc, Nc=Cc, flip=False, bias=bias, out_dtype=torch.bfloat16, wq=wq),
