@@ -469,6 +469,11 @@ class Unet(nn.Module):
         def s2_copy(c, k, transposed):      # Downsample / Upsample read (and their weight gradients want) a bf16 copy of their input
             return (use_sh and self.s2_wgrad_tr and K.igemm_bf16_in_supported(c, c, k, 2, transposed, mode, (8, 8)))
 
+        def s2_eval_copy(t, k, transposed):  # inference: the copy to_out's epilogue wrote along (attention(..., feeds_s2=True)), if any
+            if record or id(t) not in sh or not K.igemm_bf16_in_supported(t.shape[3], t.shape[3], k, 2, transposed, mode, (8, 8)):
+                return None
+            return sh[id(t)][1]
+
         zpool = [None, 0]                   # fused eval path: zeroed pool for the per-block GroupNorm sums, next free float
 
         def shadow(t):
@@ -577,7 +582,7 @@ class Unet(nn.Module):
                 tape.append(("res", blk, inp, x2, c1, st1, h1, c2, st2, out, inp_c, x2_c))
             return out
 
-        def attention(at, inp):
+        def attention(at, inp, feeds_s2=False):
             pre = at["pre"]
             # bf16 storage of the attention-internal tensors (LayerNorm output, qkv, attention output and their
             # gradients) when the 1x1 tile kernels take both projections; the residual stream stays fp32
@@ -591,8 +596,10 @@ class Unet(nn.Module):
             ao, ctx, kstat = K.linattn_fwd(qkv, _HEADS)
             # training: the block's output is a residual-stream tensor whose bf16 copy is wanted by the skip connection's consumer,
             # Downsample / Upsample and the next Block's conv: written by to_out's epilogue instead of a conversion pass
+            # (inference: only where a Downsample / Upsample reads it -- their ring kernel takes 64-channel stages of a bf16 input)
             out = conv(ao, pre + "fn.fn.to_out.", 1, residual=inp,
-                       want16=bool(use_sh and a16 and self.dual_out and inp.shape[3] % 32 == 0))
+                       want16=bool((use_sh or (feeds_s2 and not record and mode == K.MODE_BF16)) and a16 and self.dual_out
+                                   and inp.shape[3] % 32 == 0))
             if record:
                 tape.append(("attn", at, inp, ln, qkv, ctx, kstat, ao, out))
             return out
@@ -602,12 +609,12 @@ class Unet(nn.Module):
         for lvl in A.downs:
             h = resblock(lvl["res1"], h, want_out16=True)        # feeds res2's first conv
             h = resblock(lvl["res2"], h)
-            h = attention(lvl["attn"], h)
+            h = attention(lvl["attn"], h, feeds_s2=lvl["down"] is not None)
             skips.append(h)
             if lvl["down"] is not None:
                 inp = h
                 # training: the skip tensor's bf16 copy (its consumer in the up path wants it too) feeds Downsample and its weight gradient
-                inp_c = shadow(inp) if s2_copy(inp.shape[3], 3, False) else None
+                inp_c = shadow(inp) if s2_copy(inp.shape[3], 3, False) else s2_eval_copy(inp, 3, False)
                 h = conv(inp if inp_c is None else inp_c, lvl["down"]["pre"], 3, 2, 1)
                 if record:
                     tape.append(("down", lvl["down"], inp, h, inp_c))
@@ -617,9 +624,9 @@ class Unet(nn.Module):
         for lvl in A.ups:
             h = resblock(lvl["res1"], h, x2=skips.pop(), want_out16=True)          # cat((x, skip)) read in place (ddpm.py:255)
             h = resblock(lvl["res2"], h)
-            h = attention(lvl["attn"], h)
+            h = attention(lvl["attn"], h, feeds_s2=True)
             inp = h
-            inp_c = shadow(inp) if s2_copy(inp.shape[3], 4, True) else None
+            inp_c = shadow(inp) if s2_copy(inp.shape[3], 4, True) else s2_eval_copy(inp, 4, True)
             h = conv(inp if inp_c is None else inp_c, lvl["up"]["pre"], 4, 2, 1, transposed_conv=True)
             if record:
                 tape.append(("up", lvl["up"], inp, h, inp_c))

@@ -210,9 +210,8 @@ def test_ddpm_graphed_training_step(mode):
         l = m.training_step((x, None), 2); l.backward(); o.step()
         torch.cuda.synchronize()
         return float(l), m.denoising_model.flat_grads.clone(), m.denoising_model.flat_params.clone()
-    la, ga, wa = third_step_eager()
-    lc, gc, wc = third_step_eager()
-    ld, gdd, wdd = third_step_eager()
+    runs = [third_step_eager() for _ in range(5)]            # five samples of the eager step's own noise (ten pairs)
+    la, ga, wa = runs[0]
     m1, o1 = two_eager_steps()
     gs = GraphedTrainStep(m1, o1, (x, None), warmup=0)       # the capture itself executes nothing
     lb = float(gs((x, None)))
@@ -220,13 +219,14 @@ def test_ddpm_graphed_training_step(mode):
     assert o1.device_step_count() == 3
     net = m1.denoising_model
     rel = lambda a, b: float((a - b).norm() / b.norm())      # noqa: E731
-    # the noise of the eager step itself: the largest difference among three runs (one pair is a small sample of it)
-    noise_g = max(rel(gc, ga), rel(gdd, ga), rel(gdd, gc))
-    noise_w = max(rel(wc, wa), rel(wdd, wa), rel(wdd, wc))
+    # the noise of the eager step itself: the largest difference among five runs (a pair or two are too small a sample: the bf16
+    # step amplifies the order of a few fp32 atomics chaotically, and a fourth run was seen 2.4x away from three that agreed)
+    noise_g = max(rel(runs[i][1], runs[j][1]) for i in range(5) for j in range(i))
+    noise_w = max(rel(runs[i][2], runs[j][2]) for i in range(5) for j in range(i))
     err_g, err_w = rel(net.flat_grads, ga), rel(net.flat_params, wa)
     floor_g, floor_w = (2e-6, 5e-7) if mode == "fp32" else (1e-4, 1e-6)      # eager runs can also agree exactly
     record(f"graph_replay_vs_eager_{mode}", grad=err_g, weights=err_w, eager_noise_grad=noise_g, eager_noise_weights=noise_w)
-    assert abs(lb - la) <= 2 * max(abs(lc - la), abs(ld - la)) + (1e-6 if mode == "fp32" else 1e-4), (la, lb, lc, ld)
+    assert abs(lb - la) <= 2 * max(abs(r_[0] - la) for r_ in runs[1:]) + (1e-6 if mode == "fp32" else 1e-4), (la, lb, [r_[0] for r_ in runs])
     assert err_g <= 2 * noise_g + floor_g, (err_g, noise_g)
     assert err_w <= 2 * noise_w + floor_w, (err_w, noise_w)
     # the curve: finite and falling on the fixed batch
