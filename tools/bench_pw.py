@@ -7,6 +7,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "image-generation-models_amd")]
 import torch
 from src.ops import functional as K
 B = int(os.environ.get("B", 128))
+if os.environ.get("PW_TILE"):       # force conv_pw's pixel tile (64 / 128)
+    K.load_library().mi_debug_conv_pw_tile(int(os.environ["PW_TILE"])); K.PW_MIN_TILES = 0
 
 
 def timed(run, n=20):

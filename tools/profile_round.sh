@@ -30,4 +30,6 @@ done
 python bench.py > $OUT/bench.json 2> /dev/null
 python bench.py --cfg 3 --batch 32 --graph 1 --no-extras > $OUT/bench_cfg3_b32_graph.json 2> /dev/null
 python bench.py --cfg 3 --batch 32 --graph 0 --no-extras > $OUT/bench_cfg3_b32_eager.json 2> /dev/null
+# the RCCL path on one rank (init, broadcast, bucketed all-reduce on RCCL's stream, barrier-bracketed timing), eager and as the segmented graph
+for g in 0 1; do MI_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 2951$g bench.py --gpus 1 --steps 30 --warmup 5 --no-extras --graph $g 2> /dev/null | tail -1 > $OUT/bench_rccl1_graph$g.json; done
 ls -la $OUT
