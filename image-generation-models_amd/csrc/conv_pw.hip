@@ -45,7 +45,6 @@ struct PwArgs {
     int ldt, cpg, hw; float eps;
 };
 
-constexpr int PCK = 64;                         // channels per chunk
 // PT = output pixels per workgroup: 128 (four 32-pixel MFMA blocks per wave) or, for the layers whose 128-pixel tiles would leave
 // CUs without a workgroup, 64 (two blocks: a fragment feeds two MFMAs instead of four, but the grid is twice as large)
 constexpr int pw_xp(int pt) { return pt == 128 ? 192 : 128; }      // tile pixels incl. the rows above and below: 6 x 32, 10 x 16, 2 images x 10 x 8 | 4 x 32, 6 x 16, 10 x 8
@@ -111,10 +110,19 @@ constexpr int pw_lds(int pt) { return (pt == 128 ? 64 : 32) * 1024 + 2048; }   /
 // IN32: x / x2 are fp32 tensors (the residual stream: the sampler's block1 convs, fp32 block storage).  Their pieces are loaded into
 // registers (two global_load_dwordx4 per lane and piece, counted like the fragments), rounded to bf16 once and written to the lane's
 // slot of the tile -- the lane loads the channel chunk that belongs in ITS slot, as the DMA's source addresses do for bf16 input.
-template <bool OUT16, int VAR = 0, int ABL = 0, int PT = 128, bool IN32 = false>
+// F32: the exact-fp32 mode of the same kernel (Unet.compute_mode = "fp32", the reference's default precision and the mode that carries
+// the 1e-4 parity bar): x / x2 / y fp32, weights fp32 in fragment order [tap][co / 32][ci / 8][lane][4] (mi_pack_weights_f32frag),
+// v_mfma_f32_32x32x2_f32 -- bit-equal to an fp32 fmaf chain.  Everything keeps its byte geometry: a 16-byte piece of a pixel row is 4
+// fp32 channels instead of 8 bf16 ones, so a chunk is 32 channels, a step 8, a fragment is still 1 KB and feeds four MFMAs per block
+// (k = 2 each: lane half h supplies channel 4h + j of the octet in step j).  Per 16 bytes loaded the fp32 MFMA runs 8x longer than
+// the bf16 one, so this variant is bound by the matrix pipe, not by the issue of loads.
+template <bool OUT16, int VAR = 0, int ABL = 0, int PT = 128, bool IN32 = false, bool F32 = false>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     constexpr bool FUSE = VAR >= 2, GNS = VAR == 1;
     static_assert(!IN32 || (!FUSE && ABL == 0), "fp32 input: the plain conv and the variant with GroupNorm sums");
+    static_assert(!F32 || (VAR == 0 && ABL == 0 && !IN32 && !OUT16), "exact-fp32 mode: the plain conv, fp32 in and out");
+    constexpr int PCK = F32 ? 32 : 64;                       // channels per chunk (128 bytes of a pixel row)
+    constexpr int ESZ = F32 ? 4 : 2, EPP = 16 / ESZ;         // element size, elements per 16-byte piece
     constexpr int BH = PT / 32;                              // rows per band = 32-pixel blocks per wave
     constexpr int PXBUF = pw_xp(PT) * 128;                   // one chunk of the activation tile
     constexpr int PXPW = pw_xp(PT) / 8 / 4;                  // activation DMA instructions per wave and chunk
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     const int TH2 = a.TH + 2;
     const int lw = 31 - __builtin_clz(a.W), lth = 31 - __builtin_clz(a.TH);      // W and TH are powers of two
     const int nchunks = a.K / PCK;
-    const int NB = a.Nc >> 5, KQ = a.K >> 4;
+    const int NB = a.Nc >> 5, KQ = a.K / (2 * EPP);              // fragments per (tap, 32-channel block): one per step
     const bool live = n0 + 32 * wv < a.Nc;                    // a ragged last channel tile: the wave computes a copy of the last block
     const int nb = min((n0 >> 5) + wv, NB - 1);
 
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     //      lane -> pixel lane >> 3, stored 16-byte position lane & 7 holds channel chunk (lane & 7) ^ ((hp >> 1) & 7)
     // ((hp >> 1) & 7 = (4 wv + (l >> 4)) & 7 for every piece of a wave: a lane always holds the same channel chunk)
     int xpix[PXPW];
-    const int xcol = ((l & 7) ^ ((4 * wv + (l >> 4)) & 7)) * 8;
+    const int xcol = ((l & 7) ^ ((4 * wv + (l >> 4)) & 7)) * EPP;
     int img0;
     {
         int y0;
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         asm volatile("" : "+v"(xp));                         // (opaque: the 64-bit row offsets are recomputed per chunk, not hoisted into six
         size_t off = (size_t)max(xp, 0) * ld + cc + xcol;    //  register pairs that end up in scratch)
         asm volatile("" : "+v"(off));
-        const uint16_t* p = xp >= 0 ? src + off : zero + (l & 7) * 8;
+        const uint8_t* p = xp >= 0 ? reinterpret_cast<const uint8_t*>(src) + off * ESZ : reinterpret_cast<const uint8_t*>(zero) + (l & 7) * 16;
         glds16(p, lds0 + (ch & 1) * PXBUF + (wv + 4 * i) * 1024);
     };
     // fp32 input: piece i of chunk ch -> the two registers of `dst` (8 channels of this lane's pixel), asynchronous
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     //      reads (global_load_dwordx4 with a scalar base per tap, issued from asm and counted by hand like the DMA).  The nine
     //      fragments of a 16-channel step are loaded during the step before (two register sets).
     const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(a.w) + (size_t)nb * KQ * 1024;
-    const uint32_t tap_bytes = (uint32_t)a.Nc * a.K * 2;
+    const uint32_t tap_bytes = (uint32_t)a.Nc * a.K * ESZ;
     const uint32_t wl16 = l * 16;
     uint64_t wtap[9];
 #pragma unroll
@@ -413,6 +421,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             if constexpr (FUSE && ks == 1) coef_landed();
             auto mm = [&](auto ic, auto tapc, const bf16x8& xf) {
                 constexpr int i = decltype(ic)::value, tp = decltype(tapc)::value;
+                if constexpr (F32) {
+                    const f32x4 wv4 = __builtin_bit_cast(f32x4, WB[cur][tp]), xv4 = __builtin_bit_cast(f32x4, xf);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv4[j], xv4[j], acc[i], 0, 0, 0);
+                } else
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WB[cur][tp]), xf, acc[i], 0, 0, 0);
             };
 #define MI_MM(I, KY, KX, XF) mm(std::integral_constant<int, I>{}, std::integral_constant<int, (KY) * 3 + (KX)>{}, XF)
@@ -616,24 +629,26 @@ bool pw_geom(const MiConvDesc* d, int pt, int* TH, int* TI) {
     return *TI * (*TH + 2) * W <= pw_xp(pt);
 }
 
-bool pw_ok(const MiConvDesc* d, int pt, int* TH, int* TI, bool in32 = false) {
-    if (d->KH != 3 || d->KW != 3 || d->pad != 1 || d->stride != 1 || d->mode != 1) return false;
+bool pw_ok(const MiConvDesc* d, int pt, int* TH, int* TI, bool in32 = false, bool f32 = false) {
+    if (d->KH != 3 || d->KW != 3 || d->pad != 1 || d->stride != 1 || d->mode != (f32 ? 0 : 1)) return false;
     if (d->IH != d->OH || d->IW != d->OW) return false;
-    const int lda = in32 ? 4 : 8;                            // 16-byte pieces of a pixel row
-    if (d->K % 64 || d->K1 % 64 || d->Nc % 32 || d->ldx % lda || (d->K1 != d->K && d->ldx2 % lda)) return false;
+    const int lda = (in32 || f32) ? 4 : 8;                   // 16-byte pieces of a pixel row
+    const int ck = f32 ? 32 : 64;                            // channels per chunk
+    // (K % 64, Nc % 64: the layers mi_pack_weights_bf16 / _f32frag write fragment-order copies for)
+    if (d->K % 64 || d->K1 % ck || d->Nc % 64 || d->ldx % lda || (d->K1 != d->K && d->ldx2 % lda)) return false;
     if (((long)d->N * d->OH * d->OW) % pt) return false;
-    if ((long)d->Nc * d->K * 2 * 9 >= (1L << 31)) return false;      // 32-bit fragment offsets
+    if ((long)d->Nc * d->K * (f32 ? 4 : 2) * 9 >= (1L << 31)) return false;      // 32-bit fragment offsets
     return pw_geom(d, pt, TH, TI);
 }
 // 64-pixel tiles where 128-pixel ones would leave CUs without a workgroup (and the geometry allows them)
 int g_pw_force_tile = 0;                 // tests: 0 = the rule below, 64 / 128 = that tile (or unsupported)
-int pw_pick_tile(const MiConvDesc* d, int var, int* TH, int* TI, bool in32 = false) {
-    if (in32 && var >= 2) return 0;
-    if (g_pw_force_tile == 64) return (var < 2 && pw_ok(d, 64, TH, TI, in32)) ? 64 : 0;
-    if (g_pw_force_tile == 128) return pw_ok(d, 128, TH, TI, in32) ? 128 : 0;
+int pw_pick_tile(const MiConvDesc* d, int var, int* TH, int* TI, bool in32 = false, bool f32 = false) {
+    if ((in32 && var >= 2) || (f32 && var != 0)) return 0;
+    if (g_pw_force_tile == 64) return (var < 2 && pw_ok(d, 64, TH, TI, in32, f32)) ? 64 : 0;
+    if (g_pw_force_tile == 128) return pw_ok(d, 128, TH, TI, in32, f32) ? 128 : 0;
     const long t128 = ((long)d->N * d->OH * d->OW / 128) * ((d->Nc + 127) / 128);
-    if (var < 2 && t128 < 200 && pw_ok(d, 64, TH, TI, in32)) return 64;
-    return pw_ok(d, 128, TH, TI, in32) ? 128 : 0;
+    if (var < 2 && t128 < 200 && pw_ok(d, 64, TH, TI, in32, f32)) return 64;
+    return pw_ok(d, 128, TH, TI, in32, f32) ? 128 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -797,7 +812,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
 bool pw1_ok(const MiConvDesc* d) {
     if (d->KH != 1 || d->KW != 1 || d->pad != 0 || d->stride != 1 || d->mode != 1) return false;
     if (d->IH != d->OH || d->IW != d->OW) return false;
-    if (d->K % 128 || d->K1 % 128 || d->K1 <= 0 || d->K1 > d->K || d->Nc % 32 || d->ldx % 8 || (d->K1 != d->K && d->ldx2 % 8)) return false;
+    if (d->K % 128 || d->K1 % 128 || d->K1 <= 0 || d->K1 > d->K || d->Nc % 64 || d->ldx % 8 || (d->K1 != d->K && d->ldx2 % 8)) return false;
     return ((long)d->N * d->OH * d->OW) % 128 == 0;
 }
 
@@ -805,10 +820,10 @@ struct PwGn { const float* sums; const float* gamma; const float* beta; const fl
 
 static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,
                      const float* residual, void* y, int out_bf16, int var, float* gsum, const float* coef, void* stream,
-                     const PwGn* gn = nullptr, bool in32 = false) {
+                     const PwGn* gn = nullptr, bool in32 = false, bool f32 = false) {
     PwArgs a{};
     if (!d || !x || !w_frag_bf16 || !y) return mi_set_error(-1, "%s: null argument", who);
-    const int pt = pw_pick_tile(d, var, &a.TH, &a.TI, in32);
+    const int pt = pw_pick_tile(d, var, &a.TH, &a.TI, in32, f32);
     if (!pt) return mi_set_error(-1, "%s: descriptor not supported by the private-weight-stream conv kernel", who);
     if (d->K1 != d->K && !x2) return mi_set_error(-1, "%s: two-source split without x2", who);
     if ((((uintptr_t)x | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)w_frag_bf16) & 15) != 0) return mi_set_error(-1, "%s: operands must be 16-byte aligned", who);
@@ -873,7 +888,15 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
         static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, 0, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
         (void)once_; \
         hipLaunchKernelGGL((conv_pw_kernel<O16, V, 0, T, true>), grid, dim3(256), lds, st, a); } while (0)
-    if (in32) {
+    if (f32) {
+#define MI_PW_GO_F(T) do { \
+        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<false, 0, 0, T, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
+        (void)once_; \
+        hipLaunchKernelGGL((conv_pw_kernel<false, 0, 0, T, false, true>), grid, dim3(256), lds, st, a); } while (0)
+        if (out_bf16) return mi_set_error(-1, "%s: the exact-fp32 kernel writes fp32", who);
+        if (pt == 64) MI_PW_GO_F(64); else MI_PW_GO_F(128);
+#undef MI_PW_GO_F
+    } else if (in32) {
         if (pt == 64) {
             if (var == 1) { if (out_bf16) MI_PW_GO_X(true, 1, 64); else MI_PW_GO_X(false, 1, 64); }
             else { if (out_bf16) MI_PW_GO_X(true, 0, 64); else MI_PW_GO_X(false, 0, 64); }
@@ -947,6 +970,69 @@ extern "C" int mi_conv3x3_pw_x32(const MiConvDesc* d, const float* x, const floa
                                  const float* residual, void* y, int out_bf16, float* gsum, void* stream) {
     return pw_launch(__func__, d, x, x2, w_frag_bf16, bias, residual, y, out_bf16, gsum ? 1 : 0, gsum, nullptr, stream, nullptr, true);
 }
+// ---- exact-fp32 mode (d->mode = 0): x / x2 / y fp32 (pixel strides in floats, % 4 == 0), w_frag_f32 = the layer's slice of
+//      mi_pack_weights_f32frag's wfq32 (forward) or wdq32 (d->transposed = 1: data gradient)
+extern "C" int mi_conv3x3_pw_f32_tile(const MiConvDesc* d) {
+    int th, ti;
+    return d ? pw_pick_tile(d, 0, &th, &ti, false, true) : 0;
+}
+extern "C" int mi_conv3x3_pw_f32(const MiConvDesc* d, const float* x, const float* x2, const float* w_frag_f32, const float* bias,
+                                 const float* residual, float* y, void* stream) {
+    return pw_launch(__func__, d, x, x2, w_frag_f32, bias, residual, y, 0, 0, nullptr, nullptr, stream, nullptr, false, true);
+}
+
+namespace {
+// fp32 fragment-order copies of the conv weights the table flags (3x3 and 1x1 layers with ci % 64 == 0 and co % 64 == 0), same offsets
+// as the master buffer [tap][ci][co]; one workgroup per 64 x 64 tile (the tile numbering of mi_pack_weights_bf16's table):
+//   wfq32[tap][co / 32][ci / 8][lane][4] = W[tap][ci = 8 ko + 4 (lane >> 5) + j][co = 32 nb + (lane & 31)]   (forward operand)
+//   wdq32[tap][ci / 32][co / 8][lane][4] = W[tap][ci = 32 nb + (lane & 31)][co = 8 ko + 4 (lane >> 5) + j]   (data-gradient operand)
+struct PackEntryF { long long off; int taps, ci, co, tile0, frag, pad_; };
+__global__ __launch_bounds__(256) void pack_f32frag_kernel(const PackEntryF* __restrict__ ents, int nent, const float* __restrict__ master,
+                                                           float* __restrict__ wdq, float* __restrict__ wfq) {
+    __shared__ float tile[64][65];
+    int e = 0;
+    for (int hi = nent; hi - e > 1;) {
+        const int mid = (e + hi) >> 1;
+        if ((int)blockIdx.x >= ents[mid].tile0) e = mid; else hi = mid;
+    }
+    const PackEntryF en = ents[e];
+    if (!en.frag) return;
+    const int local = blockIdx.x - en.tile0, tci = en.ci / 64, tco = en.co / 64;
+    const int tap = local / (tci * tco), rem = local - tap * (tci * tco), bi = rem / tco, bj = rem - bi * tco;
+    const size_t tapo = (size_t)en.off + (size_t)tap * en.ci * en.co;
+    const float* src = master + tapo;
+    const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r0 + 16 * p;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)(bi * 64 + r) * en.co + bj * 64 + c4);
+        tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+    }
+    __syncthreads();
+    const int l = threadIdx.x & 63;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int f = (threadIdx.x >> 6) + 4 * h;            // 16 fragments per order: (32-row block f >> 3, octet f & 7)
+        const int r32 = (f >> 3) * 32 + (l & 31), c4o = (f & 7) * 8 + 4 * (l >> 5);
+        *reinterpret_cast<f32x4*>(wdq + tapo + ((size_t)(bi * 2 + (f >> 3)) * (en.co / 8) + bj * 8 + (f & 7)) * 256 + l * 4) =
+            f32x4{tile[r32][c4o], tile[r32][c4o + 1], tile[r32][c4o + 2], tile[r32][c4o + 3]};
+        *reinterpret_cast<f32x4*>(wfq + tapo + ((size_t)(bj * 2 + (f >> 3)) * (en.ci / 8) + bi * 8 + (f & 7)) * 256 + l * 4) =
+            f32x4{tile[c4o][r32], tile[c4o + 1][r32], tile[c4o + 2][r32], tile[c4o + 3][r32]};
+    }
+}
+}  // namespace
+
+// entries_dev / total_tiles: mi_pack_weights_bf16's table; wdq32 / wfq32: fp32 buffers of the master buffer's size (16-byte aligned)
+extern "C" int mi_pack_weights_f32frag(int nent, const void* entries_dev, int total_tiles, const float* master, float* wdq32, float* wfq32,
+                                       void* stream) {
+    MI_REQUIRE(nent > 0 && entries_dev && total_tiles > 0 && master && wdq32 && wfq32, "bad argument");
+    MI_REQUIRE((((uintptr_t)wdq32 | (uintptr_t)wfq32 | (uintptr_t)master) & 15) == 0, "buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(pack_f32frag_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const PackEntryF*)entries_dev, nent, master,
+                       wdq32, wfq32);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
 // BASELINE.json's named kernel on this structure: y = conv3x3(mish(x * scale + shift) + tb) + bias, x the RAW bf16 output of the
 // previous conv, coef [3][N][K] = scale, shift, tb (mi_gn_coef_from_sums / mi_gn_stats_coef)
 extern "C" int mi_conv3x3_pw_gn_mish(const MiConvDesc* d, const void* x, const float* coef, const void* w_frag_bf16, const float* bias,

@@ -281,6 +281,8 @@ class Unet(nn.Module):
         object.__setattr__(self, "_dirty", 0)
         object.__setattr__(self, "_shadow", None)
         object.__setattr__(self, "_shadow_key", None)
+        object.__setattr__(self, "_shadow32", None)
+        object.__setattr__(self, "_shadow32_key", None)
         object.__setattr__(self, "_anchor", torch.zeros(1, requires_grad=True))
         # module tree in the reference's registration order (time_mlp, downs, ups, mid_*, final_conv)
         self._plist: List[Tuple[_Entry, nn.Parameter]] = []
@@ -306,6 +308,7 @@ class Unet(nn.Module):
         object.__setattr__(self, "_sv", sv)
         object.__setattr__(self, "_offs", {e.key: e.offset for e, _ in self._plist})
         object.__setattr__(self, "_shadow_key", None)
+        object.__setattr__(self, "_shadow32_key", None)
         g = self._gflat
         if g is not None and (g.device != flat.device or g.dtype != flat.dtype):
             object.__setattr__(self, "_gflat", None)
@@ -349,6 +352,26 @@ class Unet(nn.Module):
             K.pack_weights_bf16(table, nent, tiles, flat, wd, wf, wdq, wfq)
             object.__setattr__(self, "_shadow_key", key)
         return self._shadow[:4]
+
+    def _shadows32(self):
+        """fp32 mode: fragment-order fp32 copies (data-gradient, forward operand) of the 3x3 / 1x1 conv weights for
+        mi_conv3x3_pw_f32, rebuilt by one launch whenever the master buffer changed (the table is the bf16 pack's)."""
+        flat = self._flat
+        key = (flat.data_ptr(), flat._version, self._dirty)
+        if getattr(self, "_shadow32_key", None) != key:
+            if getattr(self, "_shadow32", None) is None or self._shadow32[0].device != flat.device:
+                ents = []
+                for e in self._arch.entries:
+                    if e.layout in ("conv", "convT"):
+                        kh, kw, ci, co = e.storage_view(flat).shape
+                        ents.append((e.offset, kh * kw, ci, co))
+                table, nent, tiles = K.pack_table(ents, flat.device)
+                bufs = [torch.zeros(flat.numel(), device=flat.device, dtype=torch.float32) for _ in range(2)]
+                object.__setattr__(self, "_shadow32", (*bufs, table, nent, tiles))
+            wdq32, wfq32, table, nent, tiles = self._shadow32
+            K.pack_weights_f32frag(table, nent, tiles, flat, wdq32, wfq32)
+            object.__setattr__(self, "_shadow32_key", key)
+        return self._shadow32[:2]
 
     @property
     def flat_grads(self) -> torch.Tensor:
@@ -448,6 +471,8 @@ class Unet(nn.Module):
 
         if mode == K.MODE_BF16:
             wd_sh, wf_sh, wdq_sh, wfq_sh = self._shadows()
+        else:
+            wdq32_sh, wfq32_sh = self._shadows32()
         offs = self._offs
 
         BF = torch.bfloat16
@@ -503,6 +528,11 @@ class Unet(nn.Module):
                     return y
             assert not want16, "the bf16 copy rides in the tile kernel's epilogue only"
             assert gn_sums is None, "GroupNorm sums ride in the tile kernel's epilogue only"
+            if mode == K.MODE_FP32 and k == 3 and stride == 1 and not transposed_conv and out_dtype == torch.float32:
+                y = K.conv3x3_f32(inp, wfq32_sh[offs[pre + "weight"]:], K=ci, Nc=co, flip=False, x2=x2,
+                                  bias=sv[pre + "bias"] if bias else None, residual=residual)
+                if y is not None:
+                    return y
             ih, iw = inp.shape[1], inp.shape[2]
             if transposed_conv:
                 oh, ow = ih * stride, iw * stride
@@ -661,6 +691,8 @@ class Unet(nn.Module):
         offs = self._offs
         if mode == K.MODE_BF16:
             wd_sh, wf_sh, wdq_sh, wfq_sh = self._shadows()
+        else:
+            wdq32_sh, wfq32_sh = self._shadows32()
         G = _GradMap()
         # data parallel (a grad-ready hook is set): the two Upsample layers come early in backward, the two Downsample layers last; with
         # all four in one launch at the very end their 8 MB of gradients would be all-reduced after backward, exposed -- two per launch
@@ -740,6 +772,9 @@ class Unet(nn.Module):
                 if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, ksize=k, out=buf,
                                             accumulate=acc, wq=wdq_sh[offs[pre + "weight"]:]) is not None:
                     return
+                if (mode == K.MODE_FP32 and k == 3 and stride == 1 and not transposed_conv and buf.dtype == torch.float32
+                        and K.conv3x3_f32(dy, wdq32_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, out=buf, accumulate=acc) is not None):
+                    return
                 assert dy.dtype == torch.float32 and buf.dtype == torch.float32, "bf16 block storage needs the tile kernel"
                 if dy16 is not None and K.igemm_bf16_in_supported(co, ci, k, stride, not transposed_conv, mode, (ih, iw)):
                     dy = dy16                                         # the copy the weight gradient reads: half the bytes, 64-channel stages
@@ -755,6 +790,9 @@ class Unet(nn.Module):
                     G._g[("cat", id(inp))] = cat
                 if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, ksize=k, out=cat,
                                             accumulate=acc, wq=wdq_sh[offs[pre + "weight"]:]) is not None:
+                    return
+                if (mode == K.MODE_FP32 and k == 3 and stride == 1 and not transposed_conv
+                        and K.conv3x3_f32(dy, wdq32_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, out=cat, accumulate=acc) is not None):
                     return
                 K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=True, w_kn=False,
                              K=co, Nc=ci, out_hw=(ih, iw), mode=mode, out=cat, accumulate=acc)

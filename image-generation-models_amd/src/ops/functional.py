@@ -491,6 +491,45 @@ def pack_weights_bf16(table_dev, nent, total_tiles, master, wd, wf, wdq=None, wf
         _probe_close(e0, "pack_weights_kernel", 0.0, f"{master.numel()} params", master.numel() * (8.0 if wdq is None else 12.0))
 
 
+def pack_weights_f32frag(table_dev, nent, total_tiles, master, wdq32, wfq32):
+    """fp32 fragment-order copies (forward / data-gradient operand of mi_conv3x3_pw_f32) of the entries pack_table flags."""
+    e0 = _probe_open()
+    check(load_library().mi_pack_weights_f32frag(nent, _p(table_dev), total_tiles, _p(master), _p(wdq32), _p(wfq32), _stream()),
+          "mi_pack_weights_f32frag")
+    if e0 is not None:
+        _probe_close(e0, "pack_f32frag_kernel", 0.0, f"{master.numel()} params", master.numel() * 12.0)
+
+
+def conv3x3_f32(x, wq32, *, K, Nc, flip, x2=None, bias=None, residual=None, out=None, accumulate=False):
+    """3x3/s1/p1 conv (flip=False) or its data gradient (flip=True) in exact-fp32 mode through the private-weight-stream kernel on
+    v_mfma_f32_32x32x2_f32 (mi_conv3x3_pw_f32).  wq32: the layer's slice of the fp32 fragment-order copy.  None: not supported."""
+    _need_gpu(x)
+    if x.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32) or not USE_CONV_PW:
+        return None
+    N, H, W, K1 = x.shape
+    if x2 is None:
+        K1 = K
+    d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=int(flip),
+                   w_kn=0, mode=MODE_FP32, K1=K1, ldx=ld_of(x), ldx2=ld_of(x2) if x2 is not None else 0, ldy=Nc,
+                   ldr=ld_of(residual) if residual is not None else 0, accumulate=int(accumulate))
+    pt = _query("mi_conv3x3_pw_f32_tile", d)
+    if not pt:
+        return None
+    if out is None:
+        assert not accumulate
+        out = new_act(N, H, W, Nc, x, torch.float32)
+    d.ldy = ld_of(out)
+    if d.ldy % 8:
+        return None
+    e0 = _probe_open()
+    check(load_library().mi_conv3x3_pw_f32(C.byref(d), _p(x), _p(x2), _p(wq32), _p(bias), _p(residual), _p(out), _stream()), "mi_conv3x3_pw_f32")
+    if e0 is not None:
+        nb = (N * H * W * K * 4 + N * H * W * Nc * (4 * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 4)
+        _probe_close(e0, f"conv_pw_kernel<false, 0, 0, {pt}, false, true>", 2.0 * N * H * W * Nc * K * 9,
+                     f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} fp32 flip{int(flip)} acc{int(accumulate)}", nb)
+    return out
+
+
 def small_cin_supported(ks, Cin, Cout, wgrad=False):
     """The 3-channel-input kernels (mi_conv_small_cin_*): which (kernel size, Cin, Cout) they take."""
     if ks not in (1, 3) or not 1 <= Cin <= 4:

@@ -168,6 +168,15 @@ int mi_conv3x3_pw_x32_supported(const MiConvDesc* d);
 int mi_conv3x3_pw_x32_tile(const MiConvDesc* d);
 int mi_conv3x3_pw_x32(const MiConvDesc* d, const float* x, const float* x2, const void* w_frag_bf16, const float* bias,
                       const float* residual, void* y, int out_bf16, float* gsum, void* stream);
+/* ... and in exact-fp32 mode (d->mode = 0; Unet.compute_mode = "fp32", the reference's default precision): the same kernel on
+ * v_mfma_f32_32x32x2_f32 with fp32 x / x2 / y and fp32 weights in fragment order, written by mi_pack_weights_f32frag from the table
+ * of mi_pack_weights_bf16:  wfq32[tap][co/32][ci/8][lane][4] = W[tap][ci = 8 ko + 4 (lane >> 5) + j][co = 32 nb + (lane & 31)],
+ * wdq32[tap][ci/32][co/8][lane][4] = W[tap][ci = 32 nb + (lane & 31)][co = 8 ko + 4 (lane >> 5) + j].  K % 32 == 0, K1 % 32 == 0. */
+int mi_conv3x3_pw_f32_tile(const MiConvDesc* d);
+int mi_conv3x3_pw_f32(const MiConvDesc* d, const float* x, const float* x2, const float* w_frag_f32, const float* bias,
+                      const float* residual, float* y, void* stream);
+int mi_pack_weights_f32frag(int nent, const void* entries_dev, int total_tiles, const float* master, float* wdq32, float* wfq32,
+                            void* stream);
 int mi_debug_conv_pw_tile(int pt);               /* tests: force the pixel tile (64 / 128), 0 = automatic */
 int mi_conv3x3_pw_tile(const MiConvDesc* d);      /* pixels per workgroup the launch would use: 128, or 64 for small grids; 0 = unsupported */
 int mi_conv3x3_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,

@@ -770,6 +770,48 @@ def test_conv3x3_pw_fp32_input(K, cfg, out16, pw_always, pw_tile):
         assert torch.equal(s32, s32b)                                      # the same kernel twice: bitwise
 
 
+@pytest.mark.parametrize("cfg", [dict(N=2, H=32, Ci=128, Co=128), dict(N=4, H=16, Ci=256, Co=128, split=128), dict(N=16, H=8, Ci=512, Co=256),
+                                 dict(N=6, H=8, Ci=192, Co=320), dict(N=8, H=32, Ci=64, Co=64), dict(N=2, H=16, Ci=96, Co=64)])
+def test_conv3x3_pw_f32_fwd_and_dgrad(K, cfg, pw_always, pw_tile):
+    """Exact-fp32 mode of the private-weight-stream conv (mi_conv3x3_pw_f32 on v_mfma_f32_32x32x2_f32, fp32 fragment-order weights from
+    mi_pack_weights_f32frag): Block's 3x3 conv (ddpm.py:116) and its data gradient, two sources, bias, residual, accumulate, both tile
+    sizes, against fp64 -- the fp32 mode's bar (<= 1e-5; the contraction is an fp32 fma chain) -- and the fragment layout itself."""
+    N, H, Ci, Co = cfg["N"], cfg["H"], cfg["Ci"], cfg["Co"]
+    split = cfg.get("split")
+    g = torch.Generator().manual_seed(101)
+    x = torch.randn(N, Ci, H, H, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)
+    b = torch.randn(Co, generator=g); r = torch.randn(N, Co, H, H, generator=g); dy = torch.randn(N, Co, H, H, generator=g)
+    xq = x.double().requires_grad_(True)
+    yq = F.conv2d(xq, w.double(), b.double(), padding=1) + r.double()
+    yq.backward(dy.double())
+    ws = conv_w_storage(w.double()).float().to(DEV)                    # [3][3][Ci][Co]
+    flat = torch.zeros((ws.numel() + 63) // 64 * 64, device=DEV); flat[:ws.numel()] = ws.reshape(-1)
+    table, nent, tiles = K.pack_table([(0, 9, Ci, Co)], DEV)
+    wdq32, wfq32 = torch.zeros_like(flat), torch.zeros_like(flat)
+    K.pack_weights_f32frag(table, nent, tiles, flat, wdq32, wfq32)
+    if Ci % 64 == 0 and Co % 64 == 0:
+        wb = ws.view(9, Ci, Co)
+        fq = wfq32[:ws.numel()].view(9, Co // 32, Ci // 8, 2, 32, 4)       # [tap][nb][ko][l >> 5][l & 31][j]
+        assert torch.equal(fq, wb.permute(0, 2, 1).reshape(9, Co // 32, 32, Ci // 8, 2, 4).permute(0, 1, 3, 4, 2, 5).contiguous())
+        dq = wdq32[:ws.numel()].view(9, Ci // 32, Co // 8, 2, 32, 4)
+        assert torch.equal(dq, wb.reshape(9, Ci // 32, 32, Co // 8, 2, 4).permute(0, 1, 3, 4, 2, 5).contiguous())
+    else:
+        assert not wfq32.any()                                              # not flagged: no fragment copy, and the host layer refuses
+        assert K.conv3x3_f32(torch.zeros(N, H, H, Ci, device=DEV), wfq32, K=Ci, Nc=Co, flip=False) is None
+        return
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+    xa, xb = (nh(x[:, :split]), nh(x[:, split:])) if split else (nh(x), None)
+    yg = K.conv3x3_f32(xa, wfq32, K=Ci, Nc=Co, flip=False, x2=xb, bias=b.to(DEV), residual=to_nhwc_gpu(r))
+    dxg = K.conv3x3_f32(nh(dy), wdq32, K=Co, Nc=Ci, flip=True)
+    assert yg is not None and dxg is not None
+    assert _conv_launches(pw_always)[-2:] == [f"conv_pw_kernel<false, 0, 0, {pw_tile}, false, true>"] * 2
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(yg), yq) < 2e-6 and rel_err(from_nhwc(dxg), xq.grad) < 2e-6
+    dx2 = K.conv3x3_f32(nh(dy), wdq32, K=Co, Nc=Ci, flip=True, out=dxg.clone(), accumulate=True)
+    assert rel_err(from_nhwc(dx2), 2 * xq.grad) < 2e-6
+
+
 def test_pack_weights_fragment_order(K):
     """The MFMA-fragment-order copies mi_conv3x3_pw streams (include/mi_ddpm.h): wfq[tap][co/32][ci/16][lane][8] and
     wdq[tap][ci/32][co/16][lane][8] for the 3x3 and 1x1 layers with 64-multiples on both sides; the others get none (zero slice)."""
