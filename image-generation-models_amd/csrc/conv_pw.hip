@@ -665,8 +665,11 @@ struct Pw1Args {
     int M, K, K1, Nc, ldx, ldx2, ldy, ldr, ldy16, accumulate, gx, gy;
 };
 
-template <bool OUT16, bool DUAL, int PXT>
+// F32: exact-fp32 mode (see conv_pw_kernel): fp32 x / y, fp32 fragment-order weights, v_mfma_f32_32x32x2_f32; a chunk is 64 channels.
+template <bool OUT16, bool DUAL, int PXT, bool F32 = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
+    static_assert(!F32 || (!OUT16 && !DUAL), "exact-fp32 mode writes fp32");
+    constexpr int ESZ = F32 ? 4 : 2, EPP = 16 / ESZ, CKC = 16 * EPP;       // element size, elements per 16-byte piece, channels per chunk
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
     constexpr int NBLK = PXT / 32;                   // 32-pixel MFMA blocks per wave
@@ -682,22 +685,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
         bx = xcd * (a.gx >> 3) + slot / a.gy; by = slot % a.gy;
     }
     const int m0 = bx * PXT, n0 = by * 128;
-    const int NB = a.Nc >> 5, KQ = a.K >> 4, nchunks = a.K >> 7;
+    const int NB = a.Nc >> 5, KQ = a.K / (2 * EPP), nchunks = a.K / CKC;
     const bool live = n0 + 32 * wv < a.Nc;
     const int nb = min((n0 >> 5) + wv, NB - 1);
 
     // activation pieces of chunk ch -> buffer ch & 1: piece p = wv + 4i = pixels 8 (p % (PXT / 8)) .. +7 of half p / (PXT / 8); lane ->
     // pixel l >> 3, stored 16-byte position l & 7 holds channel chunk (l & 7) ^ ((pixel >> 1) & 7)
     auto stage_x = [&](int ch) {
-        const int c0 = min(ch, nchunks - 1) * 128;
+        const int c0 = min(ch, nchunks - 1) * CKC;
         const bool second = c0 >= a.K1;
-        const uint16_t* src = second ? a.x2 : a.x;
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(second ? a.x2 : a.x);
         const int ld = second ? a.ldx2 : a.ldx, cc = second ? c0 - a.K1 : c0;
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
             const int p = wv + 4 * i, half = p / (PXT / 8), px = 8 * (p % (PXT / 8)) + (l >> 3);
-            const int col = cc + half * 64 + ((l & 7) ^ ((px >> 1) & 7)) * 8;
-            glds16(src + (size_t)(m0 + px) * ld + col, lds0 + (ch & 1) * XB + half * XH + (p % (PXT / 8)) * 1024);
+            const int col = cc + half * (CKC / 2) + ((l & 7) ^ ((px >> 1) & 7)) * EPP;
+            glds16(src + ((size_t)(m0 + px) * ld + col) * ESZ, lds0 + (ch & 1) * XB + half * XH + (p % (PXT / 8)) * 1024);
         }
     };
     // weight fragments (nb, kq = 8 ch .. 8 ch + 7): 8 KB contiguous
@@ -749,8 +752,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
                 for (int i = 0; i < NBLK; ++i) XC[un & 1][i] = lds_b128p((xa[i] ^ ((un & 3) * 32)) + (un >> 2) * XH + xb);
             }
 #pragma unroll
-            for (int i = 0; i < NBLK; ++i)
+            for (int i = 0; i < NBLK; ++i) {
+                if constexpr (F32) {
+                    const f32x4 wv4 = __builtin_bit_cast(f32x4, WB[set][u]), xv4 = __builtin_bit_cast(f32x4, XC[u & 1][i]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv4[j], xv4[j], acc[i], 0, 0, 0);
+                } else
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WB[set][u]), XC[u & 1][i], acc[i], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -809,7 +818,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
     }
 }
 
-bool pw1_ok(const MiConvDesc* d) {
+bool pw1_ok(const MiConvDesc* d, bool f32 = false) {
+    if (f32) {
+        if (d->KH != 1 || d->KW != 1 || d->pad != 0 || d->stride != 1 || d->mode != 0 || d->IH != d->OH || d->IW != d->OW) return false;
+        if (d->K % 64 || d->K1 % 64 || d->K1 <= 0 || d->K1 > d->K || d->Nc % 64 || d->ldx % 4 || (d->K1 != d->K && d->ldx2 % 4)) return false;
+        return ((long)d->N * d->OH * d->OW) % 128 == 0;
+    }
     if (d->KH != 1 || d->KW != 1 || d->pad != 0 || d->stride != 1 || d->mode != 1) return false;
     if (d->IH != d->OH || d->IW != d->OW) return false;
     if (d->K % 128 || d->K1 % 128 || d->K1 <= 0 || d->K1 > d->K || d->Nc % 64 || d->ldx % 8 || (d->K1 != d->K && d->ldx2 % 8)) return false;
@@ -1052,6 +1066,36 @@ extern "C" int mi_conv3x3_pw_gn_mish_sums(const MiConvDesc* d, const void* x, co
 // ---- 1x1 convs with K % 128 == 0 (see conv1x1_pw_kernel): w_frag_bf16 = the layer's slice of wfq (d->transposed = 0) or wdq (data
 //      gradient); x2: second source of a two-source layer (channels K1 .. K - 1, d->K1 % 128 == 0), else null
 extern "C" int mi_conv1x1_pw_supported(const MiConvDesc* d) { return (d && pw1_ok(d)) ? 1 : 0; }
+// exact-fp32 mode (d->mode = 0): x / x2 / y fp32, w_frag_f32 from mi_pack_weights_f32frag; K % 64 == 0, K1 % 64 == 0
+extern "C" int mi_conv1x1_pw_f32_supported(const MiConvDesc* d) { return (d && pw1_ok(d, true)) ? 1 : 0; }
+extern "C" int mi_conv1x1_pw_f32(const MiConvDesc* d, const float* x, const float* x2, const float* w_frag_f32, const float* bias,
+                                 const float* residual, float* y, void* stream) {
+    MI_REQUIRE(d && x && w_frag_f32 && y, "null argument");
+    MI_REQUIRE(pw1_ok(d, true), "descriptor not supported (1x1, fp32 mode, K and K1 % 64 == 0, Nc % 64 == 0, N*H*W % 128 == 0)");
+    MI_REQUIRE(d->K1 == d->K || x2, "two-source split without x2");
+    MI_REQUIRE((((uintptr_t)x | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)w_frag_f32) & 15) == 0, "operands must be 16-byte aligned");
+    MI_REQUIRE(d->ldy % 8 == 0 && (!residual || d->ldr % 4 == 0), "pixel strides: y % 8, residual % 4");
+    Pw1Args a{};
+    a.x = (const uint16_t*)x; a.x2 = (const uint16_t*)(x2 ? x2 : x); a.w = (const uint16_t*)w_frag_f32; a.bias = bias; a.res = residual;
+    a.y = y; a.y16 = nullptr;
+    a.M = d->N * d->OH * d->OW; a.K = d->K; a.K1 = d->K1; a.Nc = d->Nc; a.ldx = d->ldx; a.ldx2 = x2 ? d->ldx2 : d->ldx;
+    a.ldy = d->ldy; a.ldr = d->ldr; a.ldy16 = 0; a.accumulate = d->accumulate;
+    a.gy = (d->Nc + 127) / 128;
+    const bool small = (long)(a.M / 128) * a.gy < 256;
+    a.gx = a.M / (small ? 64 : 128);
+    dim3 grid((unsigned)a.gx, (unsigned)a.gy);
+    if (a.gy > 1 && a.gx % 8 == 0) grid = dim3((unsigned)(a.gx * a.gy), 1, 1);
+    hipStream_t st = (hipStream_t)stream;
+    static bool once_ = [] {
+        (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<false, false, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<false, false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        return true; }();
+    (void)once_;
+    if (small) hipLaunchKernelGGL((conv1x1_pw_kernel<false, false, 64, true>), grid, dim3(256), 64 * 1024, st, a);
+    else hipLaunchKernelGGL((conv1x1_pw_kernel<false, false, 128, true>), grid, dim3(256), 64 * 1024, st, a);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
 // y fp32 or bf16 (out_bf16); y_bf16 (optional, fp32 y only): the bf16 copy of y written by the same epilogue, pixel stride ldy16
 extern "C" int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias, const float* residual,
                              void* y, int out_bf16, void* y_bf16, int ldy16, void* stream) {

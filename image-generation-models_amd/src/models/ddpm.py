@@ -533,6 +533,11 @@ class Unet(nn.Module):
                                   bias=sv[pre + "bias"] if bias else None, residual=residual)
                 if y is not None:
                     return y
+            if mode == K.MODE_FP32 and k == 1 and stride == 1 and not transposed_conv and out_dtype == torch.float32:
+                y = K.conv1x1_f32(inp, wfq32_sh[offs[pre + "weight"]:], K=ci, Nc=co, flip=False, x2=x2,
+                                  bias=sv[pre + "bias"] if bias else None, residual=residual)
+                if y is not None:
+                    return y
             ih, iw = inp.shape[1], inp.shape[2]
             if transposed_conv:
                 oh, ow = ih * stride, iw * stride
@@ -772,8 +777,9 @@ class Unet(nn.Module):
                 if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, ksize=k, out=buf,
                                             accumulate=acc, wq=wdq_sh[offs[pre + "weight"]:]) is not None:
                     return
-                if (mode == K.MODE_FP32 and k == 3 and stride == 1 and not transposed_conv and buf.dtype == torch.float32
-                        and K.conv3x3_f32(dy, wdq32_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, out=buf, accumulate=acc) is not None):
+                if (mode == K.MODE_FP32 and k in (1, 3) and stride == 1 and not transposed_conv and buf.dtype == torch.float32
+                        and (K.conv3x3_f32 if k == 3 else K.conv1x1_f32)(dy, wdq32_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, out=buf,
+                                                                          accumulate=acc) is not None):
                     return
                 assert dy.dtype == torch.float32 and buf.dtype == torch.float32, "bf16 block storage needs the tile kernel"
                 if dy16 is not None and K.igemm_bf16_in_supported(co, ci, k, stride, not transposed_conv, mode, (ih, iw)):
@@ -791,8 +797,9 @@ class Unet(nn.Module):
                 if fast and K.conv3x3_bf16w(dy, wd_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, ksize=k, out=cat,
                                             accumulate=acc, wq=wdq_sh[offs[pre + "weight"]:]) is not None:
                     return
-                if (mode == K.MODE_FP32 and k == 3 and stride == 1 and not transposed_conv
-                        and K.conv3x3_f32(dy, wdq32_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, out=cat, accumulate=acc) is not None):
+                if (mode == K.MODE_FP32 and k in (1, 3) and stride == 1 and not transposed_conv
+                        and (K.conv3x3_f32 if k == 3 else K.conv1x1_f32)(dy, wdq32_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, out=cat,
+                                                                          accumulate=acc) is not None):
                     return
                 K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=True, w_kn=False,
                              K=co, Nc=ci, out_hw=(ih, iw), mode=mode, out=cat, accumulate=acc)

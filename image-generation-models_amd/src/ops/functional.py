@@ -530,6 +530,36 @@ def conv3x3_f32(x, wq32, *, K, Nc, flip, x2=None, bias=None, residual=None, out=
     return out
 
 
+def conv1x1_f32(x, wq32, *, K, Nc, flip, x2=None, bias=None, residual=None, out=None, accumulate=False):
+    """1x1 conv (flip=False) or its data gradient (flip=True) in exact-fp32 mode through the streaming kernel (mi_conv1x1_pw_f32).
+    None: not supported."""
+    _need_gpu(x)
+    if x.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32) or not USE_CONV_PW:
+        return None
+    N, H, W, K1 = x.shape
+    if x2 is None:
+        K1 = K
+    d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=1, KW=1, stride=1, pad=0, transposed=int(flip),
+                   w_kn=0, mode=MODE_FP32, K1=K1, ldx=ld_of(x), ldx2=ld_of(x2) if x2 is not None else 0, ldy=Nc,
+                   ldr=ld_of(residual) if residual is not None else 0, accumulate=int(accumulate))
+    if not _query("mi_conv1x1_pw_f32_supported", d):
+        return None
+    if out is None:
+        assert not accumulate
+        out = new_act(N, H, W, Nc, x, torch.float32)
+    d.ldy = ld_of(out)
+    if d.ldy % 8 or (residual is not None and d.ldr % 4):
+        return None
+    e0 = _probe_open()
+    check(load_library().mi_conv1x1_pw_f32(C.byref(d), _p(x), _p(x2), _p(wq32), _p(bias), _p(residual), _p(out), _stream()), "mi_conv1x1_pw_f32")
+    if e0 is not None:
+        nb = (N * H * W * K * 4 + N * H * W * Nc * (4 * (2 if accumulate else 1) + _esz(residual)) + K * Nc * 4)
+        px = 64 if (N * H * W // 128) * ((Nc + 127) // 128) < 256 else 128
+        _probe_close(e0, f"conv1x1_pw_kernel<false, false, {px}, true>", 2.0 * N * H * W * Nc * K,
+                     f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} fp32 flip{int(flip)} acc{int(accumulate)}", nb)
+    return out
+
+
 def small_cin_supported(ks, Cin, Cout, wgrad=False):
     """The 3-channel-input kernels (mi_conv_small_cin_*): which (kernel size, Cin, Cout) they take."""
     if ks not in (1, 3) or not 1 <= Cin <= 4:

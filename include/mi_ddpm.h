@@ -175,6 +175,9 @@ int mi_conv3x3_pw_x32(const MiConvDesc* d, const float* x, const float* x2, cons
 int mi_conv3x3_pw_f32_tile(const MiConvDesc* d);
 int mi_conv3x3_pw_f32(const MiConvDesc* d, const float* x, const float* x2, const float* w_frag_f32, const float* bias,
                       const float* residual, float* y, void* stream);
+int mi_conv1x1_pw_f32_supported(const MiConvDesc* d);     /* the 1x1 convs in exact-fp32 mode: K % 64 == 0, K1 % 64 == 0, Nc % 64 == 0 */
+int mi_conv1x1_pw_f32(const MiConvDesc* d, const float* x, const float* x2, const float* w_frag_f32, const float* bias,
+                      const float* residual, float* y, void* stream);
 int mi_pack_weights_f32frag(int nent, const void* entries_dev, int total_tiles, const float* master, float* wdq32, float* wfq32,
                             void* stream);
 int mi_debug_conv_pw_tile(int pt);               /* tests: force the pixel tile (64 / 128), 0 = automatic */

@@ -812,6 +812,39 @@ def test_conv3x3_pw_f32_fwd_and_dgrad(K, cfg, pw_always, pw_tile):
     assert rel_err(from_nhwc(dx2), 2 * xq.grad) < 2e-6
 
 
+@pytest.mark.parametrize("cfg", [dict(N=8, H=32, Ci=128, Co=384), dict(N=16, H=8, Ci=512, Co=384), dict(N=8, H=8, Ci=1024, Co=256, split=512),
+                                 dict(N=4, H=16, Ci=64, Co=128), dict(N=64, H=16, Ci=384, Co=128, dgrad=True), dict(N=2, H=16, Ci=192, Co=64)])
+def test_conv1x1_pw_f32(K, cfg, pw_always):
+    """The 1x1 convs in exact-fp32 mode (mi_conv1x1_pw_f32): to_qkv / to_out / res_conv shapes (reference ddpm.py:134,151-152), two
+    sources, bias + residual, the data gradient with accumulate; against fp64 at the fp32 mode's bar."""
+    N, H, Ci, Co = cfg["N"], cfg["H"], cfg["Ci"], cfg["Co"]
+    split = cfg.get("split")
+    g = torch.Generator().manual_seed(103)
+    x = torch.randn(N, Ci, H, H, generator=g)
+    w = torch.randn(Co, Ci, 1, 1, generator=g) / math.sqrt(Ci)
+    b = torch.randn(Co, generator=g); r = torch.randn(N, Co, H, H, generator=g)
+    ws = conv_w_storage(w.double()).float().to(DEV)                    # [1][1][Ci][Co]
+    flat = torch.zeros((ws.numel() + 63) // 64 * 64, device=DEV); flat[:ws.numel()] = ws.reshape(-1)
+    table, nent, tiles = K.pack_table([(0, 1, Ci, Co)], DEV)
+    wdq32, wfq32 = torch.zeros_like(flat), torch.zeros_like(flat)
+    K.pack_weights_f32frag(table, nent, tiles, flat, wdq32, wfq32)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+    if cfg.get("dgrad"):
+        dy = torch.randn(N, Co, H, H, generator=g)
+        prev = torch.randn(N, H, H, Ci, generator=g).to(DEV)
+        ref = F.conv_transpose2d(dy.double(), w.double()) + prev.cpu().permute(0, 3, 1, 2).double()
+        out = K.conv1x1_f32(nh(dy), wdq32, K=Co, Nc=Ci, flip=True, out=prev.clone(), accumulate=True)
+        torch.cuda.synchronize()
+        assert out is not None and rel_err(from_nhwc(out), ref) < 2e-6
+    else:
+        ref = F.conv2d(x.double(), w.double(), b.double()) + r.double()
+        xa, xb = (nh(x[:, :split]), nh(x[:, split:])) if split else (nh(x), None)
+        y = K.conv1x1_f32(xa, wfq32, K=Ci, Nc=Co, flip=False, x2=xb, bias=b.to(DEV), residual=to_nhwc_gpu(r))
+        torch.cuda.synchronize()
+        assert y is not None and rel_err(from_nhwc(y), ref) < 2e-6
+    assert _conv_launches(pw_always)[-1].startswith("conv1x1_pw_kernel<false, false,") and _conv_launches(pw_always)[-1].endswith(", true>")
+
+
 def test_pack_weights_fragment_order(K):
     """The MFMA-fragment-order copies mi_conv3x3_pw streams (include/mi_ddpm.h): wfq[tap][co/32][ci/16][lane][8] and
     wdq[tap][ci/32][co/16][lane][8] for the 3x3 and 1x1 layers with 64-multiples on both sides; the others get none (zero slice)."""
