@@ -2,7 +2,7 @@
 //     Y[p][co] (+)= bias[co] + res[p][co] + sum_{ky,kx,ci} X[p + (ky-1, kx-1)][ci] * W[ky][kx][co][ci]
 // (Block's Conv2d(dim, dim_out, 3, padding=1), reference src/models/ddpm.py:116, and its input gradient.)
 //
-// What bounded conv3x3_halo.hip / conv_dma.hip / conv_shift.hip: every tap (16 MFMAs per wave) ended in a
+// What bounded conv3x3_halo.hip and round 2's conv_dma / conv_shift experiments (since removed): every tap (16 MFMAs per wave) ended in a
 // workgroup barrier because the weight tile of a tap is shared by the waves of a workgroup, and a tile's prologue (its first
 // activation rows arriving from HBM) and epilogue (its output stores) overlapped nothing: one workgroup per CU.  Here
 //   * a workgroup = 4 waves = 128 output pixels (whole image rows) x 128 output channels; wave w owns ALL 128 pixels of the
@@ -15,7 +15,7 @@
 //     64-channel chunk (LDS-DMA): ONE barrier per chunk (144 MFMAs per wave) instead of nine;
 //   * a 32-pixel MFMA block is output row i of every 4-row band of the tile, so "tap row ky of output row i" is "halo row i + ky":
 //     ONE activation fragment per halo row serves the three tap rows, and only the centre tap column is read from LDS -- the left /
-//     right columns are one-lane DPP shifts of it (conv_shift.hip), made once per halo row: per 16-channel step 6 LDS fragment
+//     right columns are one-lane DPP shifts of it (first tried in round 2's conv_shift kernel), made once per halo row: per 16-channel step 6 LDS fragment
 //     reads and 12 shifts feed 36 MFMAs;
 //   * 66 KB of LDS and <= 256 registers per lane: two workgroups per CU -- one computes while the other waits for its first rows or
 //     drains its stores.
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         bx = (xcd + 8 * (slot / a.tiles_per_img)) * a.tiles_per_img + slot % a.tiles_per_img;
     }
     int by = blockIdx.y;
-    if (a.qmap) {        // XCD = (pixel group, channel group): an XCD's L2 holds gy / Q of the weight tiles (conv_shift.hip)
+    if (a.qmap) {        // XCD = (pixel group, channel group): an XCD's L2 holds gy / Q of the weight tiles
         const int id = blockIdx.x, xcd = id & 7, slot = id >> 3, Q = a.qmap, P = 8 / Q;
         const int ppx = a.gx / P, cpq = a.gy / Q;
         bx = (xcd / Q) * ppx + slot / cpq; by = (xcd % Q) * cpq + slot % cpq;

@@ -31,27 +31,9 @@ PROBE = None      # bench.py sets this to a list: (kernel symbol, algorithmic FL
                   # HBM bytes) per launch, events recorded on the launch stream
 
 
-# MI_CONV_SHIFT=1 forces the LDS-frugal variant (csrc/conv_shift.hip: left / right tap columns by DPP lane shifts, half the LDS operand
-# reads) wherever it applies.  Its first, 4-wave form lost to the halo kernel on every shape (128->128 @32x32: 62.8 vs 52.6 us); with 8
-# waves (two per SIMD, like the halo tiles) it is the faster kernel of the two -- see _pick3x3 below.
-USE_CONV_SHIFT = debug_knob("MI_CONV_SHIFT", "0") == "1"
-# Which 3x3 kernel takes a bf16-stored layer when none is forced: the LDS-frugal conv_shift (centre-column fragments + DPP shifts: half
-# the LDS operand reads) for the layers with >= 128 channels on both sides, the register-staged halo kernel for the rest.  Per shape
-# (tools/bench_dma_conv.py, B = 128) conv_shift wins 4-7 % on the 32- and 16-pixel-wide levels (level 0: 50.1 vs 54.0 us) and ties on
-# 8x8; in the training step (one box, two runs each): halo only 5.723 ms, conv_shift everywhere 5.657 ms (+1.2 %), conv_shift on
-# the wide levels + the LDS-DMA kernel on 8x8 (where IT wins per shape, 40.6 vs 42.3 us) 5.69 ms -- so no LDS-DMA pick.
-# MI_CONV_AUTO=0: always the halo kernel.
+# MI_CONV_AUTO=0: the register-staged halo kernel (round 1 / 2) everywhere -- the fallback of the per-layer pick below, kept under test
+# by a subprocess run of the conv and UNet tests.
 CONV_AUTO = os.environ.get("MI_CONV_AUTO", "1") == "1"
-
-
-def _pick3x3(W, K, Nc):
-    if not CONV_AUTO or K < 128 or Nc < 128:
-        return "halo"
-    if W <= 8 and debug_knob("MI_CONV_PICK8", "1") == "1":
-        # 8x8 level, per shape (shift vs halo): 512 -> 512 41.7 vs 42.3 us, 256 -> 512 a tie, but 1024 -> 256 64.4 vs 57.3 and
-        # 256 -> 256 21.8 vs 19.5: the narrow / very deep layers stay with the halo kernel
-        return "shift" if (256 <= K <= 512 and Nc >= 512) else "halo"
-    return "shift"
 
 
 # The private-weight-stream kernel (csrc/conv_pw.hip): 128-pixel tiles, one barrier per 64-channel chunk, two workgroups per CU.
@@ -297,7 +279,6 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
                          f"N{N} {H}x{W} K{K}->{Nc} + GroupNorm sums", nb)
         return out
     if gn_sums is None and not want16 and ksize == 3 and _b16(x):
-        pick = "shift" if USE_CONV_SHIFT else _pick3x3(W, K, Nc)
         if USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc, d):
             pick = "pw"
     if pick == "pw":
@@ -306,18 +287,6 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
         if e0 is not None:
             nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 2)
             _probe_close(e0, _pw_sym(d, _b16(out)), 2.0 * N * H * W * Nc * K * 9,
-                         f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
-        return out
-    if pick == "shift" and _query("mi_conv3x3_shift_supported", d):
-        # bf16-stored activations: the LDS-frugal kernel (conv_shift.hip)
-        e0 = _probe_open()
-        check(lib.mi_conv3x3_shift(C.byref(d), _p(x), _p(x2), _p(wsh), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv3x3_shift")
-        if e0 is not None:
-            ni = C.c_int()
-            lib.mi_conv3x3_shift_tile(C.byref(d), C.byref(ni))
-            nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 2)
-            wm = 2 if debug_knob("MI_SHIFT_WM", "4") == "2" else 4
-            _probe_close(e0, f"conv_shift_kernel<{wm}, {ni.value}, {'true' if _b16(out) else 'false'}>", 2.0 * N * H * W * Nc * K * 9,
                          f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
         return out
     e0 = _probe_open()

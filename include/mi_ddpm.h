@@ -136,15 +136,6 @@ int mi_conv3x3_gn_mish_supported(const MiConvDesc* d);
 int mi_conv3x3_gn_mish_tile(const MiConvDesc* d, int* bm, int* ck);
 int mi_conv3x3_gn_mish(const MiConvDesc* d, const void* x, const float* coef, const void* w_nk_bf16, const float* bias,
                        void* y, int io, void* stream);
-/* ---- the same convolution for bf16-STORED activations, staged entirely by LDS-DMA (conv_shift.hip): a wave owns 128 pixels x 64
- * channels and derives the left / right tap columns' activation fragments from the centre column's by one-lane DPP shifts.
- * x / x2 bf16 (pixel strides in elements, % 8 == 0), w as for mi_conv3x3_bf16w, d->transposed = 1 -> data gradient; y fp32 or bf16
- * (out_bf16).  Needs W in {8, 16, 32} with 256-pixel row tiles (N*H*W % 256 == 0), K % 64 == 0, K1 % 64 == 0 (query _supported).
- * The host layer takes it for the layers too small for mi_conv3x3_pw's 128 x 128 tiles to fill the chip. */
-int mi_conv3x3_shift_supported(const MiConvDesc* d);
-int mi_conv3x3_shift_tile(const MiConvDesc* d, int* ni);
-int mi_conv3x3_shift(const MiConvDesc* d, const void* x, const void* x2, const void* w_nk_bf16, const float* bias,
-                     const float* residual, void* y, int out_bf16, void* stream);
 /* bf16 shadow copies of every conv weight of the flat fp32 parameter buffer (master layout
  * [tap][Cin][Cout] at float offset `off`): wd = same layout, wf = [tap][Cout][Cin].
  * entries_dev: device array of {int64 off; int32 taps, ci, co, tile0}, tile0 = first tile

@@ -498,60 +498,6 @@ def test_pack_weights_bf16(K):
                            w.permute(0, 1, 3, 2).contiguous().to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("out16", [False, True])
-@pytest.mark.parametrize("cfg", [
-    dict(N=2, H=32, Ci=128, Co=128),             # level 0: 8 rows of 32 per tile (NI = 1: few tiles)
-    dict(N=64, H=32, Ci=64, Co=128),             # NI = 2, XCD-grouped tile order
-    dict(N=4, H=16, Ci=256, Co=128, split=128),  # skip concat (two sources), one 16x16 image per tile
-    dict(N=16, H=8, Ci=512, Co=512),             # four 8x8 images per tile, 8 chunks
-    dict(N=2, H=16, Ci=64, Co=96),               # ragged co tile
-    dict(N=128, H=8, Ci=128, Co=192),            # NI = 2 with a half-empty second co tile
-    dict(N=4, H=8, Ci=1024, Co=64, split=512),   # long K
-])
-def test_conv3x3_shift_fwd_and_dgrad(K, cfg, out16):
-    """Block's 3x3 conv (ddpm.py:116) and its data gradient for bf16-stored activations through the LDS-frugal kernel
-    (mi_conv3x3_shift: left / right tap columns by one-lane DPP shifts of the centre column's fragments): bias, residual, fp32 and
-    bf16 output, accumulate; against fp64 on the same bf16-rounded operands and against the halo kernel."""
-    from src.ops.lib import MiConvDesc, load_library
-    import ctypes
-    N, H, Ci, Co = cfg["N"], cfg["H"], cfg["Ci"], cfg["Co"]
-    split = cfg.get("split")
-    g = torch.Generator().manual_seed(59)
-    x = torch.randn(N, Ci, H, H, generator=g).bfloat16()
-    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9))
-    b = torch.randn(Co, generator=g)
-    r = torch.randn(N, Co, H, H, generator=g)
-    dy = torch.randn(N, Co, H, H, generator=g).bfloat16()
-    xq = x.double().requires_grad_(True)
-    wq = w.bfloat16().double()
-    yq = F.conv2d(xq, wq, b.double(), padding=1) + r.double()
-    yq.backward(dy.double())
-    flat, wd, wf, offs = _pack(K, [conv_w_storage(w.double())])
-    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
-    xa, xb = (nh(x[:, :split]), nh(x[:, split:])) if split else (nh(x), None)
-    d = MiConvDesc(N=N, IH=H, IW=H, OH=H, OW=H, K=Ci, Nc=Co, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=1, K1=split or Ci,
-                   ldx=xa.shape[3], ldx2=xb.shape[3] if xb is not None else 0, ldy=Co, ldr=Co, accumulate=0)
-    assert load_library().mi_conv3x3_shift_supported(ctypes.byref(d)) == 1
-    was = K.USE_CONV_SHIFT
-    K.USE_CONV_SHIFT = True
-    odt = torch.bfloat16 if out16 else torch.float32
-    tol = 6e-3 if out16 else 1e-5                                        # bf16 output: one more rounding
-    try:
-        yg = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Co, flip=False, x2=xb, bias=b.to(DEV), residual=to_nhwc_gpu(r), out_dtype=odt)
-        assert yg is not None and yg.dtype == odt
-        dxg = K.conv3x3_bf16w(nh(dy), wd, K=Co, Nc=Ci, flip=True, out_dtype=odt)
-        torch.cuda.synchronize()
-        assert rel_err(from_nhwc(yg.float()), yq) < tol
-        assert rel_err(from_nhwc(dxg.float()), xq.grad) < tol
-        dx2 = K.conv3x3_bf16w(nh(dy), wd, K=Co, Nc=Ci, flip=True, out=dxg.clone(), accumulate=True)
-        assert rel_err(from_nhwc(dx2.float()), 2 * xq.grad) < 2 * tol
-        K.USE_CONV_SHIFT = False
-        y2 = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Co, flip=False, x2=xb, bias=b.to(DEV), residual=to_nhwc_gpu(r), out_dtype=odt)
-    finally:
-        K.USE_CONV_SHIFT = was
-    assert rel_err(yg.float(), y2.float()) < tol
-
-
 @pytest.fixture
 def pw_always(K):
     """Route every supported layer to the private-weight-stream kernel (the default takes it only from ~one tile per CU up) and
@@ -1499,7 +1445,7 @@ def test_small_gemm_linear(K, M, N, Kc):
 
 def test_halo_kernel_takes_every_bf16_layer_in_a_subprocess():
     """MI_CONV_AUTO=0: the register-staged halo kernel (the fallback of the per-shape pick, and the only kernel behind the dual-output,
-    epilogue-sum and fused entry points) on the bf16-stored layers that conv_pw / conv1x1_pw / conv_shift take by default -- every conv kernel test and the
+    epilogue-sum and fused entry points) on the bf16-stored layers that conv_pw / conv1x1_pw take by default -- every conv kernel test and the
     end-to-end bf16 block test."""
     import os
     import subprocess

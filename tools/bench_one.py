@@ -69,9 +69,6 @@ for _ in range(5):
     elif which == "halo":        # the register-staged halo kernel (not the per-shape pick)
         K.CONV_AUTO = False
         K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, out=y)
-    elif which == "shift":       # conv_shift, the default kernel of the bf16-stored >= 128-channel layers
-        K.USE_CONV_SHIFT = True
-        K.conv3x3_bf16w(x, wf, K=Ci, Nc=Co, flip=False, out=y)
     elif which == "pw":          # the private-weight-stream kernel (conv_pw.hip), the default of the bf16-stored layers with >= 200 tiles
         if "WQ" not in globals():
             table, nent, tiles = K.pack_table([(0, 9, Ci, Co)], DEV)

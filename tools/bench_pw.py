@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""3x3 conv forward on the cfg-2 / cfg-3 shapes, bf16-stored activations: round 2's per-shape pick (conv_shift / halo) against the
+"""3x3 conv forward on the cfg-2 / cfg-3 shapes, bf16-stored activations: round 2's register-staged halo kernel (no fragment-order weights passed) against the
 private-weight-stream kernel (conv_pw.hip); 20 back-to-back launches per timing, interleaved rounds, median.  Random operands."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
