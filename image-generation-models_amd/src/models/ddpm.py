@@ -1066,8 +1066,12 @@ class GaussianDiffusion(nn.Module):
         if use_graph is None:
             use_graph = self.noise_source is None and os.environ.get("MI_DDPM_GRAPH", "1") == "1"
         if use_graph:
-            if self._graph is None or self._graph.shape != tuple(shape):
+            # a captured denoise step bakes in the kernel picks: the numeric mode, the storage of the internal tensors, the fusion
+            net = self.denoise_fn
+            key = (tuple(shape), getattr(net, "compute_mode", None), getattr(net, "block_storage", None), str(getattr(net, "fuse_gn_conv", None)))
+            if self._graph is None or getattr(self, "_graph_key", None) != key:
                 self._graph = GraphSampler(self, tuple(shape))
+                self._graph_key = key
             return self._graph.run()
         b = shape[0]
         img = self._randn(shape, device)

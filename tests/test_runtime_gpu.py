@@ -120,6 +120,27 @@ def test_graph_sampler_sees_optimizer_step_in_bf16_mode():
     assert float((after_graph - before).abs().max()) > 1e-3
 
 
+def test_graph_sampler_is_recaptured_when_the_numeric_mode_changes():
+    """A captured denoise iteration bakes in the kernel picks; p_sample_loop must not replay a bf16-mode graph after
+    Unet.compute_mode was switched to fp32 (or the storage / fusion settings changed)."""
+    from src.models.ddpm import GaussianDiffusion, Unet
+    torch.manual_seed(0)
+    net = Unet(dim=32, dim_mults=(1, 2), channels=3).to(DEV).eval()
+    gd = GaussianDiffusion(net, image_size=(16, 16), timesteps=4).to(DEV)
+    net.compute_mode = "bf16"
+    gd.sample(batch_size=8)
+    g1 = gd._graph
+    gd.sample(batch_size=8)
+    assert gd._graph is g1                                   # same settings: the graph is reused
+    net.compute_mode = "fp32"
+    gd.sample(batch_size=8)
+    assert gd._graph is not g1
+    g2 = gd._graph
+    net.fuse_gn_conv = "0"
+    gd.sample(batch_size=8)
+    assert gd._graph is not g2
+
+
 def test_workspace_growth_keeps_old_addresses_alive():
     from src.ops import functional as K
     dev = torch.device("cuda", torch.cuda.current_device())
