@@ -256,6 +256,174 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const TrBatch b) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same weight gradient in exact-fp32 mode (Unet.compute_mode = "fp32": fp32 X and dY, v_mfma_f32_32x32x2_f32 = an fp32 fma
+// chain).  Same decomposition -- one workgroup (8 waves) = a 64 (ci) x 128 (co) tile of ALL NINE taps for one slice of the pixel
+// axis, 144 accumulators per wave, 64-pixel steps, the same k-slices, partial tiles, reduce kernel and batching -- but no transposing
+// reads are needed: the fp32 MFMA contracts over TWO pixels per instruction, lane half k supplies pixel 2 kp + k, so both operands
+// are plain ds_read_b32 of a pixel-major tile (32 lanes = 32 consecutive channels = one 128-byte row segment, conflict-free):
+//   X  [row][zero pixel | W pixels | zero pixel][64 ci] fp32 (256 bytes per pixel; a tap shift is a different address),
+//   dY [pixel][128 co] fp32.
+// Both arrive by LDS-DMA (1 KB = 4 X pixels or 2 dY pixels per wave instruction, plain row-major sources).  X rows live in a ring
+// of 4 steps (the step after the current one supplies the halo row below), dY in a ring of 2; step s requests X of step s + 2 and dY
+// of step s + 1: a step is 288 MFMAs of 64 cycles per wave (~9 us), far longer than any load.  150 KB of LDS, one workgroup per CU.
+__device__ __forceinline__ float lds_f32(uint32_t addr) {
+    typedef __attribute__((address_space(3))) float lds_float;
+    return *(lds_float*)(uintptr_t)addr;
+}
+
+template <int W>
+__device__ __forceinline__ void wgrad_tr32_body(const TrArgs& a, const int wg, uint8_t* lds_raw) {
+    constexpr int TR = 64 / W;
+    constexpr int ROWB = (W + 2) * 256;
+    constexpr int NR = 4 * TR;
+    constexpr int XRING = ROWB;                    // byte offsets: [zero row][X ring][dY ring]
+    constexpr int YRING = XRING + NR * ROWB;
+    constexpr int YSTEP = 64 * 512;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
+    const int t = threadIdx.x, l = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wi = wv >> 2, wj = wv & 3;             // 2 ci halves x 4 co quarters
+    const int ntiles = a.gx * a.gy;
+    int split = wg / ntiles, tile = wg - split * ntiles;
+    if (a.xcd_map == 1) {
+        const int xcd = wg & 7, slot = wg >> 3;
+        tile = slot % ntiles; split = xcd + 8 * (slot / ntiles);
+    } else if (a.xcd_map == 2) {
+        const int xcd = wg & 7, slot = wg >> 3, g = 8 / a.splits;
+        split = xcd / g; tile = (xcd % g) * (ntiles / g) + slot;
+    }
+    const int ci0 = (tile % a.gx) * 64, co0 = (tile / a.gx) * 128;
+    const int sb = split * a.sps, se = min(a.total, sb + a.sps);
+
+    // zero the X area once: the zero row and the zero pixels left / right of every row are never written again
+    for (int i = t * 16; i < YRING; i += 512 * 16) *reinterpret_cast<u32x4*>(lds_raw + i) = u32x4{0u, 0u, 0u, 0u};
+
+    // DMA sources.  X piece (4 pixels x 64 ci): lane -> pixel lane >> 4, 4-channel chunk lane & 15; dY piece (2 pixels x 128 co):
+    // pixel lane >> 5, chunk lane & 31
+    const bool second = ci0 >= a.I1;
+    const int ldx = second ? a.ldp2 : a.ldp;
+    const float* xsrc = reinterpret_cast<const float*>(second ? a.P2 : a.P) + (size_t)(l >> 4) * ldx +
+                        min((second ? ci0 - a.I1 : ci0) + (l & 15) * 4, (second ? a.Ci - a.I1 : a.I1) - 4);
+    const float* ysrc = reinterpret_cast<const float*>(a.Q) + (size_t)(l >> 5) * a.ldq + min(co0 + (l & 31) * 4, a.Cj - 4);
+    const int last = a.total - 1;
+    auto stage_x = [&](int step) {
+        const size_t pix0 = (size_t)min(step, last) * 64;
+        const int sm = step & 3;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = wv + 8 * k;              // piece i of the step: pixels 4i .. 4i+3 (one row: W % 4 == 0)
+            const int rr = (4 * i) / W, x = (4 * i) % W;
+            glds16(xsrc + (pix0 + 4 * i) * ldx, lds0 + XRING + (sm * TR + rr) * ROWB + (x + 1) * 256);
+        }
+    };
+    auto stage_y = [&](int step) {
+        const size_t pix0 = (size_t)min(step, last) * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = wv + 8 * k;              // piece i: pixels 2i, 2i+1
+            glds16(ysrc + (pix0 + 2 * i) * a.ldq, lds0 + YRING + (step & 1) * YSTEP + i * 1024);
+        }
+    };
+    // lane parts of the fragment addresses: pixel 2 kp + (l >> 5), channel l & 31 of the wave's 32
+    const uint32_t la = lds0 + (l >> 5) * 256 + (wi * 32 + (l & 31)) * 4;
+    const uint32_t lb = lds0 + YRING + (l >> 5) * 512 + (wj * 32 + (l & 31)) * 4;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+
+    __syncthreads();
+    if (sb > 0) {                                  // the row above the slice's first step: the last row of step sb - 1
+        const int step = sb - 1;
+        const size_t pix0 = (size_t)step * 64;
+        constexpr int PPR = W / 4;                 // pieces per row
+        if (wv < PPR) {
+            const int i = 16 - PPR + wv;
+            glds16(xsrc + (pix0 + 4 * i) * ldx, lds0 + XRING + ((step & 3) * TR + TR - 1) * ROWB + ((4 * i) % W + 1) * 256);
+        }
+        if constexpr (PPR > 8) if (wv + 8 < PPR) {
+            const int i = 16 - PPR + wv + 8;
+            glds16(xsrc + (pix0 + 4 * i) * ldx, lds0 + XRING + ((step & 3) * TR + TR - 1) * ROWB + ((4 * i) % W + 1) * 256);
+        }
+    }
+    stage_x(sb); stage_x(sb + 1); stage_y(sb);
+
+    for (int s = sb; s < se; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // X of steps <= s + 1 and dY of step s: all requested a step ago
+        __builtin_amdgcn_s_barrier();                         // ... for every wave, and every wave is done reading step s - 1
+        asm volatile("" ::: "memory");
+        stage_x(s + 2); stage_y(s + 1);
+        const int sm = s & 3, y0 = (s * TR) % a.H;
+        uint32_t RB[TR + 2];                                  // row bases of relative rows -1 .. TR (ring slot, or the zero row)
+        RB[0] = la + (y0 == 0 ? 0 : XRING + ((sm * TR + NR - 1) % NR) * ROWB);
+#pragma unroll
+        for (int rr = 0; rr < TR; ++rr) RB[rr + 1] = la + XRING + (sm * TR + rr) * ROWB;
+        RB[TR + 1] = la + (y0 + TR == a.H ? 0 : XRING + (((sm + 1) & 3) * TR) * ROWB);
+        const uint32_t yb = lb + (s & 1) * YSTEP;
+        // 32 k-pairs of two pixels; a pair's ten operands are read one pair ahead of its nine MFMAs
+        float Bv[2], Av[2][9];
+        auto load_pair = [&](auto kc) {
+            constexpr int kp = decltype(kc)::value, r = (2 * kp) / W, x = (2 * kp) % W;
+            Bv[kp & 1] = lds_f32(yb + 2 * kp * 512);
+            static_for<0, 9>([&](auto tc) {
+                constexpr int tp = decltype(tc)::value, ky = tp / 3, kx = tp % 3;
+                Av[kp & 1][tp] = lds_f32(RB[r + ky] + (x + kx) * 256);
+            });
+        };
+        load_pair(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 32>([&](auto kc) {
+            constexpr int kp = decltype(kc)::value;
+            if constexpr (kp + 1 < 32) load_pair(std::integral_constant<int, kp + 1>{});
+            static_for<0, 9>([&](auto tc) {
+                constexpr int tp = decltype(tc)::value;
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(Av[kp & 1][tp], Bv[kp & 1], acc[tp], 0, 0, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // nothing may still be writing LDS when the workgroup retires
+
+    if (a.splits == 1) {
+        const int ci = ci0 + wi * 32 + 4 * (l >> 5), co = co0 + wj * 32 + (l & 31);
+        if (co < a.Cj) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                float* o = a.dW + ((size_t)tp * a.Ci + ci) * a.Cj + co;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * a.Cj] += acc[tp][r];
+            }
+        }
+        return;
+    }
+    float* out = a.ws + (size_t)(split * ntiles + tile) * (36 * 2048) + t * 4;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+            *reinterpret_cast<f32x4*>(out + (tp * 4 + rq) * 2048) =
+                f32x4{acc[tp][4 * rq], acc[tp][4 * rq + 1], acc[tp][4 * rq + 2], acc[tp][4 * rq + 3]};
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad_tr32_kernel(const TrBatch b) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < MAXP; ++q)
+        if (q < b.n && (int)blockIdx.x >= b.p[q].wg0) p = q;
+    const TrArgs& a = b.p[p];
+    const int wg = blockIdx.x - a.wg0;
+    switch (a.W) {
+        case 8:  wgrad_tr32_body<8>(a, wg, lds_raw); break;
+        case 16: wgrad_tr32_body<16>(a, wg, lds_raw); break;
+        case 32: wgrad_tr32_body<32>(a, wg, lds_raw); break;
+        default: wgrad_tr32_body<64>(a, wg, lds_raw); break;
+    }
+}
+
 // dW[tap][ci][co] += sum over k-slices of the partial tiles (fixed order).  grid = (2G position groups, 36 slots, tiles of all
 // problems that have k-slices); a workgroup = G slice groups x (256 / G) float4 positions of one slot; each thread keeps 8
 // independent 16-byte loads in flight.
@@ -301,14 +469,15 @@ __global__ __launch_bounds__(256) void wgrad_tr_reduce_kernel(const TrBatch b) {
 }
 
 bool tr_ok(const MiWgradDesc* d) {
-    if (d->KH != 3 || d->KW != 3 || d->pad != 1 || d->stride != 1 || !d->gather_i || d->mode != 1) return false;
+    if (d->KH != 3 || d->KW != 3 || d->pad != 1 || d->stride != 1 || !d->gather_i || (d->mode != 1 && d->mode != 0)) return false;
     if (d->GH != d->DH || d->GW != d->DW) return false;
     const int W = d->DW, H = d->DH;
     if (W != 8 && W != 16 && W != 32 && W != 64) return false;
     if (H % (64 / W)) return false;
     if (((long)d->N * H * W) % 64) return false;
     if (d->Ci % 64 || d->I1 % 64 || d->Cj % 32 || d->Cj < 32) return false;
-    if (d->ldp % 8 || d->ldq % 8 || (d->I1 != d->Ci && d->ldp2 % 8)) return false;
+    const int lda = d->mode == 1 ? 8 : 4;          // 16-byte pieces: bf16 (mode 1) or fp32 (mode 0: exact-fp32 kernel) operands
+    if (d->ldp % lda || d->ldq % lda || (d->I1 != d->Ci && d->ldp2 % lda)) return false;
     return true;
 }
 
@@ -352,6 +521,7 @@ void tr_shares(int n, const MiWgradDesc* d, long* wgs) {
 }
 
 size_t tr_lds(int W) { return (size_t)((W / 8 + 2) * 1024) * (1 + 4 * (64 / W)) + 3 * 64 * 256; }
+size_t tr32_lds(int W) { return (size_t)((W + 2) * 256) * (1 + 4 * (64 / W)) + 2 * 64 * 512; }
 
 size_t tr_ws_floats(const TrArgs& a) { return a.splits > 1 ? (size_t)a.splits * a.gx * a.gy * 36 * 2048 : 0; }
 
@@ -396,6 +566,7 @@ extern "C" int mi_conv3x3_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
     long wgs[MAXP];
     for (int i = 0; i < n; ++i) {
         MI_REQUIRE(tr_ok(&descs[i]), "descriptor not supported by the LDS-DMA weight-gradient kernel (use mi_conv3x3_wgrad_io)");
+        MI_REQUIRE(descs[i].mode == descs[0].mode, "one numeric mode per batch");
         MI_REQUIRE(P[i] && Q[i] && dW[i], "null operand");
         MI_REQUIRE(descs[i].I1 == descs[i].Ci || (P2 && P2[i]), "two-source split without P2");
         MI_REQUIRE((((uintptr_t)P[i] | (uintptr_t)Q[i] | (uintptr_t)((P2 && P2[i]) ? P2[i] : P[i])) & 15) == 0, "operands must be 16-byte aligned");
@@ -420,7 +591,7 @@ extern "C" int mi_conv3x3_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         a.wg0 = wg; wg += a.gx * a.gy * a.splits;
         a.tile0 = tile; if (a.splits > 1) tile += a.gx * a.gy;
         if (a.splits > max_splits) max_splits = a.splits;
-        const size_t l = tr_lds(a.W);
+        const size_t l = descs[i].mode == 0 ? tr32_lds(a.W) : tr_lds(a.W);
         if (l > lds) lds = l;
     }
     static const int dbg = (int)mi_knob("MI_WTR_DEBUG", 0);
@@ -437,10 +608,14 @@ extern "C" int mi_conv3x3_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
     hipStream_t st = (hipStream_t)stream;
     static bool once = [] {
         (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad_tr32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)once;
-    if (g_wtr_phase != 2) hipLaunchKernelGGL(wgrad_tr_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);
+    if (g_wtr_phase != 2) {
+        if (descs[0].mode == 0) hipLaunchKernelGGL(wgrad_tr32_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);
+        else hipLaunchKernelGGL(wgrad_tr_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);
+    }
     if (g_wtr_phase != 1 && tile > 0) {
         if (max_splits >= 64) hipLaunchKernelGGL(wgrad_tr_reduce_kernel<8>, dim3(16, 36, tile), dim3(256), 0, st, b);
         else hipLaunchKernelGGL(wgrad_tr_reduce_kernel<2>, dim3(4, 36, tile), dim3(256), 0, st, b);

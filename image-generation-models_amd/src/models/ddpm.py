@@ -753,6 +753,10 @@ class Unet(nn.Module):
             elif k == 3 and stride == 1 and bias != "colsum" and mode == K.MODE_BF16:
                 # Block conv: deferred, several layers per launch (K.WgradQueue)
                 wq.push(winp, dy, gv[pre + "weight"], Ci=ci, Cj=co, hw=(ih, iw), mode=mode, P2=wx2)
+            elif (k == 3 and stride == 1 and not transposed_conv and mode == K.MODE_FP32 and winp.dtype == torch.float32
+                  and dy.dtype == torch.float32 and ci % 64 == 0):
+                # fp32 mode: the same queue, the exact-fp32 instantiation of the kernel (the bias gradient stays a column sum below)
+                wq.push(winp, dy, gv[pre + "weight"], Ci=ci, Cj=co, hw=(ih, iw), mode=mode, P2=wx2)
             elif k == 1 and stride == 1 and mode == K.MODE_BF16 and winp.dtype == torch.bfloat16:
                 # to_qkv / to_out / res_conv: deferred too; the bias gradient rides along when dy is the fp32 stream gradient
                 fuse_b = bias == "colsum" and dy.dtype == torch.float32

@@ -703,8 +703,9 @@ class WgradQueue:
     def push(self, P, Q, dW, *, Ci, Cj, hw, mode, P2=None):
         """3x3 / stride 1 / pad 1"""
         d = self._desc(P, Q, 3, Ci, Cj, hw, mode, P2)
-        ok = (USE_WGRAD_TR and self.group > 1 and _b16(P) and _b16(Q) and (P2 is None or _b16(P2))
-              and _query("mi_conv3x3_wgrad_tr_supported", d))
+        same = (lambda dt: P.dtype == dt and Q.dtype == dt and (P2 is None or P2.dtype == dt))      # noqa: E731
+        ok = (USE_WGRAD_TR and self.group > 1 and (same(torch.bfloat16) if mode == MODE_BF16 else same(torch.float32))
+              and _query("mi_conv3x3_wgrad_tr_supported", d))      # (mode 0: the exact-fp32 instantiation, fp32 operands)
         if not ok:
             conv_wgrad(P, Q, dW, kh=3, kw=3, stride=1, pad=1, gather_i=True, Ci=Ci, Cj=Cj, grid_g=hw, grid_d=hw, mode=mode, P2=P2)
             return
@@ -759,8 +760,9 @@ class WgradQueue:
                 check(lib.mi_conv3x3_wgrad_tr_batch(n, descs, arr(items, 1), arr(items, 2), arr(items, 3), arr(items, 4), _p(ws), ws.numel() * 4,
                                                     _stream()), "mi_conv3x3_wgrad_tr_batch")
             flops = sum(2.0 * it[0].N * it[0].DH * it[0].DW * it[0].Ci * it[0].Cj * 9 for it in items)
-            nb = sum(it[0].N * it[0].DH * it[0].DW * (it[0].Ci + it[0].Cj) * 2.0 for it in items)
-            self._run(go, lib.mi_debug_wgrad_tr_phase, "wgrad_tr", n, flops, nb, need)
+            f32 = items[0][0].mode == MODE_FP32
+            nb = sum(it[0].N * it[0].DH * it[0].DW * (it[0].Ci + it[0].Cj) * (4.0 if f32 else 2.0) for it in items)
+            self._run(go, lib.mi_debug_wgrad_tr_phase, "wgrad_tr32" if f32 else "wgrad_tr", n, flops, nb, need)
         if 1 in kinds and self.items1:
             items, self.items1, self._seq1 = self.items1, [], []
             _need_gpu(items[0][1])
@@ -803,7 +805,7 @@ class WgradQueue:
             phase(1)
             e0 = _probe_open(); go(); _probe_close(e0, name + "_kernel", flops, f"{n} layers", nb + need)
             phase(2)
-            e0 = _probe_open(); go(); _probe_close(e0, name + "_reduce_kernel", 0.0, f"{n} layers", float(need))
+            e0 = _probe_open(); go(); _probe_close(e0, name.replace("tr32", "tr") + "_reduce_kernel", 0.0, f"{n} layers", float(need))
         finally:
             phase(0)
 

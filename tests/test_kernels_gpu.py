@@ -1170,6 +1170,44 @@ def test_conv3x3_wgrad_queue_batches_layers(K, group):
         assert rel_err(w_from_storage(dW.view(3, 3, Ci, Co)), ref) < 2e-5, (Ci, Co)
 
 
+@pytest.mark.parametrize("group", [8, 3])
+def test_conv3x3_wgrad_queue_fp32_mode(K, group):
+    """The exact-fp32 instantiation of the LDS-DMA weight-gradient kernel (wgrad_tr32_kernel: v_mfma_f32_32x32x2_f32, plain ds_read_b32
+    of pixel-major fp32 tiles, the same k-slices / partial tiles / reduce / batching): Block conv weight gradients in fp32 mode --
+    every image width incl. 64, a two-source layer, ragged co tiles, accumulation into a non-zero dW -- against fp64 at the fp32
+    mode's bar; a second run with an odd workgroup count (odd slice boundaries: steps that start inside an image)."""
+    g = torch.Generator().manual_seed(107)
+    layers = [dict(N=8, H=32, W=32, Ci=128, Co=128), dict(N=8, H=16, W=16, Ci=256, Co=256), dict(N=8, H=8, W=8, Ci=512, Co=512),
+              dict(N=8, H=8, W=8, Ci=1024, Co=256, split=512), dict(N=4, H=64, W=64, Ci=64, Co=64), dict(N=8, H=16, W=16, Ci=128, Co=96),
+              dict(N=8, H=32, W=32, Ci=64, Co=32), dict(N=8, H=16, W=16, Ci=512, Co=128, split=256)]
+    for blocks in (0, 203):
+        K.load_library().mi_debug_wgrad_tr_blocks(blocks)
+        try:
+            q = K.WgradQueue(group=group)
+            refs, outs = [], []
+            K.PROBE = []
+            for L in layers:
+                N, H, W, Ci, Co, split = L["N"], L["H"], L["W"], L["Ci"], L["Co"], L.get("split")
+                x = torch.randn(N, Ci, H, W, generator=g)
+                dy = torch.randn(N, Co, H, W, generator=g)
+                wq = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+                F.conv2d(x.double(), wq, None, padding=1).backward(dy.double())
+                nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+                P, P2 = (nh(x[:, :split]), nh(x[:, split:])) if split else (nh(x), None)
+                dW = torch.full((9 * Ci * Co,), 0.5, device=DEV)
+                q.push(P, nh(dy), dW, Ci=Ci, Cj=Co, hw=(H, W), mode=0, P2=P2)
+                refs.append(wq.grad); outs.append((dW, Ci, Co))
+            q.flush()
+            torch.cuda.synchronize()
+            names = [p_[0] for p_ in K.PROBE]
+        finally:
+            K.PROBE = None
+            K.load_library().mi_debug_wgrad_tr_blocks(0)
+        assert q.pushed == q.flushed == len(layers) and "wgrad_tr32_kernel" in names and not any(n.startswith("wgrad_kernel") for n in names), names
+        for (dW, Ci, Co), ref in zip(outs, refs):
+            assert rel_err(w_from_storage((dW - 0.5).view(3, 3, Ci, Co)), ref) < 3e-6, (Ci, Co, blocks)
+
+
 @pytest.mark.parametrize("cfg", [
     dict(N=8, H=32, Ci=128, Co=384),             # to_qkv at level 0 (256-pixel tiles)
     dict(N=2, H=16, Ci=256, Co=128, split=128),  # res_conv on the skip concat
