@@ -281,7 +281,9 @@ int mi_conv3x3_wgrad_io(const MiWgradDesc* d, const void* P, const void* P2, con
  * elements, % 8 == 0): rows go L2 -> LDS by LDS-DMA, MFMA operands come out of LDS through the transposing ds_read_b64_tr_b16, one
  * workgroup accumulates all nine taps of a 64 x 128 (ci x co) tile over its slice of the pixel axis; slices are summed in a fixed
  * order by a second kernel through `workspace` (mi_conv3x3_wgrad_tr_workspace bytes).  dW += result, layout [3][3][Ci][Cj].
- * Needs W in {8,16,32,64}, H % (64/W) == 0, N*H*W % 64 == 0, Ci % 64 == 0, I1 % 64 == 0, Cj % 32 == 0 (query _supported). */
+ * Needs W in {8,16,32,64}, H % (64/W) == 0, N*H*W % 64 == 0, Ci % 64 == 0, I1 % 64 == 0, Cj % 32 == 0 (query _supported).
+ * d->mode = 0 (exact-fp32 mode): P / P2 / Q are fp32 tensors (strides % 4 == 0) and the contraction runs on v_mfma_f32_32x32x2_f32 with
+ * plain ds_read_b32 fragments of pixel-major fp32 tiles -- same tiles, k-slices, reduce and batching (one mode per batch). */
 int mi_conv3x3_wgrad_tr_supported(const MiWgradDesc* d);
 size_t mi_conv3x3_wgrad_tr_workspace(const MiWgradDesc* d);
 int mi_conv3x3_wgrad_tr_splits(const MiWgradDesc* d);
