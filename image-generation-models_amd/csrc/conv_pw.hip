@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     }
     const int m0 = bx * PT, n0 = by * 128;
     const int TH2 = a.TH + 2;
-    const int lw = 31 - __builtin_clz(a.W), lth = 31 - __builtin_clz(a.TH);      // W and TH are powers of two
+    const int lw = 31 - __builtin_clz(a.W);                   // W (and TH) are powers of two
     const int nchunks = a.K / PCK;
     const int NB = a.Nc >> 5, KQ = a.K / (2 * EPP);              // fragments per (tap, 32-channel block): one per step
     const bool live = n0 + 32 * wv < a.Nc;                    // a ragged last channel tile: the wave computes a copy of the last block
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     u32x4 XR32[IN32 ? 2 : 1][2];                             // main loop: the two pieces a step requests
 
     // ---- fused variants: the 3 x 8 coefficients of this lane's channel chunk of chunk ch.  Plain loads would make hipcc drain the DMA
-    //      queue (vmcnt(0)) at their first use, so they are issued from one asm statement and counted by hand (pw_newer); their
+    //      queue (vmcnt(0)) at their first use, so they are issued from one asm statement and counted by hand; their
     //      destination registers are touched again only behind coef_landed(), which sits after the counted wait that covers them.
     f32x4 cq[6];                                             // scale[8], shift[8], time bias[8] of the chunk being transformed
     typedef float f32x2 __attribute__((ext_vector_type(2)));
