@@ -732,13 +732,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
 
     stage_x(0);
     load_w(0, std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<0, 8>([&](auto uc) { landed16(WB[0][decltype(uc)::value]); });
     auto chunk = [&](int ch, auto setc) {
         constexpr int set = decltype(setc)::value;
-        // this chunk's tile and fragments have landed (every wave's pieces); the other buffer and register set are free
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // this chunk's tile and fragments have landed (this wave's requests were waited for at the end of the previous chunk -- no
+        // register-destination load is in flight across the loop's back edge, DESIGN.md "the sixth rule"); the barrier makes it every
+        // wave's pieces, and the other buffer and register set are free
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        static_for<0, 8>([&](auto uc) { landed16(WB[set][decltype(uc)::value]); });
         if (ch + 1 < nchunks) { stage_x(ch + 1); load_w(ch + 1, std::integral_constant<int, set ^ 1>{}); }
         const uint32_t xb = (ch & 1) * XB;
         bf16x8 XC[2][NBLK];
@@ -762,6 +765,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next chunk's requests (issued 32+ MFMAs ago)
+        static_for<0, 8>([&](auto uc) { landed16(WB[set ^ 1][decltype(uc)::value]); });
     };
     for (int ch = 0; ch < nchunks; ch += 2) {
         chunk(ch, std::integral_constant<int, 0>{});
