@@ -459,8 +459,23 @@ def main():
             eager_step(i, m32, o32)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        # the three symbols with the most time in that step (HIP events on the launch stream around every launch of one more step)
+        K.PROBE = []
+        try:
+            eager_step(0, m32, o32)
+            torch.cuda.synchronize()
+            agg32 = {}
+            for sym, fl, e0, e1, _, nb in K.PROBE:
+                v = agg32.setdefault(sym, [0.0, 0.0, 0])
+                v[0] += fl; v[1] += e0.elapsed_time(e1) * 1e-3; v[2] += 1
+        finally:
+            K.PROBE = None
+        top32 = {k: {"launches_per_step": v[2], "ms_per_step": round(v[1] * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 1),
+                     "frac_of_fp32_mfma_peak": round(v[0] / v[1] / 1e12 / PEAK_TFLOPS["fp32"], 3)}
+                 for k, v in sorted(agg32.items(), key=lambda kv: -kv[1][1])[:3] if v[1] > 0}
         fp32_mode = {"value": round(B * n / el, 1), "unit": "images/s", "ms_per_step": round(el / n * 1e3, 3), "steps": n,
                      "train_tflops": round(B * n / el * TRAIN_GF / 1e3, 1), "peak_tflops": PEAK_TFLOPS["fp32"],
+                     "top_kernels": top32,
                      "note": "exact-fp32 MFMA mode (v_mfma_f32_32x32x2_f32): the mode that carries the <=1e-4 epsilon-prediction bar"}
         del m32, n32, o32
 
