@@ -666,9 +666,13 @@ struct Pw1Args {
 };
 
 // F32: exact-fp32 mode (see conv_pw_kernel): fp32 x / y, fp32 fragment-order weights, v_mfma_f32_32x32x2_f32; a chunk is 64 channels.
-template <bool OUT16, bool DUAL, int PXT, bool F32 = false>
+// IN32 (bf16 MFMA mode): x / x2 are fp32 tensors (the residual-stream gradient of to_out / res_conv's data gradients, res_conv's input in
+// inference): a chunk's pieces are loaded into registers during the previous chunk, rounded to bf16 once and written to the lane's slot
+// of the tile after that chunk's MFMAs (see conv_pw_kernel's IN32).
+template <bool OUT16, bool DUAL, int PXT, bool F32 = false, bool IN32 = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
     static_assert(!F32 || (!OUT16 && !DUAL), "exact-fp32 mode writes fp32");
+    static_assert(!IN32 || !F32, "fp32 input of the bf16 MFMA mode");
     constexpr int ESZ = F32 ? 4 : 2, EPP = 16 / ESZ, CKC = 16 * EPP;       // element size, elements per 16-byte piece, channels per chunk
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
@@ -703,6 +707,32 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
             glds16(src + ((size_t)(m0 + px) * ld + col) * ESZ, lds0 + (ch & 1) * XB + half * XH + (p % (PXT / 8)) * 1024);
         }
     };
+    // fp32 input: the same pieces through registers (8 channels = 32 bytes per lane and piece)
+    u32x4 XR[IN32 ? NPC : 1][2];
+    auto load_x32 = [&](int ch) {
+        const int c0 = min(ch, nchunks - 1) * CKC;
+        const bool second = c0 >= a.K1;
+        const float* src = reinterpret_cast<const float*>(second ? a.x2 : a.x);
+        const int ld = second ? a.ldx2 : a.ldx, cc = second ? c0 - a.K1 : c0;
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int p = wv + 4 * i, half = p / (PXT / 8), px = 8 * (p % (PXT / 8)) + (l >> 3);
+            const float* pf = src + (size_t)(m0 + px) * ld + cc + half * 64 + ((l & 7) ^ ((px >> 1) & 7)) * 8;
+            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                         : "=&v"(XR[i][0]), "=&v"(XR[i][1]) : "v"(pf) : "memory");
+        }
+    };
+    auto store_x32 = [&](int ch) {                   // ... rounded and written to buffer ch & 1 (behind the wait that covers the loads)
+        typedef __attribute__((address_space(3))) u32x4 lds_u32x4_;
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int p = wv + 4 * i, half = p / (PXT / 8);
+            landed16(XR[i][0]); landed16(XR[i][1]);
+            const u32x4 o = {pack_bf16(__uint_as_float(XR[i][0].x), __uint_as_float(XR[i][0].y)), pack_bf16(__uint_as_float(XR[i][0].z), __uint_as_float(XR[i][0].w)),
+                             pack_bf16(__uint_as_float(XR[i][1].x), __uint_as_float(XR[i][1].y)), pack_bf16(__uint_as_float(XR[i][1].z), __uint_as_float(XR[i][1].w))};
+            *(lds_u32x4_*)(uintptr_t)(lds0 + (ch & 1) * XB + half * XH + (p % (PXT / 8)) * 1024 + l * 16) = o;
+        }
+    };
     // weight fragments (nb, kq = 8 ch .. 8 ch + 7): 8 KB contiguous
     uint64_t wsrc;
     {
@@ -730,10 +760,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    stage_x(0);
+    if constexpr (IN32) load_x32(0); else stage_x(0);
     load_w(0, std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     static_for<0, 8>([&](auto uc) { landed16(WB[0][decltype(uc)::value]); });
+    if constexpr (IN32) store_x32(0);
     auto chunk = [&](int ch, auto setc) {
         constexpr int set = decltype(setc)::value;
         // this chunk's tile and fragments have landed (this wave's requests were waited for at the end of the previous chunk -- no
@@ -742,7 +773,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (ch + 1 < nchunks) { stage_x(ch + 1); load_w(ch + 1, std::integral_constant<int, set ^ 1>{}); }
+        if (ch + 1 < nchunks) {
+            if constexpr (IN32) load_x32(ch + 1); else stage_x(ch + 1);
+            load_w(ch + 1, std::integral_constant<int, set ^ 1>{});
+        }
         const uint32_t xb = (ch & 1) * XB;
         bf16x8 XC[2][NBLK];
 #pragma unroll
@@ -767,6 +801,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
         });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next chunk's requests (issued 32+ MFMAs ago)
         static_for<0, 8>([&](auto uc) { landed16(WB[set ^ 1][decltype(uc)::value]); });
+        if constexpr (IN32) { if (ch + 1 < nchunks) store_x32(ch + 1); }     // into the buffer every wave stopped reading a chunk ago
     };
     for (int ch = 0; ch < nchunks; ch += 2) {
         chunk(ch, std::integral_constant<int, 0>{});
@@ -823,7 +858,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
     }
 }
 
-bool pw1_ok(const MiConvDesc* d, bool f32 = false) {
+bool pw1_ok(const MiConvDesc* d, bool f32 = false, bool in32 = false) {
+    if (in32) {
+        if (d->KH != 1 || d->KW != 1 || d->pad != 0 || d->stride != 1 || d->mode != 1 || d->IH != d->OH || d->IW != d->OW) return false;
+        if (d->K % 128 || d->K1 % 128 || d->K1 <= 0 || d->K1 > d->K || d->Nc % 64 || d->ldx % 4 || (d->K1 != d->K && d->ldx2 % 4)) return false;
+        return ((long)d->N * d->OH * d->OW) % 128 == 0;
+    }
     if (f32) {
         if (d->KH != 1 || d->KW != 1 || d->pad != 0 || d->stride != 1 || d->mode != 0 || d->IH != d->OH || d->IW != d->OW) return false;
         if (d->K % 64 || d->K1 % 64 || d->K1 <= 0 || d->K1 > d->K || d->Nc % 64 || d->ldx % 4 || (d->K1 != d->K && d->ldx2 % 4)) return false;
@@ -1071,6 +1111,34 @@ extern "C" int mi_conv3x3_pw_gn_mish_sums(const MiConvDesc* d, const void* x, co
 // ---- 1x1 convs with K % 128 == 0 (see conv1x1_pw_kernel): w_frag_bf16 = the layer's slice of wfq (d->transposed = 0) or wdq (data
 //      gradient); x2: second source of a two-source layer (channels K1 .. K - 1, d->K1 % 128 == 0), else null
 extern "C" int mi_conv1x1_pw_supported(const MiConvDesc* d) { return (d && pw1_ok(d)) ? 1 : 0; }
+// fp32 x / x2 in the bf16 MFMA mode (pixel strides in floats, % 4 == 0): rounded to bf16 once while staged
+extern "C" int mi_conv1x1_pw_x32_supported(const MiConvDesc* d) { return (d && pw1_ok(d, false, true)) ? 1 : 0; }
+extern "C" int mi_conv1x1_pw_x32(const MiConvDesc* d, const float* x, const float* x2, const void* w_frag_bf16, const float* bias,
+                                 const float* residual, void* y, int out_bf16, void* stream) {
+    MI_REQUIRE(d && x && w_frag_bf16 && y, "null argument");
+    MI_REQUIRE(pw1_ok(d, false, true), "descriptor not supported (1x1, bf16 mode, K and K1 % 128 == 0, Nc % 64 == 0, N*H*W % 128 == 0)");
+    MI_REQUIRE(d->K1 == d->K || x2, "two-source split without x2");
+    MI_REQUIRE((((uintptr_t)x | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)w_frag_bf16) & 15) == 0, "operands must be 16-byte aligned");
+    MI_REQUIRE(d->ldy % 8 == 0 && (!residual || d->ldr % 4 == 0), "pixel strides: y % 8, residual % 4");
+    Pw1Args a{};
+    a.x = (const uint16_t*)x; a.x2 = (const uint16_t*)(x2 ? x2 : x); a.w = (const uint16_t*)w_frag_bf16; a.bias = bias; a.res = residual;
+    a.y = y; a.y16 = nullptr;
+    a.M = d->N * d->OH * d->OW; a.K = d->K; a.K1 = d->K1; a.Nc = d->Nc; a.ldx = d->ldx; a.ldx2 = x2 ? d->ldx2 : d->ldx;
+    a.ldy = d->ldy; a.ldr = d->ldr; a.ldy16 = 0; a.accumulate = d->accumulate;
+    a.gy = (d->Nc + 127) / 128;
+    a.gx = a.M / 64;                 // always 64-pixel tiles: the fp32 pieces of a 128-pixel tile would not fit the register budget
+    dim3 grid((unsigned)a.gx, (unsigned)a.gy);
+    if (a.gy > 1 && a.gx % 8 == 0) grid = dim3((unsigned)(a.gx * a.gy), 1, 1);
+    hipStream_t st = (hipStream_t)stream;
+#define MI_PW1X_GO(O16, PX) do { \
+        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<O16, false, PX, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); return true; }(); \
+        (void)once_; \
+        hipLaunchKernelGGL((conv1x1_pw_kernel<O16, false, PX, false, true>), grid, dim3(256), 64 * 1024, st, a); } while (0)
+    if (out_bf16) MI_PW1X_GO(true, 64); else MI_PW1X_GO(false, 64);
+#undef MI_PW1X_GO
+    MI_LAUNCH_CHECK();
+    return 0;
+}
 // exact-fp32 mode (d->mode = 0): x / x2 / y fp32, w_frag_f32 from mi_pack_weights_f32frag; K % 64 == 0, K1 % 64 == 0
 extern "C" int mi_conv1x1_pw_f32_supported(const MiConvDesc* d) { return (d && pw1_ok(d, true)) ? 1 : 0; }
 extern "C" int mi_conv1x1_pw_f32(const MiConvDesc* d, const float* x, const float* x2, const float* w_frag_f32, const float* bias,

@@ -253,6 +253,16 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
             _probe_close(e0, f"conv1x1_pw_kernel<{'true' if _b16(out) else 'false'}, {'true' if want16 else 'false'}, {px}>", 2.0 * N * H * W * Nc * K,
                          f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
         return (out, y16) if want16 else out
+    if (ksize == 1 and not _b16(x) and USE_CONV_PW and wq is not None and not want16 and gn_sums is None and K % 128 == 0
+            and _query("mi_conv1x1_pw_x32_supported", d)):
+        # fp32-stored input of a 1x1 conv (the residual-stream gradient of to_out / res_conv's data gradients, res_conv in inference)
+        e0 = _probe_open()
+        check(lib.mi_conv1x1_pw_x32(C.byref(d), _p(x), _p(x2), _p(wq), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv1x1_pw_x32")
+        if e0 is not None:
+            nb = (N * H * W * K * 4 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + K * Nc * 2)
+            _probe_close(e0, f"conv1x1_pw_kernel<{'true' if _b16(out) else 'false'}, false, 64, false, true>", 2.0 * N * H * W * Nc * K,
+                         f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} fp32 in flip{int(flip)} acc{int(accumulate)}", nb)
+        return out
     if (ksize == 3 and not _b16(x) and USE_CONV_PW and wq is not None and not want16 and d.ldx % 4 == 0 and (x2 is None or d.ldx2 % 4 == 0)):
         # fp32-stored input (the residual stream: the sampler's block1 convs): the same kernel, pieces rounded to bf16 while staged
         pt = _query("mi_conv3x3_pw_x32_tile", d)

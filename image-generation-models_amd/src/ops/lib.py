@@ -79,6 +79,8 @@ SIGNATURES = {
     "mi_debug_conv_pw_tile": [_I],
     "mi_conv3x3_pw_f32_tile": [C.POINTER(MiConvDesc)],
     "mi_conv3x3_pw_f32": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _P],
+    "mi_conv1x1_pw_x32_supported": [C.POINTER(MiConvDesc)],
+    "mi_conv1x1_pw_x32": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
     "mi_conv1x1_pw_f32_supported": [C.POINTER(MiConvDesc)],
     "mi_conv1x1_pw_f32": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "mi_pack_weights_f32frag": [_I, _P, _I, _P, _P, _P, _P],

@@ -166,6 +166,9 @@ int mi_conv3x3_pw_x32(const MiConvDesc* d, const float* x, const float* x2, cons
 int mi_conv3x3_pw_f32_tile(const MiConvDesc* d);
 int mi_conv3x3_pw_f32(const MiConvDesc* d, const float* x, const float* x2, const float* w_frag_f32, const float* bias,
                       const float* residual, float* y, void* stream);
+int mi_conv1x1_pw_x32_supported(const MiConvDesc* d);     /* ... reading fp32 x / x2 (strides in floats, % 4): the fp32 stream gradient, inference */
+int mi_conv1x1_pw_x32(const MiConvDesc* d, const float* x, const float* x2, const void* w_frag_bf16, const float* bias,
+                      const float* residual, void* y, int out_bf16, void* stream);
 int mi_conv1x1_pw_f32_supported(const MiConvDesc* d);     /* the 1x1 convs in exact-fp32 mode: K % 64 == 0, K1 % 64 == 0, Nc % 64 == 0 */
 int mi_conv1x1_pw_f32(const MiConvDesc* d, const float* x, const float* x2, const float* w_frag_f32, const float* bias,
                       const float* residual, float* y, void* stream);

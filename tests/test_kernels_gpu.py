@@ -791,6 +791,35 @@ def test_conv1x1_pw_f32(K, cfg, pw_always):
     assert _conv_launches(pw_always)[-1].startswith("conv1x1_pw_kernel<false, false,") and _conv_launches(pw_always)[-1].endswith(", true>")
 
 
+@pytest.mark.parametrize("cfg", [dict(N=8, H=32, Ci=128, Co=128), dict(N=16, H=8, Ci=512, Co=128), dict(N=8, H=8, Ci=1024, Co=256, split=512),
+                                 dict(N=4, H=16, Ci=128, Co=256), dict(N=64, H=16, Ci=384, Co=128, acc=True)])
+@pytest.mark.parametrize("out16", [False, True])
+def test_conv1x1_pw_fp32_input(K, cfg, out16, pw_always):
+    """mi_conv1x1_pw_x32: the streaming 1x1 kernel reading fp32 activations (the fp32 residual-stream gradient in the data gradients of
+    to_out / res_conv, res_conv's input in inference): bitwise mi_f32_to_bf16 + mi_conv1x1_pw (same rounding, same contraction order)."""
+    N, H, Ci, Co = cfg["N"], cfg["H"], cfg["Ci"], cfg["Co"]
+    split = cfg.get("split")
+    g = torch.Generator().manual_seed(109)
+    x = torch.randn(N, H, H, Ci, generator=g).to(DEV)
+    w = torch.randn(Co, Ci, 1, 1, generator=g) / math.sqrt(Ci)
+    flat, wd, wf, offs, wdq, wfq = _pack(K, [conv_w_storage(w.double())], frag=True)
+    bias = torch.randn(Co, generator=g).to(DEV); res = torch.randn(N, H, H, Co, generator=g).to(DEV)
+    dt = torch.bfloat16 if out16 else torch.float32
+    xa, xb = (x[..., :split].contiguous(), x[..., split:].contiguous()) if split else (x, None)
+    kw = dict(K=Ci, Nc=Co, flip=False, ksize=1, bias=bias, residual=res)
+    if cfg.get("acc") and not out16:
+        prev = torch.randn(N, H, H, Co, generator=g).to(DEV)
+        y32 = K.conv3x3_bf16w(xa, wf, x2=xb, out=prev.clone(), accumulate=True, wq=wfq, **kw)
+        y16 = K.conv3x3_bf16w(xa.bfloat16(), wf, x2=None, out=prev.clone(), accumulate=True, wq=wfq, **kw)
+    else:
+        y32 = K.conv3x3_bf16w(xa, wf, x2=xb, out_dtype=dt, wq=wfq, **kw)
+        y16 = K.conv3x3_bf16w(xa.bfloat16(), wf, x2=xb.bfloat16() if split else None, out_dtype=dt, wq=wfq, **kw)
+    torch.cuda.synchronize()
+    ls = _conv_launches(pw_always)
+    assert ls[-2].endswith(", 64, false, true>") and ls[-2].startswith("conv1x1_pw_kernel") and ls[-1].startswith("conv1x1_pw_kernel"), ls
+    assert torch.equal(y32, y16)
+
+
 def test_pack_weights_fragment_order(K):
     """The MFMA-fragment-order copies mi_conv3x3_pw streams (include/mi_ddpm.h): wfq[tap][co/32][ci/16][lane][8] and
     wdq[tap][ci/32][co/16][lane][8] for the 3x3 and 1x1 layers with 64-multiples on both sides; the others get none (zero slice)."""
