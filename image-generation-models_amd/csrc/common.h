@@ -30,12 +30,21 @@ inline constexpr long mi_knob(const char*, long dflt) { return dflt; }
 // bits, added with INTEGER atomics -- the totals do not depend on the order in which the workgroups arrive.  (fp32 atomics made the
 // fused inference path differ from run to run: 1e-7 in the sums, a few bf16 rounding flips per layer, 7e-3 in the UNet's output.)
 // A workgroup's partial sums are formed in a fixed order before they are converted.
+// A non-finite partial sum must not turn into a finite statistic (__double2ll_rn maps NaN to 0 and saturates Inf): it raises the slot to
+// MI_GSUM_POISON with an atomic max instead -- later (finite) adds move it by far less than 2^56, the reader sees |slot| >= 2^60 and
+// returns NaN, and GroupNorm's output is NaN exactly as with the two-pass kernels.
 constexpr double MI_GSUM_SCALE = 1048576.0;
+constexpr long long MI_GSUM_POISON = 1LL << 62;
 __device__ __forceinline__ void gsum_add(void* base, size_t idx, float v) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(base) + idx, (unsigned long long)__double2ll_rn((double)v * MI_GSUM_SCALE));
+    if (__builtin_isfinite(v))
+        atomicAdd(reinterpret_cast<unsigned long long*>(base) + idx, (unsigned long long)__double2ll_rn((double)v * MI_GSUM_SCALE));
+    else
+        atomicMax(reinterpret_cast<long long*>(base) + idx, MI_GSUM_POISON);
 }
 __device__ __forceinline__ double gsum_get(const void* base, size_t idx) {
-    return (double)reinterpret_cast<const long long*>(base)[idx] * (1.0 / MI_GSUM_SCALE);
+    const long long r = reinterpret_cast<const long long*>(base)[idx];
+    if (r >= (1LL << 60) || r <= -(1LL << 60)) return __builtin_nan("");
+    return (double)r * (1.0 / MI_GSUM_SCALE);
 }
 
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {

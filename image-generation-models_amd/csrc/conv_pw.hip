@@ -1173,7 +1173,7 @@ extern "C" int mi_conv1x1_pw_f32(const MiConvDesc* d, const float* x, const floa
 extern "C" int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias, const float* residual,
                              void* y, int out_bf16, void* y_bf16, int ldy16, void* stream) {
     MI_REQUIRE(d && x && w_frag_bf16 && y, "null argument");
-    MI_REQUIRE(pw1_ok(d), "descriptor not supported (1x1, K and K1 % 128 == 0, Nc % 32 == 0, N*H*W % 128 == 0)");
+    MI_REQUIRE(pw1_ok(d), "descriptor not supported (1x1, K and K1 % 128 == 0, Nc % 64 == 0, N*H*W % 128 == 0)");
     MI_REQUIRE(d->K1 == d->K || x2, "two-source split without x2");
     MI_REQUIRE((((uintptr_t)x | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)w_frag_bf16) & 15) == 0, "operands must be 16-byte aligned");
     MI_REQUIRE(d->ldy % 8 == 0 && (!residual || d->ldr % 4 == 0) && (!y_bf16 || (ldy16 % 8 == 0 && !out_bf16 && !d->accumulate)),

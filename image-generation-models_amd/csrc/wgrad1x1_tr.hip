@@ -7,7 +7,13 @@
 // and the pixel axis is streamed in steps of 64 pixels through a ring that keeps PF steps in flight (counted s_waitcnt vmcnt).
 // X is always bf16-stored (LayerNorm output, attention output, the bf16 copy of a ResnetBlock input).  dY is bf16 (d qkv) or the
 // fp32 residual-stream gradient: fp32 rows are DMA'd raw and converted LDS -> LDS by the workgroup (v_cvt_pk_bf16_f32), which
-// is also where the bias gradient is summed.  One workgroup (8 waves) = a 64 x 128 (ci x co) tile, a wave = one 32 x 32 MFMA tile.
+// is also where the bias gradient is summed.  One workgroup (8 waves) = a (64 NI) x 128 (ci x co) tile, a wave = NI 32 x 32 MFMA tiles
+// that share the dY fragment.  Round 4: NI = 2 wherever Ci % 128 == 0 -- the kernel is bound by the bytes the CUs pull through
+// L2 (every ci tile re-reads the layer's dY rows, every co tile its X rows), and a 128-wide ci tile halves the dY re-reads: to_qkv
+// 128 -> 384 moves 1536 instead of 2304 bytes per pixel, to_out 128 -> 128 (fp32 dY) 768 = its algorithmic bytes instead of 1280.
+// fp32 dY rows are no longer converted LDS -> LDS: a lane reads the 8 pixels of its output column straight from the raw rows
+// (8 conflict-free ds_read_b32: 32 lanes = 32 consecutive channels of one pixel), rounds them with four v_cvt_pk_bf16_f32 and has
+// its MFMA B fragment -- no second buffer, no second barrier per step, and the bias gradient is the sum of the same registers.
 #include "tr_common.h"
 
 namespace {
@@ -15,7 +21,7 @@ namespace {
 struct W1Args {
     const uint16_t* P; const uint16_t* P2; const void* Q;
     float* ws; float* dW; float* dbias;
-    int Ci, Cj, I1, ldp, ldp2, ldq, q32;
+    int Ci, Cj, I1, ldp, ldp2, ldq, q32, ni;
     int total, sps, splits, gx, gy, wg0, tile0, xcd_map;
 };
 struct W1Batch { W1Args p[MAXP]; int n; };
@@ -26,12 +32,13 @@ constexpr int XSTEP = 64 * 64 * 2;    // 64 pixels x 64 channels bf16
 constexpr int YSTEP = 64 * 128 * 2;   // 64 pixels x 128 channels bf16
 constexpr int YRAW = 64 * 128 * 4;    // ... as fp32 rows
 
-template <bool Q32>
+template <bool Q32, int NI>
 __device__ __forceinline__ void wgrad1_body(const W1Args& a, const int wg, uint8_t* lds_raw) {
-    // LDS: [X ring][dY ring (bf16, Q32: one converted buffer)][Q32: raw fp32 ring]
+    // LDS: [X ring: RING x NI x 8 KB][dY ring: bf16 16 KB per step, or the raw fp32 rows 32 KB per step]
     constexpr int PF = Q32 ? 2 : 3, RING = PF + 1;
-    constexpr int YOFF = RING * XSTEP;
-    constexpr int RAWOFF = YOFF + YSTEP;
+    constexpr int XSLOT = NI * XSTEP;
+    constexpr int YOFF = RING * XSLOT;
+    constexpr int YSLOT = Q32 ? YRAW : YSTEP;
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
     const int t = threadIdx.x, l = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -47,27 +54,36 @@ __device__ __forceinline__ void wgrad1_body(const W1Args& a, const int wg, uint8
         for (int xx = 0; xx < x; ++xx) rank += (W - ((xx - a.wg0) & 7) + 7) >> 3;
     }
     const int split = rank / ntiles, tile = rank - split * ntiles;
-    const int ci0 = (tile % a.gx) * 64, co0 = (tile / a.gx) * 128;
+    const int ci0 = (tile % a.gx) * (64 * NI), co0 = (tile / a.gx) * 128;
     const int sb = split * a.sps, se = min(a.total, sb + a.sps);
     const int last = a.total - 1;
 
     // DMA sources (lane -> piece as in wgrad_tr.hip); fp32 dY rows: 2 pixels of 128 channels per wave instruction, lane -> pixel
-    // lane >> 5, 4-channel piece lane & 31
-    const bool second = ci0 >= a.I1;
-    const int ldx = second ? a.ldp2 : a.ldp;
-    const uint16_t* xsrc = (second ? a.P2 : a.P) + (size_t)((l >> 2) & 7) * ldx +
-                           min((second ? ci0 - a.I1 : ci0) + (l >> 5) * 32 + (l & 3) * 8, (second ? a.Ci - a.I1 : a.I1) - 8);
+    // lane >> 5, 4-channel piece lane & 31.  The NI 64-channel regions of the ci tile are staged independently (each may lie in
+    // either source of a two-source layer: I1 % 64 == 0).
+    const uint16_t* xsrc[NI];
+    int ldx[NI];
+#pragma unroll
+    for (int r = 0; r < NI; ++r) {
+        const int cr = ci0 + 64 * r;
+        const bool second = cr >= a.I1;
+        ldx[r] = second ? a.ldp2 : a.ldp;
+        xsrc[r] = (second ? a.P2 : a.P) + (size_t)((l >> 2) & 7) * ldx[r] +
+                  min((second ? cr - a.I1 : cr) + (l >> 5) * 32 + (l & 3) * 8, (second ? a.Ci - a.I1 : a.I1) - 8);
+    }
     const uint16_t* ysrc16 = reinterpret_cast<const uint16_t*>(a.Q) + (size_t)((l >> 2) & 3) * a.ldq + min(co0 + (l >> 4) * 32 + (l & 3) * 8, a.Cj - 8);
     const float* ysrc32 = reinterpret_cast<const float*>(a.Q) + (size_t)(l >> 5) * a.ldq + min(co0 + (l & 31) * 4, a.Cj - 4);
     auto stage = [&](int step) {
         const size_t pix0 = (size_t)min(step, last) * 64;
         const int slot = step % RING;
-        glds16(xsrc + (pix0 + wv * 8) * ldx, lds0 + slot * XSTEP + wv * 1024);                    // 8 X blocks of 8 pixels, one per wave
+#pragma unroll
+        for (int r = 0; r < NI; ++r)                                                                 // 8 X blocks of 8 pixels per region, one per wave
+            glds16(xsrc[r] + (pix0 + wv * 8) * ldx[r], lds0 + slot * XSLOT + r * XSTEP + wv * 1024);
         if constexpr (Q32) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {                                                            // 32 pixel pairs, four per wave
                 const int i = wv + 8 * k;
-                glds16(ysrc32 + (pix0 + i * 2) * a.ldq, lds0 + RAWOFF + slot * YRAW + i * 1024);
+                glds16(ysrc32 + (pix0 + i * 2) * a.ldq, lds0 + YOFF + slot * YRAW + i * 1024);
             }
         } else {
 #pragma unroll
@@ -77,79 +93,78 @@ __device__ __forceinline__ void wgrad1_body(const W1Args& a, const int wg, uint8
             }
         }
     };
-    constexpr int PER_STEP = Q32 ? 5 : 3;                // DMA instructions per wave and step
+    constexpr int PER_STEP = NI + (Q32 ? 4 : 2);                // DMA instructions per wave and step
 
     const int half = l >> 5, psub = (l & 15) >> 2;
     const int lane_b = ((l >> 4) & 1) * 32 + (l & 3) * 8;
     const int fa = half * 1024 + psub * 64 + wi * 512 + lane_b;           // X: 8-pixel block 2j + half, pixel 4r + psub
     const int fb = half * 2048 + psub * 64 + wj * 256 + lane_b;           // dY: 4-pixel block 4j + 2*half + r
-    f32x16 acc;
+    const int fr = half * (8 * 512) + (wj * 32 + (l & 31)) * 4;           // raw fp32 dY: pixel 16j + 8*half + e, this lane's output column
+    f32x16 acc[NI];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // convert pass (Q32): thread -> 4-channel piece cq = t & 31, pixels (t >> 5) + 16k
-    const int cq = t & 31, pg = t >> 5;
-    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = Q32 && a.dbias != nullptr && ci0 == 0;
+    for (int r = 0; r < NI; ++r)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[r][q] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = Q32 && a.dbias != nullptr && ci0 == 0 && wi == 0;
 
     static_for<0, PF>([&](auto kc) { stage(sb + decltype(kc)::value); });
     for (int s = sb; s < se; ++s) {
         // all but the PF - 1 newest steps have landed (this wave's pieces; the barrier makes it every wave's) ...
-        if constexpr (Q32) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        static_assert(PER_STEP * (PF - 1) == (Q32 ? 5 : 6), "vmcnt immediates above");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PER_STEP * (PF - 1)) : "memory");
         __builtin_amdgcn_s_barrier();                 // ... and every wave is done with step s-1, whose slot the next request refills
         asm volatile("" ::: "memory");
         stage(s + PF);
         const int slot = s % RING;
-        uint32_t yb;
-        if constexpr (Q32) {
-            const uint8_t* raw = lds_raw + RAWOFF + slot * YRAW;
-            uint8_t* dst = lds_raw + YOFF;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int px = pg + 16 * k;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(raw + px * 512 + cq * 16);
-                bsum += v;
-                *reinterpret_cast<uint2*>(dst + (px >> 2) * 1024 + (cq >> 3) * 256 + (px & 3) * 64 + (cq & 7) * 8) =
-                    make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
-            }
-            __syncthreads();
-            yb = lds0 + YOFF;
-        } else {
-            yb = lds0 + YOFF + slot * YSTEP;
-        }
-        const uint32_t xb = lds0 + slot * XSTEP;
+        const uint32_t xb = lds0 + slot * XSLOT;
+        const uint32_t yb = lds0 + YOFF + slot * YSLOT;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bf16x8 af = tr_pair(xb + fa + j * 2048, xb + fa + j * 2048 + 256);
-            const bf16x8 bf = tr_pair(yb + fb + j * 4096, yb + fb + j * 4096 + 1024);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+            bf16x8 bf;
+            if constexpr (Q32) {
+                const uint8_t* rp = lds_raw + YOFF + slot * YRAW + fr + j * (16 * 512);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const float*>(rp + e * 512);
+                if (do_bias) bsum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                const u32x4 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+                bf = __builtin_bit_cast(bf16x8, pk);
+            } else {
+                bf = tr_pair(yb + fb + j * 4096, yb + fb + j * 4096 + 1024);
+            }
+#pragma unroll
+            for (int r = 0; r < NI; ++r) {
+                const bf16x8 af = tr_pair(xb + r * XSTEP + fa + j * 2048, xb + r * XSTEP + fa + j * 2048 + 256);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[r], 0, 0, 0);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     if (do_bias) {
-        // lanes l and l + 32 hold the same channel piece (pixels pg, pg + ... of different parity); then one atomic per wave and piece
-        bsum.x += __shfl_xor(bsum.x, 32, 64); bsum.y += __shfl_xor(bsum.y, 32, 64);
-        bsum.z += __shfl_xor(bsum.z, 32, 64); bsum.w += __shfl_xor(bsum.w, 32, 64);
-        const int c = co0 + cq * 4;
-        if (l < 32 && c < a.Cj) {
-            atomicAdd(a.dbias + c, bsum.x); atomicAdd(a.dbias + c + 1, bsum.y);
-            atomicAdd(a.dbias + c + 2, bsum.z); atomicAdd(a.dbias + c + 3, bsum.w);
-        }
+        // lanes l and l + 32 hold the same output column (pixels of the two halves of every 16-pixel step); one atomic per column
+        bsum += __shfl_xor(bsum, 32, 64);
+        const int c = co0 + wj * 32 + l;
+        if (l < 32 && c < a.Cj) atomicAdd(a.dbias + c, bsum);
     }
     if (a.splits == 1) {
-        const int ci = ci0 + wi * 32 + 4 * (l >> 5), co = co0 + wj * 32 + (l & 31);
-        if (co < a.Cj) {
-            float* o = a.dW + (size_t)ci * a.Cj + co;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * a.Cj] += acc[r];
+        for (int r = 0; r < NI; ++r) {
+            const int ci = ci0 + 64 * r + wi * 32 + 4 * (l >> 5), co = co0 + wj * 32 + (l & 31);
+            if (co < a.Cj) {
+                float* o = a.dW + (size_t)ci * a.Cj + co;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) o[(size_t)((q & 3) + 8 * (q >> 2)) * a.Cj] += acc[r][q];
+            }
         }
         return;
     }
-    float* out = a.ws + (size_t)(split * ntiles + tile) * (4 * 2048) + t * 4;
+    float* out = a.ws + (size_t)(split * ntiles + tile) * (NI * 4 * 2048) + t * 4;
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq)
-        *reinterpret_cast<f32x4*>(out + rq * 2048) = f32x4{acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]};
+    for (int r = 0; r < NI; ++r)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+            *reinterpret_cast<f32x4*>(out + r * 8192 + rq * 2048) = f32x4{acc[r][4 * rq], acc[r][4 * rq + 1], acc[r][4 * rq + 2], acc[r][4 * rq + 3]};
 }
 
 __global__ __launch_bounds__(512, 1) void wgrad1x1_tr_kernel(const W1Batch b) {
@@ -160,11 +175,12 @@ __global__ __launch_bounds__(512, 1) void wgrad1x1_tr_kernel(const W1Batch b) {
         if (q < b.n && (int)blockIdx.x >= b.p[q].wg0) p = q;
     const W1Args& a = b.p[p];
     const int wg = blockIdx.x - a.wg0;
-    if (a.q32) wgrad1_body<true>(a, wg, lds_raw); else wgrad1_body<false>(a, wg, lds_raw);
+    if (a.ni == 2) { if (a.q32) wgrad1_body<true, 2>(a, wg, lds_raw); else wgrad1_body<false, 2>(a, wg, lds_raw); }
+    else           { if (a.q32) wgrad1_body<true, 1>(a, wg, lds_raw); else wgrad1_body<false, 1>(a, wg, lds_raw); }
 }
 
-// dW[ci][co] += sum over k-slices (fixed order); grid = (4 position groups, 4 register quads, tiles with k-slices), 256 threads =
-// 2 slice groups x 128 float4 positions
+// dW[ci][co] += sum over k-slices (fixed order); grid = (4 position groups x 64-channel regions, 4 register quads, tiles with
+// k-slices), 256 threads = 2 slice groups x 128 float4 positions
 __global__ __launch_bounds__(256) void wgrad1x1_tr_reduce_kernel(const W1Batch b) {
     __shared__ f32x4 red[128];
     int pi = 0;
@@ -172,12 +188,15 @@ __global__ __launch_bounds__(256) void wgrad1x1_tr_reduce_kernel(const W1Batch b
     for (int q = 1; q < MAXP; ++q)
         if (q < b.n && b.p[q].splits > 1 && (int)blockIdx.z >= b.p[q].tile0) pi = q;
     const W1Args& a = b.p[pi];
+    const int reg = blockIdx.x >> 2;
+    if (reg >= a.ni) return;
     const int ntiles = a.gx * a.gy, splits = a.splits;
     const int it = threadIdx.x & 127, grp = threadIdx.x >> 7;
-    const int tt = blockIdx.x * 128 + it;
+    const int tt = (blockIdx.x & 3) * 128 + it;
     const int rq = blockIdx.y, tile = blockIdx.z - a.tile0;
-    const float* p = a.ws + (size_t)tile * (4 * 2048) + (size_t)rq * 2048 + tt * 4;
-    const size_t stride = (size_t)ntiles * (4 * 2048);
+    const size_t tsz = (size_t)a.ni * (4 * 2048);
+    const float* p = a.ws + (size_t)tile * tsz + (size_t)reg * 8192 + (size_t)rq * 2048 + tt * 4;
+    const size_t stride = (size_t)ntiles * tsz;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
     int sp = grp;
     for (; sp + 2 < splits; sp += 4) {
@@ -191,7 +210,7 @@ __global__ __launch_bounds__(256) void wgrad1x1_tr_reduce_kernel(const W1Batch b
     if (grp != 0) return;
     s += red[it];
     const int wv = tt >> 6, l = tt & 63;
-    const int ci = (tile % a.gx) * 64 + (wv >> 2) * 32 + 8 * rq + 4 * (l >> 5);
+    const int ci = (tile % a.gx) * (64 * a.ni) + reg * 64 + (wv >> 2) * 32 + 8 * rq + 4 * (l >> 5);
     const int co = (tile / a.gx) * 128 + (wv & 3) * 32 + (l & 31);
     if (co >= a.Cj) return;
     float* out = a.dW + (size_t)ci * a.Cj + co;
@@ -211,9 +230,16 @@ bool w1_ok(const MiWgradDesc* d, int q32) {
 
 int g_w1_phase = 0, g_w1_blocks = 0;
 
+// 64-channel regions per ci tile: 2 wherever the layer allows it (the dY rows are then re-read Ci / 128 instead of Ci / 64 times)
+int w1_ni(const MiWgradDesc* d) {
+    static const int wide = (int)mi_knob("MI_W1_NI", 2);
+    return (wide >= 2 && d->Ci % 128 == 0) ? 2 : 1;
+}
+
 void w1_plan(const MiWgradDesc* d, W1Args& a, long wgs) {
     a.Ci = d->Ci; a.Cj = d->Cj; a.I1 = d->I1;
-    a.gx = d->Ci / 64; a.gy = (d->Cj + 127) / 128;
+    a.ni = w1_ni(d);
+    a.gx = d->Ci / (64 * a.ni); a.gy = (d->Cj + 127) / 128;
     a.total = (int)((long)d->N * d->DH * d->DW / 64);
     const int ntiles = a.gx * a.gy;
     long splits = wgs / ntiles;
@@ -227,7 +253,7 @@ void w1_plan(const MiWgradDesc* d, W1Args& a, long wgs) {
 void w1_shares(int n, const MiWgradDesc* d, const int* q32, long* wgs) {
     double tot = 0, by[MAXP];
     for (int i = 0; i < n; ++i) {
-        const double tiles_ci = d[i].Ci / 64, tiles_co = (d[i].Cj + 127) / 128;
+        const double tiles_ci = d[i].Ci / (64 * w1_ni(&d[i])), tiles_co = (d[i].Cj + 127) / 128;
         by[i] = (double)d[i].N * d[i].DH * d[i].DW * (tiles_co * d[i].Ci * 2.0 + tiles_ci * d[i].Cj * (q32[i] ? 4.0 : 2.0));
         tot += by[i];
     }
@@ -235,19 +261,24 @@ void w1_shares(int n, const MiWgradDesc* d, const int* q32, long* wgs) {
     static const int greedy = (int)mi_knob("MI_W1_BALANCE", 1);
     if (greedy) {               // whole k-slices to whoever carries the most bytes per workgroup (tr_common.h)
         long tiles[MAXP];
-        for (int i = 0; i < n; ++i) tiles[i] = (long)(d[i].Ci / 64) * ((d[i].Cj + 127) / 128);
+        for (int i = 0; i < n; ++i) tiles[i] = (long)(d[i].Ci / (64 * w1_ni(&d[i]))) * ((d[i].Cj + 127) / 128);
         balance_shares(n, by, tiles, target, wgs);
         return;
     }
     for (int i = 0; i < n; ++i) {
-        const long tiles = (long)(d[i].Ci / 64) * ((d[i].Cj + 127) / 128);
+        const long tiles = (long)(d[i].Ci / (64 * w1_ni(&d[i]))) * ((d[i].Cj + 127) / 128);
         long w = (long)(target * by[i] / tot + 0.5);
         w = w / tiles * tiles;
         wgs[i] = w < tiles ? tiles : w;
     }
 }
 
-size_t w1_ws_floats(const W1Args& a) { return a.splits > 1 ? (size_t)a.splits * a.gx * a.gy * 4 * 2048 : 0; }
+size_t w1_ws_floats(const W1Args& a) { return a.splits > 1 ? (size_t)a.splits * a.gx * a.gy * a.ni * 4 * 2048 : 0; }
+// dynamic LDS of one problem: X ring + dY ring (see wgrad1_body)
+size_t w1_lds(const W1Args& a) {
+    const size_t ring = a.q32 ? 3 : 4;
+    return ring * ((size_t)a.ni * XSTEP + (a.q32 ? YRAW : YSTEP));
+}
 
 }  // namespace
 
@@ -277,18 +308,16 @@ extern "C" int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
     W1Batch b;
     b.n = n;
     long wgs[MAXP];
-    bool any32 = false;
     for (int i = 0; i < n; ++i) {
         MI_REQUIRE(w1_ok(&descs[i], q_is_fp32[i]), "descriptor not supported by the LDS-DMA 1x1 weight-gradient kernel");
         MI_REQUIRE(P[i] && Q[i] && dW[i], "null operand");
         MI_REQUIRE(descs[i].I1 == descs[i].Ci || (P2 && P2[i]), "two-source split without P2");
         MI_REQUIRE((((uintptr_t)P[i] | (uintptr_t)Q[i] | (uintptr_t)((P2 && P2[i]) ? P2[i] : P[i])) & 15) == 0, "operands must be 16-byte aligned");
         MI_REQUIRE(!(dbias && dbias[i]) || q_is_fp32[i], "the bias gradient is summed in the fp32 conversion pass (fp32 dY only)");
-        any32 = any32 || q_is_fp32[i];
     }
     w1_shares(n, descs, q_is_fp32, wgs);
-    size_t off = 0;
-    int wg = 0, tile = 0;
+    size_t off = 0, lds = 0;
+    int wg = 0, tile = 0, nimax = 1;
     for (int i = 0; i < n; ++i) {
         W1Args& a = b.p[i];
         w1_plan(&descs[i], a, wgs[i]);
@@ -300,7 +329,8 @@ extern "C" int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         static const int xcd_env = (int)mi_knob("MI_W1_XCD", 1);
         a.xcd_map = xcd_env && a.gx * a.gy > 1 && a.splits > 1;
         a.wg0 = wg; wg += a.gx * a.gy * a.splits;
-        a.tile0 = tile; if (a.splits > 1) tile += a.gx * a.gy;
+        a.tile0 = tile; if (a.splits > 1) { tile += a.gx * a.gy; nimax = a.ni > nimax ? a.ni : nimax; }
+        lds = w1_lds(a) > lds ? w1_lds(a) : lds;
     }
     MI_REQUIRE(off == 0 || (workspace && ((uintptr_t)workspace & 15) == 0 && ws_bytes >= off * sizeof(float)),
                "workspace too small (mi_conv1x1_wgrad_tr_batch_workspace)");
@@ -310,10 +340,8 @@ extern "C" int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         return true;
     }();
     (void)once;
-    const size_t lds16 = (size_t)4 * XSTEP + (size_t)4 * YSTEP, lds32 = (size_t)3 * XSTEP + YSTEP + (size_t)3 * YRAW;
-    const size_t lds = any32 && lds32 > lds16 ? lds32 : lds16;
     if (g_w1_phase != 2) hipLaunchKernelGGL(wgrad1x1_tr_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);
-    if (g_w1_phase != 1 && tile > 0) hipLaunchKernelGGL(wgrad1x1_tr_reduce_kernel, dim3(4, 4, tile), dim3(256), 0, st, b);
+    if (g_w1_phase != 1 && tile > 0) hipLaunchKernelGGL(wgrad1x1_tr_reduce_kernel, dim3(4 * nimax, 4, tile), dim3(256), 0, st, b);
     MI_LAUNCH_CHECK();
     return 0;
 }

@@ -20,8 +20,8 @@ MODE_FP32, MODE_BF16 = 0, 1
 
 
 def debug_knob(name: str, default: str) -> str:
-    """Experiment / A-B switches (kernel picks, copies on or off): honoured only when MI_DEBUG_KNOBS=1 is set as well (tools/ do
-    that), so that a stray variable cannot put a production run on a path the test suite does not cover.  The mode selectors a
+    """Experiment / A-B switches (kernel picks, copies on or off): honoured only when MI_DEBUG_KNOBS=1 is set as well (the tools/
+    that A/B them, e.g. tools/sample_steps.py, set it), so that a stray variable cannot put a production run on a path the test suite does not cover.  The mode selectors a
     user is meant to set are read directly: MI_DDPM_MODE, MI_DDPM_STORAGE, MI_DDPM_FUSE_GN, MI_DDPM_GRAPH, MI_DDPM_LIB,
     MI_CONV_AUTO (halo-only fallback, covered by a subprocess test), MI_DDP_BUCKET_MB, MI_DIST_BACKEND."""
     if os.environ.get("MI_DEBUG_KNOBS") == "1":
@@ -539,6 +539,7 @@ def conv1x1_f32(x, wq32, *, K, Nc, flip, x2=None, bias=None, residual=None, out=
     return out
 
 
+@functools.lru_cache(maxsize=None)
 def small_cin_supported(ks, Cin, Cout, wgrad=False):
     """The 3-channel-input kernels (mi_conv_small_cin_*): which (kernel size, Cin, Cout) they take."""
     if ks not in (1, 3) or not 1 <= Cin <= 4:

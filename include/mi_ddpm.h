@@ -151,7 +151,7 @@ int mi_pack_weights_bf16(int nent, const void* entries_dev, int total_tiles, con
 /* ---- 3x3 conv / data gradient for bf16-stored activations with wave-private weight streams (conv_pw.hip; replaces the per-tap
  * workgroup barrier of the kernels above: reference op src/models/ddpm.py:116).  w_frag_bf16 = the layer's slice of wfq (forward) or
  * wdq (d->transposed = 1: data gradient, flipped taps).  Needs W in {8, 16, 32} with 128-pixel row tiles (N*H*W % 128 == 0),
- * K % 64 == 0, K1 % 64 == 0, Nc % 32 == 0, ldy % 4 == 0. */
+ * K % 64 == 0, K1 % 64 == 0, Nc % 64 == 0, ldy % 8 == 0 (pw_ok / pw_launch in conv_pw.hip are the authority). */
 int mi_conv3x3_pw_supported(const MiConvDesc* d);
 /* ... for fp32 x / x2 (the residual stream as it is; pixel strides in floats, % 4 == 0): rounded to bf16 once while staged; gsum
  * (optional): the GroupNorm sums of mi_conv3x3_pw_gnsums */

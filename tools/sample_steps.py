@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """N hipGraph denoise steps at B=64 and nothing else (for rocprofv3 --kernel-trace --stats)."""
 import os, sys
+os.environ.setdefault("MI_DEBUG_KNOBS", "1")      # MI_DDPM_SHADOW & co. are A/B switches: honoured only with this set (functional.debug_knob)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "image-generation-models_amd")]
 import torch
@@ -20,4 +21,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(n):
     gs.z.normal_(); gs.graph.replay()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f"B={B} fuse_gn={os.environ.get('MI_DDPM_FUSE_GN', '1')} shadow={os.environ.get('MI_DDPM_SHADOW', '1')}: {n / dt:.1f} denoise steps/s ({dt / n * 1e3:.3f} ms/step)")
+print(f"B={B} fuse_gn={os.environ.get('MI_DDPM_FUSE_GN', 'auto')} shadow={os.environ.get('MI_DDPM_SHADOW', '1')}: {n / dt:.1f} denoise steps/s ({dt / n * 1e3:.3f} ms/step)")
