@@ -47,6 +47,15 @@ __device__ __forceinline__ double gsum_get(const void* base, size_t idx) {
     return (double)r * (1.0 / MI_GSUM_SCALE);
 }
 
+// Wave priority of the library's kernels.  A collective's kernel (RCCL, priority 0) that shares a CU with a tile of one of ours takes issue
+// slots from that tile's waves; the tile then finishes late and -- one round of tiles per launch -- so does the whole launch
+// (tools/cu_hog.py: 8 foreign workgroups cost the step +13..36 %).  With the compute waves at a higher priority the co-runner gets the
+// slots they leave, not half of them.  Waves of one kernel all run at the same priority, so nothing changes when the chip is ours.
+#ifndef MI_PRIO
+#define MI_PRIO 2
+#endif
+#define MI_PRIO_UP() __builtin_amdgcn_s_setprio(MI_PRIO)
+
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     bf16x2 p = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(uint32_t, p);

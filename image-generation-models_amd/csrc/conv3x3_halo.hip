@@ -114,6 +114,7 @@ template <int BM, int WAVES = (BM == 256 ? 8 : 4)> struct HaloCfg {
 // workgroup (one workgroup per CU: nobody else to fill the gap) begin at the same moment.
 template <int BM, int CK, int KS, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4), bool FUSE = false, bool PIPE = false>
 __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(const HaloArgs a) {
+    MI_PRIO_UP();
     constexpr bool IN16 = IO & 1, OUT16 = IO & 2;
     static_assert(!PIPE || (KS == 3 && !SK && CK == 64), "PIPE: 3x3, 64-channel chunks");
     constexpr int WS = PIPE ? 3 : 2;               // weight slots

@@ -118,6 +118,7 @@ constexpr int pw_lds(int pt) { return (pt == 128 ? 64 : 32) * 1024 + 2048; }   /
 // the bf16 one, so this variant is bound by the matrix pipe, not by the issue of loads.
 template <bool OUT16, int VAR = 0, int ABL = 0, int PT = 128, bool IN32 = false, bool F32 = false>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
+    MI_PRIO_UP();
     constexpr bool FUSE = VAR >= 2, GNS = VAR == 1;
     static_assert(!IN32 || (!FUSE && ABL == 0), "fp32 input: the plain conv and the variant with GroupNorm sums");
     static_assert(!F32 || (VAR == 0 && ABL == 0 && !IN32 && !OUT16), "exact-fp32 mode: the plain conv, fp32 in and out");
@@ -671,6 +672,7 @@ struct Pw1Args {
 // of the tile after that chunk's MFMAs (see conv_pw_kernel's IN32).
 template <bool OUT16, bool DUAL, int PXT, bool F32 = false, bool IN32 = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
+    MI_PRIO_UP();
     static_assert(!F32 || (!OUT16 && !DUAL), "exact-fp32 mode writes fp32");
     static_assert(!IN32 || !F32, "fp32 input of the bf16 MFMA mode");
     constexpr int ESZ = F32 ? 4 : 2, EPP = 16 / ESZ, CKC = 16 * EPP;       // element size, elements per 16-byte piece, channels per chunk

@@ -238,6 +238,7 @@ __global__ void u8_gather_norm_kernel(int B, int C, int H, int W, const uint8_t*
 // fp32 [M][C] (row stride ldx) -> bf16 [M][C] (row stride ldy), round-to-nearest-even: the rounding every bf16-MFMA kernel applies
 // when it stages an fp32 activation, applied once for all of its consumers
 __global__ void f32_to_bf16_kernel(size_t M, int C4, const float* __restrict__ x, int ldx, uint16_t* __restrict__ y, int ldy) {
+    MI_PRIO_UP();
     const size_t tot = M * C4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
         const size_t m = i / C4; const int c = (int)(i % C4) * 4;
@@ -254,6 +255,7 @@ __global__ void f32_to_bf16_kernel(size_t M, int C4, const float* __restrict__ x
 template <bool CVT, bool SUM, bool ATOMIC>
 __global__ __launch_bounds__(256) void cvt_colsum_kernel(int M, int C4, const float* __restrict__ x, int ldx, uint16_t* __restrict__ y, int ldy,
                                                          float* __restrict__ out, int rows_per_block) {
+    MI_PRIO_UP();
     __shared__ float4 red[256];
     const int nr = 256 / C4, tc = threadIdx.x % C4, tr = threadIdx.x / C4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -480,7 +482,9 @@ extern "C" int mi_gather_rows(int B, int C, const float* table, const int64_t* i
 // training step behaves while another stream's kernel (a collective, in production) holds part of the chip.  Not part of the ABI.
 namespace {
 // mode 0: ALU spin (worst case for co-resident waves); mode 1: streaming copy loop over `buf` (2 x bytes per workgroup), which is
-// closer to what a collective's kernel does: mostly waiting on memory
+// closer to what a collective's kernel does: mostly waiting on memory -- but at full tilt for the whole step, i.e. gigabytes per step
+// where a gradient all-reduce moves ~0.2 GB in and ~0.2 GB out; mode 2: the same copy with the duty cycle of that all-reduce (it streams
+// for 0.5 ms of every 5 ms and sleeps in between, the workgroups staying resident as a collective's do while they wait for peers)
 __global__ __launch_bounds__(256) void spin_kernel(unsigned long long ticks, float* buf, size_t per_wg, int mode) {
     const unsigned long long t0 = wall_clock64();
     if (mode == 0) {
@@ -494,6 +498,14 @@ __global__ __launch_bounds__(256) void spin_kernel(unsigned long long ticks, flo
     }
     float4* src = reinterpret_cast<float4*>(buf + (size_t)blockIdx.x * 2 * per_wg);
     float4* dst = src + per_wg / 4;
+    if (mode == 2) {
+        while (wall_clock64() - t0 < ticks) {
+            const unsigned long long p0 = wall_clock64();
+            for (size_t i = threadIdx.x; i < per_wg / 4 && wall_clock64() - p0 < 50000ull; i += 256) { float4 v = src[i]; v.x += 1.f; dst[i] = v; }
+            while (wall_clock64() - p0 < 500000ull && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+        }
+        return;
+    }
     while (wall_clock64() - t0 < ticks)
         for (size_t i = threadIdx.x; i < per_wg / 4; i += 256) { float4 v = src[i]; v.x += 1.f; dst[i] = v; }
 }

@@ -56,6 +56,7 @@ __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
 
 template <int MODE, int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+    MI_PRIO_UP();
     using E = typename LdsElem<MODE>::type;
     constexpr int PITCH = LdsElem<MODE>::PITCH;
     constexpr int A_IT = BM / 32;          // float4 per thread for the A tile (BM x 32)
@@ -342,6 +343,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // bytes, no pack on the way into LDS.
 template <int BM, int BN, bool IN16>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void igemm_fast_kernel(const IgemmArgs a, const FastTaps tt) {
+    MI_PRIO_UP();
     constexpr int CK = IN16 ? 64 : 32;     // channels per stage
     constexpr int KS = CK / 16;            // MFMA k-steps per stage
     constexpr int PITCH = CK + 8;

@@ -207,6 +207,7 @@ __device__ __forceinline__ f32x16 tile_mm(const float* A, int ldA, int p0, int n
 // 4096 pixels behind 8 KB of loads in flight; sliced, every CU holds several workgroups and the loads of all of them.
 template <bool T16, int PH>     // T16: qkv and out are stored as bf16
 __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
+    MI_PRIO_UP();
     __shared__ float scratch[4 * 32 * 33], scratch2[PH == 1 ? 1 : 4 * 32 * 33];
     __shared__ float ctx_s[32 * 33];
     __shared__ float kmax_s[32], ksum_s[32], wsum[4 * 32], pmax[32 * 32];
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
 // per-pixel gradients of the slice.
 template <bool T16, int PH>     // T16: qkv, dout and dqkv are stored as bf16
 __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
+    MI_PRIO_UP();
     __shared__ float scratch[4 * 32 * 33];
     __shared__ float ctx_s[32 * 33], dctx_s[32 * 33];
     __shared__ float stage_s[4 * 32 * 33];

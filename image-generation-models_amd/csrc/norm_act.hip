@@ -11,6 +11,9 @@
 #ifndef MI_GN_UB0
 #define MI_GN_UB0 4      // rows per load batch of the uncached GroupNorm backward loops
 #endif
+#ifndef MI_GN_PD
+#define MI_GN_PD 2       // units whose raw loads are in flight ahead of the one being worked on (pipelined GroupNorm backward)
+#endif
 #ifndef MI_GN_WAVES
 #define MI_GN_WAVES 4     // waves per SIMD the packed-cache GroupNorm backward is compiled for
 #endif
@@ -79,6 +82,7 @@ struct GnArgs {
 // channels [u*VEC, u*VEC+VEC); pixel rows pr = t / W, step PP = 256 / W.
 template <int VEC, int MAXU, int IO = 0>     // IO bit 0: x is bf16, bit 1: y is bf16
 __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
+    MI_PRIO_UP();
     constexpr bool X16 = IO & 1, Y16 = IO & 2;
     __shared__ float red[8];
     // Workgroup -> (sample, group).  Consecutive workgroup ids go to different XCDs (id % 8), each with its own L2, while
@@ -174,8 +178,11 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
 }
 
 // Backward of y = mish(xhat*gamma+beta) + temb + res wrt x (the conv output), gamma, beta, temb.
-template <int VEC, int MAXU, int IO = 0>     // IO bit 0: x is bf16, bit 1: dx is written as bf16, bit 2: dout is bf16
+// FULL: the slice is exactly MAXU units per thread (HW == MAXU * 256 / (Cg / VEC)): no guards, and the packed-cache path runs as a
+// straight-line software pipeline (see below).
+template <int VEC, int MAXU, int IO = 0, bool FULL = false>     // IO bit 0: x is bf16, bit 1: dx is written as bf16, bit 2: dout is bf16
 __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? MI_GN_WAVES : 1)) void gn_mish_bwd_kernel(const GnArgs a) {
+    MI_PRIO_UP();
     constexpr bool X16 = IO & 1, DX16 = IO & 2, DO16 = IO & 4;
     __shared__ float part[4][256 * VEC];
     __shared__ float chs[4][128];
@@ -188,6 +195,7 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? MI_GN_WA
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         g = slot % a.G; n = xcd + 8 * (slot / a.G);
     }
+    n = __builtin_amdgcn_readfirstlane(n); g = __builtin_amdgcn_readfirstlane(g);      // wave-uniform: slice bases live in SGPRs
     const int ng = n * a.G + g;
     const int W = a.Cg / VEC, PP = 256 / W;
     const int t = threadIdx.x, u = t % W, pr = t / W;
@@ -249,6 +257,78 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? MI_GN_WA
                 cx[k].v[j] = h; cd[k].v[j] = dzz;
                 sA[j] += dzz; sD[j] += dzz * h; sT[j] += dd; sB[j] += h;
             }
+        }
+    } else if constexpr (PKC && FULL) {
+        // Round 4.  The guarded form below is one HBM round trip per unit and thread and, for an 8-unit slice in the 16-unit
+        // instantiation, eight dead branches.  With every unit live the loop is straight-line, so unit k + 2's raw loads are issued
+        // before unit k is worked on (two units = 8-12 registers in flight, counted vmcnt waits), and a scheduling barrier after
+        // every unit keeps the compiler from interleaving the units' exp / rcp chains (which is what spilled when all loads were
+        // hoisted).  Measured (B = 128, bf16): 256 channels @16x16 (8 units) 18.5 -> 13.7 us.  The 16-unit form needs ~160 registers
+        // against the 128 that four waves per SIMD leave: 70-230 bytes of scratch per lane, or its first units parked in LDS -- both
+        // measured equal to the guarded form at level 0 (27.4-28.9 us), which therefore keeps the guarded one.
+        constexpr int DQ = DO16 ? VEC / 2 : VEC;                   // dwords of dout per unit
+        constexpr int PD = MI_GN_PD;                              // prefetch distance (units)
+        uint32_t rx[PD + 1][VEC / 2], rd[PD + 1][DQ];
+        // running 32-bit element offsets (one v_add per fetch; opaque so that the 16 units' addresses are not all precomputed)
+        uint32_t xo = (uint32_t)(pr * a.ldx + cu), qo = (uint32_t)(pr * a.lddo + cu);
+        const uint32_t xstep = (uint32_t)(PP * a.ldx), qstep = (uint32_t)(PP * a.lddo);
+        auto fetch = [&](int slot) {
+            const uint16_t* xp = xg + xo;
+            if constexpr (VEC == 8) {
+                const uint4 w = *reinterpret_cast<const uint4*>(xp);
+                rx[slot][0] = w.x; rx[slot][1] = w.y; rx[slot][2] = w.z; rx[slot][3] = w.w;
+            } else {
+                const uint2 w = *reinterpret_cast<const uint2*>(xp);
+                rx[slot][0] = w.x; rx[slot][1] = w.y;
+            }
+            if constexpr (DO16) {
+                const uint16_t* dp = reinterpret_cast<const uint16_t*>(dg) + qo;
+                if constexpr (VEC == 8) {
+                    const uint4 w = *reinterpret_cast<const uint4*>(dp);
+                    rd[slot][0] = w.x; rd[slot][1] = w.y; rd[slot][2] = w.z; rd[slot][3] = w.w;
+                } else {
+                    const uint2 w = *reinterpret_cast<const uint2*>(dp);
+                    rd[slot][0] = w.x; rd[slot][1] = w.y;
+                }
+            } else {
+                const float* dp = reinterpret_cast<const float*>(dg) + qo;
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {
+                    const uint4 w = *reinterpret_cast<const uint4*>(dp + 4 * q);
+                    rd[slot][4 * q] = w.x; rd[slot][4 * q + 1] = w.y; rd[slot][4 * q + 2] = w.z; rd[slot][4 * q + 3] = w.w;
+                }
+            }
+            xo += xstep; qo += qstep;
+            asm volatile("" : "+v"(xo), "+v"(qo));
+        };
+        static_assert(MAXU >= PD, "prefetch distance");
+#pragma unroll
+        for (int k = 0; k < PD; ++k) fetch(k);
+#pragma unroll
+        for (int k = 0; k < MAXU; ++k) {
+            if (k + PD < MAXU) fetch((k + PD) % (PD + 1));
+            const int sl = k % (PD + 1);
+#pragma unroll
+            for (int j2 = 0; j2 < VEC / 2; ++j2) {
+                px[k][j2] = rx[sl][j2];
+                float dzp[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * j2 + e;
+                    const float q = __uint_as_float(e ? (rx[sl][j2] & 0xffff0000u) : (rx[sl][j2] << 16));
+                    const float dv = DO16 ? __uint_as_float(e ? (rd[sl][j2] & 0xffff0000u) : (rd[sl][j2] << 16)) : __uint_as_float(rd[sl][DO16 ? 0 : j]);
+                    const float h = (q - mean) * rstd, z = h * ga[j] + be[j];
+                    const float dzz = dv * mish_grad_fast_f(z);
+                    dzp[e] = dzz;
+                    sA[j] += dzz; sD[j] += dzz * h; sT[j] += dv; sB[j] += h;
+                }
+                pd[k][j2] = pack_bf16(dzp[0], dzp[1]);
+            }
+            // pin the unit's work here: instruction selection orders a basic block by data dependences only, and without these
+            // the four accumulation chains of all units sink below the last unit (every h / dz kept alive: 700 bytes of spills)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) asm volatile("" : "+v"(sA[j]), "+v"(sD[j]), "+v"(sT[j]), "+v"(sB[j]));
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else if constexpr (PKC) {
         // (Issuing every load of the slice -- or batches of 2..8 units -- before the first use, as the small-slice path above does,
@@ -357,10 +437,11 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? MI_GN_WA
         vstore<VEC, DX16>(a.dx, dxoff + (size_t)p * a.lddx, o);
     };
     if constexpr (PKC) {
+        uint32_t so = (uint32_t)(pr * a.lddx + cu);
 #pragma unroll
         for (int k = 0; k < MAXU; ++k) {
             const int p = pr + k * PP;
-            if (p < a.HW) {
+            if (FULL || p < a.HW) {
                 V<VEC> xh, dz;
 #pragma unroll
                 for (int j2 = 0; j2 < VEC / 2; ++j2) {
@@ -372,7 +453,13 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? MI_GN_WA
                 V<VEC> o;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) o.v[j] = rstd * (dz.v[j] * ga[j] - (s1 + xh.v[j] * s2) * icnt);
-                vstore<VEC, DX16>(dxg, (size_t)(uint32_t)(p * a.lddx + cu), o);
+                if constexpr (FULL) {
+                    vstore<VEC, DX16>(dxg, (size_t)so, o);
+                    so += (uint32_t)(PP * a.lddx);
+                    asm volatile("" : "+v"(so));
+                } else {
+                    vstore<VEC, DX16>(dxg, (size_t)(uint32_t)(p * a.lddx + cu), o);
+                }
             }
         }
     } else if constexpr (MAXU > 0) {
@@ -441,6 +528,7 @@ template <int LPX> __device__ __forceinline__ float group_sum(float v) {
 // LPX lanes per pixel (32 when C <= 128: two pixels per wave, else 64), up to MAXV float4 per lane
 template <bool Y16, int LPX, int MAXV>      // Y16: y is written as bf16 (it only feeds the to_qkv 1x1 conv)
 __global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const LnArgs a) {
+    MI_PRIO_UP();
     constexpr int PPW = 64 / LPX;
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lp = l % LPX;
     const int nq = a.C / 4;
@@ -485,6 +573,7 @@ __global__ __launch_bounds__(256) void chan_ln_fwd_kernel(const LnArgs a) {
 // dh = dy*g, S = sum dh*xc.
 template <bool DY16, int LPX, int MAXV>     // DY16: dy (the gradient of the LayerNorm output) is stored as bf16
 __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
+    MI_PRIO_UP();
     constexpr int PPW = 64 / LPX;
     __shared__ float red[2][4][LPX * MAXV * 4];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lp = l % LPX;
@@ -605,6 +694,14 @@ static bool gn_vec8(const GnArgs& a, int io_all16, std::initializer_list<int> ld
 #define GN_DISPATCH_IO(KERNEL, IOV) GN_DISPATCH_IO_(KERNEL, IOV, false)
 #define GN_DISPATCH_FWD_IO(KERNEL, IOV) GN_DISPATCH_IO_(KERNEL, IOV, true)   /* forward also caches 32-unit slices (64x64 images, C/G = 8) */
 #define GN_DISPATCH(KERNEL) GN_DISPATCH_IO(KERNEL, 0)
+/* backward, bf16 x: slices of exactly 8 units per thread take the pipelined instantiation (FULL) */
+#define GN_DISPATCH_BWD16(IOV)                                                                                          \
+    do {                                                                                                                \
+        const int ppx = 256 / (a.Cg / 4);                                                                               \
+        static const int full_on = (int)mi_knob("MI_GN_FULL", 1);                                                       \
+        if (full_on && vec == 4 && d->HW == 8 * ppx) hipLaunchKernelGGL((gn_mish_bwd_kernel<4, 8, IOV, true>), dim3(a.N * a.G), dim3(256), 0, st, a); \
+        else GN_DISPATCH_IO(gn_mish_bwd_kernel, IOV);                                                                   \
+    } while (0)
 
 extern "C" int mi_gn_mish_fwd(const MiGnDesc* d, const float* x, const float* gamma, const float* beta,
                               const float* temb, int ldt, const float* residual, float* y, float* stats,
@@ -752,13 +849,13 @@ extern "C" int mi_gn_mish_bwd_io(const MiGnDesc* d, const void* x, const float* 
     hipStream_t st = (hipStream_t)stream;
     switch (io) {
         case 0: GN_DISPATCH_IO(gn_mish_bwd_kernel, 0); break;
-        case 1: GN_DISPATCH_IO(gn_mish_bwd_kernel, 1); break;
+        case 1: GN_DISPATCH_BWD16(1); break;
         case 2: GN_DISPATCH_IO(gn_mish_bwd_kernel, 2); break;
-        case 3: GN_DISPATCH_IO(gn_mish_bwd_kernel, 3); break;
+        case 3: GN_DISPATCH_BWD16(3); break;
         case 4: GN_DISPATCH_IO(gn_mish_bwd_kernel, 4); break;
-        case 5: GN_DISPATCH_IO(gn_mish_bwd_kernel, 5); break;
+        case 5: GN_DISPATCH_BWD16(5); break;
         case 6: GN_DISPATCH_IO(gn_mish_bwd_kernel, 6); break;
-        default: GN_DISPATCH_IO(gn_mish_bwd_kernel, 7); break;
+        default: GN_DISPATCH_BWD16(7); break;
     }
     MI_LAUNCH_CHECK();
     return 0;

@@ -38,6 +38,7 @@ __device__ __forceinline__ float4 ldv(const float* p, int nvalid, bool vec) {
 
 template <int MODE, int BI, int BJ>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    MI_PRIO_UP();
     using E = typename WElem<MODE>::type;
     constexpr int PITCH = WElem<MODE>::PITCH;
     constexpr int P_IT = BI / 64, Q_IT = BJ / 64;      // channel quads per thread
@@ -212,6 +213,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int BI, int BJ>
 __global__ __launch_bounds__(256, 2) void wgrad_fast_kernel(const WgradArgs a, int dw_sh, int dhw_sh) {
+    MI_PRIO_UP();
     constexpr int PITCH = 40;
     constexpr int P_IT = BI / 64, Q_IT = BJ / 64;      // channel quads per thread
     constexpr int WI = BI / 2, WJ = BJ / 2;

@@ -168,6 +168,7 @@ __device__ __forceinline__ void wgrad1_body(const W1Args& a, const int wg, uint8
 }
 
 __global__ __launch_bounds__(512, 1) void wgrad1x1_tr_kernel(const W1Batch b) {
+    MI_PRIO_UP();
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     int p = 0;
 #pragma unroll
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(512, 1) void wgrad1x1_tr_kernel(const W1Batch b) {
 // dW[ci][co] += sum over k-slices (fixed order); grid = (4 position groups x 64-channel regions, 4 register quads, tiles with
 // k-slices), 256 threads = 2 slice groups x 128 float4 positions
 __global__ __launch_bounds__(256) void wgrad1x1_tr_reduce_kernel(const W1Batch b) {
+    MI_PRIO_UP();
     __shared__ f32x4 red[128];
     int pi = 0;
 #pragma unroll

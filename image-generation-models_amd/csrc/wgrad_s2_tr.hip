@@ -252,6 +252,7 @@ __device__ __forceinline__ void wgrad_s2_body(const S2Args& a, const int wg, uin
 }
 
 __global__ __launch_bounds__(512, 1) void wgrad_s2_tr_kernel(const S2Batch b) {
+    MI_PRIO_UP();
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     int p = 0;
 #pragma unroll
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_s2_tr_kernel(const S2Batch b) {
 // problems that have k-slices); a workgroup = G slice groups x (256 / G) float4 positions of one slot.
 template <int G>
 __global__ __launch_bounds__(256) void wgrad_s2_reduce_kernel(const S2Batch b) {
+    MI_PRIO_UP();
     constexpr int IB = 256 / G;
     __shared__ f32x4 red[G][IB];
     int pi = 0;

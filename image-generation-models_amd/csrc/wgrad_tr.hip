@@ -241,6 +241,7 @@ __device__ __forceinline__ void wgrad_tr_body(const TrArgs& a, const int wg, uin
 }
 
 __global__ __launch_bounds__(512, 1) void wgrad_tr_kernel(const TrBatch b) {
+    MI_PRIO_UP();
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     int p = 0;
 #pragma unroll
@@ -409,6 +410,7 @@ __device__ __forceinline__ void wgrad_tr32_body(const TrArgs& a, const int wg, u
 }
 
 __global__ __launch_bounds__(512, 1) void wgrad_tr32_kernel(const TrBatch b) {
+    MI_PRIO_UP();
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     int p = 0;
 #pragma unroll
@@ -429,6 +431,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tr32_kernel(const TrBatch b) {
 // independent 16-byte loads in flight.
 template <int G>
 __global__ __launch_bounds__(256) void wgrad_tr_reduce_kernel(const TrBatch b) {
+    MI_PRIO_UP();
     constexpr int IB = 256 / G;
     __shared__ f32x4 red[G][IB];
     int pi = 0;

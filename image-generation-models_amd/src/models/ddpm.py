@@ -509,7 +509,7 @@ class Unet(nn.Module):
             return ent[1]
 
         def conv(inp, pre, k, stride=1, pad=0, x2=None, residual=None, transposed_conv=False, bias=True, out_dtype=torch.float32,
-                 gn_sums=None, want16=False):
+                 gn_sums=None, want16=False, soft=False):
             w = sv[pre + "weight"]
             kh, kw, ci, co = w.shape
             if x2 is None and residual is None and stride == 1 and not transposed_conv:
@@ -526,6 +526,8 @@ class Unet(nn.Module):
                         sh[id(y[0])] = y
                         return y[0]
                     return y
+                if soft:                            # the caller has another operand to offer (res_conv: the fp32 tensors)
+                    return None
             assert not want16, "the bf16 copy rides in the tile kernel's epilogue only"
             assert gn_sums is None, "GroupNorm sums ride in the tile kernel's epilogue only"
             if mode == K.MODE_FP32 and k == 3 and stride == 1 and not transposed_conv and out_dtype == torch.float32:
@@ -605,9 +607,15 @@ class Unet(nn.Module):
                                         out_dtype=BF if lo16 else torch.float32)
                 c2 = conv(h1, pre + "block2.block.0.", 3, 1, 1, out_dtype=BF if lo16 else torch.float32)
             # res_conv reads the bf16 copies where block1's conv does (the tile kernels round an fp32 input to bf16 while staging it: the
-            # same numbers, half the bytes, and the streaming 1x1 kernel takes bf16 operands only)
-            rc_in, rc_x2 = (inp_c, x2_c) if (inp_c is not inp and inp_c.dtype == BF and (x2 is None or x2_c is not None)) else (inp, x2)
-            r = conv(rc_in, pre + "res_conv.", 1, x2=rc_x2) if blk["res"] else inp
+            # same numbers, half the bytes
+            # -- where the 1x1 tile kernel takes the layer; otherwise the fp32 tensors go to the generic kernel as before)
+            r = inp
+            if blk["res"]:
+                r = None
+                if inp_c is not inp and inp_c.dtype == BF and (x2 is None or x2_c is not None):
+                    r = conv(inp_c, pre + "res_conv.", 1, x2=x2_c, soft=True)
+                if r is None:
+                    r = conv(inp, pre + "res_conv.", 1, x2=x2)
             if want_out16 and (use_sh or (eval16 and out16_in_eval)) and co % 32 == 0:
                 out, st2, out16 = K.gn_mish_fwd(c2, sv[pre + "block2.block.1.weight"], sv[pre + "block2.block.1.bias"], residual=r, want16=True)
                 sh[id(out)] = (out, out16)

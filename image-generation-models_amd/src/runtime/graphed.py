@@ -84,16 +84,14 @@ class SegmentedGraphedTrainStep:
         self.logged = {}
 
     def _begin(self):
-        from ..ops import functional as K
         self._cur = torch.cuda.CUDAGraph()
         self._cur.capture_begin(pool=self.pool)
-        self._mark = K.LAUNCHES
 
     def _end(self, rng):
-        from ..ops import functional as K
+        # every captured segment is kept and replayed, whatever it holds (library launches, torch fills / copies / random draws):
+        # deciding "empty" from the library's launch counter would silently drop a segment of torch-only ops
         self._cur.capture_end()
-        if K.LAUNCHES != self._mark or rng is not None:        # (a trailing graph with nothing in it is dropped, not replayed)
-            self.segments.append((self._cur if K.LAUNCHES != self._mark else None, rng))
+        self.segments.append((self._cur, rng))
         self._cur = None
 
     def _cut(self, lo, hi):
@@ -105,8 +103,7 @@ class SegmentedGraphedTrainStep:
         self.x.copy_(batch[0], non_blocking=True)
         self.red.begin()
         for g, rng in self.segments:
-            if g is not None:
-                g.replay()
+            g.replay()
             if rng is not None:
                 self.red.launched.append(rng)
                 self.red.all_reduce_async(*rng)     # RCCL's stream waits for the replay just enqueued; the next segment does not wait for it

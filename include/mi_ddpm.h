@@ -330,6 +330,10 @@ size_t mi_conv_s2_wgrad_tr_batch_workspace(int n, const MiWgradDesc* descs);
 int mi_conv_s2_wgrad_tr_batch(int n, const MiWgradDesc* descs, const void* const* P, const void* const* Q, float* const* dW,
                               void* workspace, size_t ws_bytes, void* stream);
 int mi_debug_wgrad_s2_tr_phase(int phase);
+/* measurement aid (tools/cu_hog.py): `blocks` workgroups of 256 threads that stay resident on `stream` for `usec` microseconds -- mode 0
+ * an ALU spin, 1 a streaming copy over buf (2 x per_wg_floats floats per workgroup), 2 the same copy with a gradient all-reduce's duty
+ * cycle (0.5 ms of every 5 ms) -- to see how a training step behaves while another stream's kernel shares the chip */
+int mi_debug_spin(int blocks, int usec, float* buf, size_t per_wg_floats, int mode, void* stream);
 
 /* One pass over an fp32 [M][C] tensor: y_bf16 (optional) = bf16(x), colsum (optional)[c] += sum_m x[m][c].  Backward: a residual-
  * stream gradient that the LDS-DMA weight-gradient kernels want bf16-stored and whose column sums are the conv's bias gradient.

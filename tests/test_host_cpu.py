@@ -29,6 +29,11 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(library_path())
     for name in declared:
         assert getattr(raw, name) is not None
+    # ... and nothing else: every exported mi_* symbol is declared (nm -D on the built library)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", library_path()], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("mi_")}
+    assert exported == declared, exported ^ declared
     assert lib.mi_abi_version() == 4
 
 

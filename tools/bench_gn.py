@@ -20,7 +20,8 @@ def timeit(fn, n=20):
 
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-for dt in (torch.float32, torch.bfloat16):
+REP = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # the whole table REP times (drift inside one process)
+for dt in [torch.float32, torch.bfloat16] * REP:
     for H, C in [(32, 128), (16, 256), (8, 512)]:
         x = torch.randn(B, H, H, C, device="cuda").to(dt)
         ga = torch.ones(C, device="cuda"); be = torch.zeros(C, device="cuda")

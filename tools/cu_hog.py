@@ -17,7 +17,6 @@ def child(hog):
     from src.models.ddpm import DDPM
     from src.ops.lib import load_library
     lib = load_library()
-    lib.mi_debug_spin.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     torch.manual_seed(0)
     m = DDPM({"width": 32, "height": 32, "channels": 3, "transforms": {"normalize": True}}, hidden_dim=128, dim_mults=(1, 2, 4), lr=1e-4, b1=0.9, b2=0.999).to("cuda")
     m.denoising_model.compute_mode = "bf16"; m.train()
@@ -50,7 +49,9 @@ if __name__ == "__main__":
         child(int(sys.argv[1]))
     else:
         blocks = os.environ.get("HOG_W3_BLOCKS", "256").split(",")
-        for mode in os.environ.get("HOG_MODES", "1,0").split(","):   # 1 = streaming copy (collective-like), 0 = ALU spin (worst case)
+        # 0 = ALU spin (worst case for issue slots), 1 = streaming copy at full tilt for the whole step, 2 = the same copy with a
+        # gradient all-reduce's duty cycle (0.5 ms of every 5 ms; resident but asleep in between)
+        for mode in os.environ.get("HOG_MODES", "2,1,0").split(","):
             for b in blocks:
                 for hog in (0, 8, 32, 64):
                     subprocess.run([sys.executable, __file__, str(hog)], env={**os.environ, "HOG_MODE": mode, "MI_W3_BLOCKS": b}, check=False)
