@@ -39,6 +39,27 @@ NAMED_GFLOP = 38.65                                # level-0 fus
 NAMED_MB = {"fp32": 134.9, "bf16": 67.5}           # its algorithmic HBM bytes by activation storage
 
 
+# kernel symbol -> the source file that implements it (roofline.traffic comes from PMC passes made in another run: the JSON records the
+# hash of this file at collection time, bench.py compares it with the tree's and says `traffic_stale` when the kernel changed since)
+KERNEL_SOURCES = {"conv_pw_kernel": "conv_pw.hip", "conv1x1_pw_kernel": "conv_pw.hip", "conv3x3_halo_kernel": "conv3x3_halo.hip",
+                  "wgrad_tr_kernel": "wgrad_tr.hip", "wgrad1x1_tr_kernel": "wgrad1x1_tr.hip", "gn_mish": "norm_act.hip",
+                  "chan_ln": "norm_act.hip", "linattn": "linattn.hip", "igemm": "igemm_conv.hip", "wgrad_s2": "wgrad_s2_tr.hip"}
+
+
+def kernel_source_sha(sym: str):
+    """(relative path, sha256) of the csrc file behind a kernel symbol, or (None, None)"""
+    import hashlib
+    for key, fn in KERNEL_SOURCES.items():
+        if sym.startswith(key):
+            rel = os.path.join("image-generation-models_amd", "csrc", fn)
+            try:
+                with open(os.path.join(ROOT, rel), "rb") as f:
+                    return rel, hashlib.sha256(f.read()).hexdigest()
+            except OSError:
+                return rel, None
+    return None, None
+
+
 def cpu_baseline(budget_s: float = 28.0):
     """The CPU oracle (proven equal to the reference in the build container, tests/golden) timed on this box's host cores,
     fp32, the three legs of BASELINE.md section 4: train steps (fwd+bwd+Adam) at B=16 and at B=128 (the GPU line's batch), one
@@ -243,7 +264,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32-mode leg, the named-kernel microbenchmark and the CPU baseline")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("MI_BENCH_GRAPH", "-1")),
-                    help="1: replay the training step as a hipGraph (single GPU), 0: eager, -1: the trainer's default for this config")
+                    help="1: replay the training step as a hipGraph (under data parallelism: a chain of graphs cut at the gradient "
+                         "buckets), 0: eager, -1 (default): the Trainer's default = replay, eager if the capture fails")
     ap.add_argument("--dry-run-cpu", action="store_true", help="launch/rendezvous plumbing only (gloo, host stand-in step)")
     ap.add_argument("--cfg", type=int, default=2, choices=[2, 3],
                     help="2 (default, the metric's configuration): CIFAR-10 32x32, UNet 128 / 1-2-4; 3: BASELINE configs[2], CelebA 64x64, "
@@ -314,15 +336,27 @@ def main():
 
     # hipGraph replay of the step: same kernels, same order.  One graph launch per step in a single process; under data parallelism
     # a chain of graphs cut at the gradient buckets with the all-reduces issued between them (src/runtime/graphed.py)
-    use_graph = args.graph == 1
+    use_graph = args.graph != 0
+    graph_note = None
     train_step = eager_step
     if use_graph:
         from src.runtime.graphed import GraphedTrainStep, SegmentedGraphedTrainStep
         opt.device_state = True
         for i in range(3):
             eager_step(i)
-        gstep = SegmentedGraphedTrainStep(model, opt, reducer, batch) if reducer is not None else GraphedTrainStep(model, opt, batch, warmup=0)
-        train_step = lambda i: gstep(batch)        # noqa: E731
+        try:
+            gstep = SegmentedGraphedTrainStep(model, opt, reducer, batch) if reducer is not None else GraphedTrainStep(model, opt, batch, warmup=0)
+            train_step = lambda i: gstep(batch)        # noqa: E731
+        except Exception as exc:                       # noqa: BLE001  (what Trainer.fit does in its automatic mode)
+            if args.graph == 1:
+                raise
+            use_graph, graph_note = False, f"capture failed ({type(exc).__name__}: {exc}); eager"
+            torch.cuda.synchronize()
+    if use_dist:                                       # every rank must run the same kind of step
+        flag = torch.tensor([1 if use_graph else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if use_graph and int(flag) == 0:
+            use_graph, graph_note, train_step = False, "capture failed on another rank; eager", eager_step
 
     def sync():
         if use_dist:
@@ -411,13 +445,15 @@ def main():
             v[0] += fl; v[1] += sec; v[2] += 1; v[3] += nb
         sym, (fl, sec, cnt, nb) = max(agg.items(), key=lambda kv: kv[1][1])          # the symbol with the most time per step
         peak = PEAK_TFLOPS[args.mode]
-        traffic, tnote = None, None
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):               # PMC passes are separate runs (profiles/)
+        traffic, tnote, tstale = None, None, None
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC passes are separate runs (profiles/)
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     ent = json.load(f).get(sym)
                 if ent:
                     traffic, tnote = ent["hbm_bytes_per_launch"], ent["note"] + f" ({name})"
+                    # stale = the kernel's source is not the one the counters were collected on (no recorded hash: unknown -> stale)
+                    tstale = ent.get("source_sha256") is None or ent.get("source_sha256") != kernel_source_sha(sym)[1]
                     break
             except OSError:
                 pass
@@ -433,7 +469,7 @@ def main():
                 ent["algorithmic_gbs"] = round(v[3] / v[1] / 1e9, 1)
             table[k] = ent
         roof = {"kernel": sym, "bound": "mfma" if mfma_bound else "hbm", "achieved": round(ach, 1), "peak": pk,
-                "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": round(ach / pk, 4), "traffic": traffic, "traffic_note": tnote,
+                "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": round(ach / pk, 4), "traffic": traffic, "traffic_stale": tstale, "traffic_note": tnote,
                 "launches_per_step": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
                 "avg_gflop_per_launch": round(fl / cnt / 1e9, 3), "avg_algorithmic_mb_per_launch": round(nb / cnt / 1e6, 2),
                 "probed_ms_per_step": round(sum(v[1] for v in agg.values()) * 1e3, 3),
@@ -495,7 +531,10 @@ def main():
                                    ("DDPM CelebA 64x64 train step (q_sample+UNet fwd+L1+bwd+allreduce+Adam), UNet hidden 64 mults 1-2-4-8, "
                                     "T=1000 (BASELINE configs[2]; its per-GPU batch at 8 GPUs is 32)"),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "step_launch": "hipGraph replay" if use_graph else "eager",
+                       "step_launch": ("hipGraph replay" if use_graph else "eager") + (f" [{graph_note}]" if graph_note else ""),
+                       # BASELINE's metric has two halves; the second one (hipGraph-replayed reverse-diffusion step at B = 64) rides here
+                       "sampler": {"denoise_steps_per_sec": round(denoise_steps_per_s, 2), "batch": 64, "launch": "hipGraph replay",
+                                   "tflops": round(denoise_steps_per_s * 64 * FWD_GF / 1e3, 1)},
                        "activations": "NHWC; fp32 residual stream, bf16 block- and attention-internal tensors" if args.mode == "bf16" else "fp32 NHWC", "matmul": "bf16 MFMA, fp32 accumulate" if args.mode == "bf16" else "fp32 MFMA"},
             "rccl_ranks": rccl_ranks, "comm": comm,
             "denoise_steps_per_sec": round(denoise_steps_per_s, 2), "denoise_batch": 64,

@@ -95,13 +95,51 @@ def materialize_uint8(dataset, num_workers: int = 0) -> "ArrayImageDataset":
     return out
 
 
+def materialize_uint8_shared(dataset, num_workers: int = 0, local_rank: int = 0) -> "ArrayImageDataset":
+    """materialize_uint8 under data parallelism: ONE rank per node (local rank 0) decodes / resizes the dataset and leaves the
+    uint8 array in /dev/shm; the node's other ranks read it from there instead of repeating the work (CelebA: 202 599 jpgs decoded
+    and resized once instead of once per GPU, on the same host cores).  Needs an initialised process group (the name of the file is
+    agreed on by a broadcast, the hand-over is two barriers); without one it is materialize_uint8."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return materialize_uint8(dataset, num_workers)
+    if isinstance(dataset, ArrayImageDataset) and dataset.resize is None:
+        return dataset                                     # nothing to decode: every rank already holds the array it read
+    import os
+    import uuid
+    tok = [uuid.uuid4().hex if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(tok, src=0)
+    base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"mi_ddpm_u8_{tok[0]}")
+    out = None
+    if local_rank == 0:
+        out = materialize_uint8(dataset, num_workers)
+        np.save(base + "_x.npy", out.images)
+        np.save(base + "_y.npy", np.asarray(out.labels))
+    dist.barrier()                                          # the files are complete
+    try:
+        if out is None:
+            tf = dataset if isinstance(dataset, ArrayImageDataset) else dataset._tf
+            out = ArrayImageDataset(np.load(base + "_x.npy"), np.load(base + "_y.npy"), None)
+            out.normalize, out.flip = tf.normalize, tf.flip
+    finally:
+        dist.barrier()                                      # every rank has read them
+        if local_rank == 0:
+            for suffix in ("_x.npy", "_y.npy"):
+                try:
+                    os.remove(base + suffix)
+                except OSError:
+                    pass
+    return out
+
+
 class DeviceBatchLoader:
     """Serves (images fp32 NCHW, labels int64) batches from a uint8 dataset resident in HBM.  Epoch order: a fresh random
     permutation per epoch seeded from torch's global CPU generator with the draw torch's RandomSampler makes
     (`int(torch.empty((), dtype=torch.int64).random_())`), or the ShardSampler order under data-parallel training; the last
     batch is ragged (no drop_last), as with the reference's DataLoader.  NOT the reference's sample order for the same global seed:
     a torch DataLoader iterator also draws its `_base_seed` from the global generator before the sampler's seed each epoch, and the
-    flips here come from the device generator.  Under world > 1 every rank decodes and uploads the whole dataset in setup."""
+    flips here come from the device generator.  Under world > 1 every rank holds the whole uint8 dataset in its HBM (it draws its shard
+    from it); the decode / resize behind it runs once per node (materialize_uint8_shared)."""
 
     def __init__(self, dataset: ArrayImageDataset, batch_size: int, device, shuffle: bool, sampler=None):
         if dataset.resize is not None:
@@ -238,7 +276,9 @@ class BaseDatamodule(LightningDataModule):
         if self._want_resident(data):
             key = id(data)
             if key not in self._resident:
-                self._resident[key] = materialize_uint8(data, self.num_workers)
+                import os
+                self._resident[key] = (materialize_uint8_shared(data, self.num_workers, int(os.environ.get("LOCAL_RANK", self._rank)))
+                                       if self._world > 1 else materialize_uint8(data, self.num_workers))
             return DeviceBatchLoader(self._resident[key], self.batch_size, self._device, shuffle, sampler)
         kw = dict(batch_size=self.batch_size, num_workers=self.num_workers)
         if self.num_workers > 0:

@@ -74,6 +74,14 @@ class SegmentedGraphedTrainStep:
                 reducer.finish()                    # flushes that bucket into the sink (nothing to wait for)
                 if self._cur is not None:
                     self._end(None)
+            except BaseException:
+                if self._cur is not None:           # leave the stream out of capture mode before the error travels on
+                    try:
+                        self._cur.capture_end()
+                    except Exception:               # noqa: BLE001
+                        pass
+                    self._cur = None
+                raise
             finally:
                 reducer.capture_sink = None
             self.adam = torch.cuda.CUDAGraph()

@@ -58,11 +58,14 @@ class Trainer:
                  callbacks: Optional[List[Callback]] = None, logger=None, precision: str = "32", accelerator: str = "auto",
                  max_steps: int = -1, limit_train_batches: Optional[int] = None, limit_val_batches: Optional[int] = None,
                  num_sanity_val_steps: int = 2, log_every_n_steps: int = 50, enable_checkpointing: bool = True,
-                 default_root_dir: str = ".", fast_dev_run: bool = False, strategy: str = "auto", graph_step: bool = False, **unused):
-        # graph_step (not a Lightning argument; `+trainer.graph_step=true`): replay training_step + backward + optimizer step as one
+                 default_root_dir: str = ".", fast_dev_run: bool = False, strategy: str = "auto", graph_step: Optional[bool] = None, **unused):
+        # graph_step (not a Lightning argument; `+trainer.graph_step=true|false`): replay training_step + backward + optimizer step as one
         # hipGraph (src/runtime/graphed.py); under data parallelism (DDPM) as a chain of graphs cut at the gradient buckets with the
-        # all-reduces issued between them.  Automatic optimization, fused Adam only.
-        self.graph_step = bool(graph_step)
+        # all-reduces issued between them.  Automatic optimization, fused Adam only.  Default (None) = wherever the step can be
+        # captured, with the eager loop as the fallback if the capture fails: the replay is never slower than eager by more than noise
+        # (cfg 2 at B = 128: 23.9 vs 24.0 k images/s) and wins wherever the host is the bottleneck (cfg 3 at its per-GPU batch of 32:
+        # 6.57 vs 5.30 k images/s, gpurun_out/graph_ab.txt of round 4); true = insist (a failing capture raises), false = eager.
+        self.graph_step = None if graph_step is None else bool(graph_step)
         self.devices = devices
         self.max_epochs, self.max_steps = max_epochs, max_steps
         self.check_val_every_n_epoch = check_val_every_n_epoch
@@ -189,8 +192,11 @@ class Trainer:
         # one graph per step without a reducer; under data parallelism the capture is cut at the gradient buckets (graphed.py), which
         # needs the autograd-free step of the DDPM module and the overlapping single-buffer reducer
         seg_graph = (isinstance(self._reducer, FlatGradReducer) and hasattr(model, "training_step_and_backward"))
-        use_graph = (self.graph_step and not manual and isinstance(optimizer, FlatAdam) and device.type == "cuda"
+        use_graph = (self.graph_step is not False and not manual and isinstance(optimizer, FlatAdam) and device.type == "cuda"
                      and (self._reducer is None or seg_graph))
+        if self.graph_step and not use_graph:
+            raise RuntimeError("trainer.graph_step=true needs automatic optimization, the fused FlatAdam, a GPU and (under data "
+                               "parallelism) the DDPM module's autograd-free step with the flat-gradient reducer")
         gstep = None
         if use_graph:
             optimizer.device_state = True
@@ -222,12 +228,29 @@ class Trainer:
                     # step 0 ran eagerly (lazy module loads, workspaces, Adam state); capture on this batch and replay it once
                     from .graphed import GraphedTrainStep, SegmentedGraphedTrainStep
                     model._logged.clear()
-                    gstep = (SegmentedGraphedTrainStep(model, optimizer, self._reducer, batch) if self._reducer is not None
-                             else GraphedTrainStep(model, optimizer, batch, warmup=0))
-                    gstep.logged = dict(model._logged)
-                    gstep(batch)
-                    for k_, v_ in gstep.logged.items():
-                        self._log_metric(k_, v_)
+                    try:
+                        gstep = (SegmentedGraphedTrainStep(model, optimizer, self._reducer, batch) if self._reducer is not None
+                                 else GraphedTrainStep(model, optimizer, batch, warmup=0))
+                    except Exception as exc:      # noqa: BLE001  (automatic mode: an uncapturable step stays eager, loudly)
+                        if self.graph_step:
+                            raise
+                        print(f"[trainer] hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); continuing eagerly",
+                              flush=True)
+                        use_graph, gstep = False, None
+                        torch.cuda.synchronize()
+                        optimizer.zero_grad()
+                        if self._reducer is not None:
+                            self._reducer.begin()
+                        loss = model.training_step(batch, i)
+                        loss.backward()
+                        if self._reducer is not None:
+                            self._reducer.finish()
+                        optimizer.step()
+                    else:
+                        gstep.logged = dict(model._logged)
+                        gstep(batch)
+                        for k_, v_ in gstep.logged.items():
+                            self._log_metric(k_, v_)
                 else:
                     optimizer.zero_grad()
                     if self._reducer is not None:

@@ -161,6 +161,38 @@ def test_flat_grad_reducer_gloo_world2():
         assert max(b - a for a, b in launched) >= 16384            # ... while the others are full buckets
 
 
+def _shared_materialize_worker(rank, world, port, tmp):
+    import numpy as np
+    import torch.distributed as dist
+    from src.datamodules import base as B
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        imgs = rng.integers(0, 256, (12, 10, 14, 3), dtype=np.uint8)
+        ds = B.ArrayImageDataset(imgs, np.arange(12), {"normalize": True, "flip": None, "resize": {"width": 8, "height": 6}})
+        calls = []
+        orig = ds.resized
+        ds.resized = lambda im: (calls.append(1), orig(im))[1]
+        out = B.materialize_uint8_shared(ds, 0, local_rank=rank)
+        assert out.images.shape == (12, 6, 8, 3) and out.images.dtype == np.uint8 and out.normalize and not out.flip
+        assert len(calls) == (12 if rank == 0 else 0)            # decoded / resized ONCE, by local rank 0
+        np.save(os.path.join(tmp, f"r{rank}.npy"), out.images)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_resident_dataset_is_materialized_once_per_node_gloo_world2(tmp_path):
+    """Data parallelism, device-resident dataset: local rank 0 decodes and resizes, the other rank reads the array from /dev/shm
+    (src/datamodules/base.py::materialize_uint8_shared); both end up with the same bytes and the hand-over files are gone."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    mp.spawn(_shared_materialize_worker, args=(2, 32500 + os.getpid() % 2000, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
+    assert np.array_equal(a, b) and a.shape == (12, 6, 8, 3)
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("mi_ddpm_u8_")]
+
+
 def test_compose_vqvae_and_multi_buffer_reducer_gloo_world2():
     """experiment=vqvae/cifar10 composes to the reference's values; the trainer's reducer group averages several flat
     gradient buffers across 2 gloo ranks."""

@@ -2,6 +2,8 @@
 roofline.traffic).  FETCH_SIZE is doubled as MI355X_MICROARCH.md's HBM/rocprofv3 section prescribes for gfx950; both counters are
 in KB.  usage: python tools/make_traffic_json.py r02"""
 import glob, json, os, re, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import kernel_source_sha            # (path, sha256) of the csrc file behind a symbol: bench.py flags stale entries with it
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
@@ -60,7 +62,8 @@ for path in sorted(glob.glob(os.path.join(root, f"{tag}_pmc_traffic_*.txt"))):
         continue
     sym, shape, alg = CASES[case]
     hbm = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
-    out[sym] = {"shape": shape, "fetch_size_kb_raw": vals["FETCH_SIZE"], "write_size_kb_raw": vals["WRITE_SIZE"],
+    src, sha = kernel_source_sha(sym)
+    out[sym] = {"shape": shape, "source": src, "source_sha256": sha, "fetch_size_kb_raw": vals["FETCH_SIZE"], "write_size_kb_raw": vals["WRITE_SIZE"],
                 "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "ratio": round(hbm / alg, 2),
                 "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh) on {shape}; "
                         "FETCH_SIZE doubled per MI355X_MICROARCH.md"}
@@ -89,7 +92,8 @@ for case, kernels in HBM_CASES.items():
         if "us" in v:
             extra = {"duration_us_under_pmc": v["us"], "hbm_gbs_from_pmc": round(hbm / v["us"] / 1e3, 1),
                      "algorithmic_gbs": round(alg / v["us"] / 1e3, 1), "hbm_frac_of_8tbs": round(hbm / v["us"] / 1e3 / 8000.0, 3)}
-        out[f"{key} [{case}]"] = {"shape": shape, "fetch_size_kb_raw": v["FETCH_SIZE"], "write_size_kb_raw": v["WRITE_SIZE"],
+        src, sha = kernel_source_sha(key)
+        out[f"{key} [{case}]"] = {"shape": shape, "source": src, "source_sha256": sha, "fetch_size_kb_raw": v["FETCH_SIZE"], "write_size_kb_raw": v["WRITE_SIZE"],
                                   "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "ratio": round(hbm / alg, 2), **extra,
                                   "note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_traffic.sh) on {shape}; "
                                           "FETCH_SIZE doubled per MI355X_MICROARCH.md"}
