@@ -152,10 +152,17 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     const int nb = min((n0 >> 5) + wv, NB - 1);
 
     // ---- activation DMA pieces: piece p = wv + 4i covers tile pixels 8p .. 8p+7 (tile pixel hp = (image ti, row hy = y+1, column x));
-    //      lane -> pixel lane >> 3, stored 16-byte position lane & 7 holds channel chunk (lane & 7) ^ ((hp >> 1) & 7)
+    //      lane -> pixel lane >> 3, stored 16-byte position lane & 7 holds channel chunk (lane & 7) ^ swz(hp), swz = (hp >> 1) & 7
     // ((hp >> 1) & 7 = (4 wv + (l >> 4)) & 7 for every piece of a wave: a lane always holds the same channel chunk)
+    // W = 8 (round 4): a 16-lane group of a fragment read covers pixels of FOUR tile rows (two bands, or two bands x two images) with
+    // only four different x >> 1, and (hp >> 1) & 7 = 4 (row & 1) + (x >> 1) is the same for all four rows: two lanes per 16-byte
+    // slot, SQ_LDS_BANK_CONFLICT = 44 % of the LDS cycles of the 8x8-level layers.  There swz = ((hp >> 1) & 3) | ((row >> 1) & 1) << 2:
+    // the rows a group reads are {r, r + 4, r + 10, r + 14} (128-pixel tiles, two images) or {r, r + 2, r + 4, r + 6} (64-pixel tiles),
+    // and bit 1 of the row differs inside each pair that shares its columns -- 16 lanes, 16 slots.  For a wave's pieces
+    // (row >> 1) & 1 = (hp >> 4) & 1 = (wv >> 1) & 1: still one channel chunk per lane.
     int xpix[PXPW];
-    const int xcol = ((l & 7) ^ ((4 * wv + (l >> 4)) & 7)) * EPP;
+    const bool w8 = a.W == 8;
+    const int xcol = ((l & 7) ^ (w8 ? (((l >> 4) & 3) | (((wv >> 1) & 1) << 2)) : ((4 * wv + (l >> 4)) & 7))) * EPP;
     int img0;
     {
         int y0;
@@ -348,7 +355,8 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
 #pragma unroll
         for (int r = 0; r < BH + 2; ++r) {
             const int hp = (ti * TH2 + r + BH * sub) * a.W + x;
-            xr[r] = lds0 + hp * 128 + (((l >> 5) * 16) ^ (((hp >> 1) & 7) * 16));
+            const int swz = w8 ? (((hp >> 1) & 3) | (((hp >> 4) & 1) << 2)) : ((hp >> 1) & 7);
+            xr[r] = lds0 + hp * 128 + (((l >> 5) * 16) ^ (swz * 16));
         }
         ep_p0 = (ti * a.TH + BH * sub) * a.W + x;
     }
