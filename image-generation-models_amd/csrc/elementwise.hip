@@ -292,6 +292,32 @@ __global__ __launch_bounds__(256) void cvt_colsum_kernel(int M, int C4, const fl
     }
 }
 
+
+// dst[c] += sum_r src[r * ld + c] for up to MI_ROWSUM_MAX (src, dst) pairs in ONE launch: the second pass of every reduction of a
+// backward pass that leaves per-workgroup partial rows (channel LayerNorm's dg / db, round 4).  A workgroup = 64 columns x 64 rows of
+// one item (thread = column, row lane; 16 rows per thread, all loads issued before the first add), LDS combine of the four row lanes,
+// one atomic per column: rows / 64 atomics per address instead of one per producing workgroup.
+struct RowSumArgs { MiRowSum it[MI_ROWSUM_MAX]; int first[MI_ROWSUM_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void rowsum_batch_kernel(const RowSumArgs a) {
+    MI_PRIO_UP();
+    __shared__ float red[4][64];
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.first[i + 1]) ++i;
+    const MiRowSum it = a.it[i];
+    const int local = blockIdx.x - a.first[i], ctiles = (it.cols + 63) >> 6;
+    const int c = (local % ctiles) * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, r0 = (local / ctiles) * 64;
+    const int cc = min(c, it.cols - 1);
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = it.src[(size_t)min(r0 + rl + 4 * k, it.rows - 1) * it.ld + cc];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += (r0 + rl + 4 * k < it.rows) ? v[k] : 0.f;
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < it.cols) atomicAdd(it.dst + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -338,6 +364,23 @@ extern "C" int mi_f32_to_bf16_colsum(size_t M, int C, const float* x, int ldx, v
         if (y) hipLaunchKernelGGL((cvt_colsum_kernel<true, true, true>), dim3(nb), dim3(256), 0, ST, (int)M, C4, x, ldx, y, ldy, part, rows);
         else   hipLaunchKernelGGL((cvt_colsum_kernel<false, true, true>), dim3(nb), dim3(256), 0, ST, (int)M, C4, x, ldx, y, ldy, part, rows);
     }
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mi_rowsum_batch(int n, const MiRowSum* items, void* stream) {
+    MI_REQUIRE(n > 0 && n <= MI_ROWSUM_MAX && items, "1 <= n <= MI_ROWSUM_MAX items");
+    RowSumArgs a{};
+    a.n = n;
+    int tot = 0;
+    for (int i = 0; i < n; ++i) {
+        const MiRowSum& it = items[i];
+        MI_REQUIRE(it.src && it.dst && it.rows > 0 && it.cols > 0 && it.ld >= it.cols, "bad item");
+        a.it[i] = it; a.first[i] = tot;
+        tot += ((it.cols + 63) / 64) * ((it.rows + 63) / 64);
+    }
+    a.first[n] = tot;
+    hipLaunchKernelGGL(rowsum_batch_kernel, dim3(tot), dim3(256), 0, ST, a);
     MI_LAUNCH_CHECK();
     return 0;
 }

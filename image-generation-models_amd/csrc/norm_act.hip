@@ -515,6 +515,7 @@ int gn_prepare(const MiGnDesc* d, GnArgs& a, int& vec, int& units) {
 struct LnArgs {
     const float* x; const float* g; const float* b; float* y; const float* dy; float* dx; float* dg; float* db;
     int M, C, ldx, ldy, lddy, lddx, accumulate; float eps;
+    float* part;      // backward: this workgroup's row [2 C] = (dg | db) partial sums instead of the 2 C atomics (mi_chan_layernorm_bwd_part)
 };
 constexpr int LN_MAXV = 4;
 
@@ -659,8 +660,17 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_kernel(const LnArgs a) {
     for (int c = threadIdx.x; c < a.C; c += 256) {
         float v0 = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
         float v1 = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-        if (a.dg) atomicAdd(a.dg + c, v0);
-        if (a.db) atomicAdd(a.db + c, v1);
+        if (a.part) {
+            // Round 4: the 2 C atomics of <= 512 workgroups land on the same 2 C addresses and device-scope atomics on one address
+            // serialise (~20 ns each: ~10 us at the end of EVERY launch, measured by leaving them out: 57.5 -> 48.2 us at level 0,
+            // 19.7 -> 8.5 us for 256 channels @8x8).  Each workgroup leaves its row; mi_rowsum_batch adds the rows of all the step's
+            // LayerNorms in one launch.
+            a.part[(size_t)blockIdx.x * 2 * a.C + c] = v0;
+            a.part[(size_t)blockIdx.x * 2 * a.C + a.C + c] = v1;
+        } else {
+            if (a.dg) atomicAdd(a.dg + c, v0);
+            if (a.db) atomicAdd(a.db + c, v1);
+        }
     }
 }
 
@@ -889,7 +899,15 @@ static int ln_fwd_go(int M, int C, const float* x, int ldx, const float* g, cons
 }
 
 static int ln_bwd_go(int M, int C, const float* x, int ldx, const float* g, float eps, const void* dyv, int lddy, float* dx, int lddx,
-                     int accumulate_dx, float* dg, float* db, int dy16, void* stream);
+                     int accumulate_dx, float* dg, float* db, int dy16, void* stream, float* part = nullptr);
+static int ln_bwd_blocks(int M, int C) {
+    const bool half = C <= 128;                       // two pixels per wave
+    // every workgroup ends with 2*C atomics on the same C addresses: fewer, longer-running workgroups for wide layers
+    static const int capenv = (int)mi_knob("MI_LN_BLOCKS", 0);
+    const int cap = capenv ? capenv : 512;            // measured best of 256..2048 on the cfg-2 shapes
+    const int blocks = (M + (half ? 7 : 3)) / (half ? 8 : 4);
+    return blocks > cap ? cap : blocks;
+}
 extern "C" int mi_chan_layernorm_bwd(int M, int C, const float* x, int ldx, const float* g, float eps,
                                      const float* dy, int lddy, float* dx, int lddx, int accumulate_dx,
                                      float* dg, float* db, void* stream) {
@@ -901,19 +919,25 @@ extern "C" int mi_chan_layernorm_bwd_io(int M, int C, const float* x, int ldx, c
                                         float* dg, float* db, int dy16, void* stream) {
     return ln_bwd_go(M, C, x, ldx, g, eps, dy, lddy, dx, lddx, accumulate_dx, dg, db, dy16, stream);
 }
+// The parameter gradients as partial rows: part[r][2 C] = (dg | db) sums of workgroup r, r < mi_chan_layernorm_bwd_part_rows(M, C)
+// (every row is written; nothing is added to dg / db here -- mi_rowsum_batch does that for all the LayerNorms of a step at once).
+extern "C" int mi_chan_layernorm_bwd_part_rows(int M, int C) { return (M > 0 && C > 0) ? ln_bwd_blocks(M, C) : 0; }
+extern "C" int mi_chan_layernorm_bwd_part(int M, int C, const float* x, int ldx, const float* g, float eps,
+                                          const void* dy, int lddy, float* dx, int lddx, int accumulate_dx,
+                                          float* part, int dy16, void* stream) {
+    MI_REQUIRE(part, "null argument");
+    return ln_bwd_go(M, C, x, ldx, g, eps, dy, lddy, dx, lddx, accumulate_dx, nullptr, nullptr, dy16, stream, part);
+}
 static int ln_bwd_go(int M, int C, const float* x, int ldx, const float* g, float eps, const void* dyv, int lddy, float* dx, int lddx,
-                     int accumulate_dx, float* dg, float* db, int dy16, void* stream) {
+                     int accumulate_dx, float* dg, float* db, int dy16, void* stream, float* part) {
     const float* dy = (const float*)dyv;
     MI_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "C must be a multiple of 4, <= 1024");
     MI_REQUIRE(x && g && dy && dx, "null argument");
     LnArgs a{};
     a.x = x; a.g = g; a.dy = dy; a.dx = dx; a.dg = dg; a.db = db; a.M = M; a.C = C; a.ldx = ldx; a.lddy = lddy;
-    a.lddx = lddx; a.accumulate = accumulate_dx; a.eps = eps;
+    a.lddx = lddx; a.accumulate = accumulate_dx; a.eps = eps; a.part = part;
     const bool half = C <= 128;                       // two pixels per wave
-    // every workgroup ends with 2*C atomics on the same C addresses: fewer, longer-running workgroups for wide layers
-    static const int capenv = (int)mi_knob("MI_LN_BLOCKS", 0);
-    int cap = capenv ? capenv : 512;            // measured best of 256..2048 on the cfg-2 shapes
-    int blocks = (M + (half ? 7 : 3)) / (half ? 8 : 4); if (blocks > cap) blocks = cap;
+    const int blocks = ln_bwd_blocks(M, C);
     hipStream_t st = (hipStream_t)stream;
     if (half) { if (dy16) hipLaunchKernelGGL((chan_ln_bwd_kernel<true, 32, 1>), dim3(blocks), dim3(256), 0, st, a);
                 else      hipLaunchKernelGGL((chan_ln_bwd_kernel<false, 32, 1>), dim3(blocks), dim3(256), 0, st, a); }

@@ -857,7 +857,9 @@ class Unet(nn.Module):
             # that reads dout has to be issued first
             wq.flush(kinds=(1,))
             buf, acc = G.target(inp)
-            K.chan_layernorm_bwd(inp, sv[pre + "fn.norm.g"], dln, buf, acc, gv[pre + "fn.norm.g"], gv[pre + "fn.norm.b"])
+            K.chan_layernorm_bwd(inp, sv[pre + "fn.norm.g"], dln, buf, acc, gv[pre + "fn.norm.g"], gv[pre + "fn.norm.b"], defer=wq)
+            if hook is not None:
+                wq.flush(kinds=(4,))                                   # data parallel: this record's range must be final when it is reported
 
         hook = self.grad_ready_hook
         dx_in = None

@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from .lib import MiConvDesc, MiGnDesc, MiWgradDesc, check, load_library
+from .lib import ROWSUM_MAX, MiConvDesc, MiGnDesc, MiRowSum, MiWgradDesc, check, load_library
 
 MODE_FP32, MODE_BF16 = 0, 1
 
@@ -692,18 +692,21 @@ class WgradQueue:
     mi_conv1x1_wgrad_tr_batch), each layer on its share of the CUs (see include/mi_ddpm.h: an eighth of the partial-tile traffic,
     an eighth of the launches).  Layers the LDS-DMA kernels cannot take run at once through conv_wgrad.  `pushed` numbers the deferred
     layers (1, 2, ...); `flushed` = the largest n such that layers 1..n have ALL been issued (the two kinds flush independently, so a
-    count of issued layers would not say that); `on_flush()` is called after every flush."""
+    count of issued layers would not say that); `on_flush()` is called after every flush.
+    Kind 4 (round 4): reductions that leave one partial row per workgroup (channel LayerNorm's dg / db) push (rows, dst) pairs; ONE
+    mi_rowsum_batch launch adds all of them (at the final flush, or right away when a caller flushes kind 4: data parallelism)."""
 
     def __init__(self, group: int = 8, on_flush=None, group_s2=None):
         self.group, self.on_flush = max(1, min(8, int(group))), on_flush
         self.group_s2 = self.group if group_s2 is None else max(1, min(8, int(group_s2)))    # stride-2 layers per launch
-        self.items3, self.items1, self.items2 = [], [], []
+        self.items3, self.items1, self.items2, self.items4 = [], [], [], []
         self.pushed = 0
-        self._seq3, self._seq1, self._seq2 = [], [], []        # sequence numbers of the queued layers, per kind
+        self._seq3, self._seq1, self._seq2, self._seq4 = [], [], [], []        # sequence numbers of the queued layers, per kind
+        self._arena_top = 0                                    # partial rows of this backward pass (see rows_buffer)
 
     @property
     def flushed(self) -> int:
-        pending = self._seq3[:1] + self._seq1[:1] + self._seq2[:1]
+        pending = self._seq3[:1] + self._seq1[:1] + self._seq2[:1] + self._seq4[:1]
         return min(pending) - 1 if pending else self.pushed
 
     def _desc(self, P, Q, k, Ci, Cj, hw, mode, P2):
@@ -756,8 +759,33 @@ class WgradQueue:
             self.flush(kinds=(2,))
         return True
 
-    def flush(self, kinds=(3, 1, 2)):
+    def rows_buffer(self, device, nfloats):
+        """nfloats of the persistent partial-row arena (static address: capturable); valid until the next backward pass"""
+        n = (int(nfloats) + 63) // 64 * 64
+        arena = _rows_arena(device, (self._arena_top + n) * 4)
+        out = arena[self._arena_top:self._arena_top + n]
+        self._arena_top += n
+        return out
+
+    def push_rowsum(self, src, rows, cols, ld, dst):
+        """dst[c] += sum_r src[r * ld + c] (deferred)"""
+        self.items4.append((src, int(rows), int(cols), int(ld), dst))
+        self.pushed += 1
+        self._seq4.append(self.pushed)
+
+    def flush(self, kinds=(3, 1, 2, 4)):
         lib = load_library()
+        if 4 in kinds and self.items4:
+            items, self.items4, self._seq4 = self.items4, [], []
+            _need_gpu(items[0][0])
+            for i0 in range(0, len(items), ROWSUM_MAX):
+                chunk = items[i0:i0 + ROWSUM_MAX]
+                arr4 = (MiRowSum * len(chunk))(*[MiRowSum(src=it[0].data_ptr(), dst=it[4].data_ptr(), rows=it[1], cols=it[2], ld=it[3], pad_=0)
+                                                 for it in chunk])
+                e0 = _probe_open()
+                check(lib.mi_rowsum_batch(len(chunk), arr4, _stream()), "mi_rowsum_batch")
+                if e0 is not None:
+                    _probe_close(e0, "rowsum_batch_kernel", 0.0, f"{len(chunk)} items", sum(it[1] * it[2] * 4.0 for it in chunk))
         arr = lambda items, k: (C.c_void_p * len(items))(*[(it[k].data_ptr() if it[k] is not None else 0) for it in items])   # noqa: E731
         if 3 in kinds and self.items3:
             items, self.items3, self._seq3 = self.items3, [], []
@@ -823,6 +851,18 @@ class WgradQueue:
 
 _WS = {}
 _WS_RETIRED = []      # outgrown workspaces stay allocated: a captured hipGraph may still write its partial tiles there
+_ROWS = {}
+
+
+def _rows_arena(device, nbytes):
+    """Persistent per-device buffer of the partial rows a backward pass defers (WgradQueue.rows_buffer); grows like _workspace."""
+    cur = _ROWS.get(device)
+    if cur is None or cur.numel() * 4 < nbytes:
+        if cur is not None:
+            _WS_RETIRED.append(cur)
+        cur = torch.empty((max(int(nbytes) * 2, 16 << 20) + 3) // 4, device=device, dtype=torch.float32)
+        _ROWS[device] = cur
+    return cur
 
 
 def _workspace(device, nbytes):
@@ -948,12 +988,23 @@ def chan_layernorm_fwd(x, g, b, eps=1e-5, out_dtype=torch.float32):
     return y
 
 
-def chan_layernorm_bwd(x, g, dy, dx, accumulate, dg, db, eps=1e-5):
+def chan_layernorm_bwd(x, g, dy, dx, accumulate, dg, db, eps=1e-5, defer=None):
+    """defer (a WgradQueue): dg / db leave as one partial row per workgroup and are added by the queue's batched row sum -- the
+    2 C atomics of every workgroup on the same addresses cost ~10 us per launch."""
     N, H, W, Cc = x.shape
     e0 = _probe_open()
-    check(load_library().mi_chan_layernorm_bwd_io(N * H * W, Cc, _p(x), ld_of(x), _p(g), eps, _p(dy), ld_of(dy), _p(dx),
-                                                  ld_of(dx), int(accumulate), _p(dg), _p(db), _b16(dy), _stream()),
-          "mi_chan_layernorm_bwd")
+    lib = load_library()
+    if defer is not None and dg is not None and db is not None:
+        rows = lib.mi_chan_layernorm_bwd_part_rows(N * H * W, Cc)
+        part = defer.rows_buffer(x.device, rows * 2 * Cc)
+        check(lib.mi_chan_layernorm_bwd_part(N * H * W, Cc, _p(x), ld_of(x), _p(g), eps, _p(dy), ld_of(dy), _p(dx), ld_of(dx),
+                                             int(accumulate), _p(part), _b16(dy), _stream()), "mi_chan_layernorm_bwd_part")
+        defer.push_rowsum(part, rows, Cc, 2 * Cc, dg)
+        defer.push_rowsum(part[Cc:], rows, Cc, 2 * Cc, db)
+    else:
+        check(lib.mi_chan_layernorm_bwd_io(N * H * W, Cc, _p(x), ld_of(x), _p(g), eps, _p(dy), ld_of(dy), _p(dx),
+                                           ld_of(dx), int(accumulate), _p(dg), _p(db), _b16(dy), _stream()),
+              "mi_chan_layernorm_bwd")
     if e0 is not None:
         _probe_close(e0, f"chan_ln_bwd_kernel<io{_b16(dy)}>", 0.0, f"M{N * H * W} C{Cc} acc{int(accumulate)}",
                      N * H * W * Cc * (_esz(x) + _esz(dy) + _esz(dx) * (2 if accumulate else 1)))

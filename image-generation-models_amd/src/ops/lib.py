@@ -32,6 +32,11 @@ class MiGnDesc(C.Structure):
                 ("ldx", C.c_int), ("ldy", C.c_int), ("ldr", C.c_int)]
 
 
+class MiRowSum(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int), ("pad_", C.c_int)]
+
+
+ROWSUM_MAX = 16
 _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 # name -> argtypes; every function returns int (0 = ok) except the two noted below
@@ -129,6 +134,8 @@ SIGNATURES = {
     "mi_linattn_bwd_ws": [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _Z, _P],
     "mi_chan_layernorm_fwd_io": [_I, _I, _P, _I, _P, _P, _F, _P, _I, _I, _P],
     "mi_chan_layernorm_bwd_io": [_I, _I, _P, _I, _P, _F, _P, _I, _P, _I, _I, _P, _P, _I, _P],
+    "mi_chan_layernorm_bwd_part": [_I, _I, _P, _I, _P, _F, _P, _I, _P, _I, _I, _P, _I, _P],
+    "mi_rowsum_batch": [_I, _P, _P],
     "mi_time_embed": [_I, _I, _P, _P, _P],
     "mi_sample_norm_supported": [_I, _I, _I],
     "mi_sample_norm_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P],
@@ -171,6 +178,7 @@ OTHER = {"mi_abi_version": ([], C.c_int), "mi_last_error": ([], C.c_char_p),
          "mi_conv_s2_wgrad_tr_batch_workspace": ([_I, C.POINTER(MiWgradDesc)], C.c_size_t),
          "mi_f32_to_bf16_colsum_workspace": ([_Z, _I], C.c_size_t),
          "mi_linattn_workspace": ([_I, _I, _I], C.c_size_t),
+         "mi_chan_layernorm_bwd_part_rows": ([_I, _I], C.c_int),
          "mi_conv_small_wgrad_workspace": ([_I], C.c_size_t)}
 ABI_VERSION = 4
 

@@ -344,6 +344,12 @@ int mi_f32_to_bf16_colsum(size_t M, int C, const float* x, int ldx, void* y_bf16
                           size_t ws_bytes, void* stream);
 /* out[c] += sum_m x[m*ld + c]  (bias gradients) */
 int mi_colsum(int M, int C, const float* x, int ld, float* out, void* stream);
+/* dst[c] += sum_{r < rows} src[r*ld + c], c < cols, for up to MI_ROWSUM_MAX items in ONE launch: the second pass of the reductions
+ * that leave one partial row per workgroup (mi_chan_layernorm_bwd_part) -- device-scope atomics on one address serialise, so 512
+ * workgroups adding to the same C addresses cost ~10 us at the end of every launch; here an address receives rows / 64 atomics. */
+#define MI_ROWSUM_MAX 16
+typedef struct { const float* src; float* dst; int rows, cols, ld, pad_; } MiRowSum;
+int mi_rowsum_batch(int n, const MiRowSum* items, void* stream);
 
 /* ---- GroupNorm(8)+Mish (+time bias, +residual) ---------------------------------------
  * Block's GroupNorm->Mish (ddpm.py:116,62-64), the time-embedding add `h += mlp(t)`
@@ -396,6 +402,12 @@ int mi_chan_layernorm_fwd_io(int M, int C, const float* x, int ldx, const float*
 int mi_chan_layernorm_bwd_io(int M, int C, const float* x, int ldx, const float* g, float eps,
                              const void* dy, int lddy, float* dx, int lddx, int accumulate_dx,
                              float* dg, float* db, int dy16, void* stream);
+/* the same with the parameter gradients left as partial rows: part[r][2 C] = (dg | db) sums of workgroup r for
+ * r < mi_chan_layernorm_bwd_part_rows(M, C) (every row is written); mi_rowsum_batch adds them into dg / db */
+int mi_chan_layernorm_bwd_part_rows(int M, int C);
+int mi_chan_layernorm_bwd_part(int M, int C, const float* x, int ldx, const float* g, float eps,
+                               const void* dy, int lddy, float* dx, int lddx, int accumulate_dx,
+                               float* part, int dy16, void* stream);
 
 /* ---- LinearAttention core (ddpm.py:157-165), heads x 32 channels -------------------------
  * qkv[b][p][3*heads*32] (q | k | v, head-major inside each), out[b][p][heads*32].

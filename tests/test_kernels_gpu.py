@@ -376,6 +376,36 @@ def test_chan_layernorm(K, cfg):
     assert rel_err(from_nhwc(yg), y) < 1e-5
     assert rel_err(from_nhwc(dx), x.grad) < 5e-5
     assert rel_err(dg, gg.grad.reshape(-1)) < 5e-5 and rel_err(db, bb.grad.reshape(-1)) < 5e-5
+    # the parameter gradients as per-workgroup partial rows + the batched row sum (what Unet's backward uses): dx bitwise the same,
+    # dg / db added onto what the destination already holds
+    wq = K.WgradQueue()
+    dx2 = torch.empty_like(dx)
+    dg2, db2 = torch.full((C,), 0.5, device=DEV), torch.full((C,), -2.0, device=DEV)
+    K.chan_layernorm_bwd(xg, g_, to_nhwc_gpu(dy.float()), dx2, False, dg2, db2, defer=wq)
+    assert wq.flushed == 0 and wq.pushed == 2
+    wq.flush()
+    torch.cuda.synchronize()
+    assert wq.flushed == 2 and torch.equal(dx2, dx)
+    assert rel_err(dg2 - 0.5, gg.grad.reshape(-1)) < 5e-5 and rel_err(db2 + 2.0, bb.grad.reshape(-1)) < 5e-5
+
+
+@pytest.mark.parametrize("rows,cols,ld", [(1, 1, 1), (3, 5, 7), (64, 64, 64), (65, 130, 192), (512, 1024, 1024), (700, 96, 200)])
+def test_rowsum_batch(K, rows, cols, ld):
+    """mi_rowsum_batch: dst[c] += sum_r src[r * ld + c] for several items in one launch (ragged rows / columns, row stride > cols,
+    more than MI_ROWSUM_MAX items -> several launches)."""
+    g = torch.Generator().manual_seed(rows * 131 + cols)
+    wq = K.WgradQueue()
+    items = []
+    for i in range(19 if rows < 100 else 3):
+        src = torch.randn(rows + i, ld, generator=g).to(DEV)
+        dst = torch.randn(cols, generator=g).to(DEV)
+        ref = dst.double() + src[:, :cols].double().sum(0)
+        wq.push_rowsum(src, rows + i, cols, ld, dst)
+        items.append((src, dst, ref))
+    wq.flush(kinds=(4,))
+    torch.cuda.synchronize()
+    for src, dst, ref in items:
+        assert float((dst.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("cfg", [(2, 4, 4), (2, 8, 8), (3, 7, 7), (2, 32, 32), (1, 64, 64), (2, 24, 24), (16, 16, 16)])
