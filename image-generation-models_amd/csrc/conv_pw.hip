@@ -43,6 +43,7 @@ struct PwArgs {
     // parameters and the time bias rows temb [N][ldt] (may be null)
     const float* sums; const float* gamma; const float* beta; const float* temb;
     int ldt, cpg, hw; float eps;
+    double icnt;         // VAR 3: 1 / (MI_GSUM_SCALE * hw * cpg)
 };
 
 // PT = output pixels per workgroup: 128 (four 32-pixel MFMA blocks per wave) or, for the layers whose 128-pixel tiles would leave
@@ -98,7 +99,7 @@ template <int DIR> __device__ __forceinline__ bf16x8 pw_shift(const bf16x8& c, u
 }
 
 constexpr int pw_ncoef(int var) { return var == 2 ? 6 : var == 3 ? 10 : 0; }
-constexpr int pw_lds(int pt) { return (pt == 128 ? 64 : 32) * 1024 + 2048; }   // two activation buffers (24 / 16 KB); the epilogue's fp32 tile (+ the GroupNorm sums' 512 bytes)
+constexpr int pw_lds(int pt, bool raw = false) { return (pt == 128 ? (raw ? 72 : 64) : (raw ? 48 : 32)) * 1024 + 2048; }   // raw: + the fp32 staging area of the fused fp32-input variant (24 KB behind the 48 KB of tiles)   // two activation buffers (24 / 16 KB); the epilogue's fp32 tile (+ the GroupNorm sums' 512 bytes)
 
 // VAR 0: the plain conv.  VAR 1: the epilogue also accumulates the GroupNorm sums of the NEXT layer (a.gsum).  VAR 2 / 3: the named
 // fused kernel (2: coefficients given, 3: resolved here from the producer's sums) -- x is the RAW output of the previous conv and mish(x * scale[n][c] + shift[n][c]) + tb[n][c] (a.coef; GroupNorm-apply
@@ -110,6 +111,8 @@ constexpr int pw_lds(int pt) { return (pt == 128 ? 64 : 32) * 1024 + 2048; }   /
 // IN32: x / x2 are fp32 tensors (the residual stream: the sampler's block1 convs, fp32 block storage).  Their pieces are loaded into
 // registers (two global_load_dwordx4 per lane and piece, counted like the fragments), rounded to bf16 once and written to the lane's
 // slot of the tile -- the lane loads the channel chunk that belongs in ITS slot, as the DMA's source addresses do for bf16 input.
+// IN32 + VAR 2 / 3 (round 4; the named fused kernel for fp32-stored activations): the transform is applied to the fp32 values while
+// they sit in those registers, between their load and the one rounding -- no LDS read-modify-write, no unpack.
 // F32: the exact-fp32 mode of the same kernel (Unet.compute_mode = "fp32", the reference's default precision and the mode that carries
 // the 1e-4 parity bar): x / x2 / y fp32, weights fp32 in fragment order [tap][co / 32][ci / 8][lane][4] (mi_pack_weights_f32frag),
 // v_mfma_f32_32x32x2_f32 -- bit-equal to an fp32 fmaf chain.  Everything keeps its byte geometry: a 16-byte piece of a pixel row is 4
@@ -120,14 +123,13 @@ template <bool OUT16, int VAR = 0, int ABL = 0, int PT = 128, bool IN32 = false,
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     MI_PRIO_UP();
     constexpr bool FUSE = VAR >= 2, GNS = VAR == 1;
-    static_assert(!IN32 || (!FUSE && ABL == 0), "fp32 input: the plain conv and the variant with GroupNorm sums");
+    static_assert(!IN32 || ABL == 0, "fp32 input: no ablation builds");
     static_assert(!F32 || (VAR == 0 && ABL == 0 && !IN32 && !OUT16), "exact-fp32 mode: the plain conv, fp32 in and out");
     constexpr int PCK = F32 ? 32 : 64;                       // channels per chunk (128 bytes of a pixel row)
     constexpr int ESZ = F32 ? 4 : 2, EPP = 16 / ESZ;         // element size, elements per 16-byte piece
     constexpr int BH = PT / 32;                              // rows per band = 32-pixel blocks per wave
     constexpr int PXBUF = pw_xp(PT) * 128;                   // one chunk of the activation tile
     constexpr int PXPW = pw_xp(PT) / 8 / 4;                  // activation DMA instructions per wave and chunk
-    static_assert(!FUSE || PT == 128, "the fused variants are built for 128-pixel tiles");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
     const int t = threadIdx.x, l = t & 63;
@@ -257,15 +259,17 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         if constexpr (VAR == 3) {
             // mi_gn_coef_from_sums' arithmetic (norm_act.hip): the group's slabs combined in double, var = E[x^2] - mean^2
             asm volatile("" : "+v"(sq[0]), "+v"(sq[1]), "+v"(sq[2]), "+v"(sq[3]) :: "memory");
-            double sm = 0.0, qm = 0.0;
+            // (the slabs are added as integers -- exact, and two int64 -> double conversions instead of eight -- and the count enters as
+            //  a reciprocal: every lane of the workgroup runs this once per chunk, ~4 us of a level-0 launch in its first form)
+            long long si = 0, qi = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k < nslab) {
-                    sm += (double)(long long)(((unsigned long long)sq[k].y << 32) | sq[k].x) * (1.0 / MI_GSUM_SCALE);
-                    qm += (double)(long long)(((unsigned long long)sq[k].w << 32) | sq[k].z) * (1.0 / MI_GSUM_SCALE);
+                    si += (long long)(((unsigned long long)sq[k].y << 32) | sq[k].x);
+                    qi += (long long)(((unsigned long long)sq[k].w << 32) | sq[k].z);
                 }
-            const double cnt = (double)a.hw * a.cpg, mean = sm / cnt;
-            double var = qm / cnt - mean * mean;
+            const double mean = (double)si * a.icnt;
+            double var = (double)qi * a.icnt - mean * mean;
             if (var < 0.0) var = 0.0;
             const float rstd = 1.0f / sqrtf((float)var + a.eps), mf = (float)mean;
 #pragma unroll
@@ -277,31 +281,42 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                     cq[h][e] = sc;
                 }
         }
-#ifndef MI_PW_NOFOLD
 #pragma unroll
-        for (int h = 0; h < 4; ++h) cq[h] *= 1.44269504f;    // scale, shift -> scale log2(e), shift log2(e): see mish_tb
-#endif
+        for (int h = 0; h < 4; ++h) cq[h] *= 1.44269504f;    // scale, shift -> scale log2(e), shift log2(e): see mish_tb2
     };
-    // two elements (one packed register) of a piece: channels 2q, 2q + 1 of the lane's chunk
-    // mish(u) + tb with u = x * scale + shift, as mish_fast_f (common.h) computes it -- e = exp(min(u, 20)), w = e (e + 2),
-    // u w / (w + 2) -- with the constants moved to where they are free: scale and shift carry log2(e) (coef_landed), so that
-    // t = u log2(e) feeds v_exp_f32 directly, and ln(2) / (w + 2) = 1 / fma(w, 1 / ln 2, 2 / ln 2) restores u = t ln(2)
-    auto mish_tb = [&](float x, float sc, float sh, float tb) -> float {
-#ifdef MI_PW_NOFOLD
-        return mish_fast_f(fmaf(x, sc, sh)) + tb;
-#endif
-        const float t = fmaf(x, sc, sh);
-        const float e = __builtin_amdgcn_exp2f(fminf(t, 20.f * 1.44269504f));
-        const float w = e * (e + 2.f);
-        const float r = __builtin_amdgcn_rcpf(fmaf(w, 1.44269504f, 2.88539008f));
-        return fmaf(t * w, r, tb);
+    // two elements (one packed register) of a piece: channels 2q, 2q + 1 of the lane's chunk.
+    // mish(u) + tb with u = x * scale + shift.  Round 4: written for the PACKED fp32 pipe (v_pk_fma_f32 / v_pk_add_f32: two elements per
+    // instruction) and without the clamp: scale and shift carry log2(e) (coef_landed), so t = u log2(e) feeds v_exp_f32 directly;
+    // with e = 2^t, q = e (e + 2) + 2 and r = 1 / q,  tanh(softplus(u)) = 1 - 2 r,  so  mish(u) + tb = t * (ln 2 - 2 ln 2 * r) + tb.
+    // e = +inf (u > 88) gives r = 0 and the result u + tb, e = 0 gives exactly tb: no clamp, no NaN.  Per element pair: 4 packed
+    // instructions + 4 transcendentals (before: ~12 + 4) -- the transform is what the fused kernel pays over the plain conv.
+    auto mish_tb2 = [&](f32x2 x, f32x2 sc, f32x2 sh, f32x2 tb) -> f32x2 {
+        // (explicit packed instructions: left to itself instruction selection splits most of the vector arithmetic back into scalar
+        //  v_fma_f32.  A 32-bit constant is used for both halves with op_sel_hi 0; {-2 ln 2, ln 2} is ONE scalar pair read twice --
+        //  low half as the factor, high half as the addend -- since an instruction may read one scalar operand only)
+        f32x2 t, e, q, r, sm, o;
+        const f32x2 kln = {-1.38629436f, 0.693147182f};
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(x), "v"(sc), "v"(sh));
+        e = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        // (s_nop: on gfx940+ a VALU instruction must not read a transcendental's result in the very next issue slot, and hipcc does not
+        //  look for that hazard inside asm statements)
+        asm("s_nop 0\n\tv_pk_add_f32 %0, %1, 2.0 op_sel_hi:[1,0]" : "=v"(q) : "v"(e));
+        asm("v_pk_fma_f32 %0, %1, %2, 2.0 op_sel_hi:[1,1,0]" : "=v"(q) : "v"(e), "0"(q));
+        r = f32x2{__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+        asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(sm) : "v"(r), "s"(kln));
+        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o) : "v"(t), "v"(sm), "v"(tb));
+        return o;
+    };
+    auto cq2 = [&](int k, auto ec) -> f32x2 {              // elements e, e + 1 (e even) of coefficient set k (0 scale, 1 shift, 2 time bias)
+        constexpr int e = decltype(ec)::value;
+        return f32x2{cq[2 * k + (e >> 2)][e & 3], cq[2 * k + (e >> 2)][(e & 3) + 1]};
     };
     auto tpart = [&](uint32_t v, auto qc, uint32_t vmask) -> uint32_t {
-        constexpr int q = decltype(qc)::value, e0 = 2 * q, e1 = 2 * q + 1;
-        const float x0 = __uint_as_float(v << 16), x1 = __uint_as_float(v & 0xffff0000u);
-        const float m0_ = mish_tb(x0, cq[e0 >> 2][e0 & 3], cq[2 + (e0 >> 2)][e0 & 3], cq[4 + (e0 >> 2)][e0 & 3]);
-        const float m1_ = mish_tb(x1, cq[e1 >> 2][e1 & 3], cq[2 + (e1 >> 2)][e1 & 3], cq[4 + (e1 >> 2)][e1 & 3]);
-        return pack_bf16(m0_, m1_) & vmask;                  // rows above / below the image stay zero padding
+        constexpr int q = decltype(qc)::value;
+        constexpr std::integral_constant<int, 2 * q> E{};
+        const f32x2 x = {__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)};
+        const f32x2 m = mish_tb2(x, cq2(0, E), cq2(1, E), cq2(2, E));
+        return pack_bf16(m.x, m.y) & vmask;                  // rows above / below the image stay zero padding
     };
     auto piece_addr = [&](int buf, int i) -> uint32_t { return lds0 + buf * PXBUF + (wv + 4 * i) * 1024 + l * 16; };
     auto piece_mask = [&](int i) -> uint32_t {
@@ -311,6 +326,47 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     };
     typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
     u32x4 tv[2];                                             // main loop: the (at most two) pieces in transformation, rewritten in place
+    // fp32 input: half h (elements 4h .. 4h + 3 of the lane's 8 channels) of a piece in registers -> two packed registers of `dst`
+    auto xhalf = [&](const u32x4& r, auto hc, uint32_t vmask, u32x4& dst) {
+        constexpr int h = decltype(hc)::value;
+        constexpr std::integral_constant<int, 4 * h> E0{};
+        constexpr std::integral_constant<int, 4 * h + 2> E1{};
+        const f32x2 m0_ = mish_tb2(f32x2{__uint_as_float(r.x), __uint_as_float(r.y)}, cq2(0, E0), cq2(1, E0), cq2(2, E0));
+        const f32x2 m1_ = mish_tb2(f32x2{__uint_as_float(r.z), __uint_as_float(r.w)}, cq2(0, E1), cq2(1, E1), cq2(2, E1));
+        dst[2 * h] = pack_bf16(m0_.x, m0_.y) & vmask; dst[2 * h + 1] = pack_bf16(m1_.x, m1_.y) & vmask;
+    };
+
+    // fp32 input, fused (round 4): raw staging area behind the two bf16 buffers -- [wave][slot 0..2][2 KB]: a piece = 8 pixels x 64 fp32
+    // channels = two DMA instructions; lane l fetches channels xcol + 4 j .. + 3 (j = 0, 1) of ITS pixel, so that the same lane reads
+    // back its own 8 channels (conflict-free by construction), transforms them and writes the 16 bf16 bytes of its slot of the tile
+    constexpr uint32_t RAW0 = 2 * PXBUF;
+    constexpr int RHP = PXPW / 2;                            // pieces per half chunk and wave (= staging slots): 3 (128-pixel tiles) or 2
+    auto stage_raw = [&](int ch, int i, int slot) {
+        const int cc0 = min(ch, nchunks - 1) * PCK;
+        int xp = xpix[i];
+        asm volatile("" : "+v"(xp));
+        size_t off = (size_t)max(xp, 0) * a.ldx + cc0 + xcol;
+        asm volatile("" : "+v"(off));
+        const float* pf = xp >= 0 ? reinterpret_cast<const float*>(a.x) + off : reinterpret_cast<const float*>(g_zero_page3) + (l & 7) * 8;
+        glds16(pf, lds0 + RAW0 + (wv * RHP + slot) * 2048);
+        glds16(pf + 4, lds0 + RAW0 + (wv * RHP + slot) * 2048 + 1024);
+    };
+    auto raw_half = [&](int buf, int half) {                  // pieces RHP half .. of this wave: staging area -> transformed bf16 tile
+        typedef __attribute__((address_space(3))) u32x4 lds_u32x4r;
+        u32x4 rv[RHP][2];
+#pragma unroll
+        for (int i = 0; i < RHP; ++i) {
+            rv[i][0] = *(lds_u32x4r*)(uintptr_t)(lds0 + RAW0 + (wv * RHP + i) * 2048 + l * 16);
+            rv[i][1] = *(lds_u32x4r*)(uintptr_t)(lds0 + RAW0 + (wv * RHP + i) * 2048 + 1024 + l * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < RHP; ++i) {
+            const uint32_t vm = piece_mask(RHP * half + i);
+            u32x4 o;
+            xhalf(rv[i][0], std::integral_constant<int, 0>{}, vm, o); xhalf(rv[i][1], std::integral_constant<int, 1>{}, vm, o);
+            *(lds_u32x4r*)(uintptr_t)piece_addr(buf, RHP * half + i) = o;
+        }
+    };
 
     // ---- weight stream of this wave: fragment (tap, nb, kq) = 1 KB at ((tap * NB + nb) * KQ + kq) * 1024 bytes.  The fragments are
     //      wave-private, so they never touch LDS: each lane loads ITS 16 bytes of a fragment straight into the registers the MFMA
@@ -377,30 +433,52 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
 #pragma unroll
         for (int i = 0; i < PXPW; ++i) load_x32(0, i, pr[i]);
         static_for<0, NPART>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // the rows of chunk 0
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // the rows of chunk 0 (and, older, the coefficients)
+        if constexpr (FUSE) {
+            coef_landed();
 #pragma unroll
-        for (int i = 0; i < PXPW; ++i) store_x32(0, i, pr[i]);
+            for (int i = 0; i < PXPW; ++i) {
+                landed16(pr[i][0]); landed16(pr[i][1]);
+                const uint32_t vm = piece_mask(i);
+                u32x4 o;
+                xhalf(pr[i][0], std::integral_constant<int, 0>{}, vm, o); xhalf(pr[i][1], std::integral_constant<int, 1>{}, vm, o);
+                *(lds_u32x4*)(uintptr_t)piece_addr(0, i) = o;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PXPW; ++i) store_x32(0, i, pr[i]);
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < PXPW; ++i) stage_x(0, i);
         static_for<0, NPART>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
     }
-    if constexpr (FUSE) {
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // coefficients and rows of chunk 0
-        coef_landed();
-        static_for<0, 2>([&](auto hc) {                      // three pieces in flight at a time, three independent transforms
+    // bf16 input, fused: this wave's six pieces of a chunk, rewritten in place in LDS in ONE go -- three pieces (twelve independent
+    // exp -> rcp chains per lane) in flight at a time.  Round 4: the main loop does this at the chunk boundary instead of spreading
+    // the parts over the units of the steps (two element pairs per unit, "under" the MFMAs): a wave issues in order, so the two
+    // dependent transcendental chains of a unit stalled the MFMAs queued behind them -- the interleaved form cost 4.3 us per chunk of
+    // a level-0 launch, the same work as a block 1.5 us (the other workgroup of the CU owns the matrix pipe meanwhile), and the block
+    // can be skipped for the last chunk, which has no successor (a third of the transforms at K = 128).
+    constexpr int HP = PXPW / 2;                             // pieces per half chunk and wave: 3 (128-pixel tiles) or 2
+    auto transform_chunk = [&](int buf) {
+        static_for<0, 2>([&](auto hc) {
             constexpr int h = decltype(hc)::value;
-            u32x4 pv[3];
+            u32x4 pv[HP];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) pv[i] = __builtin_bit_cast(u32x4, lds_b128p(piece_addr(0, 3 * h + i)));
+            for (int i = 0; i < HP; ++i) pv[i] = __builtin_bit_cast(u32x4, lds_b128p(piece_addr(buf, HP * h + i)));
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const uint32_t vm = piece_mask(3 * h + i);
+            for (int i = 0; i < HP; ++i) {
+                const uint32_t vm = piece_mask(HP * h + i);
                 u32x4 o;
                 static_for<0, 4>([&](auto qc) { o[decltype(qc)::value] = tpart(pv[i][decltype(qc)::value], qc, vm); });
-                *(lds_u32x4*)(uintptr_t)piece_addr(0, 3 * h + i) = o;
+                *(lds_u32x4*)(uintptr_t)piece_addr(buf, HP * h + i) = o;
             }
         });
+    };
+    if constexpr (FUSE && !IN32) {
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // coefficients and rows of chunk 0
+        coef_landed();
+        transform_chunk(0);
     }
     // the rows and the fragments have landed (this wave's; the fused variant's rewritten pieces are in LDS) ...
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -414,10 +492,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     // starts once everything the previous one requested before those pieces has landed.  Chunk boundary (before the last unit of
     // step 3, whose MFMAs then cover the first reads from the other buffer): every wave has read all it needs of this chunk's rows
     // and has its pieces of the next chunk's.
-    // Fused variants: the coefficients of the next chunk are requested in step 0, the pieces requested in step k are transformed
-    // in place during units 0-3 of step k + 1 (two parts per unit) -- in the last chunk they rewrite the clamped re-fetch of its own
-    // rows, wasted VALU work (both ways of skipping them measured worse on the 36-unit body: a branch fences the parts off from the
-    // MFMAs they are meant to run under, a second copy of the body spills).
+    // Fused variants, bf16 input: coefficients and all six pieces of the next chunk are requested in step 0 and transformed as one block
+    // at the chunk boundary (transform_chunk); fp32 input: the pieces pass through registers, two per step, and are transformed there
+    // (one half of a piece per unit) -- in the last chunk that is the clamped re-fetch of its own rows, wasted VALU work.
     constexpr int XU = BH < 3 ? BH : 3;                      // the unit that requests activation pieces
     for (int ch = 0; ch < nchunks; ++ch) {
         const uint32_t xcur = (ch & 1) * PXBUF, xnxt = PXBUF - xcur;
@@ -425,9 +502,12 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             constexpr int ks = decltype(ksc)::value, cur = ks & 1, kx32 = ks * 32;
             // pieces the previous step requested behind its fragments
             constexpr int prevp = (ks > 0 && 2 * (ks - 1) < PXPW) ? (IN32 ? 4 : 2) : 0;
-            if constexpr (ks > 0 && !(ABL & 32)) asm volatile("s_waitcnt vmcnt(%0)" :: "i"((FUSE || (ABL & 2)) ? 0 : prevp) : "memory");
+            // (fused: step 0 requested the coefficients, its fragment parts and pieces, the last piece(s) (unit 2: two DMAs) behind
+            //  everything step 1 needs; fp32 input: the second half chunk's six DMAs are requested at the end of step 1, behind step
+            //  2's fragments)
+            if constexpr (ks > 0 && !(ABL & 32))
+                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(FUSE ? ((ks == 1 ? 2 : 0) + ((IN32 && ks == 2) ? 2 * (PXPW / 2) : 0)) : (ABL & 2) ? 0 : prevp) : "memory");
             static_for<0, 9>([&](auto tc) { landed16(WB[cur][decltype(tc)::value]); });
-            if constexpr (FUSE && ks == 1) coef_landed();
             auto mm = [&](auto ic, auto tapc, const bf16x8& xf) {
                 constexpr int i = decltype(ic)::value, tp = decltype(tapc)::value;
                 if constexpr (F32) {
@@ -443,8 +523,13 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             // what a unit issues besides its MFMAs
             auto issue = [&](auto uc) {
                 constexpr int u = decltype(uc)::value;
+                if constexpr (IN32 && FUSE && u == 0 && ks == 0) load_coef(ch + 1);      // (the oldest requests of the step)
                 if constexpr (u < NPART && !(ABL & 1)) load_w3(ch, std::integral_constant<int, ks + 1>{}, uc);
-                if constexpr (u == XU && IN32) {
+                if constexpr (IN32 && FUSE) {
+                    // the raw fp32 pieces of the next chunk go to the staging area by DMA, three per half chunk: pieces 0-2 in step 0
+                    // (one per unit, behind the unit's fragments), pieces 3-5 at the start of step 2 (raw_half's caller)
+                    if constexpr (ks == 0 && u < RHP) stage_raw(ch + 1, u, u);
+                } else if constexpr (u == XU && IN32) {
                     // the two pieces the previous step requested: older than this step's nine fragment requests
                     if constexpr (prevp != 0) {
                         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
@@ -452,37 +537,20 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                     }
                     if constexpr (2 * ks < PXPW) { load_x32(ch + 1, 2 * ks, XR32[0]); load_x32(ch + 1, 2 * ks + 1, XR32[1]); }
                 }
-                if constexpr (u == XU && !IN32 && 2 * ks < PXPW && !(ABL & 2)) { stage_x(ch + 1, 2 * ks); stage_x(ch + 1, 2 * ks + 1); }
-                if constexpr (u == XU && ks == 0 && FUSE) load_coef(ch + 1);
-            };
-            // fused variants: pieces 2 (ks - 1), 2 (ks - 1) + 1 of the next chunk, two parts per unit
-            auto fuse_pre = [&](auto uc) {
-                constexpr int u = decltype(uc)::value;
-                if constexpr (FUSE && ks >= 1) {
-                    if constexpr (u == 0) {
-                        tv[0] = __builtin_bit_cast(u32x4, lds_b128p(piece_addr((ch + 1) & 1, 2 * (ks - 1))));
-                        tv[1] = __builtin_bit_cast(u32x4, lds_b128p(piece_addr((ch + 1) & 1, 2 * (ks - 1) + 1)));
-                    }
-                }
-            };
-            auto fuse_mid = [&](auto uc) {                   // behind the unit's first MFMAs: the exp / rcp chains run under the others
-                constexpr int u = decltype(uc)::value;
-                if constexpr (FUSE && ks >= 1 && u < 4) {
-                    constexpr int pc = u >> 1, q0 = 2 * (u & 1);
-                    const uint32_t vm = piece_mask(2 * (ks - 1) + pc);
-                    tv[pc][q0] = tpart(tv[pc][q0], std::integral_constant<int, q0>{}, vm);
-                    tv[pc][q0 + 1] = tpart(tv[pc][q0 + 1], std::integral_constant<int, q0 + 1>{}, vm);
-                    if constexpr ((u & 1) == 1) *(lds_u32x4*)(uintptr_t)piece_addr((ch + 1) & 1, 2 * (ks - 1) + pc) = tv[pc];
-                }
+                if constexpr (FUSE && !IN32) {
+                    // Round 4: ALL pieces of the next chunk are requested in step 0 (two per unit, behind the unit's fragments; a DMA
+                    // needs no registers), so a piece has a whole step to arrive before it is read back and transformed -- requested
+                    // one unit before the step that transforms it, every step began by waiting out an HBM round trip.
+                    if constexpr (ks == 0 && u == 0) load_coef(ch + 1);
+                    if constexpr (ks == 0 && 2 * u < PXPW) { stage_x(ch + 1, 2 * u); stage_x(ch + 1, 2 * u + 1); }
+                } else if constexpr (u == XU && !IN32 && 2 * ks < PXPW && !(ABL & 2)) { stage_x(ch + 1, 2 * ks); stage_x(ch + 1, 2 * ks + 1); }
             };
             // ---- unit 0: rows 0 (output row 0, tap row 0) and BH + 1 (output row BH - 1, tap row 2)
             {
                 constexpr std::integral_constant<int, 0> U{};
-                fuse_pre(U);
                 XP = lds_b128p((xr[1] ^ kx32) + xcur);
                 issue(U);
                 MI_MM(0, 0, 1, XA); MI_MM(BH - 1, 2, 1, XB);
-                fuse_mid(U);
                 { const bf16x8 la = sh_l(XA), lb = sh_l(XB); MI_MM(0, 0, 0, la); MI_MM(BH - 1, 2, 0, lb); }
                 { const bf16x8 ra = sh_r(XA), rb = sh_r(XB); MI_MM(0, 0, 2, ra); MI_MM(BH - 1, 2, 2, rb); }
                 __builtin_amdgcn_sched_barrier(0);
@@ -495,12 +563,27 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                     auto& xn = [&]() -> bf16x8& { if constexpr (r & 1) return XQ; else return XP; }();
                     xn = lds_b128p((xr[r + 1] ^ kx32) + xcur);
                 } else if constexpr (ks == 3) {
+                    if constexpr (FUSE && !IN32) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (requested in step 0)
+                        if (ch + 1 < nchunks) { coef_landed(); transform_chunk((ch + 1) & 1); }
+                    }
+                    if constexpr (FUSE && IN32) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the second half chunk: requested two steps ago)
+                        if (ch + 1 < nchunks) raw_half((ch + 1) & 1, 1);
+                    }
                     if constexpr (ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                     XA = lds_b128p(xr[0] + xnxt); XB = lds_b128p(xr[BH + 1] + xnxt);
                 } else {
+                    if constexpr (FUSE && IN32 && ks == 1) {
+                        // first half chunk (requested in step 0; younger: this step's nine fragment requests), then the second half's
+                        // requests -- the staging slots are free once raw_half has read them
+                        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                        if (ch + 1 < nchunks) { coef_landed(); raw_half((ch + 1) & 1, 0); }
+                        static_for<0, RHP>([&](auto ic) { stage_raw(ch + 1, RHP + decltype(ic)::value, decltype(ic)::value); });
+                    }
                     XA = lds_b128p((xr[0] ^ (kx32 + 32)) + xcur); XB = lds_b128p((xr[BH + 1] ^ (kx32 + 32)) + xcur);
                 }
                 issue(rc);
@@ -513,7 +596,6 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                     });
                 };
                 taps(std::integral_constant<int, 1>{}, xc);
-                fuse_mid(rc);
                 { const bf16x8 lf = sh_l(xc); taps(std::integral_constant<int, 0>{}, lf); }
                 { const bf16x8 rf = sh_r(xc); taps(std::integral_constant<int, 2>{}, rf); }
                 __builtin_amdgcn_sched_barrier(0);
@@ -652,11 +734,11 @@ bool pw_ok(const MiConvDesc* d, int pt, int* TH, int* TI, bool in32 = false, boo
 // 64-pixel tiles where 128-pixel ones would leave CUs without a workgroup (and the geometry allows them)
 int g_pw_force_tile = 0;                 // tests: 0 = the rule below, 64 / 128 = that tile (or unsupported)
 int pw_pick_tile(const MiConvDesc* d, int var, int* TH, int* TI, bool in32 = false, bool f32 = false) {
-    if ((in32 && var >= 2) || (f32 && var != 0)) return 0;
-    if (g_pw_force_tile == 64) return (var < 2 && pw_ok(d, 64, TH, TI, in32, f32)) ? 64 : 0;
+    if (f32 && var != 0) return 0;
+    if (g_pw_force_tile == 64) return pw_ok(d, 64, TH, TI, in32, f32) ? 64 : 0;
     if (g_pw_force_tile == 128) return pw_ok(d, 128, TH, TI, in32, f32) ? 128 : 0;
     const long t128 = ((long)d->N * d->OH * d->OW / 128) * ((d->Nc + 127) / 128);
-    if (var < 2 && t128 < 200 && pw_ok(d, 64, TH, TI, in32, f32)) return 64;
+    if (t128 < 200 && pw_ok(d, 64, TH, TI, in32, f32) && (var < 2 || *TI == 1)) return 64;
     return pw_ok(d, 128, TH, TI, in32, f32) ? 128 : 0;
 }
 
@@ -907,7 +989,7 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
         if ((((uintptr_t)gn->gamma | (uintptr_t)gn->beta | (uintptr_t)gn->sums) & 7) || ((uintptr_t)gn->sums & 15) || (gn->temb && (((uintptr_t)gn->temb & 15) || gn->ldt % 4)))
             return mi_set_error(-1, "%s: misaligned GroupNorm operands", who);
         a.sums = gn->sums; a.gamma = gn->gamma; a.beta = gn->beta; a.temb = gn->temb; a.ldt = gn->ldt; a.cpg = d->K / gn->G;
-        a.hw = d->OH * d->OW; a.eps = gn->eps;
+        a.hw = d->OH * d->OW; a.eps = gn->eps; a.icnt = 1.0 / (MI_GSUM_SCALE * (double)a.hw * (double)a.cpg);
     }
     if (var == 1 && (!gsum || d->Nc % 16)) return mi_set_error(-1, "%s: GroupNorm sums need Nc %% 16 == 0 and a sum buffer", who);
     a.x = (const uint16_t*)x; a.x2 = (const uint16_t*)(x2 ? x2 : x); a.w = (const uint16_t*)w_frag_bf16; a.bias = bias; a.res = residual; a.y = y;
@@ -921,7 +1003,7 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     a.qmap = 0; a.gx = (int)grid.x; a.gy = (int)grid.y;
     if (!a.xmap && a.gy > 1 && a.gy % 2 == 0 && a.gx % 4 == 0) { a.qmap = 2; grid = dim3(grid.x * grid.y, 1, 1); }
     hipStream_t st = (hipStream_t)stream;
-    size_t lds = pw_lds(pt);
+    size_t lds = pw_lds(pt, in32 && var >= 2);
 #define MI_PW_GO_T(O16, V, A, T) do { \
         static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, A, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
         (void)once_; \
@@ -966,16 +1048,22 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
         if (pt == 64) MI_PW_GO_F(64); else MI_PW_GO_F(128);
 #undef MI_PW_GO_F
     } else if (in32) {
-        if (pt == 64) {
-            if (var == 1) { if (out_bf16) MI_PW_GO_X(true, 1, 64); else MI_PW_GO_X(false, 1, 64); }
-            else { if (out_bf16) MI_PW_GO_X(true, 0, 64); else MI_PW_GO_X(false, 0, 64); }
-        } else {
-            if (var == 1) { if (out_bf16) MI_PW_GO_X(true, 1, 128); else MI_PW_GO_X(false, 1, 128); }
-            else { if (out_bf16) MI_PW_GO_X(true, 0, 128); else MI_PW_GO_X(false, 0, 128); }
+        if (pt == 64) switch (var) {
+            case 1: if (out_bf16) MI_PW_GO_X(true, 1, 64); else MI_PW_GO_X(false, 1, 64); break;
+            case 2: if (out_bf16) MI_PW_GO_X(true, 2, 64); else MI_PW_GO_X(false, 2, 64); break;
+            case 3: if (out_bf16) MI_PW_GO_X(true, 3, 64); else MI_PW_GO_X(false, 3, 64); break;
+            default: if (out_bf16) MI_PW_GO_X(true, 0, 64); else MI_PW_GO_X(false, 0, 64); break;
+        } else switch (var) {
+            case 1: if (out_bf16) MI_PW_GO_X(true, 1, 128); else MI_PW_GO_X(false, 1, 128); break;
+            case 2: if (out_bf16) MI_PW_GO_X(true, 2, 128); else MI_PW_GO_X(false, 2, 128); break;
+            case 3: if (out_bf16) MI_PW_GO_X(true, 3, 128); else MI_PW_GO_X(false, 3, 128); break;
+            default: if (out_bf16) MI_PW_GO_X(true, 0, 128); else MI_PW_GO_X(false, 0, 128); break;
         }
-    } else if (pt == 64) {
-        if (var == 1) { if (out_bf16) MI_PW_GO_T(true, 1, 0, 64); else MI_PW_GO_T(false, 1, 0, 64); }
-        else { if (out_bf16) MI_PW_GO_T(true, 0, 0, 64); else MI_PW_GO_T(false, 0, 0, 64); }
+    } else if (pt == 64) switch (var) {
+        case 1: if (out_bf16) MI_PW_GO_T(true, 1, 0, 64); else MI_PW_GO_T(false, 1, 0, 64); break;
+        case 2: if (out_bf16) MI_PW_GO_T(true, 2, 0, 64); else MI_PW_GO_T(false, 2, 0, 64); break;
+        case 3: if (out_bf16) MI_PW_GO_T(true, 3, 0, 64); else MI_PW_GO_T(false, 3, 0, 64); break;
+        default: if (out_bf16) MI_PW_GO_T(true, 0, 0, 64); else MI_PW_GO_T(false, 0, 0, 64); break;
     } else switch (var) {
         case 1: if (out_bf16) MI_PW_GO(true, 1, 0); else MI_PW_GO(false, 1, 0); break;
         case 2: if (out_bf16) MI_PW_GO(true, 2, 0); else MI_PW_GO(false, 2, 0); break;
@@ -1009,7 +1097,13 @@ extern "C" int mi_conv3x3_pw_tile(const MiConvDesc* d) {
 // the fused GroupNorm-apply + Mish + conv variant: tiles inside one image, one source
 extern "C" int mi_conv3x3_pw_gn_mish_supported(const MiConvDesc* d) {
     int th, ti;
-    return (d && pw_ok(d, 128, &th, &ti) && ti == 1 && d->K1 == d->K) ? 1 : 0;
+    return (d && pw_pick_tile(d, 2, &th, &ti) && ti == 1 && d->K1 == d->K) ? 1 : 0;
+}
+// pixels per workgroup of the fused variants (128 or 64; 0: not supported)
+extern "C" int mi_conv3x3_pw_gn_mish_tile(const MiConvDesc* d) {
+    int th, ti;
+    const int pt = d ? pw_pick_tile(d, 2, &th, &ti) : 0;
+    return (pt && ti == 1 && d->K1 == d->K) ? pt : 0;
 }
 
 // x / x2: bf16 tensors (pixel strides in elements, % 8 == 0); w: bf16 weights in MFMA-fragment order [tap][Nc / 32][K / 16][64][8]
@@ -1116,6 +1210,28 @@ extern "C" int mi_conv3x3_pw_gn_mish_sums(const MiConvDesc* d, const void* x, co
                                           void* y, int out_bf16, void* stream) {
     const PwGn gn{sums, gamma, beta, temb, ldt, G, eps};
     return pw_launch(__func__, d, x, nullptr, w_frag_bf16, bias, nullptr, y, out_bf16, 3, nullptr, nullptr, stream, &gn);
+}
+
+// The named fused kernel for fp32-STORED activations (round 4): x is the raw fp32 output of the previous conv (pixel stride in floats,
+// % 4 == 0), the transform is applied to the fp32 values in registers between their load and the one rounding to bf16; y fp32 or bf16.
+extern "C" int mi_conv3x3_pw_x32_gn_mish_supported(const MiConvDesc* d) {
+    int th, ti;
+    return (d && pw_pick_tile(d, 2, &th, &ti, true) && ti == 1 && d->K1 == d->K) ? 1 : 0;
+}
+extern "C" int mi_conv3x3_pw_x32_gn_mish_tile(const MiConvDesc* d) {
+    int th, ti;
+    const int pt = d ? pw_pick_tile(d, 2, &th, &ti, true) : 0;
+    return (pt && ti == 1 && d->K1 == d->K) ? pt : 0;
+}
+extern "C" int mi_conv3x3_pw_x32_gn_mish(const MiConvDesc* d, const float* x, const float* coef, const void* w_frag_bf16, const float* bias,
+                                         void* y, int out_bf16, void* stream) {
+    return pw_launch(__func__, d, x, nullptr, w_frag_bf16, bias, nullptr, y, out_bf16, 2, nullptr, coef, stream, nullptr, true);
+}
+extern "C" int mi_conv3x3_pw_x32_gn_mish_sums(const MiConvDesc* d, const float* x, const float* sums, const float* gamma, const float* beta,
+                                              const float* temb, int ldt, int G, float eps, const void* w_frag_bf16, const float* bias,
+                                              void* y, int out_bf16, void* stream) {
+    const PwGn gn{sums, gamma, beta, temb, ldt, G, eps};
+    return pw_launch(__func__, d, x, nullptr, w_frag_bf16, bias, nullptr, y, out_bf16, 3, nullptr, nullptr, stream, &gn, true);
 }
 
 // ---- 1x1 convs with K % 128 == 0 (see conv1x1_pw_kernel): w_frag_bf16 = the layer's slice of wfq (d->transposed = 0) or wdq (data

@@ -820,13 +820,18 @@ __global__ __launch_bounds__(256) void gn_coef_from_sums_kernel(int N, int C, in
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * C) return;
     const int n = i / C, c = i - n * C, Cg = C / G, g = c / Cg, nslab = Cg / 16;
-    double s = 0.0, q = 0.0;
+    // (the arithmetic conv_pw's VAR 3 repeats per lane: integer slab sums, one reciprocal of the count -- bitwise the same coefficients)
+    long long si = 0, qi = 0;
+    bool poisoned = false;
     for (int k = 0; k < nslab; ++k) {
         const size_t p = ((size_t)n * (C / 16) + g * nslab + k) * 2;
-        s += gsum_get(sums, p); q += gsum_get(sums, p + 1);
+        const long long r0 = reinterpret_cast<const long long*>(sums)[p], r1 = reinterpret_cast<const long long*>(sums)[p + 1];
+        poisoned |= r0 >= (1LL << 60) || r0 <= -(1LL << 60) || r1 >= (1LL << 60) || r1 <= -(1LL << 60);
+        si += r0; qi += r1;
     }
-    const double cnt = (double)HW * Cg, mean = s / cnt;
-    double var = q / cnt - mean * mean;
+    const double icnt = 1.0 / (MI_GSUM_SCALE * (double)HW * (double)Cg);
+    const double mean = poisoned ? __builtin_nan("") : (double)si * icnt;
+    double var = (double)qi * icnt - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = 1.0f / sqrtf((float)var + eps), mf = (float)mean;
     if (stats && c == g * Cg) { stats[2 * (n * G + g)] = mf; stats[2 * (n * G + g) + 1] = rstd; }

@@ -385,7 +385,17 @@ def conv3x3_pw_gn_mish_picked(N, H, W, K, Nc):
     """Does conv3x3_gn_mish route a bf16-stored layer of this shape to the private-weight-stream fused kernel (given wq)?"""
     d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=MODE_BF16, K1=K,
                    ldx=K, ldx2=K, ldy=Nc, ldr=0, accumulate=0)
-    return bool(USE_CONV_PW and _pick_pw(N, H, W, K, Nc) and load_library().mi_conv3x3_pw_gn_mish_supported(C.byref(d)))
+    # Where it pays (measured in the B = 64 sampler, round 4): every 64-channel chunk of K costs the fused kernel one transform block
+    # (~1 us that the matrix pipe of that workgroup waits for), the GroupNorm pass it replaces costs ~4 us + its bytes -- the fusion
+    # wins up to K = 256 (level 0: -2.3 us per block, 256 channels @16x16: -4 us) and loses on the 512-channel 8x8 layers (+2 us)
+    return bool(USE_CONV_PW and K <= 256 and _pick_pw_fused(N, H, W, Nc, d, False))
+
+
+def _pick_pw_fused(N, H, W, Nc, d, in32):
+    """Tile (128 / 64 pixels; 0 = no) the fused GroupNorm + Mish + conv variants of the private-weight-stream kernel would run this
+    layer with -- the library's pick, subject to the same minimum grid as the plain conv."""
+    pt = _query("mi_conv3x3_pw_x32_gn_mish_tile" if in32 else "mi_conv3x3_pw_gn_mish_tile", d)
+    return pt if pt and (N * H * W // pt) * ((Nc + 127) // 128) >= PW_MIN_TILES else 0
 
 
 def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None, gn=None, wq=None):
@@ -398,8 +408,8 @@ def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None, gn=None, 
     d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=MODE_BF16, K1=K,
                    ldx=ld_of(x), ldx2=ld_of(x), ldy=Nc, ldr=0, accumulate=0)
     lib = load_library()
-    if (wq is not None and USE_CONV_PW and x.dtype == torch.bfloat16 and _pick_pw(N, H, W, K, Nc)
-            and _query("mi_conv3x3_pw_gn_mish_supported", d)):
+    ptf = _pick_pw_fused(N, H, W, Nc, d, x.dtype == torch.float32) if (wq is not None and USE_CONV_PW) else 0
+    if ptf and x.dtype == torch.bfloat16:
         # the private-weight-stream kernel: the transform runs once per staged element, in place in LDS
         y = new_act(N, H, W, Nc, x, x.dtype if out_dtype is None else out_dtype)
         d.ldy = Nc
@@ -414,8 +424,29 @@ def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None, gn=None, 
         else:
             check(lib.mi_conv3x3_pw_gn_mish(C.byref(d), _p(x), _p(coef), _p(wq), _p(bias), _p(y), _b16(y), _stream()), "mi_conv3x3_pw_gn_mish")
         if e0 is not None:
-            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(y) else 'false'}, {3 if coef is None else 2}, 0, 128>", 2.0 * N * H * W * Nc * K * 9,
+            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(y) else 'false'}, {3 if coef is None else 2}, 0, {ptf}>", 2.0 * N * H * W * Nc * K * 9,
                          f"N{N} {H}x{W} K{K}->{Nc} fused GN+Mish", N * H * W * (K * 2 + Nc * _esz(y)) + 9 * K * Nc * 2)
+        return y
+    if ptf and x.dtype == torch.float32:
+        # fp32-stored activations on the same kernel (round 4): the transform is applied to the fp32 values in registers, between
+        # their load and the one rounding to bf16
+        y = new_act(N, H, W, Nc, x, x.dtype if out_dtype is None else out_dtype)
+        d.ldy = Nc
+        e0 = _probe_open()
+        if coef is None and (K // gn[4]) not in (16, 32, 64):
+            _, coef = gn_coef_from_sums(gn[0], N, H * W, gn[1], gn[2], groups=gn[4], eps=gn[5], temb=gn[3])
+        if coef is None:
+            sums, gamma, beta, temb, groups, eps = gn
+            check(lib.mi_conv3x3_pw_x32_gn_mish_sums(C.byref(d), _p(x), _p(sums), _p(gamma), _p(beta), _p(temb),
+                                                     ld_of(temb) if temb is not None else 0, groups, eps, _p(wq), _p(bias), _p(y), _b16(y),
+                                                     _stream()), "mi_conv3x3_pw_x32_gn_mish_sums")
+        else:
+            check(lib.mi_conv3x3_pw_x32_gn_mish(C.byref(d), _p(x), _p(coef), _p(wq), _p(bias), _p(y), _b16(y), _stream()),
+                  "mi_conv3x3_pw_x32_gn_mish")
+        if e0 is not None:
+            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(y) else 'false'}, {3 if coef is None else 2}, 0, {ptf}, true>",
+                         2.0 * N * H * W * Nc * K * 9, f"N{N} {H}x{W} K{K}->{Nc} fused GN+Mish, fp32 in",
+                         N * H * W * (K * 4 + Nc * _esz(y)) + 9 * K * Nc * 2)
         return y
     if not lib.mi_conv3x3_gn_mish_supported(C.byref(d)):
         return None

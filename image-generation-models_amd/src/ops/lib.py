@@ -100,6 +100,11 @@ SIGNATURES = {
     "mi_conv3x3_pw_gnsums": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "mi_conv3x3_pw_gn_mish": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _P],
     "mi_conv3x3_pw_gn_mish_sums": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _I, _P],
+    "mi_conv3x3_pw_x32_gn_mish_supported": [C.POINTER(MiConvDesc)],
+    "mi_conv3x3_pw_x32_gn_mish_tile": [C.POINTER(MiConvDesc)],
+    "mi_conv3x3_pw_gn_mish_tile": [C.POINTER(MiConvDesc)],
+    "mi_conv3x3_pw_x32_gn_mish": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _P],
+    "mi_conv3x3_pw_x32_gn_mish_sums": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _I, _P],
     "mi_gn_stats_coef": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _I, _P, _P, _I, _P],
     "mi_conv3x3_gn_mish_supported": [C.POINTER(MiConvDesc)],
     "mi_conv3x3_gn_mish_tile": [C.POINTER(MiConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)],

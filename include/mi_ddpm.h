@@ -190,6 +190,7 @@ int mi_conv3x3_pw_gnsums(const MiConvDesc* d, const void* x, const void* x2, con
  * own counted wait, before the chunk barrier publishes them); rows outside the image stay zero.  Tiles lie inside one image
  * (W in {16, 32}); the normalised tensor never exists in HBM. */
 int mi_conv3x3_pw_gn_mish_supported(const MiConvDesc* d);
+int mi_conv3x3_pw_gn_mish_tile(const MiConvDesc* d);          /* pixels per workgroup the fused variants would use (128 / 64; 0: not supported) */
 int mi_conv3x3_pw_gn_mish(const MiConvDesc* d, const void* x, const float* coef, const void* w_frag_bf16, const float* bias,
                           void* y, int out_bf16, void* stream);
 /* ... or without the coefficient tensor: scale / shift are resolved per channel chunk inside the kernel from the sums the producing
@@ -198,6 +199,16 @@ int mi_conv3x3_pw_gn_mish(const MiConvDesc* d, const void* x, const float* coef,
 int mi_conv3x3_pw_gn_mish_sums(const MiConvDesc* d, const void* x, const float* sums, const float* gamma, const float* beta,
                                const float* temb, int ldt, int G, float eps, const void* w_frag_bf16, const float* bias,
                                void* y, int out_bf16, void* stream);
+/* The same two for fp32-STORED activations (block storage fp32; x = the raw fp32 output of the previous conv, pixel stride in floats,
+ * % 4 == 0): the transform is applied to the fp32 values while they pass through registers on their way to the bf16 tile (one rounding,
+ * no LDS read-modify-write).  y fp32 or bf16.  The canonical shape of BASELINE.json's named kernel in the regime SURVEY 8(d)(ii) calls balanced. */
+int mi_conv3x3_pw_x32_gn_mish_supported(const MiConvDesc* d);
+int mi_conv3x3_pw_x32_gn_mish_tile(const MiConvDesc* d);      /* pixels per workgroup (128 / 64; 0: not supported) */
+int mi_conv3x3_pw_x32_gn_mish(const MiConvDesc* d, const float* x, const float* coef, const void* w_frag_bf16, const float* bias,
+                              void* y, int out_bf16, void* stream);
+int mi_conv3x3_pw_x32_gn_mish_sums(const MiConvDesc* d, const float* x, const float* sums, const float* gamma, const float* beta,
+                                   const float* temb, int ldt, int G, float eps, const void* w_frag_bf16, const float* bias,
+                                   void* y, int out_bf16, void* stream);
 /* ---- 1x1 convs with K % 128 == 0 input channels on the same machinery (to_qkv, to_out + residual, res_conv -- also over the skip
  * concat's two sources, x2 = channels K1 .. K - 1 with K1 % 128 == 0 -- and their data gradients; reference src/models/ddpm.py:134,151-152):
  * 128 (or 64) pixels x 128 output channels per workgroup, the activation tile double-buffered per 128-channel chunk by LDS-DMA, weight

@@ -596,12 +596,12 @@ def test_conv_pw_epilogue_groupnorm_sums(K, cfg, out16, pw_always, pw_tile):
 @pytest.mark.parametrize("out16", [True, False])
 @pytest.mark.parametrize("cfg", [(16, 32, 32, 128, 128), (8, 16, 16, 256, 256), (8, 16, 16, 128, 256), (3, 32, 32, 128, 96), (2, 32, 32, 64, 64),
                                  (2, 16, 16, 512, 128)])
-def test_fused_gn_mish_conv3x3_pw(K, cfg, out16, pw_always):
+def test_fused_gn_mish_conv3x3_pw(K, cfg, out16, pw_always, pw_tile):
     """BASELINE.json's named kernel on the private-weight-stream structure (mi_conv3x3_pw_gn_mish; reference ddpm.py:112-120,139-140
     Block -> time bias -> Block's conv): the transform is applied once per staged element, in place in LDS.  Against (a) an fp64
     evaluation of GroupNorm -> Mish -> + temb -> Conv2d on the same stored bf16 c1 and bf16-rounded weights and (b) the two-pass path
     (gn_mish_fwd writing h1 as bf16, then the plain conv): same rounding points, so the two agree to a bf16 ulp of h1 here and there.
-    Image borders (zero padding must stay zero after the transform), one to eight chunks, a ragged channel tile."""
+    Image borders (zero padding must stay zero after the transform), one to eight chunks, a ragged channel tile; 128- and 64-pixel tiles."""
     N, H, W, Cc, Co = cfg
     g = torch.Generator().manual_seed(79)
     c1 = (torch.randn(N, Cc, H, W, generator=g) * 1.7 + 0.3).bfloat16()
@@ -623,7 +623,7 @@ def test_fused_gn_mish_conv3x3_pw(K, cfg, out16, pw_always):
     y = K.conv3x3_gn_mish(xg, coef, wf, K=Cc, Nc=Cop, bias=bp.to(DEV), out_dtype=dt, wq=wfq)
     assert y is not None and y.dtype == dt
     ls = _conv_launches(pw_always)
-    assert ls[-1].startswith("conv_pw_kernel") and ls[-1].endswith(", 2, 0, 128>"), ls
+    assert ls[-1].startswith("conv_pw_kernel") and ls[-1].endswith(f", 2, 0, {pw_tile}>"), ls
     h1, _ = K.gn_mish_fwd(xg, gamma.to(DEV), beta.to(DEV), temb=temb.to(DEV), out_dtype=torch.bfloat16)
     y2 = K.conv3x3_bf16w(h1, wf, K=Cc, Nc=Cop, flip=False, bias=bp.to(DEV), out_dtype=dt, wq=wfq)
     torch.cuda.synchronize()
@@ -642,9 +642,59 @@ def test_fused_gn_mish_conv3x3_pw(K, cfg, out16, pw_always):
         yb = K.conv3x3_gn_mish(xg, None, wf, K=Cc, Nc=Cop, bias=bp.to(DEV), out_dtype=dt, wq=wfq,
                                gn=(sums, gamma.to(DEV), beta.to(DEV), temb.to(DEV), 8, 1e-5))
         ls = _conv_launches(pw_always)
-        assert ls[-1].endswith(", 3, 0, 128>") and ls[-2].endswith(", 2, 0, 128>"), ls
+        assert ls[-1].endswith(f", 3, 0, {pw_tile}>") and ls[-2].endswith(f", 2, 0, {pw_tile}>"), ls
         assert torch.equal(ya, yb)
         assert rel_err(yb.float().cpu().permute(0, 3, 1, 2).double()[:, :Co], ref) < 6e-3
+
+
+@pytest.mark.parametrize("out16", [True, False])
+@pytest.mark.parametrize("cfg", [(16, 32, 32, 128, 128), (8, 16, 16, 256, 256), (8, 16, 16, 128, 256), (3, 32, 32, 128, 96), (2, 32, 32, 64, 64),
+                                 (2, 16, 16, 512, 128)])
+def test_fused_gn_mish_conv3x3_pw_fp32_storage(K, cfg, out16, pw_always, pw_tile):
+    """The named kernel for fp32-STORED activations on the private-weight-stream structure (mi_conv3x3_pw_x32_gn_mish[_sums], round 4):
+    c1 is read as fp32, GroupNorm-apply + Mish + time bias run on the fp32 values in registers, ONE rounding to bf16 at the LDS store.
+    Against fp64 GroupNorm -> Mish -> + temb -> Conv2d on the same fp32 c1 and bf16-rounded weights, and against the two-pass path
+    (gn_mish_fwd writing h1 as bf16, the plain conv): same single rounding point, so the two differ by exp / rcp approximations only."""
+    N, H, W, Cc, Co = cfg
+    g = torch.Generator().manual_seed(89)
+    c1 = torch.randn(N, Cc, H, W, generator=g) * 1.7 + 0.3
+    gamma, beta = torch.randn(Cc, generator=g) * 0.5 + 1, torch.randn(Cc, generator=g) * 0.2
+    temb = torch.randn(N, Cc, generator=g) * 0.3 + 0.5
+    w = torch.randn(Co, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc)
+    bias = torch.randn(Co, generator=g) * 0.1
+    Cop = (Co + 63) // 64 * 64
+    wp = torch.zeros(Cop, Cc, 3, 3); wp[:Co] = w
+    bp = torch.zeros(Cop); bp[:Co] = bias
+    hn = F.group_norm(c1.double(), 8, gamma.double(), beta.double(), 1e-5)
+    h = _mish64(hn) + temb.double()[:, :, None, None]
+    ref = F.conv2d(h, w.bfloat16().double(), bias.double(), padding=1)
+    xg = c1.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wf, wfq = _frag_weights(K, wp)
+    dt = torch.bfloat16 if out16 else torch.float32
+    stats, coef = K.gn_stats_coef(xg, gamma.to(DEV), beta.to(DEV), temb=temb.to(DEV))
+    y = K.conv3x3_gn_mish(xg, coef, wf, K=Cc, Nc=Cop, bias=bp.to(DEV), out_dtype=dt, wq=wfq)
+    assert y is not None and y.dtype == dt
+    ls = _conv_launches(pw_always)
+    assert ls[-1].startswith("conv_pw_kernel") and ls[-1].endswith(f", 2, 0, {pw_tile}, true>"), ls
+    h1, _ = K.gn_mish_fwd(xg, gamma.to(DEV), beta.to(DEV), temb=temb.to(DEV), out_dtype=torch.bfloat16)
+    y2 = K.conv3x3_bf16w(h1, wf, K=Cc, Nc=Cop, flip=False, bias=bp.to(DEV), out_dtype=dt, wq=wfq)
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2).double()[:, :Co]
+    two = y2.float().cpu().permute(0, 3, 1, 2).double()[:, :Co]
+    assert rel_err(got, ref) < 5e-3
+    assert rel_err(got, two) < (5e-3 if out16 else 1.5e-3)
+    assert not y[..., Co:].any()
+    if (Cc // 8) % 16 == 0:
+        xd = xg.double().view(N, H * W, Cc // 16, 16)
+        sums = K.gn_sums_encode(torch.stack([xd.sum((1, 3)), (xd * xd).sum((1, 3))], dim=-1))
+        _, coef2 = K.gn_coef_from_sums(sums, N, H * W, gamma.to(DEV), beta.to(DEV), temb=temb.to(DEV))
+        ya = K.conv3x3_gn_mish(xg, coef2, wf, K=Cc, Nc=Cop, bias=bp.to(DEV), out_dtype=dt, wq=wfq)
+        yb = K.conv3x3_gn_mish(xg, None, wf, K=Cc, Nc=Cop, bias=bp.to(DEV), out_dtype=dt, wq=wfq,
+                               gn=(sums, gamma.to(DEV), beta.to(DEV), temb.to(DEV), 8, 1e-5))
+        ls = _conv_launches(pw_always)
+        assert ls[-1].endswith(f", 3, 0, {pw_tile}, true>") and ls[-2].endswith(f", 2, 0, {pw_tile}, true>"), ls
+        assert torch.equal(ya, yb)
+        assert rel_err(yb.float().cpu().permute(0, 3, 1, 2).double()[:, :Co], ref) < 5e-3
 
 
 @pytest.mark.parametrize("cfg", [dict(N=8, H=32, Co=384, kind="qkv"), dict(N=4, H=16, Co=128, kind="out"), dict(N=16, H=8, Co=256, kind="res"),

@@ -436,7 +436,7 @@ def test_fused_eval_path_matches_two_pass(golden_dir, monkeypatch):
     with torch.no_grad():
         K.PROBE = []
         y4 = net(xn, t)                           # the default: fused where the private-weight-stream kernel takes block2's conv
-        fused_default = [q[0] for q in K.PROBE if q[0].startswith("conv_pw_kernel") and q[0].endswith(", 3, 0, 128>")]
+        fused_default = [q[0] for q in K.PROBE if q[0].startswith("conv_pw_kernel") and (", 3, 0, 128>" in q[0] or ", 3, 0, 64>" in q[0])]
         K.PROBE = None
         net.fuse_gn_conv = 1
         y1 = net(xn, t)
@@ -444,7 +444,8 @@ def test_fused_eval_path_matches_two_pass(golden_dir, monkeypatch):
         y3 = net(xn, t)
         net.fuse_gn_conv = 0
         y2 = net(xn, t)
-    assert len(fused_default) == 3, fused_default       # downs.0 block 2 (32x32, 128 ch) and downs.1's two blocks (16x16, 256 ch)
+    # every ResnetBlock whose block2 conv offers the private-weight-stream kernel PW_MIN_TILES tiles (64-pixel tiles on the small grids, round 4)
+    assert len(fused_default) >= 3, fused_default
     e12, e1, e2 = rel_err(y1, y2), rel_err(y1[:2], _t(g["eps_hat"])), rel_err(y2[:2], _t(g["eps_hat"]))
     e13, e3 = rel_err(y3, y1), rel_err(y3[:2], _t(g["eps_hat"]))
     record("cfg2_fused_eval_vs_two_pass_bf16", fused_vs_two_pass_rel_l2=e12, fused_vs_reference_rel_l2=e1, two_pass_vs_reference_rel_l2=e2,
