@@ -950,6 +950,190 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Tap-gather GEMM on the same machinery (round 4): the stride-2 Downsample conv, the ConvTranspose2d(4, 2, 1) Upsample and their data
+// gradients (reference src/models/ddpm.py:67-82), i.e. every conv that is "a few taps, each a strided view of the input":
+//     Y[out(m)][co] (+)= bias[co] + sum_{taps t of the class} sum_ci X[n, oy * si + dy_t, ox * si + dx_t][ci] * W[wt_t][co][ci]
+// over the pixels m = (n, oy, ox) of a class grid [N][GH][GW]; out(m) = (n, oy * so + ao, ox * so + bo) on the produced tensor.
+// A strided conv is ONE class with si = stride, so = 1 and k x k taps; a transposed conv (or a strided conv's data gradient) is
+// stride^2 parity classes (blockIdx.z) with si = 1, so = stride and only the taps whose parity matches the class (1, 2, 2, 4 of the 3x3
+// kernel, 4 each of the 4x4 one).  Structure = conv1x1_pw_kernel: a chunk is two 64-channel halves, each half = (tap, 64-channel
+// slice) -- the LDS-DMA gathers a half's pixel rows at the tap's offset (a DMA piece is a pixel's 128 bytes wherever it lies, so the
+// stride costs nothing; out-of-image taps read the zero page), weights are the wave's private fragment stream in mi_pack_weights_bf16's
+// fragment order, one barrier per chunk.  Replaces round 1's igemm_fast_kernel (register-staged ring, 8-16 MFMAs per barrier:
+// 200-380 TFLOP/s) for these layers.
+struct GtClass { unsigned long long dyq, dxq, wtq; int ntap, ao, bo, pad_; };     // 4-bit fields per tap: dy + 8, dx + 8, weight tap
+struct GtArgs {
+    const uint16_t* x; const uint16_t* w; const float* bias; const float* res; void* y;
+    int M, K, Nc, ldx, ldy, ldr, accumulate, gx, gy;
+    int IH, IW, lgGW, lgGHW, si, so, OH, OW;
+    GtClass cls[4];
+};
+
+template <bool OUT16, int PXT>
+__global__ __launch_bounds__(256, 2) void conv_gt_kernel(const GtArgs a) {
+    MI_PRIO_UP();
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
+    constexpr int NBLK = PXT / 32;                   // 32-pixel MFMA blocks per wave = pixels a lane stages per half
+    constexpr int XH = PXT * 128;                    // one 64-channel half of a chunk's tile (bytes)
+    constexpr int XB = 2 * XH;
+    const int t = threadIdx.x, l = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.gy > 1 && a.gx % 8 == 0) {                 // the channel tiles of one pixel tile adjacent in time on one XCD
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+        bx = xcd * (a.gx >> 3) + slot / a.gy; by = slot % a.gy;
+    }
+    const GtClass cl = a.cls[blockIdx.z];
+    const int m0 = bx * PXT, n0 = by * 128;
+    const int NB = a.Nc >> 5, KQ = a.K >> 4, kc64 = a.K >> 6;
+    const int nhc = cl.ntap * kc64, nchunks = (nhc + 1) >> 1;
+    const bool live = n0 + 32 * wv < a.Nc;
+    const int nb = min((n0 >> 5) + wv, NB - 1);
+
+    // the pixels this lane stages (one per 8-pixel block wv + 4 j of the tile, the same for both halves): image base, oy * si, ox * si
+    int pbase[NBLK], iy0[NBLK], ix0[NBLK];
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+        const int m = m0 + 8 * (wv + 4 * j) + (l >> 3);
+        const int n = m >> a.lgGHW, r = m & ((1 << a.lgGHW) - 1);
+        pbase[j] = n * a.IH * a.IW; iy0[j] = (r >> a.lgGW) * a.si; ix0[j] = (r & ((1 << a.lgGW) - 1)) * a.si;
+    }
+    const uint8_t* zero = reinterpret_cast<const uint8_t*>(g_zero_page3) + (l & 7) * 16;
+    auto stage_x = [&](int ch) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int hc = min(2 * ch + h, 2 * nchunks - 1);
+            const bool pad_half = hc >= nhc;                                      // odd number of halves: the last one multiplies zeros
+            const int hcc = min(hc, nhc - 1), tp = hcc / kc64, c0 = (hcc - tp * kc64) * 64;
+            const int dy = (int)((cl.dyq >> (4 * tp)) & 15) - 8, dx = (int)((cl.dxq >> (4 * tp)) & 15) - 8;
+#pragma unroll
+            for (int j = 0; j < NBLK; ++j) {
+                const int px = 8 * (wv + 4 * j) + (l >> 3);
+                const int iy = iy0[j] + dy, ix = ix0[j] + dx;
+                const bool ok = !pad_half && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+                size_t off = (size_t)(pbase[j] + iy * a.IW + ix) * a.ldx + c0 + ((l & 7) ^ ((px >> 1) & 7)) * 8;
+                asm volatile("" : "+v"(off));
+                const uint8_t* src = ok ? reinterpret_cast<const uint8_t*>(a.x) + off * 2 : zero;
+                glds16(src, lds0 + (ch & 1) * XB + h * XH + (wv + 4 * j) * 1024);
+            }
+        }
+    };
+    // weight fragments of half-chunk (tap wt, channels c0 ..): (wt * NB + nb) * KQ + c0 / 16 .. + 3, 4 KB contiguous
+    const uint8_t* wbase = reinterpret_cast<const uint8_t*>(a.w) + (size_t)nb * KQ * 1024;
+    const uint32_t tap_bytes = (uint32_t)NB * KQ * 1024;
+    const uint32_t wl16 = l * 16;
+    u32x4 WB[2][8];
+    auto load_w = [&](int ch, auto setc) {
+        constexpr int set = decltype(setc)::value;
+        static_for<0, 2>([&](auto hcst) {
+            constexpr int h = decltype(hcst)::value;
+            const int hcc = min(2 * min(ch, nchunks - 1) + h, nhc - 1), tp = hcc / kc64, c0 = (hcc - tp * kc64) * 64;
+            const int wt = (int)((cl.wtq >> (4 * tp)) & 15);
+            const uint64_t q = (uint64_t)(uintptr_t)(wbase + (size_t)wt * tap_bytes + (size_t)(c0 >> 4) * 1024);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
+            const uint64_t sb = ((uint64_t)hi << 32) | lo;
+            static_for<0, 4>([&](auto uc) { gload16s<decltype(uc)::value * 1024>(WB[set][4 * h + decltype(uc)::value], sb, wl16); });
+        });
+    };
+    uint32_t xa[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+        const int px = i * 32 + (l & 31);
+        xa[i] = lds0 + px * 128 + (((l >> 5) * 16) ^ (((px >> 1) & 7) * 16));
+    }
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    stage_x(0);
+    load_w(0, std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<0, 8>([&](auto uc) { landed16(WB[0][decltype(uc)::value]); });
+    auto chunk = [&](int ch, auto setc) {
+        constexpr int set = decltype(setc)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ch + 1 < nchunks) {
+            stage_x(ch + 1);
+            load_w(ch + 1, std::integral_constant<int, set ^ 1>{});
+        }
+        const uint32_t xb = (ch & 1) * XB;
+        bf16x8 XC[2][NBLK];
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) XC[0][i] = lds_b128p(xa[i] + xb);
+        static_for<0, 8>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if constexpr (u + 1 < 8) {
+                constexpr int un = u + 1;
+#pragma unroll
+                for (int i = 0; i < NBLK; ++i) XC[un & 1][i] = lds_b128p((xa[i] ^ ((un & 3) * 32)) + (un >> 2) * XH + xb);
+            }
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WB[set][u]), XC[u & 1][i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next chunk's requests (no register-destination load across the back edge)
+        static_for<0, 8>([&](auto uc) { landed16(WB[set ^ 1][decltype(uc)::value]); });
+    };
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        chunk(ch, std::integral_constant<int, 0>{});
+        if (ch + 1 < nchunks) chunk(ch + 1, std::integral_constant<int, 1>{});
+    }
+
+    // ---- epilogue: fp32 tile through LDS, whole channel rows out to the pixels' places on the produced tensor
+    __syncthreads();
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {
+            const int p = i * 32 + (l & 31);
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int ck = 8 * wv + 2 * rq + (l >> 5);
+                *(lds_f32x4*)(uintptr_t)(lds0 + p * 512 + ((ck ^ (p & 31)) << 4)) =
+                    f32x4{acc[i][4 * rq], acc[i][4 * rq + 1], acc[i][4 * rq + 2], acc[i][4 * rq + 3]};
+            }
+        }
+    }
+    __syncthreads();
+    const int j = t & 15, col = n0 + 8 * j;
+    if (col >= a.Nc) return;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (a.bias) { b0 = *reinterpret_cast<const f32x4*>(a.bias + col); b1 = *reinterpret_cast<const f32x4*>(a.bias + col + 4); }
+#pragma unroll
+    for (int it = 0; it < PXT / 16; ++it) {
+        const int p = it * 16 + (t >> 4);
+        const int mm = m0 + p, n = mm >> a.lgGHW, r = mm & ((1 << a.lgGHW) - 1);
+        const size_t m = ((size_t)n * a.OH + (r >> a.lgGW) * a.so + cl.ao) * a.OW + (r & ((1 << a.lgGW) - 1)) * a.so + cl.bo;
+        f32x4 v0 = *(lds_f32x4*)(uintptr_t)(lds0 + p * 512 + (((2 * j) ^ (p & 31)) << 4)) + b0;
+        f32x4 v1 = *(lds_f32x4*)(uintptr_t)(lds0 + p * 512 + (((2 * j + 1) ^ (p & 31)) << 4)) + b1;
+        if (a.res) {
+            v0 += *reinterpret_cast<const f32x4*>(a.res + m * a.ldr + col);
+            v1 += *reinterpret_cast<const f32x4*>(a.res + m * a.ldr + col + 4);
+        }
+        if constexpr (OUT16) {
+            uint16_t* yp = reinterpret_cast<uint16_t*>(a.y) + m * a.ldy + col;
+            if (a.accumulate) {
+                const u32x4 o = *reinterpret_cast<const u32x4*>(yp);
+                v0 += f32x4{__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16), __uint_as_float(o.y & 0xffff0000u)};
+                v1 += f32x4{__uint_as_float(o.z << 16), __uint_as_float(o.z & 0xffff0000u), __uint_as_float(o.w << 16), __uint_as_float(o.w & 0xffff0000u)};
+            }
+            *reinterpret_cast<u32x4*>(yp) = u32x4{pack_bf16(v0.x, v0.y), pack_bf16(v0.z, v0.w), pack_bf16(v1.x, v1.y), pack_bf16(v1.z, v1.w)};
+        } else {
+            float* yp = reinterpret_cast<float*>(a.y) + m * a.ldy + col;
+            if (a.accumulate) { v0 += *reinterpret_cast<const f32x4*>(yp); v1 += *reinterpret_cast<const f32x4*>(yp + 4); }
+            *reinterpret_cast<f32x4*>(yp) = v0;
+            *reinterpret_cast<f32x4*>(yp + 4) = v1;
+        }
+    }
+}
+
 bool pw1_ok(const MiConvDesc* d, bool f32 = false, bool in32 = false) {
     if (in32) {
         if (d->KH != 1 || d->KW != 1 || d->pad != 0 || d->stride != 1 || d->mode != 1 || d->IH != d->OH || d->IW != d->OW) return false;
@@ -1330,3 +1514,92 @@ extern "C" int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* x2,
     MI_LAUNCH_CHECK();
     return 0;
 }
+
+static int ilog2_exact(int v) { int lg = 0; while ((1 << lg) < v) ++lg; return (1 << lg) == v ? lg : -1; }
+
+// descriptor -> classes; false when the kernel does not take the layer
+static bool gt_plan(const MiConvDesc* d, GtArgs& a, int* ncls, int* pxt) {
+    if (!d || d->mode != 1 || d->K1 != d->K || d->K % 64 || d->Nc % 64 || d->ldx % 8) return false;
+    const int k = d->KH, s = d->stride, p = d->pad;
+    if (d->KW != k || k * k > 16 || k < 1 || (s != 1 && s != 2) || p < 0 || p > 7) return false;
+    if ((long)d->Nc * d->K * 2 * k * k >= (1L << 31)) return false;
+    int GH, GW;
+    *ncls = 0;
+    if (!d->transposed) {
+        if (d->OH != (d->IH + 2 * p - k) / s + 1 || d->OW != (d->IW + 2 * p - k) / s + 1) return false;
+        GH = d->OH; GW = d->OW; a.si = s; a.so = 1;
+        GtClass c{};
+        for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx) {
+                const int tp = c.ntap++;
+                c.dyq |= (unsigned long long)(ky - p + 8) << (4 * tp); c.dxq |= (unsigned long long)(kx - p + 8) << (4 * tp);
+                c.wtq |= (unsigned long long)(ky * k + kx) << (4 * tp);
+            }
+        a.cls[(*ncls)++] = c;
+    } else {
+        // produced pixel oy = s u + cy gathers iy = (oy + p - ky) / s where that is divisible: ky = (cy + p) mod s, + s, ...
+        if (d->OH != s * d->IH || d->OW != s * d->IW) return false;      // (the layers of this path: the produced tensor is s x the gathered one)
+        GH = d->OH / s; GW = d->OW / s; a.si = 1; a.so = s;
+        for (int cy = 0; cy < s; ++cy)
+            for (int cx = 0; cx < s; ++cx) {
+                GtClass c{};
+                c.ao = cy; c.bo = cx;
+                for (int ky = (cy + p) % s; ky < k; ky += s)
+                    for (int kx = (cx + p) % s; kx < k; kx += s) {
+                        const int dy = (cy + p - ky) / s, dx = (cx + p - kx) / s;       // exact: the numerators are multiples of s
+                        if (dy < -8 || dy > 7 || dx < -8 || dx > 7) return false;
+                        const int tp = c.ntap++;
+                        c.dyq |= (unsigned long long)(dy + 8) << (4 * tp); c.dxq |= (unsigned long long)(dx + 8) << (4 * tp);
+                        c.wtq |= (unsigned long long)(ky * k + kx) << (4 * tp);
+                    }
+                if (c.ntap == 0) return false;
+                a.cls[(*ncls)++] = c;
+            }
+    }
+    a.lgGW = ilog2_exact(GW); a.lgGHW = ilog2_exact(GH * GW);
+    if (a.lgGW < 0 || a.lgGHW < 0) return false;
+    a.M = d->N * GH * GW; a.K = d->K; a.Nc = d->Nc; a.IH = d->IH; a.IW = d->IW; a.OH = d->OH; a.OW = d->OW;
+    if (a.M % 64) return false;
+    a.gy = (d->Nc + 127) / 128;
+    const bool small = a.M % 128 != 0 || (long)(a.M / 128) * a.gy * *ncls < 256;
+    *pxt = small ? 64 : 128;
+    a.gx = a.M / *pxt;
+    return true;
+}
+extern "C" int mi_conv_gt_supported(const MiConvDesc* d) {
+    GtArgs a{};
+    int ncls, pxt;
+    return gt_plan(d, a, &ncls, &pxt) ? 1 : 0;
+}
+// x: bf16 [N][IH][IW][K] (pixel stride ldx elements); w_frag_bf16: the layer's slice of mi_pack_weights_bf16's wfq (contraction over
+// the master layout's ci: the forward convs) or wdq (over co: the data gradients); y fp32 or bf16 (out_bf16), bias / residual fp32
+extern "C" int mi_conv_gt(const MiConvDesc* d, const void* x, const void* w_frag_bf16, const float* bias, const float* residual,
+                          void* y, int out_bf16, void* stream) {
+    MI_REQUIRE(d && x && w_frag_bf16 && y, "null argument");
+    GtArgs a{};
+    int ncls, pxt;
+    MI_REQUIRE(gt_plan(d, a, &ncls, &pxt), "descriptor not supported by the tap-gather kernel (bf16 mode, one source, K and Nc % 64 == 0, "
+               "k * k <= 16 taps, stride 1 / 2, power-of-two grids, N*GH*GW % 64 == 0)");
+    MI_REQUIRE((((uintptr_t)x | (uintptr_t)w_frag_bf16) & 15) == 0, "operands must be 16-byte aligned");
+    MI_REQUIRE(d->ldy % 8 == 0 && (!residual || d->ldr % 4 == 0), "pixel strides: y % 8, residual % 4");
+    a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_frag_bf16; a.bias = bias; a.res = residual; a.y = y;
+    a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.accumulate = d->accumulate;
+    dim3 grid((unsigned)a.gx, (unsigned)a.gy, (unsigned)ncls);
+    if (a.gy > 1 && a.gx % 8 == 0) grid = dim3((unsigned)(a.gx * a.gy), 1, (unsigned)ncls);
+    hipStream_t st = (hipStream_t)stream;
+#define MI_GT_GO(O16, PX) do { \
+        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_gt_kernel<O16, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); return true; }(); \
+        (void)once_; \
+        hipLaunchKernelGGL((conv_gt_kernel<O16, PX>), grid, dim3(256), (size_t)(PX == 128 ? 64 : 32) * 1024, st, a); } while (0)
+    if (pxt == 128) { if (out_bf16) MI_GT_GO(true, 128); else MI_GT_GO(false, 128); }
+    else { if (out_bf16) MI_GT_GO(true, 64); else MI_GT_GO(false, 64); }
+#undef MI_GT_GO
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+// pixels per workgroup and number of classes (launch attribution)
+extern "C" int mi_conv_gt_tile(const MiConvDesc* d, int* pxt, int* ncls) {
+    GtArgs a{};
+    return gt_plan(d, a, ncls, pxt) ? 0 : -1;
+}
+

@@ -545,6 +545,12 @@ class Unet(nn.Module):
                 oh, ow = ih * stride, iw * stride
             else:
                 oh, ow = (ih + 2 * pad - kh) // stride + 1, (iw + 2 * pad - kw) // stride + 1
+            if mode == K.MODE_BF16 and stride == 2 and x2 is None and inp.dtype == BF and out_dtype == torch.float32:
+                # Downsample / Upsample on the tap-gather kernel (round 4): bf16 copy of the input, fragment-order weights
+                y = K.conv_gt(inp, wfq_sh[offs[pre + "weight"]:], kh=kh, kw=kw, stride=stride, pad=pad, transposed=transposed_conv, K=ci, Nc=co,
+                              out_hw=(oh, ow), bias=sv[pre + "bias"] if bias else None, residual=residual)
+                if y is not None:
+                    return y
             assert out_dtype == torch.float32 and (inp.dtype == torch.float32 or (
                 stride == 2 and K.igemm_bf16_in_supported(ci, co, k, stride, transposed_conv, mode, (oh, ow)))), \
                 "bf16 block storage needs the tile kernel"
@@ -794,6 +800,10 @@ class Unet(nn.Module):
                                                                           accumulate=acc) is not None):
                     return
                 assert dy.dtype == torch.float32 and buf.dtype == torch.float32, "bf16 block storage needs the tile kernel"
+                if dy16 is not None and stride == 2 and K.conv_gt(dy16, wdq_sh[offs[pre + "weight"]:], kh=kh, kw=kw, stride=stride, pad=pad,
+                                                                  transposed=not transposed_conv, K=co, Nc=ci, out_hw=(ih, iw), out=buf,
+                                                                  accumulate=acc) is not None:
+                    return                                            # Downsample / Upsample data gradient on the tap-gather kernel
                 if dy16 is not None and K.igemm_bf16_in_supported(co, ci, k, stride, not transposed_conv, mode, (ih, iw)):
                     dy = dy16                                         # the copy the weight gradient reads: half the bytes, 64-channel stages
                 K.conv_igemm(dy, w, kh=kh, kw=kw, stride=stride, pad=pad, transposed=not transposed_conv, w_kn=False,

@@ -172,6 +172,40 @@ def igemm_bf16_in_supported(K, Nc, k, stride, transposed, mode, out_hw):
     return bool(load_library().mi_conv_igemm_bf16w_io_supported(C.byref(d)))
 
 
+USE_CONV_GT = debug_knob("MI_CONV_GT", "1") != "0"      # A/B switch: the tap-gather kernel for the stride-2 / transposed convs
+
+
+def conv_gt(x, wq, *, kh, kw, stride, pad, transposed, K, Nc, out_hw, bias=None, residual=None, out=None, accumulate=False,
+            out_dtype=torch.float32):
+    """The stride-2 / transposed convs and their data gradients through the tap-gather kernel (mi_conv_gt): x bf16, wq = the layer's
+    fragment-order weights (wfq: contraction over the master layout's ci, wdq: over co).  Returns None when the kernel does not take
+    the layer (the caller falls back to conv_igemm)."""
+    if not USE_CONV_GT or wq is None or x.dtype != torch.bfloat16:
+        return None
+    _need_gpu(x)
+    N, IH, IW, _ = x.shape
+    OH, OW = out_hw
+    d = MiConvDesc(N=N, IH=IH, IW=IW, OH=OH, OW=OW, K=K, Nc=Nc, KH=kh, KW=kw, stride=stride, pad=pad, transposed=int(transposed), w_kn=0,
+                   mode=MODE_BF16, K1=K, ldx=ld_of(x), ldx2=0, ldy=Nc if out is None else ld_of(out),
+                   ldr=ld_of(residual) if residual is not None else 0, accumulate=int(accumulate))
+    if d.ldy % 8 or not _query("mi_conv_gt_supported", d):
+        return None
+    if out is None:
+        assert not accumulate
+        out = new_act(N, OH, OW, Nc, x, out_dtype)
+        d.ldy = ld_of(out)
+    e0 = _probe_open()
+    check(load_library().mi_conv_gt(C.byref(d), _p(x), _p(wq), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv_gt")
+    if e0 is not None:
+        pxt, ncls = C.c_int(), C.c_int()
+        load_library().mi_conv_gt_tile(C.byref(d), C.byref(pxt), C.byref(ncls))
+        flops = 2.0 * N * OH * OW * Nc * K * (kh * kw if not (transposed and stride > 1) else kh * kw / (stride * stride))
+        nb = N * IH * IW * K * 2 + N * OH * OW * Nc * _esz(out) * (2 if accumulate else 1) + kh * kw * K * Nc * 2
+        _probe_close(e0, f"conv_gt_kernel<{'true' if _b16(out) else 'false'}, {pxt.value}>", flops,
+                     f"N{N} {IH}x{IW}->{OH}x{OW} K{K}->{Nc} k{kh} s{stride} T{int(transposed)} acc{int(accumulate)}", nb)
+    return out
+
+
 def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mode, x2=None,
                bias=None, residual=None, out=None, accumulate=False, wb=None):
     """y = conv(x [| x2]) per MiConvDesc.  x: [N,IH,IW,K1], x2: [N,IH,IW,K-K1] or None."""
@@ -487,7 +521,7 @@ def pack_table(entries, device):
     rec = np.zeros(len(entries), dtype=np.dtype(PACK_ENTRY))
     tile, T = 0, pack_weights_tile()
     for i, (off, taps, ci, co) in enumerate(entries):
-        rec[i] = (off, taps, ci, co, tile, int(taps in (1, 9) and ci % 64 == 0 and co % 64 == 0), 0)
+        rec[i] = (off, taps, ci, co, tile, int(taps in (1, 9, 16) and ci % 64 == 0 and co % 64 == 0), 0)
         tile += taps * ((ci + T - 1) // T) * ((co + T - 1) // T)
     return torch.from_numpy(rec.view(np.uint8).copy()).to(device), len(entries), tile
 

@@ -82,6 +82,16 @@ int mi_conv_igemm_bf16w_io(const MiConvDesc* d, const void* x, const void* x2, c
 /* tile instantiation mi_conv_igemm will launch for d (BM x BN); used to attribute profiles */
 int mi_conv_igemm_tile(const MiConvDesc* d, int* bm, int* bn);
 
+/* ---- tap-gather GEMM (round 4): the stride-2 Downsample conv (ddpm.py:79), the ConvTranspose2d(4, 2, 1) Upsample (ddpm.py:70) and
+ * their data gradients for bf16-stored activations, same contract as mi_conv_igemm (d->transposed = 1: the parity classes of the
+ * produced tensor run as blockIdx.z).  x bf16 (K % 64 == 0, one source, ldx % 8 == 0), weights in mi_pack_weights_bf16's fragment order
+ * (wfq for the contraction over the master layout's ci, wdq over co), Nc % 64 == 0, power-of-two class grids, N*GH*GW % 64 == 0.
+ * Activations by LDS-DMA gathered per tap (the stride is free), private weight streams, one barrier per 128 contraction channels. */
+int mi_conv_gt_supported(const MiConvDesc* d);
+int mi_conv_gt_tile(const MiConvDesc* d, int* pixels_per_workgroup, int* classes);
+int mi_conv_gt(const MiConvDesc* d, const void* x, const void* w_frag_bf16, const float* bias, const float* residual,
+               void* y, int out_bf16, void* stream);
+
 /* ---- 3x3 / stride 1 / pad 1 convolution with an LDS-staged halo tile (bf16 MFMA only) -------
  * Same contract as mi_conv_igemm for the Block conv (ddpm.py:116) and its data gradient
  * (d->transposed = 1 selects the flipped-tap form), but activations are staged once per

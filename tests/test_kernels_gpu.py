@@ -146,6 +146,62 @@ def test_stride2_family_reads_bf16_activations(K, cfg):
                      transposed=False, w_kn=True, K=32, Nc=32, out_hw=(4, 4), mode=1, wb=torch.zeros(9 * 32 * 32, device=DEV).bfloat16())
 
 
+@pytest.mark.parametrize("cfg", [dict(N=4, h=16, C=128), dict(N=8, h=8, C=256), dict(N=2, h=32, C=64), dict(N=4, h=8, C=64, Co=192),
+                                 dict(N=64, h=16, C=128), dict(N=1, h=8, C=64)])
+def test_stride2_family_tap_gather_kernel(K, cfg):
+    """mi_conv_gt (round 4): Downsample (3x3 / stride 2; reference ddpm.py:76-82), Upsample (ConvTranspose2d(4, 2, 1); ddpm.py:67-73)
+    and both data gradients for bf16-stored activations on the private-weight-stream machinery -- per tap a DMA gather of the strided
+    pixel rows, the transposed forms as four parity classes.  Against fp64 on the same bf16-rounded operands; bias, accumulate,
+    fp32 and bf16 outputs, 128- and 64-pixel tiles, a channel count that is not a multiple of 128."""
+    g = torch.Generator().manual_seed(97)
+    N, h, Ci = cfg["N"], cfg["h"], cfg["C"]
+    Co = cfg.get("Co", Ci)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+    K.PROBE = []
+    try:
+        # Downsample forward + its data gradient
+        x = torch.randn(N, Ci, 2 * h, 2 * h, generator=g).bfloat16()
+        w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)).bfloat16()
+        b = torch.randn(Co, generator=g)
+        xd = x.double().requires_grad_(True)
+        y = F.conv2d(xd, w.double(), b.double(), stride=2, padding=1)
+        dy = torch.randn(y.shape, generator=g).bfloat16()
+        y.backward(dy.double())
+        flat, wd, wf, offs, wdq, wfq = _pack(K, [conv_w_storage(w.float())], frag=True)
+        yg = K.conv_gt(nh(x), wfq, kh=3, kw=3, stride=2, pad=1, transposed=False, K=Ci, Nc=Co, out_hw=(h, h), bias=b.to(DEV))
+        y16 = K.conv_gt(nh(x), wfq, kh=3, kw=3, stride=2, pad=1, transposed=False, K=Ci, Nc=Co, out_hw=(h, h), bias=b.to(DEV),
+                        out_dtype=torch.bfloat16)
+        dxg = K.conv_gt(nh(dy), wdq, kh=3, kw=3, stride=2, pad=1, transposed=True, K=Co, Nc=Ci, out_hw=(2 * h, 2 * h))
+        dx2 = K.conv_gt(nh(dy), wdq, kh=3, kw=3, stride=2, pad=1, transposed=True, K=Co, Nc=Ci, out_hw=(2 * h, 2 * h), out=dxg.clone(),
+                        accumulate=True)
+        torch.cuda.synchronize()
+        assert yg is not None and yg.dtype == torch.float32 and rel_err(from_nhwc(yg), y) < 2e-5
+        assert y16.dtype == torch.bfloat16 and rel_err(from_nhwc(y16.float()), y) < 4e-3
+        assert rel_err(from_nhwc(dxg), xd.grad) < 2e-5 and rel_err(from_nhwc(dx2), 2 * xd.grad) < 2e-5
+        # Upsample forward + its data gradient
+        x = torch.randn(N, Ci, h, h, generator=g).bfloat16()
+        w = (torch.randn(Ci, Co, 4, 4, generator=g) / math.sqrt(Ci * 4)).bfloat16()
+        xd = x.double().requires_grad_(True)
+        y = F.conv_transpose2d(xd, w.double(), b.double(), stride=2, padding=1)
+        dy = torch.randn(y.shape, generator=g).bfloat16()
+        y.backward(dy.double())
+        flat, wd, wf, offs, wdq, wfq = _pack(K, [conv_w_storage(w.float(), transposed=True)], frag=True)
+        yg = K.conv_gt(nh(x), wfq, kh=4, kw=4, stride=2, pad=1, transposed=True, K=Ci, Nc=Co, out_hw=(2 * h, 2 * h), bias=b.to(DEV))
+        dxg = K.conv_gt(nh(dy), wdq, kh=4, kw=4, stride=2, pad=1, transposed=False, K=Co, Nc=Ci, out_hw=(h, h))
+        torch.cuda.synchronize()
+        assert rel_err(from_nhwc(yg), y) < 2e-5 and rel_err(from_nhwc(dxg), xd.grad) < 2e-5
+        syms = {q[0] for q in K.PROBE if q[0].startswith(("conv", "igemm"))}
+        assert syms and all(sy.startswith("conv_gt_kernel<") for sy in syms), syms
+    finally:
+        K.PROBE = None
+    # refused (-> None, the caller falls back): fp32 input, channels not a multiple of 64, odd grids
+    assert K.conv_gt(torch.zeros(2, 8, 8, 64, device=DEV), wfq, kh=3, kw=3, stride=2, pad=1, transposed=False, K=64, Nc=64, out_hw=(4, 4)) is None
+    assert K.conv_gt(torch.zeros(2, 8, 8, 32, device=DEV).bfloat16(), wfq, kh=3, kw=3, stride=2, pad=1, transposed=False, K=32, Nc=64,
+                     out_hw=(4, 4)) is None
+    assert K.conv_gt(torch.zeros(4, 14, 14, 64, device=DEV).bfloat16(), wfq, kh=3, kw=3, stride=2, pad=1, transposed=False, K=64, Nc=64,
+                     out_hw=(7, 7)) is None
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("C", [32, 128])
 def test_conv_transpose_all(K, mode, C):
@@ -902,18 +958,19 @@ def test_conv1x1_pw_fp32_input(K, cfg, out16, pw_always):
 
 def test_pack_weights_fragment_order(K):
     """The MFMA-fragment-order copies mi_conv3x3_pw streams (include/mi_ddpm.h): wfq[tap][co/32][ci/16][lane][8] and
-    wdq[tap][ci/32][co/16][lane][8] for the 3x3 and 1x1 layers with 64-multiples on both sides; the others get none (zero slice)."""
+    wdq[tap][ci/32][co/16][lane][8] for the 3x3, 1x1 and (round 4: the tap-gather kernel's Upsample) 4x4 layers with 64-multiples on
+    both sides; the others get none (zero slice)."""
     g = torch.Generator().manual_seed(29)
     ws = [torch.randn(3, 3, 128, 64, generator=g).to(DEV), torch.randn(1, 1, 128, 384, generator=g).to(DEV),
           torch.randn(3, 3, 192, 256, generator=g).to(DEV), torch.randn(3, 3, 40, 64, generator=g).to(DEV),
-          torch.randn(4, 4, 64, 64, generator=g).to(DEV)]
+          torch.randn(4, 4, 64, 64, generator=g).to(DEV), torch.randn(4, 4, 40, 64, generator=g).to(DEV)]
     flat, wd, wf, offs, wdq, wfq = _pack(K, ws, frag=True)
     torch.cuda.synchronize()
     for w, o in zip(ws, offs):
         kh, kw, ci, co = w.shape
         n = w.numel()
         assert torch.equal(wd[o:o + n].view(w.shape), w.to(torch.bfloat16))            # the plain copies are unchanged
-        if kh * kw not in (1, 9) or ci % 64 or co % 64:
+        if kh * kw not in (1, 9, 16) or ci % 64 or co % 64:
             assert not wdq[o:o + n].any() and not wfq[o:o + n].any()
             continue
         T = kh * kw

@@ -34,4 +34,16 @@ for IH, OH, Cc, k, T, name in [(32, 16, 128, 3, 0, "Downsample fwd"), (16, 8, 25
     fl = 2.0 * B * OH * OH * Cc * Cc * (k * k / 4 if T else k * k)
     t = timeit(lambda: K.conv_igemm(x, w, kh=k, kw=k, stride=2, pad=1, transposed=bool(T), w_kn=True, K=Cc, Nc=Cc,
                                     out_hw=(OH, OH), mode=1, out=y, wb=wb))
-    print(f"B{B} {name:17s} {IH}x{IH}->{OH}x{OH} C{Cc} k{k}: {t*1e6:7.1f} us {fl/t/1e12:6.1f} TF", flush=True)
+    x16 = x.bfloat16()
+    t16 = timeit(lambda: K.conv_igemm(x16, w, kh=k, kw=k, stride=2, pad=1, transposed=bool(T), w_kn=True, K=Cc, Nc=Cc,
+                                      out_hw=(OH, OH), mode=1, out=y, wb=wb))
+    # the tap-gather kernel (round 4): fragment-order weights
+    table, nent, tiles = K.pack_table([(0, k * k, Cc, Cc)], DEV)
+    WQ = [torch.zeros(w.numel(), device=DEV, dtype=torch.bfloat16) for _ in range(4)]
+    K.pack_weights_bf16(table, nent, tiles, w.reshape(-1), *WQ)
+    tg = timeit(lambda: K.conv_gt(x16, WQ[3], kh=k, kw=k, stride=2, pad=1, transposed=bool(T), K=Cc, Nc=Cc, out_hw=(OH, OH), out=y))
+    yr = K.conv_igemm(x16, w, kh=k, kw=k, stride=2, pad=1, transposed=bool(T), w_kn=True, K=Cc, Nc=Cc, out_hw=(OH, OH), mode=1, wb=wb)
+    yg = K.conv_gt(x16, WQ[3], kh=k, kw=k, stride=2, pad=1, transposed=bool(T), K=Cc, Nc=Cc, out_hw=(OH, OH))
+    err = float((yr - yg).norm() / yr.norm())
+    print(f"B{B} {name:17s} {IH}x{IH}->{OH}x{OH} C{Cc} k{k}: igemm fp32-in {t*1e6:6.1f} us | bf16-in {t16*1e6:6.1f} us {fl/t16/1e12:6.1f} TF | "
+          f"tap-gather {tg*1e6:6.1f} us {fl/tg/1e12:6.1f} TF  (rel diff {err:.1e})", flush=True)
