@@ -3,7 +3,7 @@ image-generation-models_amd/src/models/ddpm.py) against (a) golden vectors captu
 reference and (b) the CPU oracle on the same seeded inputs.
 Stated tolerances: epsilon-prediction rel-L2 <= 1e-4 in exact-fp32 mode (north_star; measured 3e-6); parameter gradients
 rel-L2 <= 1e-3 in fp32 mode (fp32 atomics reorder sums; measured 4e-6).  The bf16-MFMA mode's tolerances are each <= 2x the
-worst error MEASURED on the MI355X and recorded by these tests in profiles/r02_parity.json (epsilon 0.9-1.1e-2 -> 2e-2; loss
+worst error MEASURED on the MI355X and recorded by these tests in profiles/r04_parity.json (rule checked by tests/test_host_cpu.py) (epsilon 0.9-1.1e-2 -> 2e-2; loss
 3e-5..7e-5 -> 2e-4; per-tensor gradient rel-L2 0.05-0.10 -> 0.1-0.2; whole flat gradient 1.5e-2 -> 3e-2); the reference itself
 under CPU bf16 autocast sits at 1.6e-2 on the epsilon prediction."""
 import os
@@ -174,7 +174,7 @@ def _seeded(dim, mults, mode):
     return net.to(DEV)
 
 
-@pytest.mark.parametrize("mode,tol,gtol", [("fp32", 1e-4, 2e-3), ("bf16", 2e-2, 2e-1)])      # bf16 measured: 9.3e-3 / 9.9e-2
+@pytest.mark.parametrize("mode,tol,gtol", [("fp32", 1e-4, 2e-3), ("bf16", 1.85e-2, 1.8e-1)])      # bf16 measured: 9.4e-3 / 9.1e-2
 def test_mid_unet_golden(golden_dir, mode, tol, gtol):
     from src.models.ddpm import GaussianDiffusion
     g = _load(golden_dir, "mid_unet.npz")
@@ -195,16 +195,17 @@ def test_mid_unet_golden(golden_dir, mode, tol, gtol):
     ref = g["gradnorm_all"]
     e_norm = float(np.max(np.abs(norms - ref) / np.maximum(ref, 1e-6 + 0.01 * ref.max())))
     record(f"mid_unet_golden_{mode}", eps_rel_l2=e_eps, loss_abs=e_loss, worst_grad_rel_l2=max(gerr.values()),
-           worst_grad_key=max(gerr, key=gerr.get), worst_gradnorm_rel=e_norm)
+           worst_grad_key=max(gerr, key=gerr.get), worst_gradnorm_rel=e_norm,
+           bounds={"eps_rel_l2": tol, "worst_grad_rel_l2": gtol, "worst_gradnorm_rel": 1e-4 if mode == "fp32" else 8.5e-2})
     assert e_eps < tol
     assert e_loss < (3e-5 if mode == "fp32" else 1e-4)                     # bf16 measured 2.6e-5
     assert max(gerr.values()) < gtol, gerr
-    assert e_norm < (1e-4 if mode == "fp32" else 0.1)                     # bf16 measured 4.9e-2
+    assert e_norm < (1e-4 if mode == "fp32" else 8.5e-2)                  # bf16 measured 4.4e-2
     ok = np.abs(norms - ref) <= gtol * 2 * np.maximum(ref, 1e-6) + 1e-7
     assert ok.all(), [(k, a, b) for (k, _), a, b, o in zip(net.named_parameters(), norms, ref, ok) if not o]
 
 
-@pytest.mark.parametrize("mode,tol", [("fp32", 1e-4), ("bf16", 2e-2)])                        # bf16 measured: 8.9e-3
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-4), ("bf16", 1.75e-2)])                     # bf16 measured: 8.9e-3
 def test_cfg2_eps_prediction_golden(golden_dir, mode, tol):
     """BASELINE cfg 2 (dim 128, mults 1-2-4, 32x32): epsilon prediction vs the reference's output."""
     from src.models.ddpm import GaussianDiffusion
@@ -228,7 +229,7 @@ def test_cfg2_eps_prediction_golden(golden_dir, mode, tol):
     e_g1 = rel_err(dict(net.named_parameters())["final_conv.1.weight"].grad, _t(g["grad.final_conv.1.weight"]))
     e_g2 = rel_err(dict(net.named_parameters())["time_mlp.3.bias"].grad, _t(g["grad.time_mlp.3.bias"]))
     record(f"cfg2_eps_prediction_golden_{mode}", eps_rel_l2=e_eps, loss_abs=e_loss, worst_gradnorm_rel=e_norm,
-           grad_final_conv_rel_l2=e_g1, grad_time_mlp3_bias_rel_l2=e_g2)
+           grad_final_conv_rel_l2=e_g1, grad_time_mlp3_bias_rel_l2=e_g2, bounds={"eps_rel_l2": tol})
     assert e_eps < tol
     assert e_loss < (3e-5 if mode == "fp32" else 1e-4)                     # bf16 measured 1.6e-5
     if mode == "fp32":
@@ -269,7 +270,7 @@ def test_full_batch_properties():
         net.compute_mode = "bf16"
         yb = net(x, t)
     e = rel_err(yb, y)
-    record("cfg2_B128_forward_bf16_vs_fp32", eps_rel_l2=e)
+    record("cfg2_B128_forward_bf16_vs_fp32", eps_rel_l2=e, bounds={"eps_rel_l2": 2e-2})
     assert torch.isfinite(y).all() and e < 2e-2
 
 
@@ -304,11 +305,11 @@ def test_full_batch_backward_properties():
         out[f"{mode}_slices_vs_full_rel_l2"] = share
         assert torch.isfinite(full).all()
     out["bf16_vs_fp32_flat_grad_rel_l2"] = rel_err(grads["bf16"], grads["fp32"])
-    record("cfg2_B128_backward_properties", **out)
+    record("cfg2_B128_backward_properties", bounds={"bf16_slices_vs_full_rel_l2": 1.1e-2, "bf16_vs_fp32_flat_grad_rel_l2": 1.6e-2}, **out)
     assert out["fp32_rerun_rel_l2"] < 1e-6 and out["bf16_rerun_rel_l2"] < 1e-6        # measured 1.3e-7 / 5e-8 (atomics order)
     assert out["fp32_slices_vs_full_rel_l2"] < 1e-6                                    # measured 2.6e-7
     assert out["bf16_slices_vs_full_rel_l2"] < 1.1e-2     # measured 5.5e-3: slices round their bf16 tensors independently of the full batch
-    assert out["bf16_vs_fp32_flat_grad_rel_l2"] < 1.8e-2                               # measured 8.8e-3
+    assert out["bf16_vs_fp32_flat_grad_rel_l2"] < 1.6e-2                               # measured 8.2e-3
 
 
 def test_cfg3_per_gpu_batch_properties():
@@ -352,7 +353,7 @@ def test_cfg3_per_gpu_batch_properties():
     assert out["fp32_forward_rerun_rel_l2"] == 0.0 and out["bf16_forward_rerun_rel_l2"] == 0.0
     assert out["fp32_forward_slice_vs_full_rel_l2"] < 1e-5 and out["fp32_rerun_rel_l2"] < 1e-6 and out["bf16_rerun_rel_l2"] < 1e-6
     assert out["fp32_slices_vs_full_rel_l2"] < 1e-6
-    # bf16 bounds <= 2x the values measured on the MI355X (profiles/r03_parity.json): 1.02e-2, 5.9e-3, 1.17e-2, 8.1e-3
+    # bf16 bounds <= 2x the values measured on the MI355X (profiles/r04_parity.json): 1.02e-2, 5.9e-3, 1.17e-2, 8.1e-3
     assert out["bf16_forward_slice_vs_full_rel_l2"] < 2e-2       # slices pick other kernel plans (tile sizes) than the full batch
     assert out["bf16_slices_vs_full_rel_l2"] < 1.2e-2
     assert out["bf16_vs_fp32_eps_rel_l2"] < 2.3e-2 and out["bf16_vs_fp32_flat_grad_rel_l2"] < 1.6e-2
@@ -449,8 +450,10 @@ def test_fused_eval_path_matches_two_pass(golden_dir, monkeypatch):
     e12, e1, e2 = rel_err(y1, y2), rel_err(y1[:2], _t(g["eps_hat"])), rel_err(y2[:2], _t(g["eps_hat"]))
     e13, e3 = rel_err(y3, y1), rel_err(y3[:2], _t(g["eps_hat"]))
     record("cfg2_fused_eval_vs_two_pass_bf16", fused_vs_two_pass_rel_l2=e12, fused_vs_reference_rel_l2=e1, two_pass_vs_reference_rel_l2=e2,
-           epilogue_stats_vs_pass_stats_rel_l2=e13, epilogue_stats_vs_reference_rel_l2=e3)
-    assert e12 < 2e-2 and e1 < 2e-2 and e2 < 2e-2
+           epilogue_stats_vs_pass_stats_rel_l2=e13, epilogue_stats_vs_reference_rel_l2=e3,
+           bounds={"fused_vs_two_pass_rel_l2": 1.6e-2, "fused_vs_reference_rel_l2": 2e-2, "two_pass_vs_reference_rel_l2": 2e-2,
+                   "epilogue_stats_vs_reference_rel_l2": 2e-2})
+    assert e12 < 1.6e-2 and e1 < 2e-2 and e2 < 2e-2
     assert e13 < 2e-2 and e3 < 2e-2                # same statistics up to fp32 summation order: bf16 rounding flips only
     e42, e4 = rel_err(y4, y2), rel_err(y4[:2], _t(g["eps_hat"]))
     record("cfg2_default_fused_eval_bf16", default_vs_two_pass_rel_l2=e42, default_vs_reference_rel_l2=e4, fused_launches=len(fused_default))
@@ -524,7 +527,7 @@ def test_run_py_end_to_end(tmp_path):
     assert lines and "train_loss/loss" in lines[-1]
 
 
-@pytest.mark.parametrize("mode,tol,gtol", [("fp32", 1e-4, 3e-3), ("bf16", 2e-2, 1e-1)])      # bf16 measured: 1.1e-2 / 4.9e-2
+@pytest.mark.parametrize("mode,tol,gtol", [("fp32", 1e-4, 3e-3), ("bf16", 2e-2, 8.5e-2)])      # bf16 measured: 1.16e-2 / 4.3e-2
 def test_cfg3_celeba_shape_vs_oracle(mode, tol, gtol):
     """BASELINE cfg 3 (CelebA 64x64, hidden 64, mults 1-2-4-8, 4 levels): forward, loss and gradients vs the oracle."""
     from oracle import ddpm_oracle as O
@@ -556,10 +559,11 @@ def test_cfg3_celeba_shape_vs_oracle(mode, tol, gtol):
     flat_ref = torch.cat([p[k].grad.flatten() for k, _ in net.named_parameters()])
     flat_got = torch.cat([q.grad.detach().cpu().flatten() for _, q in net.named_parameters()])
     record(f"cfg3_celeba_shape_vs_oracle_{mode}", eps_rel_l2=e_eps, loss_abs=e_loss, worst_grad_rel_l2=max(errs.values()),
-           worst_grad_key=max(errs, key=errs.get), whole_grad_rel_l2=rel_err(flat_got, flat_ref))
+           worst_grad_key=max(errs, key=errs.get), whole_grad_rel_l2=rel_err(flat_got, flat_ref),
+           bounds={"eps_rel_l2": tol, "worst_grad_rel_l2": gtol, "whole_grad_rel_l2": 1e-4 if mode == "fp32" else 2.6e-2})
     assert e_eps < tol
     assert e_loss < (3e-5 if mode == "fp32" else 1e-4)                     # bf16 measured 3.4e-5
-    assert rel_err(flat_got, flat_ref) < (1e-4 if mode == "fp32" else 3e-2)     # whole gradient; bf16 measured 1.5e-2
+    assert rel_err(flat_got, flat_ref) < (1e-4 if mode == "fp32" else 2.6e-2)   # whole gradient; bf16 measured 1.3e-2
     bad = [(k, e) for k, e in errs.items() if e > gtol]
     assert not bad, bad[:8]
 
@@ -623,9 +627,10 @@ def test_ragged_batch_sizes_vs_oracle(B):
             e = float((q.grad.cpu() - r).norm() / r.norm())
             if e > worst:
                 worst, wkey = e, k
-    record(f"ragged_batch_B{B}_bf16", loss_abs=abs(float(loss) - float(ref_loss)), worst_grad_rel_l2=worst, worst_grad_key=wkey)
+    record(f"ragged_batch_B{B}_bf16", loss_abs=abs(float(loss) - float(ref_loss)), worst_grad_rel_l2=worst, worst_grad_key=wkey,
+           bounds={"worst_grad_rel_l2": 0.14 if B == 5 else 0.12})
     assert abs(float(loss) - float(ref_loss)) < 1.5e-4                    # measured 3.7e-5 / 7.3e-5
-    assert worst < 0.14, worst                                            # measured 6.7e-2 / 7.0e-2
+    assert worst < (0.14 if B == 5 else 0.12), worst                      # measured 8.0e-2 (B = 5) / 6.3e-2 (B = 12)
 
 
 def test_bf16_block_storage_end_to_end(golden_dir):
@@ -656,5 +661,6 @@ def test_bf16_block_storage_end_to_end(golden_dir):
     loss3.backward()
     e_full = rel_err(g16, net.flat_grads)
     record("cfg2_bf16_block_storage", eps_rel_l2=e_eps, loss_abs=e_loss, flat_grad_rel_l2_vs_fp32_storage=e_sto,
-           flat_grad_rel_l2_vs_fp32_mode=e_full)
-    assert e_eps < 2.1e-2 and e_loss < 1e-4 and e_sto < 8.4e-2 and e_full < 0.1       # measured 1.03e-2 / 4.9e-5 / 4.2e-2 / 5.2e-2
+           flat_grad_rel_l2_vs_fp32_mode=e_full,
+           bounds={"eps_rel_l2": 2.1e-2, "flat_grad_rel_l2_vs_fp32_storage": 8.4e-2, "flat_grad_rel_l2_vs_fp32_mode": 8.4e-2})
+    assert e_eps < 2.1e-2 and e_loss < 1e-4 and e_sto < 8.4e-2 and e_full < 8.4e-2       # measured 1.03e-2 / 4.9e-5 / 4.2e-2 / 5.2e-2
