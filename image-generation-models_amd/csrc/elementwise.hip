@@ -368,6 +368,29 @@ extern "C" int mi_f32_to_bf16_colsum(size_t M, int C, const float* x, int ldx, v
     return 0;
 }
 
+// The first pass only: y_bf16 (optional) = bf16(x) and one row of column sums per workgroup into part[*rows][C] (plain stores, every row
+// written; needs mi_f32_to_bf16_colsum_workspace(M, C) bytes) -- the caller adds the rows later, with those of the other reductions of
+// the backward pass, in one mi_rowsum_batch launch instead of a second pass per tensor.  *rows = 0: M < 4096, nothing was done (use
+// mi_f32_to_bf16_colsum, which adds such a tensor's sums atomically from <= 64 workgroups).
+extern "C" int mi_f32_to_bf16_colsum_part(size_t M, int C, const float* x, int ldx, void* y_bf16, int ldy, float* part, size_t part_bytes,
+                                          int* rows, void* stream) {
+    MI_REQUIRE(M > 0 && M < (1u << 31) && C >= 4 && C <= 1024 && C % 4 == 0 && ldx % 4 == 0 && x && part && rows &&
+               (((uintptr_t)x | (uintptr_t)part) & 15) == 0, "bad argument (4 <= C <= 1024, C and ldx % 4 == 0, x / part 16-byte aligned)");
+    MI_REQUIRE(!y_bf16 || (ldy % 4 == 0 && (((uintptr_t)y_bf16) & 7) == 0), "bf16 output: ldy % 4 == 0, 8-byte aligned");
+    *rows = 0;
+    if (M < 4096) return 0;
+    MI_REQUIRE(part_bytes >= mi_f32_to_bf16_colsum_workspace(M, C), "part too small (mi_f32_to_bf16_colsum_workspace)");
+    const int C4 = C / 4, nr = 256 / C4;
+    int rpb = 16 * nr; while ((M + rpb - 1) / rpb > 2048) rpb *= 2;
+    const unsigned nb = (unsigned)((M + rpb - 1) / rpb);
+    uint16_t* y = (uint16_t*)y_bf16;
+    if (y) hipLaunchKernelGGL((cvt_colsum_kernel<true, true, false>), dim3(nb), dim3(256), 0, ST, (int)M, C4, x, ldx, y, ldy, part, rpb);
+    else   hipLaunchKernelGGL((cvt_colsum_kernel<false, true, false>), dim3(nb), dim3(256), 0, ST, (int)M, C4, x, ldx, y, ldy, part, rpb);
+    MI_LAUNCH_CHECK();
+    *rows = (int)nb;
+    return 0;
+}
+
 extern "C" int mi_rowsum_batch(int n, const MiRowSum* items, void* stream) {
     MI_REQUIRE(n > 0 && n <= MI_ROWSUM_MAX && items, "1 <= n <= MI_ROWSUM_MAX items");
     RowSumArgs a{};

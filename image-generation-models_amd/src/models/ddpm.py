@@ -729,7 +729,7 @@ class Unet(nn.Module):
             if dy.dtype != torch.float32 or not K.s2_wgrad_supported(inp.shape[0], k, ci, co, transposed_conv, big, small, mode):
                 return None
             x16 = inp if inp.dtype == torch.bfloat16 else K.to_bf16(inp)
-            dy16 = K.to_bf16(dy, colsum_out=gv[pre + "bias"] if bias == "colsum" else None)
+            dy16 = K.to_bf16(dy, colsum_out=gv[pre + "bias"] if bias == "colsum" else None, defer=wq)
             ok = wq.push_s2(x16, dy16, gv[pre + "weight"], k=k, Ci=ci, Cj=co, gather_i=not transposed_conv, grid_g=big, grid_d=small,
                             mode=mode)
             assert ok
@@ -750,7 +750,7 @@ class Unet(nn.Module):
                     and K.small_cout_supported(1, ci, co)):
                 K.conv1x1_small_cout(2, inp, None, b=dy, out=gv[pre + "weight"])
                 if bias == "colsum":
-                    K.colsum(dy, gv[pre + "bias"])
+                    K.colsum(dy, gv[pre + "bias"], defer=wq)
                 if want_dx:
                     buf, acc = G.target(inp)
                     K.conv1x1_small_cout(1, dy, w, out=buf, accumulate=acc)
@@ -786,7 +786,7 @@ class Unet(nn.Module):
                              dbias=gv[pre + "bias"] if bias == "colsum" else None)
                 bias = None                                           # handled (fused or by conv_wgrad's fallback)
             if bias == "colsum":
-                K.colsum(dy, gv[pre + "bias"])
+                K.colsum(dy, gv[pre + "bias"], defer=wq)
             if not want_dx:
                 return
             fast = mode == K.MODE_BF16 and k in (1, 3) and stride == 1 and not transposed_conv
@@ -868,8 +868,6 @@ class Unet(nn.Module):
             wq.flush(kinds=(1,))
             buf, acc = G.target(inp)
             K.chan_layernorm_bwd(inp, sv[pre + "fn.norm.g"], dln, buf, acc, gv[pre + "fn.norm.g"], gv[pre + "fn.norm.b"], defer=wq)
-            if hook is not None:
-                wq.flush(kinds=(4,))                                   # data parallel: this record's range must be final when it is reported
 
         hook = self.grad_ready_hook
         dx_in = None
@@ -932,6 +930,7 @@ class Unet(nn.Module):
                 dt1 = K.mish_bwd(t1, da1)
                 lin_bwd(dt1, te, gv["time_mlp.1.weight"], gv["time_mlp.1.bias"], sv["time_mlp.1.weight"], want_dx=False)
             if hook is not None:
+                wq.flush(kinds=(4,))        # data parallel: the record's deferred row sums go out now, its range must be final when reported
                 fifo.append((rng, wq.pushed))
                 drain()
         wq.flush()

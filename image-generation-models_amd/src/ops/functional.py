@@ -946,10 +946,12 @@ def _rows(x):
     return x.shape[0] * x.shape[1] * x.shape[2] if x.dim() == 4 else x.shape[0]
 
 
-def colsum(x, out):
-    """out[c] += sum over pixels of x[..., c]"""
+def colsum(x, out, defer=None):
+    """out[c] += sum over pixels of x[..., c]; defer (a WgradQueue): as partial rows, added by the queue's batched row sum"""
     Cc = x.shape[-1]
     M = _rows(x)
+    if defer is not None and Cc % 4 == 0 and 4 <= Cc <= 1024 and _colsum_deferred(x, None, out, defer):
+        return
     e0 = _probe_open()
     vec = Cc % 4 == 0 and 4 <= Cc <= 1024 and ld_of(x) % 4 == 0 and x.data_ptr() % 16 == 0 and x.dtype == torch.float32
     lib = load_library()
@@ -963,13 +965,36 @@ def colsum(x, out):
 
 
 # --------------------------------------------------------------------------- norms
-def to_bf16(x, colsum_out=None):
+def _colsum_deferred(x, y16, out, defer):
+    """partial rows of x's column sums (and the bf16 copy y16, if given) now, their sum into `out` with the queue's batched row sum;
+    False: the tensor is too small for that (the caller takes the direct path)"""
+    M, Cc = _rows(x), x.shape[-1]
+    need = _cvt_colsum_ws(M, Cc)
+    if M < 4096 or not need or x.dtype != torch.float32 or ld_of(x) % 4 or x.data_ptr() % 16:
+        return False
+    part = defer.rows_buffer(x.device, need // 4)
+    rows = C.c_int(0)
+    e0 = _probe_open()
+    check(load_library().mi_f32_to_bf16_colsum_part(M, Cc, _p(x), ld_of(x), _p(y16), Cc, _p(part), need, C.byref(rows), _stream()),
+          "mi_f32_to_bf16_colsum_part")
+    if e0 is not None:
+        _probe_close(e0, "cvt_colsum_kernel<true, true>" if y16 is not None else "cvt_colsum_kernel<false, true>", 0.0, f"M{M} C{Cc} (rows)",
+                     M * Cc * (6.0 if y16 is not None else 4.0))
+    assert rows.value > 0
+    defer.push_rowsum(part, rows.value, Cc, Cc, out)
+    return True
+
+
+def to_bf16(x, colsum_out=None, defer=None):
     """bf16 copy (round-to-nearest-even) of an fp32 NHWC activation or channel slice: the MFMA operand of the next conv /
     weight gradient, rounded once for all of its consumers.  colsum_out (optional)[c] += sum over pixels of x[..., c] from the
-    same pass (the bias gradient when x is a conv's output gradient)."""
+    same pass (the bias gradient when x is a conv's output gradient); defer (a WgradQueue): the sums leave as partial rows and are
+    added by the queue's batched row sum (no second pass per tensor)."""
     _need_gpu(x)
     N, H, W, Cc = x.shape
     y = new_act(N, H, W, Cc, x, torch.bfloat16)
+    if colsum_out is not None and defer is not None and _colsum_deferred(x, y, colsum_out, defer):
+        return y
     e0 = _probe_open()
     if colsum_out is not None:
         lib = load_library()

@@ -144,6 +144,7 @@ SIGNATURES = {
     "mi_chan_layernorm_bwd_io": [_I, _I, _P, _I, _P, _F, _P, _I, _P, _I, _I, _P, _P, _I, _P],
     "mi_chan_layernorm_bwd_part": [_I, _I, _P, _I, _P, _F, _P, _I, _P, _I, _I, _P, _I, _P],
     "mi_rowsum_batch": [_I, _P, _P],
+    "mi_f32_to_bf16_colsum_part": [_Z, _I, _P, _I, _P, _I, _P, _Z, C.POINTER(C.c_int), _P],
     "mi_time_embed": [_I, _I, _P, _P, _P],
     "mi_sample_norm_supported": [_I, _I, _I],
     "mi_sample_norm_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P],

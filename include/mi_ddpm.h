@@ -363,6 +363,11 @@ int mi_debug_spin(int blocks, int usec, float* buf, size_t per_wg_floats, int mo
 size_t mi_f32_to_bf16_colsum_workspace(size_t M, int C);
 int mi_f32_to_bf16_colsum(size_t M, int C, const float* x, int ldx, void* y_bf16, int ldy, float* colsum, void* workspace,
                           size_t ws_bytes, void* stream);
+/* ... the first pass only: one row of column sums per workgroup into part[*rows][C] (every row written; mi_f32_to_bf16_colsum_workspace
+ * bytes), to be added by mi_rowsum_batch together with the other deferred reductions of a backward pass.  *rows = 0: the tensor is too
+ * small for partial rows (M < 4096), nothing was done. */
+int mi_f32_to_bf16_colsum_part(size_t M, int C, const float* x, int ldx, void* y_bf16, int ldy, float* part, size_t part_bytes,
+                               int* rows, void* stream);
 /* out[c] += sum_m x[m*ld + c]  (bias gradients) */
 int mi_colsum(int M, int C, const float* x, int ld, float* out, void* stream);
 /* dst[c] += sum_{r < rows} src[r*ld + c], c < cols, for up to MI_ROWSUM_MAX items in ONE launch: the second pass of the reductions
