@@ -43,7 +43,7 @@ NAMED_MB = {"fp32": 134.9, "bf16": 67.5}           # its algorithmic HBM bytes b
 # hash of this file at collection time, bench.py compares it with the tree's and says `traffic_stale` when the kernel changed since)
 KERNEL_SOURCES = {"conv_pw_kernel": "conv_pw.hip", "conv1x1_pw_kernel": "conv_pw.hip", "conv3x3_halo_kernel": "conv3x3_halo.hip",
                   "wgrad_tr_kernel": "wgrad_tr.hip", "wgrad1x1_tr_kernel": "wgrad1x1_tr.hip", "gn_mish": "norm_act.hip",
-                  "chan_ln": "norm_act.hip", "linattn": "linattn.hip", "igemm": "igemm_conv.hip", "wgrad_s2": "wgrad_s2_tr.hip"}
+                  "chan_ln": "norm_act.hip", "linattn": "linattn.hip", "igemm": "igemm_conv.hip", "conv_gt_kernel": "conv_pw.hip", "wgrad_s2": "wgrad_s2_tr.hip"}
 
 
 def kernel_source_sha(sym: str):

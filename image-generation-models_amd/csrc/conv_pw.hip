@@ -970,9 +970,13 @@ struct GtArgs {
     GtClass cls[4];
 };
 
-template <bool OUT16, int PXT>
+// F32: exact-fp32 mode (see conv_pw_kernel): fp32 x / y, fp32 fragment-order weights (mi_pack_weights_f32frag), v_mfma_f32_32x32x2_f32; the
+// byte geometry is the same -- a half is 32 channels, a fragment 8.
+template <bool OUT16, int PXT, bool F32 = false>
 __global__ __launch_bounds__(256, 2) void conv_gt_kernel(const GtArgs a) {
     MI_PRIO_UP();
+    static_assert(!F32 || !OUT16, "exact-fp32 mode writes fp32");
+    constexpr int ESZ = F32 ? 4 : 2, EPP = 16 / ESZ, HCH = 8 * EPP;      // element size, elements per 16-byte piece, channels per half
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
     constexpr int NBLK = PXT / 32;                   // 32-pixel MFMA blocks per wave = pixels a lane stages per half
@@ -987,7 +991,7 @@ __global__ __launch_bounds__(256, 2) void conv_gt_kernel(const GtArgs a) {
     }
     const GtClass cl = a.cls[blockIdx.z];
     const int m0 = bx * PXT, n0 = by * 128;
-    const int NB = a.Nc >> 5, KQ = a.K >> 4, kc64 = a.K >> 6;
+    const int NB = a.Nc >> 5, KQ = a.K / (2 * EPP), kc64 = a.K / HCH;
     const int nhc = cl.ntap * kc64, nchunks = (nhc + 1) >> 1;
     const bool live = n0 + 32 * wv < a.Nc;
     const int nb = min((n0 >> 5) + wv, NB - 1);
@@ -1006,16 +1010,16 @@ __global__ __launch_bounds__(256, 2) void conv_gt_kernel(const GtArgs a) {
         for (int h = 0; h < 2; ++h) {
             const int hc = min(2 * ch + h, 2 * nchunks - 1);
             const bool pad_half = hc >= nhc;                                      // odd number of halves: the last one multiplies zeros
-            const int hcc = min(hc, nhc - 1), tp = hcc / kc64, c0 = (hcc - tp * kc64) * 64;
+            const int hcc = min(hc, nhc - 1), tp = hcc / kc64, c0 = (hcc - tp * kc64) * HCH;
             const int dy = (int)((cl.dyq >> (4 * tp)) & 15) - 8, dx = (int)((cl.dxq >> (4 * tp)) & 15) - 8;
 #pragma unroll
             for (int j = 0; j < NBLK; ++j) {
                 const int px = 8 * (wv + 4 * j) + (l >> 3);
                 const int iy = iy0[j] + dy, ix = ix0[j] + dx;
                 const bool ok = !pad_half && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-                size_t off = (size_t)(pbase[j] + iy * a.IW + ix) * a.ldx + c0 + ((l & 7) ^ ((px >> 1) & 7)) * 8;
+                size_t off = (size_t)(pbase[j] + iy * a.IW + ix) * a.ldx + c0 + ((l & 7) ^ ((px >> 1) & 7)) * EPP;
                 asm volatile("" : "+v"(off));
-                const uint8_t* src = ok ? reinterpret_cast<const uint8_t*>(a.x) + off * 2 : zero;
+                const uint8_t* src = ok ? reinterpret_cast<const uint8_t*>(a.x) + off * ESZ : zero;
                 glds16(src, lds0 + (ch & 1) * XB + h * XH + (wv + 4 * j) * 1024);
             }
         }
@@ -1029,9 +1033,9 @@ __global__ __launch_bounds__(256, 2) void conv_gt_kernel(const GtArgs a) {
         constexpr int set = decltype(setc)::value;
         static_for<0, 2>([&](auto hcst) {
             constexpr int h = decltype(hcst)::value;
-            const int hcc = min(2 * min(ch, nchunks - 1) + h, nhc - 1), tp = hcc / kc64, c0 = (hcc - tp * kc64) * 64;
+            const int hcc = min(2 * min(ch, nchunks - 1) + h, nhc - 1), tp = hcc / kc64, c0 = (hcc - tp * kc64) * HCH;
             const int wt = (int)((cl.wtq >> (4 * tp)) & 15);
-            const uint64_t q = (uint64_t)(uintptr_t)(wbase + (size_t)wt * tap_bytes + (size_t)(c0 >> 4) * 1024);
+            const uint64_t q = (uint64_t)(uintptr_t)(wbase + (size_t)wt * tap_bytes + (size_t)(c0 / (2 * EPP)) * 1024);
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
             const uint64_t sb = ((uint64_t)hi << 32) | lo;
             static_for<0, 4>([&](auto uc) { gload16s<decltype(uc)::value * 1024>(WB[set][4 * h + decltype(uc)::value], sb, wl16); });
@@ -1074,8 +1078,14 @@ __global__ __launch_bounds__(256, 2) void conv_gt_kernel(const GtArgs a) {
                 for (int i = 0; i < NBLK; ++i) XC[un & 1][i] = lds_b128p((xa[i] ^ ((un & 3) * 32)) + (un >> 2) * XH + xb);
             }
 #pragma unroll
-            for (int i = 0; i < NBLK; ++i)
+            for (int i = 0; i < NBLK; ++i) {
+                if constexpr (F32) {
+                    const f32x4 wv4 = __builtin_bit_cast(f32x4, WB[set][u]), xv4 = __builtin_bit_cast(f32x4, XC[u & 1][i]);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv4[jj], xv4[jj], acc[i], 0, 0, 0);
+                } else
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WB[set][u]), XC[u & 1][i], acc[i], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next chunk's requests (no register-destination load across the back edge)
@@ -1519,10 +1529,10 @@ static int ilog2_exact(int v) { int lg = 0; while ((1 << lg) < v) ++lg; return (
 
 // descriptor -> classes; false when the kernel does not take the layer
 static bool gt_plan(const MiConvDesc* d, GtArgs& a, int* ncls, int* pxt) {
-    if (!d || d->mode != 1 || d->K1 != d->K || d->K % 64 || d->Nc % 64 || d->ldx % 8) return false;
+    if (!d || (d->mode != 1 && d->mode != 0) || d->K1 != d->K || d->K % 64 || d->Nc % 64 || d->ldx % (d->mode == 1 ? 8 : 4)) return false;
     const int k = d->KH, s = d->stride, p = d->pad;
     if (d->KW != k || k * k > 16 || k < 1 || (s != 1 && s != 2) || p < 0 || p > 7) return false;
-    if ((long)d->Nc * d->K * 2 * k * k >= (1L << 31)) return false;
+    if ((long)d->Nc * d->K * (d->mode == 1 ? 2 : 4) * k * k >= (1L << 31)) return false;
     int GH, GW;
     *ncls = 0;
     if (!d->transposed) {
@@ -1571,28 +1581,31 @@ extern "C" int mi_conv_gt_supported(const MiConvDesc* d) {
     int ncls, pxt;
     return gt_plan(d, a, &ncls, &pxt) ? 1 : 0;
 }
-// x: bf16 [N][IH][IW][K] (pixel stride ldx elements); w_frag_bf16: the layer's slice of mi_pack_weights_bf16's wfq (contraction over
-// the master layout's ci: the forward convs) or wdq (over co: the data gradients); y fp32 or bf16 (out_bf16), bias / residual fp32
-extern "C" int mi_conv_gt(const MiConvDesc* d, const void* x, const void* w_frag_bf16, const float* bias, const float* residual,
+// x: bf16 [N][IH][IW][K] (pixel stride ldx elements); w_frag: the layer's slice of mi_pack_weights_bf16's wfq (contraction over the master
+// layout's ci: the forward convs) or wdq (over co: the data gradients); y fp32 or bf16 (out_bf16), bias / residual fp32.
+// d->mode = 0 (exact-fp32 mode): x and y fp32 (ldx % 4 == 0), w_frag = the slice of mi_pack_weights_f32frag's wfq32 / wdq32.
+extern "C" int mi_conv_gt(const MiConvDesc* d, const void* x, const void* w_frag, const float* bias, const float* residual,
                           void* y, int out_bf16, void* stream) {
-    MI_REQUIRE(d && x && w_frag_bf16 && y, "null argument");
+    MI_REQUIRE(d && x && w_frag && y, "null argument");
     GtArgs a{};
     int ncls, pxt;
-    MI_REQUIRE(gt_plan(d, a, &ncls, &pxt), "descriptor not supported by the tap-gather kernel (bf16 mode, one source, K and Nc % 64 == 0, "
+    MI_REQUIRE(gt_plan(d, a, &ncls, &pxt), "descriptor not supported by the tap-gather kernel (one source, K and Nc % 64 == 0, "
                "k * k <= 16 taps, stride 1 / 2, power-of-two grids, N*GH*GW % 64 == 0)");
-    MI_REQUIRE((((uintptr_t)x | (uintptr_t)w_frag_bf16) & 15) == 0, "operands must be 16-byte aligned");
+    MI_REQUIRE((((uintptr_t)x | (uintptr_t)w_frag) & 15) == 0, "operands must be 16-byte aligned");
     MI_REQUIRE(d->ldy % 8 == 0 && (!residual || d->ldr % 4 == 0), "pixel strides: y % 8, residual % 4");
-    a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_frag_bf16; a.bias = bias; a.res = residual; a.y = y;
+    MI_REQUIRE(d->mode == 1 || !out_bf16, "the exact-fp32 kernel writes fp32");
+    a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_frag; a.bias = bias; a.res = residual; a.y = y;
     a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.accumulate = d->accumulate;
     dim3 grid((unsigned)a.gx, (unsigned)a.gy, (unsigned)ncls);
     if (a.gy > 1 && a.gx % 8 == 0) grid = dim3((unsigned)(a.gx * a.gy), 1, (unsigned)ncls);
     hipStream_t st = (hipStream_t)stream;
-#define MI_GT_GO(O16, PX) do { \
-        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_gt_kernel<O16, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); return true; }(); \
+#define MI_GT_GO(O16, PX, F) do { \
+        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_gt_kernel<O16, PX, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); return true; }(); \
         (void)once_; \
-        hipLaunchKernelGGL((conv_gt_kernel<O16, PX>), grid, dim3(256), (size_t)(PX == 128 ? 64 : 32) * 1024, st, a); } while (0)
-    if (pxt == 128) { if (out_bf16) MI_GT_GO(true, 128); else MI_GT_GO(false, 128); }
-    else { if (out_bf16) MI_GT_GO(true, 64); else MI_GT_GO(false, 64); }
+        hipLaunchKernelGGL((conv_gt_kernel<O16, PX, F>), grid, dim3(256), (size_t)(PX == 128 ? 64 : 32) * 1024, st, a); } while (0)
+    if (d->mode == 0) { if (pxt == 128) MI_GT_GO(false, 128, true); else MI_GT_GO(false, 64, true); }
+    else if (pxt == 128) { if (out_bf16) MI_GT_GO(true, 128, false); else MI_GT_GO(false, 128, false); }
+    else { if (out_bf16) MI_GT_GO(true, 64, false); else MI_GT_GO(false, 64, false); }
 #undef MI_GT_GO
     MI_LAUNCH_CHECK();
     return 0;

@@ -551,6 +551,11 @@ class Unet(nn.Module):
                               out_hw=(oh, ow), bias=sv[pre + "bias"] if bias else None, residual=residual)
                 if y is not None:
                     return y
+            if mode == K.MODE_FP32 and stride == 2 and x2 is None and inp.dtype == torch.float32 and out_dtype == torch.float32:
+                y = K.conv_gt(inp, wfq32_sh[offs[pre + "weight"]:], kh=kh, kw=kw, stride=stride, pad=pad, transposed=transposed_conv, K=ci, Nc=co,
+                              out_hw=(oh, ow), bias=sv[pre + "bias"] if bias else None, residual=residual, mode=mode)
+                if y is not None:
+                    return y
             assert out_dtype == torch.float32 and (inp.dtype == torch.float32 or (
                 stride == 2 and K.igemm_bf16_in_supported(ci, co, k, stride, transposed_conv, mode, (oh, ow)))), \
                 "bf16 block storage needs the tile kernel"
@@ -800,6 +805,10 @@ class Unet(nn.Module):
                                                                           accumulate=acc) is not None):
                     return
                 assert dy.dtype == torch.float32 and buf.dtype == torch.float32, "bf16 block storage needs the tile kernel"
+                if (mode == K.MODE_FP32 and stride == 2 and K.conv_gt(dy, wdq32_sh[offs[pre + "weight"]:], kh=kh, kw=kw, stride=stride, pad=pad,
+                                                                     transposed=not transposed_conv, K=co, Nc=ci, out_hw=(ih, iw), out=buf,
+                                                                     accumulate=acc, mode=mode) is not None):
+                    return
                 if dy16 is not None and stride == 2 and K.conv_gt(dy16, wdq_sh[offs[pre + "weight"]:], kh=kh, kw=kw, stride=stride, pad=pad,
                                                                   transposed=not transposed_conv, K=co, Nc=ci, out_hw=(ih, iw), out=buf,
                                                                   accumulate=acc) is not None:

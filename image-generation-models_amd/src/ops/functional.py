@@ -176,17 +176,17 @@ USE_CONV_GT = debug_knob("MI_CONV_GT", "1") != "0"      # A/B switch: the tap-ga
 
 
 def conv_gt(x, wq, *, kh, kw, stride, pad, transposed, K, Nc, out_hw, bias=None, residual=None, out=None, accumulate=False,
-            out_dtype=torch.float32):
+            out_dtype=torch.float32, mode=MODE_BF16):
     """The stride-2 / transposed convs and their data gradients through the tap-gather kernel (mi_conv_gt): x bf16, wq = the layer's
     fragment-order weights (wfq: contraction over the master layout's ci, wdq: over co).  Returns None when the kernel does not take
-    the layer (the caller falls back to conv_igemm)."""
-    if not USE_CONV_GT or wq is None or x.dtype != torch.bfloat16:
+    the layer (the caller falls back to conv_igemm).  mode = MODE_FP32: the exact-fp32 instantiation (x fp32, wq = wfq32 / wdq32)."""
+    if not USE_CONV_GT or wq is None or x.dtype != (torch.bfloat16 if mode == MODE_BF16 else torch.float32):
         return None
     _need_gpu(x)
     N, IH, IW, _ = x.shape
     OH, OW = out_hw
     d = MiConvDesc(N=N, IH=IH, IW=IW, OH=OH, OW=OW, K=K, Nc=Nc, KH=kh, KW=kw, stride=stride, pad=pad, transposed=int(transposed), w_kn=0,
-                   mode=MODE_BF16, K1=K, ldx=ld_of(x), ldx2=0, ldy=Nc if out is None else ld_of(out),
+                   mode=mode, K1=K, ldx=ld_of(x), ldx2=0, ldy=Nc if out is None else ld_of(out),
                    ldr=ld_of(residual) if residual is not None else 0, accumulate=int(accumulate))
     if d.ldy % 8 or not _query("mi_conv_gt_supported", d):
         return None
@@ -200,8 +200,8 @@ def conv_gt(x, wq, *, kh, kw, stride, pad, transposed, K, Nc, out_hw, bias=None,
         pxt, ncls = C.c_int(), C.c_int()
         load_library().mi_conv_gt_tile(C.byref(d), C.byref(pxt), C.byref(ncls))
         flops = 2.0 * N * OH * OW * Nc * K * (kh * kw if not (transposed and stride > 1) else kh * kw / (stride * stride))
-        nb = N * IH * IW * K * 2 + N * OH * OW * Nc * _esz(out) * (2 if accumulate else 1) + kh * kw * K * Nc * 2
-        _probe_close(e0, f"conv_gt_kernel<{'true' if _b16(out) else 'false'}, {pxt.value}>", flops,
+        nb = N * IH * IW * K * _esz(x) + N * OH * OW * Nc * _esz(out) * (2 if accumulate else 1) + kh * kw * K * Nc * _esz(x)
+        _probe_close(e0, f"conv_gt_kernel<{'true' if _b16(out) else 'false'}, {pxt.value}{', true' if mode == MODE_FP32 else ''}>", flops,
                      f"N{N} {IH}x{IW}->{OH}x{OW} K{K}->{Nc} k{kh} s{stride} T{int(transposed)} acc{int(accumulate)}", nb)
     return out
 

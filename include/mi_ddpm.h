@@ -86,10 +86,11 @@ int mi_conv_igemm_tile(const MiConvDesc* d, int* bm, int* bn);
  * their data gradients for bf16-stored activations, same contract as mi_conv_igemm (d->transposed = 1: the parity classes of the
  * produced tensor run as blockIdx.z).  x bf16 (K % 64 == 0, one source, ldx % 8 == 0), weights in mi_pack_weights_bf16's fragment order
  * (wfq for the contraction over the master layout's ci, wdq over co), Nc % 64 == 0, power-of-two class grids, N*GH*GW % 64 == 0.
- * Activations by LDS-DMA gathered per tap (the stride is free), private weight streams, one barrier per 128 contraction channels. */
+ * Activations by LDS-DMA gathered per tap (the stride is free), private weight streams, one barrier per 128 contraction channels.
+ * d->mode = 0: the exact-fp32 instantiation -- x / y fp32 (ldx % 4 == 0), weights from mi_pack_weights_f32frag (wfq32 / wdq32). */
 int mi_conv_gt_supported(const MiConvDesc* d);
 int mi_conv_gt_tile(const MiConvDesc* d, int* pixels_per_workgroup, int* classes);
-int mi_conv_gt(const MiConvDesc* d, const void* x, const void* w_frag_bf16, const float* bias, const float* residual,
+int mi_conv_gt(const MiConvDesc* d, const void* x, const void* w_frag, const float* bias, const float* residual,
                void* y, int out_bf16, void* stream);
 
 /* ---- 3x3 / stride 1 / pad 1 convolution with an LDS-staged halo tile (bf16 MFMA only) -------

@@ -202,6 +202,48 @@ def test_stride2_family_tap_gather_kernel(K, cfg):
                      out_hw=(7, 7)) is None
 
 
+@pytest.mark.parametrize("cfg", [dict(N=4, h=16, C=128), dict(N=8, h=8, C=256), dict(N=2, h=16, C=64, Co=192)])
+def test_stride2_family_tap_gather_kernel_fp32_mode(K, cfg):
+    """The exact-fp32 instantiation of mi_conv_gt (Unet.compute_mode = "fp32": v_mfma_f32_32x32x2_f32, fp32 tensors, weights from
+    mi_pack_weights_f32frag): the four stride-2 layer kinds against fp64 on the same fp32 operands, <= 3e-6."""
+    g = torch.Generator().manual_seed(101)
+    N, h, Ci = cfg["N"], cfg["h"], cfg["C"]
+    Co = cfg.get("Co", Ci)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+
+    def frag32(ws):
+        n = (ws.numel() + 63) // 64 * 64
+        flat = torch.zeros(n, device=DEV); flat[:ws.numel()] = ws.reshape(-1)
+        table, nent, tiles = K.pack_table([(0, ws.shape[0] * ws.shape[1], ws.shape[2], ws.shape[3])], DEV)
+        wdq32, wfq32 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        K.pack_weights_f32frag(table, nent, tiles, flat, wdq32, wfq32)
+        return wdq32, wfq32
+    x = torch.randn(N, Ci, 2 * h, 2 * h, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)
+    b = torch.randn(Co, generator=g)
+    xd = x.double().requires_grad_(True)
+    y = F.conv2d(xd, w.double(), b.double(), stride=2, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    wdq32, wfq32 = frag32(conv_w_storage(w))
+    yg = K.conv_gt(nh(x), wfq32, kh=3, kw=3, stride=2, pad=1, transposed=False, K=Ci, Nc=Co, out_hw=(h, h), bias=b.to(DEV), mode=K.MODE_FP32)
+    dxg = K.conv_gt(nh(dy), wdq32, kh=3, kw=3, stride=2, pad=1, transposed=True, K=Co, Nc=Ci, out_hw=(2 * h, 2 * h), mode=K.MODE_FP32)
+    torch.cuda.synchronize()
+    assert yg is not None and dxg is not None
+    assert rel_err(from_nhwc(yg), y) < 3e-6 and rel_err(from_nhwc(dxg), xd.grad) < 3e-6
+    x = torch.randn(N, Ci, h, h, generator=g)
+    w = torch.randn(Ci, Co, 4, 4, generator=g) / math.sqrt(Ci * 4)
+    xd = x.double().requires_grad_(True)
+    y = F.conv_transpose2d(xd, w.double(), b.double(), stride=2, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    wdq32, wfq32 = frag32(conv_w_storage(w, transposed=True))
+    yg = K.conv_gt(nh(x), wfq32, kh=4, kw=4, stride=2, pad=1, transposed=True, K=Ci, Nc=Co, out_hw=(2 * h, 2 * h), bias=b.to(DEV), mode=K.MODE_FP32)
+    dxg = K.conv_gt(nh(dy), wdq32, kh=4, kw=4, stride=2, pad=1, transposed=False, K=Co, Nc=Ci, out_hw=(h, h), mode=K.MODE_FP32)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(yg), y) < 3e-6 and rel_err(from_nhwc(dxg), xd.grad) < 3e-6
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("C", [32, 128])
 def test_conv_transpose_all(K, mode, C):

@@ -75,6 +75,16 @@ for _ in range(5):
             WQ = [torch.zeros(w.numel(), device=DEV, dtype=torch.bfloat16) for _ in range(4)]
             K.pack_weights_bf16(table, nent, tiles, w.reshape(-1), *WQ)
         K.conv3x3_bf16w(x, WQ[1], K=Ci, Nc=Co, flip=False, out=y, wq=WQ[3])
+    elif which in ("gtdown", "gtup"):     # the tap-gather kernel: Downsample (3x3 / stride 2) on [B,H,H,Ci], Upsample (4x4 / stride 2 transposed)
+        k = 3 if which == "gtdown" else 4
+        if "WG" not in globals():
+            wg = torch.randn(k, k, Ci, Co, device=DEV) * 0.05
+            table, nent, tiles = K.pack_table([(0, k * k, Ci, Co)], DEV)
+            WG = [torch.zeros(wg.numel(), device=DEV, dtype=torch.bfloat16) for _ in range(4)]
+            K.pack_weights_bf16(table, nent, tiles, wg.reshape(-1), *WG)
+            YG = torch.empty(B, H // 2 if which == "gtdown" else 2 * H, H // 2 if which == "gtdown" else 2 * H, Co, device=DEV)
+        K.conv_gt(x.bfloat16() if x.dtype != torch.bfloat16 else x, WG[3], kh=k, kw=k, stride=2, pad=1, transposed=which == "gtup", K=Ci, Nc=Co,
+                  out_hw=(YG.shape[1], YG.shape[2]), out=YG)
     elif which == "igemm":
         K.conv_igemm(x, w, kh=3, kw=3, stride=1, pad=1, transposed=False, w_kn=True, K=Ci, Nc=Co, out_hw=(H, H), mode=1, out=y)
 torch.cuda.synchronize()

@@ -21,6 +21,12 @@ CASES = {
     "pw_128_16_256_256_bf16": ("conv_pw_kernel<true, 0, 0, 128> [16x16]", "[128,16,16,256]->256 bf16 storage", conv_bytes(128, 16, 256, 256, 2, 2)),
     "fusedpw_128_32_128_128_bf16": ("conv_pw_kernel<true, 2, 0, 128>", "fused GN+Mish+conv [128,32,32,128]->128 bf16 storage (private-weight-stream kernel)",
                                     conv_bytes(128, 32, 128, 128, 2, 2) + 3 * 128 * 128 * 4),
+    "fusedpw_128_32_128_128_fp32": ("conv_pw_kernel<false, 2, 0, 128, true>", "fused GN+Mish+conv [128,32,32,128]->128 fp32 storage (private-weight-stream kernel, round 4)",
+                                    conv_bytes(128, 32, 128, 128, 4, 4) + 3 * 128 * 128 * 4),
+    "gtdown_128_32_128_128_bf16": ("conv_gt_kernel<false, 128> [Downsample]", "Downsample 3x3 / stride 2 [128,32,32,128] bf16 -> [128,16,16,128] fp32 (tap-gather kernel)",
+                                   128 * 32 * 32 * 128 * 2 + 128 * 16 * 16 * 128 * 4 + 9 * 128 * 128 * 2),
+    "gtup_128_16_128_128_bf16": ("conv_gt_kernel<false, 128> [Upsample]", "Upsample ConvTranspose2d(4, 2, 1) [128,16,16,128] bf16 -> [128,32,32,128] fp32 (tap-gather kernel)",
+                                 128 * 16 * 16 * 128 * 2 + 128 * 32 * 32 * 128 * 4 + 16 * 128 * 128 * 2),
     "wgrad_128_32_128_128_bf16": ("wgrad_tr_kernel[single]", "[128,32,32,128]x[128,32,32,128] bf16 operands, one layer per launch",
                                   2 * 128 * 32 * 32 * 128 * 2 + 9 * 128 * 128 * 4),
     "wgrad_128_8_512_512_bf16": ("wgrad_tr_kernel[single 8x8]", "[128,8,8,512]x[128,8,8,512] bf16 operands, one layer per launch",
@@ -33,7 +39,7 @@ CASES = {
     "fused_128_32_128_128_fp32": ("conv3x3_halo_kernel<256, 64, 3, false, 0, 8, true>", "fused GN+Mish+conv [128,32,32,128]->128 fp32 storage",
                                   conv_bytes(128, 32, 128, 128, 4, 4) + 3 * 128 * 128 * 4),
 }
-MAIN = {"pw": "conv_pw_kernel", "fusedpw": "conv_pw_kernel", "shift": "conv_shift_kernel", "halo": "conv3x3_halo_kernel", "fused": "conv3x3_halo_kernel", "wgrad": "wgrad_tr_kernel(", "wgradq": "wgrad_tr_kernel("}
+MAIN = {"pw": "conv_pw_kernel", "fusedpw": "conv_pw_kernel", "gtdown": "conv_gt_kernel", "gtup": "conv_gt_kernel", "shift": "conv_shift_kernel", "halo": "conv3x3_halo_kernel", "fused": "conv3x3_halo_kernel", "wgrad": "wgrad_tr_kernel(", "wgradq": "wgrad_tr_kernel("}
 
 # HBM-bound kernels (tools/bench_one.py gn / ln / attn / c1x1 at level 0, B = 128, bf16 storage): every kernel of the pass gets a row
 E0 = 128 * 32 * 32 * 128

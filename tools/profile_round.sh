@@ -4,7 +4,7 @@
 #  2. the same over 10 bare training steps (per-kernel ms/step), and over cfg 3 at B=32
 #  3. PMC passes (separate runs, never combined with trace domains other than --kernel-trace): HBM traffic (FETCH_SIZE /
 #     WRITE_SIZE) of the dominant kernels on their cfg-2 shapes and the SQ / TCC sets of tools/pmc.sh
-tag=${1:-r03}
+tag=${1:-r04}
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $OUT
@@ -19,7 +19,7 @@ cp /tmp/prof_c/*kernel_stats.csv $OUT/cfg3_b32_kernel_stats.csv
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_s -o s -- python $GRAFT_REPO_ROOT/tools/sample_steps.py 40 > /dev/null 2>&1
 cp /tmp/prof_s/*kernel_stats.csv $OUT/denoise_kernel_stats.csv
 cd $GRAFT_REPO_ROOT
-for cfg in "pw 128 8 512 512 bf16" "pw 128 32 128 128 bf16" "pw 128 16 256 256 bf16" "fusedpw 128 32 128 128 bf16" "halo 128 32 128 128 fp32" "wgrad 128 32 128 128 bf16" "wgrad 128 8 512 512 bf16" "wgradq 128 0 0 0 bf16" "fused 128 32 128 128 bf16" "fused 128 32 128 128 fp32" "gn 128 32 128 128 bf16" "ln 128 32 128 128 bf16" "attn 128 32 128 128 bf16" "c1x1 128 32 128 384 bf16"; do
+for cfg in "pw 128 8 512 512 bf16" "pw 128 32 128 128 bf16" "pw 128 16 256 256 bf16" "fusedpw 128 32 128 128 bf16" "fusedpw 128 32 128 128 fp32" "gtdown 128 32 128 128 bf16" "gtup 128 16 128 128 bf16" "halo 128 32 128 128 fp32" "wgrad 128 32 128 128 bf16" "wgrad 128 8 512 512 bf16" "wgradq 128 0 0 0 bf16" "fused 128 32 128 128 bf16" "fused 128 32 128 128 fp32" "gn 128 32 128 128 bf16" "ln 128 32 128 128 bf16" "attn 128 32 128 128 bf16" "c1x1 128 32 128 384 bf16"; do
   name=$(echo $cfg | tr ' ' '_')
   timeout 400 bash tools/pmc_traffic.sh ${tag}_$name $cfg > $OUT/pmc_traffic_$name.txt 2>&1
 done
