@@ -226,52 +226,57 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     //      destination registers are touched again only behind coef_landed(), which sits after the counted wait that covers them.
     f32x4 cq[6];                                             // scale[8], shift[8], time bias[8] of the chunk being transformed
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    u32x4 sq[4];                                             // VAR 3: (sum, sum of squares) of the group's slabs, two 64-bit fixed-point values each
+    // VAR 3 (round 4): the statistics of ALL groups of the image once per wave -- lane g < K / cpg loads the slabs of group g in the
+    // prologue and computes (mean, rstd) there (mi_gn_coef_from_sums' arithmetic: integer slab sums, double, var = E[x^2] - mean^2);
+    // a chunk's coefficients then need two ds_bpermute per lane instead of four more loads and the double arithmetic per lane and chunk
+    // (the first form cost the sums variant 3-6 us per level-0 launch over the coefficient-tensor one).
+    u32x4 sq[4];                                             // prologue only: (sum, sum of squares) of lane's group, 64-bit fixed point each
+    float gmean = 0.f, grstd = 0.f;                          // lane g: group g of this image
     const int nslab = FUSE ? a.cpg >> 4 : 1;
+    auto load_stats = [&]() {                                // counted like the coefficients (four loads, the oldest of the prologue)
+        const int ng = a.K / a.cpg, gq = min(l, ng - 1);
+        const float* sp = a.sums + ((size_t)img0 * (a.K >> 4) + (size_t)gq * nslab) * 4;           // 16 bytes per slab
+        const float* s1 = sp + (nslab > 1 ? 4 : 0); const float* s2 = sp + (nslab > 2 ? 8 : 0); const float* s3 = sp + (nslab > 2 ? 12 : 0);
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
+                     "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off"
+                     : "=&v"(sq[0]), "=&v"(sq[1]), "=&v"(sq[2]), "=&v"(sq[3]) : "v"(sp), "v"(s1), "v"(s2), "v"(s3) : "memory");
+    };
+    auto stats_landed = [&]() {
+        asm volatile("" : "+v"(sq[0]), "+v"(sq[1]), "+v"(sq[2]), "+v"(sq[3]) :: "memory");
+        long long si = 0, qi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nslab) {
+                si += (long long)(((unsigned long long)sq[k].y << 32) | sq[k].x);
+                qi += (long long)(((unsigned long long)sq[k].w << 32) | sq[k].z);
+            }
+        const double mean = (double)si * a.icnt;
+        double var = (double)qi * a.icnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        grstd = 1.0f / sqrtf((float)var + a.eps); gmean = (float)mean;
+    };
     auto load_coef = [&](int ch) {
         const int c = min(ch, nchunks - 1) * PCK + xcol;
+        const float* p0; const float* p1; const float* p2;
         if constexpr (VAR == 2) {
-            const float* p0 = a.coef + (size_t)img0 * a.K + c;
+            p0 = a.coef + (size_t)img0 * a.K + c;
             const size_t pl = (size_t)a.N * a.K;
-            asm volatile("global_load_dwordx4 %0, %6, off\n\tglobal_load_dwordx4 %1, %6, off offset:16\n\t"
-                         "global_load_dwordx4 %2, %7, off\n\tglobal_load_dwordx4 %3, %7, off offset:16\n\t"
-                         "global_load_dwordx4 %4, %8, off\n\tglobal_load_dwordx4 %5, %8, off offset:16"
-                         : "=&v"(cq[0]), "=&v"(cq[1]), "=&v"(cq[2]), "=&v"(cq[3]), "=&v"(cq[4]), "=&v"(cq[5])
-                         : "v"(p0), "v"(p0 + pl), "v"(p0 + 2 * pl) : "memory");
-        } else {
-            // gamma, beta, the time-bias row (the zero page when there is none) and up to four slabs of the group's sums (a group
-            // with fewer slabs reads its first one again: the number of loads is what the counted waits assume)
-            const float* tb = a.temb ? a.temb + (size_t)img0 * a.ldt + c : reinterpret_cast<const float*>(g_zero_page3);
-            const float* sp = a.sums + ((size_t)img0 * (a.K >> 4) + (c / a.cpg) * nslab) * 4;       // 16 bytes per slab
-            const float* s1 = sp + (nslab > 1 ? 4 : 0); const float* s2 = sp + (nslab > 2 ? 8 : 0); const float* s3 = sp + (nslab > 2 ? 12 : 0);
-            asm volatile("global_load_dwordx4 %0, %10, off\n\tglobal_load_dwordx4 %1, %10, off offset:16\n\t"
-                         "global_load_dwordx4 %2, %11, off\n\tglobal_load_dwordx4 %3, %11, off offset:16\n\t"
-                         "global_load_dwordx4 %4, %12, off\n\tglobal_load_dwordx4 %5, %12, off offset:16\n\t"
-                         "global_load_dwordx4 %6, %13, off\n\tglobal_load_dwordx4 %7, %14, off\n\t"
-                         "global_load_dwordx4 %8, %15, off\n\tglobal_load_dwordx4 %9, %16, off"
-                         : "=&v"(cq[0]), "=&v"(cq[1]), "=&v"(cq[2]), "=&v"(cq[3]), "=&v"(cq[4]), "=&v"(cq[5]),
-                           "=&v"(sq[0]), "=&v"(sq[1]), "=&v"(sq[2]), "=&v"(sq[3])
-                         : "v"(a.gamma + c), "v"(a.beta + c), "v"(tb), "v"(sp), "v"(s1), "v"(s2), "v"(s3) : "memory");
+            p1 = p0 + pl; p2 = p0 + 2 * pl;
+        } else {             // gamma, beta, the time-bias row (the zero page when there is none)
+            p0 = a.gamma + c; p1 = a.beta + c;
+            p2 = a.temb ? a.temb + (size_t)img0 * a.ldt + c : reinterpret_cast<const float*>(g_zero_page3);
         }
+        asm volatile("global_load_dwordx4 %0, %6, off\n\tglobal_load_dwordx4 %1, %6, off offset:16\n\t"
+                     "global_load_dwordx4 %2, %7, off\n\tglobal_load_dwordx4 %3, %7, off offset:16\n\t"
+                     "global_load_dwordx4 %4, %8, off\n\tglobal_load_dwordx4 %5, %8, off offset:16"
+                     : "=&v"(cq[0]), "=&v"(cq[1]), "=&v"(cq[2]), "=&v"(cq[3]), "=&v"(cq[4]), "=&v"(cq[5])
+                     : "v"(p0), "v"(p1), "v"(p2) : "memory");
     };
-    auto coef_landed = [&]() {
+    auto coef_landed = [&](int ch) {
         asm volatile("" : "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+v"(cq[3]), "+v"(cq[4]), "+v"(cq[5]) :: "memory");
         if constexpr (VAR == 3) {
-            // mi_gn_coef_from_sums' arithmetic (norm_act.hip): the group's slabs combined in double, var = E[x^2] - mean^2
-            asm volatile("" : "+v"(sq[0]), "+v"(sq[1]), "+v"(sq[2]), "+v"(sq[3]) :: "memory");
-            // (the slabs are added as integers -- exact, and two int64 -> double conversions instead of eight -- and the count enters as
-            //  a reciprocal: every lane of the workgroup runs this once per chunk, ~4 us of a level-0 launch in its first form)
-            long long si = 0, qi = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < nslab) {
-                    si += (long long)(((unsigned long long)sq[k].y << 32) | sq[k].x);
-                    qi += (long long)(((unsigned long long)sq[k].w << 32) | sq[k].z);
-                }
-            const double mean = (double)si * a.icnt;
-            double var = (double)qi * a.icnt - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float rstd = 1.0f / sqrtf((float)var + a.eps), mf = (float)mean;
+            const int grp = (min(ch, nchunks - 1) * PCK + xcol) / a.cpg;      // the lane's 8 channels lie in one group
+            const float mf = __shfl(gmean, grp, 64), rstd = __shfl(grstd, grp, 64);
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -427,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     bf16x8 XA, XB, XP, XQ;                                   // centre fragments: rows 0 and BH + 1 of a step; odd / even rows 1 .. BH
 
     // ---- prologue: the first chunk's rows, the first step's fragments
+    if constexpr (VAR == 3) load_stats();
     if constexpr (FUSE) load_coef(0);
     if constexpr (IN32) {
         u32x4 pr[PXPW][2];
@@ -435,7 +441,8 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         static_for<0, NPART>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // the rows of chunk 0 (and, older, the coefficients)
         if constexpr (FUSE) {
-            coef_landed();
+            if constexpr (VAR == 3) stats_landed();
+            coef_landed(0);
 #pragma unroll
             for (int i = 0; i < PXPW; ++i) {
                 landed16(pr[i][0]); landed16(pr[i][1]);
@@ -476,8 +483,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         });
     };
     if constexpr (FUSE && !IN32) {
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // coefficients and rows of chunk 0
-        coef_landed();
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // statistics, coefficients and rows of chunk 0
+        if constexpr (VAR == 3) stats_landed();
+        coef_landed(0);
         transform_chunk(0);
     }
     // the rows and the fragments have landed (this wave's; the fused variant's rewritten pieces are in LDS) ...
@@ -565,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                 } else if constexpr (ks == 3) {
                     if constexpr (FUSE && !IN32) {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (requested in step 0)
-                        if (ch + 1 < nchunks) { coef_landed(); transform_chunk((ch + 1) & 1); }
+                        if (ch + 1 < nchunks) { coef_landed(ch + 1); transform_chunk((ch + 1) & 1); }
                     }
                     if constexpr (FUSE && IN32) {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the second half chunk: requested two steps ago)
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                         // first half chunk (requested in step 0; younger: this step's nine fragment requests), then the second half's
                         // requests -- the staging slots are free once raw_half has read them
                         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                        if (ch + 1 < nchunks) { coef_landed(); raw_half((ch + 1) & 1, 0); }
+                        if (ch + 1 < nchunks) { coef_landed(ch + 1); raw_half((ch + 1) & 1, 0); }
                         static_for<0, RHP>([&](auto ic) { stage_raw(ch + 1, RHP + decltype(ic)::value, decltype(ic)::value); });
                     }
                     XA = lds_b128p((xr[0] ^ (kx32 + 32)) + xcur); XB = lds_b128p((xr[BH + 1] ^ (kx32 + 32)) + xcur);
