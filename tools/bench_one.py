@@ -53,7 +53,9 @@ for _ in range(5):
                   torch.zeros(B, H, H, Ci, device=DEV), torch.zeros(Ci, device=DEV), torch.zeros(Ci, device=DEV))
         xs, g1, b1, dxs, dg1, db1 = LN
         yy = K.chan_layernorm_fwd(xs, g1, b1, out_dtype=torch.bfloat16)
-        K.chan_layernorm_bwd(xs, g1, yy, dxs, True, dg1, db1)
+        q4 = K.WgradQueue()                      # as Unet's backward runs it: dg / db as partial rows + the batched row sum
+        K.chan_layernorm_bwd(xs, g1, yy, dxs, True, dg1, db1, defer=q4)
+        q4.flush()
     elif which == "attn":        # LinearAttention core on bf16 qkv [B,H,H,384]
         if "QKV" not in globals():
             QKV = torch.randn(B, H, H, 384, device=DEV).bfloat16()
