@@ -108,9 +108,11 @@ constexpr int pw_lds(int pt, bool raw = false) { return (pt == 128 ? (raw ? 72 :
 // the image stay zero.  One image per tile (TI == 1).
 // ABL (profiling builds only, -DMI_PW_ABL_BUILD): 1 no fragment DMA in the main loop, 2 no activation DMA in the main loop, 4 no stores,
 // 16 no DPP shifts (every tap column multiplies the centre fragments), 32 loads issued but never waited for in the main loop
-// IN32: x / x2 are fp32 tensors (the residual stream: the sampler's block1 convs, fp32 block storage).  Their pieces are loaded into
-// registers (two global_load_dwordx4 per lane and piece, counted like the fragments), rounded to bf16 once and written to the lane's
-// slot of the tile -- the lane loads the channel chunk that belongs in ITS slot, as the DMA's source addresses do for bf16 input.
+// IN32: x / x2 are fp32 tensors (the residual stream: the sampler's block1 convs, fp32 block storage).  Their raw pieces arrive by
+// LDS-DMA in a staging area behind the two bf16 tiles, half a chunk at a time; each lane reads back its own 8 channels, rounds them to
+// bf16 once and writes the 16 bytes of its slot of the tile -- the lane requests the channel chunk that belongs in ITS slot, as the
+// DMA's source addresses do for bf16 input.  (Round 3 staged two pieces per step through registers with counted waits; only the
+// prologue still does.)
 // IN32 + VAR 2 / 3 (round 4; the named fused kernel for fp32-stored activations): the transform is applied to the fp32 values while
 // they sit in those registers, between their load and the one rounding -- no LDS read-modify-write, no unpack.
 // F32: the exact-fp32 mode of the same kernel (Unet.compute_mode = "fp32", the reference's default precision and the mode that carries
@@ -219,7 +221,6 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                          pack_bf16(__uint_as_float(r[1].x), __uint_as_float(r[1].y)), pack_bf16(__uint_as_float(r[1].z), __uint_as_float(r[1].w))};
         *(lds_u32x4_*)(uintptr_t)(lds0 + buf * PXBUF + (wv + 4 * i) * 1024 + l * 16) = o;
     };
-    u32x4 XR32[IN32 ? 2 : 1][2];                             // main loop: the two pieces a step requests
 
     // ---- fused variants: the 3 x 8 coefficients of this lane's channel chunk of chunk ch.  Plain loads would make hipcc drain the DMA
     //      queue (vmcnt(0)) at their first use, so they are issued from one asm statement and counted by hand; their
@@ -348,11 +349,14 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     constexpr int RHP = PXPW / 2;                            // pieces per half chunk and wave (= staging slots): 3 (128-pixel tiles) or 2
     auto stage_raw = [&](int ch, int i, int slot) {
         const int cc0 = min(ch, nchunks - 1) * PCK;
+        const bool second = cc0 >= a.K1;
+        const float* src = reinterpret_cast<const float*>(second ? a.x2 : a.x);
+        const int ld = second ? a.ldx2 : a.ldx, cc = second ? cc0 - a.K1 : cc0;
         int xp = xpix[i];
         asm volatile("" : "+v"(xp));
-        size_t off = (size_t)max(xp, 0) * a.ldx + cc0 + xcol;
+        size_t off = (size_t)max(xp, 0) * ld + cc + xcol;
         asm volatile("" : "+v"(off));
-        const float* pf = xp >= 0 ? reinterpret_cast<const float*>(a.x) + off : reinterpret_cast<const float*>(g_zero_page3) + (l & 7) * 8;
+        const float* pf = xp >= 0 ? src + off : reinterpret_cast<const float*>(g_zero_page3) + (l & 7) * 8;
         glds16(pf, lds0 + RAW0 + (wv * RHP + slot) * 2048);
         glds16(pf + 4, lds0 + RAW0 + (wv * RHP + slot) * 2048 + 1024);
     };
@@ -366,9 +370,14 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < RHP; ++i) {
-            const uint32_t vm = piece_mask(RHP * half + i);
             u32x4 o;
-            xhalf(rv[i][0], std::integral_constant<int, 0>{}, vm, o); xhalf(rv[i][1], std::integral_constant<int, 1>{}, vm, o);
+            if constexpr (FUSE) {
+                const uint32_t vm = piece_mask(RHP * half + i);
+                xhalf(rv[i][0], std::integral_constant<int, 0>{}, vm, o); xhalf(rv[i][1], std::integral_constant<int, 1>{}, vm, o);
+            } else {                                         // the plain conv: one rounding (rows outside the image were read from the zero page)
+                o = u32x4{pack_bf16(__uint_as_float(rv[i][0].x), __uint_as_float(rv[i][0].y)), pack_bf16(__uint_as_float(rv[i][0].z), __uint_as_float(rv[i][0].w)),
+                          pack_bf16(__uint_as_float(rv[i][1].x), __uint_as_float(rv[i][1].y)), pack_bf16(__uint_as_float(rv[i][1].z), __uint_as_float(rv[i][1].w))};
+            }
             *(lds_u32x4r*)(uintptr_t)piece_addr(buf, RHP * half + i) = o;
         }
     };
@@ -509,12 +518,12 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         static_for<0, 4>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value, cur = ks & 1, kx32 = ks * 32;
             // pieces the previous step requested behind its fragments
-            constexpr int prevp = (ks > 0 && 2 * (ks - 1) < PXPW) ? (IN32 ? 4 : 2) : 0;
+            constexpr int prevp = (ks > 0 && 2 * (ks - 1) < PXPW) ? 2 : 0;
             // (fused: step 0 requested the coefficients, its fragment parts and pieces, the last piece(s) (unit 2: two DMAs) behind
             //  everything step 1 needs; fp32 input: the second half chunk's six DMAs are requested at the end of step 1, behind step
             //  2's fragments)
             if constexpr (ks > 0 && !(ABL & 32))
-                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(FUSE ? ((ks == 1 ? 2 : 0) + ((IN32 && ks == 2) ? 2 * (PXPW / 2) : 0)) : (ABL & 2) ? 0 : prevp) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" :: "i"((FUSE || IN32) ? ((ks == 1 ? 2 : 0) + ((IN32 && ks == 2) ? 2 * (PXPW / 2) : 0)) : (ABL & 2) ? 0 : prevp) : "memory");
             static_for<0, 9>([&](auto tc) { landed16(WB[cur][decltype(tc)::value]); });
             auto mm = [&](auto ic, auto tapc, const bf16x8& xf) {
                 constexpr int i = decltype(ic)::value, tp = decltype(tapc)::value;
@@ -533,17 +542,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                 constexpr int u = decltype(uc)::value;
                 if constexpr (IN32 && FUSE && u == 0 && ks == 0) load_coef(ch + 1);      // (the oldest requests of the step)
                 if constexpr (u < NPART && !(ABL & 1)) load_w3(ch, std::integral_constant<int, ks + 1>{}, uc);
-                if constexpr (IN32 && FUSE) {
-                    // the raw fp32 pieces of the next chunk go to the staging area by DMA, three per half chunk: pieces 0-2 in step 0
-                    // (one per unit, behind the unit's fragments), pieces 3-5 at the start of step 2 (raw_half's caller)
+                if constexpr (IN32) {
+                    // the raw fp32 pieces of the next chunk go to the staging area by DMA, half a chunk at a time: the first half's pieces in
+                    // step 0 (one per unit, behind the unit's fragments), the second half's at the end of step 1 (raw_half's caller).
+                    // (Round 4: the plain fp32-input conv too -- it staged two pieces per step through registers with counted waits.)
                     if constexpr (ks == 0 && u < RHP) stage_raw(ch + 1, u, u);
-                } else if constexpr (u == XU && IN32) {
-                    // the two pieces the previous step requested: older than this step's nine fragment requests
-                    if constexpr (prevp != 0) {
-                        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                        store_x32((ch + 1) & 1, 2 * (ks - 1), XR32[0]); store_x32((ch + 1) & 1, 2 * (ks - 1) + 1, XR32[1]);
-                    }
-                    if constexpr (2 * ks < PXPW) { load_x32(ch + 1, 2 * ks, XR32[0]); load_x32(ch + 1, 2 * ks + 1, XR32[1]); }
                 }
                 if constexpr (FUSE && !IN32) {
                     // Round 4: ALL pieces of the next chunk are requested in step 0 (two per unit, behind the unit's fragments; a DMA
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (requested in step 0)
                         if (ch + 1 < nchunks) { coef_landed(ch + 1); transform_chunk((ch + 1) & 1); }
                     }
-                    if constexpr (FUSE && IN32) {
+                    if constexpr (IN32) {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the second half chunk: requested two steps ago)
                         if (ch + 1 < nchunks) raw_half((ch + 1) & 1, 1);
                     }
@@ -585,11 +588,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                     asm volatile("" ::: "memory");
                     XA = lds_b128p(xr[0] + xnxt); XB = lds_b128p(xr[BH + 1] + xnxt);
                 } else {
-                    if constexpr (FUSE && IN32 && ks == 1) {
+                    if constexpr (IN32 && ks == 1) {
                         // first half chunk (requested in step 0; younger: this step's nine fragment requests), then the second half's
                         // requests -- the staging slots are free once raw_half has read them
                         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                        if (ch + 1 < nchunks) { coef_landed(ch + 1); raw_half((ch + 1) & 1, 0); }
+                        if (ch + 1 < nchunks) { if constexpr (FUSE) coef_landed(ch + 1); raw_half((ch + 1) & 1, 0); }
                         static_for<0, RHP>([&](auto ic) { stage_raw(ch + 1, RHP + decltype(ic)::value, decltype(ic)::value); });
                     }
                     XA = lds_b128p((xr[0] ^ (kx32 + 32)) + xcur); XB = lds_b128p((xr[BH + 1] ^ (kx32 + 32)) + xcur);
@@ -1205,7 +1208,7 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     a.qmap = 0; a.gx = (int)grid.x; a.gy = (int)grid.y;
     if (!a.xmap && a.gy > 1 && a.gy % 2 == 0 && a.gx % 4 == 0) { a.qmap = 2; grid = dim3(grid.x * grid.y, 1, 1); }
     hipStream_t st = (hipStream_t)stream;
-    size_t lds = pw_lds(pt, in32 && var >= 2);
+    size_t lds = pw_lds(pt, in32);
 #define MI_PW_GO_T(O16, V, A, T) do { \
         static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, A, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
         (void)once_; \
