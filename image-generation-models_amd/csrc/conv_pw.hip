@@ -975,7 +975,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
 // 200-380 TFLOP/s) for these layers.
 struct GtClass { unsigned long long dyq, dxq, wtq; int ntap, ao, bo, pad_; };     // 4-bit fields per tap: dy + 8, dx + 8, weight tap
 struct GtArgs {
-    const uint16_t* x; const uint16_t* w; const float* bias; const float* res; void* y;
+    const uint16_t* x; const uint16_t* w; const float* bias; const float* res; void* y; uint16_t* y16; int ldy16;
     int M, K, Nc, ldx, ldy, ldr, accumulate, gx, gy;
     int IH, IW, lgGW, lgGHW, si, so, OH, OW;
     GtClass cls[4];
@@ -1151,6 +1151,9 @@ __global__ __launch_bounds__(256, 2) void conv_gt_kernel(const GtArgs a) {
             if (a.accumulate) { v0 += *reinterpret_cast<const f32x4*>(yp); v1 += *reinterpret_cast<const f32x4*>(yp + 4); }
             *reinterpret_cast<f32x4*>(yp) = v0;
             *reinterpret_cast<f32x4*>(yp + 4) = v1;
+            if (a.y16)         // the bf16 copy the next Block's conv and its weight gradient read, from the same epilogue (wave-uniform)
+                *reinterpret_cast<u32x4*>(a.y16 + m * a.ldy16 + col) =
+                    u32x4{pack_bf16(v0.x, v0.y), pack_bf16(v0.z, v0.w), pack_bf16(v1.x, v1.y), pack_bf16(v1.z, v1.w)};
         }
     }
 }
@@ -1595,8 +1598,22 @@ extern "C" int mi_conv_gt_supported(const MiConvDesc* d) {
 // x: bf16 [N][IH][IW][K] (pixel stride ldx elements); w_frag: the layer's slice of mi_pack_weights_bf16's wfq (contraction over the master
 // layout's ci: the forward convs) or wdq (over co: the data gradients); y fp32 or bf16 (out_bf16), bias / residual fp32.
 // d->mode = 0 (exact-fp32 mode): x and y fp32 (ldx % 4 == 0), w_frag = the slice of mi_pack_weights_f32frag's wfq32 / wdq32.
+static int gt_launch(const MiConvDesc* d, const void* x, const void* w_frag, const float* bias, const float* residual,
+                     void* y, int out_bf16, void* y_bf16, int ldy16, void* stream);
 extern "C" int mi_conv_gt(const MiConvDesc* d, const void* x, const void* w_frag, const float* bias, const float* residual,
                           void* y, int out_bf16, void* stream) {
+    return gt_launch(d, x, w_frag, bias, residual, y, out_bf16, nullptr, 0, stream);
+}
+// ... with a bf16 copy of the fp32 output written by the same epilogue (pixel stride ldy16 elements, % 8 == 0; no accumulate): the
+// operand of the next Block's conv and of its weight gradient, without a conversion launch
+extern "C" int mi_conv_gt_dual(const MiConvDesc* d, const void* x, const void* w_frag, const float* bias, const float* residual,
+                               float* y, void* y_bf16, int ldy16, void* stream) {
+    MI_REQUIRE(y_bf16 && ldy16 % 8 == 0 && (((uintptr_t)y_bf16) & 15) == 0 && d && !d->accumulate && d->mode == 1,
+               "bf16 copy: bf16 mode, 16-byte aligned, ldy16 % 8 == 0, no accumulate");
+    return gt_launch(d, x, w_frag, bias, residual, y, 0, y_bf16, ldy16, stream);
+}
+static int gt_launch(const MiConvDesc* d, const void* x, const void* w_frag, const float* bias, const float* residual,
+                     void* y, int out_bf16, void* y_bf16, int ldy16, void* stream) {
     MI_REQUIRE(d && x && w_frag && y, "null argument");
     GtArgs a{};
     int ncls, pxt;
@@ -1605,7 +1622,7 @@ extern "C" int mi_conv_gt(const MiConvDesc* d, const void* x, const void* w_frag
     MI_REQUIRE((((uintptr_t)x | (uintptr_t)w_frag) & 15) == 0, "operands must be 16-byte aligned");
     MI_REQUIRE(d->ldy % 8 == 0 && (!residual || d->ldr % 4 == 0), "pixel strides: y % 8, residual % 4");
     MI_REQUIRE(d->mode == 1 || !out_bf16, "the exact-fp32 kernel writes fp32");
-    a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_frag; a.bias = bias; a.res = residual; a.y = y;
+    a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_frag; a.bias = bias; a.res = residual; a.y = y; a.y16 = (uint16_t*)y_bf16; a.ldy16 = ldy16;
     a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.accumulate = d->accumulate;
     dim3 grid((unsigned)a.gx, (unsigned)a.gy, (unsigned)ncls);
     if (a.gy > 1 && a.gx % 8 == 0) grid = dim3((unsigned)(a.gx * a.gy), 1, (unsigned)ncls);

@@ -548,8 +548,11 @@ class Unet(nn.Module):
             if mode == K.MODE_BF16 and stride == 2 and x2 is None and inp.dtype == BF and out_dtype == torch.float32:
                 # Downsample / Upsample on the tap-gather kernel (round 4): bf16 copy of the input, fragment-order weights
                 y = K.conv_gt(inp, wfq_sh[offs[pre + "weight"]:], kh=kh, kw=kw, stride=stride, pad=pad, transposed=transposed_conv, K=ci, Nc=co,
-                              out_hw=(oh, ow), bias=sv[pre + "bias"] if bias else None, residual=residual)
+                              out_hw=(oh, ow), bias=sv[pre + "bias"] if bias else None, residual=residual, want16=use_sh)
                 if y is not None:
+                    if use_sh:                      # training: the next Block's conv and its weight gradient read the copy
+                        sh[id(y[0])] = y
+                        return y[0]
                     return y
             if mode == K.MODE_FP32 and stride == 2 and x2 is None and inp.dtype == torch.float32 and out_dtype == torch.float32:
                 y = K.conv_gt(inp, wfq32_sh[offs[pre + "weight"]:], kh=kh, kw=kw, stride=stride, pad=pad, transposed=transposed_conv, K=ci, Nc=co,

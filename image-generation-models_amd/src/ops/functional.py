@@ -176,7 +176,7 @@ USE_CONV_GT = debug_knob("MI_CONV_GT", "1") != "0"      # A/B switch: the tap-ga
 
 
 def conv_gt(x, wq, *, kh, kw, stride, pad, transposed, K, Nc, out_hw, bias=None, residual=None, out=None, accumulate=False,
-            out_dtype=torch.float32, mode=MODE_BF16):
+            out_dtype=torch.float32, mode=MODE_BF16, want16=False):
     """The stride-2 / transposed convs and their data gradients through the tap-gather kernel (mi_conv_gt): x bf16, wq = the layer's
     fragment-order weights (wfq: contraction over the master layout's ci, wdq: over co).  Returns None when the kernel does not take
     the layer (the caller falls back to conv_igemm).  mode = MODE_FP32: the exact-fp32 instantiation (x fp32, wq = wfq32 / wdq32)."""
@@ -195,7 +195,14 @@ def conv_gt(x, wq, *, kh, kw, stride, pad, transposed, K, Nc, out_hw, bias=None,
         out = new_act(N, OH, OW, Nc, x, out_dtype)
         d.ldy = ld_of(out)
     e0 = _probe_open()
-    check(load_library().mi_conv_gt(C.byref(d), _p(x), _p(wq), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv_gt")
+    y16 = None
+    if want16:          # -> (y, y16): the bf16 copy of the fp32 output from the same epilogue
+        assert out.dtype == torch.float32 and not accumulate and mode == MODE_BF16
+        y16 = new_act(N, OH, OW, Nc, x, torch.bfloat16)
+        check(load_library().mi_conv_gt_dual(C.byref(d), _p(x), _p(wq), _p(bias), _p(residual), _p(out), _p(y16), ld_of(y16), _stream()),
+              "mi_conv_gt_dual")
+    else:
+        check(load_library().mi_conv_gt(C.byref(d), _p(x), _p(wq), _p(bias), _p(residual), _p(out), _b16(out), _stream()), "mi_conv_gt")
     if e0 is not None:
         pxt, ncls = C.c_int(), C.c_int()
         load_library().mi_conv_gt_tile(C.byref(d), C.byref(pxt), C.byref(ncls))
@@ -203,7 +210,7 @@ def conv_gt(x, wq, *, kh, kw, stride, pad, transposed, K, Nc, out_hw, bias=None,
         nb = N * IH * IW * K * _esz(x) + N * OH * OW * Nc * _esz(out) * (2 if accumulate else 1) + kh * kw * K * Nc * _esz(x)
         _probe_close(e0, f"conv_gt_kernel<{'true' if _b16(out) else 'false'}, {pxt.value}{', true' if mode == MODE_FP32 else ''}>", flops,
                      f"N{N} {IH}x{IW}->{OH}x{OW} K{K}->{Nc} k{kh} s{stride} T{int(transposed)} acc{int(accumulate)}", nb)
-    return out
+    return (out, y16) if want16 else out
 
 
 def conv_igemm(x, w, *, kh, kw, stride, pad, transposed, w_kn, K, Nc, out_hw, mode, x2=None,

@@ -48,6 +48,7 @@ SIGNATURES = {
     "mi_conv_gt_supported": [C.POINTER(MiConvDesc)],
     "mi_conv_gt_tile": [C.POINTER(MiConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "mi_conv_gt": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _P],
+    "mi_conv_gt_dual": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
     "mi_conv_igemm_tile": [C.POINTER(MiConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "mi_conv3x3_bf16w": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "mi_conv3x3_bf16w_supported": [C.POINTER(MiConvDesc)],

@@ -92,6 +92,9 @@ int mi_conv_gt_supported(const MiConvDesc* d);
 int mi_conv_gt_tile(const MiConvDesc* d, int* pixels_per_workgroup, int* classes);
 int mi_conv_gt(const MiConvDesc* d, const void* x, const void* w_frag, const float* bias, const float* residual,
                void* y, int out_bf16, void* stream);
+/* ... and a bf16 copy of the fp32 output from the same epilogue (y_bf16, pixel stride ldy16 elements; bf16 mode, no accumulate) */
+int mi_conv_gt_dual(const MiConvDesc* d, const void* x, const void* w_frag, const float* bias, const float* residual,
+                    float* y, void* y_bf16, int ldy16, void* stream);
 
 /* ---- 3x3 / stride 1 / pad 1 convolution with an LDS-staged halo tile (bf16 MFMA only) -------
  * Same contract as mi_conv_igemm for the Block conv (ddpm.py:116) and its data gradient

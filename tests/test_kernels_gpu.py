@@ -171,6 +171,8 @@ def test_stride2_family_tap_gather_kernel(K, cfg):
         yg = K.conv_gt(nh(x), wfq, kh=3, kw=3, stride=2, pad=1, transposed=False, K=Ci, Nc=Co, out_hw=(h, h), bias=b.to(DEV))
         y16 = K.conv_gt(nh(x), wfq, kh=3, kw=3, stride=2, pad=1, transposed=False, K=Ci, Nc=Co, out_hw=(h, h), bias=b.to(DEV),
                         out_dtype=torch.bfloat16)
+        yd, yd16 = K.conv_gt(nh(x), wfq, kh=3, kw=3, stride=2, pad=1, transposed=False, K=Ci, Nc=Co, out_hw=(h, h), bias=b.to(DEV), want16=True)
+        assert torch.equal(yd, yg) and torch.equal(yd16, yg.bfloat16())          # the bf16 copy from the same epilogue
         dxg = K.conv_gt(nh(dy), wdq, kh=3, kw=3, stride=2, pad=1, transposed=True, K=Co, Nc=Ci, out_hw=(2 * h, 2 * h))
         dx2 = K.conv_gt(nh(dy), wdq, kh=3, kw=3, stride=2, pad=1, transposed=True, K=Co, Nc=Ci, out_hw=(2 * h, 2 * h), out=dxg.clone(),
                         accumulate=True)
