@@ -448,9 +448,12 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
 #pragma unroll
         for (int i = 0; i < PXPW; ++i) load_x32(0, i, pr[i]);
         static_for<0, NPART>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
+        if constexpr (VAR == 3) {                            // the statistics are the oldest requests: their arithmetic runs under the rows' flight
+            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + 2 * PXPW + 9) : "memory");
+            stats_landed();
+        }
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // the rows of chunk 0 (and, older, the coefficients)
         if constexpr (FUSE) {
-            if constexpr (VAR == 3) stats_landed();
             coef_landed(0);
 #pragma unroll
             for (int i = 0; i < PXPW; ++i) {
@@ -492,8 +495,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         });
     };
     if constexpr (FUSE && !IN32) {
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // statistics, coefficients and rows of chunk 0
-        if constexpr (VAR == 3) stats_landed();
+        if constexpr (VAR == 3) {                            // the statistics are the oldest requests: their arithmetic runs under the rows' flight
+            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + PXPW + 9) : "memory");
+            stats_landed();
+        }
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // coefficients and rows of chunk 0
         coef_landed(0);
         transform_chunk(0);
     }
