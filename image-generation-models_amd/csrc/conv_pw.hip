@@ -98,14 +98,13 @@ template <int DIR> __device__ __forceinline__ bf16x8 pw_shift(const bf16x8& c, u
     return __builtin_bit_cast(bf16x8, o);
 }
 
-constexpr int pw_ncoef(int var) { return var == 2 ? 6 : var == 3 ? 10 : 0; }
-constexpr int pw_lds(int pt, bool raw = false) { return (pt == 128 ? (raw ? 72 : 64) : (raw ? 48 : 32)) * 1024 + 2048; }   // raw: + the fp32 staging area of the fused fp32-input variant (24 KB behind the 48 KB of tiles)   // two activation buffers (24 / 16 KB); the epilogue's fp32 tile (+ the GroupNorm sums' 512 bytes)
+constexpr int pw_lds(int pt, bool raw = false) { return (pt == 128 ? (raw ? 72 : 64) : (raw ? 48 : 32)) * 1024 + 2048; }   // two activation buffers (24 / 16 KB each) under the epilogue's fp32 tile (+ the GroupNorm sums' 512 bytes); raw: + the fp32 staging area of the fp32-input variants (24 / 16 KB behind the tiles)
 
 // VAR 0: the plain conv.  VAR 1: the epilogue also accumulates the GroupNorm sums of the NEXT layer (a.gsum).  VAR 2 / 3: the named
 // fused kernel (2: coefficients given, 3: resolved here from the producer's sums) -- x is the RAW output of the previous conv and mish(x * scale[n][c] + shift[n][c]) + tb[n][c] (a.coef; GroupNorm-apply
 // + Mish + time bias, reference src/models/ddpm.py:112-120,139-141) is applied ONCE per staged element: every wave transforms the
-// pieces it requested itself, in place in LDS, after its own counted wait and before the chunk barrier publishes them; rows outside
-// the image stay zero.  One image per tile (TI == 1).
+// pieces it requested itself as one block per chunk (bf16 input: in place in LDS; fp32 input: from the raw staging area, half a chunk
+// at a time) before the chunk barrier publishes them; rows outside the image stay zero.  One image per tile (TI == 1).
 // ABL (profiling builds only, -DMI_PW_ABL_BUILD): 1 no fragment DMA in the main loop, 2 no activation DMA in the main loop, 4 no stores,
 // 16 no DPP shifts (every tap column multiplies the centre fragments), 32 loads issued but never waited for in the main loop
 // IN32: x / x2 are fp32 tensors (the residual stream: the sampler's block1 convs, fp32 block storage).  Their raw pieces arrive by
@@ -331,7 +330,6 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         return m;
     };
     typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
-    u32x4 tv[2];                                             // main loop: the (at most two) pieces in transformation, rewritten in place
     // fp32 input: half h (elements 4h .. 4h + 3 of the lane's 8 channels) of a piece in registers -> two packed registers of `dst`
     auto xhalf = [&](const u32x4& r, auto hc, uint32_t vmask, u32x4& dst) {
         constexpr int h = decltype(hc)::value;
@@ -515,9 +513,10 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     // starts once everything the previous one requested before those pieces has landed.  Chunk boundary (before the last unit of
     // step 3, whose MFMAs then cover the first reads from the other buffer): every wave has read all it needs of this chunk's rows
     // and has its pieces of the next chunk's.
-    // Fused variants, bf16 input: coefficients and all six pieces of the next chunk are requested in step 0 and transformed as one block
-    // at the chunk boundary (transform_chunk); fp32 input: the pieces pass through registers, two per step, and are transformed there
-    // (one half of a piece per unit) -- in the last chunk that is the clamped re-fetch of its own rows, wasted VALU work.
+    // Fused variants, bf16 input: coefficients and all pieces of the next chunk are requested in step 0 and transformed as one block at
+    // the chunk boundary (transform_chunk).  fp32 input (fused or not): the raw pieces of the next chunk arrive in the staging area half a
+    // chunk at a time and are converted / transformed by raw_half at the end of step 1 and at the chunk boundary.  The last chunk has no
+    // successor: its (clamped) requests are still issued -- the counted waits assume them -- but nothing is transformed.
     constexpr int XU = BH < 3 ? BH : 3;                      // the unit that requests activation pieces
     for (int ch = 0; ch < nchunks; ++ch) {
         const uint32_t xcur = (ch & 1) * PXBUF, xnxt = PXBUF - xcur;
