@@ -438,6 +438,16 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     bf16x8 XA, XB, XP, XQ;                                   // centre fragments: rows 0 and BH + 1 of a step; odd / even rows 1 .. BH
 
+    // bf16 output: the bias of this lane's four channel quads, requested before anything else and used only by the epilogue (there a
+    // load would put an HBM round trip in front of the tile's way out)
+    f32x4 bias_q[(OUT16 && !FUSE) ? 4 : 1];
+    if constexpr (OUT16 && !FUSE) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            bias_q[rq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias && live) bias_q[rq] = *reinterpret_cast<const f32x4*>(a.bias + n0 + 4 * (8 * wv + 2 * rq + (l >> 5)));
+        }
+    }
     // ---- prologue: the first chunk's rows, the first step's fragments
     if constexpr (VAR == 3) load_stats();
     if constexpr (FUSE) load_coef(0);
@@ -637,8 +647,77 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     //      channels] fp32, 16-byte chunk c of pixel p at position c ^ (p & 31) (conflict-free both ways), and leaves as whole rows --
     //      16 lanes x 8 channels = one pixel's 256 (bf16) / 512 (fp32) contiguous bytes; bias, residual and the accumulate operand are
     //      applied on the way out, read in the same row-contiguous pattern.
+    auto pw_gns_out = [&](float (&gs)[2][2]) {
+        // a 16-channel slab = two neighbouring lanes (j = 2q, 2q + 1) x the 16 row groups t >> 4 (4 per wave): lanes, then waves
+        // through the LDS behind the tile, then ONE atomic pair per slab, image and workgroup (rows 0-63 / 64-127 are the two images
+        // of a TI == 2 tile; with TI == 1 both halves belong to image img0)
+        float r[4] = {gs[0][0], gs[0][1], gs[1][0], gs[1][1]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r[k] += __shfl_xor(r[k], 1, 64); r[k] += __shfl_xor(r[k], 16, 64); r[k] += __shfl_xor(r[k], 32, 64);
+        }
+        float* red = reinterpret_cast<float*>(lds_raw + PT * 512);        // behind the tile: [4 waves][8 slabs][4]
+        if ((l & 0x31) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[(wv * 8 + (l >> 1)) * 4 + k] = r[k];
+        }
+        __syncthreads();
+        if (t < 32) {
+            const int q = t >> 2, k = t & 3;                 // slab, (image half, sum / sum of squares)
+            const float v = red[(0 * 8 + q) * 4 + k] + red[(1 * 8 + q) * 4 + k] + red[(2 * 8 + q) * 4 + k] + red[(3 * 8 + q) * 4 + k];
+            const int slab = (n0 >> 4) + q;
+            if (slab * 16 < a.Nc) {
+                const int img = a.TI > 1 ? img0 + (k >> 1) : img0;
+                gsum_add(a.gsum, ((size_t)img * (a.Nc >> 4) + slab) * 2 + (k & 1), v);
+            }
+        }
+        };
     __builtin_amdgcn_s_barrier();                            // every wave is done with the activation buffers, every DMA has landed
     asm volatile("" ::: "memory");
+    // Round 4: a bf16 output with nothing to add on the way out (no residual, no accumulate -- every forward Block conv and the data
+    // gradients into block-internal tensors) takes its bias in registers and crosses LDS as bf16: half the tile (32 KB), one
+    // ds_read_b128 per thread and pixel, no arithmetic between the read and the store.  8-byte slot c (4 channels) of pixel p at
+    // c ^ ((p & 15) << 1): an even XOR keeps a thread's two slots an aligned pair; rows p and p + 16 share banks (2-way on the writes only).
+    const bool tile16 = OUT16 && !FUSE && !a.res && !a.accumulate;
+    if (tile16) {
+        if constexpr (OUT16) {
+            typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+            typedef __attribute__((address_space(3))) u32x4 lds_u32x4e;
+            if (live) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int ck = 8 * wv + 2 * rq + (l >> 5);
+                    const f32x4 bq = bias_q[rq];
+#pragma unroll
+                    for (int i = 0; i < BH; ++i) {
+                        const int p = ep_p0 + i * a.W;
+                        *(lds_u32x2*)(uintptr_t)(lds0 + p * 256 + ((ck ^ ((p & 15) << 1)) << 3)) =
+                            u32x2{pack_bf16(acc[i][4 * rq] + bq.x, acc[i][4 * rq + 1] + bq.y), pack_bf16(acc[i][4 * rq + 2] + bq.z, acc[i][4 * rq + 3] + bq.w)};
+                    }
+                }
+            }
+            __syncthreads();
+            const int j = t & 15, col = n0 + 8 * j;
+            float gs[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+            if (col < a.Nc) {
+#pragma unroll
+                for (int it = 0; it < PT / 16; ++it) {
+                    const int p = it * 16 + (t >> 4);
+                    const u32x4 o = *(lds_u32x4e*)(uintptr_t)(lds0 + p * 256 + (((2 * j) ^ ((p & 15) << 1)) << 3));
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(a.y) + ((size_t)m0 + p) * a.ldy + col) = o;
+                    if constexpr (GNS) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float e0 = __uint_as_float(o[q] << 16), e1 = __uint_as_float(o[q] & 0xffff0000u);
+                            gs[it >> 2][0] += e0 + e1; gs[it >> 2][1] += e0 * e0 + e1 * e1;
+                        }
+                    }
+                }
+            }
+            if constexpr (GNS) pw_gns_out(gs);
+        }
+        return;
+    }
     if (live) {
         typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 #pragma unroll
@@ -699,31 +778,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             }
         }
     }
-    if constexpr (GNS) {
-        // a 16-channel slab = two neighbouring lanes (j = 2q, 2q + 1) x the 16 row groups t >> 4 (4 per wave): lanes, then waves
-        // through the LDS behind the tile, then ONE atomic pair per slab, image and workgroup (rows 0-63 / 64-127 are the two images
-        // of a TI == 2 tile; with TI == 1 both halves belong to image img0)
-        float r[4] = {gs[0][0], gs[0][1], gs[1][0], gs[1][1]};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            r[k] += __shfl_xor(r[k], 1, 64); r[k] += __shfl_xor(r[k], 16, 64); r[k] += __shfl_xor(r[k], 32, 64);
-        }
-        float* red = reinterpret_cast<float*>(lds_raw + PT * 512);        // behind the tile: [4 waves][8 slabs][4]
-        if ((l & 0x31) == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) red[(wv * 8 + (l >> 1)) * 4 + k] = r[k];
-        }
-        __syncthreads();
-        if (t < 32) {
-            const int q = t >> 2, k = t & 3;                 // slab, (image half, sum / sum of squares)
-            const float v = red[(0 * 8 + q) * 4 + k] + red[(1 * 8 + q) * 4 + k] + red[(2 * 8 + q) * 4 + k] + red[(3 * 8 + q) * 4 + k];
-            const int slab = (n0 >> 4) + q;
-            if (slab * 16 < a.Nc) {
-                const int img = a.TI > 1 ? img0 + (k >> 1) : img0;
-                gsum_add(a.gsum, ((size_t)img * (a.Nc >> 4) + slab) * 2 + (k & 1), v);
-            }
-        }
-    }
+    if constexpr (GNS) pw_gns_out(gs);
 }
 
 bool pw_geom(const MiConvDesc* d, int pt, int* TH, int* TI) {
