@@ -923,6 +923,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+    f32x4 bias_q[OUT16 ? 4 : 1];                     // bf16 output: the bias of this lane's channel quads, requested first (see the epilogue)
+    if constexpr (OUT16) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            bias_q[rq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias && live) bias_q[rq] = *reinterpret_cast<const f32x4*>(a.bias + n0 + 4 * (8 * wv + 2 * rq + (l >> 5)));
+        }
+    }
     if constexpr (IN32) load_x32(0); else stage_x(0);
     load_w(0, std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -971,8 +979,38 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
         if (ch + 1 < nchunks) chunk(ch + 1, std::integral_constant<int, 1>{});
     }
 
-    // ---- epilogue: as conv_pw_kernel's (fp32 tile through LDS, whole rows out)
+    // ---- epilogue: as conv_pw_kernel's (fp32 tile through LDS, whole rows out; a bf16 output with nothing to add on the way out
+    //      crosses LDS as bf16, the bias taken in registers -- to_qkv and the other bf16-output 1x1 convs are all prologue and epilogue)
     __syncthreads();
+    if constexpr (OUT16) {
+        if (!a.res && !a.accumulate) {
+            typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+            typedef __attribute__((address_space(3))) u32x4 lds_u32x4e;
+            if (live) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int ck = 8 * wv + 2 * rq + (l >> 5);
+                    const f32x4 bq = bias_q[rq];
+#pragma unroll
+                    for (int i = 0; i < NBLK; ++i) {
+                        const int p = i * 32 + (l & 31);
+                        *(lds_u32x2*)(uintptr_t)(lds0 + p * 256 + ((ck ^ ((p & 15) << 1)) << 3)) =
+                            u32x2{pack_bf16(acc[i][4 * rq] + bq.x, acc[i][4 * rq + 1] + bq.y), pack_bf16(acc[i][4 * rq + 2] + bq.z, acc[i][4 * rq + 3] + bq.w)};
+                    }
+                }
+            }
+            __syncthreads();
+            const int j = t & 15, col = n0 + 8 * j;
+            if (col >= a.Nc) return;
+#pragma unroll
+            for (int it = 0; it < PXT / 16; ++it) {
+                const int p = it * 16 + (t >> 4);
+                const u32x4 o = *(lds_u32x4e*)(uintptr_t)(lds0 + p * 256 + (((2 * j) ^ ((p & 15) << 1)) << 3));
+                *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(a.y) + ((size_t)m0 + p) * a.ldy + col) = o;
+            }
+            return;
+        }
+    }
     typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
     if (live) {
 #pragma unroll
