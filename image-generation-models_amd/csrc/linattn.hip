@@ -5,8 +5,11 @@
 //   out[p,e] = sum_d ctx[d,e] q[p,d]        (n x 32, K = 32)
 // qkv is the NHWC output of the to_qkv 1x1 conv: [b][p][q(h,d) | k(h,d) | v(h,e)].
 // One 256-thread workgroup per (b, head); the four waves split the pixel axis.  These are the
-// only matmuls in the path whose contraction is not a convolution, and they stay fp32 in both
-// numeric modes (0.4 % of the FLOPs).
+// only matmuls in the path whose contraction is not a convolution (0.4 % of the FLOPs).  fp32-stored
+// tensors: everything on the exact-fp32 MFMA.  bf16-stored tensors (bf16 mode; round 4): the softmax,
+// its statistics and the contractions over pixels (ctx, dctx) stay exact fp32, the contractions over
+// channels (out, dq, dv, dP) run on the bf16 MFMA with ctx / dctx rounded once per workgroup -- see
+// tile_mm_b16.
 #include "common.h"
 
 namespace {
@@ -200,6 +203,54 @@ __device__ __forceinline__ f32x16 tile_mm(const float* A, int ldA, int p0, int n
     return acc;
 }
 
+// bf16-stored tensors (round 4): the products whose contraction runs over CHANNELS -- out = q ctx, dq = dout ctx^T, dv = P dctx,
+// dP = v dctx^T -- on v_mfma_f32_32x32x16_bf16.  The row operand of a 32-pixel tile is read straight from memory in MFMA-fragment
+// order (lane (pixel i, k-half) = 16 contiguous bytes of the pixel's 64-byte head row: no LDS staging, no conversion), the 32 x 32
+// matrix operand (ctx / dctx, fp32 in LDS) is rounded to bf16 once per workgroup into two fragment registers per lane.  2 MFMAs
+// instead of 16 exact-fp32 ones per product and tile; the contractions over PIXELS (ctx, dctx: reduce_outer) stay exact fp32.
+// B(k, j) = Bs[k * sk + j * sj]: fragment s holds k = 16 s + 8 (lane >> 5) .. + 7 of column j = lane & 31
+__device__ __forceinline__ void frag_from_lds(const float* Bs, int sk, int sj, bf16x8 (&f)[2]) {
+    const int l = threadIdx.x & 63, jx = l & 31, kh = l >> 5;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            w[e] = pack_bf16(Bs[(16 * s2 + 8 * kh + 2 * e) * sk + jx * sj], Bs[(16 * s2 + 8 * kh + 2 * e + 1) * sk + jx * sj]);
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        f[s2] = __builtin_bit_cast(bf16x8, u32x4_{w[0], w[1], w[2], w[3]});
+    }
+}
+// T[p][j] = sum_k A[p][k] B(k, j) for the 32-pixel tile at p0, A = bf16 rows in memory (rows past n - 1 repeat the last one: their
+// output rows are never stored)
+__device__ __forceinline__ f32x16 tile_mm_b16(const float* A, int ldA, int p0, int n, const bf16x8 (&f)[2]) {
+    const int l = threadIdx.x & 63;
+    const uint16_t* row = reinterpret_cast<const uint16_t*>(A) + (size_t)min(p0 + (l & 31), n - 1) * ldA + 8 * (l >> 5);
+    const uint4 a0 = *reinterpret_cast<const uint4*>(row), a1 = *reinterpret_cast<const uint4*>(row + 16);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), f[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), f[1], acc, 0, 0, 0);
+    return acc;
+}
+// ... with the row operand taken from a wave-private fp32 LDS tile [pixel][33] (P in the backward)
+__device__ __forceinline__ f32x16 tile_mm_b16_lds(const float* At, const bf16x8 (&f)[2]) {
+    const int l = threadIdx.x & 63, i = l & 31, kh = l >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack_bf16(At[i * 33 + 16 * s2 + 8 * kh + 2 * e], At[i * 33 + 16 * s2 + 8 * kh + 2 * e + 1]);
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, u32x4_{w[0], w[1], w[2], w[3]}), f[s2], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 // PH = 0: the whole image of one (batch, head) in one workgroup (S == 1).  With S > 1 the pixel axis is cut into slices and the
 // three dependent steps become three launches over (batch, head, slice):  1: column max of k over the slice -> part_max;
 // 2: max over the slices, then exp / outer product over the slice -> part_ctx, part_sum;  3: slices summed in a fixed order
@@ -293,8 +344,12 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
     __syncthreads();
     // out[p][e] = sum_d q[p][d] ctx[d][e]
     float* o = offs<T16>(a.out, (size_t)b * a.n * hid + h * DH);
+    bf16x8 fctx[2];
+    if constexpr (T16) frag_from_lds(ctx_s, 33, 1, fctx);                // B(k = d, j = e) = ctx[d][e]
     for (int p0 = pb + 32 * w; p0 < pe; p0 += 128) {
-        f32x16 acc = tile_mm<T16>(q, a.ldq, p0, pe, ctx_s, 33, 1, scratch + w * (32 * 33));
+        f32x16 acc;
+        if constexpr (T16) acc = tile_mm_b16(q, a.ldq, p0, pe, fctx);
+        else acc = tile_mm<T16>(q, a.ldq, p0, pe, ctx_s, 33, 1, scratch + w * (32 * 33));
         store_tile<T16>(o, hid, p0, pe, acc, scratch + w * (32 * 33));
     }
 }
@@ -357,10 +412,18 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
 
     float* pt = scratch + w * (32 * 33);        // this wave's P tile [pixel][d]
     float* stg = stage_s + w * (32 * 33);       // this wave's operand staging tile
+    bf16x8 fctxT[2], fdctx[2], fdctxT[2];
+    if constexpr (T16) {
+        frag_from_lds(ctx_s, 1, 33, fctxT);                              // B(k = e, j = d) = ctx[d][e]
+        frag_from_lds(dctx_s, 33, 1, fdctx);                             // B(k = d, j = e) = dctx[d][e]
+        frag_from_lds(dctx_s, 1, 33, fdctxT);                            // B(k = e, j = d) = dctx[d][e]
+    }
     for (int p0 = pb + 32 * w; p0 < pe; p0 += 128) {
         const int col = l & 31;
         // dq[p][d] = sum_e dout[p][e] ctx[d][e]      (B(k=e, j=d) = ctx_s[d*33+e])
-        f32x16 acc = tile_mm<T16>(dout, hid, p0, pe, ctx_s, 1, 33, stg);
+        f32x16 acc;
+        if constexpr (T16) acc = tile_mm_b16(dout, hid, p0, pe, fctxT);
+        else acc = tile_mm<T16>(dout, hid, p0, pe, ctx_s, 1, 33, stg);
         store_tile<T16>(dq, a.ldq, p0, pe, acc, stg);
         // P tile into LDS (rows = pixels) so it can serve as the A operand of dv
         {
@@ -381,17 +444,21 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const AttnArgs a) {
         {
             const int i = l & 31, kk = l >> 5;
             f32x16 a2;
+            if constexpr (T16) a2 = tile_mm_b16_lds(pt, fdctx);
+            else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+                for (int r = 0; r < 16; ++r) a2[r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                int kd = 2 * s + kk;
-                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pt[i * 33 + kd], dctx_s[kd * 33 + i], a2, 0, 0, 0);
+                for (int s = 0; s < 16; ++s) {
+                    int kd = 2 * s + kk;
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pt[i * 33 + kd], dctx_s[kd * 33 + i], a2, 0, 0, 0);
+                }
             }
             store_tile<T16>(dv, a.ldq, p0, pe, a2, stg);
         }
         // dP[p][d] = sum_e v[p][e] dctx[d][e]        (B(k=e, j=d) = dctx_s[d*33+e]) ; dk = P*(dP - r)
-        acc = tile_mm<T16>(v, a.ldq, p0, pe, dctx_s, 1, 33, stg);
+        if constexpr (T16) acc = tile_mm_b16(v, a.ldq, p0, pe, fdctxT);
+        else acc = tile_mm<T16>(v, a.ldq, p0, pe, dctx_s, 1, 33, stg);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = pt[tile_row(r, l) * 33 + col] * (acc[r] - r_s[col]);
         store_tile<T16>(dk, a.ldq, p0, pe, acc, stg);
