@@ -124,16 +124,36 @@ __device__ __forceinline__ void reduce_outer(const float* A, const float* Bm, in
             } else {
                 x *= live;
             }
-            float* pa = tA + (r0 + 8 * j) * 33 + c4;
-            float* pb2 = tB + (r0 + 8 * j) * 33 + c4;
-            pa[0] = x.x; pa[1] = x.y; pa[2] = x.z; pa[3] = x.w;
-            pb2[0] = bv[j].x; pb2[1] = bv[j].y; pb2[2] = bv[j].z; pb2[3] = bv[j].w;
+            if constexpr (T16) {
+                // bf16-stored tensors (round 4): both operands parked TRANSPOSED as bf16 -- [channel][pixel], pitch 40 -- so that the
+                // fragment of the bf16 MFMA (8 consecutive pixels of one channel) is one ds_read_b128: 2 MFMAs per tile instead of
+                // 16 exact-fp32 ones.  f(A) is rounded to bf16 here (its sums, the softmax denominators, are taken from the fp32 values)
+                uint16_t* pa = reinterpret_cast<uint16_t*>(tA) + c4 * 40 + r0 + 8 * j;
+                uint16_t* pb2 = reinterpret_cast<uint16_t*>(tB) + c4 * 40 + r0 + 8 * j;
+                const uint32_t x01 = pack_bf16(x.x, x.y), x23 = pack_bf16(x.z, x.w), b01 = pack_bf16(bv[j].x, bv[j].y), b23 = pack_bf16(bv[j].z, bv[j].w);
+                pa[0] = (uint16_t)x01; pa[40] = (uint16_t)(x01 >> 16); pa[80] = (uint16_t)x23; pa[120] = (uint16_t)(x23 >> 16);
+                pb2[0] = (uint16_t)b01; pb2[40] = (uint16_t)(b01 >> 16); pb2[80] = (uint16_t)b23; pb2[120] = (uint16_t)(b23 >> 16);
+            } else {
+                float* pa = tA + (r0 + 8 * j) * 33 + c4;
+                float* pb2 = tB + (r0 + 8 * j) * 33 + c4;
+                pa[0] = x.x; pa[1] = x.y; pa[2] = x.z; pa[3] = x.w;
+                pb2[0] = bv[j].x; pb2[1] = bv[j].y; pb2[2] = bv[j].z; pb2[3] = bv[j].w;
+            }
         }
         // (wave-private LDS tiles: the wave's own ds_write -> ds_read ordering is enough)
+        if constexpr (T16) {
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            const int k = 2 * s2 + kk;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tA[k * 33 + i], tB[k * 33 + i], acc, 0, 0, 0);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const uint16_t*>(tA) + i * 40 + 16 * s2 + 8 * kk);
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const uint16_t*>(tB) + i * 40 + 16 * s2 + 8 * kk);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int k = 2 * s2 + kk;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tA[k * 33 + i], tB[k * 33 + i], acc, 0, 0, 0);
+            }
         }
     }
     float ssum = 0.f;
@@ -207,7 +227,7 @@ __device__ __forceinline__ f32x16 tile_mm(const float* A, int ldA, int p0, int n
 // dP = v dctx^T -- on v_mfma_f32_32x32x16_bf16.  The row operand of a 32-pixel tile is read straight from memory in MFMA-fragment
 // order (lane (pixel i, k-half) = 16 contiguous bytes of the pixel's 64-byte head row: no LDS staging, no conversion), the 32 x 32
 // matrix operand (ctx / dctx, fp32 in LDS) is rounded to bf16 once per workgroup into two fragment registers per lane.  2 MFMAs
-// instead of 16 exact-fp32 ones per product and tile; the contractions over PIXELS (ctx, dctx: reduce_outer) stay exact fp32.
+// instead of 16 exact-fp32 ones per product and tile; the contractions over PIXELS (ctx, dctx: reduce_outer) take the bf16 MFMA too, from operands parked transposed.
 // B(k, j) = Bs[k * sk + j * sj]: fragment s holds k = 16 s + 8 (lane >> 5) .. + 7 of column j = lane & 31
 __device__ __forceinline__ void frag_from_lds(const float* Bs, int sk, int sj, bf16x8 (&f)[2]) {
     const int l = threadIdx.x & 63, jx = l & 31, kh = l >> 5;

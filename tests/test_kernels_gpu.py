@@ -1657,7 +1657,8 @@ def test_bf16_attention_storage_kernels(K):
     qkv16 = qkv.to(BF)
     o32, ctx32, ks32 = K.linattn_fwd(qkv16.float())
     o16, ctx16, ks16 = K.linattn_fwd(qkv16)
-    assert o16.dtype == BF and rel_err(ctx16, ctx32) < 1e-6 and rel_err(o16.float(), o32) < 4e-3
+    # bf16 tensors: every product on the bf16 MFMA (exp(k - max) rounded where it is parked) -- ctx carries one bf16 rounding per term
+    assert o16.dtype == BF and rel_err(ctx16, ctx32) < 2.5e-3 and rel_err(ks16, ks32) < 1e-6 and rel_err(o16.float(), o32) < 4e-3
     do = to_nhwc_gpu(torch.randn(N, HID, H, H, generator=g)).to(BF)
     d32 = K.linattn_bwd(qkv16.float(), ctx32, ks32, do.float())
     d16 = K.linattn_bwd(qkv16, ctx16, ks16, do)
