@@ -479,7 +479,9 @@ extern "C" int mi_q_sample(int B, int C, int HW, const float* x0, const float* n
 extern "C" int mi_eps_loss(int B, int C, int HW, const float* pred, int ld, const float* target, int loss_type,
                            float* loss, float* dpred, float gscale, void* stream) {
     MI_REQUIRE(B > 0 && C > 0 && HW > 0 && ld >= C && pred && target && loss && (loss_type == 0 || loss_type == 1), "bad argument");
-    hipLaunchKernelGGL(eps_loss_kernel, dim3(nblocks((size_t)B * HW * ld, TPB, 1024)), dim3(TPB), 0, ST, B, C, HW, pred, ld,
+    // (one device-scope atomic per workgroup on ONE address: they serialise at ~16 ns each -- 1024 workgroups spent 16 of the
+    //  kernel's 17 us queueing there; 128 workgroups stream the same bytes in ~3)
+    hipLaunchKernelGGL(eps_loss_kernel, dim3(nblocks((size_t)B * HW * ld, 4 * TPB, 128)), dim3(TPB), 0, ST, B, C, HW, pred, ld,
                        target, loss_type, loss, dpred, gscale);
     MI_LAUNCH_CHECK();
     return 0;
