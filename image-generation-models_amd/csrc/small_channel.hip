@@ -13,6 +13,19 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// the wide tensor of these kernels may be stored as bf16 (round 4: the first Block's conv output / its gradient and the final Block's
+// output / its gradient, like every other block-internal tensor): a thread's channel quad is one 8-byte load / store
+template <bool B16> __device__ __forceinline__ f32x4 ldq(const void* base, size_t off) {
+    if constexpr (B16) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + off);
+        return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    } else return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off);
+}
+template <bool B16> __device__ __forceinline__ void stq(void* base, size_t off, const f32x4& v) {
+    if constexpr (B16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + off) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + off) = v;
+}
+
 constexpr int WG_BLOCKS = 768;          // weight-gradient workgroups (3 per CU): the number of partial tiles
 
 // m -> (image, row, column); POW2: W and H*W are powers of two (shifts), else divisions
@@ -78,10 +91,10 @@ __global__ __launch_bounds__(256) void small_cin_fwd_kernel(int N, int H, int W,
 // waits for them (200 registers of weights and taps, two waves per SIMD: a latency chain of ~1 M load instructions per launch at
 // B = 128).  Here a workgroup owns 64-pixel tiles (whole image rows), the tile's (rows + 2) x (W + 2) halo of padded pixels is
 // fetched by one load per thread -- the NEXT tile's while this one is computed -- and the taps are ds_read_b128.
-template <int CIN>
+template <int CIN, bool Y16 = false>
 __global__ __launch_bounds__(256) void small_cin3x3_fwd_tiled_kernel(int N, int H, int W, int Cout, const float* __restrict__ x, int ldx,
                                                                      const float* __restrict__ w, const float* __restrict__ bias,
-                                                                     float* __restrict__ y, int ldy, int w_sh, int ntiles) {
+                                                                     void* __restrict__ y, int ldy, int w_sh, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float halo_s[];          // 2 x [(rows + 2) * (W + 2)] float4
     const int nq = Cout / 4;
     const int q = threadIdx.x % nq, psub = threadIdx.x / nq, pp = 256 / nq;
@@ -116,7 +129,7 @@ __global__ __launch_bounds__(256) void small_cin3x3_fwd_tiled_kernel(int N, int 
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) acc += xv[ci] * wr[tp * CIN + ci];
             }
-            *reinterpret_cast<f32x4*>(y + (m0 + px) * ldy + 4 * q) = acc;
+            stq<Y16>(y, (m0 + px) * ldy + 4 * q, acc);
         }
         buf ^= 1;
         if (hp < HP) *reinterpret_cast<f32x4*>(halo_s + ((size_t)buf * HP + hp) * 4) = nxt;
@@ -195,9 +208,9 @@ __global__ __launch_bounds__(256) void small_cin_wgrad_kernel(int N, int H, int 
 
 // The 3x3 weight gradient with the input taps in LDS (same tiling as small_cin3x3_fwd_tiled_kernel): a workgroup walks 64-pixel
 // row tiles, a thread = (co quad, pixel lane) requests its tile's dy rows (64 / pp of them) up front, the taps are ds_read_b128.
-template <int CIN>
+template <int CIN, bool DY16 = false>
 __global__ __launch_bounds__(256) void small_cin3x3_wgrad_tiled_kernel(int N, int H, int W, int Cout, const float* __restrict__ x, int ldx,
-                                                                       const float* __restrict__ dy, int lddy, float* __restrict__ dW,
+                                                                       const void* __restrict__ dy, int lddy, float* __restrict__ dW,
                                                                        float* __restrict__ ws, int w_sh, int ntiles) {
     constexpr int NA = 9 * CIN;
     extern __shared__ __attribute__((aligned(16))) float smem[];             // [reduce area 3 * NA * nq * 4][2 halo buffers]
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(256) void small_cin3x3_wgrad_tiled_kernel(int N, in
 #pragma unroll
             for (int k = 0; k < MAXPX; ++k) {
                 const int px = base + k * pp;
-                g[k] = *reinterpret_cast<const f32x4*>(dy + (m0 + (px < 64 ? px : 63)) * lddy + 4 * q);
+                g[k] = ldq<DY16>(dy, (m0 + (px < 64 ? px : 63)) * lddy + 4 * q);
             }
 #pragma unroll
             for (int k = 0; k < MAXPX; ++k) {
@@ -299,8 +312,8 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restric
 
 // ---- 1x1 conv to/from a few channels (Cs <= 4 "small" side, C wide side), weights w[c][j] (c < C, j < Cs)
 // forward: y[px][j] = b[j] + sum_c x[px][c] w[c][j]; 8 lanes per pixel, each 4*CK channels, weights in registers
-template <int CK>
-__global__ __launch_bounds__(256) void small_cout_fwd_kernel(int M, int Cs, const float* __restrict__ x, int ldx,
+template <int CK, bool X16 = false>
+__global__ __launch_bounds__(256) void small_cout_fwd_kernel(int M, int Cs, const void* __restrict__ x, int ldx,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              float* __restrict__ y, int ldy) {
     const int sub = threadIdx.x & 7, pl = threadIdx.x >> 3;          // 32 pixels per workgroup and iteration
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(256) void small_cout_fwd_kernel(int M, int Cs, cons
     {
         const int m = min((int)blockIdx.x * 32 + pl, M - 1);
 #pragma unroll
-        for (int k = 0; k < CK; ++k) xn[k] = *reinterpret_cast<const f32x4*>(x + (size_t)m * ldx + 4 * (sub + 8 * k));
+        for (int k = 0; k < CK; ++k) xn[k] = ldq<X16>(x, (size_t)m * ldx + 4 * (sub + 8 * k));
     }
     for (int m0 = blockIdx.x * 32; m0 < M; m0 += gridDim.x * 32) {
         const int m = min(m0 + pl, M - 1);
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(256) void small_cout_fwd_kernel(int M, int Cs, cons
         {
             const int mn = min(m0 + (int)gridDim.x * 32 + pl, M - 1);
 #pragma unroll
-            for (int k = 0; k < CK; ++k) xn[k] = *reinterpret_cast<const f32x4*>(x + (size_t)mn * ldx + 4 * (sub + 8 * k));
+            for (int k = 0; k < CK; ++k) xn[k] = ldq<X16>(x, (size_t)mn * ldx + 4 * (sub + 8 * k));
         }
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -350,8 +363,9 @@ __global__ __launch_bounds__(256) void small_cout_fwd_kernel(int M, int Cs, cons
     }
 }
 // dgrad: dx[px][c] (+)= sum_j dy[px][j] w[c][j]; thread = (channel quad, pixel lane)
+template <bool DX16 = false>
 __global__ __launch_bounds__(256) void small_cout_dgrad_kernel(int M, int C, int Cs, const float* __restrict__ dy, int lddy,
-                                                               const float* __restrict__ w, float* __restrict__ dx, int lddx, int acc) {
+                                                               const float* __restrict__ w, void* __restrict__ dx, int lddx, int acc) {
     const int nq = C / 4;
     const int q = threadIdx.x % nq, psub = threadIdx.x / nq, pp = 256 / nq;
     f32x4 wr[4];                                                     // wr[e][j] = w[4q+e][j]
@@ -366,13 +380,14 @@ __global__ __launch_bounds__(256) void small_cout_dgrad_kernel(int M, int C, int
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const f32x4 pr = g * wr[e]; o[e] = (pr.x + pr.y) + (pr.z + pr.w); }
-        float* p = dx + (size_t)m * lddx + 4 * q;
-        if (acc) o += *reinterpret_cast<const f32x4*>(p);
-        *reinterpret_cast<f32x4*>(p) = o;
+        const size_t po = (size_t)m * lddx + 4 * q;
+        if (acc) o += ldq<DX16>(dx, po);
+        stq<DX16>(dx, po, o);
     }
 }
 // wgrad: dW[c][j] += sum_px x[px][c] dy[px][j]; thread = (channel quad, pixel lane), partial tile [C][4]
-__global__ __launch_bounds__(256) void small_cout_wgrad_kernel(int M, int C, int Cs, const float* __restrict__ x, int ldx,
+template <bool X16 = false>
+__global__ __launch_bounds__(256) void small_cout_wgrad_kernel(int M, int C, int Cs, const void* __restrict__ x, int ldx,
                                                                const float* __restrict__ dy, int lddy, float* __restrict__ dW,
                                                                float* __restrict__ ws) {
     extern __shared__ float red[];
@@ -384,9 +399,9 @@ __global__ __launch_bounds__(256) void small_cout_wgrad_kernel(int M, int C, int
     const int per = (M + gridDim.x - 1) / gridDim.x;
     const int mb = blockIdx.x * per, me = min(M, mb + per);
     int m = mb + psub;
-    f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)min(m, M - 1) * ldx + 4 * q);
+    f32x4 xv = ldq<X16>(x, (size_t)min(m, M - 1) * ldx + 4 * q);
     for (; m < me; m += pp) {
-        const f32x4 xnext = *reinterpret_cast<const f32x4*>(x + (size_t)min(m + pp, M - 1) * ldx + 4 * q);
+        const f32x4 xnext = ldq<X16>(x, (size_t)min(m + pp, M - 1) * ldx + 4 * q);
         const float* gp = dy + (size_t)m * lddy;
         const f32x4 g = {gp[0], Cs > 1 ? gp[1] : 0.f, Cs > 2 ? gp[2] : 0.f, Cs > 3 ? gp[3] : 0.f};
 #pragma unroll
@@ -413,11 +428,29 @@ int log2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == 
 
 extern "C" size_t mi_conv_small_wgrad_workspace(int outputs) { return (size_t)WG_BLOCKS * (size_t)outputs * sizeof(float); }
 
-extern "C" int mi_conv_small_cin_fwd(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w,
-                                     const float* bias, float* y, int ldy, void* stream) {
-    MI_REQUIRE(x && w && y && (ks == 1 || ks == 3) && Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0 &&
-               ldy % 4 == 0 && (((uintptr_t)y | (uintptr_t)w) & 15) == 0,
+namespace {
+// the whole-row-tile kernels' geometry (small_cin3x3_fwd_tiled_kernel / small_cin3x3_wgrad_tiled_kernel)
+bool cin_tiled_geom(int ks, int H, int W, int ldx, const void* x) {
+    const int w_sh = log2_exact(W), hw_sh = log2_exact(H * W);
+    const int rows = w_sh >= 0 && W <= 64 ? 64 / W : 0;
+    return ks == 3 && w_sh >= 0 && hw_sh >= 0 && ldx == 4 && ((uintptr_t)x & 15) == 0 && rows >= 1 && H % rows == 0 && (rows + 2) * (W + 2) <= 256;
+}
+}  // namespace
+
+// bf16 wide tensors (round 4): 1 when BOTH the forward conv can write its output as bf16 and the weight gradient can read a bf16 dy
+// for this layer (the whole-row-tile kernels take it)
+extern "C" int mi_conv_small_cin_bf16_supported(int ks, int N, int H, int W, int Cin, int Cout, int ldx) {
+    static const int tiled = (int)mi_knob("MI_SMALL_CIN_TILED", 1);
+    return (tiled && N > 0 && Cin >= 1 && Cin <= 4 && (Cout == 128 || Cout == 256) && ((long)N * H * W) % 64 == 0 && cin_tiled_geom(ks, H, W, ldx, nullptr) &&
+            (size_t)3 * 9 * Cin * (Cout / 4) * 16 <= 48 * 1024) ? 1 : 0;
+}
+
+extern "C" int mi_conv_small_cin_fwd_io(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w,
+                                        const float* bias, void* yv, int ldy, int y_bf16, void* stream) {
+    MI_REQUIRE(x && w && yv && (ks == 1 || ks == 3) && Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0 &&
+               ldy % 4 == 0 && (((uintptr_t)yv & (y_bf16 ? 7 : 15)) | ((uintptr_t)w & 15)) == 0,
                "needs ks 1|3, Cin <= 4, Cout a multiple of 4 with Cout/4 dividing 256, 16-byte aligned y / w");
+    float* y = (float*)yv;
     const int pp = 256 / (Cout / 4);
     long blocks = ((long)N * H * W + 2 * pp - 1) / (2 * pp); if (blocks > 4096) blocks = 4096;
     const int w_sh = log2_exact(W), hw_sh = log2_exact(H * W);
@@ -427,20 +460,20 @@ extern "C" int mi_conv_small_cin_fwd(int ks, int N, int H, int W, int Cin, int C
     {   // 3x3 on whole-row tiles of 64 pixels with the taps in LDS (see small_cin3x3_fwd_tiled_kernel)
         static const int tiled = (int)mi_knob("MI_SMALL_CIN_TILED", 1);
         const int rows = w_sh >= 0 && W <= 64 ? 64 / W : 0;
-        if (tiled && ks == 3 && pow2 && vec && ldx == 4 && rows >= 1 && H % rows == 0 && (rows + 2) * (W + 2) <= 256 && Cout <= 256) {
+        if (tiled && cin_tiled_geom(ks, H, W, ldx, x) && Cout <= 256 && ((long)N * H * W) % 64 == 0) {
             const int ntiles = N * H * W / 64;
             const int grid = ntiles < 1024 ? ntiles : 1024;
             const size_t lds = (size_t)2 * (rows + 2) * (W + 2) * 16;
-            switch (Cin) {
-                case 1: hipLaunchKernelGGL(small_cin3x3_fwd_tiled_kernel<1>, dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, w_sh, ntiles); break;
-                case 2: hipLaunchKernelGGL(small_cin3x3_fwd_tiled_kernel<2>, dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, w_sh, ntiles); break;
-                case 3: hipLaunchKernelGGL(small_cin3x3_fwd_tiled_kernel<3>, dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, w_sh, ntiles); break;
-                default: hipLaunchKernelGGL(small_cin3x3_fwd_tiled_kernel<4>, dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, w_sh, ntiles); break;
-            }
+#define MI_TILED(CIN) do { \
+                if (y_bf16) hipLaunchKernelGGL((small_cin3x3_fwd_tiled_kernel<CIN, true>), dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w, bias, yv, ldy, w_sh, ntiles); \
+                else hipLaunchKernelGGL((small_cin3x3_fwd_tiled_kernel<CIN, false>), dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w, bias, yv, ldy, w_sh, ntiles); } while (0)
+            switch (Cin) { case 1: MI_TILED(1); break; case 2: MI_TILED(2); break; case 3: MI_TILED(3); break; default: MI_TILED(4); break; }
+#undef MI_TILED
             MI_LAUNCH_CHECK();
             return 0;
         }
     }
+    MI_REQUIRE(!y_bf16, "bf16 output: only on the whole-row-tile kernel (mi_conv_small_cin_bf16_supported)");
 #define MI_GO(CIN, KS) do { \
         if (pow2 && vec) hipLaunchKernelGGL((small_cin_fwd_kernel<CIN, KS, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, w_sh, hw_sh); \
         else if (vec) hipLaunchKernelGGL((small_cin_fwd_kernel<CIN, KS, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, N, H, W, Cout, x, ldx, w, bias, y, ldy, 0, 0); \
@@ -451,13 +484,18 @@ extern "C" int mi_conv_small_cin_fwd(int ks, int N, int H, int W, int Cin, int C
     MI_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int mi_conv_small_cin_fwd(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w,
+                                     const float* bias, float* y, int ldy, void* stream) {
+    return mi_conv_small_cin_fwd_io(ks, N, H, W, Cin, Cout, x, ldx, w, bias, y, ldy, 0, stream);
+}
 
-extern "C" int mi_conv_small_cin_wgrad(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* dy,
-                                       int lddy, float* dW, void* workspace, size_t ws_bytes, void* stream) {
+extern "C" int mi_conv_small_cin_wgrad_io(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const void* dyv,
+                                          int lddy, int dy_bf16, float* dW, void* workspace, size_t ws_bytes, void* stream) {
     const int na = ks * ks * Cin;
-    MI_REQUIRE(x && dy && dW && (ks == 1 || ks == 3) && Cin >= 1 && Cin <= 4 && (Cout == 64 || Cout == 128 || Cout == 256) && lddy % 4 == 0 &&
-               ((uintptr_t)dy & 15) == 0 && (size_t)3 * na * (Cout / 4) * 16 <= 48 * 1024,
+    MI_REQUIRE(x && dyv && dW && (ks == 1 || ks == 3) && Cin >= 1 && Cin <= 4 && (Cout == 64 || Cout == 128 || Cout == 256) && lddy % 4 == 0 &&
+               ((uintptr_t)dyv & (dy_bf16 ? 7 : 15)) == 0 && (size_t)3 * na * (Cout / 4) * 16 <= 48 * 1024,
                "needs ks 1|3, Cin <= 4, Cout in {64, 128, 256} (3x3: {64, 128}), 16-byte aligned dy rows");
+    const float* dy = (const float*)dyv;
     float* ws = (workspace && ws_bytes >= mi_conv_small_wgrad_workspace(na * Cout)) ? (float*)workspace : nullptr;
     const int w_sh = log2_exact(W), hw_sh = log2_exact(H * W);
     const bool pow2 = w_sh >= 0 && hw_sh >= 0;
@@ -467,20 +505,20 @@ extern "C" int mi_conv_small_cin_wgrad(int ks, int N, int H, int W, int Cin, int
     {   // 3x3 on whole-row tiles of 64 pixels with the taps in LDS (small_cin3x3_wgrad_tiled_kernel); same partial-tile contract
         static const int tiled = (int)mi_knob("MI_SMALL_CIN_TILED", 1);
         const int rows = w_sh >= 0 && W <= 64 ? 64 / W : 0;
-        if (tiled && ks == 3 && pow2 && vec && ldx == 4 && rows >= 1 && H % rows == 0 && (rows + 2) * (W + 2) <= 256 && Cout >= 128) {
+        if (tiled && cin_tiled_geom(ks, H, W, ldx, x) && Cout >= 128 && ((long)N * H * W) % 64 == 0) {
             const int ntiles = N * H * W / 64;
             const size_t lds2 = lds + (size_t)2 * (rows + 2) * (W + 2) * 16;
-            switch (Cin) {
-                case 1: hipLaunchKernelGGL(small_cin3x3_wgrad_tiled_kernel<1>, dim3(WG_BLOCKS), dim3(256), lds2, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, w_sh, ntiles); break;
-                case 2: hipLaunchKernelGGL(small_cin3x3_wgrad_tiled_kernel<2>, dim3(WG_BLOCKS), dim3(256), lds2, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, w_sh, ntiles); break;
-                case 3: hipLaunchKernelGGL(small_cin3x3_wgrad_tiled_kernel<3>, dim3(WG_BLOCKS), dim3(256), lds2, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, w_sh, ntiles); break;
-                default: hipLaunchKernelGGL(small_cin3x3_wgrad_tiled_kernel<4>, dim3(WG_BLOCKS), dim3(256), lds2, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, w_sh, ntiles); break;
-            }
+#define MI_TILED(CIN) do { \
+                if (dy_bf16) hipLaunchKernelGGL((small_cin3x3_wgrad_tiled_kernel<CIN, true>), dim3(WG_BLOCKS), dim3(256), lds2, st, N, H, W, Cout, x, ldx, dyv, lddy, dW, ws, w_sh, ntiles); \
+                else hipLaunchKernelGGL((small_cin3x3_wgrad_tiled_kernel<CIN, false>), dim3(WG_BLOCKS), dim3(256), lds2, st, N, H, W, Cout, x, ldx, dyv, lddy, dW, ws, w_sh, ntiles); } while (0)
+            switch (Cin) { case 1: MI_TILED(1); break; case 2: MI_TILED(2); break; case 3: MI_TILED(3); break; default: MI_TILED(4); break; }
+#undef MI_TILED
             if (ws) hipLaunchKernelGGL(partial_sum_kernel, dim3((na * Cout + 31) / 32), dim3(256), 0, st, ws, WG_BLOCKS, na * Cout, dW, 0);
             MI_LAUNCH_CHECK();
             return 0;
         }
     }
+    MI_REQUIRE(!dy_bf16, "bf16 dy: only on the whole-row-tile kernel (mi_conv_small_cin_bf16_supported)");
 #define MI_GO(CIN, KS) do { \
         if (pow2 && vec) hipLaunchKernelGGL((small_cin_wgrad_kernel<CIN, KS, true, true>), dim3(WG_BLOCKS), dim3(256), lds, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, w_sh, hw_sh); \
         else if (vec) hipLaunchKernelGGL((small_cin_wgrad_kernel<CIN, KS, false, true>), dim3(WG_BLOCKS), dim3(256), lds, st, N, H, W, Cout, x, ldx, dy, lddy, dW, ws, 0, 0); \
@@ -491,6 +529,10 @@ extern "C" int mi_conv_small_cin_wgrad(int ks, int N, int H, int W, int Cin, int
     if (ws) hipLaunchKernelGGL(partial_sum_kernel, dim3((na * Cout + 31) / 32), dim3(256), 0, st, ws, WG_BLOCKS, na * Cout, dW, 0);
     MI_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int mi_conv_small_cin_wgrad(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* dy,
+                                       int lddy, float* dW, void* workspace, size_t ws_bytes, void* stream) {
+    return mi_conv_small_cin_wgrad_io(ks, N, H, W, Cin, Cout, x, ldx, dy, lddy, 0, dW, workspace, ws_bytes, stream);
 }
 
 // the 3x3 forms of the two entry points above (kept for callers of ABI version 1)
@@ -503,36 +545,48 @@ extern "C" int mi_conv3x3_small_cin_wgrad(int N, int H, int W, int Cin, int Cout
     return mi_conv_small_cin_wgrad(3, N, H, W, Cin, Cout, x, ldx, dy, lddy, dW, nullptr, 0, stream);
 }
 
-extern "C" int mi_conv1x1_small_cout_ws(int op, int M, int C, int Cs, const float* a, int lda, const float* b, int ldb,
-                                        const float* w, const float* bias, float* out, int ldo, int accumulate,
+extern "C" int mi_conv1x1_small_cout_io(int op, int M, int C, int Cs, const void* a, int lda, const float* b, int ldb,
+                                        const float* w, const float* bias, void* out, int ldo, int accumulate, int wide_bf16,
                                         void* workspace, size_t ws_bytes, void* stream) {
     // op 0: forward  (a = x[M][C], out = y[M][Cs], bias)        op 1: dgrad (a = dy[M][Cs], out = dx[M][C])
     // op 2: wgrad    (a = x[M][C], b = dy[M][Cs], out = dW[C][Cs])
+    // wide_bf16: the C-channel tensor (x of op 0 / 2, dx of op 1) is stored as bf16; the Cs-channel side and the weights stay fp32
     MI_REQUIRE(a && out && (op == 2 || w) && Cs >= 1 && Cs <= 4 && (C == 32 || C == 64 || C == 128 || C == 256) && M > 0,
                "needs Cs <= 4 and C in {32, 64, 128, 256}");
     hipStream_t st = (hipStream_t)stream;
+    const uintptr_t wal = wide_bf16 ? 7 : 15;
     if (op == 0) {
-        MI_REQUIRE(C <= 128 && lda % 4 == 0 && ((uintptr_t)a & 15) == 0, "forward: C <= 128, 16-byte aligned x rows");
+        MI_REQUIRE(C <= 128 && lda % 4 == 0 && ((uintptr_t)a & wal) == 0, "forward: C <= 128, 16-byte (bf16: 8-byte) aligned x rows");
         int blocks = (M + 31) / 32; if (blocks > 1024) blocks = 1024;
-        if (C == 128) hipLaunchKernelGGL(small_cout_fwd_kernel<4>, dim3(blocks), dim3(256), 0, st, M, Cs, a, lda, w, bias, out, ldo);
-        else if (C == 64) hipLaunchKernelGGL(small_cout_fwd_kernel<2>, dim3(blocks), dim3(256), 0, st, M, Cs, a, lda, w, bias, out, ldo);
-        else hipLaunchKernelGGL(small_cout_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, M, Cs, a, lda, w, bias, out, ldo);
+#define MI_FWD(CK) do { \
+            if (wide_bf16) hipLaunchKernelGGL((small_cout_fwd_kernel<CK, true>), dim3(blocks), dim3(256), 0, st, M, Cs, a, lda, w, bias, (float*)out, ldo); \
+            else hipLaunchKernelGGL((small_cout_fwd_kernel<CK, false>), dim3(blocks), dim3(256), 0, st, M, Cs, a, lda, w, bias, (float*)out, ldo); } while (0)
+        if (C == 128) MI_FWD(4); else if (C == 64) MI_FWD(2); else MI_FWD(1);
+#undef MI_FWD
     } else if (op == 1) {
-        MI_REQUIRE(ldo % 4 == 0 && ((uintptr_t)out & 15) == 0, "dgrad: 16-byte aligned dx rows");
+        MI_REQUIRE(ldo % 4 == 0 && ((uintptr_t)out & wal) == 0, "dgrad: 16-byte (bf16: 8-byte) aligned dx rows");
         const int pp = 256 / (C / 4);
         long blocks = ((long)M + pp - 1) / pp; if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(small_cout_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, M, C, Cs, a, lda, w, out, ldo, accumulate);
+        if (wide_bf16) hipLaunchKernelGGL(small_cout_dgrad_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, M, C, Cs, (const float*)a, lda, w, out, ldo, accumulate);
+        else hipLaunchKernelGGL(small_cout_dgrad_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, M, C, Cs, (const float*)a, lda, w, out, ldo, accumulate);
     } else if (op == 2) {
-        MI_REQUIRE(b && C >= 64 && lda % 4 == 0 && ((uintptr_t)a & 15) == 0, "wgrad: needs dy, C in {64, 128, 256}, aligned x rows");
+        MI_REQUIRE(b && C >= 64 && lda % 4 == 0 && ((uintptr_t)a & wal) == 0, "wgrad: needs dy, C in {64, 128, 256}, aligned x rows");
         float* ws = (workspace && ws_bytes >= mi_conv_small_wgrad_workspace(C * 4)) ? (float*)workspace : nullptr;
-        hipLaunchKernelGGL(small_cout_wgrad_kernel, dim3(WG_BLOCKS), dim3(256), (size_t)3 * 4 * (C / 4) * 4 * sizeof(float), st,
-                           M, C, Cs, a, lda, b, ldb, out, ws);
-        if (ws) hipLaunchKernelGGL(partial_sum_kernel, dim3((C * 4 + 31) / 32), dim3(256), 0, st, ws, WG_BLOCKS, C * 4, out, Cs);
+        const size_t lds = (size_t)3 * 4 * (C / 4) * 4 * sizeof(float);
+        if (wide_bf16) hipLaunchKernelGGL(small_cout_wgrad_kernel<true>, dim3(WG_BLOCKS), dim3(256), lds, st, M, C, Cs, a, lda, b, ldb, (float*)out, ws);
+        else hipLaunchKernelGGL(small_cout_wgrad_kernel<false>, dim3(WG_BLOCKS), dim3(256), lds, st, M, C, Cs, a, lda, b, ldb, (float*)out, ws);
+        if (ws) hipLaunchKernelGGL(partial_sum_kernel, dim3((C * 4 + 31) / 32), dim3(256), 0, st, ws, WG_BLOCKS, C * 4, (float*)out, Cs);
     } else {
         return mi_set_error(-1, "mi_conv1x1_small_cout: op must be 0, 1 or 2");
     }
     MI_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mi_conv1x1_small_cout_ws(int op, int M, int C, int Cs, const float* a, int lda, const float* b, int ldb,
+                                        const float* w, const float* bias, float* out, int ldo, int accumulate,
+                                        void* workspace, size_t ws_bytes, void* stream) {
+    return mi_conv1x1_small_cout_io(op, M, C, Cs, a, lda, b, ldb, w, bias, out, ldo, accumulate, 0, workspace, ws_bytes, stream);
 }
 
 extern "C" int mi_conv1x1_small_cout(int op, int M, int C, int Cs, const float* a, int lda, const float* b, int ldb,

@@ -259,6 +259,9 @@ class Unet(nn.Module):
         self.s2_wgrad_tr = K.debug_knob("MI_DDPM_S2_TR", "1") != "0"
         # final_conv.0's conv output stored like the other Blocks' (bf16 in bf16 mode); 0 = fp32 as in round 1
         self.final_block16 = K.debug_knob("MI_DDPM_FINAL16", "1") != "0"
+        # round 4: the two tensors at the 3-channel ends stored like every other block-internal tensor of bf16 mode -- the first Block's conv
+        # output (and its gradient) and final_conv.0's output (and its gradient); 0 = fp32 as before
+        self.ends16 = K.debug_knob("MI_DDPM_ENDS16", "1") != "0"
         # LinearAttention's to_out conv writes the bf16 copy of its (residual-stream) output along; 0 = separate conversion launches
         self.dual_out = K.debug_knob("MI_DDPM_DUAL_OUT", "1") != "0"
         self.accumulate_grads = False
@@ -514,7 +517,8 @@ class Unet(nn.Module):
             kh, kw, ci, co = w.shape
             if x2 is None and residual is None and stride == 1 and not transposed_conv:
                 if K.small_cin_supported(k, ci, co):                                    # image -> features
-                    return K.conv_small_cin_fwd(inp, w, sv[pre + "bias"] if bias else None, co, k)
+                    od = BF if (out_dtype == BF and K.small_cin_bf16_supported(k, B, inp.shape[1], inp.shape[2], ci, co, K.ld_of(inp))) else torch.float32
+                    return K.conv_small_cin_fwd(inp, w, sv[pre + "bias"] if bias else None, co, k, out_dtype=od)
                 if k == 1 and K.small_cout_supported(0, ci, co):                        # features -> image
                     return K.conv1x1_small_cout(0, inp, w, bias=sv[pre + "bias"] if bias else None, Cs=co)
             if mode == K.MODE_BF16 and k in (1, 3) and stride == 1 and not transposed_conv:
@@ -579,6 +583,9 @@ class Unet(nn.Module):
             k1 = inp.shape[3] if x2 is not None else None
             c1_16 = (lo16 and ci % 32 == 0 and all(K.fast3x3_supported(B, inp.shape[1], inp.shape[2], ci, co, k1))
                      and not (auto and K.conv3x3_uses_splitk(B, inp.shape[1], inp.shape[2], ci, co, k1)))
+            if (not c1_16 and lo16 and self.ends16 and x2 is None and K.small_cin_supported(3, ci, co, wgrad=True)
+                    and K.small_cin_bf16_supported(3, B, inp.shape[1], inp.shape[2], ci, co, K.ld_of(inp))):
+                c1_16 = True                      # the image -> features conv: its VALU kernels write c1 / read its gradient as bf16
             inp_c, x2_c = inp, x2
             if c1_16 and use_sh and inp.dtype == torch.float32 and inp.shape[3] % 8 == 0:
                 inp_c, x2_c = shadow(inp), (shadow(x2) if x2 is not None else None)
@@ -696,7 +703,9 @@ class Unet(nn.Module):
             f16 = okf[0] and okf[1] and not K.conv3x3_uses_splitk(B, h.shape[1], h.shape[2], cdim, cdim)
         h_c = shadow(h) if (f16 and use_sh) else h
         cF = conv(h_c, "final_conv.0.block.0.", 3, 1, 1, out_dtype=BF if f16 else torch.float32)
-        hF, stF = K.gn_mish_fwd(cF, sv["final_conv.0.block.1.weight"], sv["final_conv.0.block.1.bias"])
+        # round 4: hF as bf16 too where the 128 -> 3 kernels take it (they widen on load; the gradient wrt hF is written as bf16)
+        hF16 = f16 and self.ends16 and all(K.small_cout_supported(op, cdim, sv["final_conv.1.weight"].shape[3]) for op in (0, 1, 2))
+        hF, stF = K.gn_mish_fwd(cF, sv["final_conv.0.block.1.weight"], sv["final_conv.0.block.1.bias"], out_dtype=BF if hF16 else torch.float32)
         eps = conv(hF, "final_conv.1.", 1)
         if record:
             tape.append(("final", h, cF, stF, hF, eps, h_c))
@@ -807,6 +816,8 @@ class Unet(nn.Module):
                         and (K.conv3x3_f32 if k == 3 else K.conv1x1_f32)(dy, wdq32_sh[offs[pre + "weight"]:], K=co, Nc=ci, flip=True, out=buf,
                                                                           accumulate=acc) is not None):
                     return
+                if small_cin and dy.dtype != torch.float32:
+                    dy = dy.float()               # the input gradient of the image -> features conv (rarely wanted): the generic kernel reads fp32
                 assert dy.dtype == torch.float32 and buf.dtype == torch.float32, "bf16 block storage needs the tile kernel"
                 if (mode == K.MODE_FP32 and stride == 2 and K.conv_gt(dy, wdq32_sh[offs[pre + "weight"]:], kh=kh, kw=kw, stride=stride, pad=pad,
                                                                      transposed=not transposed_conv, K=co, Nc=ci, out_hw=(ih, iw), out=buf,

@@ -621,12 +621,19 @@ def small_cin_supported(ks, Cin, Cout, wgrad=False):
     return Cout % 4 == 0 and Cout <= 1024 and 256 % (Cout // 4) == 0
 
 
-def conv_small_cin_fwd(x, w, bias, Cout, ks):
-    """Conv2d(Cin<=4, Cout, ks, padding=ks//2) on an NHWC image tensor (first convs of the UNet)."""
+@functools.lru_cache(maxsize=None)
+def small_cin_bf16_supported(ks, N, H, W, Cin, Cout, ldx):
+    """The first Block's conv (Cin <= 4) can write its output as bf16 AND its weight gradient can read a bf16 dy (round 4)."""
+    return bool(load_library().mi_conv_small_cin_bf16_supported(ks, N, H, W, Cin, Cout, ldx))
+
+
+def conv_small_cin_fwd(x, w, bias, Cout, ks, out_dtype=torch.float32):
+    """Conv2d(Cin<=4, Cout, ks, padding=ks//2) on an NHWC image tensor (first convs of the UNet); out_dtype bf16: the output rounded
+    once on the way out (small_cin_bf16_supported)."""
     _need_gpu(x)
     N, H, W, Cin = x.shape
-    y = new_act(N, H, W, Cout, x)
-    check(load_library().mi_conv_small_cin_fwd(ks, N, H, W, Cin, Cout, _p(x), ld_of(x), _p(w), _p(bias), _p(y), ld_of(y), _stream()),
+    y = (torch.empty((N, H, W, Cout), device=x.device, dtype=torch.bfloat16) if out_dtype == torch.bfloat16 else new_act(N, H, W, Cout, x))
+    check(load_library().mi_conv_small_cin_fwd_io(ks, N, H, W, Cin, Cout, _p(x), ld_of(x), _p(w), _p(bias), _p(y), ld_of(y), _b16(y), _stream()),
           "mi_conv_small_cin_fwd")
     return y
 
@@ -636,8 +643,8 @@ def conv_small_cin_wgrad(x, dy, dW, ks):
     lib = load_library()
     need = lib.mi_conv_small_wgrad_workspace(ks * ks * Cin * dy.shape[3])
     ws = _workspace(x.device, need)
-    check(lib.mi_conv_small_cin_wgrad(ks, N, H, W, Cin, dy.shape[3], _p(x), ld_of(x), _p(dy), ld_of(dy), _p(dW), _p(ws), need, _stream()),
-          "mi_conv_small_cin_wgrad")
+    check(lib.mi_conv_small_cin_wgrad_io(ks, N, H, W, Cin, dy.shape[3], _p(x), ld_of(x), _p(dy), ld_of(dy), _b16(dy), _p(dW), _p(ws), need,
+                                         _stream()), "mi_conv_small_cin_wgrad")
 
 
 @functools.lru_cache(maxsize=None)      # pure function of the shape: one FFI query per distinct layer, not per step
@@ -665,8 +672,9 @@ def conv1x1_small_cout(op, a, w, *, b=None, bias=None, out=None, Cs=None, accumu
     lib = load_library()
     need = lib.mi_conv_small_wgrad_workspace(4 * C) if op == 2 else 0
     ws = _workspace(a.device, need) if op == 2 else None
-    check(lib.mi_conv1x1_small_cout_ws(op, M, C, Cs, _p(a), ld_of(a), _p(b), ld_of(b) if b is not None else 0, _p(w),
-                                       _p(bias), _p(out), ld_of(out) if out.dim() == 4 else Cs, int(accumulate), _p(ws), need, _stream()),
+    wide16 = _b16(out) if op == 1 else _b16(a)       # the C-channel tensor: x (op 0 / 2) or dx (op 1)
+    check(lib.mi_conv1x1_small_cout_io(op, M, C, Cs, _p(a), ld_of(a), _p(b), ld_of(b) if b is not None else 0, _p(w),
+                                       _p(bias), _p(out), ld_of(out) if out.dim() == 4 else Cs, int(accumulate), wide16, _p(ws), need, _stream()),
           "mi_conv1x1_small_cout")
     return out
 

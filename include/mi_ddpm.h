@@ -244,6 +244,15 @@ int mi_conv_small_cin_fwd(int ks, int N, int H, int W, int Cin, int Cout, const 
 int mi_conv_small_cin_wgrad(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* dy,
                             int lddy, float* dW, void* workspace, size_t ws_bytes, void* stream);
 size_t mi_conv_small_wgrad_workspace(int outputs);
+/* Round 4: the wide (Cout-channel) tensor stored as bf16, like every other block-internal tensor of bf16 mode (the reference keeps
+ * c1 = conv(x) and its gradient in fp32, ddpm.py:116-120; x, w, dW stay fp32, the arithmetic is the same fp32 FMA chain, the output
+ * is rounded once / dy is widened on load).  y_bf16 / dy_bf16 = 1 needs the whole-row-tile kernels: ks = 3, W a power of two <= 64,
+ * H*W a power of two, ldx == 4, 16-byte aligned x, Cout in {128, 256} -- mi_conv_small_cin_bf16_supported answers for both. */
+int mi_conv_small_cin_bf16_supported(int ks, int N, int H, int W, int Cin, int Cout, int ldx);
+int mi_conv_small_cin_fwd_io(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w,
+                             const float* bias, void* y, int ldy, int y_bf16, void* stream);
+int mi_conv_small_cin_wgrad_io(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const void* dy,
+                               int lddy, int dy_bf16, float* dW, void* workspace, size_t ws_bytes, void* stream);
 /* the 3x3 forms without workspace */
 int mi_conv3x3_small_cin_fwd(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w,
                              const float* bias, float* y, int ldy, void* stream);
@@ -256,6 +265,11 @@ int mi_conv1x1_small_cout(int op, int M, int C, int Cs, const float* a, int lda,
                           const float* w, const float* bias, float* out, int ldo, int accumulate, void* stream);
 int mi_conv1x1_small_cout_ws(int op, int M, int C, int Cs, const float* a, int lda, const float* b, int ldb,
                              const float* w, const float* bias, float* out, int ldo, int accumulate,
+                             void* workspace, size_t ws_bytes, void* stream);
+/* wide_bf16 = 1 (round 4): the C-channel tensor (x of op 0 / 2, dx of op 1: final_conv.0's output and its gradient) is bf16; the
+ * Cs-channel side, the weights and the arithmetic stay fp32 */
+int mi_conv1x1_small_cout_io(int op, int M, int C, int Cs, const void* a, int lda, const float* b, int ldb,
+                             const float* w, const float* bias, void* out, int ldo, int accumulate, int wide_bf16,
                              void* workspace, size_t ws_bytes, void* stream);
 
 /* ---- weight gradient (aten::convolution_backward, weight part) -----------------------

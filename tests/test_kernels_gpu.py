@@ -1524,6 +1524,46 @@ def test_small_channel_ends(K, cfg):
     assert rel_err(from_nhwc(dh), 2 * h.grad) < 1e-5
 
 
+@pytest.mark.parametrize("N,H,C", [(8, 16, 128), (2, 32, 128), (4, 8, 256)])
+def test_small_channel_ends_bf16_wide_tensor(K, N, H, C):
+    """Round 4: the wide tensor at the 3-channel ends stored as bf16.  Same fp32 arithmetic as the fp32-stored kernels: a bf16 output is
+    the fp32 kernel's output rounded once (bitwise), a bf16 input gives exactly what its widened fp32 copy gives."""
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(45)
+    x = to_nhwc_gpu(torch.randn(N, 3, H, H, generator=g))
+    w = torch.randn(3 * 3 * 3 * C, generator=g).to(DEV) * 0.2
+    b = torch.randn(C, generator=g).to(DEV)
+    if C > 128:                                                   # (the 3x3 weight gradient takes Cout <= 128: 48 KB of reduce area)
+        assert not K.small_cin_bf16_supported(3, N, H, H, 3, C, 4) and not K.small_cin_supported(3, 3, C, wgrad=True)
+        return
+    assert K.small_cin_bf16_supported(3, N, H, H, 3, C, 4)
+    y32 = K.conv_small_cin_fwd(x, w, b, C, 3)
+    y16 = K.conv_small_cin_fwd(x, w, b, C, 3, out_dtype=BF)
+    assert y16.dtype == BF and torch.equal(y16, y32.to(BF))
+    dy16 = to_nhwc_gpu(torch.randn(N, C, H, H, generator=g)).to(BF)
+    dWa, dWb = torch.zeros(27 * C, device=DEV), torch.zeros(27 * C, device=DEV)
+    K.conv_small_cin_wgrad(x, dy16, dWa, 3)
+    K.conv_small_cin_wgrad(x, dy16.float(), dWb, 3)
+    assert torch.equal(dWa, dWb)
+    # final conv: x (op 0 / 2) and dx (op 1) as bf16
+    h16 = to_nhwc_gpu(torch.randn(N, C, H, H, generator=g)).to(BF)
+    wf = torch.randn(C * 3, generator=g).to(DEV) * 0.1
+    bf_ = torch.randn(3, generator=g).to(DEV)
+    de = to_nhwc_gpu(torch.randn(N, 3, H, H, generator=g))
+    assert torch.equal(K.conv1x1_small_cout(0, h16, wf, bias=bf_, Cs=3), K.conv1x1_small_cout(0, h16.float(), wf, bias=bf_, Cs=3))
+    dWa, dWb = torch.zeros(C * 3, device=DEV), torch.zeros(C * 3, device=DEV)
+    K.conv1x1_small_cout(2, h16, None, b=de, out=dWa)
+    K.conv1x1_small_cout(2, h16.float(), None, b=de, out=dWb)
+    assert torch.equal(dWa, dWb)
+    dh32 = torch.empty(N, H, H, C, device=DEV)
+    dh16 = torch.empty(N, H, H, C, device=DEV, dtype=BF)
+    K.conv1x1_small_cout(1, de, wf, out=dh32)
+    K.conv1x1_small_cout(1, de, wf, out=dh16)
+    assert torch.equal(dh16, dh32.to(BF))
+    K.conv1x1_small_cout(1, de, wf, out=dh16, accumulate=True)    # += into the bf16 tensor: widened, added in fp32, rounded again
+    assert torch.equal(dh16, (dh32.to(BF).float() + dh32).to(BF))
+
+
 @pytest.mark.parametrize("kind", ["down", "down_dgrad", "up", "up_dgrad"])
 def test_igemm_bf16_weight_copy(K, kind):
     """Stride-2 Downsample / ConvTranspose Upsample (ddpm.py:70,79) through the generic kernel fed by the bf16 weight copy."""
