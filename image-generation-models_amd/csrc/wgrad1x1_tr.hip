@@ -180,37 +180,49 @@ __global__ __launch_bounds__(512, 1) void wgrad1x1_tr_kernel(const W1Batch b) {
     else           { if (a.q32) wgrad1_body<true, 1>(a, wg, lds_raw); else wgrad1_body<false, 1>(a, wg, lds_raw); }
 }
 
-// dW[ci][co] += sum over k-slices (fixed order); grid = (4 position groups x 64-channel regions, 4 register quads, tiles with
-// k-slices), 256 threads = 2 slice groups x 128 float4 positions
+// dW[ci][co] += sum over k-slices (fixed order); grid = ((512 / IB) position groups x 64-channel regions, 4 register quads, tiles with
+// k-slices), 256 threads = G slice groups x IB = 256 / G float4 positions; each thread keeps 8 independent 16-byte loads in flight.
+// (Round 4: it was 2 slice groups with 2 loads in flight -- a chain of 16 L2 round trips for the 64 k-slices of a to_qkv layer, 15 us per
+// launch and six launches per step.)
+template <int G>
 __global__ __launch_bounds__(256) void wgrad1x1_tr_reduce_kernel(const W1Batch b) {
     MI_PRIO_UP();
-    __shared__ f32x4 red[128];
+    constexpr int IB = 256 / G, PB = 512 / IB;               // positions per workgroup, workgroups per (region, quad)
+    __shared__ f32x4 red[G][IB];
     int pi = 0;
 #pragma unroll
     for (int q = 1; q < MAXP; ++q)
         if (q < b.n && b.p[q].splits > 1 && (int)blockIdx.z >= b.p[q].tile0) pi = q;
     const W1Args& a = b.p[pi];
-    const int reg = blockIdx.x >> 2;
+    const int reg = blockIdx.x / PB;
     if (reg >= a.ni) return;
     const int ntiles = a.gx * a.gy, splits = a.splits;
-    const int it = threadIdx.x & 127, grp = threadIdx.x >> 7;
-    const int tt = (blockIdx.x & 3) * 128 + it;
+    const int it = threadIdx.x % IB, grp = threadIdx.x / IB;
+    const int tt = (blockIdx.x % PB) * IB + it;
     const int rq = blockIdx.y, tile = blockIdx.z - a.tile0;
     const size_t tsz = (size_t)a.ni * (4 * 2048);
     const float* p = a.ws + (size_t)tile * tsz + (size_t)reg * 8192 + (size_t)rq * 2048 + tt * 4;
     const size_t stride = (size_t)ntiles * tsz;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     int sp = grp;
-    for (; sp + 2 < splits; sp += 4) {
-        s0 += *reinterpret_cast<const f32x4*>(p + (size_t)sp * stride);
-        s1 += *reinterpret_cast<const f32x4*>(p + (size_t)(sp + 2) * stride);
+    for (; sp + 7 * G < splits; sp += 8 * G) {
+        f32x4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + q * G) * stride);
+        s0 += v[0] + v[4]; s1 += v[1] + v[5]; s2 += v[2] + v[6]; s3 += v[3] + v[7];
     }
-    for (; sp < splits; sp += 2) s0 += *reinterpret_cast<const f32x4*>(p + (size_t)sp * stride);
-    f32x4 s = s0 + s1;
-    if (grp == 1) red[it] = s;
+    {   // the tail: up to seven more, requested together
+        f32x4 v[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) v[q] = (sp + q * G < splits) ? *reinterpret_cast<const f32x4*>(p + (size_t)(sp + q * G) * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s0 += v[0] + v[4]; s1 += v[1] + v[5]; s2 += v[2] + v[6]; s3 += v[3];
+    }
+    f32x4 s = (s0 + s1) + (s2 + s3);
+    red[grp][it] = s;
     __syncthreads();
     if (grp != 0) return;
-    s += red[it];
+#pragma unroll
+    for (int g = 1; g < G; ++g) s += red[g][it];
     const int wv = tt >> 6, l = tt & 63;
     const int ci = (tile % a.gx) * (64 * a.ni) + reg * 64 + (wv >> 2) * 32 + 8 * rq + 4 * (l >> 5);
     const int co = (tile / a.gx) * 128 + (wv & 3) * 32 + (l & 31);
@@ -319,7 +331,7 @@ extern "C" int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
     }
     w1_shares(n, descs, q_is_fp32, wgs);
     size_t off = 0, lds = 0;
-    int wg = 0, tile = 0, nimax = 1;
+    int wg = 0, tile = 0, nimax = 1, max_splits = 1;
     for (int i = 0; i < n; ++i) {
         W1Args& a = b.p[i];
         w1_plan(&descs[i], a, wgs[i]);
@@ -331,6 +343,7 @@ extern "C" int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         static const int xcd_env = (int)mi_knob("MI_W1_XCD", 1);
         a.xcd_map = xcd_env && a.gx * a.gy > 1 && a.splits > 1;
         a.wg0 = wg; wg += a.gx * a.gy * a.splits;
+        if (a.splits > max_splits) max_splits = a.splits;
         a.tile0 = tile; if (a.splits > 1) { tile += a.gx * a.gy; nimax = a.ni > nimax ? a.ni : nimax; }
         lds = w1_lds(a) > lds ? w1_lds(a) : lds;
     }
@@ -343,7 +356,10 @@ extern "C" int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
     }();
     (void)once;
     if (g_w1_phase != 2) hipLaunchKernelGGL(wgrad1x1_tr_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);
-    if (g_w1_phase != 1 && tile > 0) hipLaunchKernelGGL(wgrad1x1_tr_reduce_kernel, dim3(4 * nimax, 4, tile), dim3(256), 0, st, b);
+    if (g_w1_phase != 1 && tile > 0) {
+        if (max_splits >= 32) hipLaunchKernelGGL(wgrad1x1_tr_reduce_kernel<8>, dim3(16 * nimax, 4, tile), dim3(256), 0, st, b);
+        else hipLaunchKernelGGL(wgrad1x1_tr_reduce_kernel<2>, dim3(4 * nimax, 4, tile), dim3(256), 0, st, b);
+    }
     MI_LAUNCH_CHECK();
     return 0;
 }
