@@ -21,7 +21,7 @@ namespace {
 struct W1Args {
     const uint16_t* P; const uint16_t* P2; const void* Q;
     float* ws; float* dW; float* dbias;
-    int Ci, Cj, I1, ldp, ldp2, ldq, q32, ni;
+    int Ci, Cj, I1, ldp, ldp2, ldq, q32, ni, f32;
     int total, sps, splits, gx, gy, wg0, tile0, xcd_map;
 };
 struct W1Batch { W1Args p[MAXP]; int n; };
@@ -167,6 +167,114 @@ __device__ __forceinline__ void wgrad1_body(const W1Args& a, const int wg, uint8
             *reinterpret_cast<f32x4*>(out + r * 8192 + rq * 2048) = f32x4{acc[r][4 * rq], acc[r][4 * rq + 1], acc[r][4 * rq + 2], acc[r][4 * rq + 3]};
 }
 
+// Exact-fp32 mode (Unet.compute_mode = "fp32"; round 4): X and dY are fp32 tensors, v_mfma_f32_32x32x2_f32 -- bit-equal to an fp32 fmaf
+// chain over the pixels of a k-slice.  Same tiling (64 ci x 128 co per workgroup, wave (wi, wj) = one 32 x 32 tile), same k-slices,
+// partial tiles and reduce.  No transposition is needed: the fp32 MFMA takes ONE k per lane half, i.e. lane (i, half) reads channel i of
+// pixel 2s + half straight from the raw rows (32 lanes = 128 consecutive bytes: conflict-free).  Rows arrive by LDS-DMA: X 64 pixels x
+// 64 channels (16 KB: four pixels per wave instruction), dY 64 pixels x 128 channels (32 KB: two pixels per instruction); three slots.
+// Per 64-pixel step a wave issues 32 MFMAs (2048 clocks) for 6 DMA instructions: bound by the fp32 matrix pipe as long as the tiles of a
+// k-slice share their rows in one XCD's L2 (xcd_map, as for the bf16 kernel).  Before: the generic wgrad_kernel<0>, 46 TFLOP/s.
+constexpr int XRAW = 64 * 64 * 4;     // 64 pixels x 64 channels fp32
+__device__ __forceinline__ void wgrad1_f32_body(const W1Args& a, const int wg, uint8_t* lds_raw) {
+    constexpr int PF = 2, RING = PF + 1;
+    constexpr int YOFF = RING * XRAW;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
+    const int t = threadIdx.x, l = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wi = wv >> 2, wj = wv & 3;
+    const int ntiles = a.gx * a.gy;
+    int rank = wg;
+    if (a.xcd_map) {
+        const int W = ntiles * a.splits, x = (a.wg0 + wg) & 7;
+        rank = (wg - ((x - a.wg0) & 7)) >> 3;
+        for (int xx = 0; xx < x; ++xx) rank += (W - ((xx - a.wg0) & 7) + 7) >> 3;
+    }
+    const int split = rank / ntiles, tile = rank - split * ntiles;
+    const int ci0 = (tile % a.gx) * 64, co0 = (tile / a.gx) * 128;
+    const int sb = split * a.sps, se = min(a.total, sb + a.sps);
+    const int last = a.total - 1;
+    const bool second = ci0 >= a.I1;                                   // the ci tile lies in one source of a two-source layer (I1 % 64 == 0)
+    const int ldx = second ? a.ldp2 : a.ldp;
+    const float* xsrc = reinterpret_cast<const float*>(second ? (const void*)a.P2 : (const void*)a.P) + (size_t)(l >> 4) * ldx +
+                        (second ? ci0 - a.I1 : ci0) + (l & 15) * 4;
+    const float* ysrc = reinterpret_cast<const float*>(a.Q) + (size_t)(l >> 5) * a.ldq + min(co0 + (l & 31) * 4, a.Cj - 4);
+    auto stage = [&](int step) {
+        const size_t pix0 = (size_t)min(step, last) * 64;
+        const int slot = step % RING;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                                  // 16 blocks of 4 pixels, two per wave
+            const int i = wv + 8 * k;
+            glds16(xsrc + (pix0 + i * 4) * ldx, lds0 + slot * XRAW + i * 1024);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                  // 32 pixel pairs, four per wave
+            const int i = wv + 8 * k;
+            glds16(ysrc + (pix0 + i * 2) * a.ldq, lds0 + YOFF + slot * YRAW + i * 1024);
+        }
+    };
+    constexpr int PER_STEP = 6;
+    const int half = l >> 5;
+    const int fa = half * 256 + (wi * 32 + (l & 31)) * 4;              // X: pixel 2s + half, channel wi*32 + lane
+    const int fb = half * 512 + (wj * 32 + (l & 31)) * 4;              // dY: pixel 2s + half, channel wj*32 + lane
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = a.dbias != nullptr && ci0 == 0 && wi == 0;
+    static_for<0, PF>([&](auto kc) { stage(sb + decltype(kc)::value); });
+    for (int s = sb; s < se; ++s) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PER_STEP * (PF - 1)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage(s + PF);
+        const int slot = s % RING;
+        const uint8_t* xb = lds_raw + slot * XRAW + fa;
+        const uint8_t* yb = lds_raw + YOFF + slot * YRAW + fb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                av[e] = *reinterpret_cast<const float*>(xb + (8 * j + e) * 512);
+                bv[e] = *reinterpret_cast<const float*>(yb + (8 * j + e) * 1024);
+            }
+            if (do_bias) bsum += ((bv[0] + bv[1]) + (bv[2] + bv[3])) + ((bv[4] + bv[5]) + (bv[6] + bv[7]));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (do_bias) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        const int c = co0 + wj * 32 + l;
+        if (l < 32 && c < a.Cj) atomicAdd(a.dbias + c, bsum);
+    }
+    if (a.splits == 1) {
+        const int ci = ci0 + wi * 32 + 4 * (l >> 5), co = co0 + wj * 32 + (l & 31);
+        if (co < a.Cj) {
+            float* o = a.dW + (size_t)ci * a.Cj + co;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o[(size_t)((q & 3) + 8 * (q >> 2)) * a.Cj] += acc[q];
+        }
+        return;
+    }
+    float* out = a.ws + (size_t)(split * ntiles + tile) * (4 * 2048) + t * 4;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+        *reinterpret_cast<f32x4*>(out + rq * 2048) = f32x4{acc[4 * rq], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]};
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad1x1_f32_kernel(const W1Batch b) {
+    MI_PRIO_UP();
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < MAXP; ++q)
+        if (q < b.n && (int)blockIdx.x >= b.p[q].wg0) p = q;
+    const W1Args& a = b.p[p];
+    wgrad1_f32_body(a, blockIdx.x - a.wg0, lds_raw);
+}
+
 __global__ __launch_bounds__(512, 1) void wgrad1x1_tr_kernel(const W1Batch b) {
     MI_PRIO_UP();
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -234,7 +342,12 @@ __global__ __launch_bounds__(256) void wgrad1x1_tr_reduce_kernel(const W1Batch b
 }
 
 bool w1_ok(const MiWgradDesc* d, int q32) {
-    if (d->KH != 1 || d->KW != 1 || d->pad != 0 || d->stride != 1 || !d->gather_i || d->mode != 1) return false;
+    if (d->KH != 1 || d->KW != 1 || d->pad != 0 || d->stride != 1 || !d->gather_i || (d->mode != 1 && d->mode != 0)) return false;
+    if (d->mode == 0) {          // exact-fp32 mode: fp32 X and dY rows, 16-byte pieces
+        if (d->GH != d->DH || d->GW != d->DW || ((long)d->N * d->DH * d->DW) % 64) return false;
+        if (d->Ci % 64 || d->I1 % 64 || d->Cj % 32 || d->Cj < 32) return false;
+        return q32 && d->ldp % 4 == 0 && (d->I1 == d->Ci || d->ldp2 % 4 == 0) && d->ldq % 4 == 0;
+    }
     if (d->GH != d->DH || d->GW != d->DW) return false;
     if (((long)d->N * d->DH * d->DW) % 64) return false;
     if (d->Ci % 64 || d->I1 % 64 || d->Cj % 32 || d->Cj < 32) return false;
@@ -247,7 +360,7 @@ int g_w1_phase = 0, g_w1_blocks = 0;
 // 64-channel regions per ci tile: 2 wherever the layer allows it (the dY rows are then re-read Ci / 128 instead of Ci / 64 times)
 int w1_ni(const MiWgradDesc* d) {
     static const int wide = (int)mi_knob("MI_W1_NI", 2);
-    return (wide >= 2 && d->Ci % 128 == 0) ? 2 : 1;
+    return (wide >= 2 && d->Ci % 128 == 0 && d->mode != 0) ? 2 : 1;      // (exact-fp32 mode: 48 KB of raw rows per step and slot already)
 }
 
 void w1_plan(const MiWgradDesc* d, W1Args& a, long wgs) {
@@ -268,7 +381,7 @@ void w1_shares(int n, const MiWgradDesc* d, const int* q32, long* wgs) {
     double tot = 0, by[MAXP];
     for (int i = 0; i < n; ++i) {
         const double tiles_ci = d[i].Ci / (64 * w1_ni(&d[i])), tiles_co = (d[i].Cj + 127) / 128;
-        by[i] = (double)d[i].N * d[i].DH * d[i].DW * (tiles_co * d[i].Ci * 2.0 + tiles_ci * d[i].Cj * (q32[i] ? 4.0 : 2.0));
+        by[i] = (double)d[i].N * d[i].DH * d[i].DW * (tiles_co * d[i].Ci * (d[i].mode == 0 ? 4.0 : 2.0) + tiles_ci * d[i].Cj * (q32[i] ? 4.0 : 2.0));
         tot += by[i];
     }
     const long target = g_w1_blocks > 0 ? g_w1_blocks : 256;
@@ -290,6 +403,7 @@ void w1_shares(int n, const MiWgradDesc* d, const int* q32, long* wgs) {
 size_t w1_ws_floats(const W1Args& a) { return a.splits > 1 ? (size_t)a.splits * a.gx * a.gy * a.ni * 4 * 2048 : 0; }
 // dynamic LDS of one problem: X ring + dY ring (see wgrad1_body)
 size_t w1_lds(const W1Args& a) {
+    if (a.f32) return (size_t)3 * (XRAW + YRAW);
     const size_t ring = a.q32 ? 3 : 4;
     return ring * ((size_t)a.ni * XSTEP + (a.q32 ? YRAW : YSTEP));
 }
@@ -324,6 +438,7 @@ extern "C" int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
     long wgs[MAXP];
     for (int i = 0; i < n; ++i) {
         MI_REQUIRE(w1_ok(&descs[i], q_is_fp32[i]), "descriptor not supported by the LDS-DMA 1x1 weight-gradient kernel");
+        MI_REQUIRE(descs[i].mode == descs[0].mode, "one numeric mode per batch");
         MI_REQUIRE(P[i] && Q[i] && dW[i], "null operand");
         MI_REQUIRE(descs[i].I1 == descs[i].Ci || (P2 && P2[i]), "two-source split without P2");
         MI_REQUIRE((((uintptr_t)P[i] | (uintptr_t)Q[i] | (uintptr_t)((P2 && P2[i]) ? P2[i] : P[i])) & 15) == 0, "operands must be 16-byte aligned");
@@ -336,7 +451,7 @@ extern "C" int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         W1Args& a = b.p[i];
         w1_plan(&descs[i], a, wgs[i]);
         a.P = (const uint16_t*)P[i]; a.P2 = (const uint16_t*)((P2 && P2[i]) ? P2[i] : P[i]); a.Q = Q[i];
-        a.dW = dW[i]; a.dbias = dbias ? dbias[i] : nullptr; a.q32 = q_is_fp32[i] ? 1 : 0;
+        a.dW = dW[i]; a.dbias = dbias ? dbias[i] : nullptr; a.q32 = q_is_fp32[i] ? 1 : 0; a.f32 = descs[i].mode == 0 ? 1 : 0;
         a.ldp = descs[i].ldp; a.ldp2 = (P2 && P2[i]) ? descs[i].ldp2 : descs[i].ldp; a.ldq = descs[i].ldq;
         a.ws = (float*)workspace + off;
         off += w1_ws_floats(a);
@@ -352,10 +467,14 @@ extern "C" int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
     hipStream_t st = (hipStream_t)stream;
     static bool once = [] {
         (void)hipFuncSetAttribute((const void*)wgrad1x1_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wgrad1x1_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)once;
-    if (g_w1_phase != 2) hipLaunchKernelGGL(wgrad1x1_tr_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);
+    if (g_w1_phase != 2) {
+        if (descs[0].mode == 0) hipLaunchKernelGGL(wgrad1x1_f32_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);
+        else hipLaunchKernelGGL(wgrad1x1_tr_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);
+    }
     if (g_w1_phase != 1 && tile > 0) {
         if (max_splits >= 32) hipLaunchKernelGGL(wgrad1x1_tr_reduce_kernel<8>, dim3(16 * nimax, 4, tile), dim3(256), 0, st, b);
         else hipLaunchKernelGGL(wgrad1x1_tr_reduce_kernel<2>, dim3(4 * nimax, 4, tile), dim3(256), 0, st, b);

@@ -795,6 +795,14 @@ class Unet(nn.Module):
                            dbias=gv[pre + "bias"] if fuse_b else None)
                 if fuse_b:
                     bias = None
+            elif (k == 1 and stride == 1 and not transposed_conv and mode == K.MODE_FP32 and winp.dtype == torch.float32
+                  and dy.dtype == torch.float32 and ci % 64 == 0 and co % 32 == 0):
+                # fp32 mode (round 4): the same queue, the exact-fp32 instantiation of the 1x1 kernel; the bias gradient rides along
+                fuse_b = bias == "colsum"
+                wq.push1x1(winp, dy, gv[pre + "weight"], Ci=ci, Cj=co, hw=(ih, iw), mode=mode, P2=wx2,
+                           dbias=gv[pre + "bias"] if fuse_b else None)
+                if fuse_b:
+                    bias = None
             else:
                 if stride == 2:
                     winp = inp                                        # round 1's ring kernel converts while it stages

@@ -813,7 +813,11 @@ class WgradQueue:
         """1x1; dbias (optional) += column sums of Q"""
         d = self._desc(P, Q, 1, Ci, Cj, hw, mode, P2)
         q32 = int(Q.dtype == torch.float32)
-        ok = (USE_WGRAD_TR and self.group > 1 and _b16(P) and (P2 is None or _b16(P2)) and (dbias is None or q32)
+        if mode == MODE_FP32:       # exact-fp32 instantiation (round 4): fp32 X and dY
+            dt_ok = P.dtype == torch.float32 and (P2 is None or P2.dtype == torch.float32) and q32
+        else:
+            dt_ok = _b16(P) and (P2 is None or _b16(P2))
+        ok = (USE_WGRAD_TR and self.group > 1 and dt_ok and (dbias is None or q32)
               and _query("mi_conv1x1_wgrad_tr_supported", d, q32))
         if not ok:
             conv_wgrad(P, Q, dW, kh=1, kw=1, stride=1, pad=0, gather_i=True, Ci=Ci, Cj=Cj, grid_g=hw, grid_d=hw, mode=mode, P2=P2, dbias=dbias)
@@ -895,8 +899,9 @@ class WgradQueue:
                 check(lib.mi_conv1x1_wgrad_tr_batch(n, descs, q32, arr(items, 1), arr(items, 2), arr(items, 3), arr(items, 4), arr(items, 5),
                                                     _p(ws), ws.numel() * 4, _stream()), "mi_conv1x1_wgrad_tr_batch")
             flops = sum(2.0 * it[0].N * it[0].DH * it[0].DW * it[0].Ci * it[0].Cj for it in items)
-            nb = sum(it[0].N * it[0].DH * it[0].DW * (it[0].Ci * 2.0 + it[0].Cj * (4.0 if it[6] else 2.0)) for it in items)
-            self._run(go1, lib.mi_debug_wgrad1x1_tr_phase, "wgrad1x1_tr", n, flops, nb, need)
+            f32 = items[0][0].mode == MODE_FP32
+            nb = sum(it[0].N * it[0].DH * it[0].DW * (it[0].Ci * (4.0 if f32 else 2.0) + it[0].Cj * (4.0 if it[6] else 2.0)) for it in items)
+            self._run(go1, lib.mi_debug_wgrad1x1_tr_phase, "wgrad1x1_f32" if f32 else "wgrad1x1_tr", n, flops, nb, need)
         if 2 in kinds and self.items2:
             items, self.items2, self._seq2 = self.items2, [], []
             _need_gpu(items[0][1])
@@ -924,7 +929,7 @@ class WgradQueue:
             phase(1)
             e0 = _probe_open(); go(); _probe_close(e0, name + "_kernel", flops, f"{n} layers", nb + need)
             phase(2)
-            e0 = _probe_open(); go(); _probe_close(e0, name.replace("tr32", "tr") + "_reduce_kernel", 0.0, f"{n} layers", float(need))
+            e0 = _probe_open(); go(); _probe_close(e0, name.replace("tr32", "tr").replace("1x1_f32", "1x1_tr") + "_reduce_kernel", 0.0, f"{n} layers", float(need))
         finally:
             phase(0)
 

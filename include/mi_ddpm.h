@@ -343,7 +343,9 @@ int mi_conv3x3_wgrad_tr_batch(int n, const MiWgradDesc* descs, const void* const
  * all pixels, up to 8 layers per launch on shares of the workgroups proportional to the bytes they stream (these are HBM-bound).
  * P / P2 are bf16 tensors; Q is bf16 (q_is_fp32[i] = 0) or the fp32 residual-stream gradient (1: rows are DMA'd raw and converted
  * in LDS, and dbias[i] (optional) += column sums of Q -- the conv's bias gradient, replacing a separate mi_colsum pass).
- * Needs N*H*W % 64 == 0, Ci % 64 == 0, I1 % 64 == 0, Cj % 32 == 0, ldp % 8 == 0, ldq % 8 (bf16) / % 4 (fp32) == 0. */
+ * Needs N*H*W % 64 == 0, Ci % 64 == 0, I1 % 64 == 0, Cj % 32 == 0, ldp % 8 == 0, ldq % 8 (bf16) / % 4 (fp32) == 0.
+ * mode 0 (round 4; Unet.compute_mode = "fp32"): P / P2 and Q are fp32 tensors (q_is_fp32 = 1, ldp / ldp2 / ldq % 4 == 0), the products run
+ * on v_mfma_f32_32x32x2_f32 -- an fp32 fmaf chain per k-slice, slices added in a fixed order; one mode per batch. */
 int mi_conv1x1_wgrad_tr_supported(const MiWgradDesc* d, int q_is_fp32);
 size_t mi_conv1x1_wgrad_tr_batch_workspace(int n, const MiWgradDesc* descs, const int* q_is_fp32);
 int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const int* q_is_fp32, const void* const* P,

@@ -1271,6 +1271,48 @@ def test_conv1x1_wgrad_queue(K):
             assert rel_err(db, bref) < 1e-5, (Ci, Co)
 
 
+def test_conv1x1_wgrad_queue_fp32_mode(K):
+    """Round 4: the exact-fp32 instantiation of the batched 1x1 weight-gradient kernel (Unet.compute_mode = "fp32": fp32 X and dY,
+    v_mfma_f32_32x32x2_f32) -- to_qkv / to_out / res_conv shapes, a two-source layer, a ragged co tile, fused bias gradients -- against
+    fp64 at the fp32 bar, and against the generic fp32 kernel it replaces."""
+    g = torch.Generator().manual_seed(53)
+    layers = [dict(N=8, H=32, Ci=128, Co=384), dict(N=8, H=32, Ci=128, Co=128, bias=True), dict(N=8, H=16, Ci=256, Co=384),
+              dict(N=8, H=8, Ci=1024, Co=256, bias=True, split=512), dict(N=4, H=8, Ci=128, Co=96, bias=True),
+              dict(N=8, H=16, Ci=512, Co=128, split=256), dict(N=2, H=8, Ci=64, Co=32), dict(N=8, H=8, Ci=128, Co=512, bias=True)]
+    q = K.WgradQueue(group=8)
+    checks = []
+    K.PROBE = []
+    try:
+        for L in layers:
+            N, H, Ci, Co, split = L["N"], L["H"], L["Ci"], L["Co"], L.get("split")
+            x = torch.randn(N, Ci, H, H, generator=g)
+            dy = torch.randn(N, Co, H, H, generator=g)
+            wq = torch.zeros(Co, Ci, 1, 1, dtype=torch.float64, requires_grad=True)
+            F.conv2d(x.double(), wq, None).backward(dy.double())
+            nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+            X = nh(x)
+            P, P2 = (X[..., :split], X[..., split:]) if split else (X, None)   # channel slices of one tensor: pixel stride Ci
+            Q = nh(dy)
+            dW = torch.full((Ci * Co,), 0.25, device=DEV)                      # the kernel accumulates
+            db = torch.zeros(Co, device=DEV) if L.get("bias") else None
+            q.push1x1(P, Q, dW, Ci=Ci, Cj=Co, hw=(H, H), mode=0, P2=P2, dbias=db)
+            dWg = torch.zeros(Ci * Co, device=DEV)
+            K.conv_wgrad(P, Q, dWg, kh=1, kw=1, stride=1, pad=0, gather_i=True, Ci=Ci, Cj=Co, grid_g=(H, H), grid_d=(H, H), mode=0, P2=P2)
+            checks.append((dW, db, dWg, Ci, Co, wq.grad, dy.double().sum((0, 2, 3))))
+        assert q.pushed == 8 and q.flushed == 8                                # every layer went to the queue (one launch of eight)
+        torch.cuda.synchronize()
+        seen = [p[0] for p in K.PROBE]
+    finally:
+        K.PROBE = None
+    assert any("wgrad1x1_f32_kernel" in n for n in seen), seen
+    for dW, db, dWg, Ci, Co, ref, bref in checks:
+        got = (dW - 0.25).view(Ci, Co).t().cpu().double()
+        assert rel_err(got, ref.view(Co, Ci)) < 2e-6, (Ci, Co)
+        assert rel_err(dW - 0.25, dWg) < 2e-6, (Ci, Co)
+        if db is not None:
+            assert rel_err(db, bref) < 1e-5, (Ci, Co)
+
+
 @pytest.mark.parametrize("shape", [(128, 32, 32, 128), (16, 16, 16, 256), (3, 8, 8, 64), (2, 8, 8, 1024), (5, 7, 9, 36)])
 def test_to_bf16_with_column_sums(K, shape):
     """mi_f32_to_bf16_colsum: the bf16 copy equals torch's round-to-nearest-even, the column sums (added onto what is there) equal an
