@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
 // FULL: the slice is exactly MAXU units per thread (HW == MAXU * 256 / (Cg / VEC)): no guards, and the packed-cache path runs as a
 // straight-line software pipeline (see below).
 template <int VEC, int MAXU, int IO = 0, bool FULL = false>     // IO bit 0: x is bf16, bit 1: dx is written as bf16, bit 2: dout is bf16
-__global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? MI_GN_WAVES : 1)) void gn_mish_bwd_kernel(const GnArgs a) {
+__global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? (MAXU * VEC > 64 ? 2 : MI_GN_WAVES) : 1)) void gn_mish_bwd_kernel(const GnArgs a) {
     MI_PRIO_UP();
     constexpr bool X16 = IO & 1, DX16 = IO & 2, DO16 = IO & 4;
     __shared__ float part[4][256 * VEC];
@@ -685,6 +685,14 @@ static bool gn_vec8(const GnArgs& a, int io_all16, std::initializer_list<int> ld
     for (const void* p : ptrs) if ((uintptr_t)p & 15) return false;
     return true;
 }
+// Round 4: slices the 4-channel lanes cannot cache (more than 16 units per thread: the 64 x 64 level of cfg 3, C / G = 8, 4096 pixels)
+// take 8-channel lanes with a 16-unit packed cache instead of the uncached two-pass form (which reads x and dout twice)
+static bool gn_wide16(const GnArgs& a, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+    if (a.vec8_units <= 8 || a.vec8_units > 16) return false;
+    for (int l : lds) if (l % 8) return false;
+    for (const void* p : ptrs) if ((uintptr_t)p & 15) return false;
+    return true;
+}
 #define GN_DISPATCH_IO_(KERNEL, IOV, FWD)                                                                 \
     do {                                                                                            \
         dim3 grid(a.N * a.G), blk(256);                                                             \
@@ -709,7 +717,10 @@ static bool gn_vec8(const GnArgs& a, int io_all16, std::initializer_list<int> ld
     do {                                                                                                                \
         const int ppx = 256 / (a.Cg / 4);                                                                               \
         static const int full_on = (int)mi_knob("MI_GN_FULL", 1);                                                       \
+        static const int wide_on = (int)mi_knob("MI_GN_WIDE16", 1);                                                     \
         if (full_on && vec == 4 && d->HW == 8 * ppx) hipLaunchKernelGGL((gn_mish_bwd_kernel<4, 8, IOV, true>), dim3(a.N * a.G), dim3(256), 0, st, a); \
+        else if (wide_on && vec == 4 && units > 16 && gn_wide16(a, {d->ldx, lddo, lddx}, {x, dout, dx, gamma, beta}))    \
+            hipLaunchKernelGGL((gn_mish_bwd_kernel<8, 16, IOV, false>), dim3(a.N * a.G), dim3(256), 0, st, a);           \
         else GN_DISPATCH_IO(gn_mish_bwd_kernel, IOV);                                                                   \
     } while (0)
 

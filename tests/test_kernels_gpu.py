@@ -1699,6 +1699,45 @@ def test_bf16_block_storage_kernels(K):
         assert rel_err(db, (q(dyq) if Q.dtype == BF else dyq).sum((0, 2, 3))) < 1e-5     # bias sums use the stored values
 
 
+@pytest.mark.parametrize("dout16", [True, False])
+def test_gn_bwd_4096_pixel_slices_bf16(K, dout16):
+    """Round 4: GroupNorm backward on the 64 x 64 level of cfg 3 (C / G = 8, 4096-pixel slices: 32 units of 4-channel lanes, more than
+    the register cache holds) runs on 8-channel lanes with a 16-unit packed cache (gn_mish_bwd_kernel<8, 16>) instead of the uncached
+    two-pass form: against fp64 on the bf16-stored operands; dout bf16 (block-internal) and fp32 (residual-stream gradient)."""
+    g = torch.Generator().manual_seed(71)
+    N, H, C = 4, 64, 64
+    BF = torch.bfloat16
+
+    def q(t):
+        return t.float().bfloat16().double()
+    c = torch.randn(N, C, H, H, generator=g, dtype=torch.float64) * 2 + 0.3
+    gamma = (torch.randn(C, generator=g, dtype=torch.float64) + 1).requires_grad_(True)
+    beta = torch.randn(C, generator=g, dtype=torch.float64).requires_grad_(True)
+    temb = torch.randn(N, C, generator=g, dtype=torch.float64).requires_grad_(True)
+    cq = q(c).requires_grad_(True)
+    h = F.group_norm(cq, 8, gamma, beta)
+    yref = h * torch.tanh(F.softplus(h)) + temb[:, :, None, None]
+    dy = torch.randn(N, C, H, H, generator=g, dtype=torch.float64)
+    dyq = q(dy) if dout16 else dy.float().double()
+    yref.backward(dyq)
+    c16 = to_nhwc_gpu(c.float()).contiguous().to(BF)
+    ga, be = gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+    _, st = K.gn_mish_fwd(c16, ga, be, temb=temb.detach().float().to(DEV), out_dtype=BF)
+    dyg = to_nhwc_gpu(dy.float()).contiguous()
+    dyg = dyg.to(BF) if dout16 else dyg
+    dga, dbe, dbias = (torch.zeros(C, device=DEV) for _ in range(3))
+    dtemb = torch.zeros(N, C, device=DEV)
+    K.PROBE = []
+    try:
+        dx = K.gn_mish_bwd(c16, st, ga, be, dyg, dgamma=dga, dbeta=dbe, dtemb=dtemb, dbias=dbias, out_dtype=BF)
+        torch.cuda.synchronize()
+    finally:
+        K.PROBE = None
+    assert dx.dtype == BF and rel_err(from_nhwc(dx.float()), cq.grad) < 8e-3
+    assert rel_err(dga, gamma.grad) < 2e-3 and rel_err(dbe, beta.grad) < 2e-3 and rel_err(dtemb, temb.grad) < 2e-3
+    assert max_err(dbias, cq.grad.sum((0, 2, 3))) < 2e-2 * float(cq.grad.abs().sum((0, 2, 3)).max()) / 10
+
+
 def test_bf16_attention_storage_kernels(K):
     """bf16 storage of the attention-internal tensors: the 1x1 tile kernel / 1x1 weight gradient with bf16 operands,
     LayerNorm writing bf16 / reading a bf16 gradient, and the LinearAttention core on bf16 qkv -- each against the
