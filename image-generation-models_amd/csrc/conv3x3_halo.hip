@@ -112,8 +112,13 @@ template <int BM, int WAVES = (BM == 256 ? 8 : 4)> struct HaloCfg {
 // published by the barrier BEFORE tap g and the first MFMA operands of tap g+1 are fetched from LDS while tap g's last MFMAs
 // run.  After the barrier the matrix pipe starts at once instead of waiting for an LDS round trip that all 8 waves of the
 // workgroup (one workgroup per CU: nobody else to fill the gap) begin at the same moment.
-template <int BM, int CK, int KS, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4), bool FUSE = false, bool PIPE = false>
+// N64 (round 4): layers with at most 64 output channels (cfg 3's 64 x 64 level).  The wave grid is (WAVES / 2) x 2 with 64 channels per
+// wave column: at Nc <= 64 the second column multiplied a clamped copy of the last weight row and threw the result away -- half of the
+// workgroup's MFMAs.  Here all WAVES waves lie along M (one 32-pixel block each at BM = 256 instead of two) over the one 64-channel
+// column: same tile, same halo buffers, every MFMA used.
+template <int BM, int CK, int KS, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4), bool FUSE = false, bool PIPE = false, bool N64 = false>
 __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(const HaloArgs a) {
+    static_assert(!N64 || (HaloCfg<BM, WAVES>::MI % 2 == 0 && KS == 3 && !SK), "N64: 3x3 tiles whose waves own two pixel blocks");
     MI_PRIO_UP();
     constexpr bool IN16 = IO & 1, OUT16 = IO & 2;
     static_assert(!PIPE || (KS == 3 && !SK && CK == 64), "PIPE: 3x3, 64-channel chunks");
@@ -126,7 +131,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     constexpr int TP = KS == 3 ? 9 : 4;            // taps per unrolled group: a chunk's 9 taps, or four 32-channel stages
     constexpr int R = KS == 3 ? 3 : 4;             // ring slots (TP % R == 0)
     constexpr int NSL = KS == 3 ? 9 : 1;           // slices a halo tile is fetched in
-    constexpr int NT = HaloCfg<BM, WAVES>::NT, MI = HaloCfg<BM, WAVES>::MI, NI = 2;
+    constexpr int NT = HaloCfg<BM, WAVES>::NT, MI = N64 ? HaloCfg<BM, WAVES>::MI / 2 : HaloCfg<BM, WAVES>::MI, NI = 2;
     constexpr int PITCH = CK + 8;                  // bf16 elements; 16-B aligned rows, conflict-free b128 reads
     constexpr int MAXHP = KS == 3 ? (PIPE ? HaloCfg<BM>::MAXHP3 : HaloCfg<BM>::MAXHP) : BM;
     constexpr int ASZ = (MAXHP + 1) * PITCH;       // one halo buffer (+1 dump row for the staging slots past the tile)
@@ -142,7 +147,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     int* pix = reinterpret_cast<int*>(Bs + WS * BN * PITCH); // [MAXHP] source pixel index of each halo pixel, -1 = zero
 
     const int t = threadIdx.x, l = t & 63, wv = t >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
+    const int wm = N64 ? wv : wv >> 1, wn = N64 ? 0 : wv & 1;
     // M tile of this workgroup.  Row tiles of one image share their halo rows and consecutive workgroup ids go to
     // different XCDs (separate L2s), so with xmap ids xcd + 8*slot, slot = tile_in_image + tiles_per_img*m, belong to
     // image xcd + 8*m: an image's tiles meet in one L2 and the halo rows come from HBM once.
@@ -707,6 +712,8 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
         if (t < 16) {                                                       // thread = (wn, slab k, sum / square)
             const int wn2 = t >> 3, k = (t >> 1) & 3, q = t & 1;
             float tot = 0.f;
+            if constexpr (N64) { if (wn2 == 0) for (int w2 = 0; w2 < WAVES; ++w2) tot += red[(w2 * 4 + k) * 2 + q]; }
+            else
             for (int w2 = 0; w2 < WAVES / 2; ++w2) tot += red[((w2 * 2 + wn2) * 4 + k) * 2 + q];
             const int col = n0 + wn2 * 64 + (k >> 1) * 32 + (k & 1) * 16;
             if (col < a.Nc && (size_t)m0 < (size_t)Mtot)
@@ -716,7 +723,7 @@ __global__ __launch_bounds__((HaloCfg<BM, WAVES>::NT)) void conv3x3_halo_kernel(
     MI_TS(4);
 }
 
-template <int BM, int CK, int KS = 3, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4), bool FUSE = false, bool PIPE = false>
+template <int BM, int CK, int KS = 3, bool SK = false, int IO = 0, int WAVES = (BM == 256 ? 8 : 4), bool FUSE = false, bool PIPE = false, bool N64 = false>
 void launch_halo(const HaloArgs& a_in, hipStream_t st) {
     constexpr int PITCH = CK + 8;
     constexpr int MAXHP = KS == 3 ? (PIPE ? HaloCfg<BM>::MAXHP3 : HaloCfg<BM>::MAXHP) : BM;
@@ -747,11 +754,11 @@ void launch_halo(const HaloArgs& a_in, hipStream_t st) {
     // pixel tile adjacent, so the input tile is read from HBM once instead of once per channel tile (level 0: 203 -> 137 MB)
     if (q_env && KS == 1 && !SK && a.ksplit == 1 && a.gy > 1 && a.gx % 8 == 0) { a.qmap = 1; grid = dim3(grid.x * grid.y, 1, 1); }
     static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE, PIPE, N64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE, PIPE>), grid, dim3(HaloCfg<BM, WAVES>::NT), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE, PIPE, N64>), grid, dim3(HaloCfg<BM, WAVES>::NT), lds, st, a);
 }
 
 // fp32 [tap][k][n] master weights -> bf16 Wd[tap][k][n] (same layout) and Wf[tap][n][k] (transposed per tap); entries with frag != 0
@@ -1070,8 +1077,12 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
         }
     }
     const bool wide64 = halo_wide64(d, BM);
+    static const int n64_on = (int)mi_knob("MI_HALO_N64", 1);
+    const bool n64 = n64_on && BM == 256 && CK == 64 && d->Nc <= 64;
 #define MI_HALO_GO(IOV) \
-    do { if (BM == 256) { if (CK == 64 && halo_pipe() && a.HP <= HaloCfg<256>::MAXHP3) launch_halo<256, 64, 3, false, IOV, 8, false, true>(a, st); \
+    do { if (BM == 256) { if (n64 && halo_pipe() && a.HP <= HaloCfg<256>::MAXHP3) launch_halo<256, 64, 3, false, IOV, 8, false, true, true>(a, st); \
+                          else if (n64) launch_halo<256, 64, 3, false, IOV, 8, false, false, true>(a, st); \
+                          else if (CK == 64 && halo_pipe() && a.HP <= HaloCfg<256>::MAXHP3) launch_halo<256, 64, 3, false, IOV, 8, false, true>(a, st); \
                           else if (CK == 64) launch_halo<256, 64, 3, false, IOV>(a, st); else launch_halo<256, 32, 3, false, IOV>(a, st); } \
          else if (BM == 128) launch_halo<128, 32, 3, false, IOV>(a, st); \
          else if (wide64) launch_halo<64, 64, 3, false, IOV>(a, st); \

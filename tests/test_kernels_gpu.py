@@ -309,7 +309,7 @@ def test_linear_via_igemm(K):
 
 
 @pytest.mark.parametrize("storage", ["fp32", "bf16"])
-@pytest.mark.parametrize("cfg", [(16, 32, 32, 128, 128), (8, 16, 16, 128, 256), (16, 8, 8, 256, 512), (3, 32, 32, 64, 160)])
+@pytest.mark.parametrize("cfg", [(16, 32, 32, 128, 128), (8, 16, 16, 128, 256), (16, 8, 8, 256, 512), (3, 32, 32, 64, 160), (8, 64, 64, 64, 64)])
 def test_conv_epilogue_groupnorm_sums(K, cfg, storage):
     """mi_conv3x3_bf16w_io_gnsums + mi_gn_coef_from_sums: the next GroupNorm's statistics and coefficients from the conv's epilogue
     equal what mi_gn_stats_coef computes with a pass over the stored tensor (fp32 summation order aside), and the conv's output is
@@ -1098,6 +1098,8 @@ def test_conv3x3_pw_fwd_and_dgrad(K, cfg, out16, pw_always, pw_tile):
     dict(N=4, H=4, Ci=32, Co=32),                # CK=32 path, 4 images per tile
     dict(N=40, H=32, Ci=64, Co=128),             # many tiles
     dict(N=1, H=64, Ci=64, Co=64),               # cfg-3 level 0: 2 rows x 64 cols
+    dict(N=8, H=64, Ci=64, Co=64),               # ... 256-pixel tiles, all eight waves along M over the one 64-channel column (N64)
+    dict(N=8, H=64, Ci=128, Co=64, split=64),    # ... the up path's skip concat into 64 channels; its data gradient has 128 outputs
 ])
 def test_conv3x3_halo_fwd_and_dgrad(K, cfg):
     """Block's 3x3 conv (ddpm.py:116) and its data gradient through the LDS halo-tile kernel."""
