@@ -441,7 +441,7 @@ bool cin_tiled_geom(int ks, int H, int W, int ldx, const void* x) {
 // for this layer (the whole-row-tile kernels take it)
 extern "C" int mi_conv_small_cin_bf16_supported(int ks, int N, int H, int W, int Cin, int Cout, int ldx) {
     static const int tiled = (int)mi_knob("MI_SMALL_CIN_TILED", 1);
-    return (tiled && N > 0 && Cin >= 1 && Cin <= 4 && (Cout == 128 || Cout == 256) && ((long)N * H * W) % 64 == 0 && cin_tiled_geom(ks, H, W, ldx, nullptr) &&
+    return (tiled && N > 0 && Cin >= 1 && Cin <= 4 && (Cout == 64 || Cout == 128 || Cout == 256) && ((long)N * H * W) % 64 == 0 && cin_tiled_geom(ks, H, W, ldx, nullptr) &&
             (size_t)3 * 9 * Cin * (Cout / 4) * 16 <= 48 * 1024) ? 1 : 0;
 }
 
@@ -505,7 +505,7 @@ extern "C" int mi_conv_small_cin_wgrad_io(int ks, int N, int H, int W, int Cin, 
     {   // 3x3 on whole-row tiles of 64 pixels with the taps in LDS (small_cin3x3_wgrad_tiled_kernel); same partial-tile contract
         static const int tiled = (int)mi_knob("MI_SMALL_CIN_TILED", 1);
         const int rows = w_sh >= 0 && W <= 64 ? 64 / W : 0;
-        if (tiled && cin_tiled_geom(ks, H, W, ldx, x) && Cout >= 128 && ((long)N * H * W) % 64 == 0) {
+        if (tiled && cin_tiled_geom(ks, H, W, ldx, x) && (Cout >= 128 || dy_bf16) && ((long)N * H * W) % 64 == 0) {     // (fp32 dy at 64 channels: the untiled kernel, as measured in round 2)
             const int ntiles = N * H * W / 64;
             const size_t lds2 = lds + (size_t)2 * (rows + 2) * (W + 2) * 16;
 #define MI_TILED(CIN) do { \

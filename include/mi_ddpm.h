@@ -247,7 +247,7 @@ size_t mi_conv_small_wgrad_workspace(int outputs);
 /* Round 4: the wide (Cout-channel) tensor stored as bf16, like every other block-internal tensor of bf16 mode (the reference keeps
  * c1 = conv(x) and its gradient in fp32, ddpm.py:116-120; x, w, dW stay fp32, the arithmetic is the same fp32 FMA chain, the output
  * is rounded once / dy is widened on load).  y_bf16 / dy_bf16 = 1 needs the whole-row-tile kernels: ks = 3, W a power of two <= 64,
- * H*W a power of two, ldx == 4, 16-byte aligned x, Cout in {128, 256} -- mi_conv_small_cin_bf16_supported answers for both. */
+ * H*W a power of two, ldx == 4, 16-byte aligned x, Cout in {64, 128} (256: forward only) -- mi_conv_small_cin_bf16_supported answers for both. */
 int mi_conv_small_cin_bf16_supported(int ks, int N, int H, int W, int Cin, int Cout, int ldx);
 int mi_conv_small_cin_fwd_io(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w,
                              const float* bias, void* y, int ldy, int y_bf16, void* stream);

@@ -1568,7 +1568,7 @@ def test_small_channel_ends(K, cfg):
     assert rel_err(from_nhwc(dh), 2 * h.grad) < 1e-5
 
 
-@pytest.mark.parametrize("N,H,C", [(8, 16, 128), (2, 32, 128), (4, 8, 256)])
+@pytest.mark.parametrize("N,H,C", [(8, 16, 128), (2, 32, 128), (4, 8, 256), (2, 64, 64)])
 def test_small_channel_ends_bf16_wide_tensor(K, N, H, C):
     """Round 4: the wide tensor at the 3-channel ends stored as bf16.  Same fp32 arithmetic as the fp32-stored kernels: a bf16 output is
     the fp32 kernel's output rounded once (bitwise), a bf16 input gives exactly what its widened fp32 copy gives."""
@@ -1588,7 +1588,10 @@ def test_small_channel_ends_bf16_wide_tensor(K, N, H, C):
     dWa, dWb = torch.zeros(27 * C, device=DEV), torch.zeros(27 * C, device=DEV)
     K.conv_small_cin_wgrad(x, dy16, dWa, 3)
     K.conv_small_cin_wgrad(x, dy16.float(), dWb, 3)
-    assert torch.equal(dWa, dWb)
+    if C >= 128:
+        assert torch.equal(dWa, dWb)
+    else:                                                         # (64 channels: fp32 dy takes the untiled kernel -- another summation order)
+        assert rel_err(dWa, dWb) < 2e-6
     # final conv: x (op 0 / 2) and dx (op 1) as bf16
     h16 = to_nhwc_gpu(torch.randn(N, C, H, H, generator=g)).to(BF)
     wf = torch.randn(C * 3, generator=g).to(DEV) * 0.1
