@@ -26,6 +26,30 @@
 // without the activation DMA -16 %, without the output stores -7..12 %; the same time with one and with two waves per SIMD.
 #include "tr_common.h"
 
+#ifndef MI_PW_PABL
+#define MI_PW_PABL 0     // profiling builds: 1 no fragment requests in the pinned loop, 2 no piece requests, 4 no step-opening wait, 8 no shifts, 16 no barrier
+#endif
+#ifndef MI_PW_WSTR
+#define MI_PW_WSTR 2
+#endif
+#ifndef MI_PW_PIPE
+#define MI_PW_PIPE 1      // 0: round 3 / 4's compiler-scheduled main loop for the plain conv too (A/B builds)
+#endif
+#ifdef MI_PW_TIMING
+// profiling build only (-DMI_PW_TIMING, tools/pw_timeline.py): shader-clock stamps (s_memtime) at every row unit of conv_pw_kernel's main
+// loop, kept in registers (v_writelane: slot p holds the time of point p - 1) and written once at the end: [workgroup][wave][5][64]
+// words -- sets 0..3 = step ks, lane = chunk * (BH + 1) + unit; set 4: 0 last point, 1 loop end, 2 kernel end, 3 kernel entry, 4 loop
+// entry, 5 HW_ID, 6 XCC_ID, 7 / 8 the 100 MHz wall clock at entry / end.
+__device__ uint32_t g_pw_ts[1024 * 4 * 5 * 64];
+__device__ __forceinline__ uint32_t pw_wlane(uint32_t val, uint32_t lane, uint32_t v) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                 : "+v"(v), "=&s"(keep) : "s"(__builtin_amdgcn_readfirstlane(val)), "s"(__builtin_amdgcn_readfirstlane(lane)));
+    return v;
+}
+extern "C" int mi_debug_pw_ts(uint32_t* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pw_ts), sizeof(g_pw_ts)); }
+#endif
+
 namespace {
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -37,6 +61,10 @@ struct PwArgs {
     int N, H, W, K, Nc, K1, ldx, ldx2, ldy, ldr, accumulate, flip;
     int TH, TI, XP, tiles_per_img, xmap;
     int qmap, gx, gy;    // 1-D launch of gx pixel tiles x gy channel tiles: XCD = (pixel group, channel group) of a (8 / qmap) x qmap split
+    // round 5: the prologue's integer divisions as multiplications (q = umulhi(x, magic), magic = ceil(2^32 / d), 0 for d = 1; exact for
+    // x * d < 2^32) and the zero page's address as an argument -- 3 600 cycles passed between a wave's entry and its first request
+    uint32_t tpi_magic, cpq_magic; int ppx, cpq, lnsub;
+    const void* zero;
     float* gsum;         // VAR 1: [N][Nc / 16][2] sum / sum of squares of the stored values per sample and 16-channel slab (+=)
     const float* coef;   // VAR 2: [3][N][K] scale, shift, time bias of the GroupNorm + Mish applied to x while it is staged
     // VAR 3: the same coefficients resolved in the kernel from the sums the producing conv's epilogue left (gsum layout), the affine
@@ -48,7 +76,10 @@ struct PwArgs {
 
 // PT = output pixels per workgroup: 128 (four 32-pixel MFMA blocks per wave) or, for the layers whose 128-pixel tiles would leave
 // CUs without a workgroup, 64 (two blocks: a fragment feeds two MFMAs instead of four, but the grid is twice as large)
-constexpr int pw_xp(int pt) { return pt == 128 ? 192 : 128; }      // tile pixels incl. the rows above and below: 6 x 32, 10 x 16, 2 images x 10 x 8 | 4 x 32, 6 x 16, 10 x 8
+constexpr int pw_xp(int pt) { return pt == 256 ? 320 : pt == 128 ? 192 : 128; }      // tile pixels incl. the rows above and below: 10 x 32, 18 x 16 | 6 x 32, 10 x 16, 2 images x 10 x 8 | 4 x 32, 6 x 16, 10 x 8
+
+__device__ __forceinline__ int pw_fastdiv(int x, uint32_t magic) { return magic ? (int)__umulhi((uint32_t)x, magic) : x; }
+inline uint32_t pw_magic(int d) { return d > 1 ? (uint32_t)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d) : 0u; }
 
 // LDS-DMA with a scalar base: 16 bytes per lane from sbase + voff to LDS byte address lds_dst (wave-uniform) + 16 * lane
 __device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
@@ -98,7 +129,7 @@ template <int DIR> __device__ __forceinline__ bf16x8 pw_shift(const bf16x8& c, u
     return __builtin_bit_cast(bf16x8, o);
 }
 
-constexpr int pw_lds(int pt, bool raw = false) { return (pt == 128 ? (raw ? 72 : 64) : (raw ? 48 : 32)) * 1024 + 2048; }   // two activation buffers (24 / 16 KB each) under the epilogue's fp32 tile (+ the GroupNorm sums' 512 bytes); raw: + the fp32 staging area of the fp32-input variants (24 / 16 KB behind the tiles)
+constexpr int pw_lds(int pt, bool raw = false) { return (pt == 256 ? 128 : pt == 128 ? (raw ? 72 : 64) : (raw ? 48 : 32)) * 1024 + 2048; }   // two activation buffers (24 / 16 KB each) under the epilogue's fp32 tile (+ the GroupNorm sums' 512 bytes); raw: + the fp32 staging area of the fp32-input variants (24 / 16 KB behind the tiles)
 
 // VAR 0: the plain conv.  VAR 1: the epilogue also accumulates the GroupNorm sums of the NEXT layer (a.gsum).  VAR 2 / 3: the named
 // fused kernel (2: coefficients given, 3: resolved here from the producer's sums) -- x is the RAW output of the previous conv and mish(x * scale[n][c] + shift[n][c]) + tb[n][c] (a.coef; GroupNorm-apply
@@ -121,8 +152,24 @@ constexpr int pw_lds(int pt, bool raw = false) { return (pt == 128 ? (raw ? 72 :
 // (k = 2 each: lane half h supplies channel 4h + j of the octet in step j).  Per 16 bytes loaded the fp32 MFMA runs 8x longer than
 // the bf16 one, so this variant is bound by the matrix pipe, not by the issue of loads.
 template <bool OUT16, int VAR = 0, int ABL = 0, int PT = 128, bool IN32 = false, bool F32 = false>
-__global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
+__global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const PwArgs a) {
     MI_PRIO_UP();
+#ifdef MI_PW_TIMING
+    constexpr bool TIMED = VAR == 0 && ABL == 0 && !IN32 && !F32;
+    uint32_t tv[5] = {0u, 0u, 0u, 0u, 0u};
+    uint64_t tprev = 0;
+    if constexpr (TIMED) {
+        tprev = __builtin_amdgcn_s_memtime();
+        tv[4] = pw_wlane((uint32_t)wall_clock64(), 7, tv[4]);
+        tv[4] = pw_wlane((uint32_t)tprev, 3, tv[4]);
+    }
+#define MI_PW_STAMP(SET, LANE) do { if constexpr (TIMED) { tv[SET] = pw_wlane((uint32_t)tprev, (LANE), tv[SET]); tprev = __builtin_amdgcn_s_memtime(); } } while (0)
+#define MI_PW_NOW(LANE) do { if constexpr (TIMED) { tv[4] = pw_wlane((uint32_t)__builtin_amdgcn_s_memtime(), (LANE), tv[4]); } } while (0)
+#else
+#define MI_PW_STAMP(SET, LANE) do {} while (0)
+#define MI_PW_NOW(LANE) do {} while (0)
+#endif
+    static_assert(PT != 256 || (VAR < 2 && !IN32 && !F32), "256-pixel tiles: the plain bf16 conv (with or without the GroupNorm sums)");
     constexpr bool FUSE = VAR >= 2, GNS = VAR == 1;
     static_assert(!IN32 || ABL == 0, "fp32 input: no ablation builds");
     static_assert(!F32 || (VAR == 0 && ABL == 0 && !IN32 && !OUT16), "exact-fp32 mode: the plain conv, fp32 in and out");
@@ -137,14 +184,13 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     int bx = blockIdx.x;
     if (a.xmap) {        // an image's row tiles share rows: keep them on one XCD (ids xcd + 8*slot -> image xcd + 8*m)
-        const int xcd = bx & 7, slot = bx >> 3;
-        bx = (xcd + 8 * (slot / a.tiles_per_img)) * a.tiles_per_img + slot % a.tiles_per_img;
+        const int xcd = bx & 7, slot = bx >> 3, q = pw_fastdiv(slot, a.tpi_magic);
+        bx = (xcd + 8 * q) * a.tiles_per_img + (slot - q * a.tiles_per_img);
     }
     int by = blockIdx.y;
-    if (a.qmap) {        // XCD = (pixel group, channel group): an XCD's L2 holds gy / Q of the weight tiles
-        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3, Q = a.qmap, P = 8 / Q;
-        const int ppx = a.gx / P, cpq = a.gy / Q;
-        bx = (xcd / Q) * ppx + slot / cpq; by = (xcd % Q) * cpq + slot % cpq;
+    if (a.qmap) {        // XCD = (pixel group, channel group) of a 4 x 2 split: an XCD's L2 holds half of the weight tiles
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3, q = pw_fastdiv(slot, a.cpq_magic);
+        bx = (xcd >> 1) * a.ppx + q; by = (xcd & 1) * a.cpq + (slot - q * a.cpq);
     }
     const int m0 = bx * PT, n0 = by * 128;
     const int TH2 = a.TH + 2;
@@ -153,6 +199,52 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     const int NB = a.Nc >> 5, KQ = a.K / (2 * EPP);              // fragments per (tap, 32-channel block): one per step
     const bool live = n0 + 32 * wv < a.Nc;                    // a ragged last channel tile: the wave computes a copy of the last block
     const int nb = min((n0 >> 5) + wv, NB - 1);
+
+    // ---- weight stream of this wave: fragment (tap, nb, kq) = 1 KB at ((tap * NB + nb) * KQ + kq) * 1024 bytes.  The fragments are
+    //      wave-private, so they never touch LDS: each lane loads ITS 16 bytes of a fragment straight into the registers the MFMA
+    //      reads (global_load_dwordx4 with a scalar base per tap, issued from asm and counted by hand like the DMA).  The nine
+    //      fragments of a 16-channel step are loaded during the step before (two register sets).
+    const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(a.w) + (size_t)nb * KQ * 1024;
+    const uint32_t tap_bytes = (uint32_t)a.Nc * a.K * ESZ;
+    const uint32_t wl16 = l * 16;
+    uint64_t wtap[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        const uint64_t q = (uint64_t)(uintptr_t)(wsrc + (size_t)(a.flip ? 8 - tp : tp) * tap_bytes);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
+        wtap[tp] = ((uint64_t)hi << 32) | lo;
+    }
+    u32x4 WB[2][9];
+    // part `part` of NPART of the nine taps of step (ch, ks) (ks == 4: step 0 of chunk ch + 1; past the end: a re-fetch) -> set ks & 1.
+    // Every part is requested BEFORE the chunk boundary's wait (the last row unit requests none): no register-destination load is
+    // ever in flight across the loop's back edge or its exit, where hipcc may copy or reuse the destination registers.
+    constexpr int NPART = BH >= 3 ? 3 : 2;
+    auto load_w3 = [&](int ch, auto ksc, auto partc) {
+        constexpr int ks0 = decltype(ksc)::value, over = ks0 >= 4 ? 1 : 0, ks = ks0 - 4 * over, part = decltype(partc)::value;
+        constexpr int t0 = (9 * part + NPART - 1) / NPART, t1 = (9 * (part + 1) + NPART - 1) / NPART;
+        const uint32_t voff = wl16 + (uint32_t)min(ch + over, nchunks - 1) * 4096;
+        static_for<t0, t1>([&](auto tc) {
+            constexpr int tp = decltype(tc)::value;
+            gload16s<ks * 1024>(WB[ks & 1][tp], wtap[tp], voff);
+        });
+    };
+
+    // one tap of step (ch, ks) (round 5's pinned schedule: one request per MFMA gap)
+    auto load_w1 = [&](int ch, auto ksc, auto tapc) {
+        constexpr int ks0 = decltype(ksc)::value, over = ks0 >= 4 ? 1 : 0, ks = ks0 - 4 * over, tp = decltype(tapc)::value;
+        const uint32_t voff = wl16 + (uint32_t)min(ch + over, nchunks - 1) * 4096;
+        gload16s<ks * 1024>(WB[ks & 1][tp], wtap[tp], voff);
+    };
+
+    // (round 5: the plain conv requests its first step's fragments before anything else is computed -- they depend on the tile's
+    //  channel block only; the fused / fp32-input variants count their coefficient and row requests first and keep the old order)
+    constexpr bool EARLYW = VAR < 2 && !IN32;
+    if constexpr (EARLYW) {
+        MI_PW_NOW(10);
+        static_for<0, NPART>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
 
     // ---- activation DMA pieces: piece p = wv + 4i covers tile pixels 8p .. 8p+7 (tile pixel hp = (image ti, row hy = y+1, column x));
     //      lane -> pixel lane >> 3, stored 16-byte position lane & 7 holds channel chunk (lane & 7) ^ swz(hp), swz = (hp >> 1) & 7
@@ -170,21 +262,18 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     {
         int y0;
         if (a.TI > 1) { img0 = bx * a.TI; y0 = 0; }
-        else { img0 = bx / a.tiles_per_img; y0 = (bx % a.tiles_per_img) * a.TH; }
+        else { img0 = pw_fastdiv(bx, a.tpi_magic); y0 = (bx - img0 * a.tiles_per_img) * a.TH; }
 #pragma unroll
-        for (int i = 0; i < PXPW; ++i) {
+        for (int i = 0; i < PXPW; ++i) {                     // (branch-free: bit operations on the conditions)
             const int hp = 8 * (wv + 4 * i) + (l >> 3);
-            int v = -1;
-            if (hp < a.XP) {
-                const int row = hp >> lw, x = hp & (a.W - 1);
-                const int ti = row >= TH2 ? 1 : 0, hy = row - ti * TH2;              // at most two images per tile
-                const int iy = y0 + hy - 1, img = img0 + ti;
-                if (iy >= 0 && iy < a.H && img < a.N) v = (img * a.H + iy) * a.W + x;
-            }
-            xpix[i] = v;
+            const int row = hp >> lw, x = hp & (a.W - 1);
+            const int ti = row >= TH2 ? 1 : 0, hy = row - ti * TH2;                  // at most two images per tile
+            const int iy = y0 + hy - 1, img = img0 + ti;
+            const bool ok = (hp < a.XP) & (iy >= 0) & (iy < a.H) & (img < a.N);
+            xpix[i] = ok ? (img * a.H + iy) * a.W + x : -1;
         }
     }
-    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page3);
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(a.zero);
     auto stage_x = [&](int ch, int i) {                      // piece i of this wave of chunk ch's rows -> buffer ch & 1
         const int cc0 = min(ch, nchunks - 1) * PCK;
         const bool second = cc0 >= a.K1;
@@ -198,6 +287,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         const uint8_t* p = xp >= 0 ? reinterpret_cast<const uint8_t*>(src) + off * ESZ : reinterpret_cast<const uint8_t*>(zero) + (l & 7) * 16;
         glds16(p, lds0 + (ch & 1) * PXBUF + (wv + 4 * i) * 1024);
     };
+    if constexpr (EARLYW) {                                  // the first chunk's rows: on their way before the rest of the set-up
+#pragma unroll
+        for (int i = 0; i < PXPW; ++i) stage_x(0, i);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // fp32 input: piece i of chunk ch -> the two registers of `dst` (8 channels of this lane's pixel), asynchronous
     auto load_x32 = [&](int ch, int i, u32x4* dst) {
         const int cc0 = min(ch, nchunks - 1) * PCK;
@@ -208,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         asm volatile("" : "+v"(xp));
         size_t off = (size_t)max(xp, 0) * ld + cc + xcol;
         asm volatile("" : "+v"(off));
-        const float* pf = xp >= 0 ? src + off : reinterpret_cast<const float*>(g_zero_page3) + (l & 7) * 8;
+        const float* pf = xp >= 0 ? src + off : reinterpret_cast<const float*>(a.zero) + (l & 7) * 8;
         asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
                      : "=&v"(dst[0]), "=&v"(dst[1]) : "v"(pf) : "memory");
     };
@@ -264,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             p1 = p0 + pl; p2 = p0 + 2 * pl;
         } else {             // gamma, beta, the time-bias row (the zero page when there is none)
             p0 = a.gamma + c; p1 = a.beta + c;
-            p2 = a.temb ? a.temb + (size_t)img0 * a.ldt + c : reinterpret_cast<const float*>(g_zero_page3);
+            p2 = a.temb ? a.temb + (size_t)img0 * a.ldt + c : reinterpret_cast<const float*>(a.zero);
         }
         asm volatile("global_load_dwordx4 %0, %6, off\n\tglobal_load_dwordx4 %1, %6, off offset:16\n\t"
                      "global_load_dwordx4 %2, %7, off\n\tglobal_load_dwordx4 %3, %7, off offset:16\n\t"
@@ -354,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         asm volatile("" : "+v"(xp));
         size_t off = (size_t)max(xp, 0) * ld + cc + xcol;
         asm volatile("" : "+v"(off));
-        const float* pf = xp >= 0 ? src + off : reinterpret_cast<const float*>(g_zero_page3) + (l & 7) * 8;
+        const float* pf = xp >= 0 ? src + off : reinterpret_cast<const float*>(a.zero) + (l & 7) * 8;
         glds16(pf, lds0 + RAW0 + (wv * RHP + slot) * 2048);
         glds16(pf + 4, lds0 + RAW0 + (wv * RHP + slot) * 2048 + 1024);
     };
@@ -380,35 +474,6 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         }
     };
 
-    // ---- weight stream of this wave: fragment (tap, nb, kq) = 1 KB at ((tap * NB + nb) * KQ + kq) * 1024 bytes.  The fragments are
-    //      wave-private, so they never touch LDS: each lane loads ITS 16 bytes of a fragment straight into the registers the MFMA
-    //      reads (global_load_dwordx4 with a scalar base per tap, issued from asm and counted by hand like the DMA).  The nine
-    //      fragments of a 16-channel step are loaded during the step before (two register sets).
-    const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(a.w) + (size_t)nb * KQ * 1024;
-    const uint32_t tap_bytes = (uint32_t)a.Nc * a.K * ESZ;
-    const uint32_t wl16 = l * 16;
-    uint64_t wtap[9];
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-        const uint64_t q = (uint64_t)(uintptr_t)(wsrc + (size_t)(a.flip ? 8 - tp : tp) * tap_bytes);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
-        wtap[tp] = ((uint64_t)hi << 32) | lo;
-    }
-    u32x4 WB[2][9];
-    // part `part` of NPART of the nine taps of step (ch, ks) (ks == 4: step 0 of chunk ch + 1; past the end: a re-fetch) -> set ks & 1.
-    // Every part is requested BEFORE the chunk boundary's wait (the last row unit requests none): no register-destination load is
-    // ever in flight across the loop's back edge or its exit, where hipcc may copy or reuse the destination registers.
-    constexpr int NPART = BH >= 3 ? 3 : 2;
-    auto load_w3 = [&](int ch, auto ksc, auto partc) {
-        constexpr int ks0 = decltype(ksc)::value, over = ks0 >= 4 ? 1 : 0, ks = ks0 - 4 * over, part = decltype(partc)::value;
-        constexpr int t0 = (9 * part + NPART - 1) / NPART, t1 = (9 * (part + 1) + NPART - 1) / NPART;
-        const uint32_t voff = wl16 + (uint32_t)min(ch + over, nchunks - 1) * 4096;
-        static_for<t0, t1>([&](auto tc) {
-            constexpr int tp = decltype(tc)::value;
-            gload16s<ks * 1024>(WB[ks & 1][tp], wtap[tp], voff);
-        });
-    };
-
     // ---- fragment addressing.  A 32-pixel MFMA block = output row i (0..3) of every 4-row band of the tile: lane q = l & 31 ->
     //      column x = q % W of band (q / W) % (TH / 4) of image q / W / (TH / 4) (W = 32: one row of one image; 16: rows i, i + 4;
     //      8: rows i, i + 4 of two images).  With that, the block of tap row ky of output row i is "halo row r = i + ky of every
@@ -418,8 +483,8 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     uint32_t xr[BH + 2];                                     // byte address of X_r, 16-channel step 0, buffer 0
     int ep_p0;                                               // epilogue: tile pixel of (output row 0, this lane)
     {
-        const int q = l & 31, x = q & (a.W - 1), rest = q >> lw, nsub = a.TH / BH;
-        const int sub = rest & (nsub - 1), ti = rest / nsub;
+        const int q = l & 31, x = q & (a.W - 1), rest = q >> lw, nsub = 1 << a.lnsub;            // nsub = TH / BH
+        const int sub = rest & (nsub - 1), ti = rest >> a.lnsub;
 #pragma unroll
         for (int r = 0; r < BH + 2; ++r) {
             const int hp = (ti * TH2 + r + BH * sub) * a.W + x;
@@ -449,6 +514,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         }
     }
     // ---- prologue: the first chunk's rows, the first step's fragments
+    if constexpr (!EARLYW) MI_PW_NOW(10);
     if constexpr (VAR == 3) load_stats();
     if constexpr (FUSE) load_coef(0);
     if constexpr (IN32) {
@@ -476,9 +542,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             for (int i = 0; i < PXPW; ++i) store_x32(0, i, pr[i]);
         }
     } else {
+        if constexpr (!EARLYW) {
 #pragma unroll
-        for (int i = 0; i < PXPW; ++i) stage_x(0, i);
-        static_for<0, NPART>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
+            for (int i = 0; i < PXPW; ++i) stage_x(0, i);
+            static_for<0, NPART>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
+        }
     }
     // bf16 input, fused: this wave's six pieces of a chunk, rewritten in place in LDS in ONE go -- three pieces (twelve independent
     // exp -> rcp chains per lane) in flight at a time.  Round 4: the main loop does this at the chunk boundary instead of spreading
@@ -513,8 +581,117 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     }
     // the rows and the fragments have landed (this wave's; the fused variant's rewritten pieces are in LDS) ...
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    MI_PW_NOW(11);
     __builtin_amdgcn_s_barrier();                                          // ... every wave's
     asm volatile("" ::: "memory");
+    MI_PW_NOW(12);
+    // ---- round 5: the PINNED schedule of the plain bf16 conv (VAR 0 / 1).  The unit timeline of the loop below (tools/pw_timeline.py,
+    //      one wave per SIMD, 512 -> 512 @8x8) read 6 450 cycles per chunk against 4 608 of MFMAs: hipcc sinks each LDS read next to its
+    //      first use and clusters the three fragment requests of a unit between two MFMAs (every unit +50..150 cycles), and the chunk
+    //      boundary's vmcnt(0) waited out the fragment requests issued one unit earlier (+600).  Here every MFMA is followed by at most
+    //      one side operation and a sched_barrier, as a software pipeline over the row units:
+    //        unit u issues its MFMAs from fragments that are complete in registers (centre, left, right), reads the centre fragment
+    //        of unit u + 2 (first gap) and shifts unit u + 1's (gaps 1, 2; the last unit of a step prepares the next step's unit 0);
+    //        the next step's nine fragment requests go out one per gap (every other gap from four blocks per wave up) from the start
+    //        of the step, the next chunk's activation pieces behind them in steps 0 and 1 only -- so step 3's opening wait covers them
+    //        and the barrier (before unit BH - 1 of step 3, the first to read the other buffer) needs no vmcnt at all; the fragments
+    //        of the next chunk's first step are waited for at the very end of step 3, >= 18 gaps after their request.
+    constexpr bool PIPE = (MI_PW_PIPE != 0) && VAR < 2 && !IN32 && !F32 && ABL == 0;
+    if constexpr (PIPE) {
+        constexpr int CN = (BH % 3 == 1) ? 4 : 3;            // centre fragment registers in rotation (unit u: C[u % CN])
+        constexpr int WSTR = BH >= 4 ? MI_PW_WSTR : 1;        // a fragment request every WSTR gaps
+        constexpr int PG0 = 9 * WSTR;                         // first gap with an activation piece request
+        constexpr int PPS = (PXPW + 1) / 2;                   // pieces requested per step (steps 0 and 1)
+        bf16x8 Ac, Bc, Al, Bl, Ar, Br, C[CN], L[2], R[2];
+        Ac = lds_b128p(xr[0]); Bc = lds_b128p(xr[BH + 1]); C[1 % CN] = lds_b128p(xr[1]);
+        Al = pw_shift<0>(Ac, mask_l); Bl = pw_shift<0>(Bc, mask_l); Ar = pw_shift<1>(Ac, mask_r); Br = pw_shift<1>(Bc, mask_r);
+        __builtin_amdgcn_sched_barrier(0);
+        MI_PW_STAMP(4, 3);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const uint32_t xcur = (ch & 1) * PXBUF, xnxt = PXBUF - xcur;
+            static_for<0, 4>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value, cur = ks & 1;
+                constexpr uint32_t kx32 = ks * 32, kxn = ((ks + 1) & 3) * 32;
+                const uint32_t bufn = ks == 3 ? xnxt : xcur;                      // where the next step's rows are
+                constexpr int prevp = (ks == 1 || ks == 2) ? ((PXPW - PPS * (ks - 1)) < PPS ? (PXPW - PPS * (ks - 1)) : PPS) : 0;
+                if constexpr (ks > 0 && !(MI_PW_PABL & 4)) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(prevp) : "memory");
+                static_for<0, 9>([&](auto tc) { landed16(WB[cur][decltype(tc)::value]); });
+                auto mm = [&](auto ic, auto tapc, const bf16x8& xf) {
+                    constexpr int i = decltype(ic)::value, tp = decltype(tapc)::value;
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WB[cur][tp]), xf, acc[i], 0, 0, 0);
+                };
+                auto pw_shift0 = [&](const bf16x8& c, uint32_t m) { if constexpr (MI_PW_PABL & 8) return c; else return pw_shift<0>(c, m); };
+                auto pw_shift1 = [&](const bf16x8& c, uint32_t m) { if constexpr (MI_PW_PABL & 8) return c; else return pw_shift<1>(c, m); };
+                // what rides in gap g of the step besides the unit's own preparation: fragment requests, then piece requests
+                auto gside = [&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    if constexpr (g % WSTR == 0 && g / WSTR < 9 && !(MI_PW_PABL & 1)) load_w1(ch, std::integral_constant<int, ks + 1>{}, std::integral_constant<int, g / WSTR>{});
+                    if constexpr (!(MI_PW_PABL & 2) && ks < 2 && g >= PG0 && (g - PG0) % 2 == 0 && (g - PG0) / 2 < PPS && PPS * ks + (g - PG0) / 2 < PXPW)
+                        stage_x(ch + 1, PPS * ks + (g - PG0) / 2);
+                };
+                // ---- unit 0: rows 0 (output row 0, tap row 0) and BH + 1 (output row BH - 1, tap row 2)
+                {
+                    MI_PW_STAMP(ks, ch * (BH + 1));
+#define MI_G(J, I, KY, KX, XF, SIDE) do { mm(std::integral_constant<int, I>{}, std::integral_constant<int, (KY) * 3 + (KX)>{}, XF); SIDE; \
+                                          gside(std::integral_constant<int, (J)>{}); __builtin_amdgcn_sched_barrier(0); } while (0)
+                    MI_G(0, 0, 0, 1, Ac, C[2 % CN] = lds_b128p((xr[2] ^ kx32) + xcur));
+                    MI_G(1, BH - 1, 2, 1, Bc, L[1] = pw_shift0(C[1 % CN], mask_l));
+                    MI_G(2, 0, 0, 0, Al, R[1] = pw_shift1(C[1 % CN], mask_r));
+                    MI_G(3, BH - 1, 2, 0, Bl, (void)0);
+                    MI_G(4, 0, 0, 2, Ar, (void)0);
+                    MI_G(5, BH - 1, 2, 2, Br, (void)0);
+#undef MI_G
+                }
+                // ---- units 1 .. BH: row u feeds output rows u - ky (tap row ky)
+                static_for<1, BH + 1>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    constexpr int ky0 = u == BH ? 1 : 0, ky1 = u == 1 ? 1 : 2, n = ky1 - ky0 + 1;      // valid tap rows ky0 .. ky1
+                    constexpr int g0 = u == 1 ? 6 : 12 + 9 * (u - 2);                               // the unit's first gap of the step
+                    MI_PW_STAMP(ks, ch * (BH + 1) + u);
+                    if constexpr (ks == 3 && u == BH - 1) {
+                        // chunk boundary: every wave has read what it needs of this chunk's rows (the last read, row BH, was issued
+                        // >= 6 gaps ago) and its pieces of the next chunk landed before step 3 began
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if constexpr (!(MI_PW_PABL & 16)) __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    }
+                    static_for<0, 3 * n>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value, kxi = j / n, ky = ky0 + j % n, kx = kxi == 0 ? 1 : kxi == 1 ? 0 : 2;
+                        const bf16x8& xf = kx == 1 ? C[u % CN] : kx == 0 ? L[u & 1] : R[u & 1];
+                        mm(std::integral_constant<int, u - ky>{}, std::integral_constant<int, ky * 3 + kx>{}, xf);
+                        if constexpr (j == 0) {
+                            if constexpr (u + 2 <= BH) C[(u + 2) % CN] = lds_b128p((xr[u + 2 <= BH ? u + 2 : 0] ^ kx32) + xcur);
+                            else if constexpr (u == BH - 1) { Ac = lds_b128p((xr[0] ^ kxn) + bufn); Bc = lds_b128p((xr[BH + 1] ^ kxn) + bufn); }
+                            else C[1 % CN] = lds_b128p((xr[1] ^ kxn) + bufn);
+                        }
+                        // (the next step's unit 0 needs four shifts: from three blocks per wave up, two of them ride in the spare gaps
+                        //  of unit BH - 1 -- its rows were read in that unit's first gap -- so that the last unit, six MFMAs, carries three
+                        //  side operations like every other unit)
+                        constexpr bool SPLIT0 = BH >= 3;
+                        if constexpr (j == 1) {
+                            if constexpr (u < BH) L[(u + 1) & 1] = pw_shift0(C[(u + 1) % CN], mask_l);
+                            else if constexpr (SPLIT0) Ar = pw_shift1(Ac, mask_r);
+                            else Al = pw_shift0(Ac, mask_l);
+                        }
+                        if constexpr (j == 2) {
+                            if constexpr (u < BH) R[(u + 1) & 1] = pw_shift1(C[(u + 1) % CN], mask_r);
+                            else if constexpr (SPLIT0) Br = pw_shift1(Bc, mask_r);
+                            else Bl = pw_shift0(Bc, mask_l);
+                        }
+                        if constexpr (SPLIT0 && u == BH - 1 && j == 5) Al = pw_shift0(Ac, mask_l);
+                        if constexpr (SPLIT0 && u == BH - 1 && j == 6) Bl = pw_shift0(Bc, mask_l);
+                        if constexpr (!SPLIT0 && j == 3 && u == BH) Ar = pw_shift1(Ac, mask_r);
+                        if constexpr (!SPLIT0 && j == 4 && u == BH) Br = pw_shift1(Bc, mask_r);
+                        gside(std::integral_constant<int, g0 + j>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+                // the fragments of the next chunk's first step: no register-destination load crosses the loop's back edge (sixth rule)
+                if constexpr (ks == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            });
+        }
+        asm volatile("" :: "v"(Ac), "v"(Bc), "v"(Al), "v"(Bl), "v"(Ar), "v"(Br));
+    } else {
     XA = lds_b128p(xr[0]); XB = lds_b128p(xr[BH + 1]);
 
     // One chunk = four 16-channel steps of BH + 1 row units (rows {0, BH + 1}, then 1 .. BH: 6, 6, 9, 9, 6 MFMAs at BH = 4, 6, 6, 6 at
@@ -528,12 +705,14 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
     // chunk at a time and are converted / transformed by raw_half at the end of step 1 and at the chunk boundary.  The last chunk has no
     // successor: its (clamped) requests are still issued -- the counted waits assume them -- but nothing is transformed.
     constexpr int XU = BH < 3 ? BH : 3;                      // the unit that requests activation pieces
+    MI_PW_STAMP(4, 3);                                       // (rewrites slot 3 with the entry time; the new stamp = loop entry)
     for (int ch = 0; ch < nchunks; ++ch) {
         const uint32_t xcur = (ch & 1) * PXBUF, xnxt = PXBUF - xcur;
         static_for<0, 4>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value, cur = ks & 1, kx32 = ks * 32;
             // pieces the previous step requested behind its fragments
-            constexpr int prevp = (ks > 0 && 2 * (ks - 1) < PXPW) ? 2 : 0;
+            constexpr int PPS = PT == 256 ? 3 : 2;             // activation pieces a step requests (unit XU)
+            constexpr int prevp = ks == 0 ? 0 : (PXPW - PPS * (ks - 1) >= PPS ? PPS : (PXPW - PPS * (ks - 1) > 0 ? PXPW - PPS * (ks - 1) : 0));
             // (fused: step 0 requested the coefficients, its fragment parts and pieces, the last piece(s) (unit 2: two DMAs) behind
             //  everything step 1 needs; fp32 input: the second half chunk's six DMAs are requested at the end of step 1, behind step
             //  2's fragments)
@@ -569,11 +748,14 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                     // one unit before the step that transforms it, every step began by waiting out an HBM round trip.
                     if constexpr (ks == 0 && u == 0) load_coef(ch + 1);
                     if constexpr (ks == 0 && 2 * u < PXPW) { stage_x(ch + 1, 2 * u); stage_x(ch + 1, 2 * u + 1); }
-                } else if constexpr (u == XU && !IN32 && 2 * ks < PXPW && !(ABL & 2)) { stage_x(ch + 1, 2 * ks); stage_x(ch + 1, 2 * ks + 1); }
+                } else if constexpr (u == XU && !IN32 && PPS * ks < PXPW && !(ABL & 2)) {
+                    static_for<0, PPS>([&](auto pc) { constexpr int pi = PPS * ks + decltype(pc)::value; if constexpr (pi < PXPW) stage_x(ch + 1, pi); });
+                }
             };
             // ---- unit 0: rows 0 (output row 0, tap row 0) and BH + 1 (output row BH - 1, tap row 2)
             {
                 constexpr std::integral_constant<int, 0> U{};
+                MI_PW_STAMP(ks, ch * (BH + 1));
                 XP = lds_b128p((xr[1] ^ kx32) + xcur);
                 issue(U);
                 MI_MM(0, 0, 1, XA); MI_MM(BH - 1, 2, 1, XB);
@@ -584,6 +766,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
             // ---- units 1 .. BH: row r feeds output rows r - ky (tap row ky); the last one reads rows 0 and BH + 1 of the next step
             static_for<1, BH + 1>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
+                MI_PW_STAMP(ks, ch * (BH + 1) + r);
                 auto& xc = [&]() -> bf16x8& { if constexpr (r & 1) return XP; else return XQ; }();
                 if constexpr (r < BH) {
                     auto& xn = [&]() -> bf16x8& { if constexpr (r & 1) return XQ; else return XP; }();
@@ -629,6 +812,8 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
 #undef MI_MM
         });
     }
+    }   // !PIPE
+    MI_PW_STAMP(4, 0);                                       // slot 0: the last point's time; new stamp = loop end
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped re-fetches must not outlive the workgroup's LDS ...
     static_for<0, 9>([&](auto tc) { landed16(WB[0][decltype(tc)::value]); landed16(WB[1][decltype(tc)::value]); });   // ... nor their registers
     if constexpr ((ABL & 4) != 0) {
@@ -641,6 +826,25 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         return;
     }
 
+#ifdef MI_PW_TIMING
+    auto ts_out = [&]() {
+        if constexpr (TIMED) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tile's stores have left
+            tv[4] = pw_wlane((uint32_t)tprev, 1, tv[4]);
+            tv[4] = pw_wlane((uint32_t)__builtin_amdgcn_s_memtime(), 2, tv[4]);
+            tv[4] = pw_wlane((uint32_t)__builtin_amdgcn_s_getreg(63492), 5, tv[4]);
+            tv[4] = pw_wlane((uint32_t)__builtin_amdgcn_s_getreg(63508), 6, tv[4]);
+            tv[4] = pw_wlane((uint32_t)wall_clock64(), 8, tv[4]);
+            const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
+            if (blk < 1024) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) g_pw_ts[((blk * 4 + wv) * 5 + k) * 64 + l] = tv[k];
+            }
+        }
+    };
+#else
+    auto ts_out = [&]() {};
+#endif
     // ---- epilogue.  A lane holds 4 consecutive channels of ONE pixel per register quad: stored from here a store instruction would
     //      write 16-byte pieces of 32 different rows (a [131072][128] bf16 tensor written that way takes 13 us against 7 us in whole
     //      rows, tools/proto/store_probe.hip).  The fp32 tile goes through LDS instead (the whole 80 KB is free now): [128 pixels][128
@@ -674,6 +878,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         };
     __builtin_amdgcn_s_barrier();                            // every wave is done with the activation buffers, every DMA has landed
     asm volatile("" ::: "memory");
+    MI_PW_NOW(13);
     // Round 4: a bf16 output with nothing to add on the way out (no residual, no accumulate -- every forward Block conv and the data
     // gradients into block-internal tensors) takes its bias in registers and crosses LDS as bf16: half the tile (32 KB), one
     // ds_read_b128 per thread and pixel, no arithmetic between the read and the store.  8-byte slot c (4 channels) of pixel p at
@@ -697,6 +902,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                 }
             }
             __syncthreads();
+            MI_PW_NOW(14);
             const int j = t & 15, col = n0 + 8 * j;
             float gs[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
             if (col < a.Nc) {
@@ -709,13 +915,15 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float e0 = __uint_as_float(o[q] << 16), e1 = __uint_as_float(o[q] & 0xffff0000u);
-                            gs[it >> 2][0] += e0 + e1; gs[it >> 2][1] += e0 * e0 + e1 * e1;
+                            gs[PT >= 256 ? 0 : it >> 2][0] += e0 + e1; gs[PT >= 256 ? 0 : it >> 2][1] += e0 * e0 + e1 * e1;
                         }
                     }
                 }
             }
             if constexpr (GNS) pw_gns_out(gs);
         }
+        MI_PW_NOW(15);
+        ts_out();
         return;
     }
     if (live) {
@@ -732,6 +940,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
         }
     }
     __syncthreads();
+    MI_PW_NOW(14);
     typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
     const int j = t & 15, col = n0 + 8 * j;                  // this thread's 8 channels
     float gs[2][2] = {{0.f, 0.f}, {0.f, 0.f}};               // VAR 1: [image of the tile][sum, sum of squares]
@@ -763,7 +972,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float e0 = __uint_as_float(o[q] << 16), e1 = __uint_as_float(o[q] & 0xffff0000u);
-                        gs[it >> 2][0] += e0 + e1; gs[it >> 2][1] += e0 * e0 + e1 * e1;
+                        gs[PT >= 256 ? 0 : it >> 2][0] += e0 + e1; gs[PT >= 256 ? 0 : it >> 2][1] += e0 * e0 + e1 * e1;
                     }
                 }
             } else {
@@ -772,13 +981,15 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const PwArgs a) {
                 *reinterpret_cast<f32x4*>(yp) = v0;
                 *reinterpret_cast<f32x4*>(yp + 4) = v1;
                 if constexpr (GNS) {
-                    gs[it >> 2][0] += (v0.x + v0.y) + (v0.z + v0.w) + (v1.x + v1.y) + (v1.z + v1.w);
-                    gs[it >> 2][1] += (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w) + (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w);
+                    gs[PT >= 256 ? 0 : it >> 2][0] += (v0.x + v0.y) + (v0.z + v0.w) + (v1.x + v1.y) + (v1.z + v1.w);
+                    gs[PT >= 256 ? 0 : it >> 2][1] += (v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w) + (v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w);
                 }
             }
         }
     }
     if constexpr (GNS) pw_gns_out(gs);
+    MI_PW_NOW(15);
+    ts_out();
 }
 
 bool pw_geom(const MiConvDesc* d, int pt, int* TH, int* TI) {
@@ -803,12 +1014,16 @@ bool pw_ok(const MiConvDesc* d, int pt, int* TH, int* TI, bool in32 = false, boo
     return pw_geom(d, pt, TH, TI);
 }
 // 64-pixel tiles where 128-pixel ones would leave CUs without a workgroup (and the geometry allows them)
-int g_pw_force_tile = 0;                 // tests: 0 = the rule below, 64 / 128 = that tile (or unsupported)
+int g_pw_force_tile = 0;                 // tests: 0 = the rule below, 64 / 128 / 256 = that tile (or unsupported)
+int g_pw_auto256 = 1, g_pw_min256 = 256;  // the automatic pick takes 256-pixel tiles when they give at least g_pw_min256 workgroups
 int pw_pick_tile(const MiConvDesc* d, int var, int* TH, int* TI, bool in32 = false, bool f32 = false) {
     if (f32 && var != 0) return 0;
     if (g_pw_force_tile == 64) return pw_ok(d, 64, TH, TI, in32, f32) ? 64 : 0;
     if (g_pw_force_tile == 128) return pw_ok(d, 128, TH, TI, in32, f32) ? 128 : 0;
+    if (g_pw_force_tile == 256) return (var < 2 && !in32 && !f32 && pw_ok(d, 256, TH, TI)) ? 256 : 0;
     const long t128 = ((long)d->N * d->OH * d->OW / 128) * ((d->Nc + 127) / 128);
+    // 256-pixel tiles (one workgroup per CU, a weight fragment feeds eight MFMAs instead of four) where they still fill the chip
+    if (g_pw_auto256 && var < 2 && !in32 && !f32 && t128 >= 2 * g_pw_min256 && pw_ok(d, 256, TH, TI)) return 256;
     if (t128 < 200 && pw_ok(d, 64, TH, TI, in32, f32) && (var < 2 || *TI == 1)) return 64;
     return pw_ok(d, 128, TH, TI, in32, f32) ? 128 : 0;
 }
@@ -1305,9 +1520,14 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     a.tiles_per_img = a.TI > 1 ? 1 : a.H / a.TH;
     a.XP = a.TI * (a.TH + 2) * a.W;
     a.xmap = a.TI == 1 && a.tiles_per_img > 1 && a.N % 8 == 0;
+    static const void* zero_page = [] { void* p_ = nullptr; (void)hipGetSymbolAddress(&p_, HIP_SYMBOL(g_zero_page3)); return (const void*)p_; }();
+    if (!zero_page) return mi_set_error(-1, "%s: zero page address", who);
+    a.zero = zero_page; a.tpi_magic = pw_magic(a.tiles_per_img);
+    { int ns = a.TH / (pt / 32), ln = 0; while ((1 << ln) < ns) ++ln; a.lnsub = ln; }
     dim3 grid((unsigned)((long)d->N * d->OH * d->OW / pt), (unsigned)((d->Nc + 127) / 128));
     a.qmap = 0; a.gx = (int)grid.x; a.gy = (int)grid.y;
     if (!a.xmap && a.gy > 1 && a.gy % 2 == 0 && a.gx % 4 == 0) { a.qmap = 2; grid = dim3(grid.x * grid.y, 1, 1); }
+    a.ppx = a.gx / 4; a.cpq = a.gy / 2; a.cpq_magic = pw_magic(a.cpq);
     hipStream_t st = (hipStream_t)stream;
     size_t lds = pw_lds(pt, in32);
 #define MI_PW_GO_T(O16, V, A, T) do { \
@@ -1365,6 +1585,9 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
             case 3: if (out_bf16) MI_PW_GO_X(true, 3, 128); else MI_PW_GO_X(false, 3, 128); break;
             default: if (out_bf16) MI_PW_GO_X(true, 0, 128); else MI_PW_GO_X(false, 0, 128); break;
         }
+    } else if (pt == 256) switch (var) {
+        case 1: if (out_bf16) MI_PW_GO_T(true, 1, 0, 256); else MI_PW_GO_T(false, 1, 0, 256); break;
+        default: if (out_bf16) MI_PW_GO_T(true, 0, 0, 256); else MI_PW_GO_T(false, 0, 0, 256); break;
     } else if (pt == 64) switch (var) {
         case 1: if (out_bf16) MI_PW_GO_T(true, 1, 0, 64); else MI_PW_GO_T(false, 1, 0, 64); break;
         case 2: if (out_bf16) MI_PW_GO_T(true, 2, 0, 64); else MI_PW_GO_T(false, 2, 0, 64); break;
@@ -1391,11 +1614,17 @@ extern "C" int mi_conv3x3_pw_supported(const MiConvDesc* d) {
 }
 // test switch: force the pixel tile (64 / 128), 0 = automatic
 extern "C" int mi_debug_conv_pw_tile(int pt) {
-    if (pt != 0 && pt != 64 && pt != 128) return mi_set_error(-1, "mi_debug_conv_pw_tile: 0, 64 or 128");
+    if (pt != 0 && pt != 64 && pt != 128 && pt != 256) return mi_set_error(-1, "mi_debug_conv_pw_tile: 0, 64, 128 or 256");
     g_pw_force_tile = pt;
     return 0;
 }
-// pixels per workgroup the launch would use (128 or 64; 0: not supported) -- profiling attribution and the host layer's pick
+// A/B switch: the automatic pick takes 256-pixel tiles from min_workgroups workgroups up (0: never)
+extern "C" int mi_debug_conv_pw_auto256(int min_workgroups) {
+    if (min_workgroups < 0) return mi_set_error(-1, "mi_debug_conv_pw_auto256: min_workgroups >= 0");
+    g_pw_auto256 = min_workgroups > 0; g_pw_min256 = min_workgroups > 0 ? min_workgroups : 256;
+    return 0;
+}
+// pixels per workgroup the launch would use (256, 128 or 64; 0: not supported) -- profiling attribution and the host layer's pick
 extern "C" int mi_conv3x3_pw_tile(const MiConvDesc* d) {
     int th, ti;
     return d ? pw_pick_tile(d, 0, &th, &ti) : 0;

@@ -188,8 +188,9 @@ int mi_conv1x1_pw_f32(const MiConvDesc* d, const float* x, const float* x2, cons
                       const float* residual, float* y, void* stream);
 int mi_pack_weights_f32frag(int nent, const void* entries_dev, int total_tiles, const float* master, float* wdq32, float* wfq32,
                             void* stream);
-int mi_debug_conv_pw_tile(int pt);               /* tests: force the pixel tile (64 / 128), 0 = automatic */
-int mi_conv3x3_pw_tile(const MiConvDesc* d);      /* pixels per workgroup the launch would use: 128, or 64 for small grids; 0 = unsupported */
+int mi_debug_conv_pw_tile(int pt);               /* tests: force the pixel tile (64 / 128 / 256), 0 = automatic */
+int mi_debug_conv_pw_auto256(int min_workgroups); /* A/B switch: the automatic pick takes 256-pixel tiles from this many workgroups up (0 = never; default 256) */
+int mi_conv3x3_pw_tile(const MiConvDesc* d);      /* pixels per workgroup the launch would use: 256 (grids that still fill the chip), 128, or 64 for small grids; 0 = unsupported */
 int mi_conv3x3_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,
                   const float* residual, void* y, int out_bf16, void* stream);
 /* ... whose epilogue also adds the sum and the sum of squares of the values it stores (rounded to bf16 when y is bf16), per sample and

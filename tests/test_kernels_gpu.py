@@ -656,9 +656,28 @@ def _frag_weights(K, w):
     return wf, wfq
 
 
+@pytest.fixture
+def pw_tile256(K):
+    """Force conv_pw's 256-pixel tiles (round 5: eight MFMA blocks per wave, one workgroup per CU; 32- and 16-pixel-wide images)."""
+    lib = K.load_library()
+    lib.mi_debug_conv_pw_tile(256); K._QUERY_CACHE.clear()
+    yield 256
+    lib.mi_debug_conv_pw_tile(0); K._QUERY_CACHE.clear()
+
+
 @pytest.mark.parametrize("out16", [True, False])
 @pytest.mark.parametrize("cfg", [(16, 32, 32, 128, 128), (8, 16, 16, 256, 256), (4, 8, 8, 512, 512), (16, 16, 16, 128, 384)])
 def test_conv_pw_epilogue_groupnorm_sums(K, cfg, out16, pw_always, pw_tile):
+    _pw_gnsums_case(K, cfg, out16, pw_always, pw_tile)
+
+
+@pytest.mark.parametrize("out16", [True, False])
+@pytest.mark.parametrize("cfg", [(16, 32, 32, 128, 128), (8, 16, 16, 256, 256), (3, 16, 16, 128, 384)])
+def test_conv_pw_epilogue_groupnorm_sums_tile256(K, cfg, out16, pw_always, pw_tile256):
+    _pw_gnsums_case(K, cfg, out16, pw_always, pw_tile256)
+
+
+def _pw_gnsums_case(K, cfg, out16, pw_always, pw_tile):
     """mi_conv3x3_pw_gnsums + mi_gn_coef_from_sums: the next GroupNorm's statistics and coefficients out of the conv's row-contiguous
     epilogue (one image per tile at 32 / 16 pixels width, TWO at 8x8) equal what mi_gn_stats_coef computes with a pass over the
     stored tensor, and the conv's output is the plain entry point's (bitwise)."""
@@ -1039,6 +1058,24 @@ def test_pack_weights_fragment_order(K):
     dict(N=6, H=8, Ci=192, Co=320),              # odd chunk count, ragged channel tile
 ])
 def test_conv3x3_pw_fwd_and_dgrad(K, cfg, out16, pw_always, pw_tile):
+    _pw_fwd_dgrad_case(K, cfg, out16, pw_always, pw_tile)
+
+
+@pytest.mark.parametrize("out16", [False, True])
+@pytest.mark.parametrize("cfg", [
+    dict(N=2, H=32, Ci=128, Co=128),             # level 0: 8 rows of 32 per tile, 2 chunks
+    dict(N=8, H=32, Ci=64, Co=256),              # XCD-grouped tile order, one chunk, 2 channel tiles
+    dict(N=4, H=16, Ci=256, Co=128, split=128),  # skip concat (two sources), one 16x16 image per tile
+    dict(N=3, H=16, Ci=64, Co=96),               # ragged channel tile: one idle wave
+    dict(N=2, H=16, Ci=192, Co=320),             # odd chunk count, ragged channel tile
+    dict(N=1, H=32, Ci=512, Co=64, split=256),   # long K, half-empty channel tile
+])
+def test_conv3x3_pw_fwd_and_dgrad_tile256(K, cfg, out16, pw_always, pw_tile256):
+    """The same checks on the 256-pixel tiles (round 5): wave = 256 pixels x 32 channels, one workgroup per CU."""
+    _pw_fwd_dgrad_case(K, cfg, out16, pw_always, pw_tile256)
+
+
+def _pw_fwd_dgrad_case(K, cfg, out16, pw_always, pw_tile):
     """Block's 3x3 conv (ddpm.py:116) and its data gradient for bf16-stored activations through the private-weight-stream kernel
     (mi_conv3x3_pw: fragment-order weights by LDS-DMA per wave, one barrier per 64-channel chunk): bias, residual, fp32 and bf16
     output, accumulate; against fp64 on the same bf16-rounded operands and against the halo kernel."""

@@ -23,6 +23,8 @@ def timed(run, n=20):
 
 SHAPES = [(32, 128, 128), (16, 128, 128), (16, 128, 256), (16, 256, 256), (16, 512, 128), (8, 256, 256), (8, 256, 512), (8, 512, 512),
           (8, 1024, 256)]
+if os.environ.get("SHORT"):
+    SHAPES = [(32, 128, 128), (16, 256, 256), (16, 512, 128), (8, 512, 512), (8, 1024, 256)]
 if os.environ.get("CFG3"):
     SHAPES = [(32, 128, 128), (32, 256, 64), (16, 128, 128), (16, 256, 256), (16, 512, 128), (8, 256, 256), (8, 512, 512), (8, 1024, 256)]
 for H, Ci, Co in SHAPES:
