@@ -29,6 +29,18 @@
 #ifndef MI_PW_PABL
 #define MI_PW_PABL 0     // profiling builds: 1 no fragment requests in the pinned loop, 2 no piece requests, 4 no step-opening wait, 8 no shifts, 16 no barrier
 #endif
+#ifndef MI_PW_SPIECE
+#define MI_PW_SPIECE 1    // scalar piece addressing in the plain conv (0: stage_x's per-lane 64-bit addresses)
+#endif
+#ifndef MI_PW_SKEW
+#define MI_PW_SKEW 0      // 16-cycle units of delay per wave index behind every barrier of the pinned loop
+#endif
+#ifndef MI_PW_RSTAGE
+#define MI_PW_RSTAGE 1    // pinned loop: the next chunk's pieces through registers (global_load + ds_write_b128) instead of LDS-DMA
+#endif
+#ifndef MI_PW_ROT
+#define MI_PW_ROT 1       // per-workgroup rotation of the chunk order
+#endif
 #ifndef MI_PW_WSTR
 #define MI_PW_WSTR 2
 #endif
@@ -63,7 +75,7 @@ struct PwArgs {
     int qmap, gx, gy;    // 1-D launch of gx pixel tiles x gy channel tiles: XCD = (pixel group, channel group) of a (8 / qmap) x qmap split
     // round 5: the prologue's integer divisions as multiplications (q = umulhi(x, magic), magic = ceil(2^32 / d), 0 for d = 1; exact for
     // x * d < 2^32) and the zero page's address as an argument -- 3 600 cycles passed between a wave's entry and its first request
-    uint32_t tpi_magic, cpq_magic; int ppx, cpq, lnsub;
+    uint32_t tpi_magic, cpq_magic, nch_magic; int ppx, cpq, lnsub;
     const void* zero;
     float* gsum;         // VAR 1: [N][Nc / 16][2] sum / sum of squares of the stored values per sample and 16-channel slab (+=)
     const float* coef;   // VAR 2: [3][N][K] scale, shift, time bias of the GroupNorm + Mish applied to x while it is staged
@@ -199,6 +211,12 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     const int NB = a.Nc >> 5, KQ = a.K / (2 * EPP);              // fragments per (tap, 32-channel block): one per step
     const bool live = n0 + 32 * wv < a.Nc;                    // a ragged last channel tile: the wave computes a copy of the last block
     const int nb = min((n0 >> 5) + wv, NB - 1);
+    // round 5: every workgroup walks the contraction in its own rotation of the chunk order (iteration ch works on chunk (ch + rot) mod
+    // nchunks).  The workgroups of a channel tile otherwise request the SAME weight lines in the same microseconds -- 16 CUs of an XCD on a
+    // handful of L2 channels -- and the per-chunk time stayed at ~6 000 cycles whatever was done about issue order, waits or staging.
+    // (The sum of a pixel's products is formed in a different order per tile: deterministic, tile by tile.)
+    const int rot = MI_PW_ROT ? bx - pw_fastdiv(bx, a.nch_magic) * nchunks : 0;
+    auto cof = [&](int ch) -> int { const int c = min(ch, nchunks - 1) + rot; return c >= nchunks ? c - nchunks : c; };
 
     // ---- weight stream of this wave: fragment (tap, nb, kq) = 1 KB at ((tap * NB + nb) * KQ + kq) * 1024 bytes.  The fragments are
     //      wave-private, so they never touch LDS: each lane loads ITS 16 bytes of a fragment straight into the registers the MFMA
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     auto load_w3 = [&](int ch, auto ksc, auto partc) {
         constexpr int ks0 = decltype(ksc)::value, over = ks0 >= 4 ? 1 : 0, ks = ks0 - 4 * over, part = decltype(partc)::value;
         constexpr int t0 = (9 * part + NPART - 1) / NPART, t1 = (9 * (part + 1) + NPART - 1) / NPART;
-        const uint32_t voff = wl16 + (uint32_t)min(ch + over, nchunks - 1) * 4096;
+        const uint32_t voff = wl16 + (uint32_t)cof(ch + over) * 4096;
         static_for<t0, t1>([&](auto tc) {
             constexpr int tp = decltype(tc)::value;
             gload16s<ks * 1024>(WB[ks & 1][tp], wtap[tp], voff);
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     // one tap of step (ch, ks) (round 5's pinned schedule: one request per MFMA gap)
     auto load_w1 = [&](int ch, auto ksc, auto tapc) {
         constexpr int ks0 = decltype(ksc)::value, over = ks0 >= 4 ? 1 : 0, ks = ks0 - 4 * over, tp = decltype(tapc)::value;
-        const uint32_t voff = wl16 + (uint32_t)min(ch + over, nchunks - 1) * 4096;
+        const uint32_t voff = wl16 + (uint32_t)cof(ch + over) * 4096;
         gload16s<ks * 1024>(WB[ks & 1][tp], wtap[tp], voff);
     };
 
@@ -275,7 +293,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     }
     const uint16_t* zero = reinterpret_cast<const uint16_t*>(a.zero);
     auto stage_x = [&](int ch, int i) {                      // piece i of this wave of chunk ch's rows -> buffer ch & 1
-        const int cc0 = min(ch, nchunks - 1) * PCK;
+        const int cc0 = cof(ch) * PCK;
         const bool second = cc0 >= a.K1;
         const uint16_t* src = second ? a.x2 : a.x;
         const int ld = second ? a.ldx2 : a.ldx, cc = second ? cc0 - a.K1 : cc0;
@@ -287,14 +305,59 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
         const uint8_t* p = xp >= 0 ? reinterpret_cast<const uint8_t*>(src) + off * ESZ : reinterpret_cast<const uint8_t*>(zero) + (l & 7) * 16;
         glds16(p, lds0 + (ch & 1) * PXBUF + (wv + 4 * i) * 1024);
     };
-    if constexpr (EARLYW) {                                  // the first chunk's rows: on their way before the rest of the set-up
+    // ---- round 5, the plain conv: a piece = 8 pixels of ONE tile row (W >= 8), so everything about it but the lane's place in it is
+    //      wave-uniform: source = scalar base (tensor + row + chunk) + a per-lane offset that is the same for every piece and chunk
+    //      ((l >> 3) pixels + the lane's channel slot), i.e. no vector arithmetic per request at all (stage_x: a 64-bit multiply-add, a
+    //      compare and two selects per piece).  A piece outside the image is not fetched from a zero page: its LDS rows are zeroed once
+    //      (both buffers) and its request -- still issued, the counted waits assume it -- reads valid memory into a dump area.
+    constexpr bool SPIECE = (MI_PW_SPIECE != 0) && VAR < 2 && !IN32 && !F32 && ABL == 0;
+    int prow[SPIECE ? PXPW : 1];                             // first pixel of the piece in the tensor, 0 when outside (scalar)
+    uint32_t pvalid = 0;                                     // bit i: piece i lies in the image
+    uint32_t lane_off1 = 0, lane_off2 = 0;
+    constexpr uint32_t DUMP = 2 * PXBUF;                     // 1 KB behind the two tiles (the epilogue's tile starts over)
+    if constexpr (SPIECE) {
+        const int y0s = a.TI > 1 ? 0 : (bx - img0 * a.tiles_per_img) * a.TH;
 #pragma unroll
-        for (int i = 0; i < PXPW; ++i) stage_x(0, i);
+        for (int i = 0; i < PXPW; ++i) {
+            const int hp0 = 8 * (wv + 4 * i);
+            const int row = hp0 >> lw, x0 = hp0 & (a.W - 1);
+            const int ti = row >= TH2 ? 1 : 0, hy = row - ti * TH2;
+            const int iy = y0s + hy - 1, img = img0 + ti;
+            const bool ok = (hp0 < a.XP) & (iy >= 0) & (iy < a.H) & (img < a.N);
+            prow[i] = ok ? (img * a.H + iy) * a.W + x0 : 0;
+            pvalid |= ok ? (1u << i) : 0u;
+        }
+        lane_off1 = (uint32_t)(((l >> 3) * a.ldx + xcol) * ESZ); lane_off2 = (uint32_t)(((l >> 3) * a.ldx2 + xcol) * ESZ);
+    }
+    auto stage_s = [&](int ch, auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int cc0 = cof(ch) * PCK;
+        const bool second = cc0 >= a.K1;
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(second ? a.x2 : a.x);
+        const int ld = second ? a.ldx2 : a.ldx, cc = second ? cc0 - a.K1 : cc0;
+        const uint8_t* sb = src + ((size_t)prow[i] * ld + cc) * ESZ;
+        const uint32_t dst = ((pvalid >> i) & 1u) ? lds0 + (ch & 1) * PXBUF + (wv + 4 * i) * 1024 : lds0 + DUMP;
+        glds16s(sb, second ? lane_off2 : lane_off1, dst);
+    };
+    if constexpr (EARLYW) {                                  // the first chunk's rows: on their way before the rest of the set-up
+        if constexpr (SPIECE) {
+            static_for<0, PXPW>([&](auto ic) { stage_s(0, ic); });
+            typedef __attribute__((address_space(3))) u32x4 lds_u32x4z;
+#pragma unroll
+            for (int i = 0; i < PXPW; ++i)
+                if (!((pvalid >> i) & 1u)) {                 // zero padding, once: nothing is ever written there again
+                    *(lds_u32x4z*)(uintptr_t)(lds0 + (wv + 4 * i) * 1024 + l * 16) = u32x4{0u, 0u, 0u, 0u};
+                    *(lds_u32x4z*)(uintptr_t)(lds0 + PXBUF + (wv + 4 * i) * 1024 + l * 16) = u32x4{0u, 0u, 0u, 0u};
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PXPW; ++i) stage_x(0, i);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     // fp32 input: piece i of chunk ch -> the two registers of `dst` (8 channels of this lane's pixel), asynchronous
     auto load_x32 = [&](int ch, int i, u32x4* dst) {
-        const int cc0 = min(ch, nchunks - 1) * PCK;
+        const int cc0 = cof(ch) * PCK;
         const bool second = cc0 >= a.K1;
         const float* src = reinterpret_cast<const float*>(second ? a.x2 : a.x);
         const int ld = second ? a.ldx2 : a.ldx, cc = second ? cc0 - a.K1 : cc0;
@@ -350,7 +413,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
         grstd = 1.0f / sqrtf((float)var + a.eps); gmean = (float)mean;
     };
     auto load_coef = [&](int ch) {
-        const int c = min(ch, nchunks - 1) * PCK + xcol;
+        const int c = cof(ch) * PCK + xcol;
         const float* p0; const float* p1; const float* p2;
         if constexpr (VAR == 2) {
             p0 = a.coef + (size_t)img0 * a.K + c;
@@ -369,7 +432,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     auto coef_landed = [&](int ch) {
         asm volatile("" : "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+v"(cq[3]), "+v"(cq[4]), "+v"(cq[5]) :: "memory");
         if constexpr (VAR == 3) {
-            const int grp = (min(ch, nchunks - 1) * PCK + xcol) / a.cpg;      // the lane's 8 channels lie in one group
+            const int grp = (cof(ch) * PCK + xcol) / a.cpg;      // the lane's 8 channels lie in one group
             const float mf = __shfl(gmean, grp, 64), rstd = __shfl(grstd, grp, 64);
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -440,7 +503,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     constexpr uint32_t RAW0 = 2 * PXBUF;
     constexpr int RHP = PXPW / 2;                            // pieces per half chunk and wave (= staging slots): 3 (128-pixel tiles) or 2
     auto stage_raw = [&](int ch, int i, int slot) {
-        const int cc0 = min(ch, nchunks - 1) * PCK;
+        const int cc0 = cof(ch) * PCK;
         const bool second = cc0 >= a.K1;
         const float* src = reinterpret_cast<const float*>(second ? a.x2 : a.x);
         const int ld = second ? a.ldx2 : a.ldx, cc = second ? cc0 - a.K1 : cc0;
@@ -505,7 +568,18 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
 
     // bf16 output: the bias of this lane's four channel quads, requested before anything else and used only by the epilogue (there a
     // load would put an HBM round trip in front of the tile's way out)
+    // (round 5, pinned loop: the 128 bias values of the tile wait in LDS instead of 16 registers per lane)
+    constexpr bool PIPE_ = (MI_PW_PIPE != 0) && VAR < 2 && !IN32 && !F32 && ABL == 0;
+    constexpr uint32_t BIASL = 2 * PXBUF + 1024;             // 512 bytes behind the dump area
     f32x4 bias_q[(OUT16 && !FUSE) ? 4 : 1];
+    if constexpr (OUT16 && !FUSE && PIPE_) {
+        typedef __attribute__((address_space(3))) f32x4 lds_f32x4b;
+        if (t < 32) {
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias && n0 + 4 * t < a.Nc) bv = *reinterpret_cast<const f32x4*>(a.bias + n0 + 4 * t);
+            *(lds_f32x4b*)(uintptr_t)(lds0 + BIASL + 16 * t) = bv;
+        }
+    } else
     if constexpr (OUT16 && !FUSE) {
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
@@ -602,6 +676,33 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
         constexpr int WSTR = BH >= 4 ? MI_PW_WSTR : 1;        // a fragment request every WSTR gaps
         constexpr int PG0 = 9 * WSTR;                         // first gap with an activation piece request
         constexpr int PPS = (PXPW + 1) / 2;                   // pieces requested per step (steps 0 and 1)
+        // the four waves leave a barrier in the same cycle and would issue every request in the same gap: wave w starts w * 16 cycles late
+        // (one dwordx4 request occupies the CU's address path for about 16 cycles)
+        auto pw_skew = [&]() { if constexpr (MI_PW_SKEW > 0) for (int i_ = 0; i_ < wv * MI_PW_SKEW; ++i_) asm volatile("s_nop 15"); };
+        pw_skew();
+        // the next chunk's pieces through registers (an LDS-DMA request cost the issuing wave 50-100 cycles in the unit timeline, a plain
+        // request + ds_write_b128 a fraction of that): batch 0 = the first PPS pieces, requested in step 0 and written in step 2 (in-order
+        // returns: they have landed once step 2's fragments have), batch 1 requested in step 1 and written in step 3 before the barrier
+        constexpr bool RST = (MI_PW_RSTAGE != 0) && SPIECE;
+        u32x4 RS[2][RST ? PPS : 1];
+        const uint32_t wbase = lds0 + wv * 1024 + l * 16;
+        auto rs_load = [&](int ch, auto bc, auto jc) {
+            constexpr int b = decltype(bc)::value, j = decltype(jc)::value, i = PPS * b + j;
+            const int cc0 = cof(ch) * PCK;
+            const bool second = cc0 >= a.K1;
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(second ? a.x2 : a.x);
+            const int ld = second ? a.ldx2 : a.ldx, cc = second ? cc0 - a.K1 : cc0;
+            const uint64_t sb = (uint64_t)(uintptr_t)(src + ((size_t)prow[i < PXPW ? i : 0] * ld + cc) * ESZ);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
+            gload16s<0>(RS[b][j], ((uint64_t)hi << 32) | lo, second ? lane_off2 : lane_off1);
+        };
+        auto rs_store = [&](int ch, auto bc, auto jc) {
+            constexpr int b = decltype(bc)::value, j = decltype(jc)::value, i = PPS * b + j;
+            typedef __attribute__((address_space(3))) u32x4 lds_u32x4s;
+            landed16(RS[b][j]);
+            const uint32_t off = ((pvalid >> i) & 1u) ? (uint32_t)((ch & 1) * PXBUF + 4 * i * 1024) : (uint32_t)(DUMP - wv * 1024);
+            *(lds_u32x4s*)(uintptr_t)(wbase + off) = RS[b][j];
+        };
         bf16x8 Ac, Bc, Al, Bl, Ar, Br, C[CN], L[2], R[2];
         Ac = lds_b128p(xr[0]); Bc = lds_b128p(xr[BH + 1]); C[1 % CN] = lds_b128p(xr[1]);
         Al = pw_shift<0>(Ac, mask_l); Bl = pw_shift<0>(Bc, mask_l); Ar = pw_shift<1>(Ac, mask_r); Br = pw_shift<1>(Bc, mask_r);
@@ -627,7 +728,14 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
                     constexpr int g = decltype(gc)::value;
                     if constexpr (g % WSTR == 0 && g / WSTR < 9 && !(MI_PW_PABL & 1)) load_w1(ch, std::integral_constant<int, ks + 1>{}, std::integral_constant<int, g / WSTR>{});
                     if constexpr (!(MI_PW_PABL & 2) && ks < 2 && g >= PG0 && (g - PG0) % 2 == 0 && (g - PG0) / 2 < PPS && PPS * ks + (g - PG0) / 2 < PXPW)
-                        stage_x(ch + 1, PPS * ks + (g - PG0) / 2);
+                    {
+                        if constexpr (RST) rs_load(ch + 1, std::integral_constant<int, ks>{}, std::integral_constant<int, (g - PG0) / 2>{});
+                        else if constexpr (SPIECE) stage_s(ch + 1, std::integral_constant<int, (PPS * ks + (g - PG0) / 2) < PXPW ? (PPS * ks + (g - PG0) / 2) : 0>{});
+                        else stage_x(ch + 1, PPS * ks + (g - PG0) / 2);
+                    }
+                    // (register staging: the batch requested two steps ago goes to LDS in the odd gaps 1, 3, ... of steps 2 and 3)
+                    if constexpr (RST && ks >= 2 && (g & 1) && g / 2 < PPS && PPS * (ks - 2) + g / 2 < PXPW)
+                        rs_store(ch + 1, std::integral_constant<int, ks - 2>{}, std::integral_constant<int, g / 2>{});
                 };
                 // ---- unit 0: rows 0 (output row 0, tap row 0) and BH + 1 (output row BH - 1, tap row 2)
                 {
@@ -654,6 +762,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         if constexpr (!(MI_PW_PABL & 16)) __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
+                        pw_skew();
                     }
                     static_for<0, 3 * n>([&](auto jc) {
                         constexpr int j = decltype(jc)::value, kxi = j / n, ky = ky0 + j % n, kx = kxi == 0 ? 1 : kxi == 1 ? 0 : 2;
@@ -892,7 +1001,9 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     const int ck = 8 * wv + 2 * rq + (l >> 5);
-                    const f32x4 bq = bias_q[rq];
+                    f32x4 bq;
+                    if constexpr (PIPE_) { typedef __attribute__((address_space(3))) f32x4 lds_f32x4b; bq = *(lds_f32x4b*)(uintptr_t)(lds0 + BIASL + 16 * ck); }
+                    else bq = bias_q[rq];
 #pragma unroll
                     for (int i = 0; i < BH; ++i) {
                         const int p = ep_p0 + i * a.W;
@@ -1015,7 +1126,7 @@ bool pw_ok(const MiConvDesc* d, int pt, int* TH, int* TI, bool in32 = false, boo
 }
 // 64-pixel tiles where 128-pixel ones would leave CUs without a workgroup (and the geometry allows them)
 int g_pw_force_tile = 0;                 // tests: 0 = the rule below, 64 / 128 / 256 = that tile (or unsupported)
-int g_pw_auto256 = 1, g_pw_min256 = 256;  // the automatic pick takes 256-pixel tiles when they give at least g_pw_min256 workgroups
+int g_pw_auto256 = 0, g_pw_min256 = 256;   // (measured slower than two 128-pixel workgroups per CU on every cfg-2 shape: off)  // the automatic pick takes 256-pixel tiles when they give at least g_pw_min256 workgroups
 int pw_pick_tile(const MiConvDesc* d, int var, int* TH, int* TI, bool in32 = false, bool f32 = false) {
     if (f32 && var != 0) return 0;
     if (g_pw_force_tile == 64) return pw_ok(d, 64, TH, TI, in32, f32) ? 64 : 0;
@@ -1522,7 +1633,7 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     a.xmap = a.TI == 1 && a.tiles_per_img > 1 && a.N % 8 == 0;
     static const void* zero_page = [] { void* p_ = nullptr; (void)hipGetSymbolAddress(&p_, HIP_SYMBOL(g_zero_page3)); return (const void*)p_; }();
     if (!zero_page) return mi_set_error(-1, "%s: zero page address", who);
-    a.zero = zero_page; a.tpi_magic = pw_magic(a.tiles_per_img);
+    a.zero = zero_page; a.tpi_magic = pw_magic(a.tiles_per_img); a.nch_magic = pw_magic(d->K / (f32 ? 32 : 64));
     { int ns = a.TH / (pt / 32), ln = 0; while ((1 << ln) < ns) ++ln; a.lnsub = ln; }
     dim3 grid((unsigned)((long)d->N * d->OH * d->OW / pt), (unsigned)((d->Nc + 127) / 128));
     a.qmap = 0; a.gx = (int)grid.x; a.gy = (int)grid.y;
