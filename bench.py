@@ -115,56 +115,137 @@ def cpu_baseline(budget_s: float = 28.0):
             "legs": legs}
 
 
-def relaunch(args):
+def relaunch(args, extra_env=None, capture=False, drop=()):
     """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run and relay the line."""
-    port = 29500 + (os.getpid() % 400)
+    port = 29500 + ((os.getpid() + (hash(str(extra_env)) % 97)) % 400)
+    argv = [a_ for a_ in sys.argv[1:] if a_ not in drop]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["MI_BENCH_SELF_LAUNCHED"] = "1"
-    return subprocess.call(cmd, env=env)
+    env.update(extra_env or {})
+    if not capture:
+        return subprocess.call(cmd, env=env)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr[-2000:]
+
+
+def sweep_channels(args):
+    """--sweep-channels: the whole N-rank bench once per NCCL_MAX_NCHANNELS in {default, 8, 16} (RCCL reads the variable when the
+    communicator is created, so every value is its own set of processes); ONE line: the default run's, with the three results under
+    "channel_sweep".  Only from the self-launching form (`python bench.py --gpus N --sweep-channels`, no launcher around it)."""
+    res, main_line = [], None
+    for val in (None, "8", "16"):
+        env = {} if val is None else {"NCCL_MAX_NCHANNELS": val}
+        if val is None:
+            env["MI_BENCH_UNSET_NCHANNELS"] = "1"
+        rc, line, err = relaunch(args, env, capture=True, drop=("--sweep-channels",))
+        if rc != 0 or line is None:
+            res.append({"NCCL_MAX_NCHANNELS": val or "default", "error": err[-400:]})
+            continue
+        res.append({"NCCL_MAX_NCHANNELS": val or "default", "value": line.get("value"), "ms_per_step": line.get("ms_per_step"),
+                    "ways_ms": (line.get("comm") or {}).get("ways_ms")})
+        if main_line is None:
+            main_line = line
+    if main_line is None:
+        print(json.dumps({"error": "every run of the channel sweep failed", "channel_sweep": res}))
+        return 1
+    main_line["channel_sweep"] = res
+    print(json.dumps(main_line))
+    return 0
+
+
+def rank_spread(elapsed_s, steps, world, device="cpu"):
+    """ms per step of every rank (all_gather): min / max tell a straggler from a uniformly slow step."""
+    if world <= 1:
+        return {"min": round(elapsed_s / steps * 1e3, 3), "max": round(elapsed_s / steps * 1e3, 3)}
+    t = torch.tensor([elapsed_s / steps * 1e3], device=device, dtype=torch.float64)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    v = [float(o) for o in out]
+    return {"min": round(min(v), 3), "max": round(max(v), 3), "per_rank": [round(x, 3) for x in v]}
+
+
+def timed_leg(step, steps, warmup, sync, world, device="cpu"):
+    """warmup + `steps` calls of step(i), bracketed by sync() (barrier + device synchronize); MAX over ranks; ms per step."""
+    for i in range(warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    sync()
+    el = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return float(el) / steps * 1e3
 
 
 def dry_run_cpu(args, world, rank):
     """Launch plumbing on the host: gloo ranks, a stand-in step (bucketed all-reduce over a small flat buffer + a sleep),
-    barrier-bracketed timing, MAX over ranks, rank 0 prints the line.  No kernels run; nothing here is a measurement."""
+    barrier-bracketed timing, MAX over ranks, rank 0 prints the line.  No kernels run; nothing here is a measurement -- but the
+    rank check, the per-rank spread, the three-ways comparison, the one-rank data-parallel leg and the channel sweep's relaunching
+    are the code the GPU run executes."""
     from src.runtime.ddp import FlatGradReducer
+    solo_group = False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
+    elif not args.no_extras:                               # N = 1 through the data-parallel code path (a one-rank group)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        solo_group = True
+    grouped = world > 1 or solo_group
     flat = torch.ones(1 << 16)
-    red = FlatGradReducer(flat, bucket_bytes=1 << 16) if world > 1 else None
+    red = FlatGradReducer(flat, bucket_bytes=1 << 16) if grouped else None
     ones = torch.ones(1)
-    if world > 1:
+    if grouped:
         dist.all_reduce(ones)
+    if int(ones.item()) != world:
+        raise SystemExit(f"bench.py: the backend connected {int(ones.item())} ranks, --gpus says {world}")
 
-    def step():
+    def step(i=0):
         if red is not None:
             red.begin()
             for hi in range(flat.numel(), 0, -(1 << 13)):
                 red.range_ready(hi - (1 << 13), hi)
             red.finish()
         time.sleep(0.002)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world > 1:
-        dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    sync()
+    mine = time.perf_counter() - t0
+    spread = rank_spread(mine, args.steps, world)
+    el = torch.tensor([mine], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ways = None
+    if red is not None:
+        ways = {"segmented_graph": round(float(el) / args.steps * 1e3, 3), "eager_overlap": round(timed_leg(step, 2, 1, sync, world), 3)}
+        red.defer = True
+        ways["eager_allreduce_after_backward"] = round(timed_leg(step, 2, 1, sync, world), 3)
+        red.defer = False
+        ways["exposed_comm_ms"] = round(ways["eager_allreduce_after_backward"] - ways["eager_overlap"], 3)
     if rank == 0:
         print(json.dumps({"metric": "ddpm_cifar10_32x32_train_images_per_sec", "dry_run": True, "value": None, "unit": "images/s",
                           "n_gpus": world, "rccl_ranks": int(ones.item()), "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(float(el) / args.steps * 1e3, 3), "scaling": "weak", "higher_is_better": True,
+                          "rank_ms_per_step": spread,
                           "buckets_bytes": [4 * (hi - lo) for lo, hi in red.launched] if red else [],
+                          "comm": {"ways_ms": ways, "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS")} if red else None,
+                          "dp_path_n1": ({"ms_per_step": ways["segmented_graph"], "rccl_ranks": int(ones.item())} if solo_group else None),
                           "self_launched": os.environ.get("MI_BENCH_SELF_LAUNCHED") == "1"}))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 
@@ -270,10 +351,16 @@ def main():
     ap.add_argument("--cfg", type=int, default=2, choices=[2, 3],
                     help="2 (default, the metric's configuration): CIFAR-10 32x32, UNet 128 / 1-2-4; 3: BASELINE configs[2], CelebA 64x64, "
                          "UNet 64 / 1-2-4-8 (use --batch 32 for its per-GPU batch at 8 GPUs); the line's metric name and workload say which")
+    ap.add_argument("--sweep-channels", action="store_true",
+                    help="self-launching form only: run the N-rank bench for NCCL_MAX_NCHANNELS in {default, 8, 16} and report all three")
     args = ap.parse_args()
 
+    if os.environ.get("MI_BENCH_UNSET_NCHANNELS") == "1":
+        os.environ.pop("NCCL_MAX_NCHANNELS", None)
     if args.gpus > 1 and "RANK" not in os.environ:
-        raise SystemExit(relaunch(args))
+        raise SystemExit(sweep_channels(args) if args.sweep_channels else relaunch(args))
+    if args.sweep_channels and not args.dry_run_cpu:
+        print("[bench] --sweep-channels needs the self-launching form (python bench.py --gpus N --sweep-channels, N > 1); ignored", file=sys.stderr)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -291,6 +378,8 @@ def main():
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)                           # how many ranks RCCL really connected
         rccl_ranks = int(ones.item())
+        if rccl_ranks != world:                         # a scaling number over fewer ranks than it claims is worse than no number
+            raise SystemExit(f"bench.py: RCCL connected {rccl_ranks} ranks, --gpus says {world}")
 
     from src.models.ddpm import DDPM
     from src.ops import functional as K
@@ -371,6 +460,7 @@ def main():
         loss = train_step(i)
     sync()
     elapsed = time.perf_counter() - t0
+    spread = rank_spread(elapsed, args.steps, world if use_dist else 1, dev)
     if use_dist:
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -401,6 +491,17 @@ def main():
             t = torch.tensor([comm["allreduce_ms_exposed"]], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             comm["allreduce_ms_exposed"] = round(float(t), 3)
+        # the step three ways, so that the exposed communication is a subtraction and not an inference: the timed leg above
+        # (segmented graph when it captured), eager with the all-reduces overlapped with backward, eager with the SAME buckets issued
+        # after backward
+        w_ = world if use_dist else 1
+        ways = {"segmented_graph": round(ms_per_step, 3) if use_graph else None,
+                "eager_overlap": round(timed_leg(eager_step, 20, 3, sync, w_, dev), 3)}
+        reducer.defer = True
+        ways["eager_allreduce_after_backward"] = round(timed_leg(eager_step, 20, 3, sync, w_, dev), 3)
+        reducer.defer = False
+        ways["exposed_comm_ms"] = round(ways["eager_allreduce_after_backward"] - ways["eager_overlap"], 3)
+        comm["ways_ms"] = ways
 
     # ---- denoise rate: hipGraph-replayed reverse step at B=64 (ddpm.py:520 samples 64 images)
     from src.runtime.sampler import GraphSampler
@@ -481,6 +582,30 @@ def main():
             eager_step(i)
     sync()
 
+    # ---- N = 1 through the data-parallel code path (one-rank RCCL group, bucketed reducer, segmented graph): what SCALE's N = 1
+    #      line would read if the driver launched it under torch.distributed.run, next to the plain single-process number above
+    dp_path = None
+    if world == 1 and not use_dist and not args.no_extras:
+        try:
+            from src.runtime.graphed import SegmentedGraphedTrainStep
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            one = torch.ones(1, device=dev); dist.all_reduce(one)
+            red1 = FlatGradReducer(net.flat_grads, bucket_bytes=bucket_mb << 20)
+            net.grad_ready_hook = red1.range_ready
+            opt.device_state = True
+            g1 = SegmentedGraphedTrainStep(model, opt, red1, batch)
+            ms1 = timed_leg(lambda i: g1(batch), 30, 5, torch.cuda.synchronize, 1, dev)
+            dp_path = {"value": round(B / ms1 * 1e3, 1), "ms_per_step": round(ms1, 3), "rccl_ranks": int(one.item()),
+                       "graph_segments": len(g1.segments) + 1, "buckets_bytes": [4 * (hi - lo) for lo, hi in red1.launched]}
+            del g1
+        except Exception as exc:                            # noqa: BLE001  (an extra: reported, never fatal)
+            dp_path = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        finally:
+            net.grad_ready_hook = None
+            if dist.is_initialized():
+                dist.destroy_process_group()
+
     # ---- the parity-carrying fp32 mode (exact-fp32 MFMA), a short driver-timed leg
     fp32_mode = None
     if rank == 0 and world == 1 and not args.no_extras and args.mode != "fp32":
@@ -536,7 +661,7 @@ def main():
                        "sampler": {"denoise_steps_per_sec": round(denoise_steps_per_s, 2), "batch": 64, "launch": "hipGraph replay",
                                    "tflops": round(denoise_steps_per_s * 64 * FWD_GF / 1e3, 1)},
                        "activations": "NHWC; fp32 residual stream, bf16 block- and attention-internal tensors" if args.mode == "bf16" else "fp32 NHWC", "matmul": "bf16 MFMA, fp32 accumulate" if args.mode == "bf16" else "fp32 MFMA"},
-            "rccl_ranks": rccl_ranks, "comm": comm,
+            "rccl_ranks": rccl_ranks, "rank_ms_per_step": spread, "comm": comm, "dp_path_n1": dp_path,
             "denoise_steps_per_sec": round(denoise_steps_per_s, 2), "denoise_batch": 64,
             "denoise_image_steps_per_sec": round(denoise_steps_per_s * 64, 1),
             "train_tflops": round(images_per_s * TRAIN_GF / 1e3, 1),

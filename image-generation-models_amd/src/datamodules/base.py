@@ -106,24 +106,41 @@ def materialize_uint8_shared(dataset, num_workers: int = 0, local_rank: int = 0)
     if isinstance(dataset, ArrayImageDataset) and dataset.resize is None:
         return dataset                                     # nothing to decode: every rank already holds the array it read
     import os
+    import socket
     import uuid
-    tok = [uuid.uuid4().hex if dist.get_rank() == 0 else None]
+    # node-local rank from the process group itself (LOCAL_RANK is absent under manual RANK / WORLD_SIZE launches, mp.spawn and some
+    # Slurm set-ups; falling back to the GLOBAL rank left nodes >= 1 without a writer): the first rank on each host writes
+    hosts = [None] * dist.get_world_size()
+    dist.all_gather_object(hosts, socket.gethostname())
+    rank = dist.get_rank()
+    writer = hosts.index(hosts[rank]) == rank
+    tok = [uuid.uuid4().hex if rank == 0 else None]
     dist.broadcast_object_list(tok, src=0)
     base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"mi_ddpm_u8_{tok[0]}")
-    out = None
-    if local_rank == 0:
-        out = materialize_uint8(dataset, num_workers)
-        np.save(base + "_x.npy", out.images)
-        np.save(base + "_y.npy", np.asarray(out.labels))
-    dist.barrier()                                          # the files are complete
+    out, err = None, None
+    if writer:
+        try:
+            out = materialize_uint8(dataset, num_workers)
+            np.save(base + "_x.npy", out.images)
+            np.save(base + "_y.npy", np.asarray(out.labels))
+        except Exception as exc:      # noqa: BLE001  (reported to every rank below: a bare barrier would leave the peers waiting forever)
+            err = f"{type(exc).__name__}: {exc}"
+    errs = [None] * dist.get_world_size()
+    dist.all_gather_object(errs, err)                       # the files are complete -- or every rank learns why not
     try:
+        bad = [e for e in errs if e]
+        if bad:
+            raise RuntimeError(f"materialize_uint8_shared: the decoding rank failed ({bad[0]})")
         if out is None:
             tf = dataset if isinstance(dataset, ArrayImageDataset) else dataset._tf
-            out = ArrayImageDataset(np.load(base + "_x.npy"), np.load(base + "_y.npy"), None)
-            out.normalize, out.flip = tf.normalize, tf.flip
+            if os.path.exists(base + "_x.npy") and os.path.exists(base + "_y.npy"):
+                out = ArrayImageDataset(np.load(base + "_x.npy"), np.load(base + "_y.npy"), None)
+                out.normalize, out.flip = tf.normalize, tf.flip
+            else:                                           # (hosts that share a name but not /dev/shm: decode here after all)
+                out = materialize_uint8(dataset, num_workers)
     finally:
         dist.barrier()                                      # every rank has read them
-        if local_rank == 0:
+        if writer:
             for suffix in ("_x.npy", "_y.npy"):
                 try:
                     os.remove(base + suffix)

@@ -37,13 +37,17 @@ class FlatGradReducer:
         # stream capture of a step (src/runtime/graphed.py): a bucket that is ready is handed to this callable instead of being
         # all-reduced -- the capture is cut there and the collective is issued between the replays of the two segments
         self.capture_sink = None
+        # measurement switch (bench.py): the same buckets, but every collective is issued by finish() -- i.e. AFTER backward, nothing
+        # overlapped -- so that (this step time) - (the overlapped step time) is the communication the overlap hides
+        self.defer = False
+        self._deferred: List[tuple] = []
 
     @property
     def grad_scale(self) -> float:
         return 1.0 / self.world
 
     def begin(self):
-        self._works.clear(); self.launched.clear()
+        self._works.clear(); self.launched.clear(); self._deferred.clear()
         self._lo = self._hi = None
         self._covered = 0
         self._tail_sent = False
@@ -58,6 +62,8 @@ class FlatGradReducer:
         self.launched.append((lo, hi))
         if self.capture_sink is not None:
             self.capture_sink(lo, hi)
+        elif self.defer:
+            self._deferred.append((lo, hi))
         elif self.world > 1:
             self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -91,6 +97,9 @@ class FlatGradReducer:
         if self._lo is not None:
             self._lo = 0
             self._launch()
+        for lo, hi in self._deferred:
+            self.all_reduce_async(lo, hi)
+        self._deferred.clear()
         for w in self._works:
             w.wait()
         self._works.clear()

@@ -92,13 +92,34 @@ class SegmentedGraphedTrainStep:
         self.logged = {}
 
     def _begin(self):
-        self._cur = torch.cuda.CUDAGraph()
+        try:
+            self._cur = torch.cuda.CUDAGraph(keep_graph=True)     # (the captured hipGraph_t stays readable: _node_count)
+        except TypeError:
+            self._cur = torch.cuda.CUDAGraph()
         self._cur.capture_begin(pool=self.pool)
 
+    @staticmethod
+    def _node_count(g):
+        """Nodes of a captured graph (hipGraphGetNodes on the kept hipGraph_t), None when it cannot be read."""
+        try:
+            import ctypes
+            raw = g.raw_cuda_graph()
+            hip = ctypes.CDLL("libamdhip64.so")
+            n = ctypes.c_size_t(0)
+            rc = hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n))
+            return int(n.value) if rc == 0 else None
+        except Exception:       # noqa: BLE001
+            return None
+
     def _end(self, rng):
-        # every captured segment is kept and replayed, whatever it holds (library launches, torch fills / copies / random draws):
-        # deciding "empty" from the library's launch counter would silently drop a segment of torch-only ops
+        # every captured segment that HOLDS something is kept and replayed, whatever it holds (library launches, torch fills / copies /
+        # random draws): deciding "empty" from the library's launch counter would silently drop a segment of torch-only ops.  The one
+        # segment that can be truly empty is the trailing one without a bucket (the last bucket was cut inside backward and finish()
+        # had nothing left to flush): it is dropped only when the captured graph itself reports zero nodes.
         self._cur.capture_end()
+        if rng is None and self._node_count(self._cur) == 0:
+            self._cur = None
+            return
         self.segments.append((self._cur, rng))
         self._cur = None
 

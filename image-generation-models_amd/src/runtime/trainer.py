@@ -228,16 +228,26 @@ class Trainer:
                     # step 0 ran eagerly (lazy module loads, workspaces, Adam state); capture on this batch and replay it once
                     from .graphed import GraphedTrainStep, SegmentedGraphedTrainStep
                     model._logged.clear()
+                    cap_exc = None
                     try:
                         gstep = (SegmentedGraphedTrainStep(model, optimizer, self._reducer, batch) if self._reducer is not None
                                  else GraphedTrainStep(model, optimizer, batch, warmup=0))
                     except Exception as exc:      # noqa: BLE001  (automatic mode: an uncapturable step stays eager, loudly)
+                        cap_exc = exc
+                    # every rank must run the same KIND of step (the replayed segments and the eager autograd path issue their bucket
+                    # all-reduces from different places): one failed capture anywhere puts every rank on the eager path
+                    failed = self._any_rank(cap_exc is not None, device)
+                    if failed:
                         if self.graph_step:
-                            raise
-                        print(f"[trainer] hipGraph capture of the training step failed ({type(exc).__name__}: {exc}); continuing eagerly",
-                              flush=True)
+                            raise cap_exc if cap_exc is not None else RuntimeError("hipGraph capture failed on another rank")
+                        why = f"{type(cap_exc).__name__}: {cap_exc}" if cap_exc is not None else "failed on another rank"
+                        print(f"[trainer] hipGraph capture of the training step failed ({why}); continuing eagerly", flush=True)
                         use_graph, gstep = False, None
                         torch.cuda.synchronize()
+                        # what the aborted capture recorded never ran: derived state keyed on the parameters (bf16 weight copies, ...) is
+                        # stale although its keys say otherwise -- rebuild it before the eager step reads it
+                        for n_ in getattr(optimizer, "nets", []):
+                            n_.mark_params_dirty()
                         optimizer.zero_grad()
                         if self._reducer is not None:
                             self._reducer.begin()
@@ -286,6 +296,16 @@ class Trainer:
                 break
         if self.enable_checkpointing and self.is_global_zero and not self.checkpoint_callback.best_model_path:
             self.save_checkpoint(os.path.join(self.default_root_dir, "checkpoints", "last.ckpt"), model)
+
+    @staticmethod
+    def _any_rank(flag: bool, device) -> bool:
+        """True when `flag` holds on ANY rank (a MAX all-reduce; single process: the flag itself)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(int(t.item()))
 
     @torch.no_grad()
     def _validate(self, model, loader, device, limit=None):

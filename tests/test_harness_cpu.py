@@ -294,6 +294,36 @@ def test_bench_self_launches_ranks_without_torchrun():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["self_launched"] and out["dry_run"] and out["steps"] == 3
     assert out["buckets_bytes"] and out["scaling"] == "weak"
+    # round 5 (what the first 8-GPU minute must answer by itself): per-rank step times, the step three ways
+    sp = out["rank_ms_per_step"]
+    assert len(sp["per_rank"]) == 2 and sp["min"] <= sp["max"] and abs(sp["max"] - out["ms_per_step"]) < 1.0
+    ways = out["comm"]["ways_ms"]
+    assert set(ways) == {"segmented_graph", "eager_overlap", "eager_allreduce_after_backward", "exposed_comm_ms"}
+    assert all(isinstance(v, float) for v in ways.values())
+
+
+def test_bench_dry_run_n1_runs_the_data_parallel_path_and_the_channel_sweep_relaunches():
+    """N = 1 also reports a leg through the data-parallel code path (one-rank group); `--sweep-channels` runs the N-rank bench once
+    per NCCL_MAX_NCHANNELS in {default, 8, 16} and prints ONE line that carries all three."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NCCL_MAX_NCHANNELS")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run-cpu", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["dp_path_n1"]["rccl_ranks"] == 1 and out["dp_path_n1"]["ms_per_step"] > 0
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--sweep-channels", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    sw = out["channel_sweep"]
+    assert [e["NCCL_MAX_NCHANNELS"] for e in sw] == ["default", "8", "16"] and all("error" not in e and e["ms_per_step"] > 0 for e in sw), sw
+    assert out["n_gpus"] == 2 and out["comm"]["NCCL_MAX_NCHANNELS"] is None
 
 
 def test_wgrad_queue_flushed_is_a_prefix_not_a_count():

@@ -251,11 +251,22 @@ def test_ddpm_graphed_training_step(mode):
     assert err_g <= 2 * noise_g + floor_g, (err_g, noise_g)
     assert err_w <= 2 * noise_w + floor_w, (err_w, noise_w)
     # the curve: finite and falling on the fixed batch
-    curve = [lb] + [float(gs((x, None))) for _ in range(15)]
+    w_before = net.flat_params.clone()
+    curve, moved = [lb], []
+    for _ in range(15):
+        w_prev = net.flat_params.clone()
+        curve.append(float(gs((x, None))))
+        moved.append(float((net.flat_params - w_prev).abs().mean()))
     assert o1.device_step_count() == 18
+    # every replay applied Adam with fresh gradients: each one moves the weights by about lr per element (lr = 2e-3; a replay with a
+    # stale step count, stale gradients or no optimizer launch moves them by ~0 or by a bias-correction blow-up), and fifteen steps on
+    # one batch add up instead of cancelling
+    assert all(2e-4 < d < 4e-3 for d in moved), moved
+    assert float((net.flat_params - w_before).abs().mean()) > 3 * max(moved), (moved, float((net.flat_params - w_before).abs().mean()))
     # (every step draws fresh t / eps, so the curve is noisy: "some later step is below the first one" is the property that held on every
     #  box; "the last six are" failed once in round 4 on an unchanged fp32 path and passed on the next box)
     assert all(torch.isfinite(torch.tensor(curve))) and min(curve[1:]) < curve[0], curve
+    assert sum(curve[-5:]) / 5 < 0.97 * sum(curve[:5]) / 5, curve       # ... and the averaged curve falls (lr = 2e-3 on one batch)
     # an eager forward after the replays must use the replayed weights
     net = net.eval()
     t = torch.full((16,), 10, device=DEV, dtype=torch.long)
