@@ -547,7 +547,7 @@ def main():
         sym, (fl, sec, cnt, nb) = max(agg.items(), key=lambda kv: kv[1][1])          # the symbol with the most time per step
         peak = PEAK_TFLOPS[args.mode]
         traffic, tnote, tstale = None, None, None
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC passes are separate runs (profiles/)
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC passes are separate runs (profiles/)
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     ent = json.load(f).get(sym)
@@ -669,7 +669,14 @@ def main():
             "final_loss": round(final_loss, 5),
             "roofline": roof, "fp32_mode": fp32_mode, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        # (RCCL writes its version banner through C stdio, which is flushed at exit -- i.e. AFTER a line printed from Python: flush it
+        #  first so that the JSON line is the last line of the output)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:       # noqa: BLE001
+            pass
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -3,7 +3,7 @@ image-generation-models_amd/src/models/ddpm.py) against (a) golden vectors captu
 reference and (b) the CPU oracle on the same seeded inputs.
 Stated tolerances: epsilon-prediction rel-L2 <= 1e-4 in exact-fp32 mode (north_star; measured 3e-6); parameter gradients
 rel-L2 <= 1e-3 in fp32 mode (fp32 atomics reorder sums; measured 4e-6).  The bf16-MFMA mode's tolerances are each <= 2x the
-worst error MEASURED on the MI355X and recorded by these tests in profiles/r04_parity.json (rule checked by tests/test_host_cpu.py) (epsilon 0.9-1.1e-2 -> 2e-2; loss
+worst error MEASURED on the MI355X and recorded by these tests in profiles/r05_parity.json (rule checked by tests/test_host_cpu.py) (epsilon 0.9-1.1e-2 -> 2e-2; loss
 3e-5..7e-5 -> 2e-4; per-tensor gradient rel-L2 0.05-0.10 -> 0.1-0.2; whole flat gradient 1.5e-2 -> 3e-2); the reference itself
 under CPU bf16 autocast sits at 1.6e-2 on the epsilon prediction."""
 import os
@@ -16,6 +16,10 @@ from _parity import record
 from _util import DEV, rel_err
 
 pytestmark = pytest.mark.gpu
+
+# ONE fixed requirement for the bf16-MFMA mode, above the "bound <= 2x measured" regression guards: the epsilon prediction may be no
+# further from the reference than the reference itself is under CPU bf16 autocast (1.6e-2 relative L2)
+BF16_EPS_BUDGET = 1.6e-2
 
 
 def _t(a):
@@ -194,6 +198,7 @@ def test_mid_unet_golden(golden_dir, mode, tol, gtol):
     norms = np.array([float(p.grad.double().norm()) for p in net.parameters()])
     ref = g["gradnorm_all"]
     e_norm = float(np.max(np.abs(norms - ref) / np.maximum(ref, 1e-6 + 0.01 * ref.max())))
+    assert mode != "bf16" or e_eps <= BF16_EPS_BUDGET, e_eps
     record(f"mid_unet_golden_{mode}", eps_rel_l2=e_eps, loss_abs=e_loss, worst_grad_rel_l2=max(gerr.values()),
            worst_grad_key=max(gerr, key=gerr.get), worst_gradnorm_rel=e_norm,
            bounds={"eps_rel_l2": tol, "worst_grad_rel_l2": gtol, "worst_gradnorm_rel": 1e-4 if mode == "fp32" else 8.5e-2})
@@ -228,6 +233,7 @@ def test_cfg2_eps_prediction_golden(golden_dir, mode, tol):
     e_norm = float(np.max(np.abs(norms - ref) / np.maximum(ref, 1e-6 + 0.01 * ref.max())))
     e_g1 = rel_err(dict(net.named_parameters())["final_conv.1.weight"].grad, _t(g["grad.final_conv.1.weight"]))
     e_g2 = rel_err(dict(net.named_parameters())["time_mlp.3.bias"].grad, _t(g["grad.time_mlp.3.bias"]))
+    assert mode != "bf16" or e_eps <= BF16_EPS_BUDGET, e_eps
     record(f"cfg2_eps_prediction_golden_{mode}", eps_rel_l2=e_eps, loss_abs=e_loss, worst_gradnorm_rel=e_norm,
            grad_final_conv_rel_l2=e_g1, grad_time_mlp3_bias_rel_l2=e_g2, bounds={"eps_rel_l2": tol})
     assert e_eps < tol
@@ -353,7 +359,7 @@ def test_cfg3_per_gpu_batch_properties():
     assert out["fp32_forward_rerun_rel_l2"] == 0.0 and out["bf16_forward_rerun_rel_l2"] == 0.0
     assert out["fp32_forward_slice_vs_full_rel_l2"] < 1e-5 and out["fp32_rerun_rel_l2"] < 1e-6 and out["bf16_rerun_rel_l2"] < 1e-6
     assert out["fp32_slices_vs_full_rel_l2"] < 1e-6
-    # bf16 bounds <= 2x the values measured on the MI355X (profiles/r04_parity.json): 1.02e-2, 5.9e-3, 1.17e-2, 8.1e-3
+    # bf16 bounds <= 2x the values measured on the MI355X (profiles/r05_parity.json): 1.02e-2, 5.9e-3, 1.17e-2, 8.1e-3
     assert out["bf16_forward_slice_vs_full_rel_l2"] < 2e-2       # slices pick other kernel plans (tile sizes) than the full batch
     assert out["bf16_slices_vs_full_rel_l2"] < 1.2e-2
     assert out["bf16_vs_fp32_eps_rel_l2"] < 2.3e-2 and out["bf16_vs_fp32_flat_grad_rel_l2"] < 1.6e-2
@@ -558,6 +564,7 @@ def test_cfg3_celeba_shape_vs_oracle(mode, tol, gtol):
         errs[k] = float((q.grad.cpu() - r).norm()) / (float(r.norm()) + 1e-3 * scale * r.numel() ** 0.5)
     flat_ref = torch.cat([p[k].grad.flatten() for k, _ in net.named_parameters()])
     flat_got = torch.cat([q.grad.detach().cpu().flatten() for _, q in net.named_parameters()])
+    assert mode != "bf16" or e_eps <= BF16_EPS_BUDGET, e_eps
     record(f"cfg3_celeba_shape_vs_oracle_{mode}", eps_rel_l2=e_eps, loss_abs=e_loss, worst_grad_rel_l2=max(errs.values()),
            worst_grad_key=max(errs, key=errs.get), whole_grad_rel_l2=rel_err(flat_got, flat_ref),
            bounds={"eps_rel_l2": tol, "worst_grad_rel_l2": gtol, "whole_grad_rel_l2": 1e-4 if mode == "fp32" else 2.6e-2})
@@ -660,6 +667,7 @@ def test_bf16_block_storage_end_to_end(golden_dir):
     loss3 = gd.p_losses(x, t, noise)
     loss3.backward()
     e_full = rel_err(g16, net.flat_grads)
+    assert e_eps <= BF16_EPS_BUDGET, e_eps
     record("cfg2_bf16_block_storage", eps_rel_l2=e_eps, loss_abs=e_loss, flat_grad_rel_l2_vs_fp32_storage=e_sto,
            flat_grad_rel_l2_vs_fp32_mode=e_full,
            bounds={"eps_rel_l2": 2.1e-2, "loss_abs": 1.5e-4, "flat_grad_rel_l2_vs_fp32_storage": 7.2e-2, "flat_grad_rel_l2_vs_fp32_mode": 7.9e-2})

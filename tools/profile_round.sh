@@ -4,7 +4,7 @@
 #  2. the same over 10 bare training steps (per-kernel ms/step), and over cfg 3 at B=32
 #  3. PMC passes (separate runs, never combined with trace domains other than --kernel-trace): HBM traffic (FETCH_SIZE /
 #     WRITE_SIZE) of the dominant kernels on their cfg-2 shapes and the SQ / TCC sets of tools/pmc.sh
-tag=${1:-r04}
+tag=${1:-r05}
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $OUT
