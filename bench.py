@@ -249,15 +249,19 @@ def dry_run_cpu(args, world, rank):
         dist.destroy_process_group()
 
 
-def named_kernel_line(K, dev):
+def named_kernel_line(K, dev, N=128, H=32, W=32, Cc=128):
     """north_star's named unit at its canonical shape: GroupNorm-apply + Mish (+ time bias) + Conv3x3 on
     X = [128,32,32,128] NHWC -> 128 channels, level 0 of cfg 2, for both activation storages of the bf16-MFMA mode.  Every entry's
     `unit_us` is EVERYTHING the unit needs, timed with HIP events on the launch stream (median of 20): the two-pass unit = GroupNorm
     kernel + conv; a fused unit = the fused conv + whatever produces its statistics (a statistics pass over the tensor, or what the
     sums cost the PRODUCING conv's epilogue: that conv timed with and without them); the single fused launch is reported beside it as
     `fused_launch_us`.  hbm_frac = algorithmic bytes / unit time / 8 TB/s, mfma_frac = 38.65 GFLOP / unit time / 2.5 PFLOP/s."""
-    out = {"shape": "[128,32,32,128] NHWC -> 128, 3x3/s1/p1", "gflop": NAMED_GFLOP}
-    N, H, W, Cc = 128, 32, 32, 128
+    canonical = (N, H, W, Cc) == (128, 32, 32, 128)
+    gflop = NAMED_GFLOP if canonical else round(2.0 * N * H * W * Cc * Cc * 9 / 1e9, 2)
+    # algorithmic bytes: x in + y out in the storage type, the bf16 weights, the [3][N][C] coefficients
+    mb = NAMED_MB if canonical else {k: round((N * H * W * Cc * 2 * e + 9 * Cc * Cc * 2 + 3 * N * Cc * 4) / 1e6, 1) for k, e in (("fp32", 4), ("bf16", 2))}
+    out = {"shape": f"[{N},{H},{W},{Cc}] NHWC -> {Cc}, 3x3/s1/p1", "gflop": gflop}
+    sums_ok = (Cc // 8) % 16 == 0            # the epilogue's sums are per 16-channel slab: groups of >= 16 channels
     g = torch.Generator(device=dev).manual_seed(7)
     gamma = torch.ones(Cc, device=dev); beta = torch.zeros(Cc, device=dev)
     temb = torch.randn(N, Cc, device=dev, generator=g) * 0.1
@@ -291,29 +295,35 @@ def named_kernel_line(K, dev):
         sums = K.gn_sums_encode(torch.stack([xs.sum((1, 3)), (xs * xs).sum((1, 3))], dim=-1))       # what c1's producer would have left
         scratch = torch.zeros_like(sums)                                       # the timed producer adds into this one
         gn = (sums, gamma, beta, temb, 8, 1e-5)
+        if K.conv3x3_gn_mish(x, K.gn_stats_coef(x, gamma, beta, temb=temb)[1], w, K=Cc, Nc=Cc, bias=bias, wq=wq) is None:
+            out[sto + "_storage"] = {"unsupported": "no fused GroupNorm + Mish + conv kernel takes this shape"}
+            continue
         stats, coef = K.gn_stats_coef(x, gamma, beta, temb=temb)
         hbuf = [None]
 
         def gn_pass():
             hbuf[0], _ = K.gn_mish_fwd(x, gamma, beta, temb=temb, out_dtype=dt)
         gn_pass()
-        md, syms = timed({
+        legs = {
             "gn": gn_pass,
             "conv": lambda: K.conv3x3_bf16w(hbuf[0], w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt, wq=wq),
             "stats": lambda: K.gn_stats_coef(x, gamma, beta, temb=temb),
             "fused_coef": lambda: K.conv3x3_gn_mish(x, coef, w, K=Cc, Nc=Cc, bias=bias, wq=wq),
-            "fused_sums": lambda: K.conv3x3_gn_mish(x, None, w, K=Cc, Nc=Cc, bias=bias, gn=gn, wq=wq),
-            "producer": lambda: K.conv3x3_bf16w(xin, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt, wq=wq),
-            "producer_sums": lambda: K.conv3x3_bf16w(xin, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt, gn_sums=scratch, wq=wq),
-        })
+        }
+        if sums_ok:
+            legs.update({
+                "fused_sums": lambda: K.conv3x3_gn_mish(x, None, w, K=Cc, Nc=Cc, bias=bias, gn=gn, wq=wq),
+                "producer": lambda: K.conv3x3_bf16w(xin, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt, wq=wq),
+                "producer_sums": lambda: K.conv3x3_bf16w(xin, w, K=Cc, Nc=Cc, flip=False, ksize=3, bias=bias, out_dtype=dt, gn_sums=scratch, wq=wq)})
+        md, syms = timed(legs)
 
         def line(us):
-            return {"unit_us": round(us, 2), "algorithmic_mb": NAMED_MB[sto],
-                    "hbm_gbs": round(NAMED_MB[sto] * 1e6 / (us * 1e-6) / 1e9, 1),
-                    "hbm_frac": round(NAMED_MB[sto] * 1e6 / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
-                    "tflops": round(NAMED_GFLOP * 1e9 / (us * 1e-6) / 1e12, 1),
-                    "mfma_frac": round(NAMED_GFLOP * 1e9 / (us * 1e-6) / 1e12 / PEAK_TFLOPS["bf16"], 4)}
-        sums_cost = max(md["producer_sums"] - md["producer"], 0.0)
+            return {"unit_us": round(us, 2), "algorithmic_mb": mb[sto],
+                    "hbm_gbs": round(mb[sto] * 1e6 / (us * 1e-6) / 1e9, 1),
+                    "hbm_frac": round(mb[sto] * 1e6 / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+                    "tflops": round(gflop * 1e9 / (us * 1e-6) / 1e12, 1),
+                    "mfma_frac": round(gflop * 1e9 / (us * 1e-6) / 1e12 / PEAK_TFLOPS["bf16"], 4)}
+        sums_cost = max(md["producer_sums"] - md["producer"], 0.0) if sums_ok else 0.0
         ent = {"two_pass": dict(launches_us={syms["gn"][0]: round(md["gn"], 2), syms["conv"][0]: round(md["conv"], 2)},
                                 **line(md["gn"] + md["conv"])),
                # statistics by a pass over c1 (mi_gn_stats_coef), then the fused conv fed by the coefficient tensor
@@ -321,11 +331,14 @@ def named_kernel_line(K, dev):
                              statistics_pass_us=round(md["stats"], 2), **line(md["fused_coef"] + md["stats"])),
                # statistics from the producing conv's epilogue, coefficients resolved inside the fused kernel: Block -> Block is two
                # launches; the unit = the fused launch + what the sums add to the producer
-               "fused_epilogue_stats": dict(kernel=syms["fused_sums"][-1], fused_launch_us=round(md["fused_sums"], 2),
-                                            producer_conv=syms["producer_sums"][-1], producer_conv_us=round(md["producer"], 2),
-                                            producer_conv_with_sums_us=round(md["producer_sums"], 2),
-                                            statistics_cost_us=round(sums_cost, 2), **line(md["fused_sums"] + sums_cost))}
+               "fused_epilogue_stats": (dict(kernel=syms["fused_sums"][-1], fused_launch_us=round(md["fused_sums"], 2),
+                                             producer_conv=syms["producer_sums"][-1], producer_conv_us=round(md["producer"], 2),
+                                             producer_conv_with_sums_us=round(md["producer_sums"], 2),
+                                             statistics_cost_us=round(sums_cost, 2), **line(md["fused_sums"] + sums_cost))
+                                        if sums_ok else {"unsupported": "groups of fewer than 16 channels: no per-slab sums"})}
         out[sto + "_storage"] = ent
+    if not canonical:
+        return out
     out["default_path"] = ("bf16 storage; inference: fused_epilogue_stats wherever the private-weight-stream kernel takes block2's conv "
                            "(Unet.fuse_gn_conv = 'auto'), training: two_pass (block2's weight gradient reads the normalised tensor)")
     return out
@@ -577,6 +590,11 @@ def main():
                 "all_kernels": table}
         if not args.no_extras and args.cfg == 2:
             roof["named_kernel"] = named_kernel_line(K, dev)
+            # ... and at the one shape of the benchmarked configurations that SURVEY 8(d)(iv) calls HBM-bound: cfg 3's first level
+            try:
+                roof["named_kernel_cfg3_level0"] = named_kernel_line(K, dev, 32, 64, 64, 64)
+            except Exception as exc:                        # noqa: BLE001  (an extra entry: reported, never fatal)
+                roof["named_kernel_cfg3_level0"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     elif world > 1:
         for i in range(3):
             eager_step(i)

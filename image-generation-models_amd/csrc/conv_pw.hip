@@ -141,6 +141,22 @@ template <int DIR> __device__ __forceinline__ bf16x8 pw_shift(const bf16x8& c, u
     return __builtin_bit_cast(bf16x8, o);
 }
 
+// the same shift for the pinned loop, where the result is consumed one row unit (>= 4 MFMAs) later: no wait states inside, and HALF = 0 / 1
+// makes registers 0-1 / 2-3 only, so that a gap carries two DPP instructions instead of four (+ s_nop)
+template <int DIR, int HALF> __device__ __forceinline__ void pw_shift_h(u32x4& o, const bf16x8& c, uint32_t mask) {
+    const u32x4 v = __builtin_bit_cast(u32x4, c);
+    uint32_t a0, a1;
+    if constexpr (DIR == 0)
+        asm("v_and_b32_dpp %0, %2, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_and_b32_dpp %1, %3, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+            : "=&v"(a0), "=&v"(a1) : "v"(v[2 * HALF]), "v"(v[2 * HALF + 1]), "v"(mask));
+    else
+        asm("v_and_b32_dpp %0, %2, %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_and_b32_dpp %1, %3, %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+            : "=&v"(a0), "=&v"(a1) : "v"(v[2 * HALF]), "v"(v[2 * HALF + 1]), "v"(mask));
+    o[2 * HALF] = a0; o[2 * HALF + 1] = a1;
+}
+
 constexpr int pw_lds(int pt, bool raw = false) { return (pt == 256 ? 128 : pt == 128 ? (raw ? 72 : 64) : (raw ? 48 : 32)) * 1024 + 2048; }   // two activation buffers (24 / 16 KB each) under the epilogue's fp32 tile (+ the GroupNorm sums' 512 bytes); raw: + the fp32 staging area of the fp32-input variants (24 / 16 KB behind the tiles)
 
 // VAR 0: the plain conv.  VAR 1: the epilogue also accumulates the GroupNorm sums of the NEXT layer (a.gsum).  VAR 2 / 3: the named
@@ -703,9 +719,23 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
             const uint32_t off = ((pvalid >> i) & 1u) ? (uint32_t)((ch & 1) * PXBUF + 4 * i * 1024) : (uint32_t)(DUMP - wv * 1024);
             *(lds_u32x4s*)(uintptr_t)(wbase + off) = RS[b][j];
         };
-        bf16x8 Ac, Bc, Al, Bl, Ar, Br, C[CN], L[2], R[2];
+        bf16x8 Ac, Bc, C[CN];
+        u32x4 Al, Bl, Ar, Br, L[2], R[2];                      // shifted fragments (registers written two at a time: pw_shift_h)
+        // A shift is four DPP instructions; from three blocks per wave up it is issued as two halves in two consecutive gaps (a gap then
+        // carries at most two DPP instructions + one memory instruction), and never needs wait states: its consumer is a unit away.
+        constexpr bool HALVES = BH >= 3;
+        auto sh = [&](u32x4& dst, const bf16x8& src, auto dirc, auto slotc) {         // slot 0 / 1: lower / upper register pair
+            constexpr int dir = decltype(dirc)::value, slot = decltype(slotc)::value;
+            if constexpr (MI_PW_PABL & 8) { dst = __builtin_bit_cast(u32x4, src); }
+            else if constexpr (HALVES) pw_shift_h<dir, slot>(dst, src, dir == 0 ? mask_l : mask_r);
+            else if constexpr (slot == 0) { pw_shift_h<dir, 0>(dst, src, dir == 0 ? mask_l : mask_r); pw_shift_h<dir, 1>(dst, src, dir == 0 ? mask_l : mask_r); }
+        };
+        constexpr std::integral_constant<int, 0> I0{}; constexpr std::integral_constant<int, 1> I1{};
+        // gap (within a unit) of shift part q = 0 .. 3 (left lower, left upper, right lower, right upper); -1: folded into its lower half
+        auto sgap = [](int q) constexpr -> int { return HALVES ? 1 + q : (q == 0 ? 1 : q == 2 ? 2 : -1); };
         Ac = lds_b128p(xr[0]); Bc = lds_b128p(xr[BH + 1]); C[1 % CN] = lds_b128p(xr[1]);
-        Al = pw_shift<0>(Ac, mask_l); Bl = pw_shift<0>(Bc, mask_l); Ar = pw_shift<1>(Ac, mask_r); Br = pw_shift<1>(Bc, mask_r);
+        pw_shift_h<0, 0>(Al, Ac, mask_l); pw_shift_h<0, 1>(Al, Ac, mask_l); pw_shift_h<0, 0>(Bl, Bc, mask_l); pw_shift_h<0, 1>(Bl, Bc, mask_l);
+        pw_shift_h<1, 0>(Ar, Ac, mask_r); pw_shift_h<1, 1>(Ar, Ac, mask_r); pw_shift_h<1, 0>(Br, Bc, mask_r); pw_shift_h<1, 1>(Br, Bc, mask_r);
         __builtin_amdgcn_sched_barrier(0);
         MI_PW_STAMP(4, 3);
         for (int ch = 0; ch < nchunks; ++ch) {
@@ -721,8 +751,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
                     constexpr int i = decltype(ic)::value, tp = decltype(tapc)::value;
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WB[cur][tp]), xf, acc[i], 0, 0, 0);
                 };
-                auto pw_shift0 = [&](const bf16x8& c, uint32_t m) { if constexpr (MI_PW_PABL & 8) return c; else return pw_shift<0>(c, m); };
-                auto pw_shift1 = [&](const bf16x8& c, uint32_t m) { if constexpr (MI_PW_PABL & 8) return c; else return pw_shift<1>(c, m); };
+                auto mmu = [&](auto ic, auto tapc, const u32x4& xf) { mm(ic, tapc, __builtin_bit_cast(bf16x8, xf)); };
                 // what rides in gap g of the step besides the unit's own preparation: fragment requests, then piece requests
                 auto gside = [&](auto gc) {
                     constexpr int g = decltype(gc)::value;
@@ -737,18 +766,25 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
                     if constexpr (RST && ks >= 2 && (g & 1) && g / 2 < PPS && PPS * (ks - 2) + g / 2 < PXPW)
                         rs_store(ch + 1, std::integral_constant<int, ks - 2>{}, std::integral_constant<int, g / 2>{});
                 };
-                // ---- unit 0: rows 0 (output row 0, tap row 0) and BH + 1 (output row BH - 1, tap row 2)
+                // ---- unit 0: rows 0 (output row 0, tap row 0) and BH + 1 (output row BH - 1, tap row 2); it reads row 2 and shifts row 1
                 {
                     MI_PW_STAMP(ks, ch * (BH + 1));
-#define MI_G(J, I, KY, KX, XF, SIDE) do { mm(std::integral_constant<int, I>{}, std::integral_constant<int, (KY) * 3 + (KX)>{}, XF); SIDE; \
-                                          gside(std::integral_constant<int, (J)>{}); __builtin_amdgcn_sched_barrier(0); } while (0)
-                    MI_G(0, 0, 0, 1, Ac, C[2 % CN] = lds_b128p((xr[2] ^ kx32) + xcur));
-                    MI_G(1, BH - 1, 2, 1, Bc, L[1] = pw_shift0(C[1 % CN], mask_l));
-                    MI_G(2, 0, 0, 0, Al, R[1] = pw_shift1(C[1 % CN], mask_r));
-                    MI_G(3, BH - 1, 2, 0, Bl, (void)0);
-                    MI_G(4, 0, 0, 2, Ar, (void)0);
-                    MI_G(5, BH - 1, 2, 2, Br, (void)0);
-#undef MI_G
+                    static_for<0, 6>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        if constexpr (j == 0) mm(std::integral_constant<int, 0>{}, std::integral_constant<int, 0 * 3 + 1>{}, Ac);
+                        if constexpr (j == 1) mm(std::integral_constant<int, BH - 1>{}, std::integral_constant<int, 2 * 3 + 1>{}, Bc);
+                        if constexpr (j == 2) mmu(std::integral_constant<int, 0>{}, std::integral_constant<int, 0 * 3 + 0>{}, Al);
+                        if constexpr (j == 3) mmu(std::integral_constant<int, BH - 1>{}, std::integral_constant<int, 2 * 3 + 0>{}, Bl);
+                        if constexpr (j == 4) mmu(std::integral_constant<int, 0>{}, std::integral_constant<int, 0 * 3 + 2>{}, Ar);
+                        if constexpr (j == 5) mmu(std::integral_constant<int, BH - 1>{}, std::integral_constant<int, 2 * 3 + 2>{}, Br);
+                        if constexpr (j == 0) C[2 % CN] = lds_b128p((xr[2] ^ kx32) + xcur);
+                        if constexpr (j == sgap(0)) sh(L[1], C[1 % CN], I0, I0);
+                        if constexpr (j == sgap(1)) sh(L[1], C[1 % CN], I0, I1);
+                        if constexpr (j == sgap(2)) sh(R[1], C[1 % CN], I1, I0);
+                        if constexpr (j == sgap(3)) sh(R[1], C[1 % CN], I1, I1);
+                        gside(jc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
                 }
                 // ---- units 1 .. BH: row u feeds output rows u - ky (tap row ky)
                 static_for<1, BH + 1>([&](auto uc) {
@@ -766,31 +802,38 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
                     }
                     static_for<0, 3 * n>([&](auto jc) {
                         constexpr int j = decltype(jc)::value, kxi = j / n, ky = ky0 + j % n, kx = kxi == 0 ? 1 : kxi == 1 ? 0 : 2;
-                        const bf16x8& xf = kx == 1 ? C[u % CN] : kx == 0 ? L[u & 1] : R[u & 1];
-                        mm(std::integral_constant<int, u - ky>{}, std::integral_constant<int, ky * 3 + kx>{}, xf);
+                        if constexpr (kx == 1) mm(std::integral_constant<int, u - ky>{}, std::integral_constant<int, ky * 3 + kx>{}, C[u % CN]);
+                        else mmu(std::integral_constant<int, u - ky>{}, std::integral_constant<int, ky * 3 + kx>{}, kx == 0 ? L[u & 1] : R[u & 1]);
                         if constexpr (j == 0) {
                             if constexpr (u + 2 <= BH) C[(u + 2) % CN] = lds_b128p((xr[u + 2 <= BH ? u + 2 : 0] ^ kx32) + xcur);
                             else if constexpr (u == BH - 1) { Ac = lds_b128p((xr[0] ^ kxn) + bufn); Bc = lds_b128p((xr[BH + 1] ^ kxn) + bufn); }
                             else C[1 % CN] = lds_b128p((xr[1] ^ kxn) + bufn);
                         }
-                        // (the next step's unit 0 needs four shifts: from three blocks per wave up, two of them ride in the spare gaps
-                        //  of unit BH - 1 -- its rows were read in that unit's first gap -- so that the last unit, six MFMAs, carries three
-                        //  side operations like every other unit)
+                        // the shifts of unit u + 1's row; the last unit prepares the next step's unit 0 (four shifts: from three blocks per
+                        // wave up the two left ones ride in the spare gaps of unit BH - 1, whose first gap read those rows)
                         constexpr bool SPLIT0 = BH >= 3;
-                        if constexpr (j == 1) {
-                            if constexpr (u < BH) L[(u + 1) & 1] = pw_shift0(C[(u + 1) % CN], mask_l);
-                            else if constexpr (SPLIT0) Ar = pw_shift1(Ac, mask_r);
-                            else Al = pw_shift0(Ac, mask_l);
+                        if constexpr (u < BH) {
+                            if constexpr (j == sgap(0)) sh(L[(u + 1) & 1], C[(u + 1) % CN], I0, I0);
+                            if constexpr (j == sgap(1)) sh(L[(u + 1) & 1], C[(u + 1) % CN], I0, I1);
+                            if constexpr (j == sgap(2)) sh(R[(u + 1) & 1], C[(u + 1) % CN], I1, I0);
+                            if constexpr (j == sgap(3)) sh(R[(u + 1) & 1], C[(u + 1) % CN], I1, I1);
+                            if constexpr (SPLIT0 && u == BH - 1) {
+                                if constexpr (j == 5) sh(Al, Ac, I0, I0);
+                                if constexpr (j == 6) sh(Al, Ac, I0, I1);
+                                if constexpr (j == 7) sh(Bl, Bc, I0, I0);
+                                if constexpr (j == 8) sh(Bl, Bc, I0, I1);
+                            }
+                        } else if constexpr (SPLIT0) {
+                            if constexpr (j == 1) sh(Ar, Ac, I1, I0);
+                            if constexpr (j == 2) sh(Ar, Ac, I1, I1);
+                            if constexpr (j == 3) sh(Br, Bc, I1, I0);
+                            if constexpr (j == 4) sh(Br, Bc, I1, I1);
+                        } else {
+                            if constexpr (j == 1) sh(Al, Ac, I0, I0);
+                            if constexpr (j == 2) sh(Bl, Bc, I0, I0);
+                            if constexpr (j == 3) sh(Ar, Ac, I1, I0);
+                            if constexpr (j == 4) sh(Br, Bc, I1, I0);
                         }
-                        if constexpr (j == 2) {
-                            if constexpr (u < BH) R[(u + 1) & 1] = pw_shift1(C[(u + 1) % CN], mask_r);
-                            else if constexpr (SPLIT0) Br = pw_shift1(Bc, mask_r);
-                            else Bl = pw_shift0(Bc, mask_l);
-                        }
-                        if constexpr (SPLIT0 && u == BH - 1 && j == 5) Al = pw_shift0(Ac, mask_l);
-                        if constexpr (SPLIT0 && u == BH - 1 && j == 6) Bl = pw_shift0(Bc, mask_l);
-                        if constexpr (!SPLIT0 && j == 3 && u == BH) Ar = pw_shift1(Ac, mask_r);
-                        if constexpr (!SPLIT0 && j == 4 && u == BH) Br = pw_shift1(Bc, mask_r);
                         gside(std::integral_constant<int, g0 + j>{});
                         __builtin_amdgcn_sched_barrier(0);
                     });
