@@ -78,6 +78,7 @@ struct GnArgs {
     int vec8_units;                // > 0: units per thread if a lane took 8 channels (see gn_vec8)
 };
 
+
 // thread layout inside a (n,g) slice: W = Cg/VEC channel units per pixel; unit u = t % W handles
 // channels [u*VEC, u*VEC+VEC); pixel rows pr = t / W, step PP = 256 / W.
 template <int VEC, int MAXU, int IO = 0>     // IO bit 0: x is bf16, bit 1: y is bf16
@@ -102,9 +103,26 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
 
     V<VEC> cache[MAXU > 0 ? MAXU : 1];
     float s = 0.f;
+    // (round 5) everything the kernel reads is requested BEFORE the statistics: the small slices (8x8 / 16x16 levels: 7-12 us per launch
+    // for 8-33 MB) are a chain of dependent round trips -- x, then (after two block reductions) gamma / beta / time bias, then the
+    // residual rows inside the apply loop -- and two of the three need nothing that the statistics produce
+    float ga0[VEC], be0[VEC], tb[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        ga0[j] = a.gamma[c0 + j]; be0[j] = a.beta[c0 + j];
+        tb[j] = a.temb ? a.temb[(size_t)n * a.ldt + c0 + j] : 0.f;
+    }
+    constexpr bool RPRE = MAXU > 0 && MAXU <= 4;             // residual rows prefetched with the slice (16 more registers at most)
+    V<VEC> rpre[RPRE ? MAXU : 1];
     if constexpr (MAXU > 0) {
 #pragma unroll
         for (int k = 0; k < MAXU; ++k) cache[k] = vload<VEC, X16>(a.x, xoff + (size_t)min(pr + k * PP, a.HW - 1) * a.ldx);
+        if constexpr (RPRE) {
+            if (a.res && !a.coef) {
+#pragma unroll
+                for (int k = 0; k < MAXU; ++k) rpre[k] = V<VEC>::load(a.res + (size_t)n * a.HW * a.ldr + c0 + (size_t)min(pr + k * PP, a.HW - 1) * a.ldr);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < MAXU; ++k) {
             const float live = pr + k * PP < a.HW ? 1.f : 0.f;
@@ -138,12 +156,11 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
     const float rstd = 1.0f / sqrtf(var + a.eps);
     if (t == 0 && a.stats) { a.stats[2 * ng] = mean; a.stats[2 * ng + 1] = rstd; }
 
-    float ga[VEC], be[VEC], tb[VEC];
+    float ga[VEC], be[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        ga[j] = a.gamma[c0 + j] * rstd;
-        be[j] = a.beta[c0 + j] - mean * ga[j];
-        tb[j] = a.temb ? a.temb[(size_t)n * a.ldt + c0 + j] : 0.f;
+        ga[j] = ga0[j] * rstd;
+        be[j] = be0[j] - mean * ga[j];
     }
     if (a.coef) {
         // the apply step is folded into the consuming conv's staging (mi_conv3x3_gn_mish): hand it the per-(sample, channel)
@@ -157,12 +174,13 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
     }
     const size_t yoff = (size_t)n * a.HW * a.ldy + c0;
     const float* rb = a.res ? a.res + (size_t)n * a.HW * a.ldr + c0 : nullptr;
-    auto apply = [&](V<VEC> q, int p) {
+    auto apply = [&](V<VEC> q, int p, int k = 0) {
         V<VEC> o;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o.v[j] = (X16 ? mish_fast_f(q.v[j] * ga[j] + be[j]) : mish_f(q.v[j] * ga[j] + be[j])) + tb[j];
         if (rb) {
-            V<VEC> r = V<VEC>::load(rb + (size_t)p * a.ldr);
+            V<VEC> r;
+            if constexpr (RPRE) r = rpre[k]; else r = V<VEC>::load(rb + (size_t)p * a.ldr);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o.v[j] += r.v[j];
         }
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
     };
     if constexpr (MAXU > 0) {
 #pragma unroll
-        for (int k = 0; k < MAXU; ++k) { int p = pr + k * PP; if (p < a.HW) apply(cache[k], p); }
+        for (int k = 0; k < MAXU; ++k) { int p = pr + k * PP; if (p < a.HW) apply(cache[k], p, k); }
     } else {
         for (int p = pr; p < a.HW; p += PP) apply(vload<VEC, X16>(a.x, xoff + (size_t)p * a.ldx), p);
     }
