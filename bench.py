@@ -43,7 +43,10 @@ NAMED_MB = {"fp32": 134.9, "bf16": 67.5}           # its algorithmic HBM bytes b
 # hash of this file at collection time, bench.py compares it with the tree's and says `traffic_stale` when the kernel changed since)
 KERNEL_SOURCES = {"conv_pw_kernel": "conv_pw.hip", "conv1x1_pw_kernel": "conv_pw.hip", "conv3x3_halo_kernel": "conv3x3_halo.hip",
                   "wgrad_tr_kernel": "wgrad_tr.hip", "wgrad1x1_tr_kernel": "wgrad1x1_tr.hip", "gn_mish": "norm_act.hip",
-                  "chan_ln": "norm_act.hip", "linattn": "linattn.hip", "igemm": "igemm_conv.hip", "conv_gt_kernel": "conv_pw.hip", "wgrad_s2": "wgrad_s2_tr.hip"}
+                  "chan_ln": "norm_act.hip", "linattn": "linattn.hip", "igemm": "igemm_conv.hip", "conv_gt_kernel": "conv_pw.hip", "wgrad_s2": "wgrad_s2_tr.hip",
+                  "adam_kernel": "elementwise.hip", "pack_weights": "conv3x3_halo.hip", "small_c": "small_channel.hip", "cvt_colsum": "elementwise.hip",
+                  "colsum": "elementwise.hip", "small_gemm": "small_gemm.hip", "partial_sum": "small_channel.hip", "eps_loss": "elementwise.hip",
+                  "rowsum_batch": "elementwise.hip", "q_sample": "elementwise.hip"}
 
 
 def kernel_source_sha(sym: str):
@@ -604,6 +607,11 @@ def main():
     #      line would read if the driver launched it under torch.distributed.run, next to the plain single-process number above
     dp_path = None
     if world == 1 and not use_dist and not args.no_extras:
+        # (RCCL prints a version banner through C stdio when its first communicator comes up: this leg's stdout goes to stderr, so that
+        #  the N = 1 run keeps printing exactly one line)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
         try:
             from src.runtime.graphed import SegmentedGraphedTrainStep
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
@@ -623,6 +631,13 @@ def main():
             net.grad_ready_hook = None
             if dist.is_initialized():
                 dist.destroy_process_group()
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:       # noqa: BLE001
+                pass
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     # ---- the parity-carrying fp32 mode (exact-fp32 MFMA), a short driver-timed leg
     fp32_mode = None
