@@ -326,7 +326,8 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     //      ((l >> 3) pixels + the lane's channel slot), i.e. no vector arithmetic per request at all (stage_x: a 64-bit multiply-add, a
     //      compare and two selects per piece).  A piece outside the image is not fetched from a zero page: its LDS rows are zeroed once
     //      (both buffers) and its request -- still issued, the counted waits assume it -- reads valid memory into a dump area.
-    constexpr bool SPIECE = (MI_PW_SPIECE != 0) && VAR < 2 && !IN32 && !F32 && ABL == 0;
+    constexpr bool SPIECE = (MI_PW_SPIECE != 0 || IN32) && VAR < 2 && !F32 && ABL == 0;     // (fp32 input: the pinned loop's register staging needs it)
+    constexpr int XSZ = IN32 ? 4 : ESZ;                     // bytes per element of x / x2 in memory
     int prow[SPIECE ? PXPW : 1];                             // first pixel of the piece in the tensor, 0 when outside (scalar)
     uint32_t pvalid = 0;                                     // bit i: piece i lies in the image
     uint32_t lane_off1 = 0, lane_off2 = 0;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
             prow[i] = ok ? (img * a.H + iy) * a.W + x0 : 0;
             pvalid |= ok ? (1u << i) : 0u;
         }
-        lane_off1 = (uint32_t)(((l >> 3) * a.ldx + xcol) * ESZ); lane_off2 = (uint32_t)(((l >> 3) * a.ldx2 + xcol) * ESZ);
+        lane_off1 = (uint32_t)(((l >> 3) * a.ldx + xcol) * XSZ); lane_off2 = (uint32_t)(((l >> 3) * a.ldx2 + xcol) * XSZ);
     }
     auto stage_s = [&](int ch, auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     // bf16 output: the bias of this lane's four channel quads, requested before anything else and used only by the epilogue (there a
     // load would put an HBM round trip in front of the tile's way out)
     // (round 5, pinned loop: the 128 bias values of the tile wait in LDS instead of 16 registers per lane)
-    constexpr bool PIPE_ = (MI_PW_PIPE != 0) && VAR < 2 && !IN32 && !F32 && ABL == 0;
+    constexpr bool PIPE_ = (MI_PW_PIPE != 0) && VAR < 2 && !F32 && ABL == 0;
     constexpr uint32_t BIASL = 2 * PXBUF + 1024;             // 512 bytes behind the dump area
     f32x4 bias_q[(OUT16 && !FUSE) ? 4 : 1];
     if constexpr (OUT16 && !FUSE && PIPE_) {
@@ -630,6 +631,12 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
         } else {
 #pragma unroll
             for (int i = 0; i < PXPW; ++i) store_x32(0, i, pr[i]);
+            if constexpr (SPIECE) {                          // pinned loop: pieces outside the image are never written again (buffer 0 just got its zeros)
+                typedef __attribute__((address_space(3))) u32x4 lds_u32x4z;
+#pragma unroll
+                for (int i = 0; i < PXPW; ++i)
+                    if (!((pvalid >> i) & 1u)) *(lds_u32x4z*)(uintptr_t)(lds0 + PXBUF + (wv + 4 * i) * 1024 + l * 16) = u32x4{0u, 0u, 0u, 0u};
+            }
         }
     } else {
         if constexpr (!EARLYW) {
@@ -686,7 +693,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     //        of the step, the next chunk's activation pieces behind them in steps 0 and 1 only -- so step 3's opening wait covers them
     //        and the barrier (before unit BH - 1 of step 3, the first to read the other buffer) needs no vmcnt at all; the fragments
     //        of the next chunk's first step are waited for at the very end of step 3, >= 18 gaps after their request.
-    constexpr bool PIPE = (MI_PW_PIPE != 0) && VAR < 2 && !IN32 && !F32 && ABL == 0;
+    constexpr bool PIPE = (MI_PW_PIPE != 0) && VAR < 2 && !F32 && ABL == 0;
     if constexpr (PIPE) {
         constexpr int CN = (BH % 3 == 1) ? 4 : 3;            // centre fragment registers in rotation (unit u: C[u % CN])
         constexpr int WSTR = BH >= 4 ? MI_PW_WSTR : 1;        // a fragment request every WSTR gaps
@@ -699,8 +706,9 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
         // the next chunk's pieces through registers (an LDS-DMA request cost the issuing wave 50-100 cycles in the unit timeline, a plain
         // request + ds_write_b128 a fraction of that): batch 0 = the first PPS pieces, requested in step 0 and written in step 2 (in-order
         // returns: they have landed once step 2's fragments have), batch 1 requested in step 1 and written in step 3 before the barrier
-        constexpr bool RST = (MI_PW_RSTAGE != 0) && SPIECE;
-        u32x4 RS[2][RST ? PPS : 1];
+        constexpr bool RST = (MI_PW_RSTAGE != 0 || IN32) && SPIECE;
+        constexpr int RSN = IN32 ? 2 : 1;                      // registers sets per piece: fp32 input = 32 bytes per lane
+        u32x4 RS[2][RST ? PPS : 1][RSN];
         const uint32_t wbase = lds0 + wv * 1024 + l * 16;
         auto rs_load = [&](int ch, auto bc, auto jc) {
             constexpr int b = decltype(bc)::value, j = decltype(jc)::value, i = PPS * b + j;
@@ -708,16 +716,24 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
             const bool second = cc0 >= a.K1;
             const uint8_t* src = reinterpret_cast<const uint8_t*>(second ? a.x2 : a.x);
             const int ld = second ? a.ldx2 : a.ldx, cc = second ? cc0 - a.K1 : cc0;
-            const uint64_t sb = (uint64_t)(uintptr_t)(src + ((size_t)prow[i < PXPW ? i : 0] * ld + cc) * ESZ);
+            const uint64_t sb = (uint64_t)(uintptr_t)(src + ((size_t)prow[i < PXPW ? i : 0] * ld + cc) * XSZ);
             const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
-            gload16s<0>(RS[b][j], ((uint64_t)hi << 32) | lo, second ? lane_off2 : lane_off1);
+            gload16s<0>(RS[b][j][0], ((uint64_t)hi << 32) | lo, second ? lane_off2 : lane_off1);
+            if constexpr (IN32) gload16s<16>(RS[b][j][1], ((uint64_t)hi << 32) | lo, second ? lane_off2 : lane_off1);
         };
         auto rs_store = [&](int ch, auto bc, auto jc) {
             constexpr int b = decltype(bc)::value, j = decltype(jc)::value, i = PPS * b + j;
             typedef __attribute__((address_space(3))) u32x4 lds_u32x4s;
-            landed16(RS[b][j]);
+            landed16(RS[b][j][0]);
             const uint32_t off = ((pvalid >> i) & 1u) ? (uint32_t)((ch & 1) * PXBUF + 4 * i * 1024) : (uint32_t)(DUMP - wv * 1024);
-            *(lds_u32x4s*)(uintptr_t)(wbase + off) = RS[b][j];
+            if constexpr (IN32) {                            // one rounding, as mi_f32_to_bf16 does
+                landed16(RS[b][j][1]);
+                const u32x4 r0 = RS[b][j][0], r1 = RS[b][j][1];
+                *(lds_u32x4s*)(uintptr_t)(wbase + off) =
+                    u32x4{pack_bf16(__uint_as_float(r0.x), __uint_as_float(r0.y)), pack_bf16(__uint_as_float(r0.z), __uint_as_float(r0.w)),
+                          pack_bf16(__uint_as_float(r1.x), __uint_as_float(r1.y)), pack_bf16(__uint_as_float(r1.z), __uint_as_float(r1.w))};
+            } else
+                *(lds_u32x4s*)(uintptr_t)(wbase + off) = RS[b][j][0];
         };
         bf16x8 Ac, Bc, C[CN];
         u32x4 Al, Bl, Ar, Br, L[2], R[2];                      // shifted fragments (registers written two at a time: pw_shift_h)
@@ -745,7 +761,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
                 constexpr uint32_t kx32 = ks * 32, kxn = ((ks + 1) & 3) * 32;
                 const uint32_t bufn = ks == 3 ? xnxt : xcur;                      // where the next step's rows are
                 constexpr int prevp = (ks == 1 || ks == 2) ? ((PXPW - PPS * (ks - 1)) < PPS ? (PXPW - PPS * (ks - 1)) : PPS) : 0;
-                if constexpr (ks > 0 && !(MI_PW_PABL & 4)) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(prevp) : "memory");
+                if constexpr (ks > 0 && !(MI_PW_PABL & 4)) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(prevp * (RST ? RSN : 1)) : "memory");
                 static_for<0, 9>([&](auto tc) { landed16(WB[cur][decltype(tc)::value]); });
                 auto mm = [&](auto ic, auto tapc, const bf16x8& xf) {
                     constexpr int i = decltype(ic)::value, tp = decltype(tapc)::value;
