@@ -25,6 +25,9 @@
 // contiguous per wave and store) and wgrad_tr_reduce_kernel sums them in a fixed order (deterministic) into dW.
 #include "tr_common.h"
 
+#ifndef MI_WTR_STAGE_AT
+#define MI_WTR_STAGE_AT -1  // >= 0: the unit of a step behind whose MFMAs the requests of step s + 2 are issued instead of at the top of the step (round 5, measured: 3115 -> 3253 cycles per step, off)
+#endif
 #ifndef MI_WTR_VMCNT2
 #define MI_WTR_VMCNT2 0   // 1: leave the newest dY pieces in flight across the step barrier (measured: 0.640 vs 0.635 ms per step, no gain)
 #endif
@@ -35,9 +38,13 @@
 #ifdef MI_WTR_TIMING
 // profiling build only (-DMI_WTR_TIMING): per-workgroup phase timestamps, 100 MHz wall clock (tools/wtr_timeline.py)
 __device__ unsigned long long g_wtr_ts[6 * 1024];
+__device__ unsigned long long g_wtr_cyc[1024];       // steps of the workgroup (slot 5 of g_wtr_ts: wait cycles << 40 | work cycles, wave 0)
 #define MI_TS(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_wtr_ts[(k) * 1024 + blockIdx.x] = wall_clock64(); } while (0)
 extern "C" int mi_debug_wtr_ts(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wtr_ts), sizeof(g_wtr_ts));
+}
+extern "C" int mi_debug_wtr_steps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wtr_cyc), sizeof(g_wtr_cyc));
 }
 #else
 #define MI_TS(k) do {} while (0)
@@ -147,7 +154,13 @@ __device__ __forceinline__ void wgrad_tr_body(const TrArgs& a, const int wg, uin
     MI_TS(2);
 #endif
 
+#ifdef MI_WTR_TIMING
+    unsigned long long tw_wait = 0, tw_work = 0, tw_n = 0;
+#endif
     for (int s = sb; s < ((MI_WTR_ABL & 2) ? sb + 1 : se); ++s) {
+#ifdef MI_WTR_TIMING
+        const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
         // everything this step reads has landed: X and dY of steps <= s, the X row of step s+1 (halo below).  (MI_WTR_VMCNT2: the two
         // dY pieces of step s+1 are the newest requests and could stay in flight -- loads complete in order.)
 #if MI_WTR_VMCNT2
@@ -157,7 +170,11 @@ __device__ __forceinline__ void wgrad_tr_body(const TrArgs& a, const int wg, uin
 #endif
         __builtin_amdgcn_s_barrier();                         // ... for every wave, and every wave is done reading step s-1
         asm volatile("" ::: "memory");
-        stage(s + 2);
+#ifdef MI_WTR_TIMING
+        const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
+#endif
+        // (round 5 experiment, MI_WTR_STAGE_AT: these three requests behind the step's first MFMAs instead of in front of them -- slower)
+        if constexpr (MI_WTR_STAGE_AT < 0) stage(s + 2);
         const int sm = s & 3, y0 = (s * TR) % a.H;
         // row bases of relative rows -1 .. TR (ring slot, or the zero row at the image border)
         int RB[TR + 2];
@@ -194,13 +211,20 @@ __device__ __forceinline__ void wgrad_tr_body(const TrArgs& a, const int wg, uin
                 if constexpr (jq == qidx && ky >= 0 && ky <= 2)
                     acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[u % (PD + 1)], bfr[j], acc[ky * 3 + kx], 0, 0, 0);
             });
+            if constexpr (MI_WTR_STAGE_AT >= 0 && u == (MI_WTR_STAGE_AT < NU ? MI_WTR_STAGE_AT : NU - 1)) stage(s + 2);
             // pin the software pipeline: hipcc otherwise sinks every fragment read to just before its MFMA (read, wait for it,
             // one MFMA, next read ...), which runs at half the MFMA rate; nothing may move across a unit boundary
             __builtin_amdgcn_sched_barrier(0);
         });
+#ifdef MI_WTR_TIMING
+        { const unsigned long long tq2 = __builtin_amdgcn_s_memtime(); tw_wait += tq1 - tq0; tw_work += tq2 - tq1; ++tw_n; }
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // nothing may still be writing LDS when the workgroup retires
     MI_TS(3);
+#ifdef MI_WTR_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 1024) { g_wtr_ts[5 * 1024 + blockIdx.x] = (tw_wait << 40) | ((tw_work & 0xffffffffffull)); g_wtr_cyc[blockIdx.x] = tw_n; }
+#endif
 
 #if MI_WTR_ABL & 1      // profiling only: no partial-tile stores (one store keeps the accumulators live)
     {

@@ -27,6 +27,7 @@ e0.record(); run(); e1.record(); torch.cuda.synchronize()
 lib.mi_debug_wgrad_tr_phase(0)
 buf = np.zeros(6 * 1024, dtype=np.uint64)
 assert fn(buf.ctypes.data) == 0
+raw5 = buf.reshape(6, 1024)[5].copy()
 ts = buf.reshape(6, 1024)[:5].astype(np.int64)
 n = int((ts[4] > 0).sum())
 ts = ts[:, :n]
@@ -40,4 +41,10 @@ print("  end-time deciles:", [round(float(end[int(q * (n - 1))]), 1) for q in np
 loop = us[3] - us[2]
 for r in range(0, n, 32):
     print(f"  wg {r:3d}..: loop us", " ".join(f"{v:4.0f}" for v in loop[r:r + 32]))
+fs = lib.mi_debug_wtr_steps; fs.argtypes = [ctypes.c_void_p]; fs.restype = ctypes.c_int
+nst = np.zeros(1024, dtype=np.uint64); assert fs(nst.ctypes.data) == 0
+wait = (raw5[:n] >> np.uint64(40)).astype(np.float64); work = (raw5[:n] & np.uint64(0xffffffffff)).astype(np.float64); st = nst[:n].astype(np.float64)
+print(f"  per step (wave 0 of each workgroup, shader cycles): wait + barrier {np.mean(wait / st):.0f}, the rest {np.mean(work / st):.0f}; steps per workgroup {st.min():.0f}..{st.max():.0f}; MFMA floor per step 36 x 32 x 2 waves per SIMD = 2304")
+for r in range(0, n, 64):
+    print(f"  wg {r:3d}..: cycles/step wait", " ".join(f"{v:4.0f}" for v in (wait / st)[r:r + 16]), "| work", " ".join(f"{v:4.0f}" for v in (work / st)[r:r + 16]))
 print("  mean loop by XCD (wg & 7):", [round(float(loop[x::8].mean()), 1) for x in range(8)])
