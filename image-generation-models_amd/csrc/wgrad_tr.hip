@@ -168,7 +168,9 @@ __device__ __forceinline__ void wgrad_tr_body(const TrArgs& a, const int wg, uin
 #else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+#if !(MI_WTR_ABL & 4)      // (profiling only, 4: no step barrier -- wrong results, the time a perfectly hidden hand-over would leave)
         __builtin_amdgcn_s_barrier();                         // ... for every wave, and every wave is done reading step s-1
+#endif
         asm volatile("" ::: "memory");
 #ifdef MI_WTR_TIMING
         const unsigned long long tq1 = __builtin_amdgcn_s_memtime();

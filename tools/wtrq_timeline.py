@@ -24,6 +24,12 @@ for _ in range(5): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); run(); e1.record(); torch.cuda.synchronize()
+K.PROBE = []
+for _ in range(5): run()
+torch.cuda.synchronize()
+kus = sorted(ev0.elapsed_time(ev1) * 1e3 for _s, _f, ev0, ev1, _d, _n in K.PROBE if "wgrad_tr" in _s and "reduce" not in _s)
+K.PROBE = None
+print("wgrad_tr_kernel by HIP events around the launch (5 runs, us):", [round(v, 1) for v in kus])
 lib.mi_debug_wgrad_tr_phase(0)
 buf = np.zeros(6 * 1024, dtype=np.uint64)
 assert fn(buf.ctypes.data) == 0
