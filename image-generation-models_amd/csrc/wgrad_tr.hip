@@ -25,6 +25,9 @@
 // contiguous per wave and store) and wgrad_tr_reduce_kernel sums them in a fixed order (deterministic) into dW.
 #include "tr_common.h"
 
+#ifndef MI_WTR_PD
+#define MI_WTR_PD 4
+#endif
 #ifndef MI_WTR_STAGE_AT
 #define MI_WTR_STAGE_AT -1  // >= 0: the unit of a step behind whose MFMAs the requests of step s + 2 are issued instead of at the top of the step (round 5, measured: 3115 -> 3253 cycles per step, off)
 #endif
@@ -65,7 +68,7 @@ __device__ __forceinline__ void wgrad_tr_body(const TrArgs& a, const int wg, uin
     constexpr int JPR = W >= 16 ? W / 16 : 1;      // 16-pixel k-steps per image row (W = 8: a k-step is two rows)
     constexpr int NRI = (W == 8 ? 6 : TR - 1) + 3; // X rows a step's taps touch, counted from relative row -1
     constexpr int NU = NRI * JPR * 3;              // X fragments per step
-    constexpr int PD = 4;                          // fragments fetched ahead of the MFMAs that consume them
+    constexpr int PD = MI_WTR_PD;                  // fragments fetched ahead of the MFMAs that consume them
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
 
     const int t = threadIdx.x, l = t & 63;
@@ -191,13 +194,22 @@ __device__ __forceinline__ void wgrad_tr_body(const TrArgs& a, const int wg, uin
         bf16x8 bfr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bfr[j] = tr_pair(yb + fb + j * 4 * 1024, yb + fb + (j * 4 + 1) * 1024);
+        bf16x8 abl_last = bfr[0];                              // (profiling only, MI_WTR_ABL & 8)
         auto load_unit = [&](auto uc) -> bf16x8 {
             constexpr int u = decltype(uc)::value;
             constexpr int ri = u / (JPR * 3), qidx = (u / 3) % JPR, kx = u % 3;
+#if MI_WTR_ABL & 8       // only the centre tap column is read from LDS, the others reuse a fragment already in registers (wrong results:
+            if constexpr (kx != 1) return abl_last;              //  the time a kernel that derived the shifted fragments for free would take)
+#endif
             uint32_t rb;
             if constexpr (W == 8) rb = lds0 + (half ? RB[ri + 1] : RB[ri]);          // lanes 32-63 read the next row
             else rb = lds0 + RB[ri] + qidx * 2048;                                    // 16 pixels = two 8-pixel blocks
+#if MI_WTR_ABL & 8
+            abl_last = tr_pair(rb + fa[0][kx], rb + fa[1][kx]);
+            return abl_last;
+#else
             return tr_pair(rb + fa[0][kx], rb + fa[1][kx]);
+#endif
         };
         bf16x8 F[PD + 1];
         static_for<0, PD>([&](auto uc) { F[decltype(uc)::value] = load_unit(uc); });
