@@ -24,6 +24,13 @@
 // build, tools/abl_pw.sh): the DPP shifts are free (<= 4 %), waiting for loads is free (a build that never waits: +-1 %), what
 // costs is ISSUING vector-memory instructions next to the MFMA stream -- without the fragment loads -19 % on the deep layers,
 // without the activation DMA -16 %, without the output stores -7..12 %; the same time with one and with two waves per SIMD.
+// Round 5 ("Round 5"; tools/pw_timeline.py with -DMI_PW_TIMING): the plain bf16 / fp32-input conv (VAR 0 / 1) runs a PINNED,
+// software-pipelined main loop -- every MFMA is followed by at most one side operation and a sched_barrier; a row unit issues its MFMAs from
+// fragments that are complete in registers, reads the centre fragment of the unit after next and shifts the next unit's (two-register halves, no
+// wait states); fragment requests one per gap from the start of a step; the next chunk's pieces through registers in steps 0-1, written in steps 2-3;
+// the barrier needs no vmcnt -- behind a prologue whose first requests leave after ~1 100 cycles (was 3 600: divisions by multiplication, scalar piece
+// table), and every workgroup walks the contraction in its own rotation of the chunk order (L2 channel hot spots).  Level 0 43-46 -> 34-36 us,
+// 256 -> 256 @16x16 36-39 -> 32-35, 512 -> 512 @8x8 32-35 -> 30-32, 1024 -> 256 @8x8 46 -> 38 (same boxes, round 4's loop beside it).
 #include "tr_common.h"
 
 #ifndef MI_PW_PABL
