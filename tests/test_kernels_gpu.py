@@ -1075,6 +1075,33 @@ def test_conv3x3_pw_fwd_and_dgrad_tile256(K, cfg, out16, pw_always, pw_tile256):
     _pw_fwd_dgrad_case(K, cfg, out16, pw_always, pw_tile256)
 
 
+@pytest.mark.parametrize("cfg", [dict(N=8, H=48, W=16, Ci=128, Co=256),     # six row tiles per image (not a power of two), image-per-XCD order
+                                 dict(N=4, H=48, W=16, Ci=192, Co=768),     # (pixel, channel) XCD groups with three channel tiles per group
+                                 dict(N=2, H=24, W=8, Ci=64, Co=128)])      # three 64-pixel row tiles per image
+def test_conv3x3_pw_non_power_of_two_tile_counts(K, cfg, pw_always):
+    """Round 5: the prologue's integer divisions (row tiles per image, channel tiles per XCD group, chunks per workgroup rotation) are
+    multiplications by host-computed reciprocals -- images with 6 / 3 row tiles and layers with 3 channel tiles per group and 3 chunks
+    take every one of them off the power-of-two path; forward and data gradient against fp64 on the same bf16-rounded operands."""
+    N, H, W, Ci, Co = cfg["N"], cfg["H"], cfg["W"], cfg["Ci"], cfg["Co"]
+    g = torch.Generator().manual_seed(613)
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9))
+    b = torch.randn(Co, generator=g)
+    dy = torch.randn(N, Co, H, W, generator=g).bfloat16()
+    xq = x.double().requires_grad_(True)
+    yq = F.conv2d(xq, w.bfloat16().double(), b.double(), padding=1)
+    yq.backward(dy.double())
+    flat, wd, wf, offs, wdq, wfq = _pack(K, [conv_w_storage(w.double())], frag=True)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+    yg = K.conv3x3_bf16w(nh(x), wf, K=Ci, Nc=Co, flip=False, bias=b.to(DEV), out_dtype=torch.float32, wq=wfq)
+    dxg = K.conv3x3_bf16w(nh(dy), wd, K=Co, Nc=Ci, flip=True, out_dtype=torch.float32, wq=wdq)
+    ls = _conv_launches(pw_always)
+    assert len(ls) == 2 and all(q.startswith("conv_pw_kernel") for q in ls), ls
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(yg), yq) < 1e-5
+    assert rel_err(from_nhwc(dxg), xq.grad) < 1e-5
+
+
 def _pw_fwd_dgrad_case(K, cfg, out16, pw_always, pw_tile):
     """Block's 3x3 conv (ddpm.py:116) and its data gradient for bf16-stored activations through the private-weight-stream kernel
     (mi_conv3x3_pw: fragment-order weights by LDS-DMA per wave, one barrier per 64-channel chunk): bias, residual, fp32 and bf16
