@@ -1214,6 +1214,10 @@ int pw_pick_tile(const MiConvDesc* d, int var, int* TH, int* TI, bool in32 = fal
 // barrier per chunk (8 x PXT / 32 MFMAs per wave).  Then the row-contiguous epilogue through LDS (bias, fp32 residual, accumulate;
 // optional bf16 copy of an fp32 output: to_out's epilogue writes the residual-stream tensor AND the copy its consumers read).
 // 64 KB of LDS: two workgroups per CU.
+// LDS of a launch: two chunk tiles (PXT x 256 bytes each) under the epilogue's fp32 tile (PXT x 512 bytes).  (Round 5: the 64-pixel tiles asked
+// for the 128-pixel tiles' 64 KB -- two workgroups per CU whatever their registers allowed; with 32 KB the 126-168-register instantiations
+// run three or four.)
+constexpr size_t pw1_lds(int pxt) { return (size_t)pxt * 512; }
 struct Pw1Args {
     const uint16_t* x; const uint16_t* x2; const uint16_t* w; const float* bias; const float* res; void* y; uint16_t* y16;
     int M, K, K1, Nc, ldx, ldx2, ldy, ldr, ldy16, accumulate, gx, gy;
@@ -1971,7 +1975,7 @@ extern "C" int mi_conv1x1_pw_x32(const MiConvDesc* d, const float* x, const floa
 #define MI_PW1X_GO(O16, PX) do { \
         static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<O16, false, PX, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); return true; }(); \
         (void)once_; \
-        hipLaunchKernelGGL((conv1x1_pw_kernel<O16, false, PX, false, true>), grid, dim3(256), 64 * 1024, st, a); } while (0)
+        hipLaunchKernelGGL((conv1x1_pw_kernel<O16, false, PX, false, true>), grid, dim3(256), pw1_lds(PX), st, a); } while (0)
     if (out_bf16) MI_PW1X_GO(true, 64); else MI_PW1X_GO(false, 64);
 #undef MI_PW1X_GO
     MI_LAUNCH_CHECK();
@@ -2002,7 +2006,7 @@ extern "C" int mi_conv1x1_pw_f32(const MiConvDesc* d, const float* x, const floa
         (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<false, false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         return true; }();
     (void)once_;
-    if (small) hipLaunchKernelGGL((conv1x1_pw_kernel<false, false, 64, true>), grid, dim3(256), 64 * 1024, st, a);
+    if (small) hipLaunchKernelGGL((conv1x1_pw_kernel<false, false, 64, true>), grid, dim3(256), pw1_lds(64), st, a);
     else hipLaunchKernelGGL((conv1x1_pw_kernel<false, false, 128, true>), grid, dim3(256), 64 * 1024, st, a);
     MI_LAUNCH_CHECK();
     return 0;
@@ -2032,7 +2036,7 @@ extern "C" int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* x2,
 #define MI_PW1_GO(O16, DU, PX) do { \
         static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<O16, DU, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); return true; }(); \
         (void)once_; \
-        hipLaunchKernelGGL((conv1x1_pw_kernel<O16, DU, PX>), grid, dim3(256), lds, st, a); } while (0)
+        hipLaunchKernelGGL((conv1x1_pw_kernel<O16, DU, PX>), grid, dim3(256), pw1_lds(PX), st, a); } while (0)
 #define MI_PW1_PICK(O16, DU) do { if (small) MI_PW1_GO(O16, DU, 64); else MI_PW1_GO(O16, DU, 128); } while (0)
     if (out_bf16) MI_PW1_PICK(true, false);
     else if (y_bf16) MI_PW1_PICK(false, true);
