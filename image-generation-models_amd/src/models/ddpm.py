@@ -71,8 +71,9 @@ class _Entry:
 class _Arch:
     """Static layer list of the reference Unet (ddpm.py:182-236) + parameter table."""
 
-    def __init__(self, dim, dim_mults, channels, out_dim):
+    def __init__(self, dim, dim_mults, channels, out_dim, with_time_emb=True):
         self.dim, self.channels, self.out_dim = dim, channels, out_dim or channels
+        self.with_time = bool(with_time_emb)               # False: no time MLP, ResnetBlocks without their time Linear (ddpm.py:186-198,126-130)
         self.dims = [channels] + [dim * m for m in dim_mults]
         pairs = list(zip(self.dims[:-1], self.dims[1:]))
         self.entries: List[_Entry] = []
@@ -96,7 +97,8 @@ class _Arch:
             add(wkey, shape, "plain", "one"); add(bkey, shape, "plain", "zero")
 
         def resblock(pre, i, o):
-            linear(pre + "mlp.1.", dim, o)
+            if self.with_time:
+                linear(pre + "mlp.1.", dim, o)
             for blk, ci in (("block1.", i), ("block2.", o)):
                 conv(pre + blk + "block.0.", ci, o, 3)
                 norm_affine(pre + blk + "block.1.weight", pre + blk + "block.1.bias", (o,))
@@ -112,8 +114,9 @@ class _Arch:
             norm_affine(pre + "fn.norm.g", pre + "fn.norm.b", (1, c, 1, 1))
             return {"pre": pre, "c": c}
 
-        linear("time_mlp.1.", dim, dim * 4)
-        linear("time_mlp.3.", dim * 4, dim)
+        if self.with_time:
+            linear("time_mlp.1.", dim, dim * 4)
+            linear("time_mlp.3.", dim * 4, dim)
         self.downs, self.ups = [], []
         for L, (i, o) in enumerate(pairs):
             lvl = {"res1": resblock(f"downs.{L}.0.", i, o), "res2": resblock(f"downs.{L}.1.", o, o),
@@ -146,7 +149,7 @@ class _Arch:
         for e in mlp_w:
             e.offset = off; off += e.numel
         off = (off + 63) // 64 * 64
-        self.mlp_w_off, self.mlp_rows = mlp_w[0].offset, sum(e.shape[0] for e in mlp_w)
+        self.mlp_w_off, self.mlp_rows = (mlp_w[0].offset if mlp_w else 0), sum(e.shape[0] for e in mlp_w)
         self.mlp_b_off = off
         for e in mlp_b:
             e.offset = off; off += e.numel
@@ -167,8 +170,10 @@ class _Arch:
                     lvl[kind]["range"] = span([lvl[kind]["pre"]])
         self.mid_attn["range"] = span([self.mid_attn["pre"]])
         self.final_range = span(["final_conv."])
-        self.time_range = (0, span(["time_mlp."])[1])
+        self.time_range = (0, span(["time_mlp."])[1]) if self.with_time else (0, 0)
         col = 0
+        for blk in self.res_blocks:
+            blk["tcol"] = 0
         for blk, e in zip(self.res_blocks, mlp_w):
             assert e.key == blk["pre"] + "mlp.1.weight"
             blk["tcol"] = col; col += blk["cout"]
@@ -233,13 +238,14 @@ class Unet(nn.Module):
 
     def __init__(self, dim, out_dim=None, dim_mults=(1, 2, 4, 8), groups=8, channels=3, with_time_emb=True):
         super().__init__()
-        if not with_time_emb:
-            raise NotImplementedError("with_time_emb=False is dead code in the reference (never used by DDPM)")
         if dim % 8 or dim < 8:
             raise ValueError("dim must be a multiple of 8")
         self.channels = channels
         self.dim = dim
-        arch = _Arch(dim, tuple(dim_mults), channels, out_dim)
+        # with_time_emb=False (round 5; the reference's flag that DDPM never sets): no time_mlp, no per-block mlp -- the state_dict has
+        # neither, forward ignores `time` as the reference does (t = None, ddpm.py:241)
+        self.with_time_emb = bool(with_time_emb)
+        arch = _Arch(dim, tuple(dim_mults), channels, out_dim, with_time_emb)
         object.__setattr__(self, "_arch", arch)
         self.compute_mode = os.environ.get("MI_DDPM_MODE", "fp32")
         # bf16 mode only: storage of the ResnetBlock-internal tensors (conv output -> GroupNorm -> conv input, and
@@ -422,6 +428,8 @@ class Unet(nn.Module):
         per-block Linear(Mish(.)) (ddpm.py:126-130,139-140) depend on t only, so a T-step sampler computes them
         once instead of T times (inference only: the table is stale once the weights change)."""
         A, sv, flat = self._arch, self._sv, self._flat
+        if not A.with_time:
+            return None                                    # nothing depends on t
         T = int(timesteps)
         t = torch.arange(T, device=flat.device, dtype=torch.long)
 
@@ -458,7 +466,9 @@ class Unet(nn.Module):
             return y.view(B, o)
 
         # ---- time embedding MLP (ddpm.py:186-193) and every block's time bias (ddpm.py:126-130) in one GEMM
-        if time_bias_table is not None and not record:
+        if not A.with_time:
+            tb_all = None
+        elif time_bias_table is not None and not record:
             tb_all = K.gather_rows(time_bias_table, time)                  # sampler: precomputed per timestep
         else:
             te = K.time_embed(time, A.dim)
@@ -591,7 +601,7 @@ class Unet(nn.Module):
                 inp_c, x2_c = shadow(inp), (shadow(x2) if x2 is not None else None)
             elif c1_16 and eval16 and x2 is None and id(inp) in sh:
                 inp_c = sh[id(inp)][1]            # inference: the copy the producing GroupNorm kernel wrote along (no conversion launches)
-            tb = tb_all[:, blk["tcol"]:blk["tcol"] + co]
+            tb = tb_all[:, blk["tcol"]:blk["tcol"] + co] if tb_all is not None else None
             hw = inp.shape[1] * inp.shape[2]
             fmode = str(self.fuse_gn_conv)
             sums_ok = ((co // _GN_GROUPS) % 16 == 0 and hw % 32 == 0 and ci % 32 == 0
@@ -873,7 +883,7 @@ class Unet(nn.Module):
                                 dbias=gv[pre + "block2.block.0.bias"], out_dtype=c2.dtype)
             conv_bwd(dc2, h1, pre + "block2.block.0.", 3, 1, 1, bias=None)
             dh1 = G.take(h1)
-            dtb = dtb_all[:, blk["tcol"]:blk["tcol"] + blk["cout"]]
+            dtb = dtb_all[:, blk["tcol"]:blk["tcol"] + blk["cout"]] if A.with_time else None
             dc1 = K.gn_mish_bwd(c1, st1, sv[pre + "block1.block.1.weight"], sv[pre + "block1.block.1.bias"], dh1,
                                 dgamma=gv[pre + "block1.block.1.weight"], dbeta=gv[pre + "block1.block.1.bias"],
                                 dtemb=dtb, dbias=gv[pre + "block1.block.0.bias"], out_dtype=c1.dtype)

@@ -112,10 +112,12 @@ def unet_levels(p: Params) -> Tuple[int, int]:
 def unet_forward(p: Params, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
     """Unet.forward (ddpm.py:238-261). x [N,C,H,W], t int64 [N] -> [N,C,H,W]."""
     nd, nu = unet_levels(p)
-    dim = p["time_mlp.1.weight"].shape[1]
-    temb = sinusoidal_embedding(t, dim).to(x.dtype)
-    temb = F.linear(temb, p["time_mlp.1.weight"], p["time_mlp.1.bias"])
-    temb = F.linear(mish(temb), p["time_mlp.3.weight"], p["time_mlp.3.bias"])
+    temb = None                                              # Unet(with_time_emb=False): t = None (ddpm.py:186-198, 241)
+    if "time_mlp.1.weight" in p:
+        dim = p["time_mlp.1.weight"].shape[1]
+        temb = sinusoidal_embedding(t, dim).to(x.dtype)
+        temb = F.linear(temb, p["time_mlp.1.weight"], p["time_mlp.1.bias"])
+        temb = F.linear(mish(temb), p["time_mlp.3.weight"], p["time_mlp.3.bias"])
 
     skips: List[torch.Tensor] = []
     for L in range(nd):
@@ -237,7 +239,7 @@ def p_sample_loop(p: Params, tab, shape: Sequence[int], noise_fn: Callable[[Sequ
 # reference-compatible parameter construction (for seeded-init pins)
 # --------------------------------------------------------------------------- #
 def unet_param_spec(dim: int, dim_mults: Sequence[int] = (1, 2, 4, 8), channels: int = 3,
-                    out_dim: Optional[int] = None):
+                    out_dim: Optional[int] = None, with_time_emb: bool = True):
     """Yield (key, shape, kind, fan_in) in the reference's RNG-consuming construction
     order (ddpm.py:186-236).  kind in {'w','b','one','zero'}."""
     dims = [channels] + [dim * m for m in dim_mults]
@@ -262,7 +264,9 @@ def unet_param_spec(dim: int, dim_mults: Sequence[int] = (1, 2, 4, 8), channels:
         conv(pre + "block.0.", i, o, 3); gn(pre + "block.1.", o)
 
     def resnet(pre, i, o):
-        lin(pre + "mlp.1.", tdim, o); block(pre + "block1.", i, o); block(pre + "block2.", o, o)
+        if with_time_emb:                                    # ResnetBlock(time_emb_dim=None) has no mlp (ddpm.py:126-130)
+            lin(pre + "mlp.1.", tdim, o)
+        block(pre + "block1.", i, o); block(pre + "block2.", o, o)
         if i != o:
             conv(pre + "res_conv.", i, o, 1)
 
@@ -270,7 +274,8 @@ def unet_param_spec(dim: int, dim_mults: Sequence[int] = (1, 2, 4, 8), channels:
         conv(pre + "fn.fn.to_qkv.", c, 384, 1, bias=False); conv(pre + "fn.fn.to_out.", 128, c, 1)
         spec.append((pre + "fn.norm.g", (1, c, 1, 1), "one", 0)); spec.append((pre + "fn.norm.b", (1, c, 1, 1), "zero", 0))
 
-    lin("time_mlp.1.", dim, dim * 4); lin("time_mlp.3.", dim * 4, dim)
+    if with_time_emb:
+        lin("time_mlp.1.", dim, dim * 4); lin("time_mlp.3.", dim * 4, dim)
     n = len(in_out)
     for L, (i, o) in enumerate(in_out):
         resnet(f"downs.{L}.0.", i, o); resnet(f"downs.{L}.1.", o, o); attn(f"downs.{L}.2.", o)
@@ -300,12 +305,12 @@ def state_dict_order(keys: Sequence[str]) -> List[str]:
     return sorted(keys, key=lambda k: (rank[k.split(".")[0]], idx[k]))
 
 
-def init_unet_params(dim: int, dim_mults=(1, 2, 4, 8), channels: int = 3, out_dim=None) -> Params:
+def init_unet_params(dim: int, dim_mults=(1, 2, 4, 8), channels: int = 3, out_dim=None, with_time_emb: bool = True) -> Params:
     """Default torch init (kaiming_uniform(a=sqrt 5) weights, U(+-1/sqrt(fan_in)) biases)
     drawn from the global CPU generator in the reference's construction order, so
     ``torch.manual_seed(s); init_unet_params(...)`` == ``torch.manual_seed(s); Unet(...)``."""
     p: Params = {}
-    for key, shape, kind, fan_in in unet_param_spec(dim, dim_mults, channels, out_dim):
+    for key, shape, kind, fan_in in unet_param_spec(dim, dim_mults, channels, out_dim, with_time_emb):
         if kind == "w":
             w = torch.empty(shape)
             torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))

@@ -133,3 +133,32 @@ def test_bf16_bounds_at_most_twice_the_measured_error():
                 bad.append((case, k[6:], m, b))
     assert checked >= 10, checked
     assert not bad, bad
+
+
+def test_oracle_and_host_layer_without_time_embedding(golden_dir):
+    """Unet(with_time_emb=False) (reference ddpm.py:186-198): the oracle's parameter spec / forward and the host layer's state_dict keys and
+    seeded init equal what the reference produced (tests/golden/tiny_unet_notime.npz, tools/gen_golden_notime.py)."""
+    import numpy as np
+    from oracle import ddpm_oracle as O
+    from src.models.ddpm import Unet
+    g = dict(np.load(os.path.join(golden_dir, "tiny_unet_notime.npz")))
+    keys = [str(k) for k in g["pin.state_keys"]]
+    assert not any("mlp" in k for k in keys)
+    torch.manual_seed(0)
+    p = O.init_unet_params(8, (1, 2), 3, with_time_emb=False)
+    assert list(p.keys()) == keys and O.state_sha256(p) == str(g["pin.init_sha256"])
+    torch.manual_seed(0)
+    net = Unet(dim=8, dim_mults=(1, 2), channels=3, with_time_emb=False)
+    sd = net.state_dict()
+    assert list(sd.keys()) == keys and O.state_sha256(sd) == str(g["pin.init_sha256"])
+    assert sum(q.numel() for q in net.parameters()) == int(g["pin.param_count"])
+    P = {k[2:]: torch.from_numpy(v).clone().requires_grad_(True) for k, v in g.items() if k.startswith("w.")}
+    x, t, noise = (torch.from_numpy(g[k]) for k in ("katA.x", "katA.t", "katB.noise"))
+    y = O.unet_forward(P, x, t)
+    assert float((y - torch.from_numpy(g["katA.y"])).abs().max()) < 1e-6
+    loss, _ = O.p_losses(P, O.schedule_tables(1000), x, t, noise)
+    loss.backward()
+    assert abs(float(loss) - float(g["katB.loss"])) < 1e-6
+    for k, q in P.items():
+        r = torch.from_numpy(g["grad." + k])
+        assert float((q.grad - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-7, k
