@@ -14,6 +14,9 @@
 #ifndef MI_GN_PD
 #define MI_GN_PD 2       // units whose raw loads are in flight ahead of the one being worked on (pipelined GroupNorm backward)
 #endif
+#ifndef MI_GN_ABL
+#define MI_GN_ABL 0       // profiling builds only (bit 0: forward without Mish, bit 1: forward without the statistics' reductions)
+#endif
 #ifndef MI_GN_WAVES
 #define MI_GN_WAVES 4     // waves per SIMD the packed-cache GroupNorm backward is compiled for
 #endif
@@ -136,7 +139,11 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
             for (int j = 0; j < VEC; ++j) s += q.v[j];
         }
     }
+#if MI_GN_ABL & 2
+    const float mean = s / cnt;
+#else
     const float mean = block_sum_256(s, red) / cnt;
+#endif
     float s2 = 0.f;
     if constexpr (MAXU > 0) {
 #pragma unroll
@@ -152,7 +159,11 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
             for (int j = 0; j < VEC; ++j) { float dlt = q.v[j] - mean; s2 += dlt * dlt; }
         }
     }
+#if MI_GN_ABL & 2
+    const float var = s2 / cnt;
+#else
     const float var = block_sum_256(s2, red + 4) / cnt;
+#endif
     const float rstd = 1.0f / sqrtf(var + a.eps);
     if (t == 0 && a.stats) { a.stats[2 * ng] = mean; a.stats[2 * ng + 1] = rstd; }
 
@@ -177,7 +188,11 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
     auto apply = [&](V<VEC> q, int p, int k = 0) {
         V<VEC> o;
 #pragma unroll
+#if MI_GN_ABL & 1          // profiling: the apply step without its Mish (what the VALU work costs beside the memory phases)
+        for (int j = 0; j < VEC; ++j) o.v[j] = q.v[j] * ga[j] + be[j] + tb[j];
+#else
         for (int j = 0; j < VEC; ++j) o.v[j] = (X16 ? mish_fast_f(q.v[j] * ga[j] + be[j]) : mish_f(q.v[j] * ga[j] + be[j])) + tb[j];
+#endif
         if (rb) {
             V<VEC> r;
             if constexpr (RPRE) r = rpre[k]; else r = V<VEC>::load(rb + (size_t)p * a.ldr);
