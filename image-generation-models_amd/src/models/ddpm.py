@@ -1006,6 +1006,28 @@ def linear_beta_schedule(timesteps):
     return torch.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=torch.float64)
 
 
+# The reference module's three small helpers (ddpm.py:25-36, 268-273): none of them is on the training / sampling path, they are here so
+# that `from src.models.ddpm import ...` of a script written against the reference keeps working.
+def cycle(dl):
+    """Endless iteration over a data loader, epoch after epoch."""
+    while True:
+        yield from dl
+
+
+def num_to_groups(num, divisor):
+    """`num` split into full groups of `divisor` and, if anything is left, one smaller group."""
+    full, rest = divmod(int(num), int(divisor))
+    return [int(divisor)] * full + ([rest] if rest else [])
+
+
+def noise_like(shape, device, repeat=False):
+    """Standard normal noise of `shape`; repeat=True draws ONE sample and repeats it along the batch axis."""
+    if repeat:
+        one = torch.randn((1, *shape[1:]), device=device)
+        return one.repeat(shape[0], *((1,) * (len(shape) - 1)))
+    return torch.randn(shape, device=device)
+
+
 class _LossFunction(torch.autograd.Function):
     """q_sample -> UNet -> L1/L2 loss as one node: all three stay NHWC and on the HIP kernels."""
 

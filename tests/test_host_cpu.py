@@ -162,3 +162,18 @@ def test_oracle_and_host_layer_without_time_embedding(golden_dir):
     for k, q in P.items():
         r = torch.from_numpy(g["grad." + k])
         assert float((q.grad - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-7, k
+
+
+def test_reference_module_helpers():
+    """cycle / num_to_groups / noise_like (reference ddpm.py:25-36, 268-273): same results as the reference's definitions."""
+    from src.models.ddpm import cycle, noise_like, num_to_groups
+    assert num_to_groups(10, 4) == [4, 4, 2] and num_to_groups(8, 4) == [4, 4] and num_to_groups(3, 4) == [3] and num_to_groups(0, 4) == []
+    it = cycle([1, 2, 3])
+    assert [next(it) for _ in range(7)] == [1, 2, 3, 1, 2, 3, 1]
+    torch.manual_seed(0)
+    a = noise_like((4, 3, 2, 2), "cpu")
+    torch.manual_seed(0)
+    b = torch.randn(4, 3, 2, 2)
+    assert torch.equal(a, b)
+    r = noise_like((4, 3, 2, 2), "cpu", repeat=True)
+    assert r.shape == (4, 3, 2, 2) and all(torch.equal(r[0], r[i]) for i in range(4))
