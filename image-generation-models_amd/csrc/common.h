@@ -17,6 +17,32 @@ int mi_set_error(int code, const char* fmt, ...);
     do { hipError_t e_ = hipGetLastError(); \
          if (e_ != hipSuccess) return mi_set_error((int)e_, "%s: %s", __func__, hipGetErrorString(e_)); } while (0)
 
+// Zero fill on a stream as a KERNEL (round 5).  hipMemsetAsync becomes a memset node when the step is captured into a hipGraph, and on this
+// stack (ROCm 7.0) such a node was seen to take effect out of stream order in replays: the split-K GEMM of the time-MLP backward then added
+// its slices onto what the PREVIOUS tenant of that memory had left there (tools/proto/graph_nan.py: gradients of 1e38 from the second replay
+// on, one fresh process in ten).  A kernel node keeps its place.  bytes % 4 == 0, p 4-byte aligned.
+template <int = 0> __global__ void mi_zero_fill_kernel(uint32_t* __restrict__ p, size_t n) {
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((((uintptr_t)p) & 15) == 0) {
+        for (size_t i = i0; i < n4; i += stride) reinterpret_cast<uint4*>(p)[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (size_t i = 4 * n4 + i0; i < n; i += stride) p[i] = 0u;
+    } else {
+        for (size_t i = i0; i < n; i += stride) p[i] = 0u;
+    }
+}
+inline hipError_t mi_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (!bytes) return hipSuccess;
+#ifdef MI_ZERO_WITH_MEMSET        // A/B builds only: the memset-node form (tests/test_kernels_gpu.py::test_split_gemm_in_a_replayed_graph_starts_from_zero)
+    return hipMemsetAsync(p, 0, bytes, st);
+#endif
+    const size_t n = bytes >> 2;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((mi_zero_fill_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), n);
+    return hipGetLastError();
+}
+
 // two fp32 -> packed bf16x2 (round-to-nearest-even, one v_cvt_pk_bf16_f32)
 // Profiling / experiment switches (tile forcing, XCD maps off, alternative plans): read from the environment only in builds with
 // -DMI_EXPERIMENT (tools/), constants in the product library -- every one of them would otherwise be an untested configuration.

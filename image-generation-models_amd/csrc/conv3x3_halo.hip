@@ -1007,7 +1007,7 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
                 a.TH = th; a.TI = ti; a.tiles_per_img = ti > 1 ? 1 : a.H / th; a.HP = ti * (th + 2) * (a.W + 2);
                 a.ksplit = ks; a.xmap = 0;
                 if (!d->accumulate) {
-                    hipError_t e = hipMemsetAsync(y, 0, (size_t)d->N * d->OH * d->OW * d->ldy * sizeof(float), st);
+                    hipError_t e = mi_zero_async(y, (size_t)d->N * d->OH * d->OW * d->ldy * sizeof(float), st);
                     if (e != hipSuccess) return mi_set_error((int)e, "mi_conv3x3_bf16w: memset: %s", hipGetErrorString(e));
                 }
                 if (io & 1) launch_halo<256, 64, 3, true, 1>(a, st); else launch_halo<256, 64, 3, true>(a, st);
@@ -1030,7 +1030,7 @@ static int halo_dispatch(const MiConvDesc* d, const float* x, const float* x2, c
         if (ks > 1 && (d->accumulate || d->ldy == d->Nc)) {
             a.ksplit = ks;
             if (!d->accumulate) {
-                hipError_t e = hipMemsetAsync(y, 0, (size_t)d->N * d->OH * d->OW * d->ldy * sizeof(float), st);
+                hipError_t e = mi_zero_async(y, (size_t)d->N * d->OH * d->OW * d->ldy * sizeof(float), st);
                 if (e != hipSuccess) return mi_set_error((int)e, "mi_conv3x3_bf16w: memset: %s", hipGetErrorString(e));
             }
         }

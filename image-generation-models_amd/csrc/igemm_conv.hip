@@ -637,7 +637,7 @@ static int igemm_dispatch(const MiConvDesc* d, const float* x, const float* x2, 
             int ks = d->K / 128; if (ks > 32) ks = 32;
             a.ksplit = ks;
             if (!d->accumulate) {
-                hipError_t e = hipMemsetAsync(y, 0, (size_t)d->N * d->OH * d->OW * d->ldy * sizeof(float), st);
+                hipError_t e = mi_zero_async(y, (size_t)d->N * d->OH * d->OW * d->ldy * sizeof(float), st);
                 if (e != hipSuccess) return mi_set_error((int)e, "mi_conv_igemm: memset: %s", hipGetErrorString(e));
             }
         }

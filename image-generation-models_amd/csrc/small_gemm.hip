@@ -106,7 +106,7 @@ extern "C" int mi_small_gemm(int ta, int tb, int I, int J, int K, const float* A
     a.ksplit = (nchunks + a.cps - 1) / a.cps;
     hipStream_t st = (hipStream_t)stream;
     if (a.ksplit > 1 && !accumulate) {
-        hipError_t e = hipMemsetAsync(C, 0, (size_t)I * ldc * sizeof(float), st);
+        hipError_t e = mi_zero_async(C, (size_t)I * ldc * sizeof(float), st);
         if (e != hipSuccess) return mi_set_error((int)e, "mi_small_gemm: memset: %s", hipGetErrorString(e));
     }
     dim3 grid((I + 31) / 32, (J + 31) / 32, a.ksplit);

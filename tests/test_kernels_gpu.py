@@ -1882,6 +1882,34 @@ def test_small_gemm_linear(K, M, N, Kc):
     assert K.small_gemm(False, True, xg[:, :Kc - 1], wg[:, :Kc - 1]) is None          # K % 32 != 0 -> caller falls back
 
 
+def test_split_gemm_in_a_replayed_graph_starts_from_zero(K):
+    """The split-K forms zero their output and add their slices with atomics.  Captured into a hipGraph that zero fill has to stay in
+    stream order: as a memset node (hipMemsetAsync) it was seen to take effect BEFORE the previous writer of the same memory in replays
+    (round 5: time-MLP gradients of 1e38 from the second replay on, one fresh process in ten, tools/proto/graph_nan.py); it is a kernel
+    now (mi_zero_async).  Here the output buffer is poisoned inside the graph right before the GEMM, 300 replays.  (A guard for the kernel
+    form, not a reproducer of the fault: the memset build passes this test too -- the fault needed the whole step, one process in ~15.)"""
+    g = torch.Generator().manual_seed(7)
+    dy = torch.randn(16, 448, generator=g).to(DEV)
+    w = (torch.randn(448, 32, generator=g) / 21.0).to(DEV)
+    ref = dy.double().cpu() @ w.double().cpu()
+    out = torch.empty(16, 32, device=DEV)
+    poison = torch.full((16, 32), 3e38, device=DEV)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        assert K.small_gemm(False, False, dy, w, out=out, allow_split=True) is not None       # (lazy set-up outside the capture)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            torch.mul(poison, 1.0, out=out)                                                   # the previous tenant's leftovers (a kernel node)
+            K.small_gemm(False, False, dy, w, out=out, allow_split=True)
+    torch.cuda.current_stream().wait_stream(s)
+    worst = 0.0
+    for _ in range(300):
+        gr.replay()
+        worst = max(worst, rel_err(out, ref))
+    assert worst < 2e-6, worst
+
+
 def test_halo_kernel_takes_every_bf16_layer_in_a_subprocess():
     """MI_CONV_AUTO=0: the register-staged halo kernel (the fallback of the per-shape pick, and the only kernel behind the dual-output,
     epilogue-sum and fused entry points) on the bf16-stored layers that conv_pw / conv1x1_pw take by default -- every conv kernel test and the

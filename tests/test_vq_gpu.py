@@ -138,8 +138,12 @@ def test_vector_quantizer_module_matches_reference(golden_dir, tag):
     q2, _, _ = vq(z.detach())
     wgt = torch.randn_like(q2)
     (q2 * wgt).sum().backward()
-    ref = torch.zeros_like(cb).index_add_(0, torch.from_numpy(g[f"{tag}.idx"]), V.rows_of(wgt.cpu()))
-    assert torch.allclose(vq.embedding.grad.cpu(), ref, rtol=1e-5, atol=1e-6)
+    idx = torch.from_numpy(g[f"{tag}.idx"])
+    ref = torch.zeros_like(cb).index_add_(0, idx, V.rows_of(wgt.cpu()))
+    # (the bound is relative to the sum of the MAGNITUDES of a code's rows: the kernel adds them with fp32 atomics in whatever order they
+    #  arrive, and a sum that cancels to ~0 keeps the rounding of its summands)
+    mag = torch.zeros_like(cb).index_add_(0, idx, V.rows_of(wgt.cpu()).abs())
+    assert bool(((vq.embedding.grad.cpu() - ref).abs() <= 2e-6 * mag + 1e-6).all())
 
 
 def test_vector_quantizer_refuses_cpu():
