@@ -482,6 +482,13 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el)
     final_loss = float(loss.detach())
+    # a throughput of steps that trained garbage is not a measurement: the loss, every weight and every gradient after the timed steps
+    # must be finite (outside the timed region; round 5 found a replayed-graph fault that left NaN weights and a normal step time)
+    unet_ = model.denoising_model
+    state_finite = bool(torch.isfinite(unet_.flat_params).all()) and bool(torch.isfinite(unet_.flat_grads).all()) and final_loss == final_loss \
+        and abs(final_loss) != float("inf")
+    if not state_finite:
+        raise SystemExit(f"bench.py: non-finite training state after the timed steps (loss {final_loss}); no throughput is reported")
     ms_per_step = elapsed / args.steps * 1e3
     images_per_s = world * B * args.steps / elapsed
 
@@ -700,6 +707,7 @@ def main():
             "train_tflops": round(images_per_s * TRAIN_GF / 1e3, 1),
             "denoise_tflops": round(denoise_steps_per_s * 64 * FWD_GF / 1e3, 1),
             "final_loss": round(final_loss, 5),
+            "state_finite_after_timed_steps": state_finite,
             "roofline": roof, "fp32_mode": fp32_mode, "cpu_baseline": cpu,
         }
         # (RCCL writes its version banner through C stdio, which is flushed at exit -- i.e. AFTER a line printed from Python: flush it
