@@ -531,7 +531,7 @@ def main():
     model.eval()
     gs = GraphSampler(model.diffusion_model, (64, 3, SIDE, SIDE))
     gs._capture()
-    gs.x.normal_(); gs.t.fill_(999)
+    gs._set_image(torch.randn_like(gs.x)); gs.t.fill_(999)
     for _ in range(5):
         gs.z.normal_(); gs.graph.replay()
     sync()

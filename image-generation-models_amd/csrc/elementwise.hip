@@ -106,10 +106,12 @@ __global__ __launch_bounds__(256) void eps_loss_kernel(int B, int C, int HW, con
 }
 
 // posterior step (ddpm.py:359-397)
-__global__ void p_sample_kernel(int B, int C, int HW, const float* __restrict__ x, const float* __restrict__ eps, int ld,
+// (xp may be x itself -- every element is read and written by the same thread -- so neither is `restrict`: the graph sampler updates its
+//  image in place and takes the NHWC copy the next UNet forward reads from the same launch)
+__global__ void p_sample_kernel(int B, int C, int HW, const float* x, const float* __restrict__ eps, int ld,
                                 const float* __restrict__ z, const int64_t* __restrict__ t, const float* __restrict__ sr,
                                 const float* __restrict__ srm1, const float* __restrict__ c1, const float* __restrict__ c2,
-                                const float* __restrict__ lv, int clip, float* __restrict__ xp, float* __restrict__ xp_nhwc, int ldo) {
+                                const float* __restrict__ lv, int clip, float* xp, float* __restrict__ xp_nhwc, int ldo) {
     size_t tot = (size_t)B * C * HW;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
         int p = i % HW; size_t bc = i / HW; int c = bc % C; int b = bc / C;

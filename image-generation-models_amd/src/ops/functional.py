@@ -1421,11 +1421,17 @@ def eps_loss(pred_nhwc, target_nchw, loss_type=0, want_grad=True, gscale=1.0):
     return loss, (dpred[..., :Cc] if want_grad else None)
 
 
-def p_sample_update(x, eps_nhwc, z, t, tab, clip=True, want_nhwc=True):
+def p_sample_update(x, eps_nhwc, z, t, tab, clip=True, want_nhwc=True, out=None, out_nhwc=None):
+    """x_{t-1} from (x_t, eps prediction, z).  out: where the NCHW result goes (may be x itself: in place); out_nhwc: a [B, H, W, ldo]
+    buffer (padding channels zero) that receives the NHWC copy -- the graph sampler's static buffers."""
     B, Cc, H, W = x.shape
     ldo = (Cc + 3) // 4 * 4
-    xp = torch.empty_like(x)
-    xp_nhwc = torch.zeros((B, H, W, ldo), device=x.device, dtype=torch.float32) if want_nhwc else None
+    xp = torch.empty_like(x) if out is None else out
+    if out_nhwc is not None:
+        assert out_nhwc.shape == (B, H, W, ldo) and out_nhwc.is_contiguous() and out_nhwc.dtype == torch.float32
+        xp_nhwc = out_nhwc
+    else:
+        xp_nhwc = torch.zeros((B, H, W, ldo), device=x.device, dtype=torch.float32) if want_nhwc else None
     check(load_library().mi_p_sample_update(
         B, Cc, H * W, _p(x), _p(eps_nhwc), ld_of(eps_nhwc), _p(z), _p(t), _p(tab["sqrt_recip_alphas_cumprod"]),
         _p(tab["sqrt_recipm1_alphas_cumprod"]), _p(tab["posterior_mean_coef1"]), _p(tab["posterior_mean_coef2"]),

@@ -94,7 +94,7 @@ def test_graph_sampler_sees_optimizer_step_in_bf16_mode():
             gs._capture()
         else:
             gs.refresh()
-        gs.x.copy_(tape[0].to(DEV)); gs.t.fill_(5)
+        gs._set_image(tape[0].to(DEV)); gs.t.fill_(5)
         for i in range(6):
             gs.z.copy_(tape[1 + i].to(DEV)); gs.graph.replay()
         return gs.x.clone()

@@ -527,7 +527,7 @@ def test_graph_sampler_matches_eager():
     eager = gd.p_sample_loop(shape, use_graph=False)
     gs = GraphSampler(gd, shape)
     gs._capture()
-    gs.x.copy_(tape[0]); gs.t.fill_(5)
+    gs._set_image(tape[0]); gs.t.fill_(5)
     for i in range(6):
         gs.z.copy_(tape[1 + i]); gs.graph.replay()
     assert float((gs.x - eager).abs().max()) < 1e-5
