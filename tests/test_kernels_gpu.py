@@ -577,6 +577,12 @@ def test_diffusion_elementwise(K, golden_dir):
     xp, xp_nhwc = K.p_sample_update(xt_ref.to(DEV), to_nhwc_gpu(pred), z.to(DEV), t.to(DEV), tg)
     assert torch.allclose(xp.cpu(), xp_ref, atol=2e-5, rtol=1e-5)
     assert torch.allclose(from_nhwc(xp_nhwc), xp_ref, atol=2e-5, rtol=1e-5)
+    # the graph sampler's form: the image updated in place, the NHWC copy into a caller-owned buffer whose padding channel stays zero
+    x_io = xt_ref.to(DEV).clone()
+    nh = torch.zeros(B, 8, 8, 4, device=DEV)
+    got, got_nhwc = K.p_sample_update(x_io, to_nhwc_gpu(pred), z.to(DEV), t.to(DEV), tg, out=x_io, out_nhwc=nh)
+    assert got.data_ptr() == x_io.data_ptr() and torch.equal(x_io, xp)
+    assert got_nhwc.data_ptr() == nh.data_ptr() and torch.equal(nh[..., :3], xp_nhwc) and float(nh[..., 3].abs().max()) == 0.0
     # Adam: 3 steps against torch.optim.Adam
     p = torch.randn(1003, generator=g)
     pr = p.clone().requires_grad_(True)
@@ -1880,6 +1886,21 @@ def test_small_gemm_linear(K, M, N, Kc):
     else:
         assert rel_err(dW - 0.25, dy.t() @ x) < 2e-6
     assert K.small_gemm(False, True, xg[:, :Kc - 1], wg[:, :Kc - 1]) is None          # K % 32 != 0 -> caller falls back
+
+
+@pytest.mark.parametrize("n,off", [(1, 0), (3, 1), (4, 0), (1023, 3), (4096, 2), (1 << 20, 0), ((1 << 20) + 7, 1)])
+def test_split_k_zero_fill_sizes_and_alignments(K, n, off):
+    """mi_zero_async (the fill kernel behind every split-K output) over sizes / alignments of its vector and tail paths, through the one
+    entry point that exposes it directly: a split small GEMM into a slice that starts `off` floats into a poisoned buffer."""
+    I, J = (n + 31) // 32, 32
+    buf = torch.full((off + I * J + 64,), 7.0, device=DEV)
+    out = buf[off:off + I * J].view(I, J)
+    g = torch.Generator().manual_seed(n)
+    A = torch.randn(I, 448, generator=g).to(DEV); Bm = (torch.randn(448, J, generator=g) / 21.0).to(DEV)
+    if K.small_gemm(False, False, A, Bm, out=out, allow_split=True) is None:
+        pytest.skip("shape not taken by mi_small_gemm")
+    assert rel_err(out, A.double().cpu() @ Bm.double().cpu()) < 2e-6
+    assert bool((buf[:off] == 7.0).all()) and bool((buf[off + I * J:] == 7.0).all())         # nothing outside the slice was touched
 
 
 def test_split_gemm_in_a_replayed_graph_starts_from_zero(K):
