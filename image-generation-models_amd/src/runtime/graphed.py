@@ -12,6 +12,39 @@ from __future__ import annotations
 import torch
 
 
+def _new_graph():
+    """A CUDAGraph that keeps its captured hipGraph_t readable (node_types) where this torch can."""
+    try:
+        return torch.cuda.CUDAGraph(keep_graph=True)
+    except TypeError:
+        return torch.cuda.CUDAGraph()
+
+
+def node_types(g):
+    """{node type: count} of a captured graph, None when it cannot be read.  The steps captured here are meant to be kernel nodes only: a
+    memset node (hipMemsetAsync in a library call) was seen to take effect out of stream order in replays (round 5)."""
+    try:
+        import collections
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        names = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "waitEvent", 7: "eventRecord"}
+        raw = g.raw_cuda_graph()
+        n = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n)) != 0:
+            return None
+        arr = (ctypes.c_void_p * n.value)()
+        if hip.hipGraphGetNodes(ctypes.c_void_p(raw), arr, ctypes.byref(n)) != 0:
+            return None
+        c = collections.Counter()
+        for i in range(n.value):
+            t = ctypes.c_int(-1)
+            hip.hipGraphNodeGetType(ctypes.c_void_p(arr[i]), ctypes.byref(t))
+            c[names.get(t.value, str(t.value))] += 1
+        return dict(c)
+    except Exception:       # noqa: BLE001
+        return None
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer, example_batch, warmup: int = 3):
         self.model, self.opt = model, optimizer
@@ -26,7 +59,7 @@ class GraphedTrainStep:
                 loss.backward()
                 optimizer.step()
         torch.cuda.current_stream().wait_stream(s)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = _new_graph()
         with torch.cuda.graph(self.graph):
             self.loss = model.training_step((self.x,) + self.rest, 0)
             self.loss.backward()
