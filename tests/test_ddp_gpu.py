@@ -131,6 +131,10 @@ def _worker_graph(rank, world, port, mode, q):
                 gs = SegmentedGraphedTrainStep(m, opt, red, (x, None))        # the capture executes nothing
                 gs((x, None)); gs((x, None))
                 nseg = len(gs.segments)
+                from src.runtime.graphed import node_types
+                for g_, _r in gs.segments:                       # kernel nodes only (round 5: a memset node ran out of order in replays)
+                    kinds = node_types(g_)
+                    assert kinds is None or set(kinds) <= {"kernel"}, kinds
                 rngs = [r for _, r in gs.segments if r is not None]
                 assert all(r is not None for _, r in gs.segments[:-1])        # every graph but possibly a trailing one ends in its bucket
                 assert sorted(rngs)[0][0] == 0 and red.launched == rngs       # the buckets cover the buffer down to offset 0
