@@ -1227,11 +1227,16 @@ struct Pw1Args {
 // IN32 (bf16 MFMA mode): x / x2 are fp32 tensors (the residual-stream gradient of to_out / res_conv's data gradients, res_conv's input in
 // inference): a chunk's pieces are loaded into registers during the previous chunk, rounded to bf16 once and written to the lane's slot
 // of the tile after that chunk's MFMAs (see conv_pw_kernel's IN32).
-template <bool OUT16, bool DUAL, int PXT, bool F32 = false, bool IN32 = false>
+// NLOOP (round 5; bf16 in / bf16 out, K = 128, nothing added on the way out: to_qkv at the 128-channel level): ONE workgroup per pixel tile
+// walks all channel tiles.  The activation tile is staged once (the 2-D grid had every channel tile's workgroup fetch it again from L2 and
+// sit through its own load -> MFMA -> store chain: 3.9 TB/s of algorithmic traffic at level 0 against 6.1 for to_out), the next channel
+// tile's fragments are requested under the current tile's MFMAs, and the epilogue stages through the second (otherwise idle) buffer.
+template <bool OUT16, bool DUAL, int PXT, bool F32 = false, bool IN32 = false, bool NLOOP = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
     MI_PRIO_UP();
     static_assert(!F32 || (!OUT16 && !DUAL), "exact-fp32 mode writes fp32");
     static_assert(!IN32 || !F32, "fp32 input of the bf16 MFMA mode");
+    static_assert(!NLOOP || (OUT16 && !DUAL && !F32 && !IN32 && PXT == 128), "channel-tile loop: the bf16 -> bf16 single-chunk form");
     constexpr int ESZ = F32 ? 4 : 2, EPP = 16 / ESZ, CKC = 16 * EPP;       // element size, elements per 16-byte piece, channels per chunk
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
@@ -1243,14 +1248,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     // the channel tiles of one pixel tile are adjacent in time on one XCD (ids xcd + 8*slot): the tile is read from HBM once
     int bx = blockIdx.x, by = blockIdx.y;
-    if (a.gy > 1 && a.gx % 8 == 0) {
+    if (!NLOOP && a.gy > 1 && a.gx % 8 == 0) {
         const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
         bx = xcd * (a.gx >> 3) + slot / a.gy; by = slot % a.gy;
     }
-    const int m0 = bx * PXT, n0 = by * 128;
+    if constexpr (NLOOP) by = 0;
+    const int m0 = bx * PXT;
+    int n0 = by * 128;
     const int NB = a.Nc >> 5, KQ = a.K / (2 * EPP), nchunks = a.K / CKC;
-    const bool live = n0 + 32 * wv < a.Nc;
-    const int nb = min((n0 >> 5) + wv, NB - 1);
+    bool live = n0 + 32 * wv < a.Nc;
+    int nb = min((n0 >> 5) + wv, NB - 1);
 
     // activation pieces of chunk ch -> buffer ch & 1: piece p = wv + 4i = pixels 8 (p % (PXT / 8)) .. +7 of half p / (PXT / 8); lane ->
     // pixel l >> 3, stored 16-byte position l & 7 holds channel chunk (l & 7) ^ ((pixel >> 1) & 7)
@@ -1326,6 +1333,89 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
             bias_q[rq] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (a.bias && live) bias_q[rq] = *reinterpret_cast<const f32x4*>(a.bias + n0 + 4 * (8 * wv + 2 * rq + (l >> 5)));
         }
+    }
+    if constexpr (NLOOP) {
+        typedef __attribute__((address_space(3))) u32x2 lds_u32x2n;
+        typedef __attribute__((address_space(3))) u32x4 lds_u32x4n;
+        // fragments of channel tile jt -> register set: base of this wave's 32 channels, one 8 KB chunk
+        auto load_wj = [&](int jt, auto setc) {
+            constexpr int set = decltype(setc)::value;
+            const int nbj = min(4 * jt + wv, NB - 1);
+            const uint64_t q = (uint64_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(a.w) + (size_t)nbj * KQ * 1024);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
+            const uint64_t wj = ((uint64_t)hi << 32) | lo;
+            static_for<0, 4>([&](auto uc) { gload16s<decltype(uc)::value * 1024>(WB[set][decltype(uc)::value], wj, wl16); });
+            static_for<0, 4>([&](auto uc) { gload16s<decltype(uc)::value * 1024>(WB[set][4 + decltype(uc)::value], wj, wl16 + 4096); });
+        };
+        stage_x(0);
+        load_wj(0, std::integral_constant<int, 0>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_for<0, 8>([&](auto uc) { landed16(WB[0][decltype(uc)::value]); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // the tile is every wave's
+        asm volatile("" ::: "memory");
+        auto cotile = [&](int jt, auto setc) {
+            constexpr int set = decltype(setc)::value;
+            n0 = jt * 128; live = n0 + 32 * wv < a.Nc;
+            if (jt + 1 < a.gy) load_wj(jt + 1, std::integral_constant<int, set ^ 1>{});
+            bf16x8 XC[2][NBLK];
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i) XC[0][i] = lds_b128p(xa[i]);
+            static_for<0, 8>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if constexpr (u + 1 < 8) {
+                    constexpr int un = u + 1;
+#pragma unroll
+                    for (int i = 0; i < NBLK; ++i) XC[un & 1][i] = lds_b128p((xa[i] ^ ((un & 3) * 32)) + (un >> 2) * XH);
+                }
+#pragma unroll
+                for (int i = 0; i < NBLK; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WB[set][u]), XC[u & 1][i], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // this channel tile out through the second buffer (the first one keeps the activation tile); the stores of the previous
+            // channel tile were read out of it before the barrier that closed that epilogue
+            if (live) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int ck = 8 * wv + 2 * rq + (l >> 5);
+                    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias) bq = *reinterpret_cast<const f32x4*>(a.bias + n0 + 4 * ck);
+#pragma unroll
+                    for (int i = 0; i < NBLK; ++i) {
+                        const int p = i * 32 + (l & 31);
+                        *(lds_u32x2n*)(uintptr_t)(lds0 + XB + p * 256 + ((ck ^ ((p & 15) << 1)) << 3)) =
+                            u32x2{pack_bf16(acc[i][4 * rq] + bq.x, acc[i][4 * rq + 1] + bq.y), pack_bf16(acc[i][4 * rq + 2] + bq.z, acc[i][4 * rq + 3] + bq.w)};
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            // the next channel tile's fragments (requested 32 MFMAs ago) are waited for HERE, before this tile's stores are issued: vmcnt
+            // counts stores too, and a wait behind them would put a write round trip between two channel tiles
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            static_for<0, 8>([&](auto uc) { landed16(WB[set ^ 1][decltype(uc)::value]); });
+            __syncthreads();
+            {
+                const int j = t & 15, col = n0 + 8 * j;
+                if (col < a.Nc) {
+#pragma unroll
+                    for (int it = 0; it < PXT / 16; ++it) {
+                        const int p = it * 16 + (t >> 4);
+                        const u32x4 o = *(lds_u32x4n*)(uintptr_t)(lds0 + XB + p * 256 + (((2 * j) ^ ((p & 15) << 1)) << 3));
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(a.y) + ((size_t)m0 + p) * a.ldy + col) = o;
+                    }
+                }
+            }
+            __syncthreads();                                   // the staging area is free again (every lane holds what it read)
+        };
+        for (int jt = 0; jt < a.gy; jt += 2) {
+            cotile(jt, std::integral_constant<int, 0>{});
+            if (jt + 1 < a.gy) cotile(jt + 1, std::integral_constant<int, 1>{});
+        }
+        return;
     }
     if constexpr (IN32) load_x32(0); else stage_x(0);
     load_w(0, std::integral_constant<int, 0>{});
@@ -2012,6 +2102,13 @@ extern "C" int mi_conv1x1_pw_f32(const MiConvDesc* d, const float* x, const floa
     return 0;
 }
 // y fp32 or bf16 (out_bf16); y_bf16 (optional, fp32 y only): the bf16 copy of y written by the same epilogue, pixel stride ldy16
+static int g_pw1_nloop = 1;           // tests / A-B: 0 = the 2-D grid for every layer, 2 = the loop form from two channel tiles up whatever the grid
+static int g_pw1_nloop_min = 1024;
+extern "C" int mi_debug_conv1x1_pw_nloop(int on) {
+    const int was = g_pw1_nloop;
+    if (on >= 0) { g_pw1_nloop = on > 2 ? 1 : on; g_pw1_nloop_min = on == 2 ? 0 : 1024; }
+    return was;
+}
 extern "C" int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias, const float* residual,
                              void* y, int out_bf16, void* y_bf16, int ldy16, void* stream) {
     MI_REQUIRE(d && x && w_frag_bf16 && y, "null argument");
@@ -2038,6 +2135,16 @@ extern "C" int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* x2,
         (void)once_; \
         hipLaunchKernelGGL((conv1x1_pw_kernel<O16, DU, PX>), grid, dim3(256), pw1_lds(PX), st, a); } while (0)
 #define MI_PW1_PICK(O16, DU) do { if (small) MI_PW1_GO(O16, DU, 64); else MI_PW1_GO(O16, DU, 128); } while (0)
+    // to_qkv at the 128-channel level: one workgroup per pixel tile walks the channel tiles (conv1x1_pw_kernel's NLOOP)
+    // (from 1 024 pixel tiles up: [128,32,32,128] -> 384 goes 34.3 -> 29.3 us = 3.9 -> 4.6 TB/s of algorithmic traffic; at the sampler's B = 64 the
+    //  512 workgroups of the loop form are one round of two per CU and time the same as the 1 536 of the 2-D grid or slightly worse)
+    if (out_bf16 && !residual && !d->accumulate && !small && d->K == 128 && d->K1 == d->K && a.gy > 1 && g_pw1_nloop && a.gx >= g_pw1_nloop_min) {
+        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<true, false, 128, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); return true; }();
+        (void)once_;
+        hipLaunchKernelGGL((conv1x1_pw_kernel<true, false, 128, false, false, true>), dim3((unsigned)a.gx), dim3(256), pw1_lds(128), st, a);
+        MI_LAUNCH_CHECK();
+        return 0;
+    }
     if (out_bf16) MI_PW1_PICK(true, false);
     else if (y_bf16) MI_PW1_PICK(false, true);
     else MI_PW1_PICK(false, false);

@@ -291,7 +291,13 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
         if e0 is not None:
             nb = (N * H * W * K * 2 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual) + (2 if want16 else 0)) + K * Nc * 2)
             px = 64 if (N * H * W // 128) * ((Nc + 127) // 128) < 256 else 128
-            _probe_close(e0, f"conv1x1_pw_kernel<{'true' if _b16(out) else 'false'}, {'true' if want16 else 'false'}, {px}>", 2.0 * N * H * W * Nc * K,
+            # (the channel-tile loop instantiation: mi_conv1x1_pw's condition, restated for the symbol name only)
+            sw = lib.mi_debug_conv1x1_pw_nloop(-1)
+            nloop = (_b16(out) and residual is None and not accumulate and px == 128 and K == 128 and x2 is None and Nc > 128
+                     and (sw == 2 or (sw == 1 and N * H * W // 128 >= 1024)))
+            sym = (f"conv1x1_pw_kernel<true, false, 128, false, false, true>" if nloop else
+                   f"conv1x1_pw_kernel<{'true' if _b16(out) else 'false'}, {'true' if want16 else 'false'}, {px}>")
+            _probe_close(e0, sym, 2.0 * N * H * W * Nc * K,
                          f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} flip{int(flip)} acc{int(accumulate)}", nb)
         return (out, y16) if want16 else out
     if (ksize == 1 and not _b16(x) and USE_CONV_PW and wq is not None and not want16 and gn_sums is None and K % 128 == 0

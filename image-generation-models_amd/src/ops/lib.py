@@ -88,6 +88,7 @@ SIGNATURES = {
     "mi_conv3x3_pw_tile": [C.POINTER(MiConvDesc)],
     "mi_debug_conv_pw_tile": [_I],
     "mi_debug_conv_pw_auto256": [_I],
+    "mi_debug_conv1x1_pw_nloop": [_I],
     "mi_conv3x3_pw_f32_tile": [C.POINTER(MiConvDesc)],
     "mi_conv3x3_pw_f32": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "mi_conv1x1_pw_x32_supported": [C.POINTER(MiConvDesc)],
@@ -224,6 +225,8 @@ def load_library():
         raise RuntimeError(f"{path}: ABI version {lib.mi_abi_version()} != {ABI_VERSION}; rebuild")
     if os.environ.get("MI_DEBUG_KNOBS") == "1" and os.environ.get("MI_PW_AUTO256") is not None:
         lib.mi_debug_conv_pw_auto256(int(os.environ["MI_PW_AUTO256"]))      # A/B: 0 = no 256-pixel conv tiles, n = from n workgroups up
+    if os.environ.get("MI_DEBUG_KNOBS") == "1" and os.environ.get("MI_PW1_NLOOP") is not None:
+        lib.mi_debug_conv1x1_pw_nloop(int(os.environ["MI_PW1_NLOOP"]))     # A/B: 0 = to_qkv on the 2-D grid
     _LIB = lib
     return lib
 

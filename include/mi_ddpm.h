@@ -190,6 +190,7 @@ int mi_pack_weights_f32frag(int nent, const void* entries_dev, int total_tiles, 
                             void* stream);
 int mi_debug_conv_pw_tile(int pt);               /* tests: force the pixel tile (64 / 128 / 256), 0 = automatic */
 int mi_debug_conv_pw_auto256(int min_workgroups); /* A/B switch: the automatic pick takes 256-pixel tiles from this many workgroups up (0 = never; default 256) */
+int mi_debug_conv1x1_pw_nloop(int on);          /* A/B switch: 0 = the bf16 -> bf16 K = 128 1x1 conv (to_qkv) always on the 2-D grid, 1 = the channel-tile loop from 1024 pixel tiles up (default), 2 = from any grid (tests), < 0 = query only; returns the previous value */
 int mi_conv3x3_pw_tile(const MiConvDesc* d);      /* pixels per workgroup the launch would use: 256 (grids that still fill the chip), 128, or 64 for small grids; 0 = unsupported */
 int mi_conv3x3_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias,
                   const float* residual, void* y, int out_bf16, void* stream);

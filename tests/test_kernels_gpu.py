@@ -996,6 +996,36 @@ def test_conv1x1_pw_f32(K, cfg, pw_always):
     assert _conv_launches(pw_always)[-1].startswith("conv1x1_pw_kernel<false, false,") and _conv_launches(pw_always)[-1].endswith(", true>")
 
 
+@pytest.mark.parametrize("N,H,Co,bias", [(32, 32, 384, False), (64, 16, 384, True), (32, 32, 320, True), (256, 8, 256, False), (128, 32, 384, False)])
+def test_conv1x1_pw_channel_tile_loop(K, N, H, Co, bias, pw_always):
+    """to_qkv at the 128-channel level (bf16 in, bf16 out, K = 128, 128-pixel tiles): one workgroup per pixel tile walks the channel
+    tiles (conv1x1_pw_kernel's NLOOP).  Against fp64 on the bf16-rounded operands, and bit-equal to the 2-D-grid form of the same kernel
+    (same contraction order, same rounding); a ragged last channel tile (320 = 2.5 tiles) and a bias ride along."""
+    g = torch.Generator().manual_seed(97)
+    Ci = 128
+    x = torch.randn(N, Ci, H, H, generator=g).bfloat16()
+    w = torch.randn(Co, Ci, 1, 1, generator=g) / math.sqrt(Ci)
+    b = torch.randn(Co, generator=g) if bias else None
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+    flat, wd, wf, offs, wdq, wfq = _pack(K, [conv_w_storage(w.double())], frag=True)
+    ref = F.conv2d(x.double(), w.bfloat16().double()) + (b.double()[None, :, None, None] if bias else 0.0)
+    kw = dict(K=Ci, Nc=Co, flip=False, ksize=1, out_dtype=torch.bfloat16, wq=wfq, bias=b.to(DEV) if bias else None)
+    lib = K.load_library()
+    was = lib.mi_debug_conv1x1_pw_nloop(2)          # the loop form whatever the grid (the default takes it from 1 024 pixel tiles up)
+    try:
+        y = K.conv3x3_bf16w(nh(x), wf, **kw)
+        torch.cuda.synchronize()
+        assert _conv_launches(pw_always)[-1] == "conv1x1_pw_kernel<true, false, 128, false, false, true>", _conv_launches(pw_always)
+        assert y.dtype == torch.bfloat16 and rel_err(from_nhwc(y.float()), ref) < 6e-3
+        lib.mi_debug_conv1x1_pw_nloop(0)
+        y2 = K.conv3x3_bf16w(nh(x), wf, **kw)
+        torch.cuda.synchronize()
+        assert _conv_launches(pw_always)[-1] == "conv1x1_pw_kernel<true, false, 128>", _conv_launches(pw_always)
+    finally:
+        lib.mi_debug_conv1x1_pw_nloop(was)
+    assert torch.equal(y, y2)
+
+
 @pytest.mark.parametrize("cfg", [dict(N=8, H=32, Ci=128, Co=128), dict(N=16, H=8, Ci=512, Co=128), dict(N=8, H=8, Ci=1024, Co=256, split=512),
                                  dict(N=4, H=16, Ci=128, Co=256), dict(N=64, H=16, Ci=384, Co=128, acc=True)])
 @pytest.mark.parametrize("out16", [False, True])
