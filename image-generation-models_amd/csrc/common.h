@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <atomic>
 #include "../../include/mi_ddpm.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -16,6 +17,19 @@ int mi_set_error(int code, const char* fmt, ...);
 #define MI_LAUNCH_CHECK() \
     do { hipError_t e_ = hipGetLastError(); \
          if (e_ != hipSuccess) return mi_set_error((int)e_, "%s: %s", __func__, hipGetErrorString(e_)); } while (0)
+
+// One-time set-up PER DEVICE (hipFuncSetAttribute, symbol addresses): a function-local `static bool once = [] {...}()` does the work on
+// whichever device is current at the first call only -- a process that later launches on another device (a model moved to cuda:1, a
+// single-process multi-GPU host) would run without it.  run() is idempotent work, so two threads racing through it is harmless.
+struct MiPerDevice {
+    std::atomic<unsigned long long> done{0};
+    template <class F> void run(F&& f) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const unsigned long long bit = 1ull << (d & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) { f(); done.fetch_or(bit, std::memory_order_release); }
+    }
+};
 
 // Zero fill on a stream as a KERNEL (round 5).  hipMemsetAsync becomes a memset node when the step is captured into a hipGraph, and on this
 // stack (ROCm 7.0) such a node was seen to take effect out of stream order in replays: the split-K GEMM of the time-MLP backward then added

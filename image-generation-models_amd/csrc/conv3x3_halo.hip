@@ -753,11 +753,9 @@ void launch_halo(const HaloArgs& a_in, hipStream_t st) {
     // 1x1 convs with several channel tiles (to_qkv: 3): (P, Q) = (8, 1) -- an XCD walks its pixel tiles with the channel tiles of one
     // pixel tile adjacent, so the input tile is read from HBM once instead of once per channel tile (level 0: 203 -> 137 MB)
     if (q_env && KS == 1 && !SK && a.ksplit == 1 && a.gy > 1 && a.gx % 8 == 0) { a.qmap = 1; grid = dim3(grid.x * grid.y, 1, 1); }
-    static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE, PIPE, N64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return true;
-    }();
-    (void)once;
+    static MiPerDevice once;
+    once.run([] {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE, PIPE, N64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     hipLaunchKernelGGL((conv3x3_halo_kernel<BM, CK, KS, SK, IO, WAVES, FUSE, PIPE, N64>), grid, dim3(HaloCfg<BM, WAVES>::NT), lds, st, a);
 }
 

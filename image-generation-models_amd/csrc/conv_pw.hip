@@ -1791,8 +1791,17 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     a.tiles_per_img = a.TI > 1 ? 1 : a.H / a.TH;
     a.XP = a.TI * (a.TH + 2) * a.W;
     a.xmap = a.TI == 1 && a.tiles_per_img > 1 && a.N % 8 == 0;
-    static const void* zero_page = [] { void* p_ = nullptr; (void)hipGetSymbolAddress(&p_, HIP_SYMBOL(g_zero_page3)); return (const void*)p_; }();
-    if (!zero_page) return mi_set_error(-1, "%s: zero page address", who);
+    // (the zero page's address is per DEVICE and a failed lookup is not remembered)
+    static std::atomic<const void*> zero_pages[64];
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    const void* zero_page = zero_pages[dev_ & 63].load(std::memory_order_acquire);
+    if (!zero_page) {
+        void* p_ = nullptr;
+        if (hipGetSymbolAddress(&p_, HIP_SYMBOL(g_zero_page3)) != hipSuccess || !p_) return mi_set_error(-1, "%s: zero page address", who);
+        zero_pages[dev_ & 63].store(p_, std::memory_order_release);
+        zero_page = p_;
+    }
     a.zero = zero_page; a.tpi_magic = pw_magic(a.tiles_per_img); a.nch_magic = pw_magic(d->K / (f32 ? 32 : 64));
     { int ns = a.TH / (pt / 32), ln = 0; while ((1 << ln) < ns) ++ln; a.lnsub = ln; }
     dim3 grid((unsigned)((long)d->N * d->OH * d->OW / pt), (unsigned)((d->Nc + 127) / 128));
@@ -1802,8 +1811,8 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     hipStream_t st = (hipStream_t)stream;
     size_t lds = pw_lds(pt, in32);
 #define MI_PW_GO_T(O16, V, A, T) do { \
-        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, A, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
-        (void)once_; \
+        static MiPerDevice once_; \
+        once_.run([] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, A, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
         hipLaunchKernelGGL((conv_pw_kernel<O16, V, A, T>), grid, dim3(256), lds, st, a); } while (0)
 #define MI_PW_GO(O16, V, A) MI_PW_GO_T(O16, V, A, 128)
 #ifdef MI_PW_ABL_BUILD
@@ -1833,13 +1842,13 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     }
 #endif
 #define MI_PW_GO_X(O16, V, T) do { \
-        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, 0, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
-        (void)once_; \
+        static MiPerDevice once_; \
+        once_.run([] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, 0, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
         hipLaunchKernelGGL((conv_pw_kernel<O16, V, 0, T, true>), grid, dim3(256), lds, st, a); } while (0)
     if (f32) {
 #define MI_PW_GO_F(T) do { \
-        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<false, 0, 0, T, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
-        (void)once_; \
+        static MiPerDevice once_; \
+        once_.run([] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<false, 0, 0, T, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
         hipLaunchKernelGGL((conv_pw_kernel<false, 0, 0, T, false, true>), grid, dim3(256), lds, st, a); } while (0)
         if (out_bf16) return mi_set_error(-1, "%s: the exact-fp32 kernel writes fp32", who);
         if (pt == 64) MI_PW_GO_F(64); else MI_PW_GO_F(128);
@@ -2063,8 +2072,8 @@ extern "C" int mi_conv1x1_pw_x32(const MiConvDesc* d, const float* x, const floa
     if (a.gy > 1 && a.gx % 8 == 0) grid = dim3((unsigned)(a.gx * a.gy), 1, 1);
     hipStream_t st = (hipStream_t)stream;
 #define MI_PW1X_GO(O16, PX) do { \
-        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<O16, false, PX, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); return true; }(); \
-        (void)once_; \
+        static MiPerDevice once_; \
+        once_.run([] { (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<O16, false, PX, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); }); \
         hipLaunchKernelGGL((conv1x1_pw_kernel<O16, false, PX, false, true>), grid, dim3(256), pw1_lds(PX), st, a); } while (0)
     if (out_bf16) MI_PW1X_GO(true, 64); else MI_PW1X_GO(false, 64);
 #undef MI_PW1X_GO
@@ -2091,11 +2100,10 @@ extern "C" int mi_conv1x1_pw_f32(const MiConvDesc* d, const float* x, const floa
     dim3 grid((unsigned)a.gx, (unsigned)a.gy);
     if (a.gy > 1 && a.gx % 8 == 0) grid = dim3((unsigned)(a.gx * a.gy), 1, 1);
     hipStream_t st = (hipStream_t)stream;
-    static bool once_ = [] {
+    static MiPerDevice once_;
+    once_.run([] {
         (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<false, false, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<false, false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        return true; }();
-    (void)once_;
+        (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<false, false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); });
     if (small) hipLaunchKernelGGL((conv1x1_pw_kernel<false, false, 64, true>), grid, dim3(256), pw1_lds(64), st, a);
     else hipLaunchKernelGGL((conv1x1_pw_kernel<false, false, 128, true>), grid, dim3(256), 64 * 1024, st, a);
     MI_LAUNCH_CHECK();
@@ -2131,16 +2139,16 @@ extern "C" int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* x2,
     constexpr size_t lds = 64 * 1024;
     hipStream_t st = (hipStream_t)stream;
 #define MI_PW1_GO(O16, DU, PX) do { \
-        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<O16, DU, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); return true; }(); \
-        (void)once_; \
+        static MiPerDevice once_; \
+        once_.run([] { (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<O16, DU, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); }); \
         hipLaunchKernelGGL((conv1x1_pw_kernel<O16, DU, PX>), grid, dim3(256), pw1_lds(PX), st, a); } while (0)
 #define MI_PW1_PICK(O16, DU) do { if (small) MI_PW1_GO(O16, DU, 64); else MI_PW1_GO(O16, DU, 128); } while (0)
     // to_qkv at the 128-channel level: one workgroup per pixel tile walks the channel tiles (conv1x1_pw_kernel's NLOOP)
     // (from 1 024 pixel tiles up: [128,32,32,128] -> 384 goes 34.3 -> 29.3 us = 3.9 -> 4.6 TB/s of algorithmic traffic; at the sampler's B = 64 the
     //  512 workgroups of the loop form are one round of two per CU and time the same as the 1 536 of the 2-D grid or slightly worse)
     if (out_bf16 && !residual && !d->accumulate && !small && d->K == 128 && d->K1 == d->K && a.gy > 1 && g_pw1_nloop && a.gx >= g_pw1_nloop_min) {
-        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<true, false, 128, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); return true; }();
-        (void)once_;
+        static MiPerDevice once_;
+        once_.run([] { (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<true, false, 128, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); });
         hipLaunchKernelGGL((conv1x1_pw_kernel<true, false, 128, false, false, true>), dim3((unsigned)a.gx), dim3(256), pw1_lds(128), st, a);
         MI_LAUNCH_CHECK();
         return 0;
@@ -2243,8 +2251,8 @@ static int gt_launch(const MiConvDesc* d, const void* x, const void* w_frag, con
     if (a.gy > 1 && a.gx % 8 == 0) grid = dim3((unsigned)(a.gx * a.gy), 1, (unsigned)ncls);
     hipStream_t st = (hipStream_t)stream;
 #define MI_GT_GO(O16, PX, F) do { \
-        static bool once_ = [] { (void)hipFuncSetAttribute((const void*)conv_gt_kernel<O16, PX, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); return true; }(); \
-        (void)once_; \
+        static MiPerDevice once_; \
+        once_.run([] { (void)hipFuncSetAttribute((const void*)conv_gt_kernel<O16, PX, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); }); \
         hipLaunchKernelGGL((conv_gt_kernel<O16, PX, F>), grid, dim3(256), (size_t)(PX == 128 ? 64 : 32) * 1024, st, a); } while (0)
     if (d->mode == 0) { if (pxt == 128) MI_GT_GO(false, 128, true); else MI_GT_GO(false, 64, true); }
     else if (pxt == 128) { if (out_bf16) MI_GT_GO(true, 128, false); else MI_GT_GO(false, 128, false); }

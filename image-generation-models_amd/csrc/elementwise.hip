@@ -580,6 +580,40 @@ __global__ __launch_bounds__(256) void spin_kernel(unsigned long long ticks, flo
         for (size_t i = threadIdx.x; i < per_wg / 4; i += 256) { float4 v = src[i]; v.x += 1.f; dst[i] = v; }
 }
 }  // namespace
+// ---- measurement aid (bench.py: config.sclk_mhz_under_mfma): the shader clock the chip sustains under matrix-core load.  One workgroup
+// per CU issues back-to-back bf16 MFMAs for `usec` microseconds of the 100 MHz wall clock; workgroup 0 reports the s_memtime (shader
+// clock) and wall-clock ticks it saw across the loop.  Round 5 measured 1.57 - 1.87 GHz inside conv launches against a 2.4 GHz boost
+// clock; a 10 % box-to-box swing of the bench number can be attributed (or not) with this one number.  out: [2] uint64.
+namespace {
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long ticks, unsigned long long* out) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 b8;
+    typedef __attribute__((ext_vector_type(16))) float f16v;
+    b8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x & 7)); b[i] = (__bf16)(0.002f * (threadIdx.x & 3)); }
+    f16v c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    const unsigned long long w0 = wall_clock64(), s0 = __builtin_amdgcn_s_memtime();
+    while (wall_clock64() - w0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+        }
+    }
+    const unsigned long long s1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += c0[i] + c1[i] + c2[i] + c3[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = s1 - s0; out[1] = w1 - w0; }
+    if (v == 12345.678f) out[2] = 1;         // (keeps the MFMAs; never true)
+}
+}  // namespace
+extern "C" int mi_debug_clock_probe(int blocks, int usec, unsigned long long* out3, void* stream) {
+    MI_REQUIRE(blocks > 0 && usec > 0 && out3, "bad argument");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long)usec * 100ull, out3);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int mi_debug_spin(int blocks, int usec, float* buf, size_t per_wg_floats, int mode, void* stream) {
     hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long)usec * 100ull, buf, per_wg_floats, mode);   // 100 MHz clock
     MI_LAUNCH_CHECK();

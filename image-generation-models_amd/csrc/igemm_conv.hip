@@ -552,11 +552,9 @@ template <int BM, int BN, bool IN16>
 int launch_fast_t(const IgemmArgs& a, const FastTaps& tt, int classes, hipStream_t st) {
     dim3 grid((a.Mc + BM - 1) / BM, (a.Nc + BN - 1) / BN, classes);
     constexpr size_t lds = 2 * (size_t)(BM + BN) * ((IN16 ? 64 : 32) + 8) * sizeof(uint16_t);
-    static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)igemm_fast_kernel<BM, BN, IN16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        return true;
-    }();
-    (void)once;
+    static MiPerDevice once;
+    once.run([] {
+        (void)hipFuncSetAttribute((const void*)igemm_fast_kernel<BM, BN, IN16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     hipLaunchKernelGGL((igemm_fast_kernel<BM, BN, IN16>), grid, dim3(256), lds, st, a, tt);
     return 0;
 }

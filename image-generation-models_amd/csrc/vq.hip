@@ -251,8 +251,8 @@ extern "C" int mi_vq_nearest_fwd(int M, int D, int K, const float* z, int ldz, c
     const size_t lds = ((size_t)(rb + 128) * P + 2 * rb + 128 + 8 + 256) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
 #define VQ_GO(SP, NLD, GRID) do { \
-        static bool once = [] { (void)hipFuncSetAttribute((const void*)vq_nearest_kernel<SP, NLD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return true; }(); \
-        (void)once; hipLaunchKernelGGL((vq_nearest_kernel<SP, NLD>), dim3(GRID), dim3(256), lds, st, a); } while (0)
+        static MiPerDevice once; \
+        once.run([] { (void)hipFuncSetAttribute((const void*)vq_nearest_kernel<SP, NLD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); hipLaunchKernelGGL((vq_nearest_kernel<SP, NLD>), dim3(GRID), dim3(256), lds, st, a); } while (0)
     const int nld = D <= 32 ? 4 : D <= 64 ? 8 : 16;
     if (split) { if (nld == 4) VQ_GO(true, 4, (M + 31) / 32); else if (nld == 8) VQ_GO(true, 8, (M + 31) / 32); else VQ_GO(true, 16, (M + 31) / 32); }
     else       { if (nld == 4) VQ_GO(false, 4, (M + 127) / 128); else if (nld == 8) VQ_GO(false, 8, (M + 127) / 128); else VQ_GO(false, 16, (M + 127) / 128); }

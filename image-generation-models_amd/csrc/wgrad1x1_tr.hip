@@ -465,12 +465,10 @@ extern "C" int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
     MI_REQUIRE(off == 0 || (workspace && ((uintptr_t)workspace & 15) == 0 && ws_bytes >= off * sizeof(float)),
                "workspace too small (mi_conv1x1_wgrad_tr_batch_workspace)");
     hipStream_t st = (hipStream_t)stream;
-    static bool once = [] {
+    static MiPerDevice once;
+    once.run([] {
         (void)hipFuncSetAttribute((const void*)wgrad1x1_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad1x1_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return true;
-    }();
-    (void)once;
+        (void)hipFuncSetAttribute((const void*)wgrad1x1_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (g_w1_phase != 2) {
         if (descs[0].mode == 0) hipLaunchKernelGGL(wgrad1x1_f32_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);
         else hipLaunchKernelGGL(wgrad1x1_tr_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);

@@ -431,27 +431,23 @@ static int w3_dispatch(const MiWgradDesc* d, const float* P, const float* P2, co
     hipStream_t st = (hipStream_t)stream;
     const int XP = ((a.TH * (a.TW + KS - 1)) | 1) * 8;
     const size_t lds = (size_t)(128 * XP + BJ * 17 * 8) * 2 * 2;      // double-buffered
-    static bool once = [] {
+    static MiPerDevice once;
+    once.run([] {
         (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return true;
-    }();
-    (void)once;
+        (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (g_w3_phase == 2) {
         MI_REQUIRE(a.ws, "phase 2 needs the split plan");
     } else if (KS == 3 && io) {
-        static bool once_io = [] {
+        static MiPerDevice once_io;
+        once_io.run([] {
             (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            return true;
-        }();
-        (void)once_io;
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
 #define MI_W3_GO(IOV) do { if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2, 3, IOV>), grid, dim3(256), lds, st, a); \
                            else hipLaunchKernelGGL((wgrad3x3_kernel<1, 3, IOV>), grid, dim3(256), lds, st, a); } while (0)
         if (io == 1) MI_W3_GO(1); else if (io == 2) MI_W3_GO(2); else MI_W3_GO(3);
@@ -460,16 +456,14 @@ static int w3_dispatch(const MiWgradDesc* d, const float* P, const float* P2, co
         if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2, 3>), grid, dim3(256), lds, st, a);
         else      hipLaunchKernelGGL((wgrad3x3_kernel<1, 3>), grid, dim3(256), lds, st, a);
     } else if (io) {
-        static bool once_io1 = [] {
+        static MiPerDevice once_io1;
+        once_io1.run([] {
             (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<2, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            return true;
-        }();
-        (void)once_io1;
+            (void)hipFuncSetAttribute((const void*)wgrad3x3_kernel<1, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
 #define MI_W1_GO(IOV) do { if (wide) hipLaunchKernelGGL((wgrad3x3_kernel<2, 1, IOV>), grid, dim3(256), lds, st, a); \
                            else hipLaunchKernelGGL((wgrad3x3_kernel<1, 1, IOV>), grid, dim3(256), lds, st, a); } while (0)
         if (io == 1) MI_W1_GO(1); else if (io == 2) MI_W1_GO(2); else MI_W1_GO(3);

@@ -445,11 +445,9 @@ extern "C" int mi_conv_s2_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
     MI_REQUIRE(off == 0 || (workspace && ((uintptr_t)workspace & 15) == 0 && ws_bytes >= off * sizeof(float)),
                "workspace too small (mi_conv_s2_wgrad_tr_batch_workspace)");
     hipStream_t st = (hipStream_t)stream;
-    static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)wgrad_s2_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return true;
-    }();
-    (void)once;
+    static MiPerDevice once;
+    once.run([] {
+        (void)hipFuncSetAttribute((const void*)wgrad_s2_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (g_ws2_phase != 2) hipLaunchKernelGGL(wgrad_s2_tr_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);
     if (g_ws2_phase != 1 && tile > 0) {
         if (max_splits >= 64) hipLaunchKernelGGL(wgrad_s2_reduce_kernel<8>, dim3(16, 36, tile), dim3(256), 0, st, b);

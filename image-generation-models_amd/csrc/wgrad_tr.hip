@@ -647,12 +647,10 @@ extern "C" int mi_conv3x3_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
     MI_REQUIRE(off == 0 || (workspace && ((uintptr_t)workspace & 15) == 0 && ws_bytes >= off * sizeof(float)),
                "workspace too small (mi_conv3x3_wgrad_tr_batch_workspace)");
     hipStream_t st = (hipStream_t)stream;
-    static bool once = [] {
+    static MiPerDevice once;
+    once.run([] {
         (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)wgrad_tr32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return true;
-    }();
-    (void)once;
+        (void)hipFuncSetAttribute((const void*)wgrad_tr32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (g_wtr_phase != 2) {
         if (descs[0].mode == 0) hipLaunchKernelGGL(wgrad_tr32_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);
         else hipLaunchKernelGGL(wgrad_tr_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);

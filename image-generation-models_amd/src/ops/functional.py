@@ -1488,6 +1488,16 @@ def gather_rows(table, idx):
     return out
 
 
+def clock_probe(device, usec=300, blocks=256):
+    """Shader clock (MHz) workgroup 0 sustained while `blocks` workgroups issue back-to-back bf16 MFMAs for `usec` microseconds
+    (mi_debug_clock_probe: s_memtime ticks over 100 MHz wall-clock ticks).  A measurement aid for bench.py; synchronises."""
+    out = torch.zeros(3, device=device, dtype=torch.int64)
+    check(load_library().mi_debug_clock_probe(blocks, usec, _p(out), _stream()), "mi_debug_clock_probe")
+    torch.cuda.synchronize()
+    s, w = int(out[0]), int(out[1])
+    return round(100.0 * s / max(w, 1), 1)
+
+
 def u8_gather_normalize(data_u8, idx, flip=None, normalize=True):
     """data_u8: uint8 [N,H,W,C] on the device, idx: int64 [B], flip: uint8/bool [B] or None -> fp32 NCHW batch [B,C,H,W] with the
     reference transform chain applied (ToTensor, flip, Normalize(0.5, 0.5))."""

@@ -69,6 +69,7 @@ SIGNATURES = {
     "mi_conv_s2_wgrad_tr_batch": [_I, C.POINTER(MiWgradDesc), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _Z, _P],
     "mi_debug_wgrad_s2_tr_phase": [_I],
     "mi_debug_spin": [_I, _I, _P, _Z, _I, _P],
+    "mi_debug_clock_probe": [_I, _I, _P, _P],
     "mi_pack_weights_tile": [],
     "mi_conv3x3_bf16w_io_gnsums": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "mi_gn_coef_from_sums": [_I, _I, _I, _I, _F, _P, _P, _P, _P, _I, _P, _P, _P],

@@ -377,6 +377,9 @@ int mi_debug_wgrad_s2_tr_phase(int phase);
  * an ALU spin, 1 a streaming copy over buf (2 x per_wg_floats floats per workgroup), 2 the same copy with a gradient all-reduce's duty
  * cycle (0.5 ms of every 5 ms) -- to see how a training step behaves while another stream's kernel shares the chip */
 int mi_debug_spin(int blocks, int usec, float* buf, size_t per_wg_floats, int mode, void* stream);
+/* measurement aid (bench.py's config.sclk_mhz_under_mfma): `blocks` workgroups issue back-to-back bf16 MFMAs for `usec` microseconds;
+ * out3 (device, 3 x uint64): shader-clock ticks (s_memtime) and 100 MHz wall-clock ticks workgroup 0 saw across its loop, and a sink word */
+int mi_debug_clock_probe(int blocks, int usec, unsigned long long* out3, void* stream);
 
 /* One pass over an fp32 [M][C] tensor: y_bf16 (optional) = bf16(x), colsum (optional)[c] += sum_m x[m][c].  Backward: a residual-
  * stream gradient that the LDS-DMA weight-gradient kernels want bf16-stored and whose column sums are the conv's bias gradient.
