@@ -54,6 +54,18 @@
 #ifndef MI_PW_PIPE
 #define MI_PW_PIPE 1      // 0: round 3 / 4's compiler-scheduled main loop for the plain conv too (A/B builds)
 #endif
+#ifndef MI_PW_GNSABL
+#define MI_PW_GNSABL 0    // profiling builds of the GroupNorm-sums epilogue: 1 no reduction / atomics, 2 no per-element sums (bf16 tile path)
+#endif
+#ifndef MI_PW_GNSW
+#define MI_PW_GNSW 0
+#endif
+#ifndef MI_PW_FXABL
+#define MI_PW_FXABL 0     // profiling builds of the pinned fused loop: 1 no transform, 2 unpacked fp32 instructions
+#endif
+#ifndef MI_PW_FPIPE
+#define MI_PW_FPIPE 3     // round 6: the fused GroupNorm + Mish variants (VAR 2 / 3) on the pinned loop -- bit 0 bf16 input, bit 1 fp32 input (0: round 4's loop, A/B builds)
+#endif
 #ifdef MI_PW_TIMING
 // profiling build only (-DMI_PW_TIMING, tools/pw_timeline.py): shader-clock stamps (s_memtime) at every row unit of conv_pw_kernel's main
 // loop, kept in registers (v_writelane: slot p holds the time of point p - 1) and written once at the end: [workgroup][wave][5][64]
@@ -82,14 +94,14 @@ struct PwArgs {
     int qmap, gx, gy;    // 1-D launch of gx pixel tiles x gy channel tiles: XCD = (pixel group, channel group) of a (8 / qmap) x qmap split
     // round 5: the prologue's integer divisions as multiplications (q = umulhi(x, magic), magic = ceil(2^32 / d), 0 for d = 1; exact for
     // x * d < 2^32) and the zero page's address as an argument -- 3 600 cycles passed between a wave's entry and its first request
-    uint32_t tpi_magic, cpq_magic, nch_magic; int ppx, cpq, lnsub;
+    uint32_t tpi_magic, cpq_magic, nch_magic, cpg_magic; int ppx, cpq, lnsub;
     const void* zero;
     float* gsum;         // VAR 1: [N][Nc / 16][2] sum / sum of squares of the stored values per sample and 16-channel slab (+=)
     const float* coef;   // VAR 2: [3][N][K] scale, shift, time bias of the GroupNorm + Mish applied to x while it is staged
     // VAR 3: the same coefficients resolved in the kernel from the sums the producing conv's epilogue left (gsum layout), the affine
     // parameters and the time bias rows temb [N][ldt] (may be null)
     const float* sums; const float* gamma; const float* beta; const float* temb;
-    int ldt, cpg, hw; float eps;
+    int ldt, cpg, hw, ng; float eps;
     double icnt;         // VAR 3: 1 / (MI_GSUM_SCALE * hw * cpg)
 };
 
@@ -206,6 +218,11 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
 #endif
     static_assert(PT != 256 || (VAR < 2 && !IN32 && !F32), "256-pixel tiles: the plain bf16 conv (with or without the GroupNorm sums)");
     constexpr bool FUSE = VAR >= 2, GNS = VAR == 1;
+    // round 6: the fused variants on round 5's pinned loop.  The coefficients of ALL K channels of the tile's image (scale log2(e), shift log2(e),
+    // time bias: 12 bytes per channel, built once in the prologue) wait in LDS behind the two activation buffers, a piece of the next chunk is
+    // transformed in the registers it was loaded into (no LDS read-modify-write) and its work -- coefficient reads, two Mish pairs per half piece,
+    // the ds_write_b128 -- rides in the MFMA gaps of steps 2 and 3 like the plain conv's register staging; the counted waits are the plain conv's.
+    constexpr bool FPIPE = FUSE && !F32 && ABL == 0 && (MI_PW_PIPE != 0) && (((MI_PW_FPIPE) >> (IN32 ? 1 : 0)) & 1) != 0;
     static_assert(!IN32 || ABL == 0, "fp32 input: no ablation builds");
     static_assert(!F32 || (VAR == 0 && ABL == 0 && !IN32 && !OUT16), "exact-fp32 mode: the plain conv, fp32 in and out");
     constexpr int PCK = F32 ? 32 : 64;                       // channels per chunk (128 bytes of a pixel row)
@@ -333,7 +350,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     //      ((l >> 3) pixels + the lane's channel slot), i.e. no vector arithmetic per request at all (stage_x: a 64-bit multiply-add, a
     //      compare and two selects per piece).  A piece outside the image is not fetched from a zero page: its LDS rows are zeroed once
     //      (both buffers) and its request -- still issued, the counted waits assume it -- reads valid memory into a dump area.
-    constexpr bool SPIECE = (MI_PW_SPIECE != 0 || IN32) && VAR < 2 && !F32 && ABL == 0;     // (fp32 input: the pinned loop's register staging needs it)
+    constexpr bool SPIECE = (((MI_PW_SPIECE != 0 || IN32) && VAR < 2) || FPIPE) && !F32 && ABL == 0;     // (fp32 input, fused: the pinned loop's register staging needs it)
     constexpr int XSZ = IN32 ? 4 : ESZ;                     // bytes per element of x / x2 in memory
     int prow[SPIECE ? PXPW : 1];                             // first pixel of the piece in the tensor, 0 when outside (scalar)
     uint32_t pvalid = 0;                                     // bit i: piece i lies in the image
@@ -415,7 +432,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     float gmean = 0.f, grstd = 0.f;                          // lane g: group g of this image
     const int nslab = FUSE ? a.cpg >> 4 : 1;
     auto load_stats = [&]() {                                // counted like the coefficients (four loads, the oldest of the prologue)
-        const int ng = a.K / a.cpg, gq = min(l, ng - 1);
+        const int ng = a.ng, gq = min(l, ng - 1);
         const float* sp = a.sums + ((size_t)img0 * (a.K >> 4) + (size_t)gq * nslab) * 4;           // 16 bytes per slab
         const float* s1 = sp + (nslab > 1 ? 4 : 0); const float* s2 = sp + (nslab > 2 ? 8 : 0); const float* s3 = sp + (nslab > 2 ? 12 : 0);
         asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
@@ -456,7 +473,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     auto coef_landed = [&](int ch) {
         asm volatile("" : "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+v"(cq[3]), "+v"(cq[4]), "+v"(cq[5]) :: "memory");
         if constexpr (VAR == 3) {
-            const int grp = (cof(ch) * PCK + xcol) / a.cpg;      // the lane's 8 channels lie in one group
+            const int grp = pw_fastdiv(cof(ch) * PCK + xcol, a.cpg_magic);      // the lane's 8 channels lie in one group
             const float mf = __shfl(gmean, grp, 64), rstd = __shfl(grstd, grp, 64);
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -593,10 +610,11 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     // bf16 output: the bias of this lane's four channel quads, requested before anything else and used only by the epilogue (there a
     // load would put an HBM round trip in front of the tile's way out)
     // (round 5, pinned loop: the 128 bias values of the tile wait in LDS instead of 16 registers per lane)
-    constexpr bool PIPE_ = (MI_PW_PIPE != 0) && VAR < 2 && !F32 && ABL == 0;
+    constexpr bool PIPE_ = (MI_PW_PIPE != 0) && (VAR < 2 || FPIPE) && !F32 && ABL == 0;
     constexpr uint32_t BIASL = 2 * PXBUF + 1024;             // 512 bytes behind the dump area
+    constexpr uint32_t COEFL = 2 * PXBUF + 2048;             // FPIPE: the coefficient table, [K / 4][scale x 4, shift x 4, time bias x 4] = 12 K bytes
     f32x4 bias_q[(OUT16 && !FUSE) ? 4 : 1];
-    if constexpr (OUT16 && !FUSE && PIPE_) {
+    if constexpr (OUT16 && (!FUSE || FPIPE) && PIPE_) {
         typedef __attribute__((address_space(3))) f32x4 lds_f32x4b;
         if (t < 32) {
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -613,9 +631,121 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     }
     // ---- prologue: the first chunk's rows, the first step's fragments
     if constexpr (!EARLYW) MI_PW_NOW(10);
-    if constexpr (VAR == 3) load_stats();
-    if constexpr (FUSE) load_coef(0);
-    if constexpr (IN32) {
+    // ---- fused variants on the pinned loop: table operands (oldest requests), the first step's fragments, chunk 0's pieces through registers
+    constexpr int RSNF = IN32 ? 2 : 1;
+    auto fx_read = [&](int ch, auto hc, f32x4 (&cf)[3]) {      // coefficients of half h (4 channels) of this lane's slot of chunk ch
+        constexpr int h = decltype(hc)::value;
+        typedef __attribute__((address_space(3))) f32x4 lds_f32x4c;
+        const uint32_t ad = lds0 + COEFL + (uint32_t)(cof(ch) * (PCK / 4) + (xcol >> 2) + h) * 48u;
+        cf[0] = *(lds_f32x4c*)(uintptr_t)ad; cf[1] = *(lds_f32x4c*)(uintptr_t)(ad + 16); cf[2] = *(lds_f32x4c*)(uintptr_t)(ad + 32);
+    };
+    auto fx_apply = [&](u32x4 (&r)[RSNF], auto hc, const f32x4 (&cf)[3], u32x4& o) {   // half h of a piece in registers -> two packed registers of o (o may be r[0]: in place)
+        constexpr int h = decltype(hc)::value;
+        f32x2 x0, x1;
+        if constexpr (IN32) {
+            x0 = f32x2{__uint_as_float(r[h].x), __uint_as_float(r[h].y)}; x1 = f32x2{__uint_as_float(r[h].z), __uint_as_float(r[h].w)};
+        } else {
+            const uint32_t v0 = r[0][2 * h], v1 = r[0][2 * h + 1];
+            x0 = f32x2{__uint_as_float(v0 << 16), __uint_as_float(v0 & 0xffff0000u)}; x1 = f32x2{__uint_as_float(v1 << 16), __uint_as_float(v1 & 0xffff0000u)};
+        }
+#if MI_PW_FXABL == 1      // profiling build: no transform (wrong results; the floor of the fused loop)
+        o[2 * h] = pack_bf16(x0.x + cf[0].x, x0.y + cf[1].x); o[2 * h + 1] = pack_bf16(x1.x + cf[2].x, x1.y);
+#elif MI_PW_FXABL == 2    // plain (unpacked) fp32 instructions, one asm statement each so that nothing is SLP-packed
+        auto m1 = [&](float x, float sc, float sh, float tb) -> float {
+            float t_, e_, q_, r_, s_, o_;
+            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t_) : "v"(x), "v"(sc), "v"(sh));
+            asm("v_exp_f32 %0, %1" : "=v"(e_) : "v"(t_));
+            asm("s_nop 0\n\tv_add_f32 %0, 2.0, %1" : "=v"(q_) : "v"(e_));
+            asm("v_fma_f32 %0, %1, %2, 2.0" : "=v"(q_) : "v"(e_), "0"(q_));
+            asm("v_rcp_f32 %0, %1" : "=v"(r_) : "v"(q_));
+            asm("s_nop 0\n\tv_fma_f32 %0, %1, %2, %3" : "=v"(s_) : "v"(r_), "s"(-1.38629436f), "v"(0.693147182f));
+            asm("v_fma_f32 %0, %1, %2, %3" : "=v"(o_) : "v"(t_), "v"(s_), "v"(tb));
+            return o_;
+        };
+        o[2 * h] = pack_bf16(m1(x0.x, cf[0].x, cf[1].x, cf[2].x), m1(x0.y, cf[0].y, cf[1].y, cf[2].y));
+        o[2 * h + 1] = pack_bf16(m1(x1.x, cf[0].z, cf[1].z, cf[2].z), m1(x1.y, cf[0].w, cf[1].w, cf[2].w));
+#else
+        const f32x2 m0_ = mish_tb2(x0, f32x2{cf[0].x, cf[0].y}, f32x2{cf[1].x, cf[1].y}, f32x2{cf[2].x, cf[2].y});
+        const f32x2 m1_ = mish_tb2(x1, f32x2{cf[0].z, cf[0].w}, f32x2{cf[1].z, cf[1].w}, f32x2{cf[2].z, cf[2].w});
+        o[2 * h] = pack_bf16(m0_.x, m0_.y); o[2 * h + 1] = pack_bf16(m1_.x, m1_.y);
+#endif
+    };
+    if constexpr (FPIPE) {
+        // issue order = landing order: the statistics (VAR 3), this lane's coefficients of chunk 0 (registers: chunk 0 is transformed before
+        // the table is published), the table's operands, the first step's fragments, chunk 0's pieces
+        if constexpr (VAR == 3) load_stats();
+        load_coef(0);
+        u32x4 tq[3];
+        const int c4 = min(4 * t, a.K - 4);
+        {
+            const float* p0; const float* p1; const float* p2;
+            if constexpr (VAR == 2) {
+                p0 = a.coef + (size_t)img0 * a.K + c4;
+                const size_t pl = (size_t)a.N * a.K;
+                p1 = p0 + pl; p2 = p0 + 2 * pl;
+            } else {
+                p0 = a.gamma + c4; p1 = a.beta + c4;
+                p2 = a.temb ? a.temb + (size_t)img0 * a.ldt + c4 : reinterpret_cast<const float*>(a.zero);
+            }
+            asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %4, off\n\tglobal_load_dwordx4 %2, %5, off"
+                         : "=&v"(tq[0]), "=&v"(tq[1]), "=&v"(tq[2]) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+        }
+        static_for<0, NPART>([&](auto pc) { load_w3(0, std::integral_constant<int, 0>{}, pc); });
+        u32x4 pr[PXPW][RSNF];
+        static_for<0, PXPW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const uint64_t sb = (uint64_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(a.x) + ((size_t)prow[i] * a.ldx + cof(0) * PCK) * XSZ);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sb >> 32));
+            gload16s<0>(pr[i][0], ((uint64_t)hi << 32) | lo, lane_off1);
+            if constexpr (IN32) gload16s<16>(pr[i][1], ((uint64_t)hi << 32) | lo, lane_off1);
+        });
+        // rows outside the image: zero in both buffers, once (their requests land in the dump area)
+        {
+            typedef __attribute__((address_space(3))) u32x4 lds_u32x4z;
+#pragma unroll
+            for (int i = 0; i < PXPW; ++i)
+                if (!((pvalid >> i) & 1u)) {
+                    *(lds_u32x4z*)(uintptr_t)(lds0 + (wv + 4 * i) * 1024 + l * 16) = u32x4{0u, 0u, 0u, 0u};
+                    *(lds_u32x4z*)(uintptr_t)(lds0 + PXBUF + (wv + 4 * i) * 1024 + l * 16) = u32x4{0u, 0u, 0u, 0u};
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(9 + PXPW * RSNF) : "memory");      // statistics, coefficients, table operands
+        if constexpr (VAR == 3) stats_landed();
+        asm volatile("" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]) :: "memory");
+        {
+            f32x4 sc = __builtin_bit_cast(f32x4, tq[0]), sh = __builtin_bit_cast(f32x4, tq[1]);
+            if constexpr (VAR == 3) {
+                const int grp = pw_fastdiv(c4, a.cpg_magic);                         // a quad lies in one group (cpg % 16 == 0)
+                const float mf = __shfl(gmean, grp, 64), rstd = __shfl(grstd, grp, 64);
+                sc *= rstd; sh -= mf * sc;
+            }
+            sc *= 1.44269504f; sh *= 1.44269504f;                                     // mish_tb2 feeds v_exp_f32 directly
+            typedef __attribute__((address_space(3))) f32x4 lds_f32x4c;
+            if (4 * t < a.K) {
+                const uint32_t ad = lds0 + COEFL + (uint32_t)t * 48u;
+                *(lds_f32x4c*)(uintptr_t)ad = sc; *(lds_f32x4c*)(uintptr_t)(ad + 16) = sh; *(lds_f32x4c*)(uintptr_t)(ad + 32) = __builtin_bit_cast(f32x4, tq[2]);
+            }
+        }
+        coef_landed(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // chunk 0's pieces (and the first step's fragments)
+        static_for<0, PXPW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            landed16(pr[i][0]);
+            u32x4 o;
+            if constexpr (IN32) {
+                landed16(pr[i][1]);
+                xhalf(pr[i][0], std::integral_constant<int, 0>{}, ~0u, o); xhalf(pr[i][1], std::integral_constant<int, 1>{}, ~0u, o);
+            } else {
+                static_for<0, 4>([&](auto qc) { o[decltype(qc)::value] = tpart(pr[i][0][decltype(qc)::value], qc, ~0u); });
+            }
+            const uint32_t off = ((pvalid >> i) & 1u) ? (uint32_t)(4 * i * 1024) : (uint32_t)(DUMP - wv * 1024);
+            *(lds_u32x4*)(uintptr_t)(lds0 + wv * 1024 + l * 16 + off) = o;
+        });
+    }
+    if constexpr (VAR == 3 && !FPIPE) load_stats();
+    if constexpr (FUSE && !FPIPE) load_coef(0);
+    if constexpr (FPIPE) {
+    } else if constexpr (IN32) {
         u32x4 pr[PXPW][2];
 #pragma unroll
         for (int i = 0; i < PXPW; ++i) load_x32(0, i, pr[i]);
@@ -674,7 +804,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
             }
         });
     };
-    if constexpr (FUSE && !IN32) {
+    if constexpr (FUSE && !IN32 && !FPIPE) {
         if constexpr (VAR == 3) {                            // the statistics are the oldest requests: their arithmetic runs under the rows' flight
             asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 + PXPW + 9) : "memory");
             stats_landed();
@@ -700,7 +830,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     //        of the step, the next chunk's activation pieces behind them in steps 0 and 1 only -- so step 3's opening wait covers them
     //        and the barrier (before unit BH - 1 of step 3, the first to read the other buffer) needs no vmcnt at all; the fragments
     //        of the next chunk's first step are waited for at the very end of step 3, >= 18 gaps after their request.
-    constexpr bool PIPE = (MI_PW_PIPE != 0) && VAR < 2 && !F32 && ABL == 0;
+    constexpr bool PIPE = PIPE_;
     if constexpr (PIPE) {
         constexpr int CN = (BH % 3 == 1) ? 4 : 3;            // centre fragment registers in rotation (unit u: C[u % CN])
         constexpr int WSTR = BH >= 4 ? MI_PW_WSTR : 1;        // a fragment request every WSTR gaps
@@ -713,7 +843,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
         // the next chunk's pieces through registers (an LDS-DMA request cost the issuing wave 50-100 cycles in the unit timeline, a plain
         // request + ds_write_b128 a fraction of that): batch 0 = the first PPS pieces, requested in step 0 and written in step 2 (in-order
         // returns: they have landed once step 2's fragments have), batch 1 requested in step 1 and written in step 3 before the barrier
-        constexpr bool RST = (MI_PW_RSTAGE != 0 || IN32) && SPIECE;
+        constexpr bool RST = (MI_PW_RSTAGE != 0 || IN32 || FPIPE) && SPIECE;
         constexpr int RSN = IN32 ? 2 : 1;                      // registers sets per piece: fp32 input = 32 bytes per lane
         u32x4 RS[2][RST ? PPS : 1][RSN];
         const uint32_t wbase = lds0 + wv * 1024 + l * 16;
@@ -743,6 +873,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
                 *(lds_u32x4s*)(uintptr_t)(wbase + off) = RS[b][j][0];
         };
         bf16x8 Ac, Bc, C[CN];
+        f32x4 CF[2][3];                                        // fused: the coefficients of the half pieces being transformed
         u32x4 Al, Bl, Ar, Br, L[2], R[2];                      // shifted fragments (registers written two at a time: pw_shift_h)
         // A shift is four DPP instructions; from three blocks per wave up it is issued as two halves in two consecutive gaps (a gap then
         // carries at most two DPP instructions + one memory instruction), and never needs wait states: its consumer is a unit away.
@@ -786,6 +917,39 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
                         else stage_x(ch + 1, PPS * ks + (g - PG0) / 2);
                     }
                     // (register staging: the batch requested two steps ago goes to LDS in the odd gaps 1, 3, ... of steps 2 and 3)
+                    if constexpr (FPIPE) {
+                        // fused: the batch requested two steps ago (PPS pieces) is transformed IN its registers, half pieces at a time so that a
+                        // half's coefficients (three ds_read_b128, the same for every piece: a lane keeps its channel slot) are read once per batch:
+                        // gap 1: coefficients of half 0; gaps 2 .. 1 + PPS: half 0 of piece 0 .. PPS - 1; then half 1 the same way; then the PPS
+                        // writes -- 2 PPS + 2 + PPS gaps from gap 1 (four blocks per wave: gaps 1 .. 11, the barrier of step 3 sits before gap 21;
+                        // two blocks per wave: 18 gaps per step, barrier before gap 6 -- both halves' coefficients in gap 1, a piece per gap, the
+                        // writes with the second piece).  The last chunk has no successor: its (clamped) requests were issued, nothing is transformed.
+                        if constexpr (ks >= 2 && g >= 1) {
+                            constexpr int b = ks - 2, q = g - 1;
+                            constexpr int NPB = (PXPW - PPS * b) < PPS ? (PXPW - PPS * b) : PPS;     // pieces of this batch
+                            auto fx_write = [&](auto jc) {
+                                constexpr int j = decltype(jc)::value, i = PPS * b + j;
+                                typedef __attribute__((address_space(3))) u32x4 lds_u32x4s;
+                                const uint32_t off = ((pvalid >> i) & 1u) ? (uint32_t)(((ch + 1) & 1) * PXBUF + 4 * i * 1024) : (uint32_t)(DUMP - wv * 1024);
+                                *(lds_u32x4s*)(uintptr_t)(wbase + off) = RS[b][j][0];
+                            };
+                            if (ch + 1 < nchunks) {
+                                if constexpr (BH >= 4) {
+                                    if constexpr (q == 0) { static_for<0, NPB>([&](auto jc) { landed16(RS[b][decltype(jc)::value][0]); if constexpr (IN32) landed16(RS[b][decltype(jc)::value][1]); }); fx_read(ch + 1, I0, CF[0]); }
+                                    if constexpr (q >= 1 && q <= NPB) fx_apply(RS[b][q - 1], I0, CF[0], RS[b][q - 1][0]);
+                                    if constexpr (q == NPB) fx_read(ch + 1, I1, CF[1]);
+                                    if constexpr (q >= NPB + 1 && q <= 2 * NPB) fx_apply(RS[b][q - NPB - 1], I1, CF[1], RS[b][q - NPB - 1][0]);
+                                    if constexpr (q >= 2 * NPB + 1 && q <= 3 * NPB) fx_write(std::integral_constant<int, q - 2 * NPB - 1>{});
+                                } else {
+                                    if constexpr (q == 0) { static_for<0, NPB>([&](auto jc) { landed16(RS[b][decltype(jc)::value][0]); if constexpr (IN32) landed16(RS[b][decltype(jc)::value][1]); }); fx_read(ch + 1, I0, CF[0]); fx_read(ch + 1, I1, CF[1]); }
+                                    if constexpr (q >= 1 && q <= NPB) {
+                                        fx_apply(RS[b][q - 1], I0, CF[0], RS[b][q - 1][0]); fx_apply(RS[b][q - 1], I1, CF[1], RS[b][q - 1][0]);
+                                        fx_write(std::integral_constant<int, q - 1>{});
+                                    }
+                                }
+                            }
+                        }
+                    } else
                     if constexpr (RST && ks >= 2 && (g & 1) && g / 2 < PPS && PPS * (ks - 2) + g / 2 < PXPW)
                         rs_store(ch + 1, std::integral_constant<int, ks - 2>{}, std::integral_constant<int, g / 2>{});
                 };
@@ -1027,6 +1191,10 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     //      16 lanes x 8 channels = one pixel's 256 (bf16) / 512 (fp32) contiguous bytes; bias, residual and the accumulate operand are
     //      applied on the way out, read in the same row-contiguous pattern.
     auto pw_gns_out = [&](float (&gs)[2][2]) {
+#if MI_PW_GNSABL == 1      // profiling build: the per-element sums only (no reduction, no atomics)
+        if (gs[0][0] + gs[0][1] + gs[1][0] + gs[1][1] == 123.456f) a.gsum[t] = 1.f;
+        return;
+#endif
         // a 16-channel slab = two neighbouring lanes (j = 2q, 2q + 1) x the 16 row groups t >> 4 (4 per wave): lanes, then waves
         // through the LDS behind the tile, then ONE atomic pair per slab, image and workgroup (rows 0-63 / 64-127 are the two images
         // of a TI == 2 tile; with TI == 1 both halves belong to image img0)
@@ -1035,12 +1203,31 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
         for (int k = 0; k < 4; ++k) {
             r[k] += __shfl_xor(r[k], 1, 64); r[k] += __shfl_xor(r[k], 16, 64); r[k] += __shfl_xor(r[k], 32, 64);
         }
+#if MI_PW_GNSW == 1        // A/B build: every wave adds its own partial sums (no LDS, no barrier; four times the atomics)
+        if ((l & 0x31) == 0) {
+            const int slab = (n0 >> 4) + (l >> 1);
+            if (slab * 16 < a.Nc) {
+                if (a.TI > 1) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) gsum_add(a.gsum, ((size_t)(img0 + (k >> 1)) * (a.Nc >> 4) + slab) * 2 + (k & 1), r[k]);
+                } else {
+                    gsum_add(a.gsum, ((size_t)img0 * (a.Nc >> 4) + slab) * 2, r[0] + r[2]);
+                    gsum_add(a.gsum, ((size_t)img0 * (a.Nc >> 4) + slab) * 2 + 1, r[1] + r[3]);
+                }
+            }
+        }
+        return;
+#endif
         float* red = reinterpret_cast<float*>(lds_raw + PT * 512);        // behind the tile: [4 waves][8 slabs][4]
         if ((l & 0x31) == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) red[(wv * 8 + (l >> 1)) * 4 + k] = r[k];
         }
-        __syncthreads();
+        // (round 6: NOT __syncthreads() -- its vmcnt(0) made every wave wait out the tile's global stores, 2 - 3 us of a level-0 launch;
+        //  only the four LDS writes above have to be visible)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         if (t < 32) {
             const int q = t >> 2, k = t & 3;                 // slab, (image half, sum / sum of squares)
             const float v = red[(0 * 8 + q) * 4 + k] + red[(1 * 8 + q) * 4 + k] + red[(2 * 8 + q) * 4 + k] + red[(3 * 8 + q) * 4 + k];
@@ -1058,7 +1245,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     // gradients into block-internal tensors) takes its bias in registers and crosses LDS as bf16: half the tile (32 KB), one
     // ds_read_b128 per thread and pixel, no arithmetic between the read and the store.  8-byte slot c (4 channels) of pixel p at
     // c ^ ((p & 15) << 1): an even XOR keeps a thread's two slots an aligned pair; rows p and p + 16 share banks (2-way on the writes only).
-    const bool tile16 = OUT16 && !FUSE && !a.res && !a.accumulate;
+    const bool tile16 = OUT16 && (!FUSE || FPIPE) && !a.res && !a.accumulate;
     if (tile16) {
         if constexpr (OUT16) {
             typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
@@ -1088,7 +1275,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
                     const int p = it * 16 + (t >> 4);
                     const u32x4 o = *(lds_u32x4e*)(uintptr_t)(lds0 + p * 256 + (((2 * j) ^ ((p & 15) << 1)) << 3));
                     *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(a.y) + ((size_t)m0 + p) * a.ldy + col) = o;
-                    if constexpr (GNS) {
+                    if constexpr (GNS && MI_PW_GNSABL != 2) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float e0 = __uint_as_float(o[q] << 16), e1 = __uint_as_float(o[q] & 0xffff0000u);
@@ -1193,8 +1380,10 @@ bool pw_ok(const MiConvDesc* d, int pt, int* TH, int* TI, bool in32 = false, boo
 // 64-pixel tiles where 128-pixel ones would leave CUs without a workgroup (and the geometry allows them)
 int g_pw_force_tile = 0;                 // tests: 0 = the rule below, 64 / 128 / 256 = that tile (or unsupported)
 int g_pw_auto256 = 0, g_pw_min256 = 256;   // (measured slower than two 128-pixel workgroups per CU on every cfg-2 shape: off)  // the automatic pick takes 256-pixel tiles when they give at least g_pw_min256 workgroups
+constexpr bool pw_fpipe(bool in32) { return (MI_PW_PIPE != 0) && (((MI_PW_FPIPE) >> (in32 ? 1 : 0)) & 1) != 0; }   // conv_pw_kernel's FPIPE
 int pw_pick_tile(const MiConvDesc* d, int var, int* TH, int* TI, bool in32 = false, bool f32 = false) {
     if (f32 && var != 0) return 0;
+    if (var >= 2 && pw_fpipe(in32) && d->K > 1024) return 0;   // the coefficient table of the pinned fused loop: 12 K bytes of LDS
     if (g_pw_force_tile == 64) return pw_ok(d, 64, TH, TI, in32, f32) ? 64 : 0;
     if (g_pw_force_tile == 128) return pw_ok(d, 128, TH, TI, in32, f32) ? 128 : 0;
     if (g_pw_force_tile == 256) return (var < 2 && !in32 && !f32 && pw_ok(d, 256, TH, TI)) ? 256 : 0;
@@ -1781,7 +1970,7 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
         if ((((uintptr_t)gn->gamma | (uintptr_t)gn->beta | (uintptr_t)gn->sums) & 7) || ((uintptr_t)gn->sums & 15) || (gn->temb && (((uintptr_t)gn->temb & 15) || gn->ldt % 4)))
             return mi_set_error(-1, "%s: misaligned GroupNorm operands", who);
         a.sums = gn->sums; a.gamma = gn->gamma; a.beta = gn->beta; a.temb = gn->temb; a.ldt = gn->ldt; a.cpg = d->K / gn->G;
-        a.hw = d->OH * d->OW; a.eps = gn->eps; a.icnt = 1.0 / (MI_GSUM_SCALE * (double)a.hw * (double)a.cpg);
+        a.cpg_magic = pw_magic(a.cpg); a.ng = gn->G; a.hw = d->OH * d->OW; a.eps = gn->eps; a.icnt = 1.0 / (MI_GSUM_SCALE * (double)a.hw * (double)a.cpg);
     }
     if (var == 1 && (!gsum || d->Nc % 16)) return mi_set_error(-1, "%s: GroupNorm sums need Nc %% 16 == 0 and a sum buffer", who);
     a.x = (const uint16_t*)x; a.x2 = (const uint16_t*)(x2 ? x2 : x); a.w = (const uint16_t*)w_frag_bf16; a.bias = bias; a.res = residual; a.y = y;
@@ -1809,7 +1998,11 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     if (!a.xmap && a.gy > 1 && a.gy % 2 == 0 && a.gx % 4 == 0) { a.qmap = 2; grid = dim3(grid.x * grid.y, 1, 1); }
     a.ppx = a.gx / 4; a.cpq = a.gy / 2; a.cpq_magic = pw_magic(a.cpq);
     hipStream_t st = (hipStream_t)stream;
-    size_t lds = pw_lds(pt, in32);
+    size_t lds = pw_lds(pt, in32 && !(var >= 2 && pw_fpipe(true)));
+    if (var >= 2 && pw_fpipe(in32)) {                        // the coefficient table sits behind the two activation buffers + 2 KB
+        const size_t need = (size_t)2 * pw_xp(pt) * 128 + 2048 + (size_t)12 * d->K;
+        if (need > lds) lds = need;
+    }
 #define MI_PW_GO_T(O16, V, A, T) do { \
         static MiPerDevice once_; \
         once_.run([] { (void)hipFuncSetAttribute((const void*)conv_pw_kernel<O16, V, A, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
