@@ -17,6 +17,9 @@
 #ifndef MI_GN_ABL
 #define MI_GN_ABL 0       // profiling builds only (bit 0: forward without Mish, bit 1: forward without the statistics' reductions)
 #endif
+#ifndef MI_GN_FULL16
+#define MI_GN_FULL16 0    // A/B builds: 16-unit slices (level 0 of cfg 2) on the pipelined backward -- 4: at four waves per SIMD (spills), 3: at three
+#endif
 #ifndef MI_GN_WAVES
 #define MI_GN_WAVES 4     // waves per SIMD the packed-cache GroupNorm backward is compiled for
 #endif
@@ -67,6 +70,38 @@ template <int VEC, bool T16> __device__ __forceinline__ void vstore(void* base, 
     else if constexpr (VEC == 4)
         *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + off) = make_uint2(pack_bf16(v.v[0], v.v[1]), pack_bf16(v.v[2], v.v[3]));
     else reinterpret_cast<uint16_t*>(base)[off] = (uint16_t)(pack_bf16(v.v[0], 0.f) & 0xffff);
+}
+
+// ---- round 6: packed-fp32 arithmetic for the bf16-storage GroupNorm backward.  The kernel is VALU-bound, not HBM-bound (level 0, B = 128:
+// ~27 full-rate instructions + 2 transcendentals per element = ~15 us of VALU under a 16 us memory floor, 27.5 us measured; dephasing the
+// workgroups changed nothing): two channels per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) and the closed form
+//     d mish / dz = e w / n^2,   e = exp(min(z, 20)),  n = (e + 2) e + 2,  w = ((e + 4) e + (4 z + 6)) e + 4 z + 4
+// (one exp, one rcp, 11 packed instructions per PAIR; the tanh / sigmoid form above is ~17 per element).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ f32x2 pk_fma_s(f32x2 a, f32x2 sb, f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(sb), "v"(c)); return d; }   // sb: wave-uniform pair
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 unpack_bf16x2(uint32_t v) { return f32x2{__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)}; }
+__device__ __forceinline__ f32x2 mish_grad_pk(f32x2 z) {
+    const f32x2 zc = {fminf(z.x, 20.f), fminf(z.y, 20.f)};
+    const f32x2 k6l = {6.0f, 1.44269504f};                   // ONE scalar pair: low half = 6, high half = log2(e)
+    f32x2 zl, ep, n, t1, e4, p1, t2, om, er, g, o;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(zl) : "v"(zc), "s"(k6l));
+    const f32x2 e = {__builtin_amdgcn_exp2f(zl.x), __builtin_amdgcn_exp2f(zl.y)};
+    // (s_nop: a VALU instruction must not read a transcendental's result in the next issue slot, and hipcc does not look inside asm)
+    asm("s_nop 0\n\tv_pk_add_f32 %0, %1, 2.0 op_sel_hi:[1,0]" : "=v"(ep) : "v"(e));
+    asm("v_pk_fma_f32 %0, %1, %2, 2.0 op_sel_hi:[1,1,0]" : "=v"(n) : "v"(e), "v"(ep));
+    const f32x2 r = {__builtin_amdgcn_rcpf(n.x), __builtin_amdgcn_rcpf(n.y)};
+    asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(zc), "s"(k6l));      // 4 z + 6
+    asm("v_pk_add_f32 %0, %1, 4.0 op_sel_hi:[1,0]" : "=v"(e4) : "v"(e));
+    p1 = pk_fma(e4, e, t1);
+    asm("v_pk_add_f32 %0, %1, -2.0 op_sel_hi:[1,0]" : "=v"(t2) : "v"(t1));                                       // 4 z + 4
+    om = pk_fma(p1, e, t2);
+    asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(er) : "v"(e), "v"(r));
+    g = pk_mul(om, r);
+    o = pk_mul(er, g);
+    return o;
 }
 
 struct GnArgs {
@@ -214,7 +249,7 @@ __global__ __launch_bounds__(256) void gn_mish_fwd_kernel(const GnArgs a) {
 // FULL: the slice is exactly MAXU units per thread (HW == MAXU * 256 / (Cg / VEC)): no guards, and the packed-cache path runs as a
 // straight-line software pipeline (see below).
 template <int VEC, int MAXU, int IO = 0, bool FULL = false>     // IO bit 0: x is bf16, bit 1: dx is written as bf16, bit 2: dout is bf16
-__global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? (MAXU * VEC > 64 ? 2 : MI_GN_WAVES) : 1)) void gn_mish_bwd_kernel(const GnArgs a) {
+__global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? (MAXU * VEC > 64 ? 2 : (FULL && MAXU * VEC == 64 && MI_GN_FULL16 == 3) ? 3 : MI_GN_WAVES) : 1)) void gn_mish_bwd_kernel(const GnArgs a) {
     MI_PRIO_UP();
     constexpr bool X16 = IO & 1, DX16 = IO & 2, DO16 = IO & 4;
     __shared__ float part[4][256 * VEC];
@@ -256,6 +291,28 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? (MAXU * 
     float sA[VEC], sD[VEC], sT[VEC], sB[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) sA[j] = sD[j] = sT[j] = sB[j] = 0.f;
+    // bf16 x (round 6): two channels per instruction -- packed coefficients, packed accumulators, mish_grad_pk
+    constexpr bool PK2 = X16 && VEC >= 2;
+    constexpr int H2 = VEC >= 2 ? VEC / 2 : 1;
+    f32x2 ga2[H2], be2[H2], aA[H2], aD[H2], aT[H2], aB[H2];
+    const f32x2 rstd2 = {rstd, rstd};
+    const float nmr = -mean * rstd;
+    const f32x2 nmr2 = {nmr, nmr};
+    if constexpr (PK2) {
+#pragma unroll
+        for (int j2 = 0; j2 < H2; ++j2) {
+            ga2[j2] = f32x2{ga[2 * j2], ga[2 * j2 + 1]}; be2[j2] = f32x2{be[2 * j2], be[2 * j2 + 1]};
+            aA[j2] = aD[j2] = aT[j2] = aB[j2] = f32x2{0.f, 0.f};
+        }
+    }
+    // one pair of channels of one pixel: x as loaded (two bf16), dout as a float pair -> dz (returned), xhat in h2; the four sums advance
+    auto pair1q = [&](f32x2 q2, f32x2 d2, int j2, f32x2& h2) -> f32x2 {
+        h2 = pk_fma_s(q2, rstd2, nmr2);
+        const f32x2 dz2 = pk_mul(d2, mish_grad_pk(pk_fma(h2, ga2[j2], be2[j2])));
+        aA[j2] = pk_add(aA[j2], dz2); aD[j2] = pk_fma(dz2, h2, aD[j2]); aT[j2] = pk_add(aT[j2], d2); aB[j2] = pk_add(aB[j2], h2);
+        return dz2;
+    };
+    auto pair1 = [&](uint32_t xr, f32x2 d2, int j2, f32x2& h2) -> f32x2 { return pair1q(unpack_bf16x2(xr), d2, j2, h2); };
 
     auto pass1 = [&](int p, V<VEC>& xh, V<VEC>& dz) {
         V<VEC> q = vload<VEC, X16>(a.x, xoff + (size_t)p * a.ldx);
@@ -282,6 +339,17 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? (MAXU * 
 #pragma unroll
         for (int k = 0; k < MAXU; ++k) {
             const float live = pr + k * PP < a.HW ? 1.f : 0.f;
+            if constexpr (PK2) {
+                // (a masked row: x = mean and dout = 0 give xhat = 0, dz = 0 -- nothing reaches the sums)
+                const float qdead = pr + k * PP < a.HW ? 0.f : 1.f;
+#pragma unroll
+                for (int j2 = 0; j2 < H2; ++j2) {
+                    const f32x2 q2 = {cx[k].v[2 * j2] * live + qdead * mean, cx[k].v[2 * j2 + 1] * live + qdead * mean};
+                    f32x2 h2;
+                    const f32x2 dz2 = pair1q(q2, f32x2{cd[k].v[2 * j2] * live, cd[k].v[2 * j2 + 1] * live}, j2, h2);
+                    cx[k].v[2 * j2] = h2.x; cx[k].v[2 * j2 + 1] = h2.y; cd[k].v[2 * j2] = dz2.x; cd[k].v[2 * j2 + 1] = dz2.y;
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const float h = (cx[k].v[j] - mean) * rstd * live, dd = cd[k].v[j] * live;
@@ -289,6 +357,7 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? (MAXU * 
                 const float dzz = dd * (X16 ? mish_grad_fast_f(z) : mish_grad_f(z));
                 cx[k].v[j] = h; cd[k].v[j] = dzz;
                 sA[j] += dzz; sD[j] += dzz * h; sT[j] += dd; sB[j] += h;
+            }
             }
         }
     } else if constexpr (PKC && FULL) {
@@ -344,23 +413,16 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? (MAXU * 
 #pragma unroll
             for (int j2 = 0; j2 < VEC / 2; ++j2) {
                 px[k][j2] = rx[sl][j2];
-                float dzp[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int j = 2 * j2 + e;
-                    const float q = __uint_as_float(e ? (rx[sl][j2] & 0xffff0000u) : (rx[sl][j2] << 16));
-                    const float dv = DO16 ? __uint_as_float(e ? (rd[sl][j2] & 0xffff0000u) : (rd[sl][j2] << 16)) : __uint_as_float(rd[sl][DO16 ? 0 : j]);
-                    const float h = (q - mean) * rstd, z = h * ga[j] + be[j];
-                    const float dzz = dv * mish_grad_fast_f(z);
-                    dzp[e] = dzz;
-                    sA[j] += dzz; sD[j] += dzz * h; sT[j] += dv; sB[j] += h;
-                }
-                pd[k][j2] = pack_bf16(dzp[0], dzp[1]);
+                f32x2 d2, h2;
+                if constexpr (DO16) d2 = unpack_bf16x2(rd[sl][j2]);
+                else d2 = f32x2{__uint_as_float(rd[sl][DO16 ? 0 : 2 * j2]), __uint_as_float(rd[sl][DO16 ? 0 : 2 * j2 + 1])};
+                const f32x2 dz2 = pair1(rx[sl][j2], d2, j2, h2);
+                pd[k][j2] = pack_bf16(dz2.x, dz2.y);
             }
             // pin the unit's work here: instruction selection orders a basic block by data dependences only, and without these
             // the four accumulation chains of all units sink below the last unit (every h / dz kept alive: 700 bytes of spills)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) asm volatile("" : "+v"(sA[j]), "+v"(sD[j]), "+v"(sT[j]), "+v"(sB[j]));
+            for (int j2 = 0; j2 < VEC / 2; ++j2) asm volatile("" : "+v"(aA[j2]), "+v"(aD[j2]), "+v"(aT[j2]), "+v"(aB[j2]));
             __builtin_amdgcn_sched_barrier(0);
         }
     } else if constexpr (PKC) {
@@ -384,17 +446,9 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? (MAXU * 
                 const V<VEC> d = vload<VEC, DO16>(dg, (size_t)(uint32_t)(p * a.lddo + cu));
 #pragma unroll
                 for (int j2 = 0; j2 < VEC / 2; ++j2) {
-                    float dzp[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int j = 2 * j2 + e;
-                        const float q = __uint_as_float(e ? (px[k][j2] & 0xffff0000u) : (px[k][j2] << 16));
-                        const float h = (q - mean) * rstd, z = h * ga[j] + be[j];
-                        const float dzz = d.v[j] * mish_grad_fast_f(z);
-                        dzp[e] = dzz;
-                        sA[j] += dzz; sD[j] += dzz * h; sT[j] += d.v[j]; sB[j] += h;
-                    }
-                    pd[k][j2] = pack_bf16(dzp[0], dzp[1]);
+                    f32x2 h2;
+                    const f32x2 dz2 = pair1(px[k][j2], f32x2{d.v[2 * j2], d.v[2 * j2 + 1]}, j2, h2);
+                    pd[k][j2] = pack_bf16(dz2.x, dz2.y);
                 }
             }
         }
@@ -424,6 +478,13 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? (MAXU * 
                     sA[j] += dzz; sD[j] += dzz * h; sT[j] += dd; sB[j] += h;
                 }
             }
+        }
+    }
+    if constexpr (PKC || (PK2 && MAXU > 0 && MAXU <= 4)) {
+#pragma unroll
+        for (int j2 = 0; j2 < H2; ++j2) {
+            sA[2 * j2] = aA[j2].x; sA[2 * j2 + 1] = aA[j2].y; sD[2 * j2] = aD[j2].x; sD[2 * j2 + 1] = aD[j2].y;
+            sT[2 * j2] = aT[j2].x; sT[2 * j2 + 1] = aT[j2].y; sB[2 * j2] = aB[j2].x; sB[2 * j2 + 1] = aB[j2].y;
         }
     }
 #pragma unroll
@@ -470,22 +531,24 @@ __global__ __launch_bounds__(256, (((IO & 1) && MAXU > 4 && VEC >= 4) ? (MAXU * 
         vstore<VEC, DX16>(a.dx, dxoff + (size_t)p * a.lddx, o);
     };
     if constexpr (PKC) {
+        const f32x2 s2v = {s2, s2}, s1v = {s1, s1}, nri2 = {-rstd * icnt, -rstd * icnt};
+        f32x2 rga2[H2];
+#pragma unroll
+        for (int j2 = 0; j2 < H2; ++j2) rga2[j2] = f32x2{rstd * ga[2 * j2], rstd * ga[2 * j2 + 1]};
         uint32_t so = (uint32_t)(pr * a.lddx + cu);
 #pragma unroll
         for (int k = 0; k < MAXU; ++k) {
             const int p = pr + k * PP;
             if (FULL || p < a.HW) {
-                V<VEC> xh, dz;
-#pragma unroll
-                for (int j2 = 0; j2 < VEC / 2; ++j2) {
-                    xh.v[2 * j2] = (__uint_as_float(px[k][j2] << 16) - mean) * rstd;
-                    xh.v[2 * j2 + 1] = (__uint_as_float(px[k][j2] & 0xffff0000u) - mean) * rstd;
-                    dz.v[2 * j2] = __uint_as_float(pd[k][j2] << 16);
-                    dz.v[2 * j2 + 1] = __uint_as_float(pd[k][j2] & 0xffff0000u);
-                }
+                // dx = rstd (dz gamma - (s1 + xhat s2) / cnt) = dz (rstd gamma) + (xhat s2 + s1) (-rstd / cnt), two channels per instruction
                 V<VEC> o;
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) o.v[j] = rstd * (dz.v[j] * ga[j] - (s1 + xh.v[j] * s2) * icnt);
+                for (int j2 = 0; j2 < VEC / 2; ++j2) {
+                    const f32x2 h2 = pk_fma_s(unpack_bf16x2(px[k][j2]), rstd2, nmr2);
+                    const f32x2 u2 = pk_fma_s(h2, s2v, s1v);
+                    const f32x2 o2 = pk_fma_s(u2, nri2, pk_mul(unpack_bf16x2(pd[k][j2]), rga2[j2]));
+                    o.v[2 * j2] = o2.x; o.v[2 * j2 + 1] = o2.y;
+                }
                 if constexpr (FULL) {
                     vstore<VEC, DX16>(dxg, (size_t)so, o);
                     so += (uint32_t)(PP * a.lddx);
@@ -752,6 +815,7 @@ static bool gn_wide16(const GnArgs& a, std::initializer_list<int> lds, std::init
         static const int full_on = (int)mi_knob("MI_GN_FULL", 1);                                                       \
         static const int wide_on = (int)mi_knob("MI_GN_WIDE16", 1);                                                     \
         if (full_on && vec == 4 && d->HW == 8 * ppx) hipLaunchKernelGGL((gn_mish_bwd_kernel<4, 8, IOV, true>), dim3(a.N * a.G), dim3(256), 0, st, a); \
+        else if (MI_GN_FULL16 && full_on && vec == 4 && d->HW == 16 * ppx) hipLaunchKernelGGL((gn_mish_bwd_kernel<4, 16, IOV, true>), dim3(a.N * a.G), dim3(256), 0, st, a); \
         else if (wide_on && vec == 4 && units > 16 && gn_wide16(a, {d->ldx, lddo, lddx}, {x, dout, dx, gamma, beta}))    \
             hipLaunchKernelGGL((gn_mish_bwd_kernel<8, 16, IOV, false>), dim3(a.N * a.G), dim3(256), 0, st, a);           \
         else GN_DISPATCH_IO(gn_mish_bwd_kernel, IOV);                                                                   \
