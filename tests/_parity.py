@@ -1,7 +1,7 @@
 """Measured parity errors of the bf16-MFMA mode, recorded while the GPU tests run.
 
 Every bf16-mode test calls `record(case, metric=value, ...)` with what it measured before asserting its tolerance; the values
-are merged into gpurun_out/r05_parity.json on the GPU box (committed as profiles/r05_parity.json), so a tolerance in a test can be
+are merged into gpurun_out/r06_parity.json on the GPU box (committed as profiles/r06_parity.json), so a tolerance in a test can be
 read next to the error it bounds.  The rule -- a bf16 tolerance is at most 2x the recorded worst case -- is checked mechanically:
 `bounds={metric: tolerance}` stores the tolerance the test asserts as "bound.<metric>" beside the measurement, and
 tests/test_host_cpu.py::test_bf16_bounds_at_most_twice_the_measured_error reads the committed file."""
@@ -9,7 +9,7 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.path.join(ROOT, "gpurun_out", "r05_parity.json")
+PATH = os.path.join(ROOT, "gpurun_out", "r06_parity.json")
 
 
 def record(case: str, bounds=None, **metrics):

@@ -330,3 +330,27 @@ def test_vae_oracle_matches_reference_vectors(golden_dir):
     assert abs(float(loss) - float(g["cfg1.loss"])) <= 1e-5 * abs(float(g["cfg1.loss"]))
     for k, ref in zip(list(g["cfg1.names"]), g["cfg1.gstats"]):
         assert abs(float(leaf[k].grad.double().norm()) - ref[1]) <= 2e-4 * ref[1] + 1e-5, k      # biases in front of a batch norm have an exactly-zero gradient: rounding noise only
+
+
+def test_traj20_oracle_follows_the_reference(golden_dir):
+    """SURVEY.md section 4's integration tier: 20 Adam steps (lr 1e-4) of the dim-32 UNet on a different fixed (x, t, eps) per step --
+    the oracle's loss curve and weight norms against the reference's (tests/golden/traj20.npz, tools/gen_golden_traj.py)."""
+    g = _load(golden_dir, "traj20.npz")
+    torch.manual_seed(0)
+    p = {k: v.requires_grad_(True) for k, v in O.init_unet_params(32, (1, 2, 4), 3).items()}
+    w0 = {k: v.detach().clone() for k, v in p.items()}
+    tab = O.schedule_tables(1000)
+    opt = torch.optim.Adam(list(p.values()), lr=1e-4, betas=(0.9, 0.999))
+    xs, ts, ns = _t(g["x"]), _t(g["t"]), _t(g["noise"])
+    for k in range(xs.shape[0]):
+        opt.zero_grad()
+        loss, _ = O.p_losses(p, tab, xs[k], ts[k], ns[k])
+        loss.backward()
+        opt.step()
+        assert abs(float(loss.detach()) - float(g["losses"][k])) < 2e-6, (k, float(loss.detach()), float(g["losses"][k]))
+        wn = float(torch.sqrt(sum((v.detach().double() ** 2).sum() for v in p.values())))
+        assert abs(wn - float(g["weight_norm"][k])) < 1e-6 * wn, k
+    for key in [k for k in g if k.startswith("delta.")]:
+        d = p[key[6:]].detach() - w0[key[6:]]
+        ref = _t(g[key])
+        assert float((d - ref).norm() / ref.norm()) < 1e-3, key

@@ -3,7 +3,7 @@ image-generation-models_amd/src/models/ddpm.py) against (a) golden vectors captu
 reference and (b) the CPU oracle on the same seeded inputs.
 Stated tolerances: epsilon-prediction rel-L2 <= 1e-4 in exact-fp32 mode (north_star; measured 3e-6); parameter gradients
 rel-L2 <= 1e-3 in fp32 mode (fp32 atomics reorder sums; measured 4e-6).  The bf16-MFMA mode's tolerances are each <= 2x the
-worst error MEASURED on the MI355X and recorded by these tests in profiles/r05_parity.json (rule checked by tests/test_host_cpu.py) (epsilon 0.9-1.1e-2 -> 2e-2; loss
+worst error MEASURED on the MI355X and recorded by these tests in profiles/r06_parity.json (rule checked by tests/test_host_cpu.py) (epsilon 0.9-1.1e-2 -> 2e-2; loss
 3e-5..7e-5 -> 2e-4; per-tensor gradient rel-L2 0.05-0.10 -> 0.1-0.2; whole flat gradient 1.5e-2 -> 3e-2); the reference itself
 under CPU bf16 autocast sits at 1.6e-2 on the epsilon prediction."""
 import os
@@ -406,7 +406,7 @@ def test_cfg3_per_gpu_batch_properties():
     assert out["fp32_forward_rerun_rel_l2"] == 0.0 and out["bf16_forward_rerun_rel_l2"] == 0.0
     assert out["fp32_forward_slice_vs_full_rel_l2"] < 1e-5 and out["fp32_rerun_rel_l2"] < 1e-6 and out["bf16_rerun_rel_l2"] < 1e-6
     assert out["fp32_slices_vs_full_rel_l2"] < 1e-6
-    # bf16 bounds <= 2x the values measured on the MI355X (profiles/r05_parity.json): 1.02e-2, 5.9e-3, 1.17e-2, 8.1e-3
+    # bf16 bounds <= 2x the values measured on the MI355X (profiles/r06_parity.json): 1.02e-2, 5.9e-3, 1.17e-2, 8.1e-3
     assert out["bf16_forward_slice_vs_full_rel_l2"] < 2e-2       # slices pick other kernel plans (tile sizes) than the full batch
     assert out["bf16_slices_vs_full_rel_l2"] < 1.2e-2
     assert out["bf16_vs_fp32_eps_rel_l2"] < 2.3e-2 and out["bf16_vs_fp32_flat_grad_rel_l2"] < 1.6e-2
@@ -719,3 +719,81 @@ def test_bf16_block_storage_end_to_end(golden_dir):
            flat_grad_rel_l2_vs_fp32_mode=e_full,
            bounds={"eps_rel_l2": 2.1e-2, "loss_abs": 1.5e-4, "flat_grad_rel_l2_vs_fp32_storage": 7.2e-2, "flat_grad_rel_l2_vs_fp32_mode": 7.9e-2})
     assert e_eps < 2.1e-2 and e_loss < 1.5e-4 and e_sto < 7.2e-2 and e_full < 7.9e-2       # measured 1.08e-2 / 8.0e-5 / 3.6e-2 / 4.0e-2 (round 4, bf16 ends)
+
+
+class _FixedInputsStep:
+    """training_step on (x, t, eps) read from static device buffers: what GraphedTrainStep captures for the trajectory test."""
+
+    def __init__(self, gd, t, noise):
+        self.gd, self.t, self.noise = gd, t, noise
+
+    def training_step(self, batch, i):
+        return self.gd.p_losses(batch[0], self.t, self.noise)
+
+
+@pytest.mark.parametrize("launch", ["eager", "graph"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_traj20_golden(golden_dir, mode, launch):
+    """SURVEY.md section 4, integration tier: 20 Adam steps (lr 1e-4, betas .9 / .999) of the dim-32 UNet from the reference's seeded
+    initialisation, a different fixed (x, t, eps) per step (tests/golden/traj20.npz, captured from the reference by
+    tools/gen_golden_traj.py): the loss of EVERY step, the norm of the whole parameter vector after every step and how far a few
+    tensors moved, eager and as one replayed hipGraph.  fp32 mode: per-step loss <= 1e-4 (the north-star's bar; measured ~1e-6);
+    bf16 mode: within <= 2x the recorded distance (profiles/r06_parity.json)."""
+    from src.models.ddpm import GaussianDiffusion
+    from src.runtime.graphed import GraphedTrainStep, node_types
+    from src.runtime.optim import FlatAdam
+    g = _load(golden_dir, "traj20.npz")
+    xs, ts, ns = _t(g["x"]).to(DEV), _t(g["t"]).to(DEV), _t(g["noise"]).to(DEV)
+    steps = xs.shape[0]
+
+    def build():
+        net = _seeded(32, (1, 2, 4), mode)
+        net.train()
+        gd = GaussianDiffusion(net, image_size=(16, 16), timesteps=1000).to(DEV)
+        return net, gd, FlatAdam(net, lr=1e-4, betas=(0.9, 0.999), device_state=(launch == "graph"))
+    net, gd, opt = build()
+    w0 = {k: v.detach().clone() for k, v in net.named_parameters()}
+    losses, wnorm = [], []
+    if launch == "graph":
+        # everything lazy (packed weight tables, Adam's moments and device step count, workspaces) is created by two eager steps
+        # BEFORE the capture; then weights, moments and step count go back to the reference's initial state
+        init = net.flat_params.clone()
+        for i in range(2):
+            l = gd.p_losses(xs[0], ts[0], ns[0]); l.backward(); opt.step()
+        net.flat_params.copy_(init); net.mark_params_dirty()
+        for buf in opt._m + opt._v:
+            buf.zero_()
+        opt._step = 0
+        opt._state.view(torch.int32)[0] = 0
+        fx = _FixedInputsStep(gd, ts[0].clone(), ns[0].clone())
+        gstep = GraphedTrainStep(fx, opt, (xs[0].clone(),), warmup=0)
+        nt = node_types(gstep.graph)
+        assert nt is None or set(nt) <= {"kernel"}, nt
+    for k in range(steps):
+        if launch == "graph":
+            fx.t.copy_(ts[k]); fx.noise.copy_(ns[k])
+            loss = gstep((xs[k],))
+        else:
+            loss = gd.p_losses(xs[k], ts[k], ns[k])
+            loss.backward(); opt.step()
+        losses.append(float(loss))
+        wnorm.append(float(net.flat_params.double().norm()))
+    e_loss = float(np.max(np.abs(np.array(losses) - g["losses"])))
+    # the flat buffer holds the parameters (and alignment padding that stays zero): its norm is the reference's weight norm
+    e_wn = float(np.max(np.abs(np.array(wnorm) - g["weight_norm"]) / g["weight_norm"]))
+    params = dict(net.named_parameters())
+    e_delta = {k[6:]: rel_err(params[k[6:]].detach() - w0[k[6:]], _t(g[k])) for k in g if k.startswith("delta.")}
+    moved = float(torch.sqrt(sum(((p.detach() - w0[k]).double() ** 2).sum() for k, p in net.named_parameters())))
+    e_moved = abs(moved - float(g["moved_norm"])) / float(g["moved_norm"])
+    # bf16 measured on the MI355X (eager / graph): loss 5.6e-4 / 5.2e-4, displacement 0.160 / 0.160 (mid_attn to_qkv) -- the two rule-bound
+    # metrics (<= 2x measured); the two norm metrics are differences of large sums and move 1.7x from run to run (fp32 atomics' order):
+    # recorded, asserted against fixed limits
+    b = {"fp32": dict(loss=1e-4, wn=1e-6, delta=2e-2, moved=1e-3), "bf16": dict(loss=1.04e-3, wn=2e-5, delta=0.319, moved=2e-3)}[mode]
+    record(f"traj20_{mode}_{launch}", worst_loss_abs=e_loss, worst_weight_norm_rel=e_wn, worst_delta_rel_l2=max(e_delta.values()),
+           worst_delta_key=max(e_delta, key=e_delta.get), moved_norm_rel=e_moved,
+           bounds={"worst_loss_abs": b["loss"], "worst_delta_rel_l2": b["delta"]})
+    assert np.isfinite(losses).all()
+    assert e_loss < b["loss"], (e_loss, losses)
+    assert e_wn < b["wn"], e_wn
+    assert max(e_delta.values()) < b["delta"], e_delta
+    assert e_moved < b["moved"], e_moved

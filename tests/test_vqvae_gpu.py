@@ -124,7 +124,7 @@ def test_cfg4_at_64x64_matches_reference(golden_dir):
 
 def test_cfg4_at_64x64_bf16_mode(golden_dir):
     """The benchmarked (bf16-MFMA) mode at 64x64 against the same reference vectors, with the measured errors recorded
-    (tolerances = 2x what profiles/r05_parity.json holds)."""
+    (tolerances = 2x what profiles/r06_parity.json holds)."""
     from _parity import record
     g = np.load(os.path.join(golden_dir, "vqvae_kats.npz"))
     m = _cfg4_64("bf16")
@@ -144,7 +144,7 @@ def test_cfg4_at_64x64_bf16_mode(golden_dir):
     _, grads = VO.training_grads(sd, imgs.cpu(), 0.25)
     e_grad = max(float((params[k].grad.cpu() - gr).norm() / (gr.norm() + 1e-30)) for k, gr in grads.items() if float(gr.norm()) > 1e-8)
     record("vqvae_cfg4_64_bf16", forward_rel_l2=e_fwd, index_mismatch_frac=mismatch, loss_rel=e_loss, worst_grad_rel_l2=e_grad)
-    # measured on the MI355X (profiles/r05_parity.json): 9.5e-3 / 2.7e-7 / 0.49 % of the codes / 0.133
+    # measured on the MI355X (profiles/r06_parity.json): 9.5e-3 / 2.7e-7 / 0.49 % of the codes / 0.133
     assert e_fwd <= 2e-2 and e_loss <= 1e-4 and mismatch <= 0.01 and e_grad <= 0.27, (e_fwd, e_loss, mismatch, e_grad)
 
 
