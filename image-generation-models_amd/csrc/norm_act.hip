@@ -94,13 +94,16 @@ __device__ __forceinline__ f32x2 mish_grad_pk(f32x2 z) {
     asm("v_pk_fma_f32 %0, %1, %2, 2.0 op_sel_hi:[1,1,0]" : "=v"(n) : "v"(e), "v"(ep));
     const f32x2 r = {__builtin_amdgcn_rcpf(n.x), __builtin_amdgcn_rcpf(n.y)};
     asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(zc), "s"(k6l));      // 4 z + 6
-    asm("v_pk_add_f32 %0, %1, 4.0 op_sel_hi:[1,0]" : "=v"(e4) : "v"(e));
+    // (every statement that reads e or r either carries the s_nop or depends on one that does: hipcc is free to reorder these asm statements,
+    //  and an unguarded reader scheduled straight behind the v_exp / v_rcp takes the register's OLD value -- found by the poisoned-allocator
+    //  soak test, not by the numerics tests)
+    asm("v_pk_add_f32 %0, %1, 2.0 op_sel_hi:[1,0]" : "=v"(e4) : "v"(ep));                                         // e + 4, through ep
     p1 = pk_fma(e4, e, t1);
     asm("v_pk_add_f32 %0, %1, -2.0 op_sel_hi:[1,0]" : "=v"(t2) : "v"(t1));                                       // 4 z + 4
     om = pk_fma(p1, e, t2);
     asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(er) : "v"(e), "v"(r));
-    g = pk_mul(om, r);
-    o = pk_mul(er, g);
+    g = pk_mul(er, om);
+    o = pk_mul(g, r);
     return o;
 }
 

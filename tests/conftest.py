@@ -30,3 +30,17 @@ def _seeded():
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(20240905)
     yield
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_allocator(request):
+    """GPU tests run on a caching allocator whose free blocks hold NaN (round 6).  A kernel that reads memory nobody wrote -- or a register
+    nobody wrote: the transcendental-forwarding hazard inside hand-written asm that round 6's GroupNorm backward had -- returns whatever
+    the previous tenant left; with ordinary leftovers (finite activations) such a result can sit inside a bf16 tolerance.  Blocks of
+    every size class are filled with NaN and freed before each test, so the next torch.empty() hands them out."""
+    import torch
+    if request.node.get_closest_marker("gpu") is not None and torch.cuda.is_available() and os.environ.get("MI_TEST_POISON", "1") == "1":
+        junk = [torch.full((n,), float("nan"), device="cuda") for n in (1 << 7, 1 << 10, 1 << 13, 1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 24) for _ in range(2)]
+        torch.cuda.synchronize()
+        del junk
+    yield
