@@ -255,7 +255,7 @@ def dry_run_cpu(args, world, rank):
 def named_kernel_line(K, dev, N=128, H=32, W=32, Cc=128):
     """north_star's named unit at its canonical shape: GroupNorm-apply + Mish (+ time bias) + Conv3x3 on
     X = [128,32,32,128] NHWC -> 128 channels, level 0 of cfg 2, for both activation storages of the bf16-MFMA mode.  Every entry's
-    `unit_us` is EVERYTHING the unit needs, timed with HIP events on the launch stream (median of 20): the two-pass unit = GroupNorm
+    `unit_us` is EVERYTHING the unit needs, timed with HIP events on the launch stream (10 calls back to back per sample, median of 7 samples): the two-pass unit = GroupNorm
     kernel + conv; a fused unit = the fused conv + whatever produces its statistics (a statistics pass over the tensor, or what the
     sums cost the PRODUCING conv's epilogue: that conv timed with and without them); the single fused launch is reported beside it as
     `fused_launch_us`.  hbm_frac = algorithmic bytes / unit time / 8 TB/s, mfma_frac = 38.65 GFLOP / unit time / 2.5 PFLOP/s."""
@@ -274,21 +274,30 @@ def named_kernel_line(K, dev, N=128, H=32, W=32, Cc=128):
     K.pack_weights_bf16(table, nent, tiles, w32, wd, w, wdq, wq)
     bias = torch.zeros(Cc, device=dev)
 
-    def timed(fns):
-        """{name: callable} -> median us of each callable's launches (sum over the launches it makes), interleaved rounds"""
-        for fn in fns.values():
-            for _ in range(3):
+    def timed(fns, reps=10, rounds=7):
+        """{name: callable} -> us per call of each callable, and the kernel symbols it launches.  A call is timed the way it runs inside the
+        replayed step -- back to back on a busy stream: `reps` calls between two HIP events on the launch stream, `rounds` interleaved
+        rounds over the legs, the median round.  (Until round 5 every call was synchronised on its own: an idle chip in front of each
+        launch reads 3 - 5 us more per launch than the same kernel shows in the step's rocprofv3 trace.)"""
+        syms = {}
+        for k, fn in fns.items():
+            K.PROBE = []
+            fn()
+            torch.cuda.synchronize()
+            syms[k] = [q[0] for q in K.PROBE]
+            K.PROBE = None
+            for _ in range(2):
                 fn()
         t = {k: [] for k in fns}
-        syms = {k: [] for k in fns}
-        for _ in range(20):
+        for _ in range(rounds):
             for k, fn in fns.items():
-                K.PROBE = []
-                fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _r in range(reps):
+                    fn()
+                e1.record()
                 torch.cuda.synchronize()
-                t[k].append(sum(e0.elapsed_time(e1) for _s, _f, e0, e1, _d, _n in K.PROBE) * 1e3)
-                syms[k] = [q[0] for q in K.PROBE]
-                K.PROBE = None
+                t[k].append(e0.elapsed_time(e1) * 1e3 / reps)
         return {k: sorted(v)[len(v) // 2] for k, v in t.items()}, syms
 
     for sto, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
