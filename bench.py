@@ -498,6 +498,10 @@ def main():
     unet_ = model.denoising_model
     state_finite = bool(torch.isfinite(unet_.flat_params).all()) and bool(torch.isfinite(unet_.flat_grads).all()) and final_loss == final_loss \
         and abs(final_loss) != float("inf")
+    if use_dist:                                        # every rank leaves together (a lone SystemExit would hang the peers' collectives)
+        flag_ = torch.tensor([1 if state_finite else 0], device=dev)
+        dist.all_reduce(flag_, op=dist.ReduceOp.MIN)
+        state_finite = bool(int(flag_))
     if not state_finite:
         raise SystemExit(f"bench.py: non-finite training state after the timed steps (loss {final_loss}); no throughput is reported")
     ms_per_step = elapsed / args.steps * 1e3
@@ -542,7 +546,7 @@ def main():
     model.eval()
     gs = GraphSampler(model.diffusion_model, (64, 3, SIDE, SIDE))
     gs._capture()
-    gs._set_image(torch.randn_like(gs.x)); gs.t.fill_(999)
+    gs.set_image(torch.randn_like(gs.x)); gs.t.fill_(999)
     for _ in range(5):
         gs.z.normal_(); gs.graph.replay()
     sync()

@@ -1363,6 +1363,7 @@ bool pw_geom(const MiConvDesc* d, int pt, int* TH, int* TI) {
     if (rows <= H) { if (H % rows) return false; *TH = rows; *TI = 1; }
     else { if (rows % H) return false; *TH = H; *TI = rows / H; if ((long)d->N % *TI) return false; }
     if ((*TH & (*TH - 1)) || *TH % bh || *TI > 2) return false; // the kernel's index arithmetic: shifts, bands of bh rows, at most two images per tile
+    if (pt == 256 && *TI > 1) return false;                     // (the 256-pixel tile's GroupNorm-sums epilogue attributes every row to ONE image)
     return *TI * (*TH + 2) * W <= pw_xp(pt);
 }
 

@@ -78,6 +78,7 @@ template <int VEC, bool T16> __device__ __forceinline__ void vstore(void* base, 
 //     d mish / dz = e w / n^2,   e = exp(min(z, 20)),  n = (e + 2) e + 2,  w = ((e + 4) e + (4 z + 6)) e + 4 z + 4
 // (one exp, one rcp, 11 packed instructions per PAIR; the tanh / sigmoid form above is ~17 per element).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ f32x2 pk_fma_s(f32x2 a, f32x2 sb, f32x2 c) { f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(sb), "v"(c)); return d; }   // sb: wave-uniform pair
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
@@ -956,6 +957,149 @@ extern "C" int mi_gn_coef_from_sums(int N, int C, int G, int HW, float eps, cons
                "bad argument (C / G must be a multiple of 16)");
     hipLaunchKernelGGL(gn_coef_from_sums_kernel, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, C, G, HW, eps, sums, gamma,
                        beta, temb, ldt, stats, coef);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+// ---- round 6: GroupNorm + Mish (+ time bias) (+ residual) as a STREAMING apply.  The statistics come from the (sum, sum of squares) the
+//      producing conv's epilogue left per sample and 16-channel slab (mi_conv3x3_pw_gnsums; mi_gn_coef_from_sums' arithmetic, resolved per
+//      workgroup), so nothing has to see a whole (sample, group) slice: a workgroup = a run of pixels of ONE sample x ALL channels, every
+//      load of the run requested before anything is computed, no block reduction, no second phase; reads and writes of different
+//      workgroups overlap by themselves.  x bf16 (the conv's output); y bf16, or fp32 with an optional bf16 copy (the residual stream).
+//      Also writes stats [N][G][2] = {mean, rstd} for the backward pass (the workgroup of a sample's first run).
+namespace {
+struct GnApplyArgs {
+    const uint16_t* x; const long long* sums; const float* gamma; const float* beta; const float* temb; const float* res;
+    void* y; uint16_t* y16; float* stats;
+    int N, HW, C, G, Cg, ldx, ldy, ldr, ldt, ldy16, chunks; float eps; double icnt;
+};
+// mish(z) + tb for a channel pair: z w / (w + 2), w = e (e + 2), e = exp(min(z, 20)) (mish_fast_f's arithmetic), two channels per instruction
+__device__ __forceinline__ f32x2 mish_tb_pk(f32x2 z, f32x2 tb) {
+    const f32x2 zc = {fminf(z.x, 20.f), fminf(z.y, 20.f)};
+    const f32x2 kl = {1.44269504f, 1.44269504f};
+    f32x2 zl, ep, w, n, t, o;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(zl) : "v"(zc), "s"(kl));
+    const f32x2 e = {__builtin_amdgcn_exp2f(zl.x), __builtin_amdgcn_exp2f(zl.y)};
+    // (the ONLY direct reader of e, and below of r, carries the s_nop; everything else depends on it: see mish_grad_pk)
+    asm("s_nop 0\n\tv_pk_add_f32 %0, %1, 2.0 op_sel_hi:[1,0]" : "=v"(ep) : "v"(e));
+    w = pk_mul(e, ep);
+    asm("v_pk_add_f32 %0, %1, 2.0 op_sel_hi:[1,0]" : "=v"(n) : "v"(w));
+    const f32x2 r = {__builtin_amdgcn_rcpf(n.x), __builtin_amdgcn_rcpf(n.y)};
+    t = pk_mul(z, w);
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3" : "=v"(o) : "v"(t), "v"(r), "v"(tb));
+    return o;
+}
+template <bool Y16, bool RES, int UNR>
+__global__ __launch_bounds__(256) void gn_apply_sums_kernel(const GnApplyArgs a) {
+    MI_PRIO_UP();
+    __shared__ float s_stat[2 * 64];
+    const int t = threadIdx.x;
+    const int TPP = a.C >> 3, PP = 256 / TPP;                 // threads per pixel (8 channels each), pixels per pass
+    const int n = blockIdx.x / a.chunks, chunk = blockIdx.x - n * a.chunks;
+    const int u = t & (TPP - 1), pr = t / TPP, c0 = u * 8;
+    const size_t pix0 = (size_t)n * a.HW + (size_t)chunk * (PP * UNR) + pr;
+    // ---- every x (and residual) row of the run: requested before the statistics are even read
+    uint4 xr[UNR];
+    f32x4 rr[RES ? UNR : 1][2];
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) xr[k] = *reinterpret_cast<const uint4*>(a.x + (pix0 + (size_t)k * PP) * a.ldx + c0);
+    if constexpr (RES) {
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const float* rp = a.res + (pix0 + (size_t)k * PP) * a.ldr + c0;
+            rr[k][0] = *reinterpret_cast<const f32x4*>(rp); rr[k][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+        }
+    }
+    // ---- the sample's statistics (G <= 64 groups): thread g combines its group's slabs -- integer sums, double, var = E[x^2] - mean^2
+    if (t < a.G) {
+        const int nslab = a.Cg >> 4;
+        long long si = 0, qi = 0;
+        bool poisoned = false;
+        for (int k = 0; k < nslab; ++k) {
+            const size_t p = ((size_t)n * (a.C >> 4) + (size_t)t * nslab + k) * 2;
+            const long long r0 = a.sums[p], r1 = a.sums[p + 1];
+            poisoned |= r0 >= (1LL << 60) || r0 <= -(1LL << 60) || r1 >= (1LL << 60) || r1 <= -(1LL << 60);
+            si += r0; qi += r1;
+        }
+        const double mean = poisoned ? __builtin_nan("") : (double)si * a.icnt;
+        double var = (double)qi * a.icnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = 1.0f / sqrtf((float)var + a.eps), mf = (float)mean;
+        s_stat[2 * t] = mf; s_stat[2 * t + 1] = rstd;
+        if (chunk == 0 && a.stats) { a.stats[2 * (n * a.G + t)] = mf; a.stats[2 * (n * a.G + t) + 1] = rstd; }
+    }
+    f32x2 ga2[4], sh2[4], tb2[4];
+    {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.gamma + c0), g1 = *reinterpret_cast<const f32x4*>(a.gamma + c0 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.beta + c0), b1 = *reinterpret_cast<const f32x4*>(a.beta + c0 + 4);
+        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+        if (a.temb) { const float* tp = a.temb + (size_t)n * a.ldt + c0; t0 = *reinterpret_cast<const f32x4*>(tp); t1 = *reinterpret_cast<const f32x4*>(tp + 4); }
+        __syncthreads();
+        const int g = c0 / a.Cg;                              // the thread's 8 channels lie in one group (Cg % 16 == 0)
+        const float mean = s_stat[2 * g], rstd = s_stat[2 * g + 1];
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s0 = gv[2 * j] * rstd, s1 = gv[2 * j + 1] * rstd;
+            ga2[j] = f32x2{s0, s1}; sh2[j] = f32x2{bv[2 * j] - mean * s0, bv[2 * j + 1] - mean * s1}; tb2[j] = f32x2{tv[2 * j], tv[2 * j + 1]};
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+        const uint32_t xv[4] = {xr[k].x, xr[k].y, xr[k].z, xr[k].w};
+        f32x2 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = mish_tb_pk(pk_fma(unpack_bf16x2(xv[j]), ga2[j], sh2[j]), tb2[j]);
+        if constexpr (RES) {
+            o[0] = pk_add(o[0], f32x2{rr[k][0].x, rr[k][0].y}); o[1] = pk_add(o[1], f32x2{rr[k][0].z, rr[k][0].w});
+            o[2] = pk_add(o[2], f32x2{rr[k][1].x, rr[k][1].y}); o[3] = pk_add(o[3], f32x2{rr[k][1].z, rr[k][1].w});
+        }
+        const size_t p = pix0 + (size_t)k * PP;
+        const uint4 pk = make_uint4(pack_bf16(o[0].x, o[0].y), pack_bf16(o[1].x, o[1].y), pack_bf16(o[2].x, o[2].y), pack_bf16(o[3].x, o[3].y));
+        if constexpr (Y16) {
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.y) + p * a.ldy + c0) = pk;
+        } else {
+            float* yp = reinterpret_cast<float*>(a.y) + p * a.ldy + c0;
+            *reinterpret_cast<f32x4*>(yp) = f32x4{o[0].x, o[0].y, o[1].x, o[1].y};
+            *reinterpret_cast<f32x4*>(yp + 4) = f32x4{o[2].x, o[2].y, o[3].x, o[3].y};
+            if (a.y16) *reinterpret_cast<uint4*>(a.y16 + p * a.ldy16 + c0) = pk;
+        }
+    }
+}
+}  // namespace
+// x: bf16 [N][HW][C] (pixel stride d->ldx); sums: [N][C / 16][2] 64-bit fixed point (mi_conv3x3_pw_gnsums); y: bf16 (y_is_bf16) or fp32
+// (pixel stride d->ldy), residual fp32 (optional, fp32 y only, stride d->ldr), y_bf16: optional bf16 copy of an fp32 y (stride ldy16),
+// stats [N][G][2] (optional).  C / G a multiple of 16 and <= 64 groups, C / 8 a power of two <= 256, 16-byte aligned rows.
+// Returns 1 when the shape is not taken (the caller keeps mi_gn_mish_fwd_io), 0 when launched.
+extern "C" int mi_gn_mish_apply_sums(const MiGnDesc* d, const void* x, const void* sums, const float* gamma, const float* beta, const float* temb,
+                                     int ldt, const float* residual, void* y, int y_is_bf16, void* y_bf16, int ldy16, float* stats, void* stream) {
+    MI_REQUIRE(d && x && sums && gamma && beta && y, "null argument");
+    MI_REQUIRE(!(y_is_bf16 && (residual || y_bf16)), "residual / bf16 copy: fp32 y only");
+    const int C = d->C, G = d->G;
+    if (C <= 0 || G <= 0 || G > 64 || C % G || (C / G) % 16 || C % 8 || C / 8 > 256 || ((C / 8) & (C / 8 - 1))) return 1;
+    if (d->ldx % 8 || d->ldy % 8 || (residual && d->ldr % 4) || (y_bf16 && ldy16 % 8) || (temb && ldt % 4)) return 1;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)(temb ? temb : gamma) | (uintptr_t)(residual ? residual : gamma) |
+          (uintptr_t)(y_bf16 ? y_bf16 : y)) & 15) || ((uintptr_t)sums & 7)) return 1;
+    const int PP = 256 / (C / 8);
+    int unr = residual ? 4 : 8;
+    while (unr > 1 && d->HW % (PP * unr)) unr >>= 1;
+    if (d->HW % (PP * unr)) return 1;
+    GnApplyArgs a{};
+    a.x = (const uint16_t*)x; a.sums = (const long long*)sums; a.gamma = gamma; a.beta = beta; a.temb = temb; a.res = residual; a.y = y;
+    a.y16 = (uint16_t*)y_bf16; a.stats = stats; a.N = d->N; a.HW = d->HW; a.C = C; a.G = G; a.Cg = C / G; a.ldx = d->ldx; a.ldy = d->ldy;
+    a.ldr = d->ldr; a.ldt = ldt; a.ldy16 = ldy16; a.eps = d->eps; a.icnt = 1.0 / (MI_GSUM_SCALE * (double)d->HW * (double)(C / G));
+    a.chunks = d->HW / (PP * unr);
+    const dim3 grid((unsigned)(d->N * a.chunks)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+#define GN_APPLY_GO(Y16, RES) do { switch (unr) { \
+        case 8: hipLaunchKernelGGL((gn_apply_sums_kernel<Y16, RES, 8>), grid, blk, 0, st, a); break; \
+        case 4: hipLaunchKernelGGL((gn_apply_sums_kernel<Y16, RES, 4>), grid, blk, 0, st, a); break; \
+        case 2: hipLaunchKernelGGL((gn_apply_sums_kernel<Y16, RES, 2>), grid, blk, 0, st, a); break; \
+        default: hipLaunchKernelGGL((gn_apply_sums_kernel<Y16, RES, 1>), grid, blk, 0, st, a); break; } } while (0)
+    if (y_is_bf16) GN_APPLY_GO(true, false);
+    else if (residual) GN_APPLY_GO(false, true);
+    else GN_APPLY_GO(false, false);
+#undef GN_APPLY_GO
     MI_LAUNCH_CHECK();
     return 0;
 }

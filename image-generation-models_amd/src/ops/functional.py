@@ -420,6 +420,33 @@ def gn_coef_from_sums(sums, N, HW, gamma, beta, *, groups=8, eps=1e-5, temb=None
     return stats, coef
 
 
+def gn_mish_apply_sums(x, sums, gamma, beta, *, groups=8, eps=1e-5, temb=None, residual=None, out_dtype=torch.float32, want16=False):
+    """GroupNorm + Mish (+ time bias) (+ residual) as one streaming pass over x (bf16, the output of a conv that ran with gn_sums=sums):
+    the statistics come from the conv's epilogue sums, so there is no statistics phase.  -> (y, stats[, y16]) like gn_mish_fwd, or None when
+    the library does not take the shape (the caller then runs gn_mish_fwd)."""
+    _need_gpu(x)
+    if x.dtype != torch.bfloat16:
+        return None
+    N, H, W, Cc = x.shape
+    y16 = None
+    y = new_act(N, H, W, Cc, x, out_dtype)
+    if want16:
+        assert out_dtype == torch.float32
+        y16 = new_act(N, H, W, Cc, x, torch.bfloat16)
+    stats = torch.empty((N, groups, 2), device=x.device, dtype=torch.float32)
+    d = MiGnDesc(N=N, HW=H * W, C=Cc, G=groups, eps=eps, ldx=ld_of(x), ldy=ld_of(y), ldr=ld_of(residual) if residual is not None else 0)
+    e0 = _probe_open()
+    rc = load_library().mi_gn_mish_apply_sums(C.byref(d), _p(x), _p(sums), _p(gamma), _p(beta), _p(temb), ld_of(temb) if temb is not None else 0,
+                                              _p(residual), _p(y), _b16(y), _p(y16), ld_of(y16) if y16 is not None else 0, _p(stats), _stream())
+    if rc == 1:
+        return None
+    check(rc, "mi_gn_mish_apply_sums")
+    if e0 is not None:
+        _probe_close(e0, f"gn_apply_sums_kernel<io{1 + 2 * _b16(y)}>", 0.0, f"N{N} HW{H * W} C{Cc}",
+                     N * H * W * Cc * (_esz(x) + _esz(y) + _esz(residual) + _esz(y16)))
+    return (y, stats, y16) if want16 else (y, stats)
+
+
 @functools.lru_cache(maxsize=None)      # pure function of the shape: one FFI query per distinct layer, not per step
 def conv3x3_gn_mish_supported(N, H, W, K, Nc):
     d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=MODE_BF16, K1=K,

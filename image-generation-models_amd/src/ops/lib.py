@@ -73,6 +73,7 @@ SIGNATURES = {
     "mi_pack_weights_tile": [],
     "mi_conv3x3_bf16w_io_gnsums": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "mi_gn_coef_from_sums": [_I, _I, _I, _I, _F, _P, _P, _P, _P, _I, _P, _P, _P],
+    "mi_gn_mish_apply_sums": [C.POINTER(MiGnDesc), _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P],
     "mi_conv3x3_bf16w_io_dual": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "mi_conv3x3_gn_mish_sums": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _I, _P],
     "mi_debug_wgrad1x1_tr_blocks": [_I],

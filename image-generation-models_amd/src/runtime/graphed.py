@@ -125,24 +125,14 @@ class SegmentedGraphedTrainStep:
         self.logged = {}
 
     def _begin(self):
-        try:
-            self._cur = torch.cuda.CUDAGraph(keep_graph=True)     # (the captured hipGraph_t stays readable: _node_count)
-        except TypeError:
-            self._cur = torch.cuda.CUDAGraph()
+        self._cur = _new_graph()                                  # (the captured hipGraph_t stays readable: node_types)
         self._cur.capture_begin(pool=self.pool)
 
     @staticmethod
     def _node_count(g):
-        """Nodes of a captured graph (hipGraphGetNodes on the kept hipGraph_t), None when it cannot be read."""
-        try:
-            import ctypes
-            raw = g.raw_cuda_graph()
-            hip = ctypes.CDLL("libamdhip64.so")
-            n = ctypes.c_size_t(0)
-            rc = hip.hipGraphGetNodes(ctypes.c_void_p(raw), None, ctypes.byref(n))
-            return int(n.value) if rc == 0 else None
-        except Exception:       # noqa: BLE001
-            return None
+        """Nodes of a captured graph, None when it cannot be read."""
+        nt = node_types(g)
+        return None if nt is None else sum(nt.values())
 
     def _end(self, rng):
         # every captured segment that HOLDS something is kept and replayed, whatever it holds (library launches, torch fills / copies /

@@ -46,7 +46,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._state = st
 
     def device_step_count(self) -> int:
-        return int(self._state.view(torch.int32)[0]) if self._state is not None else self._step
+        return int(self._state.view(torch.int32)[0]) if (self.device_state and self._state is not None) else self._step
 
     @torch.no_grad()
     def step(self, closure=None):

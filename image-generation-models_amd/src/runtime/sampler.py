@@ -38,7 +38,10 @@ class GraphSampler:
         K.p_sample_update(self.x, eps, self.z, self.t, gd._tables(), clip=True, out=self.x, out_nhwc=self.xh_full)
         self.t.sub_(self.one)
 
-    def _set_image(self, x):
+    def set_image(self, x):
+        """The ONLY way to put an image into the sampler: the UNet reads the NHWC buffer (`xh`), the posterior kernel the NCHW one
+        (`x`, read-only for callers) -- writing `gs.x` directly would leave the two apart and the next step would predict epsilon
+        for the old image."""
         self.x.copy_(x)
         self.xh.copy_(K.nchw_to_nhwc(self.x))
 
@@ -62,7 +65,7 @@ class GraphSampler:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                      # warm-up outside capture (allocator, lazy init)
             self.t.fill_(1)
-            self._set_image(torch.zeros_like(self.x))
+            self.set_image(torch.zeros_like(self.x))
             self._iteration()
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
@@ -78,7 +81,7 @@ class GraphSampler:
             self.refresh()
         # noise: device Philox by default; `gd.noise_source` (parity runs) supplies a host tape in the reference's draw order --
         # randn(shape) for x_T, then one draw per step (ddpm.py:404-408,268-273)
-        self._set_image(gd._randn(self.shape, self.x.device))
+        self.set_image(gd._randn(self.shape, self.x.device))
         self.t.fill_(gd.num_timesteps - 1)
         for _ in range(gd.num_timesteps):
             if gd.noise_source is None:

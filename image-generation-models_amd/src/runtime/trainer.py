@@ -243,6 +243,7 @@ class Trainer:
                         why = f"{type(cap_exc).__name__}: {cap_exc}" if cap_exc is not None else "failed on another rank"
                         print(f"[trainer] hipGraph capture of the training step failed ({why}); continuing eagerly", flush=True)
                         use_graph, gstep = False, None
+                        optimizer.device_state = False          # the eager path keeps its step count and lr on the host again
                         torch.cuda.synchronize()
                         # what the aborted capture recorded never ran: derived state keyed on the parameters (bf16 weight copies, ...) is
                         # stale although its keys say otherwise -- rebuild it before the eager step reads it

@@ -434,6 +434,15 @@ int mi_gn_mish_fwd_io(const MiGnDesc* d, const void* x, const float* gamma, cons
 int mi_gn_mish_fwd_dual(const MiGnDesc* d, const void* x, const float* gamma, const float* beta,
                         const float* temb, int ldt, const float* residual, void* y, void* y16, int ldy16,
                         float* stats, int io, void* stream);
+/* GroupNorm + Mish (+ time bias) (+ residual) as a STREAMING apply fed by the sums the producing conv's epilogue left (mi_conv3x3_pw_gnsums:
+ * sums [N][C / 16][2], 64-bit fixed point): no statistics pass, no (sample, group) workgroups -- a workgroup is a run of pixels of one
+ * sample x all channels.  Replaces aten::native_group_norm + Mish + the broadcast / residual adds of reference src/models/ddpm.py:112-120,
+ * 139-143 where a tile-kernel conv produced x.  x bf16 [N][HW][C]; y bf16 (y_is_bf16) or fp32, residual fp32 (fp32 y only), y_bf16 an
+ * optional bf16 copy of an fp32 y, stats [N][G][2] = {mean, rstd} (optional, what the backward pass reads).  Returns 0 when launched,
+ * 1 when the shape is not taken (C / G % 16, C / 8 a power of two <= 256, HW a multiple of the pixels per pass, 16-byte aligned rows):
+ * the caller then runs mi_gn_mish_fwd_io. */
+int mi_gn_mish_apply_sums(const MiGnDesc* d, const void* x, const void* sums, const float* gamma, const float* beta, const float* temb,
+                          int ldt, const float* residual, void* y, int y_is_bf16, void* y_bf16, int ldy16, float* stats, void* stream);
 /* statistics-only pass for the fused conv above */
 int mi_gn_stats_coef(const MiGnDesc* d, const void* x, const float* gamma, const float* beta, const float* temb, int ldt,
                      float* stats, float* coef, int x_is_bf16, void* stream);

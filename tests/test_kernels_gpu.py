@@ -1974,3 +1974,31 @@ def test_halo_kernel_takes_every_bf16_layer_in_a_subprocess():
                         "-p", "no:cacheprovider", "-k", "(conv and not subprocess) or bf16_block or cfg2_eps or mid_unet"],
                        capture_output=True, text=True, timeout=1200, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("variant", ["bf16", "fp32", "fp32+res+copy"])
+@pytest.mark.parametrize("cfg", [(16, 32, 32, 128), (8, 16, 16, 256), (8, 16, 16, 128), (4, 8, 8, 512), (4, 8, 8, 256), (2, 4, 4, 128)])
+def test_gn_mish_apply_from_epilogue_sums(K, cfg, variant):
+    """mi_gn_mish_apply_sums (round 6): GroupNorm + Mish + time bias (+ residual, + bf16 copy) as ONE streaming pass fed by the sums a
+    conv's epilogue leaves, against the two-phase kernel (mi_gn_mish_fwd_io / _dual) on the same bf16 tensor: same statistics (the sums
+    are exact sums of the stored values; var = E[x^2] - mean^2 in double against the two-pass variance), same packed / fast Mish."""
+    N, H, W, Cc = cfg
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = (torch.randn(N, H, W, Cc, device=DEV, generator=g) * 1.5 + 0.3).bfloat16()
+    ga = torch.randn(Cc, device=DEV, generator=g); be = torch.randn(Cc, device=DEV, generator=g)
+    tb = torch.randn(N, Cc, device=DEV, generator=g)
+    res = torch.randn(N, H, W, Cc, device=DEV, generator=g) if "res" in variant else None
+    xs = x.double().view(N, H * W, Cc // 16, 16)
+    sums = K.gn_sums_encode(torch.stack([xs.sum((1, 3)), (xs * xs).sum((1, 3))], dim=-1))
+    dt = torch.bfloat16 if variant == "bf16" else torch.float32
+    want16 = "copy" in variant
+    ref = K.gn_mish_fwd(x, ga, be, temb=tb, residual=res, out_dtype=dt, want16=want16)
+    out = K.gn_mish_apply_sums(x, sums, ga, be, temb=tb, residual=res, out_dtype=dt, want16=want16)
+    assert out is not None, "shape not taken"
+    assert out[0].dtype == dt and torch.isfinite(out[0].float()).all()
+    tol = 8e-3 if dt == torch.bfloat16 else 2e-5                 # bf16 output: one rounding flip of 2^-8; fp32: the statistics' last bits
+    assert rel_err(out[0].float(), ref[0].float()) < tol
+    assert float((out[1] - ref[1].view_as(out[1])).abs().max() / ref[1].abs().max()) < 2e-5      # {mean, rstd}
+    if want16:
+        assert rel_err(out[2].float(), ref[2].float()) < 8e-3
+        assert torch.equal(out[2], out[0].bfloat16())

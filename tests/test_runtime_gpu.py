@@ -94,7 +94,7 @@ def test_graph_sampler_sees_optimizer_step_in_bf16_mode():
             gs._capture()
         else:
             gs.refresh()
-        gs._set_image(tape[0].to(DEV)); gs.t.fill_(5)
+        gs.set_image(tape[0].to(DEV)); gs.t.fill_(5)
         for i in range(6):
             gs.z.copy_(tape[1 + i].to(DEV)); gs.graph.replay()
         return gs.x.clone()
@@ -377,7 +377,7 @@ def test_captured_steps_hold_kernel_nodes_only(B):
     gs = GraphSampler(m.diffusion_model, (8, 3, 16, 16))
     gs.refresh()
     with torch.cuda.stream(s):
-        gs.t.fill_(1); gs._set_image(torch.zeros_like(gs.x)); gs._iteration()
+        gs.t.fill_(1); gs.set_image(torch.zeros_like(gs.x)); gs._iteration()
         g2 = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(g2, stream=s):
             gs._iteration()

@@ -80,7 +80,7 @@ def test_tiny_loss_and_grads_golden(golden_dir):
 def test_unet_without_time_embedding_golden(golden_dir, mode):
     """Unet(with_time_emb=False) -- the reference's constructor flag that DDPM never sets (ddpm.py:186-198: no time MLP, ResnetBlocks without
     their time Linear, forward with t = None): forward, L1 p_losses and every parameter gradient against vectors produced by the reference
-    itself (tools/gen_golden_notime.py); the sampler's time-bias table does not exist for it and the graph-free sampler still runs."""
+    itself (tools/gen_golden_notime.py); the sampler's time-bias table does not exist for it and the sampler (graph path, the default) still runs."""
     from src.models.ddpm import GaussianDiffusion, Unet
     g = _load(golden_dir, "tiny_unet_notime.npz")
     net = Unet(dim=8, dim_mults=(1, 2), channels=3, with_time_emb=False)
@@ -527,7 +527,7 @@ def test_graph_sampler_matches_eager():
     eager = gd.p_sample_loop(shape, use_graph=False)
     gs = GraphSampler(gd, shape)
     gs._capture()
-    gs._set_image(tape[0]); gs.t.fill_(5)
+    gs.set_image(tape[0]); gs.t.fill_(5)
     for i in range(6):
         gs.z.copy_(tape[1 + i]); gs.graph.replay()
     assert float((gs.x - eager).abs().max()) < 1e-5

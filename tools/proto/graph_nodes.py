@@ -42,7 +42,7 @@ m.eval()
 gs = GraphSampler(m.diffusion_model, (64, 3, 32, 32))
 gs.refresh()
 with torch.cuda.stream(s):
-    gs.t.fill_(1); gs._set_image(torch.zeros_like(gs.x)); gs._iteration()
+    gs.t.fill_(1); gs.set_image(torch.zeros_like(gs.x)); gs._iteration()
     g2 = torch.cuda.CUDAGraph(keep_graph=True)
     with torch.cuda.graph(g2, stream=s):
         gs._iteration()

@@ -14,7 +14,7 @@ m = DDPM({"width": 32, "height": 32, "channels": 3, "transforms": {"normalize": 
 m.denoising_model.compute_mode = os.environ.get("MODE", "bf16"); m.eval()
 gs = GraphSampler(m.diffusion_model, (B, 3, 32, 32)); gs._capture()
 import time
-gs._set_image(torch.randn_like(gs.x)); gs.t.fill_(999)
+gs.set_image(torch.randn_like(gs.x)); gs.t.fill_(999)
 for _ in range(5):
     gs.z.normal_(); gs.graph.replay()
 torch.cuda.synchronize(); t0 = time.perf_counter()
