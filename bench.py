@@ -585,7 +585,7 @@ def main():
         sym, (fl, sec, cnt, nb) = max(agg.items(), key=lambda kv: kv[1][1])          # the symbol with the most time per step
         peak = PEAK_TFLOPS[args.mode]
         traffic, tnote, tstale = None, None, None
-        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC passes are separate runs (profiles/)
+        for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):   # PMC passes are separate runs (profiles/)
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     ent = json.load(f).get(sym)
