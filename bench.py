@@ -771,6 +771,9 @@ def main():
                        "sclk_mhz_under_mfma": sclk,
                        "rccl_ranks": rccl_ranks,
                        "allreduce_ms_exposed": (comm or {}).get("allreduce_ms_exposed"),
+                       "comm_exposed_ms_by_subtraction": ((comm or {}).get("ways_ms") or {}).get("exposed_comm_ms"),
+                       "eager_overlap_ms_per_step": ((comm or {}).get("ways_ms") or {}).get("eager_overlap"),
+                       "graph_segments": (comm or {}).get("graph_segments"),
                        "rank_ms_min": spread.get("min"), "rank_ms_max": spread.get("max"),
                        "final_loss": round(final_loss, 5), "state_finite": state_finite,
                        "matmul": "bf16 MFMA, fp32 accumulate" if args.mode == "bf16" else "fp32 MFMA"},
