@@ -366,7 +366,7 @@ def main():
                          "CPU-bound (HIP lazy module loads, caching-allocator growth), see tools/coldstart.py")
     ap.add_argument("--mode", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=128, help="images per GPU (reference default 128)")
-    ap.add_argument("--denoise-steps", type=int, default=40)
+    ap.add_argument("--denoise-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32-mode leg, the named-kernel microbenchmark and the CPU baseline")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("MI_BENCH_GRAPH", "-1")),
@@ -492,6 +492,13 @@ def main():
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el)
+    # the shader clock right behind the timed steps (the chip is in its sustained state: a probe after an idle stretch reads 10 - 15 % low)
+    sclk = None
+    if rank == 0 and not args.no_extras:
+        try:
+            sclk = K.clock_probe(dev, usec=300)
+        except Exception:                                   # noqa: BLE001
+            sclk = None
     final_loss = float(loss.detach())
     # a throughput of steps that trained garbage is not a measurement: the loss, every weight and every gradient after the timed steps
     # must be finite (outside the timed region; round 5 found a replayed-graph fault that left NaN weights and a normal step time)
@@ -547,7 +554,9 @@ def main():
     gs = GraphSampler(model.diffusion_model, (64, 3, SIDE, SIDE))
     gs._capture()
     gs.set_image(torch.randn_like(gs.x)); gs.t.fill_(999)
-    for _ in range(5):
+    # (60 untimed replays first: from idle the chip's shader clock takes tens of milliseconds of load to reach its sustained value --
+    #  tools/proto/clock_probe.py: 2 050 MHz in the first millisecond, 2 390 after ~30 ms -- and a T = 1000 sampling run lasts a second)
+    for _ in range(60):
         gs.z.normal_(); gs.graph.replay()
     sync()
     t0 = time.perf_counter()
@@ -643,7 +652,7 @@ def main():
             net.grad_ready_hook = red1.range_ready
             opt.device_state = True
             g1 = SegmentedGraphedTrainStep(model, opt, red1, batch)
-            ms1 = timed_leg(lambda i: g1(batch), 30, 5, torch.cuda.synchronize, 1, dev)
+            ms1 = timed_leg(lambda i: g1(batch), 30, 12, torch.cuda.synchronize, 1, dev)
             dp_path = {"value": round(B / ms1 * 1e3, 1), "ms_per_step": round(ms1, 3), "rccl_ranks": int(one.item()),
                        "graph_segments": len(g1.segments) + 1, "buckets_bytes": [4 * (hi - lo) for lo, hi in red1.launched]}
             del g1
@@ -715,14 +724,6 @@ def main():
             del gstep3, m3, n3, o3
         except Exception as exc:                            # noqa: BLE001  (an extra: reported, never fatal)
             cfg3 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-
-    # ---- the shader clock this box sustains under matrix-core load (round 5: 1.57 - 1.87 GHz inside conv launches; boxes differ)
-    sclk = None
-    if rank == 0 and not args.no_extras:
-        try:
-            sclk = K.clock_probe(dev)
-        except Exception:                                   # noqa: BLE001
-            sclk = None
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_extras and args.cfg == 2:
