@@ -23,7 +23,12 @@ struct W1Args {
     float* ws; float* dW; float* dbias;
     int Ci, Cj, I1, ldp, ldp2, ldq, q32, ni, f32;
     int total, sps, splits, gx, gy, wg0, tile0, xcd_map;
+    // round 6, exact-fp32 mode only: ONE TAP of a stride-2 / transposed conv's weight gradient as a gathered 1x1 problem -- the pixels m of the
+    // small (dense) grid [N][1 << (lghw - lgw)][1 << lgw] meet pixel (2 y + gdy, 2 x + gdx) of the big [N][GH][GW] tensor (zero outside)
+    int gmode;          // 0: plain 1x1; 1: P is the big (gathered) tensor; 2: Q is
+    int gdy, gdx, lgw, lghw, GH, GW;
 };
+__device__ __attribute__((aligned(16))) uint32_t g_w1_zero[128];      // 512 zero bytes: what a tap reads outside the big tensor
 struct W1Batch { W1Args p[MAXP]; int n; };
 
 // PF steps are requested ahead of the one being multiplied (3 for bf16 dY, 2 when the raw fp32 rows take 32 KB per step); a step is
@@ -198,18 +203,33 @@ __device__ __forceinline__ void wgrad1_f32_body(const W1Args& a, const int wg, u
     const float* xsrc = reinterpret_cast<const float*>(second ? (const void*)a.P2 : (const void*)a.P) + (size_t)(l >> 4) * ldx +
                         (second ? ci0 - a.I1 : ci0) + (l & 15) * 4;
     const float* ysrc = reinterpret_cast<const float*>(a.Q) + (size_t)(l >> 5) * a.ldq + min(co0 + (l & 31) * 4, a.Cj - 4);
+    // gathered operand (gmode): dense pixel m -> its big-tensor pixel for this problem's tap, or -1 outside the tensor
+    auto gpix = [&](int m) -> long {
+        const int n = m >> a.lghw, r = m & ((1 << a.lghw) - 1);
+        const int gy = 2 * (r >> a.lgw) + a.gdy, gx = 2 * (r & ((1 << a.lgw) - 1)) + a.gdx;
+        return ((unsigned)gy < (unsigned)a.GH && (unsigned)gx < (unsigned)a.GW) ? ((long)n * a.GH + gy) * a.GW + gx : -1L;
+    };
+    const float* xch = xsrc - (size_t)(l >> 4) * ldx;                  // channel part only (the pixel part is computed per request)
+    const float* ych = ysrc - (size_t)(l >> 5) * a.ldq;
+    const float* zsrc = reinterpret_cast<const float*>(g_w1_zero);
     auto stage = [&](int step) {
         const size_t pix0 = (size_t)min(step, last) * 64;
         const int slot = step % RING;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {                                  // 16 blocks of 4 pixels, two per wave
             const int i = wv + 8 * k;
-            glds16(xsrc + (pix0 + i * 4) * ldx, lds0 + slot * XRAW + i * 1024);
+            if (a.gmode == 1) {
+                const long g = gpix((int)pix0 + i * 4 + (l >> 4));
+                glds16(g >= 0 ? xch + (size_t)g * ldx : zsrc + (l & 15) * 4, lds0 + slot * XRAW + i * 1024);
+            } else glds16(xsrc + (pix0 + i * 4) * ldx, lds0 + slot * XRAW + i * 1024);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                                  // 32 pixel pairs, four per wave
             const int i = wv + 8 * k;
-            glds16(ysrc + (pix0 + i * 2) * a.ldq, lds0 + YOFF + slot * YRAW + i * 1024);
+            if (a.gmode == 2) {
+                const long g = gpix((int)pix0 + i * 2 + (l >> 5));
+                glds16(g >= 0 ? ych + (size_t)g * a.ldq : zsrc + (l & 31) * 4, lds0 + YOFF + slot * YRAW + i * 1024);
+            } else glds16(ysrc + (pix0 + i * 2) * a.ldq, lds0 + YOFF + slot * YRAW + i * 1024);
         }
     };
     constexpr int PER_STEP = 6;
@@ -478,5 +498,97 @@ extern "C" int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
         else hipLaunchKernelGGL(wgrad1x1_tr_reduce_kernel<2>, dim3(4 * nimax, 4, tile), dim3(256), 0, st, b);
     }
     MI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- round 6, exact-fp32 mode: the weight gradients of Downsample = Conv2d(C, C, 3, 2, 1) and Upsample = ConvTranspose2d(C, C, 4, 2, 1)
+//      (reference src/models/ddpm.py:70,79) as k x k GATHERED 1x1 problems of wgrad1x1_f32_kernel, up to eight taps per launch:
+//          dW[ky][kx][ci][co] += sum_m P[pix_p(m)][ci] * Q[pix_q(m)][co],   m over the small grid [N][DH][DW],
+//      the big tensor read at (2 y + ky - 1, 2 x + kx - 1) (gather_i: P is the big one, else Q).  Replaces the generic wgrad_kernel<0> for
+//      these four layers (0.87 ms of fp32 mode's 21.8 ms step at 0.40 of the fp32 matrix peak).
+namespace {
+bool s2f_ok(const MiWgradDesc* d) {
+    if (!d || d->mode != 0 || d->stride != 2 || d->pad != 1 || d->KH != d->KW || (d->KH != 3 && d->KH != 4)) return false;
+    if (d->I1 != d->Ci || d->Ci % 64 || d->Cj % 32 || d->Cj < 32 || d->ldp % 4 || d->ldq % 4) return false;
+    if (d->GH != 2 * d->DH || d->GW != 2 * d->DW || (d->DH & (d->DH - 1)) || (d->DW & (d->DW - 1))) return false;
+    return ((long)d->N * d->DH * d->DW) % 64 == 0;
+}
+MiWgradDesc s2f_tap_desc(const MiWgradDesc* d) {          // the dense 1x1 problem one tap is planned as
+    MiWgradDesc t = *d;
+    t.KH = t.KW = 1; t.pad = 0; t.stride = 1; t.gather_i = 1; t.GH = d->DH; t.GW = d->DW;
+    return t;
+}
+int s2f_groups(int ntap, int* first, int* count) {          // taps per launch: 9 -> 5 + 4, 16 -> 8 + 8
+    const int ng = (ntap + MAXP - 1) / MAXP;
+    int t0 = 0;
+    for (int g = 0; g < ng; ++g) { first[g] = t0; count[g] = (ntap - t0 + (ng - g) - 1) / (ng - g); t0 += count[g]; }
+    return ng;
+}
+size_t s2f_group_ws(const MiWgradDesc* d, int n) {
+    const MiWgradDesc t = s2f_tap_desc(d);
+    MiWgradDesc ds[MAXP]; int q32[MAXP]; long wgs[MAXP];
+    for (int i = 0; i < n; ++i) { ds[i] = t; q32[i] = 1; }
+    w1_shares(n, ds, q32, wgs);
+    size_t fl = 0;
+    for (int i = 0; i < n; ++i) { W1Args a{}; w1_plan(&t, a, wgs[i]); fl += w1_ws_floats(a); }
+    return fl;
+}
+}  // namespace
+extern "C" int mi_conv_s2_wgrad_f32_supported(const MiWgradDesc* d) { return s2f_ok(d) ? 1 : 0; }
+extern "C" size_t mi_conv_s2_wgrad_f32_workspace(const MiWgradDesc* d) {
+    if (!s2f_ok(d)) return 0;
+    int first[4], count[4];
+    const int ng = s2f_groups(d->KH * d->KW, first, count);
+    size_t fl = 0;
+    for (int g = 0; g < ng; ++g) { const size_t f = s2f_group_ws(d, count[g]); fl = f > fl ? f : fl; }
+    return fl * sizeof(float) + 256;
+}
+extern "C" int mi_conv_s2_wgrad_f32(const MiWgradDesc* d, const float* P, const float* Q, float* dW, void* workspace, size_t ws_bytes, void* stream) {
+    MI_REQUIRE(s2f_ok(d), "descriptor not supported (exact-fp32 mode, 3x3 or 4x4, stride 2, pad 1, one source, Ci % 64, Cj % 32, power-of-two small grid)");
+    MI_REQUIRE(P && Q && dW && ((((uintptr_t)P | (uintptr_t)Q) & 15) == 0), "null or misaligned operand");
+    hipStream_t st = (hipStream_t)stream;
+    static MiPerDevice once;
+    once.run([] { (void)hipFuncSetAttribute((const void*)wgrad1x1_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    const MiWgradDesc t = s2f_tap_desc(d);
+    int lgw = 0, lgh = 0;
+    while ((1 << lgw) < d->DW) ++lgw;
+    while ((1 << lgh) < d->DH) ++lgh;
+    int first[4], count[4];
+    const int ng = s2f_groups(d->KH * d->KW, first, count);
+    for (int g = 0; g < ng; ++g) {
+        const int n = count[g];
+        MiWgradDesc ds[MAXP]; int q32[MAXP]; long wgs[MAXP];
+        for (int i = 0; i < n; ++i) { ds[i] = t; q32[i] = 1; }
+        w1_shares(n, ds, q32, wgs);
+        W1Batch b;
+        b.n = n;
+        size_t off = 0, lds = 0;
+        int wg = 0, tile = 0, max_splits = 1;
+        for (int i = 0; i < n; ++i) {
+            const int tap = first[g] + i, ky = tap / d->KW, kx = tap % d->KW;
+            W1Args& a = b.p[i];
+            a = W1Args{};
+            w1_plan(&t, a, wgs[i]);
+            a.P = (const uint16_t*)P; a.P2 = (const uint16_t*)P; a.Q = Q;
+            a.dW = dW + (size_t)tap * d->Ci * d->Cj; a.dbias = nullptr; a.q32 = 1; a.f32 = 1;
+            a.ldp = d->ldp; a.ldp2 = d->ldp; a.ldq = d->ldq;
+            a.ws = (float*)workspace + off;
+            off += w1_ws_floats(a);
+            a.xcd_map = a.gx * a.gy > 1 && a.splits > 1;
+            a.wg0 = wg; wg += a.gx * a.gy * a.splits;
+            if (a.splits > max_splits) max_splits = a.splits;
+            a.tile0 = tile; if (a.splits > 1) tile += a.gx * a.gy;
+            a.gmode = d->gather_i ? 1 : 2; a.gdy = ky - d->pad; a.gdx = kx - d->pad; a.lgw = lgw; a.lghw = lgw + lgh; a.GH = d->GH; a.GW = d->GW;
+            lds = w1_lds(a) > lds ? w1_lds(a) : lds;
+        }
+        MI_REQUIRE(off == 0 || (workspace && ((uintptr_t)workspace & 15) == 0 && ws_bytes >= off * sizeof(float)),
+                   "workspace too small (mi_conv_s2_wgrad_f32_workspace)");
+        hipLaunchKernelGGL(wgrad1x1_f32_kernel, dim3((unsigned)wg), dim3(512), lds, st, b);
+        if (tile > 0) {
+            if (max_splits >= 32) hipLaunchKernelGGL(wgrad1x1_tr_reduce_kernel<8>, dim3(16, 4, tile), dim3(256), 0, st, b);
+            else hipLaunchKernelGGL(wgrad1x1_tr_reduce_kernel<2>, dim3(4, 4, tile), dim3(256), 0, st, b);
+        }
+        MI_LAUNCH_CHECK();
+    }
     return 0;
 }

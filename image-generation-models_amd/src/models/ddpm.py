@@ -788,6 +788,10 @@ class Unet(nn.Module):
             elif (stride == 2 and mode == K.MODE_BF16 and self.s2_wgrad_tr and
                   (dy16 := s2_push(dy, winp, pre, kh, ci, co, transposed_conv, (ih, iw), (oh, ow), bias)) is not None):
                 bias = None                                           # Downsample / Upsample: deferred, bias gradient rode along
+            elif (stride == 2 and mode == K.MODE_FP32 and x2 is None and pad == 1 and
+                  K.conv_s2_wgrad_f32(inp, dy, gv[pre + "weight"], k=kh, Ci=ci, Cj=co, gather_i=not transposed_conv,
+                                      grid_g=(oh, ow) if transposed_conv else (ih, iw), grid_d=(ih, iw) if transposed_conv else (oh, ow))):
+                pass                    # fp32 mode (round 6): Downsample / Upsample as gathered 1x1 problems of the exact-fp32 kernel (bias: column sum below)
             elif transposed_conv:   # dW[tap][ci][co] = sum over input pixels  x[j] * dy[gather(j, tap)]
                 K.conv_wgrad(inp, dy, gv[pre + "weight"], kh=kh, kw=kw, stride=stride, pad=pad, gather_i=False,
                              Ci=ci, Cj=co, grid_g=(oh, ow), grid_d=(ih, iw), mode=mode)

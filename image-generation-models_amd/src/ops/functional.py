@@ -791,6 +791,29 @@ def conv_wgrad(P, Q, dW, *, kh, kw, stride, pad, gather_i, Ci, Cj, grid_g, grid_
 
 
 @functools.lru_cache(maxsize=None)      # pure function of the shape: one FFI query per distinct layer, not per step
+def conv_s2_wgrad_f32(P, Q, dW, *, k, Ci, Cj, gather_i, grid_g, grid_d):
+    """Exact-fp32 mode: the weight gradient of Downsample (3x3 / stride 2, gather_i: P is the big tensor) or Upsample (ConvTranspose 4x4 /
+    stride 2: Q is) as k x k gathered problems of the fp32 1x1 weight-gradient kernel (mi_conv_s2_wgrad_f32).  dW [k][k][Ci][Cj] +=.
+    Returns True when the library took the layer, False when the caller has to use conv_wgrad."""
+    if P.dtype != torch.float32 or Q.dtype != torch.float32:
+        return False
+    _need_gpu(P)
+    N = P.shape[0]
+    d = MiWgradDesc(N=N, GH=grid_g[0], GW=grid_g[1], DH=grid_d[0], DW=grid_d[1], Ci=Ci, Cj=Cj, KH=k, KW=k, stride=2, pad=1,
+                    gather_i=int(gather_i), mode=MODE_FP32, I1=Ci, ldp=ld_of(P), ldp2=0, ldq=ld_of(Q))
+    if not _query("mi_conv_s2_wgrad_f32_supported", d):
+        return False
+    lib = load_library()
+    need = lib.mi_conv_s2_wgrad_f32_workspace(C.byref(d))
+    ws = _workspace(P.device, need)
+    e0 = _probe_open()
+    check(lib.mi_conv_s2_wgrad_f32(C.byref(d), _p(P), _p(Q), _p(dW), _p(ws), ws.numel() * 4, _stream()), "mi_conv_s2_wgrad_f32")
+    if e0 is not None:
+        _probe_close(e0, "wgrad1x1_f32_kernel[s2 taps]", 2.0 * N * grid_d[0] * grid_d[1] * Ci * Cj * k * k, f"N{N} {grid_d[0]}x{grid_d[1]} Ci{Ci} Cj{Cj} k{k}",
+                     N * (grid_g[0] * grid_g[1] * (Ci if gather_i else Cj) + grid_d[0] * grid_d[1] * (Cj if gather_i else Ci)) * 4.0)
+    return True
+
+
 def s2_wgrad_supported(N, k, Ci, Cj, transposed, big, small, mode):
     """Can the stride-2 LDS-DMA weight-gradient kernel take this Downsample (3x3 conv) / Upsample (4x4 transposed conv) layer
     (dense bf16 operands)?  big / small: the (H, W) of the 2x-resolution tensor and of the other one."""

@@ -67,6 +67,8 @@ SIGNATURES = {
     "mi_debug_wgrad1x1_tr_phase": [_I],
     "mi_conv_s2_wgrad_tr_supported": [C.POINTER(MiWgradDesc)],
     "mi_conv_s2_wgrad_tr_batch": [_I, C.POINTER(MiWgradDesc), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _Z, _P],
+    "mi_conv_s2_wgrad_f32_supported": [C.POINTER(MiWgradDesc)],
+    "mi_conv_s2_wgrad_f32": [C.POINTER(MiWgradDesc), _P, _P, _P, _P, _Z, _P],
     "mi_debug_wgrad_s2_tr_phase": [_I],
     "mi_debug_spin": [_I, _I, _P, _Z, _I, _P],
     "mi_debug_clock_probe": [_I, _I, _P, _P],
@@ -194,6 +196,7 @@ OTHER = {"mi_abi_version": ([], C.c_int), "mi_last_error": ([], C.c_char_p),
          "mi_conv3x3_wgrad_tr_batch_workspace": ([_I, C.POINTER(MiWgradDesc)], C.c_size_t),
          "mi_conv1x1_wgrad_tr_batch_workspace": ([_I, C.POINTER(MiWgradDesc), C.POINTER(_I)], C.c_size_t),
          "mi_conv_s2_wgrad_tr_batch_workspace": ([_I, C.POINTER(MiWgradDesc)], C.c_size_t),
+         "mi_conv_s2_wgrad_f32_workspace": ([C.POINTER(MiWgradDesc)], C.c_size_t),
          "mi_f32_to_bf16_colsum_workspace": ([_Z, _I], C.c_size_t),
          "mi_linattn_workspace": ([_I, _I, _I], C.c_size_t),
          "mi_chan_layernorm_bwd_part_rows": ([_I, _I], C.c_int),

@@ -373,6 +373,13 @@ size_t mi_conv_s2_wgrad_tr_batch_workspace(int n, const MiWgradDesc* descs);
 int mi_conv_s2_wgrad_tr_batch(int n, const MiWgradDesc* descs, const void* const* P, const void* const* Q, float* const* dW,
                               void* workspace, size_t ws_bytes, void* stream);
 int mi_debug_wgrad_s2_tr_phase(int phase);
+/* Exact-fp32 mode (d->mode = 0), round 6: the same two layers' weight gradients (Conv2d(C, C, 3, 2, 1) of Downsample, ConvTranspose2d(C, C, 4,
+ * 2, 1) of Upsample; reference src/models/ddpm.py:70,79 -- aten::convolution_backward (weight)) as k x k gathered problems of the exact-fp32
+ * 1x1 weight-gradient kernel (v_mfma_f32_32x32x2_f32 = an fp32 fmaf chain), up to eight taps per launch.  P fp32 [N][..][Ci], Q fp32
+ * [N][..][Cj], d->gather_i: P lies on the big grid (GH = 2 DH), else Q; dW [KH][KW][Ci][Cj] += ...; workspace from _workspace(). */
+int mi_conv_s2_wgrad_f32_supported(const MiWgradDesc* d);
+size_t mi_conv_s2_wgrad_f32_workspace(const MiWgradDesc* d);
+int mi_conv_s2_wgrad_f32(const MiWgradDesc* d, const float* P, const float* Q, float* dW, void* workspace, size_t ws_bytes, void* stream);
 /* measurement aid (tools/cu_hog.py): `blocks` workgroups of 256 threads that stay resident on `stream` for `usec` microseconds -- mode 0
  * an ALU spin, 1 a streaming copy over buf (2 x per_wg_floats floats per workgroup), 2 the same copy with a gradient all-reduce's duty
  * cycle (0.5 ms of every 5 ms) -- to see how a training step behaves while another stream's kernel shares the chip */

@@ -2002,3 +2002,39 @@ def test_gn_mish_apply_from_epilogue_sums(K, cfg, variant):
     if want16:
         assert rel_err(out[2].float(), ref[2].float()) < 8e-3
         assert torch.equal(out[2], out[0].bfloat16())
+
+
+def test_stride2_wgrad_exact_fp32_gathered_taps(K):
+    """mi_conv_s2_wgrad_f32 (round 6; fp32 mode, the mode that carries the 1e-4 bar): the weight gradients of Downsample (3x3 / stride 2)
+    and Upsample (ConvTranspose 4x4 / stride 2) as gathered 1x1 problems of the exact-fp32 kernel -- cfg-2 / cfg-3 layer shapes at a
+    small batch, a ragged small-side channel count, every image border -- against fp64 on the same fp32 operands, accumulating into a
+    non-zero dW; other geometries are refused."""
+    g = torch.Generator().manual_seed(59)
+    layers = [dict(kind="down", N=4, h=16, C=128), dict(kind="down", N=8, h=8, C=256), dict(kind="up", N=8, h=8, C=256),
+              dict(kind="up", N=4, h=16, C=128), dict(kind="down", N=2, h=32, C=64), dict(kind="up", N=2, h=32, C=64),
+              dict(kind="down", N=8, h=8, C=192, Co=96), dict(kind="up", N=8, h=8, C=64, Co=160), dict(kind="down", N=16, h=4, C=64)]
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)          # noqa: E731
+    for L in layers:
+        N, h, Ci, Co = L["N"], L["h"], L["C"], L.get("Co", L["C"])
+        if L["kind"] == "down":
+            x = torch.randn(N, Ci, 2 * h, 2 * h, generator=g); dy = torch.randn(N, Co, h, h, generator=g)
+            w = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+            F.conv2d(x.double(), w, None, stride=2, padding=1).backward(dy.double())
+            k, tr = 3, False
+        else:
+            x = torch.randn(N, Ci, h, h, generator=g); dy = torch.randn(N, Co, 2 * h, 2 * h, generator=g)
+            w = torch.zeros(Ci, Co, 4, 4, dtype=torch.float64, requires_grad=True)
+            F.conv_transpose2d(x.double(), w, None, stride=2, padding=1).backward(dy.double())
+            k, tr = 4, True
+        base = torch.randn(k * k * Ci * Co, generator=g).to(DEV)
+        dW = base.clone()
+        ok = K.conv_s2_wgrad_f32(nh(x), nh(dy), dW, k=k, Ci=Ci, Cj=Co, gather_i=not tr, grid_g=(2 * h, 2 * h), grid_d=(h, h))
+        assert ok, L
+        torch.cuda.synchronize()
+        got = w_from_storage((dW - base).view(k, k, Ci, Co), transposed=tr)
+        assert rel_err(got, w.grad) < 2e-6, (L, rel_err(got, w.grad))
+    # bf16 operands, odd grids and channel counts the kernel does not tile are refused (the caller keeps conv_wgrad)
+    z = lambda n, hh, c, dt=torch.float32: torch.zeros(n, hh, hh, c, device=DEV, dtype=dt)          # noqa: E731
+    assert not K.conv_s2_wgrad_f32(z(2, 16, 64, torch.bfloat16), z(2, 8, 64), torch.zeros(9 * 64 * 64, device=DEV), k=3, Ci=64, Cj=64, gather_i=True, grid_g=(16, 16), grid_d=(8, 8))
+    assert not K.conv_s2_wgrad_f32(z(2, 12, 64), z(2, 6, 64), torch.zeros(9 * 64 * 64, device=DEV), k=3, Ci=64, Cj=64, gather_i=True, grid_g=(12, 12), grid_d=(6, 6))
+    assert not K.conv_s2_wgrad_f32(z(2, 16, 32), z(2, 8, 64), torch.zeros(9 * 32 * 64, device=DEV), k=3, Ci=32, Cj=64, gather_i=True, grid_g=(16, 16), grid_d=(8, 8))
