@@ -453,7 +453,7 @@ extern "C" int mi_conv1x1_wgrad_tr_batch(int n, const MiWgradDesc* descs, const 
                                          const void* const* P2, const void* const* Q, float* const* dW, float* const* dbias,
                                          void* workspace, size_t ws_bytes, void* stream) {
     MI_REQUIRE(n >= 1 && n <= MAXP && descs && q_is_fp32 && P && Q && dW, "1..8 problems, non-null arrays");
-    W1Batch b;
+    W1Batch b{};                                          // (every field a kernel reads is defined: gmode = 0 means no gather)
     b.n = n;
     long wgs[MAXP];
     for (int i = 0; i < n; ++i) {
@@ -560,7 +560,7 @@ extern "C" int mi_conv_s2_wgrad_f32(const MiWgradDesc* d, const float* P, const 
         MiWgradDesc ds[MAXP]; int q32[MAXP]; long wgs[MAXP];
         for (int i = 0; i < n; ++i) { ds[i] = t; q32[i] = 1; }
         w1_shares(n, ds, q32, wgs);
-        W1Batch b;
+        W1Batch b{};                                          // (every field a kernel reads is defined: gmode = 0 means no gather)
         b.n = n;
         size_t off = 0, lds = 0;
         int wg = 0, tile = 0, max_splits = 1;
