@@ -1736,6 +1736,209 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Inference: channel LayerNorm applied while to_qkv's input is staged (PreNorm(LinearAttention / Attention), reference
+// src/models/ddpm.py:85-106,151: y = (x - mean) / (sqrt(var) + eps) * g + b over the channels of a pixel, then the bias-free 1x1 conv).  The
+// normalised tensor is never written: one workgroup per PXT-pixel tile reads the fp32 residual stream once (every lane its pixels' channel octets --
+// NPB pixel blocks x NCH 128-channel chunks x two halves, all in registers), forms the two-pass mean / variance per pixel (a pixel = the 8 lanes of a
+// 16-byte row of LDS positions), normalises, rounds to bf16 once and writes ITS slots of the [chunk][half][pixel][128 B] tile -- conv1x1_pw_kernel's
+// layout and swizzle; then walks the channel tiles and chunks as conv1x1_pw_kernel's NLOOP form does: the wave's 8 fragments of the next
+// (channel tile, chunk) unit are requested under the current unit's MFMAs, a channel tile leaves through a staging area behind the tile.
+// Training keeps chan_ln_fwd_kernel: to_qkv's weight gradient reads the normalised tensor.
+struct LnPw1Args {
+    const float* x; const uint16_t* w; const float* g; const float* b; const float* bias; uint16_t* y;
+    int M, K, Nc, ldx, ldy, gx, gy; float eps;
+};
+constexpr size_t lnpw1_lds(int pxt, int nch) { return (size_t)nch * pxt * 256 + (size_t)pxt * 256 + (size_t)nch * 1024; }
+template <int PXT, int NCH, bool G2 = false>
+__global__ __launch_bounds__(256, 2) void ln_conv1x1_pw_kernel(const LnPw1Args a) {
+    MI_PRIO_UP();
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    typedef __attribute__((address_space(3))) u32x2 lds_u32x2n;
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4n;
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4n;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds_raw;
+    constexpr int NBLK = PXT / 32;                   // 32-pixel MFMA blocks per wave
+    constexpr int NPB = PXT / 32;                    // 8-pixel blocks a wave stages (block wv + 4 j)
+    constexpr int XH = PXT * 128, XB = 2 * XH;       // one 64-channel half / one 128-channel chunk of the tile
+    constexpr int STG = NCH * XB;                    // the channel tile's way out: PXT x 256 bytes
+    constexpr int GB = STG + PXT * 256;              // g | b: 2 x K floats
+    const int t = threadIdx.x, l = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    // G2: a workgroup per (pixel tile, channel tile) -- every channel tile normalises the pixel tile again (the small levels: their launches are
+    // chains of latencies, not bytes); the channel tiles of a pixel tile are adjacent ids on one XCD: the tile comes from HBM once
+    int bx = blockIdx.x, jt0 = 0, jt1 = a.gy;
+    if constexpr (G2) {
+        if (a.gx % 8 == 0) { const int id = blockIdx.x, xcd = id & 7, slot = id >> 3; bx = xcd * (a.gx >> 3) + slot / a.gy; jt0 = slot % a.gy; }
+        else { bx = blockIdx.x / a.gy; jt0 = blockIdx.x % a.gy; }
+        jt1 = jt0 + 1;
+    }
+    const int m0 = bx * PXT;
+    const int NB = a.Nc >> 5, KQ = a.K / 16;
+
+    // ---- the tile: raw values -> registers
+    const int cidx = (l & 7) ^ ((4 * wv + (l >> 4)) & 7);          // the channel octet of a half that belongs in this lane's slot (the same for every block)
+    f32x4 XR[NPB][NCH][2][2];
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+        const float* px = a.x + (size_t)(m0 + 8 * (wv + 4 * j) + (l >> 3)) * a.ldx + cidx * 8;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                XR[j][ch][h][0] = *reinterpret_cast<const f32x4*>(px + ch * 128 + h * 64);
+                XR[j][ch][h][1] = *reinterpret_cast<const f32x4*>(px + ch * 128 + h * 64 + 4);
+            }
+    }
+    // the affine parameters -> LDS (K <= 512: one float4 per thread and vector is enough for two of them)
+    for (int q = t; q < a.K / 4; q += 256) {
+        *(lds_f32x4n*)(uintptr_t)(lds0 + GB + q * 16) = *reinterpret_cast<const f32x4*>(a.g + 4 * q);
+        *(lds_f32x4n*)(uintptr_t)(lds0 + GB + a.K * 4 + q * 16) = *reinterpret_cast<const f32x4*>(a.b + 4 * q);
+    }
+    // the first unit's fragments
+    const uint32_t wl16 = l * 16;
+    u32x4 WB[2][8];
+    auto load_wu = [&](int jt, int ch, auto setc) {
+        constexpr int set = decltype(setc)::value;
+        const int nbj = min(4 * jt + wv, NB - 1);
+        const uint64_t q = (uint64_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(a.w) + ((size_t)nbj * KQ + 8 * ch) * 1024);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
+        const uint64_t wj = ((uint64_t)hi << 32) | lo;
+        static_for<0, 4>([&](auto uc) { gload16s<decltype(uc)::value * 1024>(WB[set][decltype(uc)::value], wj, wl16); });
+        static_for<0, 4>([&](auto uc) { gload16s<decltype(uc)::value * 1024>(WB[set][4 + decltype(uc)::value], wj, wl16 + 4096); });
+    };
+    load_wu(jt0, 0, std::integral_constant<int, 0>{});
+    __syncthreads();                                  // g | b are in LDS (the waits of the plain loads above are hipcc's)
+
+    const float invc = 1.0f / (float)a.K;
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) s += (XR[j][ch][h][v].x + XR[j][ch][h][v].y) + (XR[j][ch][h][v].z + XR[j][ch][h][v].w);
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        const float mean = s * invc;
+        float s2 = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const f32x4 d = XR[j][ch][h][v] - mean;
+                    s2 += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                }
+        s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
+        const float inv = 1.0f / (sqrtf(s2 * invc) + a.eps);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t gq = lds0 + GB + (ch * 128 + h * 64 + cidx * 8) * 4;
+                const f32x4 g0 = *(lds_f32x4n*)(uintptr_t)gq, g1 = *(lds_f32x4n*)(uintptr_t)(gq + 16);
+                const f32x4 b0 = *(lds_f32x4n*)(uintptr_t)(gq + a.K * 4), b1 = *(lds_f32x4n*)(uintptr_t)(gq + a.K * 4 + 16);
+                const f32x4 o0 = (XR[j][ch][h][0] - mean) * inv * g0 + b0, o1 = (XR[j][ch][h][1] - mean) * inv * g1 + b1;
+                *(lds_u32x4n*)(uintptr_t)(lds0 + ch * XB + h * XH + (wv + 4 * j) * 1024 + l * 16) =
+                    u32x4{pack_bf16(o0.x, o0.y), pack_bf16(o0.z, o0.w), pack_bf16(o1.x, o1.y), pack_bf16(o1.z, o1.w)};
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<0, 8>([&](auto uc) { landed16(WB[0][decltype(uc)::value]); });
+    __syncthreads();                                  // the tile is every wave's
+
+    uint32_t xa[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+        const int px = i * 32 + (l & 31);
+        xa[i] = lds0 + px * 128 + (((l >> 5) * 16) ^ (((px >> 1) & 7) * 16));
+    }
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // unit (jt, ch): the fragments in set (JP * NCH + ch) & 1 (JP = jt & 1), the next unit's requested into the other set
+    auto unit = [&](int jt, auto chc, auto setc) {
+        constexpr int ch = decltype(chc)::value, set = decltype(setc)::value;
+        const bool last_unit = ch == NCH - 1 && jt + 1 >= jt1;
+        if (!last_unit) {
+            if constexpr (ch + 1 < NCH) load_wu(jt, ch + 1, std::integral_constant<int, set ^ 1>{});
+            else load_wu(jt + 1, 0, std::integral_constant<int, set ^ 1>{});
+        }
+        bf16x8 XC[2][NBLK];
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) XC[0][i] = lds_b128p(xa[i] + ch * XB);
+        static_for<0, 8>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if constexpr (u + 1 < 8) {
+                constexpr int un = u + 1;
+#pragma unroll
+                for (int i = 0; i < NBLK; ++i) XC[un & 1][i] = lds_b128p((xa[i] ^ ((un & 3) * 32)) + (un >> 2) * XH + ch * XB);
+            }
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, WB[set][u]), XC[u & 1][i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (ch == NCH - 1) {
+            const int n0 = jt * 128;
+            if (n0 + 32 * wv < a.Nc) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int ck = 8 * wv + 2 * rq + (l >> 5);
+                    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias) bq = *reinterpret_cast<const f32x4*>(a.bias + n0 + 4 * ck);
+#pragma unroll
+                    for (int i = 0; i < NBLK; ++i) {
+                        const int p = i * 32 + (l & 31);
+                        *(lds_u32x2n*)(uintptr_t)(lds0 + STG + p * 256 + ((ck ^ ((p & 15) << 1)) << 3)) =
+                            u32x2{pack_bf16(acc[i][4 * rq] + bq.x, acc[i][4 * rq + 1] + bq.y), pack_bf16(acc[i][4 * rq + 2] + bq.z, acc[i][4 * rq + 3] + bq.w)};
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        }
+        // the next unit's fragments are waited for before this channel tile's stores are issued (vmcnt counts stores too)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_for<0, 8>([&](auto uc) { landed16(WB[set ^ 1][decltype(uc)::value]); });
+        if constexpr (ch == NCH - 1) {
+            const int n0 = jt * 128;
+            __syncthreads();
+            {
+                const int j = t & 15, col = n0 + 8 * j;
+                if (col < a.Nc) {
+#pragma unroll
+                    for (int it = 0; it < PXT / 16; ++it) {
+                        const int p = it * 16 + (t >> 4);
+                        const u32x4 o = *(lds_u32x4n*)(uintptr_t)(lds0 + STG + p * 256 + (((2 * j) ^ ((p & 15) << 1)) << 3));
+                        *reinterpret_cast<u32x4*>(a.y + ((size_t)m0 + p) * a.ldy + col) = o;
+                    }
+                }
+            }
+            __syncthreads();                                   // the staging area is free again
+        }
+    };
+    auto cotile = [&](int jt, auto jpc) {
+        constexpr int JP = decltype(jpc)::value;
+        static_for<0, NCH>([&](auto chc) {
+            constexpr int ch = decltype(chc)::value;
+            unit(jt, chc, std::integral_constant<int, (JP * NCH + ch) & 1>{});
+        });
+    };
+    for (int jt = jt0; jt < jt1; jt += 2) {
+        cotile(jt, std::integral_constant<int, 0>{});
+        if (jt + 1 < jt1) cotile(jt + 1, std::integral_constant<int, 1>{});
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Tap-gather GEMM on the same machinery (round 4): the stride-2 Downsample conv, the ConvTranspose2d(4, 2, 1) Upsample and their data
 // gradients (reference src/models/ddpm.py:67-82), i.e. every conv that is "a few taps, each a strided view of the input":
 //     Y[out(m)][co] (+)= bias[co] + sum_{taps t of the class} sum_ci X[n, oy * si + dy_t, ox * si + dx_t][ci] * W[wt_t][co][ci]
@@ -2352,6 +2555,40 @@ extern "C" int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* x2,
     else MI_PW1_PICK(false, false);
 #undef MI_PW1_PICK
 #undef MI_PW1_GO
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- inference: channel LayerNorm + the bias-free 1x1 conv behind it in one launch (see ln_conv1x1_pw_kernel).  x: the fp32 residual stream
+//      [M][ldx], g / b: the LayerNorm's affine parameters [K], w_frag_bf16: the conv's slice of wfq, y: bf16 [M][ldy]
+static bool lnpw1_ok(const MiConvDesc* d) {
+    if (!d || d->KH != 1 || d->KW != 1 || d->pad != 0 || d->stride != 1 || d->mode != 1 || d->IH != d->OH || d->IW != d->OW) return false;
+    if ((d->K != 128 && d->K != 256 && d->K != 512) || d->K1 != d->K || d->Nc % 64 || d->ldx % 4 || d->ldy % 8 || d->accumulate) return false;
+    return ((long)d->N * d->OH * d->OW) % 128 == 0;
+}
+extern "C" int mi_ln_conv1x1_pw_supported(const MiConvDesc* d) { return lnpw1_ok(d) ? 1 : 0; }
+extern "C" int mi_ln_conv1x1_pw(const MiConvDesc* d, const float* x, const float* ln_g, const float* ln_b, float eps, const void* w_frag_bf16,
+                                const float* bias, void* y_bf16, void* stream) {
+    MI_REQUIRE(d && x && ln_g && ln_b && w_frag_bf16 && y_bf16, "null argument");
+    MI_REQUIRE(lnpw1_ok(d), "descriptor not supported (1x1, bf16 mode, one source, K = 128 / 256 / 512, Nc % 64 == 0, N*H*W % 128 == 0, ldx % 4, ldy % 8)");
+    MI_REQUIRE((((uintptr_t)x | (uintptr_t)ln_g | (uintptr_t)ln_b | (uintptr_t)w_frag_bf16 | (uintptr_t)y_bf16) & 15) == 0, "operands must be 16-byte aligned");
+    LnPw1Args a{};
+    a.x = x; a.w = (const uint16_t*)w_frag_bf16; a.g = ln_g; a.b = ln_b; a.bias = bias; a.y = (uint16_t*)y_bf16;
+    a.M = d->N * d->OH * d->OW; a.K = d->K; a.Nc = d->Nc; a.ldx = d->ldx; a.ldy = d->ldy; a.gy = (d->Nc + 127) / 128; a.eps = eps;
+    hipStream_t st = (hipStream_t)stream;
+#define MI_LNPW1_GO(PX, NC, G) do { \
+        static MiPerDevice once_; \
+        once_.run([] { (void)hipFuncSetAttribute((const void*)ln_conv1x1_pw_kernel<PX, NC, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lnpw1_lds(PX, NC)); }); \
+        a.gx = a.M / PX; \
+        hipLaunchKernelGGL((ln_conv1x1_pw_kernel<PX, NC, G>), dim3((unsigned)(a.gx * (G ? a.gy : 1))), dim3(256), lnpw1_lds(PX, NC), st, a); } while (0)
+    // fewer than two workgroups per CU: one workgroup per (pixel tile, channel tile) -- sampler, B = 64, in the replayed step: 16x16 x 256 ch 12.0 -> 9.8 us,
+    // 8x8 x 512 ch 13.5 -> 9.3 us; the 32x32 level (512 tiles of 128 pixels) stays on the channel-tile loop (19.9 us; 23.6 as a 2-D grid)
+#define MI_LNPW1_PICK(PX, NC) do { if (a.M / PX < 512) MI_LNPW1_GO(PX, NC, true); else MI_LNPW1_GO(PX, NC, false); } while (0)
+    if (d->K == 128) { if (a.M / 128 >= 512) MI_LNPW1_GO(128, 1, false); else MI_LNPW1_PICK(64, 1); }
+    else if (d->K == 256) MI_LNPW1_PICK(64, 2);
+    else MI_LNPW1_PICK(64, 4);
+#undef MI_LNPW1_PICK
+#undef MI_LNPW1_GO
     MI_LAUNCH_CHECK();
     return 0;
 }

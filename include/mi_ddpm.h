@@ -183,6 +183,11 @@ int mi_conv3x3_pw_f32(const MiConvDesc* d, const float* x, const float* x2, cons
 int mi_conv1x1_pw_x32_supported(const MiConvDesc* d);     /* ... reading fp32 x / x2 (strides in floats, % 4): the fp32 stream gradient, inference */
 int mi_conv1x1_pw_x32(const MiConvDesc* d, const float* x, const float* x2, const void* w_frag_bf16, const float* bias,
                       const float* residual, void* y, int out_bf16, void* stream);
+/* inference: channel LayerNorm (reference src/models/ddpm.py:85-95) + the bias-free 1x1 conv behind it (to_qkv, :151) in one launch -- the
+   normalised tensor is never written.  x fp32 [M][ldx], ln_g / ln_b [K], K = 128 / 256 / 512, y bf16 [M][ldy] */
+int mi_ln_conv1x1_pw_supported(const MiConvDesc* d);
+int mi_ln_conv1x1_pw(const MiConvDesc* d, const float* x, const float* ln_g, const float* ln_b, float eps, const void* w_frag_bf16,
+                     const float* bias, void* y_bf16, void* stream);
 int mi_conv1x1_pw_f32_supported(const MiConvDesc* d);     /* the 1x1 convs in exact-fp32 mode: K % 64 == 0, K1 % 64 == 0, Nc % 64 == 0 */
 int mi_conv1x1_pw_f32(const MiConvDesc* d, const float* x, const float* x2, const float* w_frag_f32, const float* bias,
                       const float* residual, float* y, void* stream);

@@ -1055,6 +1055,39 @@ def test_conv1x1_pw_fp32_input(K, cfg, out16, pw_always):
     assert torch.equal(y32, y16)
 
 
+@pytest.mark.parametrize("N,H,Ci,Co,bias", [(64, 32, 128, 384, False), (32, 32, 128, 384, False), (8, 32, 128, 384, False), (64, 16, 256, 384, False),
+                                            (128, 16, 256, 384, True), (64, 8, 512, 384, True), (512, 8, 512, 384, False), (2, 8, 512, 320, False),
+                                            (8, 16, 256, 128, True), (2, 8, 128, 64, False)])
+def test_layernorm_conv1x1_fused(K, N, H, Ci, Co, bias, pw_always):
+    """mi_ln_conv1x1_pw (inference): PreNorm's channel LayerNorm (reference ddpm.py:85-95: eps added to the std) applied while to_qkv's
+    input is staged -- every tile form (128 pixels x one chunk, 64 pixels x 1 / 2 / 4 chunks; channel-tile loop from 512 pixel tiles up, a
+    workgroup per channel tile below), ragged last channel tile, bias.  Against
+    fp64 on the operands the two-launch path rounds (bf16 LayerNorm output, bf16 weights), and against that path itself: the two differ only
+    where the LayerNorm's summation order moves a value across a bf16 rounding boundary."""
+    g = torch.Generator().manual_seed(211 + Ci + H)
+    x = (torch.randn(N, H, H, Ci, generator=g) * 1.7 - 0.4).to(DEV)
+    gg = (torch.randn(Ci, generator=g) * 0.3 + 1).to(DEV); bb = (torch.randn(Ci, generator=g) * 0.2).to(DEV)
+    w = torch.randn(Co, Ci, 1, 1, generator=g) / math.sqrt(Ci)
+    b = torch.randn(Co, generator=g).to(DEV) if bias else None
+    flat, wd, wf, offs, wdq, wfq = _pack(K, [conv_w_storage(w.double())], frag=True)
+    assert K.ln_conv1x1_supported(N, H, H, Ci, Co)
+    y = K.ln_conv1x1(x, gg, bb, wfq, Nc=Co, bias=b)
+    ln = K.chan_layernorm_fwd(x, gg, bb, out_dtype=torch.bfloat16)
+    y2 = K.conv3x3_bf16w(ln, wf, K=Ci, Nc=Co, flip=False, ksize=1, out_dtype=torch.bfloat16, wq=wfq, bias=b)
+    torch.cuda.synchronize()
+    assert y.dtype == torch.bfloat16 and y.shape == (N, H, H, Co)
+    xd = x.double().cpu()
+    std = xd.var(dim=3, unbiased=False, keepdim=True).sqrt()
+    lnd = (xd - xd.mean(3, keepdim=True)) / (std + 1e-5) * gg.double().cpu() + bb.double().cpu()
+    assert rel_err(ln.float().cpu(), lnd) < 4e-3
+    ref = torch.einsum("nhwc,oc->nhwo", ln.double().cpu(), w[:, :, 0, 0].bfloat16().double()) + (b.double().cpu() if bias else 0.0)
+    e_fused, e_two = rel_err(y.float().cpu(), ref), rel_err(y2.float().cpu(), ref)
+    assert e_two < 6e-3 and e_fused < 6e-3, (e_fused, e_two)
+    # the two paths against each other: a handful of bf16 ulps where the LayerNorm output crossed a rounding boundary
+    diff = (y.float() - y2.float()).abs()
+    assert float(diff.max()) <= 0.05 * float(y2.float().abs().max()) and float((diff > 0).float().mean()) < 0.2, (float(diff.max()), float((diff > 0).float().mean()))
+
+
 def test_pack_weights_fragment_order(K):
     """The MFMA-fragment-order copies mi_conv3x3_pw streams (include/mi_ddpm.h): wfq[tap][co/32][ci/16][lane][8] and
     wdq[tap][ci/32][co/16][lane][8] for the 3x3, 1x1 and (round 4: the tap-gather kernel's Upsample) 4x4 layers with 64-multiples on

@@ -491,7 +491,11 @@ def test_fused_eval_path_matches_two_pass(golden_dir, monkeypatch):
         K.PROBE = []
         y4 = net(xn, t)                           # the default: fused where the private-weight-stream kernel takes block2's conv
         fused_default = [q[0] for q in K.PROBE if q[0].startswith("conv_pw_kernel") and (", 3, 0, 128>" in q[0] or ", 3, 0, 64>" in q[0])]
+        ln_fused = [q[0] for q in K.PROBE if q[0].startswith("ln_conv1x1_pw_kernel")]
         K.PROBE = None
+        net.fuse_ln_qkv = False                   # PreNorm's LayerNorm as its own launch (what training runs) instead of inside to_qkv's staging
+        y5 = net(xn, t)
+        net.fuse_ln_qkv = True
         net.fuse_gn_conv = 1
         y1 = net(xn, t)
         net.fuse_gn_conv = 2                      # ... with the GroupNorm statistics from conv1's epilogue instead of a pass over c1
@@ -511,6 +515,12 @@ def test_fused_eval_path_matches_two_pass(golden_dir, monkeypatch):
     e42, e4 = rel_err(y4, y2), rel_err(y4[:2], _t(g["eps_hat"]))
     record("cfg2_default_fused_eval_bf16", default_vs_two_pass_rel_l2=e42, default_vs_reference_rel_l2=e4, fused_launches=len(fused_default))
     assert e42 < 2e-2 and e4 < 2e-2
+    # all six attention blocks took the LayerNorm + to_qkv kernel (mi_ln_conv1x1_pw); against the two-launch form: bf16 rounding flips only
+    assert len(ln_fused) == 6, ln_fused
+    e45, e5 = rel_err(y4, y5), rel_err(y5[:2], _t(g["eps_hat"]))
+    record("cfg2_layernorm_in_to_qkv_bf16", fused_vs_two_launch_rel_l2=e45, two_launch_vs_reference_rel_l2=e5,
+           bounds={"fused_vs_two_launch_rel_l2": 9.0e-3})                  # measured 4.8e-3
+    assert e45 < 9.0e-3 and e5 < 2e-2
 
 
 def test_graph_sampler_matches_eager():
