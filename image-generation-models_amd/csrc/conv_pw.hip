@@ -103,6 +103,10 @@ struct PwArgs {
     const float* sums; const float* gamma; const float* beta; const float* temb;
     int ldt, cpg, hw, ng; float eps;
     double icnt;         // VAR 3: 1 / (MI_GSUM_SCALE * hw * cpg)
+    // split-K (gridDim.z = ksplit > 1; launches that would leave CUs without a workgroup): slice s = ksplit - 1 - blockIdx.z contracts chunks
+    // [s, s + 1) * nchunks / ksplit.  Slices 1 .. ksplit - 1 are dispatched FIRST, leave their fp32 accumulators in sk_part (register order, per wave)
+    // and raise the wave's flag; slice 0 (dispatched last: whatever it waits for is resident or done) adds them and runs the epilogue.
+    int ksplit; float* sk_part; int* sk_flag;
 };
 
 // PT = output pixels per workgroup: 128 (four 32-pixel MFMA blocks per wave) or, for the layers whose 128-pixel tiles would leave
@@ -247,7 +251,8 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     const int m0 = bx * PT, n0 = by * 128;
     const int TH2 = a.TH + 2;
     const int lw = 31 - __builtin_clz(a.W);                   // W (and TH) are powers of two
-    const int nchunks = a.K / PCK;
+    const int slice = a.ksplit > 1 ? a.ksplit - 1 - (int)blockIdx.z : 0;
+    const int nchunks = a.K / PCK / a.ksplit, kbase = slice * nchunks;      // this workgroup's share of the contraction
     const int NB = a.Nc >> 5, KQ = a.K / (2 * EPP);              // fragments per (tap, 32-channel block): one per step
     const bool live = n0 + 32 * wv < a.Nc;                    // a ragged last channel tile: the wave computes a copy of the last block
     const int nb = min((n0 >> 5) + wv, NB - 1);
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     // handful of L2 channels -- and the per-chunk time stayed at ~6 000 cycles whatever was done about issue order, waits or staging.
     // (The sum of a pixel's products is formed in a different order per tile: deterministic, tile by tile.)
     const int rot = MI_PW_ROT ? bx - pw_fastdiv(bx, a.nch_magic) * nchunks : 0;
-    auto cof = [&](int ch) -> int { const int c = min(ch, nchunks - 1) + rot; return c >= nchunks ? c - nchunks : c; };
+    auto cof = [&](int ch) -> int { const int c = min(ch, nchunks - 1) + rot; return kbase + (c >= nchunks ? c - nchunks : c); };
 
     // ---- weight stream of this wave: fragment (tap, nb, kq) = 1 KB at ((tap * NB + nb) * KQ + kq) * 1024 bytes.  The fragments are
     //      wave-private, so they never touch LDS: each lane loads ITS 16 bytes of a fragment straight into the registers the MFMA
@@ -1155,6 +1160,49 @@ __global__ __launch_bounds__(256, PT == 256 ? 1 : 2) void conv_pw_kernel(const P
     MI_PW_STAMP(4, 0);                                       // slot 0: the last point's time; new stamp = loop end
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped re-fetches must not outlive the workgroup's LDS ...
     static_for<0, 9>([&](auto tc) { landed16(WB[0][decltype(tc)::value]); landed16(WB[1][decltype(tc)::value]); });   // ... nor their registers
+    if (a.ksplit > 1) {
+        // one exchange per WAVE: wave w of slice s > 0 writes its accumulators (register quad q of block i = 1 KB: 16 bytes per lane) and raises
+        // flag [s - 1][tile][w]; wave w of slice 0 waits for it, adds, and lowers it for the next launch.  The two workgroups may sit on different XCDs,
+        // whose L2s do not see each other's lines: every access of the exchange carries sc1 (agent-coherent: written through / read past the L2), so
+        // that no cache-wide write-back or invalidate is needed -- an agent-scope fence per wave (buffer_wbl2 / buffer_inv sc1) threw the weight
+        // lines of every workgroup of the XCD out of its L2: 8x8 x 512 -> 512 at B = 64 took 34 us split against 23 us unsplit.
+        const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
+        if (!a.sk_flag) { if (slice > 0) return; }
+        else if (slice > 0) {
+            if (live) {
+                float* part = a.sk_part + ((size_t)(slice - 1) * ntiles + tile) * (PT * 128) + (size_t)wv * (PT * 32) + l * 4;
+#pragma unroll
+                for (int i = 0; i < BH; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(part + (i * 4 + q) * 256), "v"(v) : "memory");
+                    }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (l == 0) __hip_atomic_store(a.sk_flag + ((size_t)(slice - 1) * ntiles + tile) * 4 + wv, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        if (live && a.sk_flag) {
+            for (int sl = 1; sl < a.ksplit; ++sl) {
+                int* flag = a.sk_flag + ((size_t)(sl - 1) * ntiles + tile) * 4 + wv;
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) __builtin_amdgcn_s_sleep(4);
+                const float* part = a.sk_part + ((size_t)(sl - 1) * ntiles + tile) * (PT * 128) + (size_t)wv * (PT * 32) + l * 4;
+                u32x4 pv[BH * 4];
+#pragma unroll
+                for (int k = 0; k < BH * 4; ++k) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(pv[k]) : "v"(part + k * 256) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < BH * 4; ++k) {
+                    landed16(pv[k]);
+                    const int i = k >> 2, q = k & 3;
+                    acc[i][4 * q] += __uint_as_float(pv[k].x); acc[i][4 * q + 1] += __uint_as_float(pv[k].y);
+                    acc[i][4 * q + 2] += __uint_as_float(pv[k].z); acc[i][4 * q + 3] += __uint_as_float(pv[k].w);
+                }
+                if (l == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     if constexpr ((ABL & 4) != 0) {
         float v = 0.f;
 #pragma unroll
@@ -1382,9 +1430,49 @@ bool pw_ok(const MiConvDesc* d, int pt, int* TH, int* TI, bool in32 = false, boo
 int g_pw_force_tile = 0;                 // tests: 0 = the rule below, 64 / 128 / 256 = that tile (or unsupported)
 int g_pw_auto256 = 0, g_pw_min256 = 256;   // (measured slower than two 128-pixel workgroups per CU on every cfg-2 shape: off)  // the automatic pick takes 256-pixel tiles when they give at least g_pw_min256 workgroups
 constexpr bool pw_fpipe(bool in32) { return (MI_PW_PIPE != 0) && (((MI_PW_FPIPE) >> (in32 ? 1 : 0)) & 1) != 0; }   // conv_pw_kernel's FPIPE
-int pw_pick_tile(const MiConvDesc* d, int var, int* TH, int* TI, bool in32 = false, bool f32 = false) {
+// split-K workspace of conv_pw_kernel, per device: [flags: 64 KB of ints, zero when no launch is in flight][fp32 partial tiles].  The caller owns the
+// memory (zeroed once, alive as long as any captured graph may replay); launches that use it must be ordered against each other (one stream).
+std::atomic<void*> g_pw_sk_ws[64];
+std::atomic<size_t> g_pw_sk_bytes[64];
+int g_pw_sk_mode = 1;                    // 0 off, 1 the rule below, 2 / 4: that split wherever the geometry allows (tests)
+constexpr size_t PW_SK_FLAG_BYTES = 64 * 1024;
+// Split-K: launches that leave CUs without a workgroup (the sampler at B = 64, cfg 3 at B = 32: the 16x16 / 8x8 levels).  Their 64-pixel tiles are
+// bound by the weight bytes a CU gets from L2 (two MFMAs per fragment); 128-pixel tiles whose contraction is cut in 2 or 4 move half of those bytes
+// for the same number of workgroups, and the fp32 partial tiles cross L2 once.  -> the split (1: none) and the tile it runs on
+int pw_split(const MiConvDesc* d, int var, bool in32, int* pt, int* TH, int* TI) {
+    if (!g_pw_sk_mode) return 1;
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!g_pw_sk_ws[dev_ & 63].load(std::memory_order_acquire)) return 1;
+    int cand = g_pw_force_tile;
+    if (cand == 256) return 1;
+    if (!cand) cand = (pw_ok(d, 128, TH, TI, in32) && (var < 2 || *TI == 1)) ? 128 : 64;
+    if (!pw_ok(d, cand, TH, TI, in32) || (var >= 2 && *TI != 1)) return 1;
+    const long tiles = ((long)d->N * d->OH * d->OW / cand) * ((d->Nc + 127) / 128);
+    const int nch = d->K / 64;
+    // the rule (tools/bench_splitk.py, B = 64 / 32, microseconds per launch): a split pays where the contraction is long and the tiles are few --
+    // 8x8 x 1024 -> 512: 45.6 -> 38.1 (two slices of 128 tiles), 39.1 -> 26.8 (four slices of 64 tiles).  8x8 x 512 -> 512: 23.4 -> 22.6 at 128
+    // tiles, 17.0 -> 18.2 at 64; every 16x16 layer loses (256 -> 256: 18.4 -> 22.1): the exchange costs ~4 us and without it (wrong results,
+    // -DMI_PW_SK_ABL) the 512 -> 512 layer would only reach 18.7 -- those launches are not short of workgroups, they are short of work per weight byte.
+    int ks = 1;
+    if (g_pw_sk_mode >= 2) ks = g_pw_sk_mode;
+    else if (tiles < 200 && nch >= 16) ks = tiles * 2 >= 256 ? 2 : 4;
+    while (ks > 1 && (nch % ks || nch / ks < 2)) ks >>= 1;
+    if (ks <= 1) return 1;
+    const size_t need = PW_SK_FLAG_BYTES + (size_t)(ks - 1) * tiles * cand * 128 * 4;
+    if ((size_t)(ks - 1) * tiles * 4 * sizeof(int) > PW_SK_FLAG_BYTES || need > g_pw_sk_bytes[dev_ & 63].load(std::memory_order_acquire)) return 1;
+    *pt = cand;
+    return ks;
+}
+int pw_pick_tile(const MiConvDesc* d, int var, int* TH, int* TI, bool in32 = false, bool f32 = false, int* ksplit = nullptr) {
+    if (ksplit) *ksplit = 1;
     if (f32 && var != 0) return 0;
     if (var >= 2 && pw_fpipe(in32) && d->K > 1024) return 0;   // the coefficient table of the pinned fused loop: 12 K bytes of LDS
+    if (!f32 && ksplit) {
+        int pts = 0;
+        const int ks = pw_split(d, var, in32, &pts, TH, TI);
+        if (ks > 1) { *ksplit = ks; return pts; }
+    }
     if (g_pw_force_tile == 64) return pw_ok(d, 64, TH, TI, in32, f32) ? 64 : 0;
     if (g_pw_force_tile == 128) return pw_ok(d, 128, TH, TI, in32, f32) ? 128 : 0;
     if (g_pw_force_tile == 256) return (var < 2 && !in32 && !f32 && pw_ok(d, 256, TH, TI)) ? 256 : 0;
@@ -2159,8 +2247,17 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
                      const PwGn* gn = nullptr, bool in32 = false, bool f32 = false) {
     PwArgs a{};
     if (!d || !x || !w_frag_bf16 || !y) return mi_set_error(-1, "%s: null argument", who);
-    const int pt = pw_pick_tile(d, var, &a.TH, &a.TI, in32, f32);
+    const int pt = pw_pick_tile(d, var, &a.TH, &a.TI, in32, f32, &a.ksplit);
     if (!pt) return mi_set_error(-1, "%s: descriptor not supported by the private-weight-stream conv kernel", who);
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (a.ksplit > 1) {
+        uint8_t* ws = reinterpret_cast<uint8_t*>(g_pw_sk_ws[dev_ & 63].load(std::memory_order_acquire));
+        a.sk_flag = reinterpret_cast<int*>(ws); a.sk_part = reinterpret_cast<float*>(ws + PW_SK_FLAG_BYTES);
+#ifdef MI_PW_SK_ABL
+        a.sk_flag = nullptr;                     // profiling build: no exchange (wrong results)
+#endif
+    }
     if (d->K1 != d->K && !x2) return mi_set_error(-1, "%s: two-source split without x2", who);
     if ((((uintptr_t)x | (uintptr_t)(x2 ? x2 : x) | (uintptr_t)w_frag_bf16) & 15) != 0) return mi_set_error(-1, "%s: operands must be 16-byte aligned", who);
     if (d->ldy % 8 || (residual && d->ldr % 4)) return mi_set_error(-1, "%s: output pixel stride must be a multiple of 8, the residual's of 4", who);
@@ -2186,8 +2283,6 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
     a.xmap = a.TI == 1 && a.tiles_per_img > 1 && a.N % 8 == 0;
     // (the zero page's address is per DEVICE and a failed lookup is not remembered)
     static std::atomic<const void*> zero_pages[64];
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
     const void* zero_page = zero_pages[dev_ & 63].load(std::memory_order_acquire);
     if (!zero_page) {
         void* p_ = nullptr;
@@ -2195,12 +2290,13 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
         zero_pages[dev_ & 63].store(p_, std::memory_order_release);
         zero_page = p_;
     }
-    a.zero = zero_page; a.tpi_magic = pw_magic(a.tiles_per_img); a.nch_magic = pw_magic(d->K / (f32 ? 32 : 64));
+    a.zero = zero_page; a.tpi_magic = pw_magic(a.tiles_per_img); a.nch_magic = pw_magic(d->K / (f32 ? 32 : 64) / a.ksplit);
     { int ns = a.TH / (pt / 32), ln = 0; while ((1 << ln) < ns) ++ln; a.lnsub = ln; }
     dim3 grid((unsigned)((long)d->N * d->OH * d->OW / pt), (unsigned)((d->Nc + 127) / 128));
     a.qmap = 0; a.gx = (int)grid.x; a.gy = (int)grid.y;
     if (!a.xmap && a.gy > 1 && a.gy % 2 == 0 && a.gx % 4 == 0) { a.qmap = 2; grid = dim3(grid.x * grid.y, 1, 1); }
     a.ppx = a.gx / 4; a.cpq = a.gy / 2; a.cpq_magic = pw_magic(a.cpq);
+    grid.z = (unsigned)a.ksplit;
     hipStream_t st = (hipStream_t)stream;
     size_t lds = pw_lds(pt, in32 && !(var >= 2 && pw_fpipe(true)));
     if (var >= 2 && pw_fpipe(in32)) {                        // the coefficient table sits behind the two activation buffers + 2 KB
@@ -2284,6 +2380,29 @@ static int pw_launch(const char* who, const MiConvDesc* d, const void* x, const 
 }
 
 }  // namespace
+
+// split-K workspace (see pw_launch): ws = device memory the caller zeroed once and keeps alive, bytes >= 64 KB of flags + the partial tiles of the
+// largest split launch (a launch that does not fit runs unsplit); null / 0 switches the split launches off for the calling thread's device.
+extern "C" int mi_conv_pw_set_splitk_workspace(void* ws, size_t bytes) {
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (ws && (bytes < 2 * PW_SK_FLAG_BYTES || ((uintptr_t)ws & 255))) return mi_set_error(-1, "mi_conv_pw_set_splitk_workspace: 256-byte aligned, >= 128 KB");
+    g_pw_sk_bytes[dev_ & 63].store(ws ? bytes : 0, std::memory_order_release);
+    g_pw_sk_ws[dev_ & 63].store(ws, std::memory_order_release);
+    return 0;
+}
+// tests / A-B: 0 no split launches, 1 the rule (default), 2 / 4 that split wherever the geometry allows; returns the previous mode
+extern "C" int mi_debug_conv_pw_splitk(int mode) {
+    const int was = g_pw_sk_mode;
+    if (mode == 0 || mode == 1 || mode == 2 || mode == 4) g_pw_sk_mode = mode;
+    return was;
+}
+// the split a launch of this descriptor would use now (1: none) + 16 x the tile it would run on -- profiling attribution
+extern "C" int mi_conv3x3_pw_splitk(const MiConvDesc* d, int var, int in32) {
+    int th, ti, ks = 1;
+    const int pt = d ? pw_pick_tile(d, var, &th, &ti, in32 != 0, false, &ks) : 0;
+    return pt ? (pt << 4) | ks : 1;
+}
 
 extern "C" int mi_conv3x3_pw_supported(const MiConvDesc* d) {
     int th, ti;

@@ -43,7 +43,14 @@ USE_CONV_PW = CONV_AUTO and debug_knob("MI_CONV_PW", "1") == "1"     # MI_CONV_A
 def _pw_sym(d, out16, var=0):
     """conv_pw_kernel's symbol as rocprofv3 prints it."""
     pt = _query("mi_conv3x3_pw_tile", d) if var < 2 else 128
+    pt = _pw_tile_now(d, var, False, pt)
     return f"conv_pw_kernel<{'true' if out16 else 'false'}, {var}, 0, {pt or 128}>"
+
+
+def _pw_tile_now(d, var, in32, pt):
+    """The tile a launch runs on right now: a split-K launch (mi_conv3x3_pw_splitk) takes 128-pixel tiles where the unsplit rule takes 64."""
+    q = _query("mi_conv3x3_pw_splitk", d, var, int(in32))
+    return (q >> 4) if (q & 15) > 1 else pt
 
 
 def _pick_pw(N, H, W, K, Nc, d=None):
@@ -141,6 +148,26 @@ def _need_gpu(t: torch.Tensor):
     if t.device.index != _cur_dev():
         raise RuntimeError(f"tensor is on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}; "
                            "call torch.cuda.set_device(tensor.device) first (one process per GPU)")
+    if t.device.index not in _SPLITK_WS:
+        _splitk_workspace(t.device)
+
+
+# Split-K launches of the 3x3 tile kernel (the layers whose tiles would leave CUs without a workgroup: the sampler at B = 64, cfg 3 at 32 images
+# per GPU) exchange fp32 partial tiles through a per-device workspace the library is told about once: zeroed here, never freed (captured graphs
+# hold its address).  SPLITK_MB = 0 (MI_CONV_PW_SPLITK_MB with MI_DEBUG_KNOBS=1) leaves every launch unsplit.
+_SPLITK_WS = {}
+SPLITK_MB = int(debug_knob("MI_CONV_PW_SPLITK_MB", "64"))
+
+
+def _splitk_workspace(device):
+    ws = None
+    if SPLITK_MB > 0 and USE_CONV_PW and not torch.cuda.is_current_stream_capturing():
+        ws = torch.zeros(SPLITK_MB << 20, dtype=torch.uint8, device=device)
+        torch.cuda.current_stream().synchronize()
+        check(load_library().mi_conv_pw_set_splitk_workspace(ws.data_ptr(), ws.numel()), "mi_conv_pw_set_splitk_workspace")
+    elif torch.cuda.is_current_stream_capturing():
+        return                                   # decided by the first eager call on this device
+    _SPLITK_WS[device.index] = ws
 
 
 def ld_of(t: torch.Tensor) -> int:
@@ -320,7 +347,7 @@ def conv3x3_bf16w(x, wsh, *, K, Nc, flip, ksize=3, x2=None, bias=None, residual=
                   "mi_conv3x3_pw_x32")
             if e0 is not None:
                 nb = (N * H * W * K * 4 + N * H * W * Nc * (_esz(out) * (2 if accumulate else 1) + _esz(residual)) + 9 * K * Nc * 2)
-                _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(out) else 'false'}, {0 if gn_sums is None else 1}, 0, {pt}, true>",
+                _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(out) else 'false'}, {0 if gn_sums is None else 1}, 0, {_pw_tile_now(d, 0, True, pt)}, true>",
                              2.0 * N * H * W * Nc * K * 9, f"N{N} {H}x{W} K{K}{'(2src)' if x2 is not None else ''}->{Nc} fp32 in flip{int(flip)} acc{int(accumulate)}", nb)
             return out
     if (gn_sums is not None and ksize == 3 and _b16(x) and USE_CONV_PW and wq is not None and _pick_pw(N, H, W, K, Nc, d)
@@ -498,7 +525,7 @@ def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None, gn=None, 
         else:
             check(lib.mi_conv3x3_pw_gn_mish(C.byref(d), _p(x), _p(coef), _p(wq), _p(bias), _p(y), _b16(y), _stream()), "mi_conv3x3_pw_gn_mish")
         if e0 is not None:
-            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(y) else 'false'}, {3 if coef is None else 2}, 0, {ptf}>", 2.0 * N * H * W * Nc * K * 9,
+            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(y) else 'false'}, {3 if coef is None else 2}, 0, {_pw_tile_now(d, 2, False, ptf)}>", 2.0 * N * H * W * Nc * K * 9,
                          f"N{N} {H}x{W} K{K}->{Nc} fused GN+Mish", N * H * W * (K * 2 + Nc * _esz(y)) + 9 * K * Nc * 2)
         return y
     if ptf and x.dtype == torch.float32:
@@ -518,7 +545,7 @@ def conv3x3_gn_mish(x, coef, wsh, *, K, Nc, bias=None, out_dtype=None, gn=None, 
             check(lib.mi_conv3x3_pw_x32_gn_mish(C.byref(d), _p(x), _p(coef), _p(wq), _p(bias), _p(y), _b16(y), _stream()),
                   "mi_conv3x3_pw_x32_gn_mish")
         if e0 is not None:
-            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(y) else 'false'}, {3 if coef is None else 2}, 0, {ptf}, true>",
+            _probe_close(e0, f"conv_pw_kernel<{'true' if _b16(y) else 'false'}, {3 if coef is None else 2}, 0, {_pw_tile_now(d, 2, True, ptf)}, true>",
                          2.0 * N * H * W * Nc * K * 9, f"N{N} {H}x{W} K{K}->{Nc} fused GN+Mish, fp32 in",
                          N * H * W * (K * 4 + Nc * _esz(y)) + 9 * K * Nc * 2)
         return y

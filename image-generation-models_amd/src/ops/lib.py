@@ -97,6 +97,9 @@ SIGNATURES = {
     "mi_conv3x3_pw_f32": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "mi_conv1x1_pw_x32_supported": [C.POINTER(MiConvDesc)],
     "mi_conv1x1_pw_x32": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _I, _P],
+    "mi_conv_pw_set_splitk_workspace": [_P, C.c_size_t],
+    "mi_conv3x3_pw_splitk": [C.POINTER(MiConvDesc), _I, _I],
+    "mi_debug_conv_pw_splitk": [_I],
     "mi_ln_conv1x1_pw_supported": [C.POINTER(MiConvDesc)],
     "mi_ln_conv1x1_pw": [C.POINTER(MiConvDesc), _P, _P, _P, C.c_float, _P, _P, _P, _P],
     "mi_conv1x1_pw_f32_supported": [C.POINTER(MiConvDesc)],

@@ -183,6 +183,13 @@ int mi_conv3x3_pw_f32(const MiConvDesc* d, const float* x, const float* x2, cons
 int mi_conv1x1_pw_x32_supported(const MiConvDesc* d);     /* ... reading fp32 x / x2 (strides in floats, % 4): the fp32 stream gradient, inference */
 int mi_conv1x1_pw_x32(const MiConvDesc* d, const float* x, const float* x2, const void* w_frag_bf16, const float* bias,
                       const float* residual, void* y, int out_bf16, void* stream);
+/* split-K launches of the 3x3 tile kernel (mi_conv3x3_pw*; the layers whose tiles would leave CUs without a workgroup: the sampler at B = 64,
+   BASELINE configs[2] at 32 images per GPU): ws = device memory the caller zeroed once and keeps alive (64 KB of flags + the fp32 partial tiles;
+   a launch that does not fit runs unsplit), registered for the calling thread's device; launches that use it must be ordered on one stream.
+   null / 0: no split launches.  mi_conv3x3_pw_splitk: the split a launch would use now (1: none) + 16 x its pixel tile. */
+int mi_conv_pw_set_splitk_workspace(void* ws, size_t bytes);
+int mi_conv3x3_pw_splitk(const MiConvDesc* d, int var, int in32);
+int mi_debug_conv_pw_splitk(int mode);                     /* tests: 0 off, 1 the rule, 2 / 4 that split wherever the geometry allows; -> previous */
 /* inference: channel LayerNorm (reference src/models/ddpm.py:85-95) + the bias-free 1x1 conv behind it (to_qkv, :151) in one launch -- the
    normalised tensor is never written.  x fp32 [M][ldx], ln_g / ln_b [K], K = 128 / 256 / 512, y bf16 [M][ldy] */
 int mi_ln_conv1x1_pw_supported(const MiConvDesc* d);

@@ -1055,6 +1055,98 @@ def test_conv1x1_pw_fp32_input(K, cfg, out16, pw_always):
     assert torch.equal(y32, y16)
 
 
+@pytest.mark.parametrize("split", [2, 4])
+@pytest.mark.parametrize("cfg", [(16, 8, 8, 512, 512), (8, 16, 16, 256, 256), (4, 16, 16, 256, 320), (2, 32, 32, 256, 128), (4, 8, 8, 1024, 256, 512)])
+def test_conv3x3_pw_split_k(K, cfg, split, pw_always, pw_tile):
+    """Split-K launches of conv_pw_kernel (the layers whose tiles would leave CUs without a workgroup): slices 1 .. S-1 of the contraction
+    leave their fp32 accumulators in the registered workspace, slice 0 adds them and runs the unchanged epilogue.  Every variant the
+    sampler and cfg 3 launch that way -- plain conv (bf16 / fp32 out, bias + residual, accumulate), GroupNorm sums from the epilogue,
+    fp32 input, two sources, the fused GroupNorm + Mish forms -- against the unsplit launch of the same kernel (fp32 summation order
+    is all that differs) and fp64; twice in a row (the flags are lowered for the next launch) and from a replayed graph."""
+    N, H, W, Ci, Co = cfg[:5]
+    K1 = cfg[5] if len(cfg) > 5 else None
+    if Ci // 64 % split or Ci // 64 // split < 2:
+        pytest.skip("fewer than two chunks per slice")
+    lib = K.load_library()
+    dev = torch.device(DEV, torch.cuda.current_device())
+    had_ws = K._SPLITK_WS.get(dev.index) is not None
+    if not had_ws:                                 # MI_CONV_AUTO=0 runs (the halo-only subprocess): no workspace was registered
+        K._splitk_workspace(dev)
+    g = torch.Generator().manual_seed(131 + split)
+    x = torch.randn(N, H, W, Ci, generator=g).to(DEV)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)
+    Cop = (Co + 63) // 64 * 64
+    wp = torch.zeros(Cop, Ci, 3, 3); wp[:Co] = w
+    wf, wfq = _frag_weights(K, wp)
+    bias = torch.randn(Cop, generator=g).to(DEV); res = torch.randn(N, H, W, Cop, generator=g).to(DEV)
+    xb = x.bfloat16()
+    xa, x2 = (xb[..., :K1].contiguous(), xb[..., K1:].contiguous()) if K1 else (xb, None)
+    ref = F.conv2d(xb.double().cpu().permute(0, 3, 1, 2), w.bfloat16().double(), padding=1).permute(0, 2, 3, 1)
+    gamma, beta = (torch.rand(Ci, generator=g) + 0.5).to(DEV), torch.randn(Ci, generator=g).to(DEV)
+    temb = torch.randn(N, Ci, generator=g).to(DEV)
+
+    def run_all():
+        out = {}
+        out["bf16"] = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Cop, flip=False, x2=x2, bias=bias, out_dtype=torch.bfloat16, wq=wfq)
+        out["f32"] = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Cop, flip=False, x2=x2, bias=bias, residual=res, wq=wfq)
+        out["acc"] = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Cop, flip=False, x2=x2, out=res.clone(), accumulate=True, wq=wfq)
+        if K1 is None:
+            sums = K.gn_sums_buffer(N, Cop, DEV)
+            out["gns"] = K.conv3x3_bf16w(xb, wf, K=Ci, Nc=Cop, flip=False, bias=bias, out_dtype=torch.bfloat16, gn_sums=sums, wq=wfq)
+            out["sums"] = K.gn_sums_decode(sums).clone()
+            out["x32"] = K.conv3x3_bf16w(x, wf, K=Ci, Nc=Cop, flip=False, bias=bias, out_dtype=torch.bfloat16, wq=wfq)
+            if (Ci // 8) % 16 == 0 and Ci // 8 <= 64 and H * W >= 128:         # (one image per tile: the fused forms)
+                st, coef = K.gn_stats_coef(xb, gamma, beta, temb=temb)
+                out["fused"] = K.conv3x3_gn_mish(xb, coef, wf, K=Ci, Nc=Cop, bias=bias, out_dtype=torch.bfloat16, wq=wfq)
+                st32, coef32 = K.gn_stats_coef(x, gamma, beta, temb=temb)
+                out["fused32"] = K.conv3x3_gn_mish(x, coef32, wf, K=Ci, Nc=Cop, bias=bias, out_dtype=torch.bfloat16, wq=wfq)
+        torch.cuda.synchronize()
+        return out
+
+    was = lib.mi_debug_conv_pw_splitk(0); K._QUERY_CACHE.clear()
+    try:
+        base = run_all()
+        assert all(lib.mi_conv3x3_pw_splitk(C_byref(K, N, H, W, Ci, Cop, K1), v, 0) & 15 == 1 for v in (0, 2))
+        lib.mi_debug_conv_pw_splitk(split); K._QUERY_CACHE.clear()
+        q = lib.mi_conv3x3_pw_splitk(C_byref(K, N, H, W, Ci, Cop, K1), 0, 0)
+        assert q & 15 == split and q >> 4 == pw_tile, (q, split, pw_tile)
+        a = run_all()
+        b = run_all()                              # the flags were lowered: a second launch waits for ITS partial tiles
+        gph = torch.cuda.CUDAGraph(); st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(gph, stream=st):
+                yg = K.conv3x3_bf16w(xa, wf, K=Ci, Nc=Cop, flip=False, x2=x2, bias=bias, residual=res, wq=wfq)
+        for _ in range(3):
+            gph.replay()
+        torch.cuda.synchronize()
+    finally:
+        lib.mi_debug_conv_pw_splitk(was); K._QUERY_CACHE.clear()
+        if not had_ws:
+            lib.mi_conv_pw_set_splitk_workspace(None, 0); K._SPLITK_WS[dev.index] = None
+    for k, v in a.items():
+        if v is None:
+            continue
+        assert torch.equal(v, b[k]), k                                         # deterministic: the slices are added in a fixed order
+        d0 = (v.double() - base[k].double()).abs().max()
+        scale = float(base[k].double().abs().max())
+        if k == "sums":                                                        # of the stored bf16 values: a flipped rounding moves a sum
+            assert float(d0) <= 1e-3 * scale, (k, float(d0), scale)
+        elif v.dtype == torch.bfloat16:
+            assert float(d0) <= 2 ** -7 * scale and float((v != base[k]).float().mean()) < 0.05, (k, float(d0), scale)
+        else:
+            assert float(d0) <= 3e-6 * scale, (k, float(d0), scale)
+    assert torch.equal(yg, a["f32"])
+    got = a["f32"].double().cpu() - bias.double().cpu() - res.double().cpu()
+    assert rel_err(got[..., :Co], ref) < 1e-5
+
+
+def C_byref(K, N, H, W, Ci, Co, K1):
+    import ctypes
+    d = K.MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=Ci, Nc=Co, KH=3, KW=3, stride=1, pad=1, transposed=0, w_kn=0, mode=K.MODE_BF16,
+                     K1=K1 or Ci, ldx=K1 or Ci, ldx2=(Ci - K1) if K1 else 0, ldy=Co, ldr=0, accumulate=0)
+    return ctypes.byref(d)
+
+
 @pytest.mark.parametrize("N,H,Ci,Co,bias", [(64, 32, 128, 384, False), (32, 32, 128, 384, False), (8, 32, 128, 384, False), (64, 16, 256, 384, False),
                                             (128, 16, 256, 384, True), (64, 8, 512, 384, True), (512, 8, 512, 384, False), (2, 8, 512, 320, False),
                                             (8, 16, 256, 128, True), (2, 8, 128, 64, False)])
