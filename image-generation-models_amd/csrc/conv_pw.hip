@@ -1831,10 +1831,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
 // 16-byte row of LDS positions), normalises, rounds to bf16 once and writes ITS slots of the [chunk][half][pixel][128 B] tile -- conv1x1_pw_kernel's
 // layout and swizzle; then walks the channel tiles and chunks as conv1x1_pw_kernel's NLOOP form does: the wave's 8 fragments of the next
 // (channel tile, chunk) unit are requested under the current unit's MFMAs, a channel tile leaves through a staging area behind the tile.
-// Training keeps chan_ln_fwd_kernel: to_qkv's weight gradient reads the normalised tensor.
+// Training (a.ln_out): to_qkv's weight gradient reads the normalised tensor -- the lane that rounds a piece for the tile also stores it.
 struct LnPw1Args {
     const float* x; const uint16_t* w; const float* g; const float* b; const float* bias; uint16_t* y;
     int M, K, Nc, ldx, ldy, gx, gy; float eps;
+    uint16_t* ln_out; int ldl;      // training: the normalised tensor as well (bf16 [M][ldl]): to_qkv's weight gradient reads it
 };
 constexpr size_t lnpw1_lds(int pxt, int nch) { return (size_t)nch * pxt * 256 + (size_t)pxt * 256 + (size_t)nch * 1024; }
 template <int PXT, int NCH, bool G2 = false>
@@ -1929,8 +1930,11 @@ __global__ __launch_bounds__(256, 2) void ln_conv1x1_pw_kernel(const LnPw1Args a
                 const f32x4 g0 = *(lds_f32x4n*)(uintptr_t)gq, g1 = *(lds_f32x4n*)(uintptr_t)(gq + 16);
                 const f32x4 b0 = *(lds_f32x4n*)(uintptr_t)(gq + a.K * 4), b1 = *(lds_f32x4n*)(uintptr_t)(gq + a.K * 4 + 16);
                 const f32x4 o0 = (XR[j][ch][h][0] - mean) * inv * g0 + b0, o1 = (XR[j][ch][h][1] - mean) * inv * g1 + b1;
-                *(lds_u32x4n*)(uintptr_t)(lds0 + ch * XB + h * XH + (wv + 4 * j) * 1024 + l * 16) =
-                    u32x4{pack_bf16(o0.x, o0.y), pack_bf16(o0.z, o0.w), pack_bf16(o1.x, o1.y), pack_bf16(o1.z, o1.w)};
+                const u32x4 o = {pack_bf16(o0.x, o0.y), pack_bf16(o0.z, o0.w), pack_bf16(o1.x, o1.y), pack_bf16(o1.z, o1.w)};
+                *(lds_u32x4n*)(uintptr_t)(lds0 + ch * XB + h * XH + (wv + 4 * j) * 1024 + l * 16) = o;
+                // (the 8 lanes of a pixel write the 128 bytes of its 64-channel half: whole lines)
+                if (a.ln_out && jt0 == 0)
+                    *reinterpret_cast<u32x4*>(a.ln_out + (size_t)(m0 + 8 * (wv + 4 * j) + (l >> 3)) * a.ldl + ch * 128 + h * 64 + cidx * 8) = o;
             }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2686,14 +2690,27 @@ static bool lnpw1_ok(const MiConvDesc* d) {
     return ((long)d->N * d->OH * d->OW) % 128 == 0;
 }
 extern "C" int mi_ln_conv1x1_pw_supported(const MiConvDesc* d) { return lnpw1_ok(d) ? 1 : 0; }
+static int lnpw1_launch(const MiConvDesc* d, const float* x, const float* ln_g, const float* ln_b, float eps, const void* w_frag_bf16,
+                        const float* bias, void* y_bf16, void* ln_bf16, int ldl, void* stream);
 extern "C" int mi_ln_conv1x1_pw(const MiConvDesc* d, const float* x, const float* ln_g, const float* ln_b, float eps, const void* w_frag_bf16,
                                 const float* bias, void* y_bf16, void* stream) {
+    return lnpw1_launch(d, x, ln_g, ln_b, eps, w_frag_bf16, bias, y_bf16, nullptr, 0, stream);
+}
+// ... that also writes the normalised tensor (bf16 [M][ldl], ldl % 8 == 0): training -- to_qkv's weight gradient reads it, the LayerNorm launch is gone
+extern "C" int mi_ln_conv1x1_pw_dual(const MiConvDesc* d, const float* x, const float* ln_g, const float* ln_b, float eps, const void* w_frag_bf16,
+                                     const float* bias, void* y_bf16, void* ln_bf16, int ldl, void* stream) {
+    MI_REQUIRE(ln_bf16 && ldl % 8 == 0 && (((uintptr_t)ln_bf16) & 15) == 0, "the normalised tensor: 16-byte aligned, ldl % 8 == 0");
+    return lnpw1_launch(d, x, ln_g, ln_b, eps, w_frag_bf16, bias, y_bf16, ln_bf16, ldl, stream);
+}
+static int lnpw1_launch(const MiConvDesc* d, const float* x, const float* ln_g, const float* ln_b, float eps, const void* w_frag_bf16,
+                        const float* bias, void* y_bf16, void* ln_bf16, int ldl, void* stream) {
     MI_REQUIRE(d && x && ln_g && ln_b && w_frag_bf16 && y_bf16, "null argument");
     MI_REQUIRE(lnpw1_ok(d), "descriptor not supported (1x1, bf16 mode, one source, K = 128 / 256 / 512, Nc % 64 == 0, N*H*W % 128 == 0, ldx % 4, ldy % 8)");
     MI_REQUIRE((((uintptr_t)x | (uintptr_t)ln_g | (uintptr_t)ln_b | (uintptr_t)w_frag_bf16 | (uintptr_t)y_bf16) & 15) == 0, "operands must be 16-byte aligned");
     LnPw1Args a{};
     a.x = x; a.w = (const uint16_t*)w_frag_bf16; a.g = ln_g; a.b = ln_b; a.bias = bias; a.y = (uint16_t*)y_bf16;
     a.M = d->N * d->OH * d->OW; a.K = d->K; a.Nc = d->Nc; a.ldx = d->ldx; a.ldy = d->ldy; a.gy = (d->Nc + 127) / 128; a.eps = eps;
+    a.ln_out = (uint16_t*)ln_bf16; a.ldl = ldl;
     hipStream_t st = (hipStream_t)stream;
 #define MI_LNPW1_GO(PX, NC, G) do { \
         static MiPerDevice once_; \

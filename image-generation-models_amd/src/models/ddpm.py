@@ -270,9 +270,10 @@ class Unet(nn.Module):
         self.ends16 = K.debug_knob("MI_DDPM_ENDS16", "1") != "0"
         # LinearAttention's to_out conv writes the bf16 copy of its (residual-stream) output along; 0 = separate conversion launches
         self.dual_out = K.debug_knob("MI_DDPM_DUAL_OUT", "1") != "0"
-        # inference: PreNorm's LayerNorm applied while to_qkv's input is staged (mi_ln_conv1x1_pw); training keeps the LayerNorm kernel --
-        # to_qkv's weight gradient reads the normalised tensor
+        # PreNorm's LayerNorm applied while to_qkv's input is staged (mi_ln_conv1x1_pw; training: _dual -- the same launch writes the
+        # normalised tensor for to_qkv's weight gradient)
         self.fuse_ln_qkv = K.debug_knob("MI_DDPM_FUSE_LN", "1") != "0"
+        self.fuse_ln_qkv_train = K.debug_knob("MI_DDPM_FUSE_LN_TRAIN", "1") != "0"
         self.accumulate_grads = False
         self.grad_ready_hook = None        # callable(lo, hi): flat_grads[lo:hi) is final (set by the DDP reducer)
 
@@ -669,10 +670,13 @@ class Unet(nn.Module):
                    and all(K.fast1x1_supported(B, inp.shape[1], inp.shape[2], _HEADS * _DHEAD, c)))
             dt = BF if a16 else torch.float32
             nq = 3 * _HEADS * _DHEAD
-            if (not record and a16 and self.fuse_ln_qkv and inp.dtype == torch.float32
+            if (a16 and self.fuse_ln_qkv and (not record or self.fuse_ln_qkv_train) and inp.dtype == torch.float32
                     and K.ln_conv1x1_supported(B, inp.shape[1], inp.shape[2], c, nq, K.ld_of(inp))):
-                ln = None                           # inference: never materialised
-                qkv = K.ln_conv1x1(inp, sv[pre + "fn.norm.g"], sv[pre + "fn.norm.b"], wfq_sh[offs[pre + "fn.fn.to_qkv.weight"]:], Nc=nq)
+                # the LayerNorm rides in to_qkv's staging; inference never materialises the normalised tensor, training has the same
+                # launch write it along (to_qkv's weight gradient reads it)
+                r_ = K.ln_conv1x1(inp, sv[pre + "fn.norm.g"], sv[pre + "fn.norm.b"], wfq_sh[offs[pre + "fn.fn.to_qkv.weight"]:], Nc=nq,
+                                  want_ln=record)
+                qkv, ln = r_ if record else (r_, None)
             else:
                 ln = K.chan_layernorm_fwd(inp, sv[pre + "fn.norm.g"], sv[pre + "fn.norm.b"], out_dtype=dt)
                 qkv = conv(ln, pre + "fn.fn.to_qkv.", 1, bias=False, out_dtype=dt)

@@ -1188,23 +1188,29 @@ def ln_conv1x1_supported(N, H, W, K, Nc, ldx=None):
     return bool(_query("mi_ln_conv1x1_pw_supported", d))
 
 
-def ln_conv1x1(x, g, b, wq, *, Nc, eps=1e-5, bias=None):
-    """Inference: y = conv1x1(chan_layernorm(x)) as bf16 in ONE launch (the normalised tensor is never written): PreNorm + to_qkv,
-    reference src/models/ddpm.py:85-106,151.  x: the fp32 residual stream [N, H, W, K], wq: the conv's slice of pack_weights_bf16's wfq."""
+def ln_conv1x1(x, g, b, wq, *, Nc, eps=1e-5, bias=None, want_ln=False):
+    """y = conv1x1(chan_layernorm(x)) as bf16 in ONE launch: PreNorm + to_qkv, reference src/models/ddpm.py:85-106,151.  x: the fp32
+    residual stream [N, H, W, K], wq: the conv's slice of pack_weights_bf16's wfq.  Inference: the normalised tensor is never written;
+    want_ln (training: to_qkv's weight gradient reads it): -> (y, ln), ln bf16, written by the same launch."""
     _need_gpu(x)
     assert x.dtype == torch.float32
     N, H, W, K = x.shape
     y = new_act(N, H, W, Nc, x, torch.bfloat16)
+    ln = new_act(N, H, W, K, x, torch.bfloat16) if want_ln else None
     d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=K, Nc=Nc, KH=1, KW=1, stride=1, pad=0, transposed=0, w_kn=0, mode=MODE_BF16, K1=K,
                    ldx=ld_of(x), ldx2=0, ldy=ld_of(y), ldr=0, accumulate=0)
     e0 = _probe_open()
-    check(load_library().mi_ln_conv1x1_pw(C.byref(d), _p(x), _p(g), _p(b), eps, _p(wq), _p(bias), _p(y), _stream()), "mi_ln_conv1x1_pw")
+    if want_ln:
+        check(load_library().mi_ln_conv1x1_pw_dual(C.byref(d), _p(x), _p(g), _p(b), eps, _p(wq), _p(bias), _p(y), _p(ln), ld_of(ln), _stream()),
+              "mi_ln_conv1x1_pw_dual")
+    else:
+        check(load_library().mi_ln_conv1x1_pw(C.byref(d), _p(x), _p(g), _p(b), eps, _p(wq), _p(bias), _p(y), _stream()), "mi_ln_conv1x1_pw")
     if e0 is not None:
         px, nch = (128 if (K == 128 and N * H * W // 128 >= 512) else 64), K // 128
         g2 = "true" if (px == 64 and N * H * W // 64 < 512) else "false"      # mi_ln_conv1x1_pw's pick, restated for the symbol name only
         _probe_close(e0, f"ln_conv1x1_pw_kernel<{px}, {nch}, {g2}>", 2.0 * N * H * W * Nc * K, f"N{N} {H}x{W} K{K}->{Nc} fp32 in + LayerNorm",
-                     N * H * W * (K * 4 + Nc * 2) + K * Nc * 2)
-    return y
+                     N * H * W * (K * 4 + Nc * 2 + (2 * K if want_ln else 0)) + K * Nc * 2)
+    return (y, ln) if want_ln else y
 
 
 def chan_layernorm_bwd(x, g, dy, dx, accumulate, dg, db, eps=1e-5, defer=None):

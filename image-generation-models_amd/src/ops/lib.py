@@ -102,6 +102,7 @@ SIGNATURES = {
     "mi_debug_conv_pw_splitk": [_I],
     "mi_ln_conv1x1_pw_supported": [C.POINTER(MiConvDesc)],
     "mi_ln_conv1x1_pw": [C.POINTER(MiConvDesc), _P, _P, _P, C.c_float, _P, _P, _P, _P],
+    "mi_ln_conv1x1_pw_dual": [C.POINTER(MiConvDesc), _P, _P, _P, C.c_float, _P, _P, _P, _P, _I, _P],
     "mi_conv1x1_pw_f32_supported": [C.POINTER(MiConvDesc)],
     "mi_conv1x1_pw_f32": [C.POINTER(MiConvDesc), _P, _P, _P, _P, _P, _P, _P],
     "mi_pack_weights_f32frag": [_I, _P, _I, _P, _P, _P, _P],

@@ -195,6 +195,9 @@ int mi_debug_conv_pw_splitk(int mode);                     /* tests: 0 off, 1 th
 int mi_ln_conv1x1_pw_supported(const MiConvDesc* d);
 int mi_ln_conv1x1_pw(const MiConvDesc* d, const float* x, const float* ln_g, const float* ln_b, float eps, const void* w_frag_bf16,
                      const float* bias, void* y_bf16, void* stream);
+/* ... that also writes the normalised tensor (bf16 [M][ldl]): training -- to_qkv's weight gradient reads it, no LayerNorm launch */
+int mi_ln_conv1x1_pw_dual(const MiConvDesc* d, const float* x, const float* ln_g, const float* ln_b, float eps, const void* w_frag_bf16,
+                          const float* bias, void* y_bf16, void* ln_bf16, int ldl, void* stream);
 int mi_conv1x1_pw_f32_supported(const MiConvDesc* d);     /* the 1x1 convs in exact-fp32 mode: K % 64 == 0, K1 % 64 == 0, Nc % 64 == 0 */
 int mi_conv1x1_pw_f32(const MiConvDesc* d, const float* x, const float* x2, const float* w_frag_f32, const float* bias,
                       const float* residual, float* y, void* stream);

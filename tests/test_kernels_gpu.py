@@ -1164,6 +1164,7 @@ def test_layernorm_conv1x1_fused(K, N, H, Ci, Co, bias, pw_always):
     flat, wd, wf, offs, wdq, wfq = _pack(K, [conv_w_storage(w.double())], frag=True)
     assert K.ln_conv1x1_supported(N, H, H, Ci, Co)
     y = K.ln_conv1x1(x, gg, bb, wfq, Nc=Co, bias=b)
+    yt, lnt = K.ln_conv1x1(x, gg, bb, wfq, Nc=Co, bias=b, want_ln=True)      # training's form: the normalised tensor written along
     ln = K.chan_layernorm_fwd(x, gg, bb, out_dtype=torch.bfloat16)
     y2 = K.conv3x3_bf16w(ln, wf, K=Ci, Nc=Co, flip=False, ksize=1, out_dtype=torch.bfloat16, wq=wfq, bias=b)
     torch.cuda.synchronize()
@@ -1175,6 +1176,13 @@ def test_layernorm_conv1x1_fused(K, N, H, Ci, Co, bias, pw_always):
     ref = torch.einsum("nhwc,oc->nhwo", ln.double().cpu(), w[:, :, 0, 0].bfloat16().double()) + (b.double().cpu() if bias else 0.0)
     e_fused, e_two = rel_err(y.float().cpu(), ref), rel_err(y2.float().cpu(), ref)
     assert e_two < 6e-3 and e_fused < 6e-3, (e_fused, e_two)
+    # the dual form: the same y, and the tensor the MFMAs read -- the LayerNorm kernel's output up to summation-order flips of a bf16 ulp
+    assert torch.equal(yt, y) and lnt.dtype == torch.bfloat16 and lnt.shape == x.shape
+    assert rel_err(lnt.float().cpu(), lnd) < 4e-3
+    dl = (lnt.float() - ln.float()).abs()
+    assert float((dl > 0).float().mean()) < 0.02 and float(dl.max()) <= 2 ** -7 * float(ln.float().abs().max())
+    ref_t = torch.einsum("nhwc,oc->nhwo", lnt.double().cpu(), w[:, :, 0, 0].bfloat16().double()) + (b.double().cpu() if bias else 0.0)
+    assert rel_err(yt.float().cpu(), ref_t) < 4e-3                         # y IS the conv of the tensor written along (bf16 output rounding only)
     # the two paths against each other: a handful of bf16 ulps where the LayerNorm output crossed a rounding boundary
     diff = (y.float() - y2.float()).abs()
     assert float(diff.max()) <= 0.05 * float(y2.float().abs().max()) and float((diff > 0).float().mean()) < 0.2, (float(diff.max()), float((diff > 0).float().mean()))

@@ -727,8 +727,8 @@ def test_bf16_block_storage_end_to_end(golden_dir):
     assert e_eps <= BF16_EPS_BUDGET, e_eps
     record("cfg2_bf16_block_storage", eps_rel_l2=e_eps, loss_abs=e_loss, flat_grad_rel_l2_vs_fp32_storage=e_sto,
            flat_grad_rel_l2_vs_fp32_mode=e_full,
-           bounds={"eps_rel_l2": 2.1e-2, "loss_abs": 1.5e-4, "flat_grad_rel_l2_vs_fp32_storage": 7.2e-2, "flat_grad_rel_l2_vs_fp32_mode": 7.9e-2})
-    assert e_eps < 2.1e-2 and e_loss < 1.5e-4 and e_sto < 7.2e-2 and e_full < 7.9e-2       # measured 1.08e-2 / 8.0e-5 / 3.6e-2 / 4.0e-2 (round 4, bf16 ends)
+           bounds={"eps_rel_l2": 2.1e-2, "loss_abs": 1.4e-4, "flat_grad_rel_l2_vs_fp32_storage": 6.7e-2, "flat_grad_rel_l2_vs_fp32_mode": 7.9e-2})
+    assert e_eps < 2.1e-2 and e_loss < 1.4e-4 and e_sto < 6.7e-2 and e_full < 7.9e-2       # measured 1.10e-2 / 7.1e-5 / 3.4e-2 / 4.3e-2 (round 6)
 
 
 class _FixedInputsStep:
