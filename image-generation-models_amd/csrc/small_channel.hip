@@ -91,10 +91,14 @@ __global__ __launch_bounds__(256) void small_cin_fwd_kernel(int N, int H, int W,
 // waits for them (200 registers of weights and taps, two waves per SIMD: a latency chain of ~1 M load instructions per launch at
 // B = 128).  Here a workgroup owns 64-pixel tiles (whole image rows), the tile's (rows + 2) x (W + 2) halo of padded pixels is
 // fetched by one load per thread -- the NEXT tile's while this one is computed -- and the taps are ds_read_b128.
-template <int CIN, bool Y16 = false>
+// DUAL: the ResnetBlock's res_conv (Conv2d(Cin, Cout, 1) on the same input, reference ddpm.py:134,143) rides along -- its input is the centre
+// tap: 3 more FMAs per output quad and a second (fp32) output instead of a launch that reads the image again.
+template <int CIN, bool Y16 = false, bool DUAL = false>
 __global__ __launch_bounds__(256) void small_cin3x3_fwd_tiled_kernel(int N, int H, int W, int Cout, const float* __restrict__ x, int ldx,
                                                                      const float* __restrict__ w, const float* __restrict__ bias,
-                                                                     void* __restrict__ y, int ldy, int w_sh, int ntiles) {
+                                                                     void* __restrict__ y, int ldy, int w_sh, int ntiles,
+                                                                     const float* __restrict__ w1 = nullptr, const float* __restrict__ bias1 = nullptr,
+                                                                     float* __restrict__ y1 = nullptr, int ldy1 = 0) {
     extern __shared__ __attribute__((aligned(16))) float halo_s[];          // 2 x [(rows + 2) * (W + 2)] float4
     const int nq = Cout / 4;
     const int q = threadIdx.x % nq, psub = threadIdx.x / nq, pp = 256 / nq;
@@ -103,6 +107,12 @@ __global__ __launch_bounds__(256) void small_cin3x3_fwd_tiled_kernel(int N, int 
 #pragma unroll
     for (int i = 0; i < 9 * CIN; ++i) wr[i] = *reinterpret_cast<const f32x4*>(w + (size_t)i * Cout + 4 * q);
     const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 wr1[DUAL ? CIN : 1], b1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) wr1[i] = *reinterpret_cast<const f32x4*>(w1 + (size_t)i * Cout + 4 * q);
+        if (bias1) b1 = *reinterpret_cast<const f32x4*>(bias1 + 4 * q);
+    }
     // this thread's halo pixel (HP <= 256): position -> (row, column) of the tile's halo
     const int hp = threadIdx.x, hy = hp / W2, hx = hp - hy * W2;
     auto fetch = [&](int tile) -> f32x4 {
@@ -122,14 +132,21 @@ __global__ __launch_bounds__(256) void small_cin3x3_fwd_tiled_kernel(int N, int 
         const size_t m0 = (size_t)tile * 64;
         for (int px = psub; px < 64; px += pp) {
             const int ty = px >> w_sh, tx = px & (W - 1);
-            f32x4 acc = b4;
+            f32x4 acc = b4, acc1 = b1;
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(hs + (size_t)((ty + tp / 3) * W2 + tx + tp % 3) * 4);
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci) acc += xv[ci] * wr[tp * CIN + ci];
+                if constexpr (DUAL) {
+                    if (tp == 4) {
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci) acc1 += xv[ci] * wr1[ci];
+                    }
+                }
             }
             stq<Y16>(y, (m0 + px) * ldy + 4 * q, acc);
+            if constexpr (DUAL) stq<false>(y1, (m0 + px) * ldy1 + 4 * q, acc1);
         }
         buf ^= 1;
         if (hp < HP) *reinterpret_cast<f32x4*>(halo_s + ((size_t)buf * HP + hp) * 4) = nxt;
@@ -481,6 +498,31 @@ extern "C" int mi_conv_small_cin_fwd_io(int ks, int N, int H, int W, int Cin, in
 #define MI_GO_CIN(KS) do { switch (Cin) { case 1: MI_GO(1, KS); break; case 2: MI_GO(2, KS); break; case 3: MI_GO(3, KS); break; default: MI_GO(4, KS); break; } } while (0)
     if (ks == 3) MI_GO_CIN(3); else MI_GO_CIN(1);
 #undef MI_GO
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+// The first ResnetBlock's block1 conv (3x3) AND its res_conv (1x1) on the same image in one launch: y3 (fp32 or bf16) = conv3x3(x, w3) + bias3,
+// y1 (fp32) = conv1x1(x, w1) + bias1.  Whole-row-tile geometry only (mi_conv_small_cin_fwd_dual_supported).
+extern "C" int mi_conv_small_cin_fwd_dual_supported(int N, int H, int W, int Cin, int Cout, int ldx) {
+    static const int tiled = (int)mi_knob("MI_SMALL_CIN_TILED", 1);
+    return (tiled && N > 0 && Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && Cout <= 256 && 256 % (Cout / 4) == 0 && ((long)N * H * W) % 64 == 0 &&
+            cin_tiled_geom(3, H, W, ldx, nullptr)) ? 1 : 0;
+}
+extern "C" int mi_conv_small_cin_fwd_dual(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w3, const float* bias3,
+                                          void* y3, int ldy3, int y3_bf16, const float* w1, const float* bias1, float* y1, int ldy1, void* stream) {
+    MI_REQUIRE(x && w3 && y3 && w1 && y1 && mi_conv_small_cin_fwd_dual_supported(N, H, W, Cin, Cout, ldx) && ((uintptr_t)x & 15) == 0 &&
+               ldy3 % 4 == 0 && ldy1 % 4 == 0 && (((uintptr_t)y3 & (y3_bf16 ? 7 : 15)) | ((uintptr_t)y1 & 15) | ((uintptr_t)w3 & 15) | ((uintptr_t)w1 & 15)) == 0,
+               "needs the whole-row-tile geometry (power-of-two W <= 64, ldx == 4), Cout / 4 dividing 256, aligned operands");
+    const int w_sh = log2_exact(W), rows = 64 / W;
+    const int ntiles = N * H * W / 64;
+    const int grid = ntiles < 1024 ? ntiles : 1024;
+    const size_t lds = (size_t)2 * (rows + 2) * (W + 2) * 16;
+    hipStream_t st = (hipStream_t)stream;
+#define MI_TILED2(CIN) do { \
+        if (y3_bf16) hipLaunchKernelGGL((small_cin3x3_fwd_tiled_kernel<CIN, true, true>), dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w3, bias3, y3, ldy3, w_sh, ntiles, w1, bias1, y1, ldy1); \
+        else hipLaunchKernelGGL((small_cin3x3_fwd_tiled_kernel<CIN, false, true>), dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w3, bias3, y3, ldy3, w_sh, ntiles, w1, bias1, y1, ldy1); } while (0)
+    switch (Cin) { case 1: MI_TILED2(1); break; case 2: MI_TILED2(2); break; case 3: MI_TILED2(3); break; default: MI_TILED2(4); break; }
+#undef MI_TILED2
     MI_LAUNCH_CHECK();
     return 0;
 }

@@ -274,6 +274,7 @@ class Unet(nn.Module):
         # normalised tensor for to_qkv's weight gradient)
         self.fuse_ln_qkv = K.debug_knob("MI_DDPM_FUSE_LN", "1") != "0"
         self.fuse_ln_qkv_train = K.debug_knob("MI_DDPM_FUSE_LN_TRAIN", "1") != "0"
+        self.small_cin_dual = K.debug_knob("MI_DDPM_CIN_DUAL", "1") != "0"      # the first block's 3x3 conv + res_conv in one launch
         self.accumulate_grads = False
         self.grad_ready_hook = None        # callable(lo, hi): flat_grads[lo:hi) is final (set by the DDP reducer)
 
@@ -622,7 +623,15 @@ class Unet(nn.Module):
                     zpool[0] = torch.zeros(2 * B * sum(rb["cout"] // 16 + 1 for rb in A.res_blocks), device=inp.device, dtype=torch.int64)
                 sums = zpool[0][zpool[1]:zpool[1] + nsum]
                 zpool[1] += (nsum + 3) // 4 * 4
-            c1 = conv(inp_c, pre + "block1.block.0.", 3, 1, 1, x2=x2_c, out_dtype=BF if c1_16 else torch.float32, gn_sums=sums)
+            r_pre = None
+            if (blk["res"] and x2 is None and sums is None and self.small_cin_dual and K.small_cin_supported(3, ci, co)
+                    and K.small_cin_dual_supported(B, inp.shape[1], inp.shape[2], ci, co, K.ld_of(inp))):
+                # the image -> features block: its 3x3 conv and its res_conv read the same 3-channel image -- one launch (the 1x1's input is the centre tap)
+                od = BF if (c1_16 and K.small_cin_bf16_supported(3, B, inp.shape[1], inp.shape[2], ci, co, K.ld_of(inp))) else torch.float32
+                c1, r_pre = K.conv_small_cin_fwd_dual(inp, sv[pre + "block1.block.0.weight"], sv[pre + "block1.block.0.bias"],
+                                                      sv[pre + "res_conv.weight"], sv[pre + "res_conv.bias"], co, out_dtype=od)
+            else:
+                c1 = conv(inp_c, pre + "block1.block.0.", 3, 1, 1, x2=x2_c, out_dtype=BF if c1_16 else torch.float32, gn_sums=sums)
             c2 = None
             if fuse:
                 # inference / sampling: GroupNorm-apply + Mish + time bias ride in block2's conv staging (the named fused kernel);
@@ -645,7 +654,9 @@ class Unet(nn.Module):
             # same numbers, half the bytes
             # -- where the 1x1 tile kernel takes the layer; otherwise the fp32 tensors go to the generic kernel as before)
             r = inp
-            if blk["res"]:
+            if r_pre is not None:
+                r = r_pre
+            elif blk["res"]:
                 r = None
                 if inp_c is not inp and inp_c.dtype == BF and (x2 is None or x2_c is not None):
                     r = conv(inp_c, pre + "res_conv.", 1, x2=x2_c, soft=True)

@@ -266,6 +266,10 @@ size_t mi_conv_small_wgrad_workspace(int outputs);
  * is rounded once / dy is widened on load).  y_bf16 / dy_bf16 = 1 needs the whole-row-tile kernels: ks = 3, W a power of two <= 64,
  * H*W a power of two, ldx == 4, 16-byte aligned x, Cout in {64, 128} (256: forward only) -- mi_conv_small_cin_bf16_supported answers for both. */
 int mi_conv_small_cin_bf16_supported(int ks, int N, int H, int W, int Cin, int Cout, int ldx);
+/* round 6: the first ResnetBlock's 3x3 conv and its res_conv (Conv2d(Cin, Cout, 1), reference ddpm.py:134,143) on the same image in one launch */
+int mi_conv_small_cin_fwd_dual_supported(int N, int H, int W, int Cin, int Cout, int ldx);
+int mi_conv_small_cin_fwd_dual(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w3, const float* bias3,
+                               void* y3, int ldy3, int y3_bf16, const float* w1, const float* bias1, float* y1, int ldy1, void* stream);
 int mi_conv_small_cin_fwd_io(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w,
                              const float* bias, void* y, int ldy, int y_bf16, void* stream);
 int mi_conv_small_cin_wgrad_io(int ks, int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const void* dy,

@@ -1844,6 +1844,32 @@ def test_small_channel_ends_bf16_wide_tensor(K, N, H, C):
     assert torch.equal(dh16, (dh32.to(BF).float() + dh32).to(BF))
 
 
+@pytest.mark.parametrize("N,H,C", [(8, 32, 128), (2, 16, 128), (4, 64, 64), (2, 8, 256)])
+@pytest.mark.parametrize("out16", [False, True])
+def test_small_cin_block_conv_and_res_conv_in_one_launch(K, N, H, C, out16):
+    """mi_conv_small_cin_fwd_dual (round 6): the image -> features ResnetBlock's 3x3 conv and its res_conv (Conv2d(3, C, 1), reference
+    ddpm.py:134,143) from one pass over the image.  Same FMA chains as the two kernels it replaces: bitwise their outputs."""
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(61)
+    x = to_nhwc_gpu(torch.randn(N, 3, H, H, generator=g))
+    w3 = torch.randn(3 * 3 * 3 * C, generator=g).to(DEV) * 0.2; b3 = torch.randn(C, generator=g).to(DEV)
+    w1 = torch.randn(3 * C, generator=g).to(DEV) * 0.5; b1 = torch.randn(C, generator=g).to(DEV)
+    if out16 and not K.small_cin_bf16_supported(3, N, H, H, 3, C, 4):
+        pytest.skip("bf16 output: Cout <= 128")
+    assert K.small_cin_dual_supported(N, H, H, 3, C, K.ld_of(x))
+    dt = BF if out16 else torch.float32
+    y3, y1 = K.conv_small_cin_fwd_dual(x, w3, b3, w1, b1, C, out_dtype=dt)
+    r3 = K.conv_small_cin_fwd(x, w3, b3, C, 3, out_dtype=dt)
+    r1 = K.conv_small_cin_fwd(x, w1, b1, C, 1)
+    torch.cuda.synchronize()
+    assert y3.dtype == dt and y1.dtype == torch.float32
+    assert torch.equal(y3, r3)
+    assert torch.equal(y1, r1) or rel_err(y1, r1) < 2e-7
+    xd = from_nhwc(x).double()
+    ref1 = F.conv2d(xd, w1.double().cpu().view(3, C).t().reshape(C, 3, 1, 1), b1.double().cpu())
+    assert rel_err(from_nhwc(y1), ref1) < 2e-6
+
+
 @pytest.mark.parametrize("kind", ["down", "down_dgrad", "up", "up_dgrad"])
 def test_igemm_bf16_weight_copy(K, kind):
     """Stride-2 Downsample / ConvTranspose Upsample (ddpm.py:70,79) through the generic kernel fed by the bf16 weight copy."""
