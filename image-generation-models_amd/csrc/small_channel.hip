@@ -379,6 +379,79 @@ __global__ __launch_bounds__(256) void small_cout_fwd_kernel(int M, int Cs, cons
         }
     }
 }
+// Inference, final_conv (reference ddpm.py:232-235: Block = conv -> GroupNorm -> Mish, then Conv2d(dim, channels, 1)): the Block's GroupNorm-apply
+// + Mish ride in the 1x1 conv's load.  x = the Block conv's bf16 output, the statistics come from the sums its epilogue left (mi_conv3x3_pw_gnsums;
+// mi_gn_coef_from_sums' arithmetic per lane); the normalised tensor is never written and never rounded to bf16.  A workgroup takes a contiguous run
+// of ppw pixels (one sample when ppw divides H * W): the coefficients of a lane's 4 * CK channels are resolved once per sample.
+template <int CK>
+__global__ __launch_bounds__(256) void small_cout_fwd_gn_kernel(int M, int HW, int Cs, const uint16_t* __restrict__ x, int ldx,
+                                                                const long long* __restrict__ sums, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int G, float eps, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ y, int ldy, int ppw) {
+    constexpr int C = 32 * CK;
+    const int sub = threadIdx.x & 7, pl = threadIdx.x >> 3;          // 32 pixels per iteration, 8 lanes per pixel
+    f32x4 wr[CK][4];                                                 // wr[k][e][j] = w[c = 4*(sub+8k)+e][j]
+    f32x4 ga[CK], be[CK];
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* wp = w + (size_t)(4 * (sub + 8 * k) + e) * Cs;
+            wr[k][e] = f32x4{wp[0], Cs > 1 ? wp[1] : 0.f, Cs > 2 ? wp[2] : 0.f, Cs > 3 ? wp[3] : 0.f};
+        }
+        ga[k] = *reinterpret_cast<const f32x4*>(gamma + 4 * (sub + 8 * k));
+        be[k] = *reinterpret_cast<const f32x4*>(beta + 4 * (sub + 8 * k));
+    }
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias) { b4.x = bias[0]; if (Cs > 1) b4.y = bias[1]; if (Cs > 2) b4.z = bias[2]; if (Cs > 3) b4.w = bias[3]; }
+    const int Cg = C / G, nslab = Cg / 16;
+    const double icnt = 1.0 / (MI_GSUM_SCALE * (double)HW * (double)Cg);
+    const int mb = blockIdx.x * ppw, me = min(M, mb + ppw);
+    int ncur = -1;
+    f32x4 sc[CK], sh[CK];
+    for (int m0 = mb; m0 < me; m0 += 32) {
+        const int m = min(m0 + pl, M - 1);
+        f32x4 xv[CK];
+#pragma unroll
+        for (int k = 0; k < CK; ++k) xv[k] = ldq<true>(x, (size_t)m * ldx + 4 * (sub + 8 * k));
+        const int n = m / HW;
+        if (n != ncur) {
+            ncur = n;
+#pragma unroll
+            for (int k = 0; k < CK; ++k) {
+                const int g = (4 * (sub + 8 * k)) / Cg;              // (a channel quad lies in one group: Cg % 16 == 0)
+                long long si = 0, qi = 0;
+                bool poisoned = false;
+                for (int j = 0; j < nslab; ++j) {
+                    const size_t p = ((size_t)n * (C / 16) + g * nslab + j) * 2;
+                    const long long r0 = sums[p], r1 = sums[p + 1];
+                    poisoned |= r0 >= (1LL << 60) || r0 <= -(1LL << 60) || r1 >= (1LL << 60) || r1 <= -(1LL << 60);
+                    si += r0; qi += r1;
+                }
+                const double mean = poisoned ? __builtin_nan("") : (double)si * icnt;
+                double var = (double)qi * icnt - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float rstd = 1.0f / sqrtf((float)var + eps), mf = (float)mean;
+                sc[k] = ga[k] * rstd;
+                sh[k] = be[k] - mf * sc[k];
+            }
+        }
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < CK; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a += mish_fast_f(xv[k][e] * sc[k][e] + sh[k][e]) * wr[k][e];
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64);
+            a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+        }
+        if (sub == 0 && m0 + pl < me) {
+            a += b4;                                                 // (channels Cs .. 3 of the padded pixel: exactly 0 -- their weights and bias are)
+            *reinterpret_cast<f32x4*>(y + (size_t)m * ldy) = a;
+        }
+    }
+}
 // dgrad: dx[px][c] (+)= sum_j dy[px][j] w[c][j]; thread = (channel quad, pixel lane)
 template <bool DX16 = false>
 __global__ __launch_bounds__(256) void small_cout_dgrad_kernel(int M, int C, int Cs, const float* __restrict__ dy, int lddy,
@@ -621,6 +694,27 @@ extern "C" int mi_conv1x1_small_cout_io(int op, int M, int C, int Cs, const void
     } else {
         return mi_set_error(-1, "mi_conv1x1_small_cout: op must be 0, 1 or 2");
     }
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+// y[M][Cs] = bias + conv1x1(mish(groupnorm(x))), x bf16 [M][ldx] = the producing conv's output, sums = what its epilogue left (see
+// small_cout_fwd_gn_kernel).  C = 64 or 128, (C / G) % 16 == 0.
+extern "C" int mi_conv1x1_small_cout_gn_supported(int C, int Cs, int G) {
+    return ((C == 64 || C == 128) && Cs >= 1 && Cs <= 4 && G > 0 && C % G == 0 && (C / G) % 16 == 0) ? 1 : 0;
+}
+extern "C" int mi_conv1x1_small_cout_gn_fwd(int M, int HW, int C, int Cs, const void* x_bf16, int ldx, const void* sums, const float* gamma,
+                                            const float* beta, int G, float eps, const float* w, const float* bias, float* y, int ldy, void* stream) {
+    MI_REQUIRE(x_bf16 && sums && gamma && beta && w && y && M > 0 && HW > 0 && M % HW == 0 && mi_conv1x1_small_cout_gn_supported(C, Cs, G) &&
+               ldx % 4 == 0 && ldy == 4 && (((uintptr_t)x_bf16 & 7) | ((uintptr_t)sums & 15) | ((uintptr_t)gamma & 15) | ((uintptr_t)beta & 15) | ((uintptr_t)y & 15)) == 0,
+               "needs C in {64, 128}, (C / G) % 16 == 0, Cs <= 4, y as padded 4-channel pixels, aligned operands");
+    // contiguous runs of pixels per workgroup: a divisor of H * W where there is one (one sample per workgroup), about 1 024 workgroups
+    int ppw = 32;
+    while ((long)M / ppw > 1536 && HW % (2 * ppw) == 0) ppw *= 2;
+    const int blocks = (M + ppw - 1) / ppw;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 128) hipLaunchKernelGGL((small_cout_fwd_gn_kernel<4>), dim3(blocks), dim3(256), 0, st, M, HW, Cs, (const uint16_t*)x_bf16, ldx, (const long long*)sums, gamma, beta, G, eps, w, bias, y, ldy, ppw);
+    else hipLaunchKernelGGL((small_cout_fwd_gn_kernel<2>), dim3(blocks), dim3(256), 0, st, M, HW, Cs, (const uint16_t*)x_bf16, ldx, (const long long*)sums, gamma, beta, G, eps, w, bias, y, ldy, ppw);
     MI_LAUNCH_CHECK();
     return 0;
 }

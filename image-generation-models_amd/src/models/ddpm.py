@@ -275,6 +275,7 @@ class Unet(nn.Module):
         self.fuse_ln_qkv = K.debug_knob("MI_DDPM_FUSE_LN", "1") != "0"
         self.fuse_ln_qkv_train = K.debug_knob("MI_DDPM_FUSE_LN_TRAIN", "1") != "0"
         self.small_cin_dual = K.debug_knob("MI_DDPM_CIN_DUAL", "1") != "0"      # the first block's 3x3 conv + res_conv in one launch
+        self.fuse_final = K.debug_knob("MI_DDPM_FUSE_FINAL", "1") != "0"        # inference: final_conv.0's GroupNorm + Mish inside final_conv.1's load
         self.accumulate_grads = False
         self.grad_ready_hook = None        # callable(lo, hi): flat_grads[lo:hi) is final (set by the DDP reducer)
 
@@ -519,6 +520,15 @@ class Unet(nn.Module):
 
         zpool = [None, 0]                   # fused eval path: zeroed pool for the per-block GroupNorm sums, next free float
 
+        def take_sums(nc, device):    # [B][nc / 16][2] of the pool: ONE zero fill per forward for every block's sums (+ final_conv.0's)
+            nsum = B * (nc // 16) * 2
+            if zpool[0] is None:
+                zpool[0] = torch.zeros(2 * B * (sum(rb["cout"] // 16 + 1 for rb in A.res_blocks) + A.dim // 16 + 1), device=device, dtype=torch.int64)
+            assert zpool[1] + nsum <= zpool[0].numel()
+            sl = zpool[0][zpool[1]:zpool[1] + nsum]
+            zpool[1] += (nsum + 3) // 4 * 4
+            return sl
+
         def shadow(t):
             ent = sh.get(id(t))
             if ent is None:
@@ -618,11 +628,7 @@ class Unet(nn.Module):
             # ... with block1's GroupNorm statistics taken from conv1's epilogue when the tile kernel runs it (no pass over c1 at all)
             sums = None
             if fuse and fmode in ("2", "auto") and sums_ok:
-                nsum = B * (co // 16) * 2
-                if zpool[0] is None:      # one zero fill per forward for every block's sums
-                    zpool[0] = torch.zeros(2 * B * sum(rb["cout"] // 16 + 1 for rb in A.res_blocks), device=inp.device, dtype=torch.int64)
-                sums = zpool[0][zpool[1]:zpool[1] + nsum]
-                zpool[1] += (nsum + 3) // 4 * 4
+                sums = take_sums(co, inp.device)
             r_pre = None
             if (blk["res"] and x2 is None and sums is None and self.small_cin_dual and K.small_cin_supported(3, ci, co)
                     and K.small_cin_dual_supported(B, inp.shape[1], inp.shape[2], ci, co, K.ld_of(inp))):
@@ -736,6 +742,16 @@ class Unet(nn.Module):
             okf = K.fast3x3_supported(B, h.shape[1], h.shape[2], cdim, cdim)
             f16 = okf[0] and okf[1] and not K.conv3x3_uses_splitk(B, h.shape[1], h.shape[2], cdim, cdim)
         h_c = shadow(h) if (f16 and use_sh) else h
+        ncs = sv["final_conv.1.weight"].shape[3]
+        # inference: final_conv.0's GroupNorm-apply + Mish ride in final_conv.1's load, the statistics come from final_conv.0's conv epilogue
+        fuse_final = (f16 and not record and self.fuse_final and str(self.fuse_gn_conv) != "0" and (cdim // _GN_GROUPS) % 16 == 0
+                      and (h.shape[1] * h.shape[2]) % 32 == 0 and K.small_cout_gn_supported(cdim, ncs, _GN_GROUPS)
+                      and K.conv3x3_pw_gn_mish_picked(B, h.shape[1], h.shape[2], cdim, cdim))
+        if fuse_final:
+            sumsF = take_sums(cdim, h.device) if cdim == A.dim else K.gn_sums_buffer(B, cdim, h.device)
+            cF = conv(h_c, "final_conv.0.block.0.", 3, 1, 1, out_dtype=BF, gn_sums=sumsF)
+            return K.conv1x1_small_cout_gn(cF, sumsF, sv["final_conv.0.block.1.weight"], sv["final_conv.0.block.1.bias"],
+                                           sv["final_conv.1.weight"], sv["final_conv.1.bias"], ncs, groups=_GN_GROUPS), tape
         cF = conv(h_c, "final_conv.0.block.0.", 3, 1, 1, out_dtype=BF if f16 else torch.float32)
         # round 4: hF as bf16 too where the 128 -> 3 kernels take it (they widen on load; the gradient wrt hF is written as bf16)
         hF16 = f16 and self.ends16 and all(K.small_cout_supported(op, cdim, sv["final_conv.1.weight"].shape[3]) for op in (0, 1, 2))

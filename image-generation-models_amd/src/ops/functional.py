@@ -699,6 +699,27 @@ def conv_small_cin_fwd(x, w, bias, Cout, ks, out_dtype=torch.float32):
 
 
 @functools.lru_cache(maxsize=None)
+def small_cout_gn_supported(C, Cs, G):
+    return bool(load_library().mi_conv1x1_small_cout_gn_supported(C, Cs, G))
+
+
+def conv1x1_small_cout_gn(x, sums, gamma, beta, w, bias, Cs, groups=8, eps=1e-5):
+    """Inference, final_conv: y = conv1x1(mish(groupnorm(x))) + bias with x the Block conv's bf16 output and its GroupNorm statistics taken from
+    the sums that conv's epilogue left (conv3x3_bf16w(..., gn_sums=sums)) -- one launch, the normalised tensor is never written."""
+    _need_gpu(x)
+    assert x.dtype == torch.bfloat16 and sums.dtype == torch.int64
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, H, W, 4), device=x.device, dtype=torch.float32)       # padded 4-channel pixels; the kernel writes the padding (zero) too
+    e0 = _probe_open()
+    check(load_library().mi_conv1x1_small_cout_gn_fwd(N * H * W, H * W, Cc, Cs, _p(x), ld_of(x), _p(sums), _p(gamma), _p(beta), groups, eps,
+                                                      _p(w), _p(bias), _p(y), ld_of(y), _stream()), "mi_conv1x1_small_cout_gn_fwd")
+    if e0 is not None:
+        _probe_close(e0, f"small_cout_fwd_gn_kernel<{Cc // 32}>", 2.0 * N * H * W * Cc * Cs, f"M{N * H * W} C{Cc}->{Cs} GN+Mish in the load",
+                     N * H * W * (Cc * 2 + 16))
+    return y[..., :Cs]
+
+
+@functools.lru_cache(maxsize=None)
 def small_cin_dual_supported(N, H, W, Cin, Cout, ldx):
     return bool(load_library().mi_conv_small_cin_fwd_dual_supported(N, H, W, Cin, Cout, ldx))
 

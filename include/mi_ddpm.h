@@ -266,6 +266,11 @@ size_t mi_conv_small_wgrad_workspace(int outputs);
  * is rounded once / dy is widened on load).  y_bf16 / dy_bf16 = 1 needs the whole-row-tile kernels: ks = 3, W a power of two <= 64,
  * H*W a power of two, ldx == 4, 16-byte aligned x, Cout in {64, 128} (256: forward only) -- mi_conv_small_cin_bf16_supported answers for both. */
 int mi_conv_small_cin_bf16_supported(int ks, int N, int H, int W, int Cin, int Cout, int ldx);
+/* round 6, inference: final_conv (reference ddpm.py:232-235) -- the Block's GroupNorm-apply + Mish inside the Conv2d(dim, channels, 1)'s load: x = the
+   Block conv's bf16 output, sums = what its epilogue left (mi_conv3x3_pw_gnsums); C = 64 / 128, (C / G) % 16 == 0 */
+int mi_conv1x1_small_cout_gn_supported(int C, int Cs, int G);
+int mi_conv1x1_small_cout_gn_fwd(int M, int HW, int C, int Cs, const void* x_bf16, int ldx, const void* sums, const float* gamma,
+                                 const float* beta, int G, float eps, const float* w, const float* bias, float* y, int ldy, void* stream);
 /* round 6: the first ResnetBlock's 3x3 conv and its res_conv (Conv2d(Cin, Cout, 1), reference ddpm.py:134,143) on the same image in one launch */
 int mi_conv_small_cin_fwd_dual_supported(int N, int H, int W, int Cin, int Cout, int ldx);
 int mi_conv_small_cin_fwd_dual(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w3, const float* bias3,

@@ -1844,6 +1844,32 @@ def test_small_channel_ends_bf16_wide_tensor(K, N, H, C):
     assert torch.equal(dh16, (dh32.to(BF).float() + dh32).to(BF))
 
 
+@pytest.mark.parametrize("N,H,C,G", [(8, 32, 128, 8), (64, 32, 128, 8), (3, 16, 128, 4), (4, 16, 64, 4), (2, 6, 128, 8)])
+def test_final_conv_groupnorm_mish_in_the_load(K, N, H, C, G):
+    """mi_conv1x1_small_cout_gn_fwd (round 6, inference): final_conv = Block(conv -> GroupNorm -> Mish) -> Conv2d(dim, 3, 1) (reference
+    ddpm.py:232-235) with the GroupNorm-apply + Mish inside the 1x1 conv's load, statistics from the epilogue sums of the Block's conv.  Against fp64
+    on the stored bf16 tensor, and against the two launches it replaces (which round the normalised tensor to bf16 in between)."""
+    g = torch.Generator().manual_seed(67)
+    x = (torch.randn(N, H, H, C, generator=g) * 1.3 + 0.2).to(DEV).bfloat16()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    w = (torch.randn(C * 3, generator=g) * 0.1).to(DEV); b = torch.randn(3, generator=g).to(DEV)
+    assert K.small_cout_gn_supported(C, 3, G)
+    xd = x.double().view(N, H * H, C // 16, 16)
+    sums = K.gn_sums_encode(torch.stack([xd.sum((1, 3)), (xd * xd).sum((1, 3))], dim=-1))
+    y = K.conv1x1_small_cout_gn(x, sums, gamma, beta, w, b, 3, groups=G)
+    torch.cuda.synchronize()
+    assert y.shape == (N, H, H, 3) and not y.untyped_storage().nbytes() % 16 and float(y.as_strided((N, H, H, 4), (H * H * 4, H * 4, 4, 1))[..., 3].abs().max()) == 0.0
+    x64 = x.double().cpu().permute(0, 3, 1, 2)
+    hn = _mish64(F.group_norm(x64, G, gamma.double().cpu(), beta.double().cpu(), 1e-5))
+    ref = F.conv2d(hn, w.double().cpu().view(C, 3).t().reshape(3, C, 1, 1), b.double().cpu()).permute(0, 2, 3, 1)
+    assert rel_err(y.cpu(), ref) < 2e-5
+    if (C // G) in (16, 32, 64) and C // G <= 128 // 8 * 8 and G == 8:
+        h16, _ = K.gn_mish_fwd(x, gamma, beta, out_dtype=torch.bfloat16)
+        y2 = K.conv1x1_small_cout(0, h16, w, bias=b, Cs=3)
+        torch.cuda.synchronize()
+        assert rel_err(y2.cpu(), ref) < 4e-3 and rel_err(y.cpu(), y2.cpu().double()) < 4e-3
+
+
 @pytest.mark.parametrize("N,H,C", [(8, 32, 128), (2, 16, 128), (4, 64, 64), (2, 8, 256)])
 @pytest.mark.parametrize("out16", [False, True])
 def test_small_cin_block_conv_and_res_conv_in_one_launch(K, N, H, C, out16):

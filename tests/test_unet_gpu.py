@@ -492,10 +492,14 @@ def test_fused_eval_path_matches_two_pass(golden_dir, monkeypatch):
         y4 = net(xn, t)                           # the default: fused where the private-weight-stream kernel takes block2's conv
         fused_default = [q[0] for q in K.PROBE if q[0].startswith("conv_pw_kernel") and (", 3, 0, 128>" in q[0] or ", 3, 0, 64>" in q[0])]
         ln_fused = [q[0] for q in K.PROBE if q[0].startswith("ln_conv1x1_pw_kernel")]
+        fin_fused = [q[0] for q in K.PROBE if q[0].startswith("small_cout_fwd_gn_kernel")]
         K.PROBE = None
         net.fuse_ln_qkv = False                   # PreNorm's LayerNorm as its own launch (what training runs) instead of inside to_qkv's staging
         y5 = net(xn, t)
         net.fuse_ln_qkv = True
+        net.fuse_final = False                    # final_conv.0's GroupNorm + Mish as their own launch instead of inside final_conv.1's load
+        y6 = net(xn, t)
+        net.fuse_final = True
         net.fuse_gn_conv = 1
         y1 = net(xn, t)
         net.fuse_gn_conv = 2                      # ... with the GroupNorm statistics from conv1's epilogue instead of a pass over c1
@@ -521,6 +525,13 @@ def test_fused_eval_path_matches_two_pass(golden_dir, monkeypatch):
     record("cfg2_layernorm_in_to_qkv_bf16", fused_vs_two_launch_rel_l2=e45, two_launch_vs_reference_rel_l2=e5,
            bounds={"fused_vs_two_launch_rel_l2": 9.0e-3})                  # measured 4.8e-3
     assert e45 < 9.0e-3 and e5 < 2e-2
+    # final_conv: the Block's GroupNorm + Mish inside the 128 -> 3 conv's load (mi_conv1x1_small_cout_gn_fwd); the two-launch form rounds the
+    # normalised tensor to bf16 in between
+    assert len(fin_fused) == 1, fin_fused
+    e46, e6 = rel_err(y4, y6), rel_err(y6[:2], _t(g["eps_hat"]))
+    record("cfg2_final_conv_fused_bf16", fused_vs_two_launch_rel_l2=e46, two_launch_vs_reference_rel_l2=e6,
+           bounds={"fused_vs_two_launch_rel_l2": 3.2e-3})                  # measured 1.6e-3
+    assert e46 < 3.2e-3 and e6 < 2e-2
 
 
 def test_graph_sampler_matches_eager():
