@@ -409,11 +409,25 @@ __global__ __launch_bounds__(256) void small_cout_fwd_gn_kernel(int M, int HW, i
     const int mb = blockIdx.x * ppw, me = min(M, mb + ppw);
     int ncur = -1;
     f32x4 sc[CK], sh[CK];
+    // (the next 32 pixels' rows are requested before this iteration's arithmetic, as in small_cout_fwd_kernel)
+    typedef unsigned int u32x2q __attribute__((ext_vector_type(2)));
+    u32x2q xn[CK];
+    {
+        const int m = min(mb + pl, M - 1);
+#pragma unroll
+        for (int k = 0; k < CK; ++k) xn[k] = *reinterpret_cast<const u32x2q*>(x + (size_t)m * ldx + 4 * (sub + 8 * k));
+    }
     for (int m0 = mb; m0 < me; m0 += 32) {
         const int m = min(m0 + pl, M - 1);
         f32x4 xv[CK];
 #pragma unroll
-        for (int k = 0; k < CK; ++k) xv[k] = ldq<true>(x, (size_t)m * ldx + 4 * (sub + 8 * k));
+        for (int k = 0; k < CK; ++k)
+            xv[k] = f32x4{__uint_as_float(xn[k].x << 16), __uint_as_float(xn[k].x & 0xffff0000u), __uint_as_float(xn[k].y << 16), __uint_as_float(xn[k].y & 0xffff0000u)};
+        {
+            const int mn = min(m0 + 32 + pl, M - 1);
+#pragma unroll
+            for (int k = 0; k < CK; ++k) xn[k] = *reinterpret_cast<const u32x2q*>(x + (size_t)mn * ldx + 4 * (sub + 8 * k));
+        }
         const int n = m / HW;
         if (n != ncur) {
             ncur = n;
@@ -708,9 +722,11 @@ extern "C" int mi_conv1x1_small_cout_gn_fwd(int M, int HW, int C, int Cs, const 
     MI_REQUIRE(x_bf16 && sums && gamma && beta && w && y && M > 0 && HW > 0 && M % HW == 0 && mi_conv1x1_small_cout_gn_supported(C, Cs, G) &&
                ldx % 4 == 0 && ldy == 4 && (((uintptr_t)x_bf16 & 7) | ((uintptr_t)sums & 15) | ((uintptr_t)gamma & 15) | ((uintptr_t)beta & 15) | ((uintptr_t)y & 15)) == 0,
                "needs C in {64, 128}, (C / G) % 16 == 0, Cs <= 4, y as padded 4-channel pixels, aligned operands");
-    // contiguous runs of pixels per workgroup: a divisor of H * W where there is one (one sample per workgroup), about 1 024 workgroups
+    // contiguous runs of pixels per workgroup: a divisor of H * W where there is one (one sample per workgroup), about 512 workgroups
+    // (B = 64, 32x32 x 128: 24.0 us with 2 048 workgroups, 15.5 with 1 024, 12.0 with 512 or 256, 17.9 with 128 -- the per-workgroup set-up, 48 weight
+    //  loads and the coefficients in double, wants to be paid a few hundred times, not a few thousand)
     int ppw = 32;
-    while ((long)M / ppw > 1536 && HW % (2 * ppw) == 0) ppw *= 2;
+    while ((long)M / ppw > 768 && HW % (2 * ppw) == 0) ppw *= 2;
     const int blocks = (M + ppw - 1) / ppw;
     hipStream_t st = (hipStream_t)stream;
     if (C == 128) hipLaunchKernelGGL((small_cout_fwd_gn_kernel<4>), dim3(blocks), dim3(256), 0, st, M, HW, Cs, (const uint16_t*)x_bf16, ldx, (const long long*)sums, gamma, beta, G, eps, w, bias, y, ldy, ppw);
