@@ -489,7 +489,8 @@ def conv3x3_pw_gn_mish_picked(N, H, W, K, Nc):
     # Where it pays (measured in the B = 64 sampler, round 4): every 64-channel chunk of K costs the fused kernel one transform block
     # (~1 us that the matrix pipe of that workgroup waits for), the GroupNorm pass it replaces costs ~4 us + its bytes -- the fusion
     # wins up to K = 256 (level 0: -2.3 us per block, 256 channels @16x16: -4 us) and loses on the 512-channel 8x8 layers (+2 us)
-    return bool(USE_CONV_PW and K <= 256 and _pick_pw_fused(N, H, W, Nc, d, False))
+    # (round 6, the fused variants on the pinned loop: K = 512 is break-even or slightly ahead -- sampler 994-1 003 -> 1 002-1 004 steps/s)
+    return bool(USE_CONV_PW and K <= int(debug_knob("MI_FUSE_GN_MAXK", "512")) and _pick_pw_fused(N, H, W, Nc, d, False))
 
 
 def _pick_pw_fused(N, H, W, Nc, d, in32):

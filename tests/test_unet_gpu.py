@@ -523,8 +523,8 @@ def test_fused_eval_path_matches_two_pass(golden_dir, monkeypatch):
     assert len(ln_fused) == 6, ln_fused
     e45, e5 = rel_err(y4, y5), rel_err(y5[:2], _t(g["eps_hat"]))
     record("cfg2_layernorm_in_to_qkv_bf16", fused_vs_two_launch_rel_l2=e45, two_launch_vs_reference_rel_l2=e5,
-           bounds={"fused_vs_two_launch_rel_l2": 9.0e-3})                  # measured 4.8e-3
-    assert e45 < 9.0e-3 and e5 < 2e-2
+           bounds={"fused_vs_two_launch_rel_l2": 6.5e-3})                  # measured 3.3e-3 .. 4.8e-3
+    assert e45 < 6.5e-3 and e5 < 2e-2
     # final_conv: the Block's GroupNorm + Mish inside the 128 -> 3 conv's load (mi_conv1x1_small_cout_gn_fwd); the two-launch form rounds the
     # normalised tensor to bf16 in between
     assert len(fin_fused) == 1, fin_fused
