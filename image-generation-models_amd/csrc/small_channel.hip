@@ -375,7 +375,9 @@ __global__ __launch_bounds__(256) void small_cout_fwd_kernel(int M, int Cs, cons
         if (sub == 0 && m0 + pl < M) {
             a += b4;
             float* yp = y + (size_t)m * ldy;
-            yp[0] = a.x; if (Cs > 1) yp[1] = a.y; if (Cs > 2) yp[2] = a.z; if (Cs > 3) yp[3] = a.w;
+            // (the padding channels Cs .. ldy - 1 of a padded pixel are written too -- as zeros: the caller needs no fill)
+            yp[0] = a.x; if (Cs > 1 || ldy > 1) yp[1] = Cs > 1 ? a.y : 0.f; if (Cs > 2 || ldy > 2) yp[2] = Cs > 2 ? a.z : 0.f;
+            if (Cs > 3 || ldy > 3) yp[3] = Cs > 3 ? a.w : 0.f;
         }
     }
 }

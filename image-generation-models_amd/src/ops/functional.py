@@ -765,7 +765,7 @@ def conv1x1_small_cout(op, a, w, *, b=None, bias=None, out=None, Cs=None, accumu
     if op == 0:
         C, Cs = a.shape[3], Cs
         if out is None:
-            buf = torch.zeros((N, H, W, (Cs + 3) // 4 * 4), device=a.device, dtype=torch.float32)
+            buf = torch.empty((N, H, W, (Cs + 3) // 4 * 4), device=a.device, dtype=torch.float32)      # (the kernel writes the padding channels: zeros)
             out = buf[..., :Cs]
     elif op == 1:
         Cs = a.shape[3]; C = out.shape[3]
