@@ -98,7 +98,21 @@ __global__ __launch_bounds__(256) void small_cin3x3_fwd_tiled_kernel(int N, int 
                                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                                      void* __restrict__ y, int ldy, int w_sh, int ntiles,
                                                                      const float* __restrict__ w1 = nullptr, const float* __restrict__ bias1 = nullptr,
-                                                                     float* __restrict__ y1 = nullptr, int ldy1 = 0) {
+                                                                     float* __restrict__ y1 = nullptr, int ldy1 = 0,
+                                                                     unsigned long long* __restrict__ zero = nullptr, int nzero = 0,
+                                                                     const float* __restrict__ gsrc = nullptr, const long long* __restrict__ gidx = nullptr,
+                                                                     float* __restrict__ gdst = nullptr, int grow = 0, int gB = 0) {
+    // (DUAL, inference: this is the first launch of a forward -- it also does the forward's two chores whose consumers are LATER launches: it clears
+    //  the pool of GroupNorm sums the conv epilogues add into, and it gathers the step's time-bias rows gdst[b][:] = gsrc[gidx[b]][:] (the sampler's
+    //  precomputed table): two launches less per denoise step)
+    if constexpr (DUAL) {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nzero; i += gridDim.x * 256) zero[i] = 0ull;
+        const int rq = grow >> 2;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < gB * rq; i += gridDim.x * 256) {
+            const int b = i / rq, q = i - b * rq;
+            *reinterpret_cast<f32x4*>(gdst + (size_t)b * grow + 4 * q) = *reinterpret_cast<const f32x4*>(gsrc + (size_t)gidx[b] * grow + 4 * q);
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) float halo_s[];          // 2 x [(rows + 2) * (W + 2)] float4
     const int nq = Cout / 4;
     const int q = threadIdx.x % nq, psub = threadIdx.x / nq, pp = 256 / nq;
@@ -597,8 +611,29 @@ extern "C" int mi_conv_small_cin_fwd_dual_supported(int N, int H, int W, int Cin
     return (tiled && N > 0 && Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && Cout <= 256 && 256 % (Cout / 4) == 0 && ((long)N * H * W) % 64 == 0 &&
             cin_tiled_geom(3, H, W, ldx, nullptr)) ? 1 : 0;
 }
+struct CinChores { void* zero; size_t zero_bytes; const float* gsrc; const long long* gidx; float* gdst; int grow, gB; };
+static int cin_dual_launch(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w3, const float* bias3,
+                           void* y3, int ldy3, int y3_bf16, const float* w1, const float* bias1, float* y1, int ldy1, const CinChores& ch, void* stream);
 extern "C" int mi_conv_small_cin_fwd_dual(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w3, const float* bias3,
                                           void* y3, int ldy3, int y3_bf16, const float* w1, const float* bias1, float* y1, int ldy1, void* stream) {
+    return cin_dual_launch(N, H, W, Cin, Cout, x, ldx, w3, bias3, y3, ldy3, y3_bf16, w1, bias1, y1, ldy1, CinChores{}, stream);
+}
+// ... that also zero-fills `zero` (zero_bytes % 8 == 0, 8-byte aligned): the pool of GroupNorm sums the conv epilogues of the forward's LATER launches
+// add into (this launch is the first of a forward)
+// ... and / or gathers rows gather_dst[b][0 .. row) = gather_src[gather_idx[b]][0 .. row) for b < gather_n (the sampler's time-bias table; row % 4 == 0,
+// 16-byte aligned).  Either chore may be absent (null).
+extern "C" int mi_conv_small_cin_fwd_dual_zero(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w3, const float* bias3,
+                                               void* y3, int ldy3, int y3_bf16, const float* w1, const float* bias1, float* y1, int ldy1,
+                                               void* zero, size_t zero_bytes, const float* gather_src, const void* gather_idx, float* gather_dst,
+                                               int gather_row, int gather_n, void* stream) {
+    MI_REQUIRE(!zero || (zero_bytes % 8 == 0 && ((uintptr_t)zero & 7) == 0 && zero_bytes < (1u << 30)), "zero fill: 8-byte aligned, a multiple of 8 bytes");
+    MI_REQUIRE(!gather_dst || (gather_src && gather_idx && gather_row > 0 && gather_row % 4 == 0 && gather_n > 0 && (long)gather_row * gather_n < (1L << 30) &&
+                               (((uintptr_t)gather_src | (uintptr_t)gather_dst) & 15) == 0), "row gather: rows of a multiple of 4 floats, 16-byte aligned");
+    CinChores ch{zero, zero ? zero_bytes : 0, gather_src, (const long long*)gather_idx, gather_dst, gather_dst ? gather_row : 0, gather_dst ? gather_n : 0};
+    return cin_dual_launch(N, H, W, Cin, Cout, x, ldx, w3, bias3, y3, ldy3, y3_bf16, w1, bias1, y1, ldy1, ch, stream);
+}
+static int cin_dual_launch(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w3, const float* bias3,
+                           void* y3, int ldy3, int y3_bf16, const float* w1, const float* bias1, float* y1, int ldy1, const CinChores& ch, void* stream) {
     MI_REQUIRE(x && w3 && y3 && w1 && y1 && mi_conv_small_cin_fwd_dual_supported(N, H, W, Cin, Cout, ldx) && ((uintptr_t)x & 15) == 0 &&
                ldy3 % 4 == 0 && ldy1 % 4 == 0 && (((uintptr_t)y3 & (y3_bf16 ? 7 : 15)) | ((uintptr_t)y1 & 15) | ((uintptr_t)w3 & 15) | ((uintptr_t)w1 & 15)) == 0,
                "needs the whole-row-tile geometry (power-of-two W <= 64, ldx == 4), Cout / 4 dividing 256, aligned operands");
@@ -608,8 +643,8 @@ extern "C" int mi_conv_small_cin_fwd_dual(int N, int H, int W, int Cin, int Cout
     const size_t lds = (size_t)2 * (rows + 2) * (W + 2) * 16;
     hipStream_t st = (hipStream_t)stream;
 #define MI_TILED2(CIN) do { \
-        if (y3_bf16) hipLaunchKernelGGL((small_cin3x3_fwd_tiled_kernel<CIN, true, true>), dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w3, bias3, y3, ldy3, w_sh, ntiles, w1, bias1, y1, ldy1); \
-        else hipLaunchKernelGGL((small_cin3x3_fwd_tiled_kernel<CIN, false, true>), dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w3, bias3, y3, ldy3, w_sh, ntiles, w1, bias1, y1, ldy1); } while (0)
+        if (y3_bf16) hipLaunchKernelGGL((small_cin3x3_fwd_tiled_kernel<CIN, true, true>), dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w3, bias3, y3, ldy3, w_sh, ntiles, w1, bias1, y1, ldy1, (unsigned long long*)ch.zero, (int)(ch.zero_bytes / 8), ch.gsrc, ch.gidx, ch.gdst, ch.grow, ch.gB); \
+        else hipLaunchKernelGGL((small_cin3x3_fwd_tiled_kernel<CIN, false, true>), dim3(grid), dim3(256), lds, st, N, H, W, Cout, x, ldx, w3, bias3, y3, ldy3, w_sh, ntiles, w1, bias1, y1, ldy1, (unsigned long long*)ch.zero, (int)(ch.zero_bytes / 8), ch.gsrc, ch.gidx, ch.gdst, ch.grow, ch.gB); } while (0)
     switch (Cin) { case 1: MI_TILED2(1); break; case 2: MI_TILED2(2); break; case 3: MI_TILED2(3); break; default: MI_TILED2(4); break; }
 #undef MI_TILED2
     MI_LAUNCH_CHECK();

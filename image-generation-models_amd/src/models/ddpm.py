@@ -275,6 +275,7 @@ class Unet(nn.Module):
         self.fuse_ln_qkv = K.debug_knob("MI_DDPM_FUSE_LN", "1") != "0"
         self.fuse_ln_qkv_train = K.debug_knob("MI_DDPM_FUSE_LN_TRAIN", "1") != "0"
         self.small_cin_dual = K.debug_knob("MI_DDPM_CIN_DUAL", "1") != "0"      # the first block's 3x3 conv + res_conv in one launch
+        self.cin_dual_zero = K.debug_knob("MI_DDPM_CIN_ZERO", "1") != "0"       # ... which also clears the forward's pool of GroupNorm sums
         self.fuse_final = K.debug_knob("MI_DDPM_FUSE_FINAL", "1") != "0"        # inference: final_conv.0's GroupNorm + Mish inside final_conv.1's load
         self.accumulate_grads = False
         self.grad_ready_hook = None        # callable(lo, hi): flat_grads[lo:hi) is final (set by the DDP reducer)
@@ -459,6 +460,7 @@ class Unet(nn.Module):
         tape: Optional[list] = [] if record else None
         B, H, W, _ = x.shape
         flat = self._flat
+        tb_pending: list = []
 
         def lin(inp, wkey, rows=None, w=None, b=None):
             w = sv[wkey + "weight"] if w is None else w
@@ -475,7 +477,15 @@ class Unet(nn.Module):
         if not A.with_time:
             tb_all = None
         elif time_bias_table is not None and not record:
-            tb_all = K.gather_rows(time_bias_table, time)                  # sampler: precomputed per timestep
+            # sampler: precomputed per timestep.  Where the image -> features block takes the dual small-Cin kernel (the forward's first launch), that
+            # launch gathers the rows too (tb_pending); else its own launch
+            b0 = A.downs[0]["res1"]
+            if (self.cin_dual_zero and self.small_cin_dual and b0["res"] and time_bias_table.is_contiguous() and time_bias_table.shape[1] % 4 == 0
+                    and K.small_cin_supported(3, b0["cin"], b0["cout"]) and K.small_cin_dual_supported(B, H, W, b0["cin"], b0["cout"], K.ld_of(x))):
+                tb_all = torch.empty((B, time_bias_table.shape[1]), device=x.device, dtype=torch.float32)
+                tb_pending.append((time_bias_table, time, tb_all))
+            else:
+                tb_all = K.gather_rows(time_bias_table, time)
         else:
             te = K.time_embed(time, A.dim)
             t1 = lin(te, "time_mlp.1.")
@@ -634,8 +644,15 @@ class Unet(nn.Module):
                     and K.small_cin_dual_supported(B, inp.shape[1], inp.shape[2], ci, co, K.ld_of(inp))):
                 # the image -> features block: its 3x3 conv and its res_conv read the same 3-channel image -- one launch (the 1x1's input is the centre tap)
                 od = BF if (c1_16 and K.small_cin_bf16_supported(3, B, inp.shape[1], inp.shape[2], ci, co, K.ld_of(inp))) else torch.float32
+                # inference: this is the forward's first launch -- it clears the pool of GroupNorm sums the later conv epilogues add into
+                if not record and mode == K.MODE_BF16 and zpool[0] is None and str(self.fuse_gn_conv) != "0" and self.cin_dual_zero:
+                    zpool[0] = torch.empty(2 * B * (sum(rb["cout"] // 16 + 1 for rb in A.res_blocks) + A.dim // 16 + 1), device=inp.device, dtype=torch.int64)
+                    zfill = zpool[0]
+                else:
+                    zfill = None
                 c1, r_pre = K.conv_small_cin_fwd_dual(inp, sv[pre + "block1.block.0.weight"], sv[pre + "block1.block.0.bias"],
-                                                      sv[pre + "res_conv.weight"], sv[pre + "res_conv.bias"], co, out_dtype=od)
+                                                      sv[pre + "res_conv.weight"], sv[pre + "res_conv.bias"], co, out_dtype=od, zero=zfill,
+                                                      gather=tb_pending.pop() if tb_pending else None)
             else:
                 c1 = conv(inp_c, pre + "block1.block.0.", 3, 1, 1, x2=x2_c, out_dtype=BF if c1_16 else torch.float32, gn_sums=sums)
             c2 = None
@@ -712,6 +729,7 @@ class Unet(nn.Module):
         h = x
         for lvl in A.downs:
             h = resblock(lvl["res1"], h, want_out16=True)        # feeds res2's first conv
+            assert not tb_pending, "the time-bias rows were left to a launch that did not happen"
             h = resblock(lvl["res2"], h)
             h = attention(lvl["attn"], h, feeds_s2=lvl["down"] is not None)
             skips.append(h)

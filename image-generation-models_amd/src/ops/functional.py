@@ -725,15 +725,27 @@ def small_cin_dual_supported(N, H, W, Cin, Cout, ldx):
     return bool(load_library().mi_conv_small_cin_fwd_dual_supported(N, H, W, Cin, Cout, ldx))
 
 
-def conv_small_cin_fwd_dual(x, w3, bias3, w1, bias1, Cout, out_dtype=torch.float32):
-    """The first ResnetBlock's block1 conv (3x3) and its res_conv (1x1) on the same image in one launch -> (y3 in out_dtype, y1 fp32)."""
+def conv_small_cin_fwd_dual(x, w3, bias3, w1, bias1, Cout, out_dtype=torch.float32, zero=None, gather=None):
+    """The first ResnetBlock's block1 conv (3x3) and its res_conv (1x1) on the same image in one launch -> (y3 in out_dtype, y1 fp32).
+    This is a forward's first launch; it can do the forward's chores whose consumers come later -- zero: an int64 tensor it clears (the pool of
+    GroupNorm sums); gather = (table [T, R], idx int64 [B], out [B, R]): out[b] = table[idx[b]] (the sampler's time-bias rows)."""
     _need_gpu(x)
     N, H, W, Cin = x.shape
     y3 = (torch.empty((N, H, W, Cout), device=x.device, dtype=torch.bfloat16) if out_dtype == torch.bfloat16 else new_act(N, H, W, Cout, x))
     y1 = new_act(N, H, W, Cout, x)
     e0 = _probe_open()
-    check(load_library().mi_conv_small_cin_fwd_dual(N, H, W, Cin, Cout, _p(x), ld_of(x), _p(w3), _p(bias3), _p(y3), ld_of(y3), _b16(y3),
-                                                    _p(w1), _p(bias1), _p(y1), ld_of(y1), _stream()), "mi_conv_small_cin_fwd_dual")
+    if zero is not None or gather is not None:
+        assert zero is None or (zero.dtype == torch.int64 and zero.is_contiguous())
+        gt, gi, go = gather if gather is not None else (None, None, None)
+        assert gather is None or (gt.is_contiguous() and go.is_contiguous() and gi.dtype == torch.int64 and go.shape == (gi.shape[0], gt.shape[1]))
+        check(load_library().mi_conv_small_cin_fwd_dual_zero(N, H, W, Cin, Cout, _p(x), ld_of(x), _p(w3), _p(bias3), _p(y3), ld_of(y3), _b16(y3),
+                                                             _p(w1), _p(bias1), _p(y1), ld_of(y1), _p(zero), zero.numel() * 8 if zero is not None else 0,
+                                                             _p(gt), _p(gi), _p(go), gt.shape[1] if gather is not None else 0,
+                                                             gi.shape[0] if gather is not None else 0, _stream()),
+              "mi_conv_small_cin_fwd_dual_zero")
+    else:
+        check(load_library().mi_conv_small_cin_fwd_dual(N, H, W, Cin, Cout, _p(x), ld_of(x), _p(w3), _p(bias3), _p(y3), ld_of(y3), _b16(y3),
+                                                        _p(w1), _p(bias1), _p(y1), ld_of(y1), _stream()), "mi_conv_small_cin_fwd_dual")
     if e0 is not None:
         _probe_close(e0, f"small_cin3x3_fwd_tiled_kernel<{Cin}, {'true' if _b16(y3) else 'false'}, true>", 2.0 * N * H * W * Cout * Cin * 10,
                      f"N{N} {H}x{W} K{Cin}->{Cout} 3x3 + res_conv", N * H * W * (16 + Cout * (_esz(y3) + 4)))

@@ -1893,6 +1893,13 @@ def test_small_cin_block_conv_and_res_conv_in_one_launch(K, N, H, C, out16):
     assert y3.dtype == dt and y1.dtype == torch.float32
     assert torch.equal(y3, r3)
     assert torch.equal(y1, r1) or rel_err(y1, r1) < 2e-7
+    # the chores of a forward's first launch: clear the pool of GroupNorm sums, gather the step's time-bias rows
+    pool = torch.full((1001,), 7, device=DEV, dtype=torch.int64)
+    table = torch.randn(50, 132, generator=g).to(DEV); idx = torch.randint(0, 50, (N,), generator=g).to(DEV)
+    rows = torch.full((N, 132), float("nan"), device=DEV)
+    y3b, y1b = K.conv_small_cin_fwd_dual(x, w3, b3, w1, b1, C, out_dtype=dt, zero=pool, gather=(table, idx, rows))
+    torch.cuda.synchronize()
+    assert torch.equal(y3b, y3) and torch.equal(y1b, y1) and not pool.any() and torch.equal(rows, table[idx])
     xd = from_nhwc(x).double()
     ref1 = F.conv2d(xd, w1.double().cpu().view(3, C).t().reshape(C, 3, 1, 1), b1.double().cpu())
     assert rel_err(from_nhwc(y1), ref1) < 2e-6
