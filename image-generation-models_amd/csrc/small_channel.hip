@@ -622,7 +622,7 @@ extern "C" int mi_conv_small_cin_fwd_dual(int N, int H, int W, int Cin, int Cout
 // add into (this launch is the first of a forward)
 // ... and / or gathers rows gather_dst[b][0 .. row) = gather_src[gather_idx[b]][0 .. row) for b < gather_n (the sampler's time-bias table; row % 4 == 0,
 // 16-byte aligned).  Either chore may be absent (null).
-extern "C" int mi_conv_small_cin_fwd_dual_zero(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w3, const float* bias3,
+extern "C" int mi_conv_small_cin_fwd_dual_chores(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w3, const float* bias3,
                                                void* y3, int ldy3, int y3_bf16, const float* w1, const float* bias1, float* y1, int ldy1,
                                                void* zero, size_t zero_bytes, const float* gather_src, const void* gather_idx, float* gather_dst,
                                                int gather_row, int gather_n, void* stream) {

@@ -275,7 +275,7 @@ class Unet(nn.Module):
         self.fuse_ln_qkv = K.debug_knob("MI_DDPM_FUSE_LN", "1") != "0"
         self.fuse_ln_qkv_train = K.debug_knob("MI_DDPM_FUSE_LN_TRAIN", "1") != "0"
         self.small_cin_dual = K.debug_knob("MI_DDPM_CIN_DUAL", "1") != "0"      # the first block's 3x3 conv + res_conv in one launch
-        self.cin_dual_zero = K.debug_knob("MI_DDPM_CIN_ZERO", "1") != "0"       # ... which also clears the forward's pool of GroupNorm sums
+        self.cin_dual_chores = K.debug_knob("MI_DDPM_CIN_CHORES", "1") != "0"       # ... which also does the forward's chores (sums pool, time-bias rows)
         self.fuse_final = K.debug_knob("MI_DDPM_FUSE_FINAL", "1") != "0"        # inference: final_conv.0's GroupNorm + Mish inside final_conv.1's load
         self.accumulate_grads = False
         self.grad_ready_hook = None        # callable(lo, hi): flat_grads[lo:hi) is final (set by the DDP reducer)
@@ -480,7 +480,7 @@ class Unet(nn.Module):
             # sampler: precomputed per timestep.  Where the image -> features block takes the dual small-Cin kernel (the forward's first launch), that
             # launch gathers the rows too (tb_pending); else its own launch
             b0 = A.downs[0]["res1"]
-            if (self.cin_dual_zero and self.small_cin_dual and b0["res"] and time_bias_table.is_contiguous() and time_bias_table.shape[1] % 4 == 0
+            if (self.cin_dual_chores and self.small_cin_dual and b0["res"] and time_bias_table.is_contiguous() and time_bias_table.shape[1] % 4 == 0
                     and K.small_cin_supported(3, b0["cin"], b0["cout"]) and K.small_cin_dual_supported(B, H, W, b0["cin"], b0["cout"], K.ld_of(x))):
                 tb_all = torch.empty((B, time_bias_table.shape[1]), device=x.device, dtype=torch.float32)
                 tb_pending.append((time_bias_table, time, tb_all))
@@ -645,7 +645,7 @@ class Unet(nn.Module):
                 # the image -> features block: its 3x3 conv and its res_conv read the same 3-channel image -- one launch (the 1x1's input is the centre tap)
                 od = BF if (c1_16 and K.small_cin_bf16_supported(3, B, inp.shape[1], inp.shape[2], ci, co, K.ld_of(inp))) else torch.float32
                 # inference: this is the forward's first launch -- it clears the pool of GroupNorm sums the later conv epilogues add into
-                if not record and mode == K.MODE_BF16 and zpool[0] is None and str(self.fuse_gn_conv) != "0" and self.cin_dual_zero:
+                if not record and mode == K.MODE_BF16 and zpool[0] is None and str(self.fuse_gn_conv) != "0" and self.cin_dual_chores:
                     zpool[0] = torch.empty(2 * B * (sum(rb["cout"] // 16 + 1 for rb in A.res_blocks) + A.dim // 16 + 1), device=inp.device, dtype=torch.int64)
                     zfill = zpool[0]
                 else:

@@ -738,11 +738,11 @@ def conv_small_cin_fwd_dual(x, w3, bias3, w1, bias1, Cout, out_dtype=torch.float
         assert zero is None or (zero.dtype == torch.int64 and zero.is_contiguous())
         gt, gi, go = gather if gather is not None else (None, None, None)
         assert gather is None or (gt.is_contiguous() and go.is_contiguous() and gi.dtype == torch.int64 and go.shape == (gi.shape[0], gt.shape[1]))
-        check(load_library().mi_conv_small_cin_fwd_dual_zero(N, H, W, Cin, Cout, _p(x), ld_of(x), _p(w3), _p(bias3), _p(y3), ld_of(y3), _b16(y3),
+        check(load_library().mi_conv_small_cin_fwd_dual_chores(N, H, W, Cin, Cout, _p(x), ld_of(x), _p(w3), _p(bias3), _p(y3), ld_of(y3), _b16(y3),
                                                              _p(w1), _p(bias1), _p(y1), ld_of(y1), _p(zero), zero.numel() * 8 if zero is not None else 0,
                                                              _p(gt), _p(gi), _p(go), gt.shape[1] if gather is not None else 0,
                                                              gi.shape[0] if gather is not None else 0, _stream()),
-              "mi_conv_small_cin_fwd_dual_zero")
+              "mi_conv_small_cin_fwd_dual_chores")
     else:
         check(load_library().mi_conv_small_cin_fwd_dual(N, H, W, Cin, Cout, _p(x), ld_of(x), _p(w3), _p(bias3), _p(y3), ld_of(y3), _b16(y3),
                                                         _p(w1), _p(bias1), _p(y1), ld_of(y1), _stream()), "mi_conv_small_cin_fwd_dual")

@@ -277,7 +277,7 @@ int mi_conv_small_cin_fwd_dual(int N, int H, int W, int Cin, int Cout, const flo
                                void* y3, int ldy3, int y3_bf16, const float* w1, const float* bias1, float* y1, int ldy1, void* stream);
 /* ... that also does a forward's two chores whose consumers are later launches (this is a forward's first launch): zero-fills the pool of GroupNorm
    sums, gathers the denoise step's time-bias rows gather_dst[b][:] = gather_src[gather_idx[b]][:] (int64 indices); either may be null */
-int mi_conv_small_cin_fwd_dual_zero(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w3, const float* bias3,
+int mi_conv_small_cin_fwd_dual_chores(int N, int H, int W, int Cin, int Cout, const float* x, int ldx, const float* w3, const float* bias3,
                                     void* y3, int ldy3, int y3_bf16, const float* w1, const float* bias1, float* y1, int ldy1,
                                     void* zero, size_t zero_bytes, const float* gather_src, const void* gather_idx, float* gather_dst,
                                     int gather_row, int gather_n, void* stream);
