@@ -506,16 +506,27 @@ __global__ __launch_bounds__(256) void small_cout_dgrad_kernel(int M, int C, int
     }
 }
 // wgrad: dW[c][j] += sum_px x[px][c] dy[px][j]; thread = (channel quad, pixel lane), partial tile [C][4]
-template <bool X16 = false>
+// DG (round 6): the data gradient of the same layer rides along -- same thread mapping, same dy: dx[px][4q + e] (+)= sum_j dy[px][j] w[4q + e][j],
+// small_cout_dgrad_kernel's arithmetic; one pass over (x, dy) instead of two launches
+template <bool X16 = false, bool DG = false, bool DX16 = false>
 __global__ __launch_bounds__(256) void small_cout_wgrad_kernel(int M, int C, int Cs, const void* __restrict__ x, int ldx,
                                                                const float* __restrict__ dy, int lddy, float* __restrict__ dW,
-                                                               float* __restrict__ ws) {
+                                                               float* __restrict__ ws, const float* __restrict__ w = nullptr,
+                                                               void* __restrict__ dx = nullptr, int lddx = 0, int dacc = 0) {
     extern __shared__ float red[];
     const int nq = C / 4;
     const int q = threadIdx.x % nq, psub = threadIdx.x / nq, pp = 256 / nq;
     f32x4 acc[4];                                                    // acc[e][j] for channel 4q+e
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 wr[DG ? 4 : 1];                                            // wr[e][j] = w[4q+e][j]
+    if constexpr (DG) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* wp = w + (size_t)(4 * q + e) * Cs;
+            wr[e] = f32x4{wp[0], Cs > 1 ? wp[1] : 0.f, Cs > 2 ? wp[2] : 0.f, Cs > 3 ? wp[3] : 0.f};
+        }
+    }
     const int per = (M + gridDim.x - 1) / gridDim.x;
     const int mb = blockIdx.x * per, me = min(M, mb + per);
     int m = mb + psub;
@@ -526,6 +537,14 @@ __global__ __launch_bounds__(256) void small_cout_wgrad_kernel(int M, int C, int
         const f32x4 g = {gp[0], Cs > 1 ? gp[1] : 0.f, Cs > 2 ? gp[2] : 0.f, Cs > 3 ? gp[3] : 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] += xv[e] * g;
+        if constexpr (DG) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const f32x4 pr = g * wr[e]; o[e] = (pr.x + pr.y) + (pr.z + pr.w); }
+            const size_t po = (size_t)m * lddx + 4 * q;
+            if (dacc) o += ldq<DX16>(dx, po);
+            stq<DX16>(dx, po, o);
+        }
         xv = xnext;
     }
     block_reduce_quads<4>(acc, nq, red);
@@ -768,6 +787,24 @@ extern "C" int mi_conv1x1_small_cout_gn_fwd(int M, int HW, int C, int Cs, const 
     hipStream_t st = (hipStream_t)stream;
     if (C == 128) hipLaunchKernelGGL((small_cout_fwd_gn_kernel<4>), dim3(blocks), dim3(256), 0, st, M, HW, Cs, (const uint16_t*)x_bf16, ldx, (const long long*)sums, gamma, beta, G, eps, w, bias, y, ldy, ppw);
     else hipLaunchKernelGGL((small_cout_fwd_gn_kernel<2>), dim3(blocks), dim3(256), 0, st, M, HW, Cs, (const uint16_t*)x_bf16, ldx, (const long long*)sums, gamma, beta, G, eps, w, bias, y, ldy, ppw);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward of y = x w + bias in one pass over (x, dy): dW[c][j] += sum_px x[px][c] dy[px][j] AND dx[px][c] (+)= sum_j dy[px][j] w[c][j] (the two launches
+// mi_conv1x1_small_cout_io op 2 / op 1 make; bitwise their results).  x_bf16 / dx_bf16: the wide tensors' storage.  workspace as for op 2.
+extern "C" int mi_conv1x1_small_cout_bwd(int M, int C, int Cs, const void* x, int ldx, int x_bf16, const float* dy, int lddy, const float* w,
+                                         float* dW, void* dx, int lddx, int dx_bf16, int accumulate_dx, void* workspace, size_t ws_bytes, void* stream) {
+    MI_REQUIRE(x && dy && w && dW && dx && Cs >= 1 && Cs <= 4 && (C == 64 || C == 128 || C == 256) && M > 0 && ldx % 4 == 0 && lddx % 4 == 0 &&
+               ((uintptr_t)x & (x_bf16 ? 7 : 15)) == 0 && ((uintptr_t)dx & (dx_bf16 ? 7 : 15)) == 0, "needs Cs <= 4, C in {64, 128, 256}, aligned rows");
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (workspace && ws_bytes >= mi_conv_small_wgrad_workspace(C * 4)) ? (float*)workspace : nullptr;
+    const size_t lds = (size_t)3 * 4 * (C / 4) * 4 * sizeof(float);
+#define MI_BWD(X16, D16) hipLaunchKernelGGL((small_cout_wgrad_kernel<X16, true, D16>), dim3(WG_BLOCKS), dim3(256), lds, st, M, C, Cs, x, ldx, dy, lddy, dW, ws, w, dx, lddx, accumulate_dx)
+    if (x_bf16) { if (dx_bf16) MI_BWD(true, true); else MI_BWD(true, false); }
+    else { if (dx_bf16) MI_BWD(false, true); else MI_BWD(false, false); }
+#undef MI_BWD
+    if (ws) hipLaunchKernelGGL(partial_sum_kernel, dim3((C * 4 + 31) / 32), dim3(256), 0, st, ws, WG_BLOCKS, C * 4, dW, Cs);
     MI_LAUNCH_CHECK();
     return 0;
 }

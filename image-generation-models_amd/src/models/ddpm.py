@@ -276,6 +276,7 @@ class Unet(nn.Module):
         self.fuse_ln_qkv_train = K.debug_knob("MI_DDPM_FUSE_LN_TRAIN", "1") != "0"
         self.small_cin_dual = K.debug_knob("MI_DDPM_CIN_DUAL", "1") != "0"      # the first block's 3x3 conv + res_conv in one launch
         self.cin_dual_chores = K.debug_knob("MI_DDPM_CIN_CHORES", "1") != "0"       # ... which also does the forward's chores (sums pool, time-bias rows)
+        self.small_cout_bwd1 = K.debug_knob("MI_DDPM_COUT_BWD1", "1") != "0"    # the C -> 3 conv's weight and data gradient in one launch
         self.fuse_final = K.debug_knob("MI_DDPM_FUSE_FINAL", "1") != "0"        # inference: final_conv.0's GroupNorm + Mish inside final_conv.1's load
         self.accumulate_grads = False
         self.grad_ready_hook = None        # callable(lo, hi): flat_grads[lo:hi) is final (set by the DDP reducer)
@@ -833,7 +834,12 @@ class Unet(nn.Module):
             dy16 = None
             if (x2 is None and stride == 1 and not transposed_conv and k == 1 and K.small_cout_supported(2, ci, co)
                     and K.small_cout_supported(1, ci, co)):
-                K.conv1x1_small_cout(2, inp, None, b=dy, out=gv[pre + "weight"])
+                if want_dx and self.small_cout_bwd1 and ci in (64, 128, 256):
+                    buf, acc = G.target(inp)                      # weight gradient and data gradient from one pass over (inp, dy)
+                    K.conv1x1_small_cout_bwd(inp, dy, w, gv[pre + "weight"], buf, accumulate=acc)
+                    want_dx = False
+                else:
+                    K.conv1x1_small_cout(2, inp, None, b=dy, out=gv[pre + "weight"])
                 if bias == "colsum":
                     K.colsum(dy, gv[pre + "bias"], defer=wq)
                 if want_dx:

@@ -699,6 +699,19 @@ def conv_small_cin_fwd(x, w, bias, Cout, ks, out_dtype=torch.float32):
     return y
 
 
+def conv1x1_small_cout_bwd(x, dy, w, dW, dx, accumulate=False):
+    """Backward of the C -> Cs (<= 4) 1x1 conv in one pass over (x, dy): dW[C][Cs] += x^T dy and dx (+)= dy w^T (what conv1x1_small_cout op 2 and
+    op 1 compute in two launches; bitwise the same)."""
+    _need_gpu(x)
+    N, H, W, Cc = x.shape
+    Cs = dy.shape[3]
+    lib = load_library()
+    need = lib.mi_conv_small_wgrad_workspace(4 * Cc)
+    ws = _workspace(x.device, need)
+    check(lib.mi_conv1x1_small_cout_bwd(N * H * W, Cc, Cs, _p(x), ld_of(x), _b16(x), _p(dy), ld_of(dy), _p(w), _p(dW), _p(dx), ld_of(dx), _b16(dx),
+                                        int(accumulate), _p(ws), need, _stream()), "mi_conv1x1_small_cout_bwd")
+
+
 @functools.lru_cache(maxsize=None)
 def small_cout_gn_supported(C, Cs, G):
     return bool(load_library().mi_conv1x1_small_cout_gn_supported(C, Cs, G))

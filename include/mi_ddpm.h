@@ -266,6 +266,9 @@ size_t mi_conv_small_wgrad_workspace(int outputs);
  * is rounded once / dy is widened on load).  y_bf16 / dy_bf16 = 1 needs the whole-row-tile kernels: ks = 3, W a power of two <= 64,
  * H*W a power of two, ldx == 4, 16-byte aligned x, Cout in {64, 128} (256: forward only) -- mi_conv_small_cin_bf16_supported answers for both. */
 int mi_conv_small_cin_bf16_supported(int ks, int N, int H, int W, int Cin, int Cout, int ldx);
+/* round 6: backward of the C -> 3 conv (final_conv.1, reference ddpm.py:235) in one pass over (x, dy): weight gradient and data gradient */
+int mi_conv1x1_small_cout_bwd(int M, int C, int Cs, const void* x, int ldx, int x_bf16, const float* dy, int lddy, const float* w,
+                              float* dW, void* dx, int lddx, int dx_bf16, int accumulate_dx, void* workspace, size_t ws_bytes, void* stream);
 /* round 6, inference: final_conv (reference ddpm.py:232-235) -- the Block's GroupNorm-apply + Mish inside the Conv2d(dim, channels, 1)'s load: x = the
    Block conv's bf16 output, sums = what its epilogue left (mi_conv3x3_pw_gnsums); C = 64 / 128, (C / G) % 16 == 0 */
 int mi_conv1x1_small_cout_gn_supported(int C, int Cs, int G);

@@ -1842,6 +1842,13 @@ def test_small_channel_ends_bf16_wide_tensor(K, N, H, C):
     assert torch.equal(dh16, dh32.to(BF))
     K.conv1x1_small_cout(1, de, wf, out=dh16, accumulate=True)    # += into the bf16 tensor: widened, added in fp32, rounded again
     assert torch.equal(dh16, (dh32.to(BF).float() + dh32).to(BF))
+    # round 6: weight gradient and data gradient from ONE pass over (x, dy) (mi_conv1x1_small_cout_bwd): bitwise the two launches' results
+    for xin, dt in ((h16, BF), (h16.float(), torch.float32)):
+        dWc = torch.zeros(C * 3, device=DEV); dhc = torch.full((N, H, H, C), float("nan"), device=DEV, dtype=dt)
+        K.conv1x1_small_cout_bwd(xin, de, wf, dWc, dhc)
+        assert torch.equal(dWc, dWa) and torch.equal(dhc, dh32.to(dt))
+        K.conv1x1_small_cout_bwd(xin, de, wf, dWc, dhc, accumulate=True)
+        assert torch.equal(dhc, (dh32.to(dt).float() + dh32).to(dt)) and torch.equal(dWc, dWa + dWa)
 
 
 @pytest.mark.parametrize("N,H,C,G", [(8, 32, 128, 8), (64, 32, 128, 8), (3, 16, 128, 4), (4, 16, 64, 4), (2, 6, 128, 8)])
