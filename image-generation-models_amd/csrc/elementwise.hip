@@ -88,18 +88,36 @@ __global__ __launch_bounds__(256) void eps_loss_kernel(int B, int C, int HW, con
                                                         const float* __restrict__ target, int loss_type,
                                                         float* __restrict__ loss, float* __restrict__ dpred, float gscale) {
     __shared__ float red[8];
-    size_t tot = (size_t)B * HW * ld;
+    // (32-bit index arithmetic: the three 64-bit divisions per element made this 6 MB pass a 15 us launch; the host checks B * HW * ld < 2^31)
+    const unsigned tot = (unsigned)B * HW * ld;
     const float inv = 1.0f / ((float)B * (float)C * (float)HW);
     float acc = 0.f;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
-        int c = i % ld; size_t bp = i / ld; int p = bp % HW; int b = bp / HW;
-        float g = 0.f;
-        if (c < C) {
-            float d = pred[i] - target[((size_t)b * C + c) * HW + p];
-            if (loss_type == 0) { acc += fabsf(d); g = (d > 0.f) ? 1.f : (d < 0.f ? -1.f : 0.f); }
-            else { acc += d * d; g = 2.f * d; }
+    // four elements per thread and iteration, their loads requested together: the launch was a chain of dependent round trips
+    // (128 workgroups -- more would queue on the one atomic -- x 16 iterations of load -> compute -> store)
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < tot; i0 += 4 * stride) {
+        float pv[4], tv[4];
+        bool live[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = i0 + u * stride;
+            const unsigned ic = min(i, tot - 1);
+            const unsigned bp = ic / (unsigned)ld, c = ic - bp * ld, b = bp / (unsigned)HW, p = bp - b * HW;
+            live[u] = i < tot && (int)c < C;
+            pv[u] = pred[ic];
+            tv[u] = target[((size_t)b * C + min(c, (unsigned)C - 1)) * HW + p];
         }
-        if (dpred) dpred[i] = g * inv * gscale;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = i0 + u * stride;
+            float g = 0.f;
+            if (live[u]) {
+                const float d = pv[u] - tv[u];
+                if (loss_type == 0) { acc += fabsf(d); g = (d > 0.f) ? 1.f : (d < 0.f ? -1.f : 0.f); }
+                else { acc += d * d; g = 2.f * d; }
+            }
+            if (dpred && i < tot) dpred[i] = g * inv * gscale;
+        }
     }
     float s = block_sum_256(acc, red);
     if (threadIdx.x == 0) atomicAdd(loss, s * inv);
@@ -480,7 +498,8 @@ extern "C" int mi_q_sample(int B, int C, int HW, const float* x0, const float* n
 }
 extern "C" int mi_eps_loss(int B, int C, int HW, const float* pred, int ld, const float* target, int loss_type,
                            float* loss, float* dpred, float gscale, void* stream) {
-    MI_REQUIRE(B > 0 && C > 0 && HW > 0 && ld >= C && pred && target && loss && (loss_type == 0 || loss_type == 1), "bad argument");
+    MI_REQUIRE(B > 0 && C > 0 && HW > 0 && ld >= C && pred && target && loss && (loss_type == 0 || loss_type == 1) && (size_t)B * HW * ld < (1ull << 31),
+               "bad argument");
     // (one device-scope atomic per workgroup on ONE address: they serialise at ~16 ns each -- 1024 workgroups spent 16 of the
     //  kernel's 17 us queueing there; 128 workgroups stream the same bytes in ~3)
     hipLaunchKernelGGL(eps_loss_kernel, dim3(nblocks((size_t)B * HW * ld, 4 * TPB, 128)), dim3(TPB), 0, ST, B, C, HW, pred, ld,
