@@ -805,7 +805,9 @@ class Unet(nn.Module):
                           group_s2=2 if self.grad_ready_hook is not None else None)
         x_in = tape[-1][1]
         B = x_in.shape[0]
-        dtb_all = torch.zeros((B, A.mlp_rows), device=x_in.device, dtype=torch.float32)
+        # (every column is WRITTEN by its block's GroupNorm backward -- one workgroup per (sample, channel) stores its sum -- before the time MLP's
+        #  backward reads it: no fill)
+        dtb_all = torch.empty((B, A.mlp_rows), device=x_in.device, dtype=torch.float32)
 
         def s2_push(dy, inp, pre, k, ci, co, transposed_conv, ihw, ohw, bias):
             """Downsample / Upsample weight gradient through the LDS-DMA kernel: both operands as bf16 (the input's copy is the one
