@@ -809,7 +809,7 @@ def test_traj20_golden(golden_dir, mode, launch):
     # bf16 measured on the MI355X over five runs (eager / graph): loss 4.5e-4 .. 5.6e-4, displacement 0.160 (mid_attn to_qkv) -- the two rule-bound
     # metrics (<= 2x measured); the two norm metrics are differences of large sums and move 1.7x from run to run (fp32 atomics' order):
     # recorded, asserted against fixed limits
-    b = {"fp32": dict(loss=1e-4, wn=1e-6, delta=2e-2, moved=1e-3), "bf16": dict(loss=9.0e-4, wn=2e-5, delta=0.319, moved=2e-3)}[mode]
+    b = {"fp32": dict(loss=1e-4, wn=1e-6, delta=2e-2, moved=1e-3), "bf16": dict(loss=8.0e-4, wn=2e-5, delta=0.319, moved=2e-3)}[mode]
     record(f"traj20_{mode}_{launch}", worst_loss_abs=e_loss, worst_weight_norm_rel=e_wn, worst_delta_rel_l2=max(e_delta.values()),
            worst_delta_key=max(e_delta, key=e_delta.get), moved_norm_rel=e_moved,
            bounds={"worst_loss_abs": b["loss"], "worst_delta_rel_l2": b["delta"]})
