@@ -1499,6 +1499,7 @@ constexpr size_t pw1_lds(int pxt) { return (size_t)pxt * 512; }
 struct Pw1Args {
     const uint16_t* x; const uint16_t* x2; const uint16_t* w; const float* bias; const float* res; void* y; uint16_t* y16;
     int M, K, K1, Nc, ldx, ldx2, ldy, ldr, ldy16, accumulate, gx, gy;
+    int wbatch, hw;      // per-sample weights (mi_conv1x1_pw_batched): the fragments of the tile's sample start wbatch elements x (m0 / hw) behind w
 };
 
 // F32: exact-fp32 mode (see conv_pw_kernel): fp32 x / y, fp32 fragment-order weights, v_mfma_f32_32x32x2_f32; a chunk is 64 channels.
@@ -1580,7 +1581,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_kernel(const Pw1Args a) {
     // weight fragments (nb, kq = 8 ch .. 8 ch + 7): 8 KB contiguous
     uint64_t wsrc;
     {
-        const uint64_t q = (uint64_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(a.w) + (size_t)nb * KQ * 1024);
+        const size_t wb = a.wbatch ? (size_t)(m0 / a.hw) * a.wbatch * ESZ : 0;
+        const uint64_t q = (uint64_t)(uintptr_t)(reinterpret_cast<const uint8_t*>(a.w) + wb + (size_t)nb * KQ * 1024);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)q), hi = __builtin_amdgcn_readfirstlane((uint32_t)(q >> 32));
         wsrc = ((uint64_t)hi << 32) | lo;
     }
@@ -2637,8 +2639,22 @@ extern "C" int mi_debug_conv1x1_pw_nloop(int on) {
     if (on >= 0) { g_pw1_nloop = on > 2 ? 1 : on; g_pw1_nloop_min = on == 2 ? 0 : 1024; }
     return was;
 }
+static int pw1_go(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, int wbatch, const float* bias, const float* residual,
+                  void* y, int out_bf16, void* y_bf16, int ldy16, void* stream);
 extern "C" int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, const float* bias, const float* residual,
                              void* y, int out_bf16, void* y_bf16, int ldy16, void* stream) {
+    return pw1_go(d, x, x2, w_frag_bf16, 0, bias, residual, y, out_bf16, y_bf16, ldy16, stream);
+}
+// ... with PER-SAMPLE weights: sample n of the batch (OH * OW pixels) multiplies with the fragments at w_frag_bf16 + n * wbatch elements (wbatch % 8 == 0;
+// a pixel tile must lie inside one sample: OH * OW % 64 == 0).  The LinearAttention fold: x = qkv (ldx = 3 * hidden, K = hidden: the q channels),
+// weights from mi_linattn_fold_fwd.
+extern "C" int mi_conv1x1_pw_batched(const MiConvDesc* d, const void* x, const void* w_frag_bf16, int wbatch, const float* bias, const float* residual,
+                                     void* y, int out_bf16, void* y_bf16, int ldy16, void* stream) {
+    MI_REQUIRE(d && wbatch > 0 && wbatch % 8 == 0 && (d->OH * d->OW) % 64 == 0 && d->K1 == d->K, "per-sample weights: wbatch % 8 == 0, OH * OW % 64 == 0, one source");
+    return pw1_go(d, x, nullptr, w_frag_bf16, wbatch, bias, residual, y, out_bf16, y_bf16, ldy16, stream);
+}
+static int pw1_go(const MiConvDesc* d, const void* x, const void* x2, const void* w_frag_bf16, int wbatch, const float* bias, const float* residual,
+                  void* y, int out_bf16, void* y_bf16, int ldy16, void* stream) {
     MI_REQUIRE(d && x && w_frag_bf16 && y, "null argument");
     MI_REQUIRE(pw1_ok(d), "descriptor not supported (1x1, K and K1 % 128 == 0, Nc % 64 == 0, N*H*W % 128 == 0)");
     MI_REQUIRE(d->K1 == d->K || x2, "two-source split without x2");
@@ -2651,8 +2667,9 @@ extern "C" int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* x2,
     a.M = d->N * d->OH * d->OW; a.K = d->K; a.K1 = d->K1; a.Nc = d->Nc; a.ldx = d->ldx; a.ldx2 = x2 ? d->ldx2 : d->ldx;
     a.ldy = d->ldy; a.ldr = d->ldr; a.ldy16 = ldy16; a.accumulate = d->accumulate;
     a.gy = (d->Nc + 127) / 128;
-    // 64-pixel tiles when 128-pixel ones would leave CUs without a workgroup
-    const bool small = (long)(a.M / 128) * a.gy < 256;
+    a.wbatch = wbatch; a.hw = d->OH * d->OW;
+    // 64-pixel tiles when 128-pixel ones would leave CUs without a workgroup (or would straddle two samples' weights)
+    const bool small = (long)(a.M / 128) * a.gy < 256 || (wbatch && a.hw % 128 != 0);
     a.gx = a.M / (small ? 64 : 128);
     dim3 grid((unsigned)a.gx, (unsigned)a.gy);
     if (a.gy > 1 && a.gx % 8 == 0) grid = dim3((unsigned)(a.gx * a.gy), 1, 1);
@@ -2666,7 +2683,7 @@ extern "C" int mi_conv1x1_pw(const MiConvDesc* d, const void* x, const void* x2,
     // to_qkv at the 128-channel level: one workgroup per pixel tile walks the channel tiles (conv1x1_pw_kernel's NLOOP)
     // (from 1 024 pixel tiles up: [128,32,32,128] -> 384 goes 34.3 -> 29.3 us = 3.9 -> 4.6 TB/s of algorithmic traffic; at the sampler's B = 64 the
     //  512 workgroups of the loop form are one round of two per CU and time the same as the 1 536 of the 2-D grid or slightly worse)
-    if (out_bf16 && !residual && !d->accumulate && !small && d->K == 128 && d->K1 == d->K && a.gy > 1 && g_pw1_nloop && a.gx >= g_pw1_nloop_min) {
+    if (out_bf16 && !residual && !d->accumulate && !small && !wbatch && d->K == 128 && d->K1 == d->K && a.gy > 1 && g_pw1_nloop && a.gx >= g_pw1_nloop_min) {
         static MiPerDevice once_;
         once_.run([] { (void)hipFuncSetAttribute((const void*)conv1x1_pw_kernel<true, false, 128, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); });
         hipLaunchKernelGGL((conv1x1_pw_kernel<true, false, 128, false, false, true>), dim3((unsigned)a.gx), dim3(256), pw1_lds(128), st, a);

@@ -23,6 +23,8 @@ struct AttnArgs {
     int B, n, heads, ldq;        // ldq = 3*heads*32
     int S, per;                  // pixel slices per (batch, head) and pixels per slice (S == 1: the whole image in one workgroup)
     float* part;                 // S > 1: per-slice partial results (see the PH template parameter of the kernels)
+    // FOLD (inference, S == 1): instead of out, the workgroup writes ITS 32 input columns of to_out's effective weights (see linattn_fwd_kernel)
+    const uint16_t* wout; uint16_t* weff; int C;      // wout: to_out's bf16 weight rows [co][heads * 32]
 };
 
 // workgroup -> (batch, head, slice).  The heads (and slices) of one batch element share cache lines (32 channels = 64..128 bytes of a
@@ -276,8 +278,14 @@ __device__ __forceinline__ f32x16 tile_mm_b16_lds(const float* At, const bf16x8 
 // 2: max over the slices, then exp / outer product over the slice -> part_ctx, part_sum;  3: slices summed in a fixed order
 // (deterministic), normalised, written to ctx / kstat by slice 0, then out for the slice's pixels.  One image per workgroup keeps
 // 4096 pixels behind 8 KB of loads in flight; sliced, every CU holds several workgroups and the loads of all of them.
-template <bool T16, int PH>     // T16: qkv and out are stored as bf16
+// FOLD (round 6, inference, PH == 0): out = ctx^T q is linear in q and to_out is a 1x1 conv over out's channels, so
+//   to_out(out)[co][p] = sum_{h,d} ( sum_e W_out[co][h*32 + e] ctx_h[d][e] ) q[h*32 + d][p]
+// -- a 1x1 conv of q with PER-SAMPLE weights W_eff[b] = W_out blockdiag(ctx_h^T).  The workgroup (b, h) writes its 32 input columns of W_eff[b]
+// (C x 32 bf16, in conv1x1_pw_kernel's fragment order [co / 32][k / 16][lane][8]) instead of running the third phase: q is not read here, out is
+// never written; mi_conv1x1_pw_batched then reads q straight out of qkv.
+template <bool T16, int PH, bool FOLD = false>     // T16: qkv and out are stored as bf16
 __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
+    static_assert(!FOLD || (T16 && PH == 0), "the fold: bf16 storage, one workgroup per (batch, head)");
     MI_PRIO_UP();
     __shared__ float scratch[4 * 32 * 33], scratch2[PH == 1 ? 1 : 4 * 32 * 33];
     __shared__ float ctx_s[32 * 33];
@@ -350,18 +358,45 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const AttnArgs a) {
         }
         __syncthreads();
     }
-    float* ctx_g = a.ctx + (size_t)bh * 32 * 32;
+    float* ctx_g = FOLD ? nullptr : a.ctx + (size_t)bh * 32 * 32;
     for (int idx = t; idx < 32 * 32; idx += 256) {
         int d = idx >> 5, e = idx & 31;
         float c = ctx_s[d * 33 + e] / ksum_s[d];
         ctx_s[d * 33 + e] = c;
-        if (sl == 0) ctx_g[idx] = c;
+        if constexpr (!FOLD) { if (sl == 0) ctx_g[idx] = c; }
     }
-    if (t < 32 && sl == 0) {
-        float* ks = a.kstat + (size_t)bh * 64;
-        ks[2 * t] = kmax_s[t]; ks[2 * t + 1] = ksum_s[t];
+    if constexpr (!FOLD) {
+        if (t < 32 && sl == 0) {
+            float* ks = a.kstat + (size_t)bh * 64;
+            ks[2 * t] = kmax_s[t]; ks[2 * t + 1] = ksum_s[t];
+        }
     }
     __syncthreads();
+    if constexpr (FOLD) {
+        // W_eff[co][h*32 + d] = sum_e W_out[co][h*32 + e] ctx[d][e]: 32-channel tiles of to_out's bf16 weight rows [co][hidden] times ctx^T on the bf16
+        // MFMA (two per tile), through the wave's LDS tile into conv1x1_pw_kernel's fragment order: 16 bytes = 8 consecutive k of one co
+        bf16x8 fT[2];
+        frag_from_lds(ctx_s, 1, 33, fT);                      // B(k = e, j = d) = ctx[d][e]
+        const int KQ = hid / 16;
+        const float* wrow = reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(a.wout) + h * DH);
+        uint16_t* wb = a.weff + (size_t)b * a.C * hid;
+        float* tile = scratch + w * (32 * 33);
+        for (int co0 = 32 * w; co0 < a.C; co0 += 128) {
+            const f32x16 acc = tile_mm_b16(wrow, hid, co0, a.C, fT);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[tile_row(r, l) * 33 + (l & 31)] = acc[r];
+            // (wave-private LDS region: the wave's own ds_write -> ds_read ordering is enough)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int dg = (l >> 5) + 2 * i, cl = l & 31;
+                const float* q8 = tile + cl * 33 + dg * 8;
+                typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<u32x4w*>(wb + ((size_t)((co0 >> 5) * KQ + 2 * h + (dg >> 1)) * 64 + cl + 32 * (dg & 1)) * 8) =
+                    u32x4w{pack_bf16(q8[0], q8[1]), pack_bf16(q8[2], q8[3]), pack_bf16(q8[4], q8[5]), pack_bf16(q8[6], q8[7])};
+            }
+        }
+        return;
+    }
     // out[p][e] = sum_d q[p][d] ctx[d][e]
     float* o = offs<T16>(a.out, (size_t)b * a.n * hid + h * DH);
     bf16x8 fctx[2];
@@ -562,6 +597,20 @@ static int linattn_bwd_go(int B, int n, int heads, const void* qkv, const float*
     return 0;
 }
 
+// Inference (see linattn_fwd_kernel's FOLD): qkv bf16 [B][n][3 * heads * 32], w_out_bf16 = to_out's weights as bf16 rows [C][heads * 32] (the
+// reference's Conv2d(hidden, dim, 1), ddpm.py:152; mi_pack_weights_bf16's plain forward copy wf) -> weff bf16 [B][C * heads * 32]: per-sample
+// weights of the 1x1 conv mi_conv1x1_pw_batched runs on q, in fragment order.  C % 32 == 0.
+extern "C" int mi_linattn_fold_fwd(int B, int n, int heads, const void* qkv_bf16, const void* w_out_bf16, int C, void* weff_bf16, void* stream) {
+    MI_REQUIRE(B > 0 && n > 0 && heads > 0 && (heads * DH) % 16 == 0 && qkv_bf16 && w_out_bf16 && weff_bf16 && C > 0 && C % 32 == 0 &&
+               (((uintptr_t)weff_bf16 | (uintptr_t)w_out_bf16) & 15) == 0, "bad argument (C % 32 == 0, 16-byte aligned weights)");
+    AttnArgs a{};
+    a.qkv = (const float*)qkv_bf16; a.B = B; a.n = n; a.heads = heads; a.ldq = 3 * heads * DH;
+    a.wout = (const uint16_t*)w_out_bf16; a.weff = (uint16_t*)weff_bf16; a.C = C;
+    attn_plan(a, 1, nullptr);
+    hipLaunchKernelGGL((linattn_fwd_kernel<true, 0, true>), dim3(B * heads), dim3(256), 0, (hipStream_t)stream, a);
+    MI_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int mi_linattn_fwd(int B, int n, int heads, const float* qkv, float* out, float* ctx, float* kstat,
                               void* stream) {
     return linattn_fwd_go(B, n, heads, qkv, out, ctx, kstat, 0, nullptr, 0, stream);

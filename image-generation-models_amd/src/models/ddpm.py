@@ -276,6 +276,9 @@ class Unet(nn.Module):
         self.fuse_ln_qkv_train = K.debug_knob("MI_DDPM_FUSE_LN_TRAIN", "1") != "0"
         self.small_cin_dual = K.debug_knob("MI_DDPM_CIN_DUAL", "1") != "0"      # the first block's 3x3 conv + res_conv in one launch
         self.cin_dual_chores = K.debug_knob("MI_DDPM_CIN_CHORES", "1") != "0"       # ... which also does the forward's chores (sums pool, time-bias rows)
+        # inference: LinearAttention folded into to_out's (per-sample) weights -- built, tested, measured 1 % SLOWER in the replayed sampler step
+        # (1 057-1 071 against 1 075-1 080 steps/s: per-sample weights are not shared between workgroups): off
+        self.fold_attn = K.debug_knob("MI_DDPM_FOLD_ATTN", "0") == "1"
         self.small_cout_bwd1 = K.debug_knob("MI_DDPM_COUT_BWD1", "1") != "0"    # the C -> 3 conv's weight and data gradient in one launch
         self.fuse_final = K.debug_knob("MI_DDPM_FUSE_FINAL", "1") != "0"        # inference: final_conv.0's GroupNorm + Mish inside final_conv.1's load
         self.accumulate_grads = False
@@ -715,6 +718,16 @@ class Unet(nn.Module):
             else:
                 ln = K.chan_layernorm_fwd(inp, sv[pre + "fn.norm.g"], sv[pre + "fn.norm.b"], out_dtype=dt)
                 qkv = conv(ln, pre + "fn.fn.to_qkv.", 1, bias=False, out_dtype=dt)
+            if not record and a16 and self.fold_attn and mode == K.MODE_BF16:
+                # inference: the attention output is never formed -- to_out runs on q with per-sample weights W_out blockdiag(ctx^T)
+                w16 = bool(feeds_s2 and self.dual_out and inp.shape[3] % 32 == 0)
+                r_ = K.linattn_to_out_folded(qkv, wf_sh[offs[pre + "fn.fn.to_out.weight"]:], c, sv[pre + "fn.fn.to_out.bias"], inp,
+                                             heads=_HEADS, want16=w16)
+                if r_ is not None:
+                    if w16:
+                        sh[id(r_[0])] = r_
+                        return r_[0]
+                    return r_
             ao, ctx, kstat = K.linattn_fwd(qkv, _HEADS)
             # training: the block's output is a residual-stream tensor whose bf16 copy is wanted by the skip connection's consumer,
             # Downsample / Upsample and the next Block's conv: written by to_out's epilogue instead of a conversion pass

@@ -1372,6 +1372,39 @@ def linattn_fwd(qkv, heads=4):
     return out, ctx, kstat
 
 
+def linattn_to_out_folded(qkv, w_out16, Cc, bias, residual, heads=4, want16=False):
+    """Inference: LinearAttention + its to_out conv + the Residual add (reference ddpm.py:146-165, Residual) as TWO launches that never form the
+    attention output: (1) mi_linattn_fold_fwd -- softmax statistics and context per (sample, head) as in linattn_fwd, then the per-sample
+    effective weights W_eff[b] = W_out blockdiag(ctx_h^T) in fragment order; (2) mi_conv1x1_pw_batched -- y = W_eff[b] q + bias + residual,
+    q read straight out of qkv.  qkv bf16 [N, H, W, 3 * heads * 32], w_out16: to_out's bf16 weight rows [C][heads * 32] (pack_weights_bf16's wf slice).
+    -> y fp32 (want16: (y, its bf16 copy)); None when the shape is not taken."""
+    _need_gpu(qkv)
+    N, H, W, C3 = qkv.shape
+    hid = heads * 32
+    if (qkv.dtype != torch.bfloat16 or C3 != 3 * hid or not qkv.is_contiguous() or hid % 128 or Cc % 64 or (H * W) % 64 or (N * H * W) % 128
+            or _linattn_ws(N, H * W, heads)):
+        return None
+    lib = load_library()
+    weff = torch.empty((N, Cc * hid), device=qkv.device, dtype=torch.bfloat16)
+    e0 = _probe_open()
+    check(lib.mi_linattn_fold_fwd(N, H * W, heads, _p(qkv), _p(w_out16), Cc, _p(weff), _stream()), "mi_linattn_fold_fwd")
+    if e0 is not None:
+        _probe_close(e0, "linattn_fwd_kernel<io1, fold>", 2.0 * N * heads * 32 * 32 * (H * W + Cc), f"N{N} n{H * W} C{Cc}",
+                     N * H * W * 2 * hid * 2 + N * Cc * hid * 2)
+    y = new_act(N, H, W, Cc, qkv, torch.float32)
+    y16 = new_act(N, H, W, Cc, qkv, torch.bfloat16) if want16 else None
+    d = MiConvDesc(N=N, IH=H, IW=W, OH=H, OW=W, K=hid, Nc=Cc, KH=1, KW=1, stride=1, pad=0, transposed=0, w_kn=0, mode=MODE_BF16, K1=hid,
+                   ldx=C3, ldx2=0, ldy=ld_of(y), ldr=ld_of(residual) if residual is not None else 0, accumulate=0)
+    e0 = _probe_open()
+    check(lib.mi_conv1x1_pw_batched(C.byref(d), _p(qkv), _p(weff), Cc * hid, _p(bias), _p(residual), _p(y), 0, _p(y16),
+                                    ld_of(y16) if y16 is not None else 0, _stream()), "mi_conv1x1_pw_batched")
+    if e0 is not None:
+        px = 64 if ((N * H * W // 128) * ((Cc + 127) // 128) < 256 or (H * W) % 128) else 128
+        _probe_close(e0, f"conv1x1_pw_kernel<false, {'true' if want16 else 'false'}, {px}>", 2.0 * N * H * W * Cc * hid,
+                     f"N{N} {H}x{W} K{hid}->{Cc} per-sample weights", N * H * W * (hid * 2 + Cc * (4 + _esz(residual) + (2 if want16 else 0))) + N * Cc * hid * 2)
+    return (y, y16) if want16 else y
+
+
 def linattn_bwd(qkv, ctx, kstat, dout, heads=4):
     N, H, W, C3 = qkv.shape
     assert dout.is_contiguous() and dout.dtype == qkv.dtype

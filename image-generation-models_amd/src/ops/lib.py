@@ -130,6 +130,8 @@ SIGNATURES = {
     "mi_conv1x1_small_cout": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "mi_conv1x1_small_cout_ws": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P, _Z, _P],
     "mi_conv1x1_small_cout_io": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _Z, _P],
+    "mi_linattn_fold_fwd": [_I, _I, _I, _P, _P, _I, _P, _P],
+    "mi_conv1x1_pw_batched": [C.POINTER(MiConvDesc), _P, _P, _I, _P, _P, _P, _I, _P, _I, _P],
     "mi_conv1x1_small_cout_bwd": [_I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, C.c_size_t, _P],
     "mi_conv1x1_small_cout_gn_supported": [_I, _I, _I],
     "mi_conv1x1_small_cout_gn_fwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _I, C.c_float, _P, _P, _P, _I, _P],

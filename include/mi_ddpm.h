@@ -266,6 +266,13 @@ size_t mi_conv_small_wgrad_workspace(int outputs);
  * is rounded once / dy is widened on load).  y_bf16 / dy_bf16 = 1 needs the whole-row-tile kernels: ks = 3, W a power of two <= 64,
  * H*W a power of two, ldx == 4, 16-byte aligned x, Cout in {64, 128} (256: forward only) -- mi_conv_small_cin_bf16_supported answers for both. */
 int mi_conv_small_cin_bf16_supported(int ks, int N, int H, int W, int Cin, int Cout, int ldx);
+/* round 6, inference -- LinearAttention (reference ddpm.py:146-165) folded into its to_out conv: out = ctx^T q is linear in q, so to_out(out) is a 1x1
+   conv of q with per-sample weights W_eff[b] = W_out blockdiag(ctx_h^T).  mi_linattn_fold_fwd: qkv bf16 [B][n][3 * heads * 32], w_out_bf16 = to_out's
+   bf16 weight rows [C][heads * 32] (mi_pack_weights_bf16's wf) -> weff bf16 [B][C * heads * 32] in fragment order; mi_conv1x1_pw_batched: mi_conv1x1_pw with the weights of sample b at
+   w_frag_bf16 + b * wbatch elements (x = qkv, d->ldx = 3 * hidden, d->K = hidden: the q channels) */
+int mi_linattn_fold_fwd(int B, int n, int heads, const void* qkv_bf16, const void* w_out_bf16, int C, void* weff_bf16, void* stream);
+int mi_conv1x1_pw_batched(const MiConvDesc* d, const void* x, const void* w_frag_bf16, int wbatch, const float* bias, const float* residual,
+                          void* y, int out_bf16, void* y_bf16, int ldy16, void* stream);
 /* round 6: backward of the C -> 3 conv (final_conv.1, reference ddpm.py:235) in one pass over (x, dy): weight gradient and data gradient */
 int mi_conv1x1_small_cout_bwd(int M, int C, int Cs, const void* x, int ldx, int x_bf16, const float* dy, int lddy, const float* w,
                               float* dW, void* dx, int lddx, int dx_bf16, int accumulate_dx, void* workspace, size_t ws_bytes, void* stream);

@@ -2092,6 +2092,41 @@ def test_bf16_attention_storage_kernels(K):
     assert d16.dtype == BF and rel_err(d16.float(), d32) < 4e-3
 
 
+@pytest.mark.parametrize("N,H,C,want16", [(64, 32, 128, True), (8, 32, 128, False), (64, 16, 256, True), (64, 8, 512, False), (2, 8, 64, False), (3, 16, 320, True)])
+def test_linear_attention_folded_into_to_out(K, N, H, C, want16):
+    """mi_linattn_fold_fwd + mi_conv1x1_pw_batched (round 6, inference): LinearAttention (reference ddpm.py:146-165) + to_out + the Residual add
+    without the attention output -- out = ctx^T q is linear in q, so to_out(out) = (W_out blockdiag(ctx_h^T)) q: a 1x1 conv of q with per-sample
+    weights.  Against fp64 on the stored bf16 qkv, and against the launches it replaces (linattn_fwd -> bf16 attention output -> to_out)."""
+    BF = torch.bfloat16
+    heads, HID = 4, 128
+    g = torch.Generator().manual_seed(83 + C)
+    qkv = (torch.randn(N, H, H, 3 * HID, generator=g) * 0.8).to(DEV).to(BF)
+    w = (torch.randn(C, HID, generator=g) / math.sqrt(HID))
+    bias = torch.randn(C, generator=g).to(DEV); res = torch.randn(N, H, H, C, generator=g).to(DEV)
+    flat, wd, wf, offs, wdq, wfq = _pack(K, [conv_w_storage(w.double().view(C, HID, 1, 1))], frag=True)      # wf: bf16 rows [co][ci]
+    r = K.linattn_to_out_folded(qkv, wf, C, bias, res, heads=heads, want16=want16)
+    if K._linattn_ws(N, H * H, heads) or C % 64:                      # few (sample, head) pairs: the pixel axis is sliced -- the fold takes whole images only
+        assert r is None
+        return
+    assert r is not None, "shape not taken"
+    y = r[0] if want16 else r
+    torch.cuda.synchronize()
+    q64 = qkv.double().cpu().view(N, H * H, 3, heads, 32)
+    qd, kd, vd = q64[:, :, 0], q64[:, :, 1], q64[:, :, 2]              # [N][n][h][d]
+    P = torch.softmax(kd, dim=1)
+    ctx = torch.einsum("bnhd,bnhe->bhde", P, vd)
+    out = torch.einsum("bhde,bnhd->bnhe", ctx, qd).reshape(N, H, H, HID)
+    ref = torch.einsum("bhwk,ck->bhwc", out, w.bfloat16().double()) + bias.double().cpu() + res.double().cpu()
+    assert rel_err(y.cpu(), ref) < 4e-3
+    if want16:
+        assert torch.equal(r[1], y.to(BF))
+    # the launches it replaces
+    ao, _, _ = K.linattn_fwd(qkv, heads)
+    y2 = K.conv3x3_bf16w(ao, wf, K=HID, Nc=C, flip=False, ksize=1, bias=bias, residual=res, wq=wfq)
+    torch.cuda.synchronize()
+    assert rel_err(y2.cpu(), ref) < 4e-3 and rel_err(y.cpu(), y2.cpu().double()) < 4e-3
+
+
 @pytest.mark.parametrize("M,N,Kc", [(128, 512, 128), (128, 128, 512), (128, 3584, 128), (96, 200, 64)])
 def test_small_gemm_linear(K, M, N, Kc):
     """nn.Linear of the time MLP through mi_small_gemm: forward, input gradient, weight gradient (exact fp32)."""
